@@ -1,0 +1,173 @@
+/*
+ * blues_engine.h -- C-ABI of the MI355X-native NCMC alchemical-Langevin engine.
+ *
+ * This is the drop-in boundary for the one hot path of MobleyLab/blues: the
+ * switching trajectory that blues.simulation.BLUESSimulation._stepNCMC
+ * (reference blues/simulation.py:1039-1098) drives through
+ * blues.integrators.AlchemicalExternalLangevinIntegrator
+ * (reference blues/integrators.py:98-249).  BLUES itself has no FFI: the
+ * surface it consumes is the OpenMM Python object triple
+ * Simulation / Context / CustomIntegrator.  Every entry point below names the
+ * OpenMM-side call it replaces and the reference line that issues that call.
+ *
+ * Conventions
+ *   - plain C, caller-allocated buffers, no torch / HIP types in signatures;
+ *   - units are OpenMM's: nm, ps, amu, kJ/mol, elementary charge, kelvin;
+ *   - xyz arrays are [n_atoms][3] row-major doubles in the caller's atom order;
+ *   - every function returns 0 on success, nonzero on error; the message is
+ *     available from blues_last_error(h) (or blues_last_error(NULL) for
+ *     failures of blues_engine_create);
+ *   - a handle is owned by one host thread at a time (OpenMM contexts have the
+ *     same rule); handles on different devices are independent.
+ *
+ * The same two descriptor structs are consumed by the CPU oracle
+ * (oracle/blues_oracle.h), so a parity test builds one description and hands
+ * it to both sides.
+ */
+#ifndef BLUES_ENGINE_H
+#define BLUES_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLUES_ABI_VERSION 1
+
+/* nonbonded_method */
+#define BLUES_NB_NOCUTOFF 0   /* oracle only: vacuum systems (vacDivaline, two-body checks) */
+#define BLUES_NB_PME_DIRECT 1 /* periodic cutoff, erfc(alpha r)/r direct-space Coulomb + 12-6 LJ */
+
+/*
+ * Flat description of the alchemical System that
+ * SystemFactory.generateAlchSystem builds (reference blues/simulation.py:221-317:
+ * openmmtools AbsoluteAlchemicalFactory(alchemical_pme_treatment='direct-space',
+ * disable_alchemical_dispersion_correction=True) over AlchemicalRegion(
+ * softcore_alpha=0.5, a=b=1, c=6, beta=0, d=e=1, f=2, annihilate_electrostatics=True,
+ * annihilate_sterics=False)), after freeze_radius / freeze_atoms
+ * (simulation.py:364-480) zeroed the masses of frozen atoms and after
+ * restrain_positions (simulation.py:319-362) added its CustomExternalForce.
+ */
+typedef struct BluesSystemDesc {
+    int32_t n_atoms;
+    double box[9];                 /* rows a,b,c (nm); only orthorhombic boxes: off-diagonals must be 0 */
+    const double *mass;            /* [n] amu; 0 => frozen (utils.zero_masses, reference blues/utils.py:202-221) */
+    const double *charge;          /* [n] e   */
+    const double *sigma;           /* [n] nm  */
+    const double *epsilon;         /* [n] kJ/mol */
+    int32_t n_exclusions;          /* pairs with no regular nonbonded term (1-2, 1-3 and every exception pair) */
+    const int32_t *exclusions;     /* [2*n_exclusions] */
+    int32_t n_exceptions;          /* 1-4 style exceptions with their own parameters */
+    const int32_t *exception_atoms;   /* [2*n_exceptions] */
+    const double *exception_params;   /* [3*n_exceptions] chargeProd (e^2), sigma (nm), epsilon (kJ/mol) */
+    int32_t n_bonds;
+    const int32_t *bond_atoms;     /* [2*n] */
+    const double *bond_params;     /* [2*n] r0 (nm), k (kJ/mol/nm^2); E = 0.5 k (r-r0)^2 */
+    int32_t n_angles;
+    const int32_t *angle_atoms;    /* [3*n] */
+    const double *angle_params;    /* [2*n] theta0 (rad), k (kJ/mol/rad^2); E = 0.5 k (t-t0)^2 */
+    int32_t n_torsions;
+    const int32_t *torsion_atoms;  /* [4*n] */
+    const double *torsion_params;  /* [3*n] periodicity, phase (rad), k (kJ/mol); E = k (1+cos(n phi - phase)) */
+    int32_t n_constraints;
+    const int32_t *constraint_atoms; /* [2*n] */
+    const double *constraint_dist;   /* [n] nm */
+    int32_t n_alchemical;
+    const int32_t *alchemical_atoms; /* [n_alchemical] */
+    int32_t n_restraints;          /* k_restr*periodicdistance(x,y,z,x0,y0,z0)^2, simulation.py:347 */
+    const int32_t *restraint_atoms;
+    const double *restraint_x0;    /* [3*n_restraints] nm */
+    double restraint_k;            /* kJ/mol/nm^2 */
+    int32_t nonbonded_method;      /* BLUES_NB_* */
+    double cutoff;                 /* nm */
+    double ewald_alpha;            /* nm^-1: sqrt(-ln(2 tol))/cutoff */
+    double softcore_alpha;         /* 0.5 */
+    int32_t annihilate_electrostatics; /* 1 */
+    int32_t annihilate_sterics;        /* 0 */
+    int32_t remove_cm_motion;      /* CMMotionRemover from removeCMMotion: True (examples/rotmove_cuda.yml:24) */
+} BluesSystemDesc;
+
+/*
+ * Parameters of AlchemicalExternalLangevinIntegrator.__init__
+ * (reference blues/integrators.py:98-145) as generateNCMCIntegrator passes
+ * them (reference blues/simulation.py:650-705).  The Lepton strings in
+ * alchemical_functions are evaluated by the host language into two tables
+ * indexed by lambda_step: entry i is f(i / n_lambda_steps),
+ * n_lambda_steps = nsteps_neq * (number of 'H' in splitting).
+ */
+typedef struct BluesIntegratorDesc {
+    double timestep;               /* ps */
+    double temperature;            /* K  */
+    double collision_rate;         /* 1/ps; BLUES always ends up with 1.0 (simulation.py:664,697-704) */
+    int32_t nsteps_neq;
+    int32_t nprop;
+    double prop_lambda_min;        /* _get_prop_lambda, integrators.py:147-157 */
+    double prop_lambda_max;
+    const char *splitting;         /* e.g. "H V R O R V H"; letters R V O H */
+    int32_t n_lambda_steps;
+    const double *lambda_sterics;        /* [n_lambda_steps+1] */
+    const double *lambda_electrostatics; /* [n_lambda_steps+1] */
+    double constraint_tolerance;   /* 1e-8, integrators.py:104 */
+    uint64_t seed;                 /* Philox key; stream = replica */
+    int32_t replica;
+    int32_t precision;             /* 0 = mixed (f32 pair math, f64 accumulation), 1 = double */
+} BluesIntegratorDesc;
+
+typedef struct BluesEngine BluesEngine;
+
+/* openmm.app.Simulation(topology, system, integrator, platform, properties)
+ * (reference blues/simulation.py:730-737).  device = HIP device ordinal. */
+int blues_engine_create(const BluesSystemDesc *sys, const BluesIntegratorDesc *integ, int device, BluesEngine **out);
+int blues_engine_destroy(BluesEngine *h);
+const char *blues_last_error(const BluesEngine *h);
+int blues_abi_version(void);
+
+/* context.setPositions / setVelocities / setPeriodicBoxVectors
+ * (reference blues/simulation.py:957-962, blues/moves.py:307). */
+int blues_set_positions(BluesEngine *h, const double *xyz_nm, int32_t n_atoms);
+int blues_set_velocities(BluesEngine *h, const double *xyz_nm_per_ps, int32_t n_atoms);
+int blues_set_box(BluesEngine *h, const double box[9]);
+/* context.getState(getPositions/getVelocities/getForces...) (simulation.py:904-910) */
+int blues_get_positions(BluesEngine *h, double *xyz_nm, int32_t n_atoms);
+int blues_get_velocities(BluesEngine *h, double *xyz_nm_per_ps, int32_t n_atoms);
+int blues_get_forces(BluesEngine *h, double *xyz_kj_per_mol_nm, int32_t n_atoms);
+int blues_get_box(BluesEngine *h, double box[9]);
+/* context.setVelocitiesToTemperature(T) (simulation.py:743, 1187) */
+int blues_set_velocities_to_temperature(BluesEngine *h, double temperature, uint64_t seed);
+/* state.getPotentialEnergy() / getKineticEnergy() (simulation.py:908-909) */
+int blues_get_energy(BluesEngine *h, double *potential, double *kinetic);
+/* per-term potential energies at the current state, for parity tests:
+ * [0] bonds [1] angles [2] torsions [3] nonbonded env-env [4] exceptions
+ * [5] alchemical sterics [6] alchemical electrostatics [7] restraint */
+#define BLUES_N_ENERGY_TERMS 8
+int blues_get_energy_terms(BluesEngine *h, double terms[BLUES_N_ENERGY_TERMS]);
+
+/* integrator.step(n)  (reference blues/simulation.py:1082) */
+int blues_step(BluesEngine *h, int32_t n_steps);
+/* the same n calls of step(1) executed device-resident without returning to
+ * the host between steps; optional per-step protocol-work trace (kJ/mol). */
+int blues_run_switch(BluesEngine *h, int32_t n_steps, double *work_trace /* [n_steps] or NULL */);
+
+/* integrator.getGlobalVariableByName / setGlobalVariableByName
+ * (reference blues/simulation.py:935, blues/moves.py:1082, blues/reporters.py:415-418).
+ * names: lambda step lambda_step n_lambda_steps nsteps protocol_work shadow_work
+ *        perturbed_pe unperturbed_pe first_step nprop prop prop_lambda_min
+ *        prop_lambda_max Eold Enew heat kT lambda_sterics lambda_electrostatics */
+int blues_get_global(BluesEngine *h, const char *name, double *value);
+int blues_set_global(BluesEngine *h, const char *name, double value);
+/* AlchemicalExternalLangevinIntegrator.reset (reference blues/integrators.py:240-249) */
+int blues_reset(BluesEngine *h);
+
+/* engine counters for bench.py / profiling: [0] force passes [1] neighbour
+ * rebuilds [2] kernel launches [3] n i-tiles [4] n clusters [5] j-list capacity */
+#define BLUES_N_STATS 8
+int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
+/* time `reps` launches of the dominant nonbonded kernel alone with HIP events
+ * on the engine's own stream; returns mean microseconds per launch. */
+int blues_time_nonbonded(BluesEngine *h, int32_t reps, double *usec_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLUES_ENGINE_H */

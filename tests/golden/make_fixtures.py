@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Generates the committed data fixtures.  Run in the BUILD container only
+(it reads the reference checkout at /root/reference; the GPU box never does):
+
+    python tests/golden/make_fixtures.py
+
+Outputs
+  blues_amd/data/tol_box.npz
+      975-atom toluene/TIP3P box as a flat SystemData, derived from the data files the
+      reference's own tests hold (blues/tests/data/TOL-parm.prmtop / .inpcrd): parameters
+      converted to OpenMM units, TIP3P assigned to the water atoms (their ATOM_TYPE_INDEX
+      is 0 in that file, TOL-parm.prmtop:556-560), HBonds + rigid water constraints,
+      hydrogen mass 3.024 Da; coordinates relaxed by steepest descent and thermalised
+      with the CPU oracle's Langevin integrator (seeded), velocities included.
+  tests/golden/reference_known_answers.json
+      values the reference's own files state for this path.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/blues/tests/data"
+
+from blues_amd import amber, systems  # noqa: E402
+from blues_amd._abi import IntegratorData  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def make_tol_box():
+    prm = amber.read_prmtop(os.path.join(REF, "TOL-parm.prmtop"))
+    pos, _, box = amber.read_inpcrd(os.path.join(REF, "TOL-parm.inpcrd"))
+    s = amber.system_from_amber(prm, pos, box, cutoff=1.0, ewald_error_tolerance=0.005, constraints="HBonds",
+                                rigid_water=True, hydrogen_mass=3.024, remove_cm_motion=True,
+                                alchemical_atoms=range(15))
+    print("atoms", s.n_atoms, "box", s.box, "constraints", len(s.constraint_dist), "bonds", len(s.bond_atoms),
+          "angles", len(s.angle_atoms), "torsions", len(s.torsion_atoms), "excl", len(s.exclusions), "exc14", len(s.exception_atoms))
+    print("net charge", s.charge.sum())
+
+    def langevin(nsteps, dt, gamma, seed):
+        return IntegratorData(timestep=dt, temperature=300.0, nsteps_neq=10 ** 9, lambda_sterics=[1.0],
+                              lambda_electrostatics=[1.0], splitting="V R O R V", collision_rate=gamma, seed=seed)
+
+    o = oracle.Oracle(s, langevin(0, 0.001, 10.0, 11))
+    e0 = o.energy_forces()[0]
+    e1 = o.minimize(max_iter=600, step0=0.005)
+    print("energy before/after minimisation", e0, e1)
+    x = o.get_positions()
+    # thermalise: 2 ps at 1 fs with strong friction, then 4 ps at 2 fs, then 4 ps at 4 fs (gamma 1/ps)
+    v = np.zeros_like(x)
+    for (nsteps, dt, gamma, seed) in ((2000, 0.001, 10.0, 11), (2000, 0.002, 5.0, 12), (1000, 0.004, 1.0, 13)):
+        o = oracle.Oracle(s, langevin(nsteps, dt, gamma, seed))
+        o.set_positions(x)
+        if not v.any():
+            o.set_velocities_to_temperature(300.0, 2017)
+        else:
+            o.set_velocities(v)
+        for blk in range(nsteps // 500):
+            o.step(500)
+            ke = o.kinetic_energy()
+            ndof = 3 * s.n_atoms - len(s.constraint_dist)
+            print("  dt", dt, "step", (blk + 1) * 500, "PE", o.potential_energy(), "T", 2 * ke / (ndof * 0.0083144626))
+        x, v = o.get_positions(), o.get_velocities()
+    s.positions = x
+    out = os.path.join(ROOT, "blues_amd", "data", "tol_box.npz")
+    systems.save_system(out, s, velocities=v)
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+
+def make_known_answers():
+    """Values stated by the reference's own sources (file:line) for the host logic of this path."""
+    ka = {
+        "_source": "MobleyLab/blues; see SURVEY.md Appendix C and section 4 for the file:line of each entry",
+        # blues/utils.py:89-145, hand-executed on the reference formulas
+        "calculateNCMCSteps": [
+            {"nstepsNC": 10, "nprop": 1, "propLambda": 0.3, "expect": [10, 10, 5]},
+            {"nstepsNC": 20, "nprop": 1, "propLambda": 0.3, "expect": [20, 20, 10]},
+            {"nstepsNC": 100, "nprop": 1, "propLambda": 0.3, "expect": [100, 100, 50]},
+            {"nstepsNC": 1000, "nprop": 1, "propLambda": 0.3, "expect": [1000, 1000, 500]},
+            {"nstepsNC": 2000, "nprop": 1, "propLambda": 0.3, "expect": [2000, 2000, 1000]},
+            {"nstepsNC": 5000, "nprop": 1, "propLambda": 0.3, "expect": [5000, 5000, 2500]},
+            {"nstepsNC": 10000, "nprop": 1, "propLambda": 0.3, "expect": [10000, 10000, 5000]},
+            {"nstepsNC": 1000, "nprop": 2, "propLambda": 0.3, "expect": [1000, 1000, 500]},
+            {"nstepsNC": 3000, "nprop": 3, "propLambda": 0.3, "expect": [3000, 3000, 1500]},
+            {"nstepsNC": 100, "nprop": 2, "propLambda": 0.1, "expect": [100, 100, 50]},
+            {"nstepsNC": 101, "nprop": 1, "propLambda": 0.3, "expect": [100, 100, 50]},
+        ],
+        # blues/integrators.py:147-157; blues/tests/test_simulation.py:286-288 expects (0.4, 0.6) for 0.1
+        "get_prop_lambda": [
+            {"prop_lambda": 0.3, "expect": [0.2, 0.8]}, {"prop_lambda": 0.1, "expect": [0.4, 0.6]},
+            {"prop_lambda": 0.0, "expect": [2.0, -1.0]}, {"prop_lambda": -0.2, "expect": [2.0, -1.0]},
+        ],
+        # default schedules, blues/simulation.py:654-659
+        "lambda_table": {
+            "lambda": [0.0, 0.1, 0.2, 0.35, 0.5, 0.65, 0.8, 0.9, 1.0],
+            "lambda_sterics": [1.0, 1.0, 1.0, 0.5, 0.0, 0.5, 1.0, 1.0, 1.0],
+            "lambda_electrostatics": [1.0, 0.5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.5, 1.0],
+        },
+        # blues/tests/test_simulation.py:262-289 (integrator attributes for the given cfg)
+        "integrator_attributes": {
+            "cfg": {"nstepsNC": 100, "temperature": 100.0, "dt": 0.001, "nprop": 2, "propLambda": 0.1,
+                    "splitting": "V H R O R H V",
+                    "alchemical_functions": {"lambda_sterics": "1", "lambda_electrostatics": "1"}},
+            "expect": {"_n_steps_neq": 100, "_n_lambda_steps": 200, "_prop_lambda": [0.4, 0.6],
+                       "_splitting": "V H R O R H V"},
+        },
+        # unit constants
+        "kT_300K": 2.494339, "kT_200K": 1.662893,
+        "ewald_alpha": [{"tol": 0.005, "cutoff": 1.0, "alpha": 2.145966}, {"tol": 0.0005, "cutoff": 1.0, "alpha": 2.628261}],
+        # blues/tests/test_watertranslation.py:106,112 ; blues/moves.py:1082
+        "protocol_work_before_first_step": 0.0, "afterMove_rejection_work": 999999,
+        # blues/tests/test_ethylene.py:144-163
+        "ethylene_populations": [0.25, 0.75],
+        # TOL-parm.prmtop:7-10 POINTERS
+        "tol_parm_pointers": {"NATOM": 975, "NTYPES": 4, "NBONH": 648, "MBONA": 7, "NTHETH": 336, "MTHETA": 8,
+                              "NPHIH": 27, "NPHIA": 9, "NNB": 1348, "NRES": 321},
+        # ethylene_system.xml:27 cross-check of the Amber->OpenMM bond constant conversion
+        "bond_k_conversion": {"amber_k": 569.4, "openmm_k": 476473.92},
+    }
+    out = os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")
+    with open(out, "w") as fh:
+        json.dump(ka, fh, indent=1)
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    make_known_answers()
+    make_tol_box()
