@@ -1,0 +1,40 @@
+"""Builds the HIP engine in-tree: blues_amd/csrc/libblues_hip.so (gfx950 only)."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libblues_hip.so")
+SOURCES = ["blues_engine.hip", "device_common.h", "kernels_nb.h", "kernels_alch.h", "kernels_bonded.h", "kernels_integrate.h"]
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(_HERE, "..", "include", "blues_engine.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_engine(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> libblues_hip.so; returns the library path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB_PATH, os.path.join(CSRC, "blues_engine.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_engine(force=True, verbose=True))

@@ -1,0 +1,1005 @@
+// blues_engine.hip -- host side of the MI355X-native NCMC engine and its C-ABI
+// (include/blues_engine.h).  gfx950 only; no torch types; one engine per replica per GPU.
+//
+// The host mirrors the *deterministic* control state of
+// AlchemicalExternalLangevinIntegrator (reference blues/integrators.py:159-231): step,
+// lambda_step, prop, first_step.  It walks the splitting string, batches the substeps
+// between two force evaluations into one k_integrate launch (a "program"), and schedules a
+// force pass only when positions have changed -- one pass per NCMC step for "H V R O R V H"
+// instead of the reference's three full energy/force evaluations.
+// Accumulators (protocol work, forces, flags) stay on the device; nothing is read back
+// between steps.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/blues_engine.h"
+#include "device_common.h"
+#include "kernels_alch.h"
+#include "kernels_bonded.h"
+#include "kernels_integrate.h"
+#include "kernels_nb.h"
+
+static thread_local std::string g_create_error;
+
+template <typename T> struct DBuf {
+    T* p = nullptr; size_t n = 0;
+    void alloc(size_t count) {
+        release(); n = count;
+        if (hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::string("hipMalloc failed");
+        hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+    }
+    void upload(const std::vector<T>& h) {
+        if (h.size() != n || !p) alloc(h.size());
+        if (!h.empty() && hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw std::string("hipMemcpy H2D failed");
+    }
+    void download(std::vector<T>& h) const {
+        h.resize(n);
+        if (n && hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) throw std::string("hipMemcpy D2H failed");
+    }
+    void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+    ~DBuf() { release(); }
+};
+
+struct HostCluster { int atoms[4]; int type, nc; double dist[3]; };
+
+// ---- 3-D Hilbert index (Skilling's transpose algorithm), 10 bits per axis
+static uint32_t hilbert3(uint32_t x, uint32_t y, uint32_t z, int bits) {
+    uint32_t X[3] = {x, y, z};
+    const uint32_t M = 1u << (bits - 1);
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {
+        const uint32_t P = Q - 1;
+        for (int i = 0; i < 3; i++) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    for (int i = 1; i < 3; i++) X[i] ^= X[i - 1];
+    uint32_t t = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
+    for (int i = 0; i < 3; i++) X[i] ^= t;
+    uint32_t key = 0;
+    for (int b = bits - 1; b >= 0; b--) for (int i = 0; i < 3; i++) key = (key << 1) | ((X[i] >> b) & 1u);
+    return key;
+}
+
+struct BluesEngine {
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // ---- system (host copies, caller order)
+    int n = 0;
+    double box[3] = {0, 0, 0};
+    std::vector<double> mass, charge, sigma, eps;
+    std::vector<std::vector<int>> excl;  // per atom, both directions
+    std::vector<int> alch;               // caller indices
+    std::vector<int> alch_local;         // [n] -> local index or -1
+    int nb_method = 1; double cutoff = 1, alpha = 0, sc_alpha = 0.5;
+    int annih_elec = 1, annih_ster = 0, remove_cm = 0;
+    double skin = 0.12;
+    // ---- integrator
+    double dt = 0, temperature = 0, gamma = 1, kT = 0, tol = 1e-8;
+    int nsteps = 0, nprop = 1, n_lambda = 0, precision = 0;
+    double prop_min = 0, prop_max = 0;
+    std::string split; int n_R = 0, n_V = 0, n_O = 0, n_H = 0;
+    std::vector<double> tab_ls, tab_le;
+    uint64_t seed = 0; int replica = 0;
+    // ---- mirrored control state
+    int h_step = 0, h_lambda_step = 0, h_prop = 1, h_first_step = 0;
+    unsigned h_draw = 0;
+    double cur_ls = 1.0, cur_le = 1.0, h_lambda = 0.0;
+    double h_perturbed = 0, h_unperturbed = 0; bool unpert_valid = false, x_edited = false;
+    bool pass_valid = false; int pass_L = 0;
+    bool have_positions = false, sorted_ok = false, lists_forced = true;
+    std::vector<double> hx;        // host copy of the last positions handed in (caller order, [n][3])
+    std::vector<double> hx_sort;   // positions at the last sort
+    double e_frozen[2] = {0, 0}; bool e_frozen_valid = false;
+    // ---- derived topology
+    std::vector<int> mobile;       // caller indices with mass > 0
+    std::vector<HostCluster> clusters;
+    int n_itiles = 0, n_tiles = 0, jcap = 0, nchunk = 1, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0;
+    int int_blocks = 1, int_threads = 128;
+    double total_mass = 0;
+    // ---- device buffers
+    DBuf<double> d_x[3], d_v[3], d_xbuild[3], d_mass, d_charge, d_sigma, d_eps;
+    DBuf<AtomF> d_img_f; DBuf<AtomD> d_img_d;
+    DBuf<int> d_sorted_of_orig, d_orig_of_sorted, d_tile_atoms, d_jlist, d_jcount, d_batch_slot, d_pool_count, d_ex_start, d_ex_idx, d_islot;
+    DBuf<unsigned long long> d_mask_pool;
+    DBuf<DevFlags> d_flags; DBuf<DevAccum> d_acc;
+    DBuf<double> d_fpart, d_epart_nb, d_fJ, d_self_part, d_e_part, d_fbond, d_epart_b, d_cm_part, d_trace, d_scratch;
+    DBuf<int> d_alch_orig, d_alch_local, d_exc_start, d_exc_partner; DBuf<double> d_exc_params;
+    DBuf<int> d_cl_atoms, d_cl_type, d_cl_nc; DBuf<double> d_cl_dist;
+    // bonded
+    DBuf<int> d_row_atom, d_row_start, d_ent_type, d_ent_term, d_ent_role;
+    DBuf<int> d_term_atoms[T_NTYPES]; DBuf<double> d_term_params[T_NTYPES];
+    int n_terms[T_NTYPES] = {0, 0, 0, 0, 0}; int n_rows = 0; double restr_k = 0;
+    // pending integrate program
+    Program prog; unsigned prog_draw_base = 0; int prog_trace = -1; bool tracing = false;
+    // stats
+    int64_t st_passes = 0, st_launches = 0;
+    std::vector<int> h_sorted_of_orig, h_orig_of_sorted;
+
+    ~BluesEngine() {
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+
+#define E_FAIL(h, ...) do { char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__); (h)->err = _b; return 1; } while (0)
+#define HIP_OK(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) { E_FAIL(h, "%s: %s", #call, hipGetErrorString(_e)); } } while (0)
+
+static Box3 make_box(const BluesEngine* h) {
+    Box3 b; for (int k = 0; k < 3; k++) { b.L[k] = h->box[k]; b.invL[k] = 1.0 / h->box[k]; } return b;
+}
+template <typename R> static NbConst<R> make_nbconst(const BluesEngine* h) {
+    NbConst<R> c;
+    const double two = sizeof(R) == 4 ? 4294967296.0 : 18446744073709551616.0;
+    for (int k = 0; k < 3; k++) { c.dscale[k] = h->box[k] / two; c.scale[k] = (R)c.dscale[k]; }
+    c.rc2 = (R)(h->cutoff * h->cutoff); c.alpha = (R)h->alpha;
+    c.rlist2 = (h->cutoff + h->skin) * (h->cutoff + h->skin);
+    return c;
+}
+
+// ------------------------------------------------------------------ topology set-up (once)
+static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
+    const int n = h->n;
+    std::vector<std::vector<std::pair<int, double>>> adj(n);
+    std::vector<std::pair<int, int>> cons; std::vector<double> cdist;
+    for (int c = 0; c < s->n_constraints; c++) {
+        const int i = s->constraint_atoms[2 * c], j = s->constraint_atoms[2 * c + 1];
+        const bool mi = h->mass[i] == 0.0, mj = h->mass[j] == 0.0;
+        if (mi && mj) continue;  // OpenMM ignores constraints between two massless particles
+        if (mi != mj) E_FAIL(h, "A constraint cannot involve a massless particle (%d-%d)", i, j);
+        cons.push_back({i, j}); cdist.push_back(s->constraint_dist[c]);
+    }
+    // connected components, ordered by smallest atom index, constraints in list order (as the oracle)
+    std::vector<int> parent(n); std::iota(parent.begin(), parent.end(), 0);
+    auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+    for (auto& c : cons) { int a = find(c.first), b = find(c.second); if (a != b) parent[std::max(a, b)] = std::min(a, b); }
+    std::map<int, std::vector<int>> by_root;
+    for (size_t c = 0; c < cons.size(); c++) by_root[find(cons[c].first)].push_back((int)c);
+    std::vector<char> in_cluster(n, 0);
+    std::vector<HostCluster> alch_first, rest;
+    auto push = [&](const HostCluster& hc) {
+        bool is_alch = false;
+        for (int a = 0; a < 4; a++) if (hc.atoms[a] >= 0 && h->alch_local[hc.atoms[a]] >= 0) is_alch = true;
+        (is_alch ? alch_first : rest).push_back(hc);
+    };
+    for (auto& kv : by_root) {
+        const std::vector<int>& cl = kv.second;
+        HostCluster hc; for (int a = 0; a < 4; a++) hc.atoms[a] = -1; hc.dist[0] = hc.dist[1] = hc.dist[2] = 0; hc.nc = (int)cl.size();
+        if (cl.size() > 3) E_FAIL(h, "constraint cluster with %zu constraints is not supported (HBonds / rigid water only)", cl.size());
+        std::vector<int> atoms;
+        for (int c : cl) for (int a : {cons[c].first, cons[c].second}) if (std::find(atoms.begin(), atoms.end(), a) == atoms.end()) atoms.push_back(a);
+        if (atoms.size() > 4) E_FAIL(h, "constraint cluster with %zu atoms is not supported", atoms.size());
+        if (cl.size() == 3 && atoms.size() == 3) {  // triangle: canonical order (0,1),(0,2),(1,2)
+            int a = cons[cl[0]].first, b = cons[cl[0]].second, c2a = cons[cl[1]].first, c2b = cons[cl[1]].second;
+            int shared, other1, third;
+            if (c2a == a || c2b == a) { shared = a; other1 = b; third = (c2a == a) ? c2b : c2a; }
+            else if (c2a == b || c2b == b) { shared = b; other1 = a; third = (c2a == b) ? c2b : c2a; }
+            else E_FAIL(h, "malformed triangle constraint cluster");
+            hc.type = 2; hc.atoms[0] = shared; hc.atoms[1] = other1; hc.atoms[2] = third;
+            hc.dist[0] = cdist[cl[0]]; hc.dist[1] = cdist[cl[1]]; hc.dist[2] = cdist[cl[2]];
+        } else {  // star: common centre, leaves in list order
+            int centre = -1;
+            if (cl.size() == 1) centre = cons[cl[0]].first;
+            else {
+                for (int cand : {cons[cl[0]].first, cons[cl[0]].second}) {
+                    bool all = true;
+                    for (int c : cl) if (cons[c].first != cand && cons[c].second != cand) all = false;
+                    if (all) centre = cand;
+                }
+                if (centre < 0) E_FAIL(h, "constraint cluster is neither a star nor a triangle");
+            }
+            hc.type = 1; hc.atoms[0] = centre;
+            for (size_t q = 0; q < cl.size(); q++) {
+                hc.atoms[q + 1] = cons[cl[q]].first == centre ? cons[cl[q]].second : cons[cl[q]].first;
+                hc.dist[q] = cdist[cl[q]];
+            }
+        }
+        for (int a = 0; a < 4; a++) if (hc.atoms[a] >= 0) in_cluster[hc.atoms[a]] = 1;
+        push(hc);
+    }
+    for (int i : h->mobile) if (!in_cluster[i]) {
+        HostCluster hc; hc.atoms[0] = i; hc.atoms[1] = hc.atoms[2] = hc.atoms[3] = -1; hc.type = 0; hc.nc = 0; hc.dist[0] = hc.dist[1] = hc.dist[2] = 0;
+        push(hc);
+    }
+    h->clusters = alch_first; h->clusters.insert(h->clusters.end(), rest.begin(), rest.end());
+    if (alch_first.size() > 128) E_FAIL(h, "too many alchemical constraint clusters");
+    const int ncl = (int)h->clusters.size();
+    std::vector<int> ca(ncl * 4), ct(ncl), cn(ncl); std::vector<double> cd(ncl * 3);
+    for (int c = 0; c < ncl; c++) {
+        for (int a = 0; a < 4; a++) ca[c * 4 + a] = h->clusters[c].atoms[a];
+        ct[c] = h->clusters[c].type; cn[c] = h->clusters[c].nc;
+        for (int q = 0; q < 3; q++) cd[c * 3 + q] = h->clusters[c].dist[q];
+    }
+    h->d_cl_atoms.upload(ca); h->d_cl_type.upload(ct); h->d_cl_nc.upload(cn); h->d_cl_dist.upload(cd);
+    h->int_threads = ncl <= 256 ? std::max(128, ((ncl + 63) / 64) * 64) : 256;
+    h->int_blocks = std::max(1, (ncl + h->int_threads - 1) / h->int_threads);
+    h->d_cm_part.alloc((size_t)h->int_blocks * 3);
+    return 0;
+}
+
+static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
+    // all terms are kept for energies; rows (force gather) only for mobile atoms
+    std::vector<int> ta[T_NTYPES]; std::vector<double> tp[T_NTYPES];
+    auto is_alch = [&](int i) { return h->alch_local[i] >= 0; };
+    for (int b = 0; b < s->n_bonds; b++) { ta[T_BOND].push_back(s->bond_atoms[2 * b]); ta[T_BOND].push_back(s->bond_atoms[2 * b + 1]); tp[T_BOND].push_back(s->bond_params[2 * b]); tp[T_BOND].push_back(s->bond_params[2 * b + 1]); }
+    for (int a = 0; a < s->n_angles; a++) { for (int q = 0; q < 3; q++) ta[T_ANGLE].push_back(s->angle_atoms[3 * a + q]); tp[T_ANGLE].push_back(s->angle_params[2 * a]); tp[T_ANGLE].push_back(s->angle_params[2 * a + 1]); }
+    for (int t = 0; t < s->n_torsions; t++) { for (int q = 0; q < 4; q++) ta[T_TORSION].push_back(s->torsion_atoms[4 * t + q]); for (int q = 0; q < 3; q++) tp[T_TORSION].push_back(s->torsion_params[3 * t + q]); }
+    // exceptions: env-env go to the bonded kernel, those touching alchemical atoms to the alchemical kernel
+    std::vector<std::vector<int>> arow_partner(h->alch.size()); std::vector<std::vector<double>> arow_par(h->alch.size());
+    for (int e = 0; e < s->n_exceptions; e++) {
+        const int i = s->exception_atoms[2 * e], j = s->exception_atoms[2 * e + 1];
+        const double* p = s->exception_params + 3 * e;
+        if (!is_alch(i) && !is_alch(j)) { ta[T_EXC].push_back(i); ta[T_EXC].push_back(j); for (int q = 0; q < 3; q++) tp[T_EXC].push_back(p[q]); }
+        else if (is_alch(i) && is_alch(j)) {
+            arow_partner[h->alch_local[i]].push_back(j); for (int q = 0; q < 3; q++) arow_par[h->alch_local[i]].push_back(p[q]);
+            arow_partner[h->alch_local[j]].push_back(i); for (int q = 0; q < 3; q++) arow_par[h->alch_local[j]].push_back(p[q]);
+        } else if (p[0] != 0.0 || p[2] != 0.0)
+            E_FAIL(h, "1-4 exception between an alchemical and a non-alchemical atom (%d-%d) is not supported yet", i, j);
+    }
+    for (int r = 0; r < s->n_restraints; r++) { ta[T_RESTR].push_back(s->restraint_atoms[r]); for (int q = 0; q < 3; q++) tp[T_RESTR].push_back(s->restraint_x0[3 * r + q]); }
+    h->restr_k = s->restraint_k;
+    const int width[T_NTYPES] = {2, 3, 4, 2, 1};
+    std::vector<std::vector<int>> rtype(h->n), rterm(h->n), rrole(h->n);
+    for (int ty = 0; ty < T_NTYPES; ty++) {
+        h->n_terms[ty] = (int)ta[ty].size() / width[ty];
+        for (int t = 0; t < h->n_terms[ty]; t++) for (int q = 0; q < width[ty]; q++) {
+            const int i = ta[ty][t * width[ty] + q];
+            if (i < 0 || i >= h->n) E_FAIL(h, "bonded term references atom %d", i);
+            if (h->mass[i] != 0.0) { rtype[i].push_back(ty); rterm[i].push_back(t); rrole[i].push_back(q); }
+        }
+        h->d_term_atoms[ty].upload(ta[ty]); h->d_term_params[ty].upload(tp[ty]);
+    }
+    std::vector<int> row_atom, row_start(1, 0), et, ei, er;
+    for (int i = 0; i < h->n; i++) if (!rtype[i].empty()) {
+        row_atom.push_back(i);
+        et.insert(et.end(), rtype[i].begin(), rtype[i].end()); ei.insert(ei.end(), rterm[i].begin(), rterm[i].end()); er.insert(er.end(), rrole[i].begin(), rrole[i].end());
+        row_start.push_back((int)et.size());
+    }
+    h->n_rows = (int)row_atom.size();
+    h->d_row_atom.upload(row_atom); h->d_row_start.upload(row_start); h->d_ent_type.upload(et); h->d_ent_term.upload(ei); h->d_ent_role.upload(er);
+    int total_terms = 0; for (int ty = 0; ty < T_NTYPES; ty++) total_terms += h->n_terms[ty];
+    h->d_epart_b.alloc((size_t)((total_terms + 255) / 256 + 1) * T_NTYPES);
+    // alchemical exception rows
+    std::vector<int> es(1, 0), ep; std::vector<double> epar;
+    for (size_t a = 0; a < h->alch.size(); a++) { ep.insert(ep.end(), arow_partner[a].begin(), arow_partner[a].end()); epar.insert(epar.end(), arow_par[a].begin(), arow_par[a].end()); es.push_back((int)ep.size()); }
+    h->d_exc_start.upload(es); h->d_exc_partner.upload(ep); h->d_exc_params.upload(epar);
+    return 0;
+}
+
+// ------------------------------------------------------------------ spatial sort + tile image (host, at set_positions)
+static int sort_and_tile(BluesEngine* h) {
+    const int n = h->n;
+    std::vector<std::pair<uint32_t, int>> keys(n);
+    for (int i = 0; i < n; i++) {
+        uint32_t c[3];
+        for (int k = 0; k < 3; k++) { double fr = h->hx[3 * i + k] / h->box[k]; fr -= std::floor(fr); c[k] = std::min<uint32_t>(1023u, (uint32_t)(fr * 1024.0)); }
+        keys[i] = {hilbert3(c[0], c[1], c[2], 10), i};
+    }
+    std::stable_sort(keys.begin(), keys.end());
+    h->h_orig_of_sorted.resize(n); h->h_sorted_of_orig.resize(n);
+    for (int s = 0; s < n; s++) { h->h_orig_of_sorted[s] = keys[s].second; h->h_sorted_of_orig[keys[s].second] = s; }
+    // i-tiles: mobile, non-alchemical atoms in sorted order
+    std::vector<int> tile_atoms, islot(n, -1);
+    for (int s = 0; s < n; s++) {
+        const int o = h->h_orig_of_sorted[s];
+        if (h->mass[o] != 0.0 && h->alch_local[o] < 0) { islot[o] = (int)tile_atoms.size(); tile_atoms.push_back(s); }
+    }
+    h->n_itiles = ((int)tile_atoms.size() + 63) / 64;
+    tile_atoms.resize((size_t)h->n_itiles * 64, -1);
+    h->n_tiles = h->n_itiles + (h->alch.empty() ? 0 : 1);
+    if (!h->alch.empty()) { for (size_t a = 0; a < 64; a++) tile_atoms.push_back(a < h->alch.size() ? h->h_sorted_of_orig[h->alch[a]] : -1); }
+    if (h->n_tiles == 0) { tile_atoms.assign(64, -1); }
+    h->n_islots = std::max(1, h->n_itiles) * 64;
+    // capacities
+    const double rl = h->cutoff + h->skin;
+    const double vol = h->box[0] * h->box[1] * h->box[2], rho = n / vol;
+    const double a = std::cbrt(64.0 / std::max(rho, 1e-9)) * 1.35;  // tile edge incl. slack for diffusion
+    double est = rho * (a * a * a + 6 * a * a * rl + 3 * M_PI * a * rl * rl + 4.0 / 3.0 * M_PI * rl * rl * rl) * 1.5;
+    int jcap = (int)std::min<double>(n, est);
+    jcap = std::max(64, ((jcap + 63) / 64) * 64);
+    jcap = std::min(jcap, 16384);
+    if (((n + 63) / 64) * 64 <= jcap) jcap = ((n + 63) / 64) * 64;
+    h->jcap = jcap;
+    const int nt = std::max(1, h->n_tiles);
+    h->nchunk = std::max(1, std::min(std::min(64, jcap / 64), (8192 + std::max(1, h->n_itiles) - 1) / std::max(1, h->n_itiles)));
+    h->pool_cap = nt * 12 + 64;
+    h->PA = 1; while (h->PA < (int)h->alch.size()) h->PA <<= 1;
+    h->k2_nblocks_env = (jcap * h->PA + 255) / 256;
+    // exclusions in sorted space (self included)
+    std::vector<int> ex_start(n + 1, 0), ex_idx;
+    for (int s = 0; s < n; s++) {
+        const int o = h->h_orig_of_sorted[s];
+        std::vector<int> row; row.push_back(s);
+        for (int p : h->excl[o]) row.push_back(h->h_sorted_of_orig[p]);
+        std::sort(row.begin(), row.end());
+        ex_idx.insert(ex_idx.end(), row.begin(), row.end());
+        ex_start[s + 1] = (int)ex_idx.size();
+    }
+    // image
+    const double sq = std::sqrt(ONE_4PI_EPS0);
+    std::vector<AtomF> imf; std::vector<AtomD> imd;
+    if (h->precision == 0) imf.resize(n); else imd.resize(n);
+    for (int s = 0; s < n; s++) {
+        const int o = h->h_orig_of_sorted[s];
+        const bool al = h->alch_local[o] >= 0;
+        const unsigned flags = (al ? FLAG_ALCH : 0u) | ((h->mass[o] != 0.0 && !al) ? FLAG_MOBILE : 0u);
+        unsigned long long u[3];
+        for (int k = 0; k < 3; k++) { double fr = h->hx[3 * o + k] / h->box[k]; fr -= std::floor(fr); if (fr >= 1.0) fr = 0.0; u[k] = (unsigned long long)(fr * 18446744073709551616.0); }
+        const double q = al ? 0.0 : h->charge[o] * sq, hs = 0.5 * h->sigma[o], se = al ? 0.0 : 2.0 * std::sqrt(h->eps[o]);
+        if (h->precision == 0) {
+            AtomF& A = imf[s];
+            A.x = (uint32_t)((u[0] + 0x80000000ull) >> 32); A.y = (uint32_t)((u[1] + 0x80000000ull) >> 32); A.z = (uint32_t)((u[2] + 0x80000000ull) >> 32);
+            A.q = (float)q; A.hs = (float)hs; A.se = (float)se; A.flags = flags; A.orig = o;
+        } else {
+            AtomD& A = imd[s];
+            A.x = u[0]; A.y = u[1]; A.z = u[2]; A.q = q; A.hs = hs; A.se = se; A.flags = flags; A.orig = o; A.pad = 0;
+        }
+    }
+    try {
+        if (h->precision == 0) h->d_img_f.upload(imf); else h->d_img_d.upload(imd);
+        h->d_sorted_of_orig.upload(h->h_sorted_of_orig); h->d_orig_of_sorted.upload(h->h_orig_of_sorted);
+        h->d_tile_atoms.upload(tile_atoms); h->d_islot.upload(islot);
+        h->d_ex_start.upload(ex_start); h->d_ex_idx.upload(ex_idx);
+        h->d_jlist.alloc((size_t)nt * jcap); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
+        h->d_mask_pool.alloc((size_t)h->pool_cap * 64); h->d_pool_count.alloc(1);
+        h->d_fpart.alloc((size_t)h->nchunk * 3 * h->n_islots);
+        h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->nchunk * 2 + 2 * ((n + 255) / 256));
+        h->d_fJ.alloc((size_t)9 * n);
+        h->d_self_part.alloc((size_t)(h->k2_nblocks_env + 1) * 9 * 64); h->d_e_part.alloc((size_t)(h->k2_nblocks_env + 1) * K2_NE);
+    } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    h->hx_sort = h->hx;
+    h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->e_frozen_valid = false;
+    return 0;
+}
+
+// ------------------------------------------------------------------ launches
+static IntArgs make_int_args(BluesEngine* h) {
+    IntArgs A; memset(&A, 0, sizeof A);
+    A.n = h->n; A.n_clusters = (int)h->clusters.size();
+    A.cl_atoms = h->d_cl_atoms.p; A.cl_type = h->d_cl_type.p; A.cl_nc = h->d_cl_nc.p; A.cl_dist = h->d_cl_dist.p;
+    for (int k = 0; k < 3; k++) { A.x[k] = h->d_x[k].p; A.v[k] = h->d_v[k].p; A.xbuild[k] = h->d_xbuild[k].p; }
+    A.mass = h->d_mass.p;
+    A.fpart = h->d_fpart.p; A.nchunk = h->nchunk; A.n_islots = h->n_islots; A.islot_of_orig = h->d_islot.p;
+    A.fbond = h->d_fbond.p; A.fJ = h->d_fJ.p; A.sorted_of_orig = h->d_sorted_of_orig.p;
+    A.self_part = h->d_self_part.p; A.e_part = h->d_e_part.p;
+    A.jcount_alch = h->d_jcount.p + h->n_itiles; A.k2_nblocks_env = h->k2_nblocks_env; A.PA = h->PA; A.n_alch = (int)h->alch.size();
+    A.alch_local_of_orig = h->d_alch_local.p;
+    for (int s = 0; s < 3; s++) { const int L = std::min(h->pass_L + s, h->n_lambda); A.le[s] = h->tab_le[L]; }
+    A.hV = h->dt / std::max(1, h->n_V); A.hR = h->dt / std::max(1, h->n_R);
+    const double hO = h->dt / std::max(1, h->n_O);
+    A.aO = std::exp(-h->gamma * hO); A.bO = std::sqrt(1.0 - std::exp(-2.0 * h->gamma * hO));
+    A.kT = h->kT; A.tol = h->tol; A.seed = h->seed; A.stream = (unsigned)h->replica * 4u; A.draw_base = h->prog_draw_base;
+    A.box = make_box(h); A.periodic = h->nb_method == BLUES_NB_PME_DIRECT;
+    A.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; A.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
+    A.half_skin2 = 0.25 * h->skin * h->skin; A.flags = h->d_flags.p; A.pool_count = h->d_pool_count.p;
+    A.total_mass = h->total_mass; A.cm_part = h->d_cm_part.p; A.cm_nblocks = h->int_blocks;
+    A.acc = h->d_acc.p; A.work_trace = h->tracing ? h->d_trace.p : nullptr; A.trace_index = h->prog_trace;
+    A.prog = h->prog;
+    return A;
+}
+
+static int flush_program(BluesEngine* h) {
+    if (h->prog.n == 0) return 0;
+    IntArgs A = make_int_args(h);
+    hipLaunchKernelGGL(k_integrate, dim3(h->int_blocks), dim3(h->int_threads), 0, h->stream, A);
+    h->st_launches++;
+    h->prog.n = 0; h->prog_trace = -1; h->prog_draw_base = h->h_draw;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+static int emit(BluesEngine* h, int op) {
+    if (h->prog.n == 0) h->prog_draw_base = h->h_draw;
+    if (h->prog.n >= MAX_OPS) { if (flush_program(h)) return 1; h->prog_draw_base = h->h_draw; }
+    h->prog.ops[h->prog.n++] = (unsigned char)op;
+    if (op == OP_O) h->h_draw++;
+    return 0;
+}
+
+template <typename R> static int launch_lists(BluesEngine* h, int force) {
+    ListArgs a; memset(&a, 0, sizeof a);
+    a.n = h->n; a.n_tiles = h->n_tiles; a.n_itiles = h->n_itiles; a.jcap = h->jcap; a.pool_cap = h->pool_cap;
+    a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p;
+    a.mask_pool = h->d_mask_pool.p; a.pool_count = h->d_pool_count.p; a.ex_start = h->d_ex_start.p; a.ex_idx = h->d_ex_idx.p; a.flags = h->d_flags.p;
+    for (int k = 0; k < 3; k++) { a.x[k] = h->d_x[k].p; a.xbuild[k] = h->d_xbuild[k].p; }
+    a.fJ = h->d_fJ.p; a.n_fJ = 9 * h->n;
+    if (force) HIP_OK(h, hipMemsetAsync(h->d_pool_count.p, 0, sizeof(int), h->stream));
+    const typename Img<R>::Atom* img;
+    if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
+    hipLaunchKernelGGL(k_build_lists<R>, dim3(std::max(1, h->n_tiles)), dim3(256), 0, h->stream, a, make_nbconst<R>(h), img, force);
+    h->st_launches++;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
+    NbArgs<R> a; memset(&a, 0, sizeof a);
+    a.n_itiles = h->n_itiles; a.nchunk = h->nchunk; a.jcap = h->jcap; a.n_islots = h->n_islots;
+    a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p; a.mask_pool = h->d_mask_pool.p;
+    a.fpart = h->d_fpart.p; a.epart = h->d_epart_nb.p; a.flags = h->d_flags.p;
+    const typename Img<R>::Atom* img;
+    if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
+    const int waves = std::max(1, h->n_itiles * h->nchunk);
+    hipLaunchKernelGGL((k_nonbonded<R, ENERGY>), dim3((waves + 3) / 4), dim3(256), 0, h->stream, a, make_nbconst<R>(h), img);
+    h->st_launches++;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+static int launch_alchemical(BluesEngine* h, const double ls[3], const double le[3], int slot_mask) {
+    if (h->alch.empty()) return 0;
+    AlchArgs A; memset(&A, 0, sizeof A);
+    A.n = h->n; A.n_alch = (int)h->alch.size(); A.PA = h->PA; A.jcap = h->jcap; A.nblocks_env = h->k2_nblocks_env;
+    A.alch_orig = h->d_alch_orig.p; A.jlist = h->d_jlist.p + (size_t)h->n_itiles * h->jcap; A.jcount = h->d_jcount.p + h->n_itiles;
+    A.orig_of_sorted = h->d_orig_of_sorted.p; A.sorted_of_orig = h->d_sorted_of_orig.p;
+    for (int k = 0; k < 3; k++) A.x[k] = h->d_x[k].p;
+    A.charge = h->d_charge.p; A.sigma = h->d_sigma.p; A.eps = h->d_eps.p; A.ex_start = h->d_ex_start.p; A.ex_idx = h->d_ex_idx.p;
+    A.exc_start = h->d_exc_start.p; A.exc_partner = h->d_exc_partner.p; A.exc_params = h->d_exc_params.p;
+    A.box = make_box(h); A.rc2 = h->cutoff * h->cutoff; A.alpha = h->alpha; A.sc_alpha = h->sc_alpha;
+    A.pme = h->nb_method == BLUES_NB_PME_DIRECT; A.annih_elec = h->annih_elec; A.annih_ster = h->annih_ster; A.slot_mask = slot_mask;
+    for (int s = 0; s < 3; s++) { A.ls[s] = ls[s]; A.le[s] = le[s]; }
+    A.fJ = h->d_fJ.p; A.self_part = h->d_self_part.p; A.e_part = h->d_e_part.p;
+    hipLaunchKernelGGL(k_alchemical, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->stream, A);
+    h->st_launches++;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+static BondedArgs make_bonded_args(BluesEngine* h) {
+    BondedArgs B; memset(&B, 0, sizeof B);
+    B.n_rows = h->n_rows; B.row_atom = h->d_row_atom.p; B.row_start = h->d_row_start.p;
+    B.ent_type = h->d_ent_type.p; B.ent_term = h->d_ent_term.p; B.ent_role = h->d_ent_role.p;
+    for (int ty = 0; ty < T_NTYPES; ty++) { B.n_terms[ty] = h->n_terms[ty]; B.atoms[ty] = h->d_term_atoms[ty].p; B.params[ty] = h->d_term_params[ty].p; }
+    B.restr_k = h->restr_k;
+    for (int k = 0; k < 3; k++) B.x[k] = h->d_x[k].p;
+    B.box = make_box(h); B.periodic = h->nb_method == BLUES_NB_PME_DIRECT; B.fbond = h->d_fbond.p; B.n = h->n; B.epart = h->d_epart_b.p;
+    return B;
+}
+
+static int ensure_sorted(BluesEngine* h) {
+    if (!h->have_positions) E_FAIL(h, "positions have not been set");
+    if (!h->sorted_ok) return sort_and_tile(h);
+    return 0;
+}
+
+// one force pass at the current positions: lists (if stale) -> alchemical -> nonbonded -> bonded
+static int force_pass(BluesEngine* h, int base_L) {
+    if (ensure_sorted(h)) return 1;
+    double ls[3], le[3];
+    for (int s = 0; s < 3; s++) { const int L = std::min(base_L + s, h->n_lambda); ls[s] = h->tab_ls[L]; le[s] = h->tab_le[L]; }
+    int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced) : launch_lists<double>(h, h->lists_forced);
+    h->lists_forced = false;
+    if (rc) return 1;
+    if (launch_alchemical(h, ls, le, 7)) return 1;
+    rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
+    if (rc) return 1;
+    if (h->n_rows > 0) {
+        hipLaunchKernelGGL(k_bonded_forces, dim3((h->n_rows + 127) / 128), dim3(128), 0, h->stream, make_bonded_args(h));
+        h->st_launches++;
+    }
+    h->pass_valid = true; h->pass_L = base_L; h->st_passes++;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+static int check_flags(BluesEngine* h) {
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    DevFlags f;
+    HIP_OK(h, hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost));
+    if (f.nan_flag) E_FAIL(h, "Particle coordinate is nan");
+    if (f.list_overflow) E_FAIL(h, "neighbour list capacity exceeded (jcap=%d)", h->jcap);
+    if (f.constraint_fail) E_FAIL(h, "constraint solver did not converge");
+    return 0;
+}
+
+// full potential energy breakdown at the current state and alchemical parameters (on demand; synchronises)
+static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
+    if (flush_program(h)) return 1;
+    if (ensure_sorted(h)) return 1;
+    for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) T[t] = 0.0;
+    double ls[3] = {h->cur_ls, h->cur_ls, h->cur_ls}, le[3] = {h->cur_le, h->cur_le, h->cur_le};
+    int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced) : launch_lists<double>(h, h->lists_forced);
+    h->lists_forced = false;
+    if (rc) return 1;
+    h->pass_valid = false;  // slabs are about to be overwritten with parameters that are not a regular pass
+    if (launch_alchemical(h, ls, le, 1)) return 1;
+    rc = h->precision == 0 ? launch_nonbonded<float, true>(h) : launch_nonbonded<double, true>(h);
+    if (rc) return 1;
+    int total_terms = 0; for (int ty = 0; ty < T_NTYPES; ty++) total_terms += h->n_terms[ty];
+    const int nbb = (total_terms + 255) / 256;
+    if (nbb > 0) { hipLaunchKernelGGL(k_bonded_energy, dim3(nbb), dim3(256), 0, h->stream, make_bonded_args(h)); h->st_launches++; }
+    const int nfb = (h->n + 255) / 256;
+    if (!h->e_frozen_valid) {
+        double* ep = h->d_epart_nb.p + (size_t)std::max(1, h->n_itiles) * h->nchunk * 2;
+        if (h->precision == 0) hipLaunchKernelGGL(k_energy_frozen<float>, dim3(nfb), dim3(256), 0, h->stream, h->n, make_nbconst<float>(h), h->d_img_f.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
+        else hipLaunchKernelGGL(k_energy_frozen<double>, dim3(nfb), dim3(256), 0, h->stream, h->n, make_nbconst<double>(h), h->d_img_d.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
+        h->st_launches++;
+    }
+    if (check_flags(h)) return 1;
+    std::vector<double> e;
+    try {
+        h->d_epart_nb.download(e);
+        const int nw = h->n_itiles * h->nchunk;
+        double enb = 0.0; for (int w = 0; w < nw; w++) enb += e[2 * w] + e[2 * w + 1];
+        if (!h->e_frozen_valid) {
+            const size_t off = (size_t)std::max(1, h->n_itiles) * h->nchunk * 2;
+            h->e_frozen[0] = h->e_frozen[1] = 0.0;
+            for (int b = 0; b < nfb; b++) { h->e_frozen[0] += e[off + 2 * b]; h->e_frozen[1] += e[off + 2 * b + 1]; }
+            h->e_frozen_valid = true;
+        }
+        T[3] = enb + h->e_frozen[0] + h->e_frozen[1];
+        if (nbb > 0) {
+            h->d_epart_b.download(e);
+            for (int b = 0; b < nbb; b++) { T[0] += e[b * T_NTYPES + T_BOND]; T[1] += e[b * T_NTYPES + T_ANGLE]; T[2] += e[b * T_NTYPES + T_TORSION]; T[4] += e[b * T_NTYPES + T_EXC]; T[7] += e[b * T_NTYPES + T_RESTR]; }
+        }
+        if (!h->alch.empty()) {
+            std::vector<int> jc; h->d_jcount.download(jc);
+            const int cnt = jc[h->n_itiles], nb_env = (cnt * h->PA + 255) / 256;
+            h->d_e_part.download(e);
+            double s[K2_NE] = {0, 0, 0, 0, 0, 0};
+            for (int b = 0; b <= h->k2_nblocks_env; b++) { if (b >= nb_env && b != h->k2_nblocks_env) continue; for (int q = 0; q < K2_NE; q++) s[q] += e[(size_t)b * K2_NE + q]; }
+            T[5] = s[1] + s[4]; T[6] = h->cur_le * s[0] + s[5];
+        }
+    } catch (std::string& msg) { E_FAIL(h, "%s", msg.c_str()); }
+    return 0;
+}
+
+static int total_energy(BluesEngine* h, double* E) {
+    double T[BLUES_N_ENERGY_TERMS];
+    if (energy_terms(h, T)) return 1;
+    *E = 0.0; for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) *E += T[t];
+    return 0;
+}
+
+static int add_work(BluesEngine* h, double delta) {
+    if (flush_program(h)) return 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    DevAccum a;
+    HIP_OK(h, hipMemcpy(&a, h->d_acc.p, sizeof a, hipMemcpyDeviceToHost));
+    a.protocol_work += delta;
+    HIP_OK(h, hipMemcpy(h->d_acc.p, &a, sizeof a, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int emit_cm(BluesEngine* h) {
+    if (!h->remove_cm) return 0;
+    if (h->int_blocks == 1) return emit(h, OP_CM_BLOCK);
+    if (emit(h, OP_CM_REDUCE)) return 1;
+    if (flush_program(h)) return 1;
+    return emit(h, OP_CM_APPLY);
+}
+
+static int need_pass(BluesEngine* h, int lo, int hi) {  // need slots covering L in [lo, hi] of the current x
+    if (h->pass_valid && lo - h->pass_L >= 0 && hi - h->pass_L <= 2) return 0;
+    if (flush_program(h)) return 1;
+    return force_pass(h, lo);
+}
+
+static int splitting_pass(BluesEngine* h) {
+    if (emit_cm(h)) return 1;
+    for (char c : h->split) {
+        switch (c) {
+        case 'V': {
+            if (need_pass(h, h->h_lambda_step, h->h_lambda_step)) return 1;
+            if (emit(h, OP_V0 + (h->h_lambda_step - h->pass_L))) return 1;
+        } break;
+        case 'R': if (emit(h, OP_R)) return 1; h->pass_valid = false; break;
+        case 'O': if (emit(h, OP_O)) return 1; break;
+        case 'H': {
+            if (h->h_prop != 1) break;  // reference blues/integrators.py:217
+            const int L = h->h_lambda_step;
+            if (L + 1 > h->n_lambda) break;
+            if (need_pass(h, L, L + 1)) return 1;
+            if (emit(h, OP_H01 + (L - h->pass_L))) return 1;
+            h->h_lambda_step = L + 1; h->h_lambda = (double)(L + 1) / h->n_lambda;
+            h->cur_ls = h->tab_ls[L + 1]; h->cur_le = h->tab_le[L + 1];
+        } break;
+        default: break;
+        }
+    }
+    return 0;
+}
+
+// reference blues/integrators.py:159-209
+static int do_steps(BluesEngine* h, int nsteps) {
+    if (ensure_sorted(h)) return 1;
+    for (int s = 0; s < nsteps; s++) {
+        if (h->h_step == 0) {  // first call after construction / reset
+            if (flush_program(h)) return 1;
+            if (emit(h, OP_PREP)) return 1;
+            if (flush_program(h)) return 1;
+            h->pass_valid = false;
+            HIP_OK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(DevAccum), h->stream));
+            h->h_lambda = 0.0; h->h_lambda_step = 0; h->cur_ls = h->tab_ls[0]; h->cur_le = h->tab_le[0];
+            h->h_perturbed = h->h_unperturbed = 0.0; h->unpert_valid = false;
+        }
+        if (h->h_step < h->nsteps) {
+            if (h->h_first_step < 1) { h->h_first_step = 1; }
+            else if (h->x_edited && h->unpert_valid) {  // work done by an instantaneous Move (integrators.py:184-191)
+                double E;
+                if (total_energy(h, &E)) return 1;
+                h->h_perturbed = E;
+                if (add_work(h, h->h_perturbed - h->h_unperturbed)) return 1;
+            }
+            h->x_edited = false; h->unpert_valid = false;
+            if (splitting_pass(h)) return 1;
+            if (h->h_lambda > h->prop_min && h->h_lambda <= h->prop_max)
+                while (h->h_prop < h->nprop) { h->h_prop++; if (splitting_pass(h)) return 1; }
+            if (h->prog_trace >= 0) { if (flush_program(h)) return 1; }
+            if (emit(h, OP_END)) return 1;
+            h->prog_trace = h->h_step;
+            h->h_step++; h->h_prop = 1;
+        }
+    }
+    return flush_program(h);
+}
+
+// ------------------------------------------------------------------ C-ABI
+extern "C" {
+
+int blues_abi_version(void) { return BLUES_ABI_VERSION; }
+
+const char* blues_last_error(const BluesEngine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesIntegratorDesc* it) {
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) if (r != c && s->box[3 * r + c] != 0.0) E_FAIL(h, "only orthorhombic boxes are supported");
+    if (s->nonbonded_method != BLUES_NB_PME_DIRECT) E_FAIL(h, "the GPU engine supports periodic PME-direct systems only");
+    const int n = h->n = s->n_atoms;
+    if (n <= 0) E_FAIL(h, "empty system");
+    h->box[0] = s->box[0]; h->box[1] = s->box[4]; h->box[2] = s->box[8];
+    h->nb_method = s->nonbonded_method; h->cutoff = s->cutoff; h->alpha = s->ewald_alpha; h->sc_alpha = s->softcore_alpha;
+    for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * h->cutoff) E_FAIL(h, "box edge %g < 2*cutoff", h->box[k]);
+    if (const char* sk = getenv("BLUES_SKIN")) h->skin = atof(sk);
+    for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) h->skin = std::max(0.0, 0.5 * h->box[k] - h->cutoff - 1e-6);
+    h->annih_elec = s->annihilate_electrostatics; h->annih_ster = s->annihilate_sterics; h->remove_cm = s->remove_cm_motion;
+    h->mass.assign(s->mass, s->mass + n); h->charge.assign(s->charge, s->charge + n); h->sigma.assign(s->sigma, s->sigma + n); h->eps.assign(s->epsilon, s->epsilon + n);
+    h->excl.assign(n, {});
+    for (int e = 0; e < s->n_exclusions; e++) {
+        const int a = s->exclusions[2 * e], b = s->exclusions[2 * e + 1];
+        if (a < 0 || b < 0 || a >= n || b >= n) E_FAIL(h, "exclusion references atom out of range");
+        h->excl[a].push_back(b); h->excl[b].push_back(a);
+    }
+    h->alch.assign(s->alchemical_atoms, s->alchemical_atoms + s->n_alchemical);
+    if (h->alch.size() > 64) E_FAIL(h, "more than 64 alchemical atoms is not supported yet");
+    h->alch_local.assign(n, -1);
+    for (size_t a = 0; a < h->alch.size(); a++) h->alch_local[h->alch[a]] = (int)a;
+    h->total_mass = 0.0;
+    for (int i = 0; i < n; i++) if (h->mass[i] != 0.0) { h->mobile.push_back(i); h->total_mass += h->mass[i]; }
+    // integrator
+    h->dt = it->timestep; h->temperature = it->temperature; h->gamma = it->collision_rate; h->kT = KB_KJ * it->temperature;
+    h->tol = it->constraint_tolerance; h->nsteps = it->nsteps_neq; h->nprop = it->nprop; h->n_lambda = it->n_lambda_steps;
+    h->prop_min = it->prop_lambda_min; h->prop_max = it->prop_lambda_max; h->seed = it->seed; h->replica = it->replica; h->precision = it->precision;
+    for (const char* p = it->splitting; *p; p++) {
+        if (*p == ' ') continue;
+        if (*p != 'R' && *p != 'V' && *p != 'O' && *p != 'H') E_FAIL(h, "unsupported splitting token '%c'", *p);
+        h->split.push_back(*p);
+        if (*p == 'R') h->n_R++; else if (*p == 'V') h->n_V++; else if (*p == 'O') h->n_O++; else h->n_H++;
+    }
+    if (h->n_lambda != h->nsteps * h->n_H) E_FAIL(h, "n_lambda_steps must equal nsteps_neq * (number of H in splitting)");
+    h->tab_ls.assign(it->lambda_sterics, it->lambda_sterics + h->n_lambda + 1);
+    h->tab_le.assign(it->lambda_electrostatics, it->lambda_electrostatics + h->n_lambda + 1);
+    h->prog.n = 0;
+    HIP_OK(h, hipSetDevice(h->device));
+    HIP_OK(h, hipStreamCreate(&h->stream));
+    HIP_OK(h, hipEventCreate(&h->ev0)); HIP_OK(h, hipEventCreate(&h->ev1));
+    try {
+        for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); }
+        h->d_mass.upload(h->mass); h->d_charge.upload(h->charge); h->d_sigma.upload(h->sigma); h->d_eps.upload(h->eps);
+        h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_fbond.alloc((size_t)3 * n);
+        h->d_alch_orig.upload(h->alch); h->d_alch_local.upload(h->alch_local);
+        h->d_trace.alloc((size_t)std::max(1, h->nsteps)); h->d_scratch.alloc((size_t)std::max(3 * n, 1024));
+    } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    if (build_clusters(h, s)) return 1;
+    try { if (build_bonded(h, s)) return 1; } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    return 0;
+}
+
+int blues_engine_create(const BluesSystemDesc* s, const BluesIntegratorDesc* it, int device, BluesEngine** out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available: the blues_amd engine has no CPU fallback"; return 2; }
+    if (device < 0 || device >= ndev) { g_create_error = "invalid device ordinal"; return 2; }
+    BluesEngine* h = new BluesEngine();
+    h->device = device;
+    int rc;
+    try { rc = create_impl(h, s, it); } catch (std::string& e) { h->err = e; rc = 1; }
+    if (rc) { g_create_error = h->err; delete h; return rc; }
+    *out = h;
+    return 0;
+}
+
+int blues_engine_destroy(BluesEngine* h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    delete h;
+    return 0;
+}
+
+static int upload_xyz(BluesEngine* h, const double* xyz, DBuf<double>* dst) {
+    std::vector<double> tmp(h->n);
+    for (int k = 0; k < 3; k++) {
+        for (int i = 0; i < h->n; i++) tmp[i] = xyz[3 * i + k];
+        HIP_OK(h, hipMemcpy(dst[k].p, tmp.data(), sizeof(double) * h->n, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+static int download_xyz(BluesEngine* h, double* xyz, DBuf<double>* src) {
+    std::vector<double> tmp(h->n);
+    for (int k = 0; k < 3; k++) {
+        HIP_OK(h, hipMemcpy(tmp.data(), src[k].p, sizeof(double) * h->n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < h->n; i++) xyz[3 * i + k] = tmp[i];
+    }
+    return 0;
+}
+
+int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
+    if (n_atoms != h->n) E_FAIL(h, "expected %d atoms, got %d", h->n, n_atoms);
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    // work bookkeeping for instantaneous moves: remember U(x_old, lambda) before overwriting (integrators.py:205)
+    if (h->have_positions && h->h_first_step >= 1 && h->h_step > 0 && h->h_step < h->nsteps && !h->unpert_valid) {
+        double E;
+        if (total_energy(h, &E)) return 1;
+        h->h_unperturbed = E; h->unpert_valid = true;
+    }
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    bool frozen_moved = !h->have_positions;
+    if (h->have_positions) for (int i = 0; i < h->n && !frozen_moved; i++) if (h->mass[i] == 0.0 && h->alch_local[i] < 0)
+        for (int k = 0; k < 3; k++) if (h->hx[3 * i + k] != xyz[3 * i + k]) { frozen_moved = true; break; }
+    h->hx.assign(xyz, xyz + 3 * (size_t)h->n);
+    if (upload_xyz(h, xyz, h->d_x)) return 1;
+    h->have_positions = true; h->x_edited = true; h->pass_valid = false;
+    if (frozen_moved) h->e_frozen_valid = false;
+    // re-sort when never sorted or when atoms have drifted far from where the tiles were formed
+    bool resort = !h->sorted_ok;
+    if (!resort) {
+        double worst = 0.0;
+        for (int i = 0; i < h->n; i++) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; k++) { double d = h->hx[3 * i + k] - h->hx_sort[3 * i + k]; d -= h->box[k] * std::nearbyint(d / h->box[k]); d2 += d * d; }
+            worst = std::max(worst, d2);
+        }
+        resort = worst > 0.25 * 0.25;
+    }
+    if (resort) { h->sorted_ok = false; if (sort_and_tile(h)) return 1; }
+    else {
+        Box3 b = make_box(h);
+        if (h->precision == 0) hipLaunchKernelGGL(k_pack_positions<float>, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->n, h->d_x[0].p, h->d_x[1].p, h->d_x[2].p, h->d_sorted_of_orig.p, h->d_img_f.p, b);
+        else hipLaunchKernelGGL(k_pack_positions<double>, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->n, h->d_x[0].p, h->d_x[1].p, h->d_x[2].p, h->d_sorted_of_orig.p, h->d_img_d.p, b);
+        h->st_launches++;
+        h->lists_forced = true;
+    }
+    return 0;
+}
+
+int blues_set_velocities(BluesEngine* h, const double* xyz, int32_t n_atoms) {
+    if (n_atoms != h->n) E_FAIL(h, "expected %d atoms, got %d", h->n, n_atoms);
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return upload_xyz(h, xyz, h->d_v);
+}
+
+int blues_set_box(BluesEngine* h, const double box[9]) {
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) if (r != c && box[3 * r + c] != 0.0) E_FAIL(h, "only orthorhombic boxes are supported");
+    if (box[0] == h->box[0] && box[4] == h->box[1] && box[8] == h->box[2]) return 0;
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    h->box[0] = box[0]; h->box[1] = box[4]; h->box[2] = box[8];
+    for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) E_FAIL(h, "box edge %g < 2*(cutoff+skin)", h->box[k]);
+    h->sorted_ok = false; h->pass_valid = false; h->e_frozen_valid = false;
+    if (h->have_positions) { if (download_xyz(h, h->hx.data(), h->d_x)) return 1; return sort_and_tile(h); }
+    return 0;
+}
+
+int blues_get_positions(BluesEngine* h, double* xyz, int32_t n_atoms) {
+    if (n_atoms != h->n) E_FAIL(h, "expected %d atoms, got %d", h->n, n_atoms);
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return download_xyz(h, xyz, h->d_x);
+}
+int blues_get_velocities(BluesEngine* h, double* xyz, int32_t n_atoms) {
+    if (n_atoms != h->n) E_FAIL(h, "expected %d atoms, got %d", h->n, n_atoms);
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return download_xyz(h, xyz, h->d_v);
+}
+int blues_get_box(BluesEngine* h, double box[9]) {
+    for (int i = 0; i < 9; i++) box[i] = 0.0;
+    box[0] = h->box[0]; box[4] = h->box[1]; box[8] = h->box[2];
+    return 0;
+}
+
+int blues_get_forces(BluesEngine* h, double* out, int32_t n_atoms) {
+    if (n_atoms != h->n) E_FAIL(h, "expected %d atoms, got %d", h->n, n_atoms);
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    // forces at the current alchemical parameters: evaluate a pass whose slot 0 carries them
+    if (ensure_sorted(h)) return 1;
+    double ls[3] = {h->cur_ls, h->cur_ls, h->cur_ls}, le[3] = {h->cur_le, h->cur_le, h->cur_le};
+    int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced) : launch_lists<double>(h, h->lists_forced);
+    h->lists_forced = false;
+    if (rc) return 1;
+    h->pass_valid = false;
+    if (launch_alchemical(h, ls, le, 1)) return 1;
+    rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
+    if (rc) return 1;
+    if (h->n_rows > 0) { hipLaunchKernelGGL(k_bonded_forces, dim3((h->n_rows + 127) / 128), dim3(128), 0, h->stream, make_bonded_args(h)); h->st_launches++; }
+    IntArgs A = make_int_args(h);
+    DBuf<double> tmp;
+    try { tmp.alloc((size_t)3 * h->n); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    hipLaunchKernelGGL(k_gather_forces, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, A, 0, tmp.p);
+    h->st_launches++;
+    if (check_flags(h)) return 1;
+    HIP_OK(h, hipMemcpy(out, tmp.p, sizeof(double) * 3 * h->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int blues_set_velocities_to_temperature(BluesEngine* h, double temperature, uint64_t seed) {
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    hipLaunchKernelGGL(k_maxwell, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->n, h->d_mass.p, h->d_v[0].p, h->d_v[1].p, h->d_v[2].p, KB_KJ * temperature, (unsigned long long)seed, (unsigned)h->replica * 4u + 1u);
+    h->st_launches++;
+    if (emit(h, OP_RATTLE)) return 1;
+    if (flush_program(h)) return 1;
+    return check_flags(h);
+}
+
+int blues_get_energy(BluesEngine* h, double* potential, double* kinetic) {
+    HIP_OK(h, hipSetDevice(h->device));
+    if (potential) { if (total_energy(h, potential)) return 1; }
+    if (kinetic) {
+        if (flush_program(h)) return 1;
+        const int nb = (h->n + 255) / 256;
+        hipLaunchKernelGGL(k_kinetic, dim3(nb), dim3(256), 0, h->stream, h->n, h->d_mass.p, h->d_v[0].p, h->d_v[1].p, h->d_v[2].p, h->d_scratch.p);
+        h->st_launches++;
+        HIP_OK(h, hipStreamSynchronize(h->stream));
+        std::vector<double> part(nb);
+        HIP_OK(h, hipMemcpy(part.data(), h->d_scratch.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
+        double ke = 0.0; for (double p : part) ke += p;
+        *kinetic = ke;
+    }
+    return 0;
+}
+
+int blues_get_energy_terms(BluesEngine* h, double terms[BLUES_N_ENERGY_TERMS]) {
+    HIP_OK(h, hipSetDevice(h->device));
+    return energy_terms(h, terms);
+}
+
+int blues_step(BluesEngine* h, int32_t n_steps) {
+    HIP_OK(h, hipSetDevice(h->device));
+    h->tracing = false;
+    if (do_steps(h, n_steps)) return 1;
+    return check_flags(h);
+}
+
+int blues_run_switch(BluesEngine* h, int32_t n_steps, double* work_trace) {
+    HIP_OK(h, hipSetDevice(h->device));
+    const int first = h->h_step;
+    h->tracing = work_trace != nullptr;
+    int rc = do_steps(h, n_steps);
+    h->tracing = false;
+    if (rc) return 1;
+    if (check_flags(h)) return 1;
+    if (work_trace) {
+        const int done = h->h_step - first;
+        if (done > 0) HIP_OK(h, hipMemcpy(work_trace, h->d_trace.p + first, sizeof(double) * done, hipMemcpyDeviceToHost));
+        for (int i = std::max(done, 0); i < n_steps; i++) work_trace[i] = done > 0 ? work_trace[done - 1] : 0.0;
+    }
+    return 0;
+}
+
+static int read_acc(BluesEngine* h, DevAccum* a) {
+    if (flush_program(h)) return 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    HIP_OK(h, hipMemcpy(a, h->d_acc.p, sizeof *a, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int blues_get_global(BluesEngine* h, const char* name, double* value) {
+    HIP_OK(h, hipSetDevice(h->device));
+    std::string k(name);
+    DevAccum a;
+    if (k == "lambda") *value = h->h_lambda;
+    else if (k == "step") *value = h->h_step;
+    else if (k == "lambda_step") *value = h->h_lambda_step;
+    else if (k == "n_lambda_steps") *value = h->n_lambda;
+    else if (k == "nsteps") *value = h->nsteps;
+    else if (k == "protocol_work") { if (read_acc(h, &a)) return 1; *value = a.protocol_work; }
+    else if (k == "shadow_work") *value = 0.0;
+    else if (k == "perturbed_pe") *value = h->h_perturbed;
+    else if (k == "unperturbed_pe") *value = h->h_unperturbed;
+    else if (k == "first_step") *value = h->h_first_step;
+    else if (k == "nprop") *value = h->nprop;
+    else if (k == "prop") *value = h->h_prop;
+    else if (k == "prop_lambda_min") *value = h->prop_min;
+    else if (k == "prop_lambda_max") *value = h->prop_max;
+    else if (k == "Enew" || k == "Eold") {
+        double E; if (total_energy(h, &E)) return 1;
+        if (read_acc(h, &a)) return 1;
+        *value = (k == "Enew") ? E : E - a.dE_last;
+    }
+    else if (k == "heat") *value = 0.0;
+    else if (k == "kT") *value = h->kT;
+    else if (k == "lambda_sterics") *value = h->cur_ls;
+    else if (k == "lambda_electrostatics") *value = h->cur_le;
+    else E_FAIL(h, "unknown global variable '%s'", name);
+    return 0;
+}
+
+int blues_set_global(BluesEngine* h, const char* name, double value) {
+    HIP_OK(h, hipSetDevice(h->device));
+    std::string k(name);
+    if (k == "protocol_work") {
+        DevAccum a; if (read_acc(h, &a)) return 1;
+        a.protocol_work = value;
+        HIP_OK(h, hipMemcpy(h->d_acc.p, &a, sizeof a, hipMemcpyHostToDevice));
+    }
+    else if (k == "step") h->h_step = (int)value;
+    else if (k == "lambda") h->h_lambda = value;
+    else if (k == "lambda_step") { h->h_lambda_step = (int)value; h->pass_valid = false; }
+    else if (k == "first_step") h->h_first_step = (int)value;
+    else if (k == "prop") h->h_prop = (int)value;
+    else if (k == "nprop") h->nprop = (int)value;
+    else if (k == "perturbed_pe") h->h_perturbed = value;
+    else if (k == "unperturbed_pe") { h->h_unperturbed = value; }
+    else if (k == "shadow_work") { if (value != 0.0) E_FAIL(h, "shadow work is not measured (measure_shadow_work=False)"); }
+    else if (k == "lambda_sterics") { h->cur_ls = value; h->pass_valid = false; }
+    else if (k == "lambda_electrostatics") { h->cur_le = value; h->pass_valid = false; }
+    else E_FAIL(h, "global variable '%s' cannot be set", name);
+    return 0;
+}
+
+int blues_reset(BluesEngine* h) {
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    h->h_step = 0; h->h_lambda = 0.0; h->h_first_step = 0; h->h_perturbed = 0.0; h->h_unperturbed = 0.0; h->h_prop = 1; h->h_lambda_step = 0;
+    h->unpert_valid = false; h->x_edited = false; h->pass_valid = false;
+    HIP_OK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(DevAccum), h->stream));
+    return 0;
+}
+
+int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
+    for (int i = 0; i < BLUES_N_STATS; i++) stats[i] = 0;
+    stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->nchunk;
+    if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) stats[1] = f.list_gen; }
+    return 0;
+}
+
+int blues_time_nonbonded(BluesEngine* h, int32_t reps, double* usec) {
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    if (ensure_sorted(h)) return 1;
+    int rc = h->precision == 0 ? launch_lists<float>(h, 1) : launch_lists<double>(h, 1);
+    if (rc) return 1;
+    h->pass_valid = false;
+    for (int w = 0; w < 3; w++) { rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h); if (rc) return 1; }
+    HIP_OK(h, hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < reps; r++) { rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h); if (rc) return 1; }
+    HIP_OK(h, hipEventRecord(h->ev1, h->stream));
+    HIP_OK(h, hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_OK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *usec = 1000.0 * ms / std::max(1, reps);
+    return check_flags(h);
+}
+
+}  // extern "C"

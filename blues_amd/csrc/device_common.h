@@ -1,0 +1,154 @@
+// device_common.h -- shared device-side types and math for the gfx950 NCMC engine.
+//
+// Data layout in HBM:
+//   master state   x,v (fp64 SoA, caller's atom order)   -- integrator, bonded and alchemical kernels
+//   tile image     AtomF / AtomD (32 / 64 B AoS, Hilbert-sorted order) -- nonbonded kernel
+//     positions are FIXED-POINT fractions of the box edge (u32 or u64): the difference of
+//     two such integers is exact and already minimum-imaged by wrap-around, so the pair
+//     kernel needs no periodic-shift arithmetic and loses no precision to large coordinates.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ONE_4PI_EPS0 138.935456
+#define KB_KJ 0.0083144626
+#define TWO_OVER_SQRT_PI 1.1283791670955126
+#define WAVE 64
+#define FLAG_ALCH 1u
+#define FLAG_MOBILE 2u
+
+struct AtomF {  // 32 B
+    uint32_t x, y, z;
+    float q;   // charge * sqrt(ONE_4PI_EPS0)
+    float hs;  // sigma / 2            (sigma_ij = hs_i + hs_j)
+    float se;  // 2 * sqrt(epsilon)    (4 eps_ij = se_i * se_j)
+    uint32_t flags;
+    int32_t orig;
+};
+struct AtomD {  // 64 B
+    uint64_t x, y, z;
+    double q, hs, se;
+    uint32_t flags;
+    int32_t orig;
+    uint64_t pad;
+};
+
+template <typename R> struct Img;
+template <> struct Img<float> {
+    using Atom = AtomF; using ufix = uint32_t; using sfix = int32_t;
+};
+template <> struct Img<double> {
+    using Atom = AtomD; using ufix = uint64_t; using sfix = int64_t;
+};
+
+struct Box3 { double L[3]; double invL[3]; };
+
+// ---------------------------------------------------------------- Philox4x32-10 (same stream as oracle/blues_oracle.c)
+__host__ __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__host__ __device__ inline void gaussians3(uint64_t seed, uint32_t stream, uint32_t draw, uint32_t atom, double g[3]) {
+    uint32_t r[4];
+    philox4x32(atom, draw, stream, 0x424C5545u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const double S = 2.3283064365386963e-10;
+    double u1 = ((double)r[0] + 0.5) * S, u2 = ((double)r[1] + 0.5) * S;
+    double u3 = ((double)r[2] + 0.5) * S, u4 = ((double)r[3] + 0.5) * S;
+    double ra = sqrt(-2.0 * log(u1)), rb = sqrt(-2.0 * log(u3));
+    const double TWO_PI = 6.283185307179586476925286766559;
+    g[0] = ra * cos(TWO_PI * u2);
+    g[1] = ra * sin(TWO_PI * u2);
+    g[2] = rb * cos(TWO_PI * u4);
+}
+
+// ---------------------------------------------------------------- pair math
+// fp32 erfc: erfc(x) = exp(-x^2) * t * P(t), t = 1/(1+0.55x); |rel err| < 3.5e-7 on [0,4] in fp32.
+__device__ inline float erfc_scaled_f(float x) {  // returns erfc(x)*exp(x^2)
+    float t = __frcp_rn(1.0f + 0.55f * x);
+    float p = -7.091228587e-02f;
+    p = fmaf(p, t, 3.810680318e-01f);
+    p = fmaf(p, t, -7.630493514e-01f);
+    p = fmaf(p, t, 5.768974586e-01f);
+    p = fmaf(p, t, -5.936511826e-02f);
+    p = fmaf(p, t, 3.227979795e-01f);
+    p = fmaf(p, t, 3.017286883e-01f);
+    p = fmaf(p, t, 3.108345779e-01f);
+    return p * t;
+}
+
+// Regular (non-alchemical) pair: 12-6 LJ + erfc-screened Coulomb.  r2 < cutoff^2 is the caller's business.
+// q is pre-multiplied by sqrt(ONE_4PI_EPS0); sig = hs_i+hs_j; eps4 = se_i*se_j.
+// Returns fscale = -dU/dr / r ; *e_lj, *e_c energies.
+template <typename R> __device__ inline R pair_regular(R r2, R qq, R sig, R eps4, R alpha, R* e_lj, R* e_c);
+
+template <> __device__ inline float pair_regular<float>(float r2, float qq, float sig, float eps4, float alpha, float* e_lj, float* e_c) {
+    float inv_r = rsqrtf(r2);
+    float inv_r2 = inv_r * inv_r;
+    float s2 = sig * sig * inv_r2, s6 = s2 * s2 * s2;
+    *e_lj = eps4 * (s6 * s6 - s6);
+    float f = eps4 * (12.0f * s6 * s6 - 6.0f * s6) * inv_r2;
+    float r = r2 * inv_r, ar = alpha * r;
+    float ex = __expf(-ar * ar);
+    float ec = erfc_scaled_f(ar) * ex;
+    *e_c = qq * ec * inv_r;
+    f += qq * (ec * inv_r + (float)TWO_OVER_SQRT_PI * alpha * ex) * inv_r2;
+    return f;
+}
+
+template <> __device__ inline double pair_regular<double>(double r2, double qq, double sig, double eps4, double alpha, double* e_lj, double* e_c) {
+    double r = sqrt(r2), inv_r = 1.0 / r, inv_r2 = inv_r * inv_r;
+    double s2 = sig * sig * inv_r2, s6 = s2 * s2 * s2;
+    *e_lj = eps4 * (s6 * s6 - s6);
+    double f = eps4 * (12.0 * s6 * s6 - 6.0 * s6) * inv_r2;
+    double ar = alpha * r;
+    double ec = erfc(ar), ex = exp(-ar * ar);
+    *e_c = qq * ec * inv_r;
+    f += qq * (ec * inv_r + TWO_OVER_SQRT_PI * alpha * ex) * inv_r2;
+    return f;
+}
+
+// fp64 forms used by the alchemical kernel.
+// softcore LJ: U = ls*4 eps x (x-1), x = 1/(alpha(1-ls) + (r/sig)^6).  returns U, *fs = -dU/dr / r
+__device__ inline double softcore_lj_d(double r2, double sig, double eps, double ls, double sc_alpha, double* fs) {
+    if (eps == 0.0 || sig == 0.0) { *fs = 0.0; return 0.0; }
+    double s2 = sig * sig, q2 = r2 / s2, q6 = q2 * q2 * q2;
+    double x = 1.0 / (sc_alpha * (1.0 - ls) + q6);
+    *fs = ls * 4.0 * eps * (2.0 * x - 1.0) * x * x * 6.0 * q2 * q2 / s2;
+    return ls * 4.0 * eps * x * (x - 1.0);
+}
+// Coulomb per unit lambda_electrostatics; screened = erfc(alpha r)/r, else 1/r.
+__device__ inline double coulomb_d(double r2, double qq, double alpha, bool screened, double* fs) {
+    if (qq == 0.0) { *fs = 0.0; return 0.0; }
+    double r = sqrt(r2), pre = ONE_4PI_EPS0 * qq;
+    if (!screened) { *fs = pre / (r * r2); return pre / r; }
+    double ar = alpha * r, ec = erfc(ar);
+    *fs = pre * (ec / r + TWO_OVER_SQRT_PI * alpha * exp(-ar * ar)) / r2;
+    return pre * ec / r;
+}
+__device__ inline double plain_lj_d(double r2, double sig, double eps, double* fs) {
+    if (eps == 0.0) { *fs = 0.0; return 0.0; }
+    double sr2 = sig * sig / r2, sr6 = sr2 * sr2 * sr2;
+    *fs = 4.0 * eps * (12.0 * sr6 * sr6 - 6.0 * sr6) / r2;
+    return 4.0 * eps * (sr6 * sr6 - sr6);
+}
+
+__device__ inline double min_image_d(double d, double L, double invL) { return d - L * rint(d * invL); }
+
+// wave64 reductions
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ inline double seg_sum(double v, int width) {  // sum over aligned groups of `width` lanes (power of two)
+    for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}

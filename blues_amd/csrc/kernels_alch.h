@@ -1,0 +1,208 @@
+// kernels_alch.h -- the lambda-dependent pairs (K2), entirely in fp64.
+//
+// Replaces what openmmtools' AbsoluteAlchemicalFactory adds to the System
+// (reference blues/simulation.py:300-316; forms in SURVEY.md Appendix B) and the two
+// total-energy evaluations of every H step (reference blues/integrators.py:219-230):
+// instead of differencing two O(1e5 kJ/mol) totals, the protocol-work increment
+// Enew - Eold is formed directly from the few thousand pairs that depend on lambda.
+//
+// One pass at fixed positions serves up to three consecutive lambda indices (slots):
+//   electrostatics is linear in lambda_electrostatics, so the Coulomb sum C is computed once
+//   and E_elec(slot) = le[slot] * C;  softcore sterics S(slot) is recomputed per slot from the
+//   shared (r/sigma)^6.  Forces are produced for the slots in `slot_mask`.
+//
+// Thread layout: lane = (j-slot, a) with the alchemical atom index a fastest (PA = padded
+// power of two), so the force on environment atom j is a segmented shuffle reduction over
+// PA lanes and the force on alchemical atom a a strided one; block partials are written to
+// slabs and summed in fixed order by the integrator kernel (no atomics, reproducible).
+#pragma once
+#include "device_common.h"
+
+#define K2_NE 6  // energy partials per block: C_scaled, S0, S1, S2, const_lj, const_coul
+
+struct AlchArgs {
+    int n, n_alch, PA, jcap, nblocks_env;
+    const int* alch_orig;       // [n_alch]
+    const int* jlist;           // j-list of the alchemical tile (sorted indices)
+    const int* jcount;          // -> its count
+    const int* orig_of_sorted;
+    const int* sorted_of_orig;
+    const double* x[3];
+    const double* charge; const double* sigma; const double* eps;  // caller order
+    const int* ex_start; const int* ex_idx;                         // sorted index space
+    // alchemical exceptions as rows per alchemical atom: partner (caller index) and parameters
+    const int* exc_start;       // [n_alch+1]
+    const int* exc_partner;
+    const double* exc_params;   // [3*] chargeProd, sigma, epsilon
+    Box3 box;
+    double rc2, alpha, sc_alpha;
+    int pme, annih_elec, annih_ster, slot_mask;
+    double ls[3], le[3];
+    double* fJ;         // [3 slots][3][n] force on environment atoms by sorted index
+    double* self_part;  // [nblocks][3 slots][3][64]
+    double* e_part;     // [nblocks][K2_NE]
+};
+
+__device__ inline bool excluded_sorted(const int* ex_start, const int* ex_idx, int a_sorted, int j_sorted) {
+    bool ex = false;
+    for (int e = ex_start[a_sorted]; e < ex_start[a_sorted + 1]; e++) ex |= (ex_idx[e] == j_sorted);
+    return ex;
+}
+
+__global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int PA = A.PA;
+    const int a = tid & (PA - 1);
+    __shared__ double s_self[4][9][64];
+    __shared__ double s_e[4][K2_NE];
+    double f[3][3];  // [slot][xyz] force on the alchemical atom from this pair
+#pragma unroll
+    for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = 0.0; }
+    double e[K2_NE];
+#pragma unroll
+    for (int q = 0; q < K2_NE; q++) e[q] = 0.0;
+
+    const bool env_block = blockIdx.x < A.nblocks_env;
+    if (env_block) {
+        const int count = *A.jcount;
+        if ((blockIdx.x * 256) / PA >= count) return;  // nothing to do; the integrator sums only the used blocks
+        const int js = (blockIdx.x * 256 + tid) / PA;
+        const bool valid = js < count && a < A.n_alch;
+        int jsrt = -1;
+        if (valid) {
+            jsrt = A.jlist[js];
+            const int jo = A.orig_of_sorted[jsrt], ao = A.alch_orig[a];
+            double d[3];
+            for (int k = 0; k < 3; k++) d[k] = min_image_d(A.x[k][ao] - A.x[k][jo], A.box.L[k], A.box.invL[k]);
+            const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            if (r2 < A.rc2 && !excluded_sorted(A.ex_start, A.ex_idx, A.sorted_of_orig[ao], jsrt)) {
+                const double sig = 0.5 * (A.sigma[ao] + A.sigma[jo]), eps = sqrt(A.eps[ao] * A.eps[jo]);
+                const double qq = A.charge[ao] * A.charge[jo];
+                double fc;
+                const double ec = coulomb_d(r2, qq, A.alpha, A.pme != 0, &fc);
+                e[0] = ec;
+#pragma unroll
+                for (int s = 0; s < 3; s++) {
+                    double fs;
+                    e[1 + s] = softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
+                    const double ft = fs + A.le[s] * fc;
+                    f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                }
+            }
+        }
+        // force on environment atom j: minus the sum over the PA alchemical lanes
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            if (!((A.slot_mask >> s) & 1)) continue;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double fj = seg_sum(f[s][k], PA);
+                if (a == 0 && js < count) A.fJ[(size_t)(s * 3 + k) * A.n + A.jlist[js]] = -fj;
+            }
+        }
+    } else {
+        // ---- alchemical x alchemical pairs: thread (a2, b) with b fastest
+        const int rows_per_iter = 256 / PA;
+        for (int a0 = 0; a0 < A.n_alch; a0 += rows_per_iter) {
+            const int a2 = a0 + tid / PA, b = a;
+            double g[3][3];
+#pragma unroll
+            for (int s = 0; s < 3; s++) { g[s][0] = g[s][1] = g[s][2] = 0.0; }
+            if (a2 < A.n_alch && b < A.n_alch && a2 != b) {
+                const int ao = A.alch_orig[a2], bo = A.alch_orig[b];
+                if (!excluded_sorted(A.ex_start, A.ex_idx, A.sorted_of_orig[ao], A.sorted_of_orig[bo])) {
+                    double d[3];
+                    for (int k = 0; k < 3; k++) d[k] = min_image_d(A.x[k][ao] - A.x[k][bo], A.box.L[k], A.box.invL[k]);
+                    const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                    if (!A.pme || r2 < A.rc2) {
+                        const double sig = 0.5 * (A.sigma[ao] + A.sigma[bo]), eps = sqrt(A.eps[ao] * A.eps[bo]);
+                        double fc, fl = 0.0;
+                        const double ec = coulomb_d(r2, A.charge[ao] * A.charge[bo], A.alpha, A.pme != 0, &fc);
+                        if (A.annih_elec) e[0] += 0.5 * ec; else e[5] += 0.5 * ec;
+                        if (!A.annih_ster) e[4] += 0.5 * plain_lj_d(r2, sig, eps, &fl);
+#pragma unroll
+                        for (int s = 0; s < 3; s++) {
+                            double fs = fl;
+                            if (A.annih_ster) e[1 + s] += 0.5 * softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
+                            const double ft = fs + (A.annih_elec ? A.le[s] : 1.0) * fc;
+                            g[s][0] = ft * d[0]; g[s][1] = ft * d[1]; g[s][2] = ft * d[2];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 3; s++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double v = seg_sum(g[s][k], PA);
+                    // lane b==0 of row a2 owns the row sum; park it in the lane that maps to atom a2 in the final reduce
+                    if (b == 0 && a2 < A.n_alch) s_self[0][s * 3 + k][a2] = v;
+                }
+        }
+        __syncthreads();
+        // ---- exceptions that involve alchemical atoms: one thread per alchemical atom row
+        double h[3][3];
+#pragma unroll
+        for (int s = 0; s < 3; s++) { h[s][0] = h[s][1] = h[s][2] = 0.0; }
+        if (tid < A.n_alch) {
+            const int ao = A.alch_orig[tid];
+            for (int q = A.exc_start[tid]; q < A.exc_start[tid + 1]; q++) {
+                const int po = A.exc_partner[q];
+                const double qq = A.exc_params[3 * q], sig = A.exc_params[3 * q + 1], eps = A.exc_params[3 * q + 2];
+                double d[3];
+                for (int k = 0; k < 3; k++) d[k] = min_image_d(A.x[k][ao] - A.x[k][po], A.box.L[k], A.box.invL[k]);
+                const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                double fc, fl = 0.0;
+                const double ec = coulomb_d(r2, qq, 0.0, false, &fc);
+                if (A.annih_elec) e[0] += 0.5 * ec; else e[5] += 0.5 * ec;
+                if (!A.annih_ster) e[4] += 0.5 * plain_lj_d(r2, sig, eps, &fl);
+#pragma unroll
+                for (int s = 0; s < 3; s++) {
+                    double fs = fl;
+                    if (A.annih_ster) e[1 + s] += 0.5 * softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
+                    const double ft = fs + (A.annih_elec ? A.le[s] : 1.0) * fc;
+                    h[s][0] += ft * d[0]; h[s][1] += ft * d[1]; h[s][2] += ft * d[2];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 3; s++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) s_self[0][s * 3 + k][tid] += h[s][k];
+        }
+        __syncthreads();
+        if (tid < 64) {
+#pragma unroll
+            for (int q = 0; q < 9; q++)
+                A.self_part[((size_t)blockIdx.x * 9 + q) * 64 + tid] = (tid < A.n_alch) ? s_self[0][q][tid] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < K2_NE; q++) e[q] = wave_sum(e[q]);
+        if (lane == 0) for (int q = 0; q < K2_NE; q++) s_e[wv][q] = e[q];
+        __syncthreads();
+        if (tid < K2_NE) A.e_part[(size_t)blockIdx.x * K2_NE + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
+        return;
+    }
+
+    // ---- env blocks: force on alchemical atom a = sum over the j's of this block
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double v = f[s][k];
+            for (int off = PA; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (lane < PA) s_self[wv][s * 3 + k][lane] = v;
+        }
+#pragma unroll
+    for (int q = 0; q < K2_NE; q++) e[q] = wave_sum(e[q]);
+    if (lane == 0) for (int q = 0; q < K2_NE; q++) s_e[wv][q] = e[q];
+    __syncthreads();
+    if (tid < 64) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            double v = 0.0;
+            if (tid < PA) v = s_self[0][q][tid] + s_self[1][q][tid] + s_self[2][q][tid] + s_self[3][q][tid];
+            A.self_part[((size_t)blockIdx.x * 9 + q) * 64 + tid] = v;
+        }
+    }
+    if (tid < K2_NE) A.e_part[(size_t)blockIdx.x * K2_NE + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
+}

@@ -1,0 +1,385 @@
+// kernels_integrate.h -- the Langevin splitting substeps (K5), constraints (K6), COM-motion
+// removal (K8) and the protocol-work bookkeeping (K7), fp64, one thread per constraint cluster.
+//
+// The reference assembles ~40 CustomIntegrator sub-steps per NCMC step
+// (reference blues/integrators.py:159-231 on top of openmmtools' R/V/O steps); each becomes
+// at least one kernel launch plus host-evaluated conditions on OpenMM's GPU platforms.
+// Here the host (which mirrors the deterministic control state: step, lambda_step, prop)
+// hands the device a short PROGRAM of ops per launch and one launch covers everything
+// between two force passes, e.g. for "H V R O R V H":
+//       V(slot0) H(0->1) END | CM H(1->2) V(slot2) R O R
+//   = finish step k          | first half of step k+1
+// HBonds / rigid-water constraints couple at most 4 atoms (X-H1..3 stars, water triangles),
+// so SHAKE/RATTLE iterate inside one thread's registers: no cross-thread iteration.
+#pragma once
+#include "device_common.h"
+#include "kernels_alch.h"
+#include "kernels_nb.h"
+
+enum {
+    OP_V0 = 0, OP_V1, OP_V2,   // v += hV f/m with the alchemical force of slot 0/1/2, then RATTLE
+    OP_R,                      // x += hR v ; SHAKE ; v += (x - x1)/hR ; RATTLE
+    OP_O,                      // v = a v + b sqrt(kT/m) xi ; RATTLE
+    OP_H01, OP_H12,            // protocol_work += E(slot+1) - E(slot)
+    OP_END,                    // end of an NCMC step: record the work trace
+    OP_PREP,                   // first-step block: constrain positions and velocities
+    OP_CM_BLOCK,               // CMMotionRemover, whole system inside this (single) block
+    OP_CM_REDUCE,              // write this block's momentum partial (last op of a launch)
+    OP_CM_APPLY,               // subtract total momentum / total mass (first op of the next launch)
+    OP_RATTLE,                 // velocity constraints only (setVelocitiesToTemperature)
+};
+
+#define MAX_OPS 24
+struct Program { int n; unsigned char ops[MAX_OPS]; };
+
+struct DevAccum {
+    double protocol_work, dE_last, e_slot[3], heat;
+};
+
+struct IntArgs {
+    int n, n_clusters;
+    const int* cl_atoms;    // [ncl*4] caller index or -1
+    const int* cl_type;     // 0 single, 1 star (atom 0 = centre), 2 triangle
+    const int* cl_nc;       // constraints in the cluster
+    const double* cl_dist;  // [ncl*3]
+    double* x[3]; double* v[3];
+    const double* mass;
+    // force sources
+    const double* fpart; int nchunk, n_islots; const int* islot_of_orig;
+    const double* fbond;
+    const double* fJ; const int* sorted_of_orig;
+    const double* self_part; const double* e_part; const int* jcount_alch; int k2_nblocks_env, PA, n_alch;
+    const int* alch_local_of_orig;
+    double le[3];
+    // constants
+    double hV, hR, aO, bO, kT, tol;
+    unsigned long long seed; unsigned stream, draw_base;
+    Box3 box; int periodic;
+    // tile image refresh + list validity
+    AtomF* img_f; AtomD* img_d;
+    const double* xbuild[3]; double half_skin2;
+    DevFlags* flags; int* pool_count;
+    // COM removal
+    double total_mass; double* cm_part; int cm_nblocks;
+    DevAccum* acc; double* work_trace; int trace_index;
+    Program prog;
+};
+
+__device__ inline void cl_pair(int type, int c, int& i, int& j) {
+    if (type == 1) { i = 0; j = c + 1; }
+    else { i = (c == 2) ? 1 : 0; j = (c == 0) ? 1 : 2; }
+}
+
+struct Cluster {
+    double x[4][3], v[4][3], w[4];  // w = 1/m
+    int id[4];
+    int na, nc, type;
+    double d2[3];
+};
+
+#define FOR_CONS(c, CL, i, j, ...)                                                   \
+    _Pragma("unroll") for (int c = 0; c < 3; c++) {                                  \
+        if (c < CL.nc) {                                                             \
+            if (CL.type == 1) { const int i = 0, j = c + 1; __VA_ARGS__ }            \
+            else { const int i = (c == 2) ? 1 : 0, j = (c == 0) ? 1 : 2; __VA_ARGS__ } \
+        }                                                                            \
+    }
+
+__device__ inline void rattle(Cluster& C, double tol, const IntArgs& A) {
+    if (C.nc == 0) return;
+    for (int it = 0; it < 500; it++) {
+        bool done = true;
+        FOR_CONS(c, C, i, j, {
+            double r[3], rv[3];
+            for (int k = 0; k < 3; k++) {
+                r[k] = C.x[i][k] - C.x[j][k];
+                if (A.periodic) r[k] = min_image_d(r[k], A.box.L[k], A.box.invL[k]);
+                rv[k] = C.v[i][k] - C.v[j][k];
+            }
+            const double delta = -(rv[0] * r[0] + rv[1] * r[1] + rv[2] * r[2]) / ((r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * (C.w[i] + C.w[j]));
+            if (fabs(delta) > tol) {
+                done = false;
+                for (int k = 0; k < 3; k++) { C.v[i][k] += C.w[i] * delta * r[k]; C.v[j][k] -= C.w[j] * delta * r[k]; }
+            }
+        })
+        if (done) break;
+    }
+}
+
+// positions C.x are the unconstrained ones; xr the reference (last constrained) geometry
+__device__ inline bool shake(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
+    if (C.nc == 0) return true;
+    int it;
+    for (it = 0; it < 500; it++) {
+        bool done = true;
+        FOR_CONS(c, C, i, j, {
+            double rp[3];
+            for (int k = 0; k < 3; k++) {
+                rp[k] = C.x[i][k] - C.x[j][k];
+                if (A.periodic) rp[k] = min_image_d(rp[k], A.box.L[k], A.box.invL[k]);
+            }
+            const double diff = C.d2[c] - (rp[0] * rp[0] + rp[1] * rp[1] + rp[2] * rp[2]);
+            if (fabs(diff) > 2.0 * tol * C.d2[c]) {
+                done = false;
+                double r[3];
+                for (int k = 0; k < 3; k++) {
+                    r[k] = xr[i][k] - xr[j][k];
+                    if (A.periodic) r[k] = min_image_d(r[k], A.box.L[k], A.box.invL[k]);
+                }
+                const double delta = diff / (2.0 * (rp[0] * r[0] + rp[1] * r[1] + rp[2] * r[2]) * (C.w[i] + C.w[j]));
+                for (int k = 0; k < 3; k++) { C.x[i][k] += C.w[i] * delta * r[k]; C.x[j][k] -= C.w[j] * delta * r[k]; }
+            }
+        })
+        if (done) break;
+    }
+    return it < 500;
+}
+
+__device__ inline void load_force(const IntArgs& A, const Cluster& C, int slot, const double (*s_alch)[64], double F[4][3]) {
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        F[a][0] = F[a][1] = F[a][2] = 0.0;
+        if (a < C.na) {
+            const int i = C.id[a];
+            const int isl = A.islot_of_orig[i];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                double f = A.fbond[(size_t)k * A.n + i];
+                if (isl >= 0) for (int ch = 0; ch < A.nchunk; ch++) f += A.fpart[((size_t)ch * 3 + k) * A.n_islots + isl];
+                if (A.n_alch > 0) {
+                    const int al = A.alch_local_of_orig[i];
+                    if (al >= 0) f += s_alch[slot * 3 + k][al];
+                    else f += A.fJ[(size_t)(slot * 3 + k) * A.n + A.sorted_of_orig[i]];
+                }
+                F[a][k] = f;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
+    const int tid = threadIdx.x;
+    const int cl = blockIdx.x * blockDim.x + tid;
+    __shared__ double s_alch[9][64];
+    __shared__ double s_red[4][4];
+    __shared__ double s_cm[3];
+    __shared__ double s_e[K2_NE];
+
+    // ---- block 0 gathers the alchemical kernel's block partials (forces on alchemical atoms, energies)
+    if (blockIdx.x == 0 && A.n_alch > 0) {
+        const int cnt = *A.jcount_alch;
+        const int nb_env = (cnt * A.PA + 255) / 256;
+        for (int t = tid; t < 9 * 64; t += blockDim.x) {
+            const int q = t >> 6, a = t & 63;
+            double s = 0.0;
+            if (a < A.n_alch) {
+                for (int b = 0; b < nb_env; b++) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
+                s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
+            }
+            s_alch[q][a] = s;
+        }
+        if (tid < K2_NE) {
+            double s = 0.0;
+            for (int b = 0; b < nb_env; b++) s += A.e_part[(size_t)b * K2_NE + tid];
+            s += A.e_part[(size_t)A.k2_nblocks_env * K2_NE + tid];
+            s_e[tid] = s;
+        }
+        __syncthreads();
+        if (tid == 0) for (int s = 0; s < 3; s++) A.acc->e_slot[s] = A.le[s] * s_e[0] + s_e[1 + s];
+    }
+
+    Cluster C;
+    C.na = 0; C.nc = 0; C.type = 0;
+    const bool active = cl < A.n_clusters;
+    if (active) {
+        C.type = A.cl_type[cl]; C.nc = A.cl_nc[cl];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            C.id[a] = A.cl_atoms[cl * 4 + a];
+            if (C.id[a] >= 0) {
+                C.na = a + 1;
+                for (int k = 0; k < 3; k++) { C.x[a][k] = A.x[k][C.id[a]]; C.v[a][k] = A.v[k][C.id[a]]; }
+                C.w[a] = 1.0 / A.mass[C.id[a]];
+            } else {
+                for (int k = 0; k < 3; k++) { C.x[a][k] = 0.0; C.v[a][k] = 0.0; }
+                C.w[a] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const double d = A.cl_dist[cl * 3 + c]; C.d2[c] = d * d; }
+    }
+    bool moved = false, ok = true;
+    unsigned draw = A.draw_base;
+
+    for (int op_i = 0; op_i < A.prog.n; op_i++) {
+        const int op = A.prog.ops[op_i];
+        switch (op) {
+        case OP_V0: case OP_V1: case OP_V2: {
+            if (active) {
+                double F[4][3];
+                load_force(A, C, op - OP_V0, s_alch, F);
+#pragma unroll
+                for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * F[a][k] * C.w[a];
+                rattle(C, A.tol, A);
+            }
+        } break;
+        case OP_R: {
+            if (active) {
+                double xr[4][3], x1[4][3];
+#pragma unroll
+                for (int a = 0; a < 4; a++) for (int k = 0; k < 3; k++) {
+                    xr[a][k] = C.x[a][k];
+                    if (a < C.na) C.x[a][k] += A.hR * C.v[a][k];
+                    x1[a][k] = C.x[a][k];
+                }
+                ok &= shake(C, xr, A.tol, A);
+#pragma unroll
+                for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += (C.x[a][k] - x1[a][k]) / A.hR;
+                rattle(C, A.tol, A);
+                moved = true;
+            }
+        } break;
+        case OP_O: {
+            if (active) {
+#pragma unroll
+                for (int a = 0; a < 4; a++) if (a < C.na) {
+                    double g[3];
+                    gaussians3(A.seed, A.stream, draw, (unsigned)C.id[a], g);
+                    const double s = sqrt(A.kT * C.w[a]);
+                    for (int k = 0; k < 3; k++) C.v[a][k] = A.aO * C.v[a][k] + A.bO * s * g[k];
+                }
+                rattle(C, A.tol, A);
+            }
+            draw++;
+        } break;
+        case OP_H01: case OP_H12: {
+            if (blockIdx.x == 0 && tid == 0) {
+                const int s = op - OP_H01;
+                const double dE = A.acc->e_slot[s + 1] - A.acc->e_slot[s];
+                A.acc->protocol_work += dE; A.acc->dE_last = dE;
+            }
+        } break;
+        case OP_END: {
+            if (blockIdx.x == 0 && tid == 0 && A.work_trace) A.work_trace[A.trace_index] = A.acc->protocol_work;
+        } break;
+        case OP_RATTLE: {
+            if (active) rattle(C, A.tol, A);
+        } break;
+        case OP_PREP: {
+            if (active) {
+                double xr[4][3];
+#pragma unroll
+                for (int a = 0; a < 4; a++) for (int k = 0; k < 3; k++) xr[a][k] = C.x[a][k];
+                ok &= shake(C, xr, A.tol, A);
+                rattle(C, A.tol, A);
+                moved = true;
+            }
+        } break;
+        case OP_CM_BLOCK: case OP_CM_REDUCE: {
+            double p[3] = {0.0, 0.0, 0.0};
+            if (active) {
+_Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) p[k] += C.v[a][k] / C.w[a];
+            }
+            for (int k = 0; k < 3; k++) { p[k] = wave_sum(p[k]); if ((tid & 63) == 0) s_red[tid >> 6][k] = p[k]; }
+            __syncthreads();
+            if (tid < 3) {
+                double s = 0.0;
+                for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += s_red[w][tid];
+                if (op == OP_CM_BLOCK) s_cm[tid] = s / A.total_mass; else A.cm_part[blockIdx.x * 3 + tid] = s;
+            }
+            __syncthreads();
+            if (op == OP_CM_BLOCK && active) {
+_Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] -= s_cm[k];
+            }
+        } break;
+        case OP_CM_APPLY: {
+            if (tid < 3) {
+                double s = 0.0;
+                for (int b = 0; b < A.cm_nblocks; b++) s += A.cm_part[b * 3 + tid];
+                s_cm[tid] = s / A.total_mass;
+            }
+            __syncthreads();
+            if (active) {
+_Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] -= s_cm[k];
+            }
+        } break;
+        }
+    }
+
+    if (!active) return;
+    // ---- write back, refresh the fixed-point image, check list validity
+    bool need_rebuild = false, bad = false;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        if (a < C.na) {
+            const int i = C.id[a];
+            for (int k = 0; k < 3; k++) { A.v[k][i] = C.v[a][k]; bad |= !(C.x[a][k] == C.x[a][k]) || !(C.v[a][k] == C.v[a][k]); }
+            if (moved) {
+                double d2 = 0.0;
+                for (int k = 0; k < 3; k++) { A.x[k][i] = C.x[a][k]; const double d = C.x[a][k] - A.xbuild[k][i]; d2 += d * d; }
+                need_rebuild |= d2 > A.half_skin2;
+                unsigned long long u[3];
+                to_fixed(C.x[a], A.box, u);
+                const int s = A.sorted_of_orig[i];
+                if (A.img_f) { A.img_f[s].x = (unsigned)((u[0] + 0x80000000ull) >> 32); A.img_f[s].y = (unsigned)((u[1] + 0x80000000ull) >> 32); A.img_f[s].z = (unsigned)((u[2] + 0x80000000ull) >> 32); }
+                else { A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
+            }
+        }
+    }
+    if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; *A.pool_count = 0; }
+    if (bad) A.flags->nan_flag = 1;
+    if (!ok) A.flags->constraint_fail = 1;
+}
+
+// kinetic energy: per-block partials of sum 0.5 m v^2 over mobile atoms
+__global__ void __launch_bounds__(256) k_kinetic(int n, const double* __restrict__ mass, const double* vx, const double* vy, const double* vz, double* part) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double ke = 0.0;
+    if (i < n && mass[i] != 0.0) ke = 0.5 * mass[i] * (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]);
+    __shared__ double s[4];
+    ke = wave_sum(ke);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = ke;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// setVelocitiesToTemperature: v = sqrt(kT/m) N(0,1) for mobile atoms, 0 for frozen ones
+__global__ void k_maxwell(int n, const double* __restrict__ mass, double* vx, double* vy, double* vz, double kT, unsigned long long seed, unsigned stream) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double g[3] = {0.0, 0.0, 0.0};
+    if (mass[i] != 0.0) { gaussians3(seed, stream, 0u, (unsigned)i, g); const double s = sqrt(kT / mass[i]); g[0] *= s; g[1] *= s; g[2] *= s; }
+    vx[i] = g[0]; vy[i] = g[1]; vz[i] = g[2];
+}
+
+// total forces in caller order for getState(getForces=True): env partials + bonded + alchemical (slot)
+__global__ void k_gather_forces(IntArgs A, int slot, double* out /*[n][3]*/) {
+    __shared__ double s_alch[9][64];
+    if (A.n_alch > 0) {
+        const int cnt = *A.jcount_alch;
+        const int nb_env = (cnt * A.PA + 255) / 256;
+        for (int t = threadIdx.x; t < 9 * 64; t += blockDim.x) {
+            const int q = t >> 6, a = t & 63;
+            double s = 0.0;
+            if (a < A.n_alch) {
+                for (int b = 0; b < nb_env; b++) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
+                s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
+            }
+            s_alch[q][a] = s;
+        }
+        __syncthreads();
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const int isl = A.islot_of_orig[i];
+    for (int k = 0; k < 3; k++) {
+        double f = A.fbond[(size_t)k * A.n + i];
+        if (isl >= 0) for (int ch = 0; ch < A.nchunk; ch++) f += A.fpart[((size_t)ch * 3 + k) * A.n_islots + isl];
+        if (A.n_alch > 0) {
+            const int al = A.alch_local_of_orig[i];
+            if (al >= 0) f += s_alch[slot * 3 + k][al];
+            else f += A.fJ[(size_t)(slot * 3 + k) * A.n + A.sorted_of_orig[i]];
+        }
+        out[3 * i + k] = A.mass[i] != 0.0 ? f : 0.0;
+    }
+}

@@ -1,0 +1,305 @@
+// kernels_nb.h -- neighbour-tile list build and the direct-space nonbonded kernel (K1).
+//
+// K1 replaces, for the environment (non-alchemical) atoms, what OpenMM's NonbondedForce
+// computes when the CustomIntegrator program of reference blues/integrators.py:159-231
+// asks for `f` / `energy`: 12-6 LJ + erfc(alpha r)/r Coulomb inside the cutoff with
+// exclusions (openmmtools keeps that force for env x env with the alchemical atoms'
+// charge and epsilon zeroed -- SURVEY.md Appendix B).
+//
+// Work decomposition: an i-tile is 64 mobile atoms (one per lane of a wave64); its j-list
+// holds every atom within cutoff+skin of the tile's bounding box.  A work item is
+// (i-tile, chunk): the wave stages 64 j-atoms at a time into its private LDS slab and every
+// lane walks them (broadcast LDS reads), accumulating the force on its own i-atom in fp64.
+// No Newton's-third-law scatter, no atomics: chunk partials go to a slab that the
+// integrator kernel sums in a fixed order, so results are bitwise reproducible.
+#pragma once
+#include "device_common.h"
+
+struct DevFlags {  // device-resident control words
+    unsigned list_gen, req_gen;  // neighbour lists are current iff equal
+    int list_overflow;           // j-list or mask-pool capacity exceeded
+    int constraint_fail;
+    int nan_flag;
+    int pad[3];
+};
+
+template <typename R> struct NbConst {
+    R scale[3];   // box edge / 2^32 (or 2^64)
+    R rc2;        // cutoff^2
+    R alpha;      // Ewald alpha
+    double rlist2;  // (cutoff+skin)^2
+    double dscale[3];
+};
+
+struct ListArgs {
+    int n, n_tiles, n_itiles, jcap, pool_cap;
+    const int* tile_atoms;   // [n_tiles*64] sorted atom index or -1
+    int* jlist;              // [n_tiles*jcap]
+    int* jcount;             // [n_tiles]
+    int* batch_slot;         // [n_tiles*(jcap/64)]
+    unsigned long long* mask_pool;  // [pool_cap*64]
+    int* pool_count;
+    const int* ex_start;     // [n+1] exclusion CSR in sorted index space (self included)
+    const int* ex_idx;
+    DevFlags* flags;
+    // bookkeeping done by the same launch when a rebuild happens
+    const double* x[3];      // master positions (caller order)
+    double* xbuild[3];
+    double* fJ;              // [9*n] alchemical forces on environment atoms, zeroed on rebuild
+    int n_fJ;
+};
+
+template <typename R>
+__global__ void __launch_bounds__(256) k_build_lists(ListArgs a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, int force) {
+    using sfix = typename Img<R>::sfix;
+    using ufix = typename Img<R>::ufix;
+    if (!force && a.flags->list_gen == a.flags->req_gen) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t = blockIdx.x;
+    // ---- shared bookkeeping: remember where the lists were built, clear alchemical env forces
+    for (int i = blockIdx.x * 256 + tid; i < a.n; i += gridDim.x * 256) {
+        a.xbuild[0][i] = a.x[0][i]; a.xbuild[1][i] = a.x[1][i]; a.xbuild[2][i] = a.x[2][i];
+    }
+    for (int i = blockIdx.x * 256 + tid; i < a.n_fJ; i += gridDim.x * 256) a.fJ[i] = 0.0;
+    if (t >= a.n_tiles) return;
+
+    __shared__ ufix s_cfix[3];
+    __shared__ double s_half[3];
+    __shared__ int s_wcount[4];
+    __shared__ int s_total;
+    __shared__ int s_need[256];
+    const bool alch_tile = (t >= a.n_itiles);
+
+    // ---- bounding box of the tile in fixed point relative to its first atom
+    if (wv == 0) {
+        int ia = a.tile_atoms[t * 64 + lane];
+        int i0 = a.tile_atoms[t * 64];
+        ufix ref[3] = {img[i0].x, img[i0].y, img[i0].z};
+        ufix p[3] = {ref[0], ref[1], ref[2]};
+        if (ia >= 0) { p[0] = img[ia].x; p[1] = img[ia].y; p[2] = img[ia].z; }
+        for (int k = 0; k < 3; k++) {
+            double off = (double)(sfix)(p[k] - ref[k]) * c.dscale[k];
+            double lo = off, hi = off;
+            for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+            if (lane == 0) {
+                double mid = 0.5 * (lo + hi);
+                s_cfix[k] = ref[k] + (ufix)(sfix)llrint(mid / c.dscale[k]);
+                s_half[k] = 0.5 * (hi - lo) + 2.0 * c.dscale[k];
+            }
+        }
+        if (lane == 0) s_total = 0;
+    }
+    __syncthreads();
+    const ufix cf[3] = {s_cfix[0], s_cfix[1], s_cfix[2]};
+    const double hf[3] = {s_half[0], s_half[1], s_half[2]};
+
+    // ---- ordered stream compaction of every atom within cutoff+skin of the box
+    int* jl = a.jlist + (size_t)t * a.jcap;
+    for (int base = 0; base < a.n; base += 256) {
+        int j = base + tid;
+        bool pass = false;
+        if (j < a.n) {
+            const typename Img<R>::Atom aj = img[j];
+            double d2 = 0.0;
+            ufix pj[3] = {aj.x, aj.y, aj.z};
+            for (int k = 0; k < 3; k++) {
+                double d = fabs((double)(sfix)(pj[k] - cf[k]) * c.dscale[k]) - hf[k];
+                d = d > 0.0 ? d : 0.0;
+                d2 += d * d;
+            }
+            pass = d2 < c.rlist2 && !(aj.flags & FLAG_ALCH);
+        }
+        unsigned long long b = __ballot(pass);
+        if (lane == 0) s_wcount[wv] = __popcll(b);
+        __syncthreads();
+        int off = s_total;
+        for (int w = 0; w < wv; w++) off += s_wcount[w];
+        if (pass) {
+            int pos = off + __popcll(b & ((1ull << lane) - 1ull));
+            if (pos < a.jcap) jl[pos] = j;
+        }
+        __syncthreads();
+        if (tid == 0) s_total += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+        __syncthreads();
+    }
+    int count = s_total;
+    if (count > a.jcap) { if (tid == 0) a.flags->list_overflow = 1; count = a.jcap; }
+    if (tid == 0) a.jcount[t] = count;
+    const int nb = (count + 63) >> 6;
+    const int nbmax = a.jcap >> 6;
+    for (int b = tid; b < nbmax; b += 256) { s_need[b] = 0; a.batch_slot[t * nbmax + b] = -1; }
+    __syncthreads();
+    if (alch_tile) return;  // the alchemical kernel checks exclusions itself
+
+    // ---- exclusion bitmasks: one 64x64 bit tile per (i-tile, j-batch) that holds an excluded pair
+    const int ia = a.tile_atoms[t * 64 + lane];
+    int e0 = 0, e1 = 0;
+    if (ia >= 0) { e0 = a.ex_start[ia]; e1 = a.ex_start[ia + 1]; }
+    for (int pass = 0; pass < 2; pass++) {
+        for (int e = e0 + wv; e < e1; e += 4) {
+            int p = a.ex_idx[e];
+            int lo = 0, hi = count;  // binary search p in jl[0..count)
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (jl[mid] < p) lo = mid + 1; else hi = mid; }
+            if (lo < count && jl[lo] == p) {
+                if (pass == 0) s_need[lo >> 6] = 1;
+                else atomicOr(&a.mask_pool[(size_t)s_need[lo >> 6] * 64 + lane], 1ull << (lo & 63));
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            for (int b = tid; b < nb; b += 256) {
+                if (s_need[b]) {
+                    int slot = atomicAdd(a.pool_count, 1);
+                    if (slot >= a.pool_cap) { a.flags->list_overflow = 1; slot = 0; }
+                    s_need[b] = slot; a.batch_slot[t * nbmax + b] = slot;
+                } else s_need[b] = -1;
+            }
+            __syncthreads();
+            for (int b = 0; b < nb; b++) {
+                int slot = s_need[b];
+                if (slot >= 0 && tid < 64) a.mask_pool[(size_t)slot * 64 + tid] = 0ull;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+}
+
+template <typename R> struct NbArgs {
+    int n_itiles, nchunk, jcap, n_islots;
+    const int* tile_atoms;
+    const int* jlist;
+    const int* jcount;
+    const int* batch_slot;
+    const unsigned long long* mask_pool;
+    double* fpart;   // [nchunk][3][n_islots]
+    double* epart;   // [n_itiles*nchunk][2] (ENERGY only)
+    DevFlags* flags;
+};
+
+template <typename R, bool ENERGY>
+__global__ void __launch_bounds__(256) k_nonbonded(NbArgs<R> a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img) {
+    using Atom = typename Img<R>::Atom;
+    using sfix = typename Img<R>::sfix;
+    __shared__ Atom lds[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int w = blockIdx.x * 4 + wv;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.flags->list_gen = a.flags->req_gen;  // lists are current for this pass
+    const int t = w / a.nchunk, ch = w - t * a.nchunk;
+    if (t >= a.n_itiles) return;  // wave-uniform
+
+    const int ia = a.tile_atoms[t * 64 + lane];
+    Atom ai;
+    if (ia >= 0) ai = img[ia]; else { ai = img[a.tile_atoms[t * 64]]; }
+    const bool valid = ia >= 0;
+    const int count = a.jcount[t];
+    const int nb = (count + 63) >> 6;
+    const int nbmax = a.jcap >> 6;
+    const int* jl = a.jlist + (size_t)t * a.jcap;
+    double fx = 0.0, fy = 0.0, fz = 0.0, elj = 0.0, ecl = 0.0;
+    Atom* my = lds[wv];
+
+    for (int b = ch; b < nb; b += a.nchunk) {
+        const int p = b * 64 + lane;
+        const int nvalid = min(64, count - b * 64);
+        if (lane < nvalid) my[lane] = img[jl[p]];
+        const int slot = a.batch_slot[t * nbmax + b];
+        unsigned long long m = 0ull;
+        if (slot >= 0) m = a.mask_pool[(size_t)slot * 64 + lane];
+        if (!valid) m = ~0ull;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS stores have landed (waves are independent)
+        for (int k = 0; k < nvalid; k++) {
+            const Atom bj = my[k];
+            R dx = (R)(sfix)(ai.x - bj.x) * c.scale[0];
+            R dy = (R)(sfix)(ai.y - bj.y) * c.scale[1];
+            R dz = (R)(sfix)(ai.z - bj.z) * c.scale[2];
+            R r2 = dx * dx + dy * dy + dz * dz;
+            bool in = (r2 < c.rc2) && !((m >> k) & 1ull);
+            if (in) {
+                R e1, e2;
+                R fs = pair_regular<R>(r2, ai.q * bj.q, ai.hs + bj.hs, ai.se * bj.se, c.alpha, &e1, &e2);
+                fx += (double)(fs * dx); fy += (double)(fs * dy); fz += (double)(fs * dz);
+                if (ENERGY) {
+                    double wgt = (bj.flags & FLAG_MOBILE) ? 0.5 : 1.0;
+                    elj += wgt * (double)e1; ecl += wgt * (double)e2;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads done before the slab is overwritten
+    }
+    const int slot_i = t * 64 + lane;
+    double* fp = a.fpart + (size_t)ch * 3 * a.n_islots;
+    fp[slot_i] = fx; fp[a.n_islots + slot_i] = fy; fp[2 * a.n_islots + slot_i] = fz;
+    if (ENERGY) {
+        elj = wave_sum(elj); ecl = wave_sum(ecl);
+        if (lane == 0) { a.epart[2 * w] = elj; a.epart[2 * w + 1] = ecl; }
+    }
+}
+
+// One-off: LJ + Coulomb energy among FROZEN environment atoms (constant while they and the box
+// stay put).  Brute force over the sorted image; partial sums per block.
+template <typename R>
+__global__ void __launch_bounds__(256) k_energy_frozen(int n, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img,
+                                                       const int* __restrict__ ex_start, const int* __restrict__ ex_idx, double* epart) {
+    using sfix = typename Img<R>::sfix;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double elj = 0.0, ecl = 0.0;
+    if (i < n) {
+        const typename Img<R>::Atom ai = img[i];
+        if (!(ai.flags & (FLAG_ALCH | FLAG_MOBILE))) {
+            const int e0 = ex_start[i], e1 = ex_start[i + 1];
+            for (int j = i + 1; j < n; j++) {
+                const typename Img<R>::Atom bj = img[j];
+                if (bj.flags & (FLAG_ALCH | FLAG_MOBILE)) continue;
+                R dx = (R)(sfix)(ai.x - bj.x) * c.scale[0];
+                R dy = (R)(sfix)(ai.y - bj.y) * c.scale[1];
+                R dz = (R)(sfix)(ai.z - bj.z) * c.scale[2];
+                R r2 = dx * dx + dy * dy + dz * dz;
+                if (r2 < c.rc2) {
+                    bool ex = false;
+                    for (int e = e0; e < e1; e++) ex |= (ex_idx[e] == j);
+                    if (!ex) {
+                        R a1, a2;
+                        pair_regular<R>(r2, ai.q * bj.q, ai.hs + bj.hs, ai.se * bj.se, c.alpha, &a1, &a2);
+                        elj += (double)a1; ecl += (double)a2;
+                    }
+                }
+            }
+        }
+    }
+    __shared__ double s[2][4];
+    elj = wave_sum(elj); ecl = wave_sum(ecl);
+    if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = elj; s[1][threadIdx.x >> 6] = ecl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        epart[2 * blockIdx.x] = s[0][0] + s[0][1] + s[0][2] + s[0][3];
+        epart[2 * blockIdx.x + 1] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+    }
+}
+
+// Refresh the fixed-point tile image from the fp64 master positions (all atoms).
+template <typename R>
+__global__ void k_pack_positions(int n, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                                 const int* __restrict__ sorted_of_orig, typename Img<R>::Atom* img, Box3 box) {
+    using ufix = typename Img<R>::ufix;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double p[3] = {x[i], y[i], z[i]};
+    ufix f[3];
+    for (int k = 0; k < 3; k++) {
+        double fr = p[k] * box.invL[k]; fr -= floor(fr);
+        if (fr >= 1.0) fr = 0.0;
+        unsigned long long u = (unsigned long long)(fr * 18446744073709551616.0);
+        if (sizeof(ufix) == 4) f[k] = (ufix)((u + 0x80000000ull) >> 32); else f[k] = (ufix)u;
+    }
+    const int s = sorted_of_orig[i];
+    img[s].x = f[0]; img[s].y = f[1]; img[s].z = f[2];
+}
+
+__device__ inline void to_fixed(const double p[3], const Box3& box, unsigned long long u[3]) {
+    for (int k = 0; k < 3; k++) {
+        double fr = p[k] * box.invL[k]; fr -= floor(fr);
+        if (fr >= 1.0) fr = 0.0;
+        u[k] = (unsigned long long)(fr * 18446744073709551616.0);
+    }
+}

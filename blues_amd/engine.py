@@ -1,0 +1,111 @@
+"""Thin ctypes wrapper over the C-ABI of include/blues_engine.h (one handle per replica)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import load
+
+_dp = C.POINTER(C.c_double)
+
+
+class EngineError(RuntimeError):
+    """Raised for any nonzero return of the C-ABI; carries blues_last_error()."""
+
+
+class NativeEngine:
+    def __init__(self, system: _abi.SystemData, integrator: _abi.IntegratorData, device=0):
+        self._lib = load()
+        sd, self._keep_s = system.to_desc()
+        idesc, self._keep_i = integrator.to_desc()
+        h = C.c_void_p()
+        rc = self._lib.blues_engine_create(C.byref(sd), C.byref(idesc), int(device), C.byref(h))
+        if rc:
+            raise EngineError(self._lib.blues_last_error(None).decode())
+        self._h = h
+        self.n = system.n_atoms
+        self.system = system
+        self.integrator = integrator
+        if system.positions is not None:
+            self.set_positions(system.positions)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.blues_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise EngineError(self._lib.blues_last_error(self._h).decode())
+
+    @staticmethod
+    def _ptr(a):
+        return a.ctypes.data_as(_dp)
+
+    def set_positions(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.n, 3)
+        self._check(self._lib.blues_set_positions(self._h, self._ptr(x), self.n))
+
+    def set_velocities(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.n, 3)
+        self._check(self._lib.blues_set_velocities(self._h, self._ptr(v), self.n))
+
+    def set_box(self, box3):
+        b = np.zeros(9); b[0], b[4], b[8] = np.asarray(box3, dtype=np.float64).reshape(-1)[[0, 1, 2]] if np.size(box3) == 3 else np.asarray(box3).reshape(3, 3).diagonal()
+        self._check(self._lib.blues_set_box(self._h, self._ptr(b)))
+
+    def get_positions(self):
+        x = np.empty((self.n, 3)); self._check(self._lib.blues_get_positions(self._h, self._ptr(x), self.n)); return x
+
+    def get_velocities(self):
+        v = np.empty((self.n, 3)); self._check(self._lib.blues_get_velocities(self._h, self._ptr(v), self.n)); return v
+
+    def get_forces(self):
+        f = np.empty((self.n, 3)); self._check(self._lib.blues_get_forces(self._h, self._ptr(f), self.n)); return f
+
+    def get_box(self):
+        b = np.zeros(9); self._check(self._lib.blues_get_box(self._h, self._ptr(b))); return b.reshape(3, 3)
+
+    def set_velocities_to_temperature(self, T, seed=0):
+        self._check(self._lib.blues_set_velocities_to_temperature(self._h, float(T), int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def potential_energy(self):
+        e = C.c_double(); self._check(self._lib.blues_get_energy(self._h, C.byref(e), None)); return e.value
+
+    def kinetic_energy(self):
+        k = C.c_double(); self._check(self._lib.blues_get_energy(self._h, None, C.byref(k))); return k.value
+
+    def energy_terms(self):
+        t = np.zeros(_abi.N_ENERGY_TERMS); self._check(self._lib.blues_get_energy_terms(self._h, self._ptr(t))); return t
+
+    def step(self, n=1):
+        self._check(self._lib.blues_step(self._h, int(n)))
+
+    def run_switch(self, n, trace=False):
+        if trace:
+            w = np.zeros(int(n)); self._check(self._lib.blues_run_switch(self._h, int(n), self._ptr(w))); return w
+        self._check(self._lib.blues_run_switch(self._h, int(n), None))
+        return None
+
+    def get_global(self, name):
+        v = C.c_double(); self._check(self._lib.blues_get_global(self._h, name.encode(), C.byref(v))); return v.value
+
+    def set_global(self, name, value):
+        self._check(self._lib.blues_set_global(self._h, name.encode(), float(value)))
+
+    def reset(self):
+        self._check(self._lib.blues_reset(self._h))
+
+    def stats(self):
+        s = (C.c_int64 * _abi.N_STATS)(); self._check(self._lib.blues_get_stats(self._h, s))
+        return {"force_passes": s[0], "list_generation": s[1], "kernel_launches": s[2], "i_tiles": s[3],
+                "clusters": s[4], "jcap": s[5], "nchunk": s[6]}
+
+    def time_nonbonded(self, reps=20):
+        u = C.c_double(); self._check(self._lib.blues_time_nonbonded(self._h, int(reps), C.byref(u))); return u.value
