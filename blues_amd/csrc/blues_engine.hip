@@ -107,7 +107,9 @@ struct BluesEngine {
     // ---- derived topology
     std::vector<int> mobile;       // caller indices with mass > 0
     std::vector<HostCluster> clusters;
-    int n_itiles = 0, n_tiles = 0, jcap = 0, nchunk = 1, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0;
+    int n_itiles = 0, n_tiles = 0, jcap = 0, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0;
+    int seg_len = 64, waves_tile = 4, wpb = 4, npart = 1;  // K1 decomposition
+    int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
     double total_mass = 0;
     // ---- device buffers
@@ -116,7 +118,8 @@ struct BluesEngine {
     DBuf<int> d_sorted_of_orig, d_orig_of_sorted, d_tile_atoms, d_jlist, d_jcount, d_batch_slot, d_pool_count, d_ex_start, d_ex_idx, d_islot;
     DBuf<unsigned long long> d_mask_pool;
     DBuf<DevFlags> d_flags; DBuf<DevAccum> d_acc;
-    DBuf<double> d_fpart, d_epart_nb, d_fJ, d_self_part, d_e_part, d_fbond, d_epart_b, d_cm_part, d_trace, d_scratch;
+    DBuf<double> d_fpart, d_epart_nb, d_fJ, d_self_part, d_e_part, d_fent, d_ftot, d_alch_self, d_epart_b, d_cm_part, d_trace, d_scratch;
+    DBuf<int> d_orig_of_islot, d_row_of_orig;
     DBuf<int> d_alch_orig, d_alch_local, d_exc_start, d_exc_partner; DBuf<double> d_exc_params;
     DBuf<int> d_cl_atoms, d_cl_type, d_cl_nc; DBuf<double> d_cl_dist;
     // bonded
@@ -269,7 +272,9 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
         et.insert(et.end(), rtype[i].begin(), rtype[i].end()); ei.insert(ei.end(), rterm[i].begin(), rterm[i].end()); er.insert(er.end(), rrole[i].begin(), rrole[i].end());
         row_start.push_back((int)et.size());
     }
-    h->n_rows = (int)row_atom.size();
+    h->n_rows = (int)row_atom.size(); h->n_entries = (int)et.size();
+    { std::vector<int> row_of(h->n, -1); for (int r = 0; r < h->n_rows; r++) row_of[row_atom[r]] = r; h->d_row_of_orig.upload(row_of); }
+    h->d_fent.alloc((size_t)3 * std::max(1, h->n_entries));
     h->d_row_atom.upload(row_atom); h->d_row_start.upload(row_start); h->d_ent_type.upload(et); h->d_ent_term.upload(ei); h->d_ent_role.upload(er);
     int total_terms = 0; for (int ty = 0; ty < T_NTYPES; ty++) total_terms += h->n_terms[ty];
     h->d_epart_b.alloc((size_t)((total_terms + 255) / 256 + 1) * T_NTYPES);
@@ -315,7 +320,19 @@ static int sort_and_tile(BluesEngine* h) {
     if (((n + 63) / 64) * 64 <= jcap) jcap = ((n + 63) / 64) * 64;
     h->jcap = jcap;
     const int nt = std::max(1, h->n_tiles);
-    h->nchunk = std::max(1, std::min(std::min(64, jcap / 64), (8192 + std::max(1, h->n_itiles) - 1) / std::max(1, h->n_itiles)));
+    {   // K1 decomposition: segments of seg_len j-atoms, waves_tile waves per i-tile in blocks of wpb waves
+        const int nit = std::max(1, h->n_itiles);
+        const double est_count = std::min<double>(jcap, est / 1.5);
+        int CH = 64;
+        while (CH > 8 && nit * (est_count / CH) < 4096.0) CH >>= 1;
+        if (const char* e = getenv("BLUES_SEG")) CH = std::max(8, std::min(64, atoi(e)));
+        int NW = std::max(1, std::min(jcap / CH, (8192 + nit - 1) / nit));
+        int WPB = h->precision == 0 ? 16 : 8;
+        while (WPB > 1 && (WPB > NW || nit * (NW / WPB) < 512)) WPB >>= 1;
+        if (const char* e = getenv("BLUES_WPB")) WPB = std::max(1, std::min(h->precision == 0 ? 16 : 8, atoi(e)));
+        NW = std::max(WPB, (NW / WPB) * WPB);
+        h->seg_len = CH; h->waves_tile = NW; h->wpb = WPB; h->npart = NW / WPB;
+    }
     h->pool_cap = nt * 12 + 64;
     h->PA = 1; while (h->PA < (int)h->alch.size()) h->PA <<= 1;
     h->k2_nblocks_env = (jcap * h->PA + 255) / 256;
@@ -356,8 +373,9 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_ex_start.upload(ex_start); h->d_ex_idx.upload(ex_idx);
         h->d_jlist.alloc((size_t)nt * jcap); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
         h->d_mask_pool.alloc((size_t)h->pool_cap * 64); h->d_pool_count.alloc(1);
-        h->d_fpart.alloc((size_t)h->nchunk * 3 * h->n_islots);
-        h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->nchunk * 2 + 2 * ((n + 255) / 256));
+        h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
+        h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 + 2 * ((n + 255) / 256));
+        { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi); }
         h->d_fJ.alloc((size_t)9 * n);
         h->d_self_part.alloc((size_t)(h->k2_nblocks_env + 1) * 9 * 64); h->d_e_part.alloc((size_t)(h->k2_nblocks_env + 1) * K2_NE);
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
@@ -373,12 +391,9 @@ static IntArgs make_int_args(BluesEngine* h) {
     A.cl_atoms = h->d_cl_atoms.p; A.cl_type = h->d_cl_type.p; A.cl_nc = h->d_cl_nc.p; A.cl_dist = h->d_cl_dist.p;
     for (int k = 0; k < 3; k++) { A.x[k] = h->d_x[k].p; A.v[k] = h->d_v[k].p; A.xbuild[k] = h->d_xbuild[k].p; }
     A.mass = h->d_mass.p;
-    A.fpart = h->d_fpart.p; A.nchunk = h->nchunk; A.n_islots = h->n_islots; A.islot_of_orig = h->d_islot.p;
-    A.fbond = h->d_fbond.p; A.fJ = h->d_fJ.p; A.sorted_of_orig = h->d_sorted_of_orig.p;
-    A.self_part = h->d_self_part.p; A.e_part = h->d_e_part.p;
-    A.jcount_alch = h->d_jcount.p + h->n_itiles; A.k2_nblocks_env = h->k2_nblocks_env; A.PA = h->PA; A.n_alch = (int)h->alch.size();
+    A.ftot = h->d_ftot.p; A.alch_self = h->d_alch_self.p;
+    A.fJ = h->d_fJ.p; A.sorted_of_orig = h->d_sorted_of_orig.p; A.n_alch = (int)h->alch.size();
     A.alch_local_of_orig = h->d_alch_local.p;
-    for (int s = 0; s < 3; s++) { const int L = std::min(h->pass_L + s, h->n_lambda); A.le[s] = h->tab_le[L]; }
     A.hV = h->dt / std::max(1, h->n_V); A.hR = h->dt / std::max(1, h->n_R);
     const double hO = h->dt / std::max(1, h->n_O);
     A.aO = std::exp(-h->gamma * hO); A.bO = std::sqrt(1.0 - std::exp(-2.0 * h->gamma * hO));
@@ -426,15 +441,28 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
     return 0;
 }
 
+template <typename R, bool ENERGY, int WPB> static void launch_nb_wpb(BluesEngine* h, const NbArgs<R>& a, const typename Img<R>::Atom* img) {
+    const int blocks = std::max(1, h->n_itiles) * (h->waves_tile / WPB);
+    hipLaunchKernelGGL((k_nonbonded<R, ENERGY, WPB>), dim3(blocks), dim3(WPB * 64), 0, h->stream, a, make_nbconst<R>(h), img);
+}
+
 template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
     NbArgs<R> a; memset(&a, 0, sizeof a);
-    a.n_itiles = h->n_itiles; a.nchunk = h->nchunk; a.jcap = h->jcap; a.n_islots = h->n_islots;
+    a.n_itiles = h->n_itiles; a.jcap = h->jcap; a.n_islots = h->n_islots;
+    a.seg_len = h->seg_len; a.waves_tile = h->waves_tile; a.npart = h->npart;
     a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p; a.mask_pool = h->d_mask_pool.p;
     a.fpart = h->d_fpart.p; a.epart = h->d_epart_nb.p; a.flags = h->d_flags.p;
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
-    const int waves = std::max(1, h->n_itiles * h->nchunk);
-    hipLaunchKernelGGL((k_nonbonded<R, ENERGY>), dim3((waves + 3) / 4), dim3(256), 0, h->stream, a, make_nbconst<R>(h), img);
+    switch (h->wpb) {
+    case 1: launch_nb_wpb<R, ENERGY, 1>(h, a, img); break;
+    case 2: launch_nb_wpb<R, ENERGY, 2>(h, a, img); break;
+    case 4: launch_nb_wpb<R, ENERGY, 4>(h, a, img); break;
+    case 8: launch_nb_wpb<R, ENERGY, 8>(h, a, img); break;
+    default:
+        if constexpr (sizeof(R) == 4) launch_nb_wpb<R, ENERGY, 16>(h, a, img); else launch_nb_wpb<R, ENERGY, 8>(h, a, img);
+        break;
+    }
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -466,8 +494,27 @@ static BondedArgs make_bonded_args(BluesEngine* h) {
     for (int ty = 0; ty < T_NTYPES; ty++) { B.n_terms[ty] = h->n_terms[ty]; B.atoms[ty] = h->d_term_atoms[ty].p; B.params[ty] = h->d_term_params[ty].p; }
     B.restr_k = h->restr_k;
     for (int k = 0; k < 3; k++) B.x[k] = h->d_x[k].p;
-    B.box = make_box(h); B.periodic = h->nb_method == BLUES_NB_PME_DIRECT; B.fbond = h->d_fbond.p; B.n = h->n; B.epart = h->d_epart_b.p;
+    B.box = make_box(h); B.periodic = h->nb_method == BLUES_NB_PME_DIRECT; B.fent = h->d_fent.p; B.n_entries = h->n_entries; B.n = h->n; B.epart = h->d_epart_b.p;
     return B;
+}
+
+static int launch_bonded_and_finalize(BluesEngine* h, const double le[3]) {
+    if (h->n_entries > 0) {
+        hipLaunchKernelGGL(k_bonded_entries, dim3((h->n_entries + 127) / 128), dim3(128), 0, h->stream, make_bonded_args(h));
+        h->st_launches++;
+    }
+    FinArgs F; memset(&F, 0, sizeof F);
+    F.n = h->n; F.n_islots = h->n_islots; F.npart = h->npart; F.n_alch = (int)h->alch.size(); F.PA = h->PA; F.k2_nblocks_env = h->k2_nblocks_env; F.n_entries = h->n_entries;
+    F.orig_of_islot = h->d_orig_of_islot.p; F.row_of_orig = h->d_row_of_orig.p; F.row_start = h->d_row_start.p;
+    F.fpart = h->d_fpart.p; F.fent = h->d_fent.p; F.alch_orig = h->d_alch_orig.p;
+    F.self_part = h->d_self_part.p; F.e_part = h->d_e_part.p; F.jcount_alch = h->d_jcount.p + h->n_itiles;
+    for (int s = 0; s < 3; s++) F.le[s] = le[s];
+    F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p;
+    const int nb_atoms = (h->n_islots + F.n_alch + 255) / 256;
+    hipLaunchKernelGGL(k_finalize, dim3(nb_atoms + 1), dim3(256), 0, h->stream, F);
+    h->st_launches++;
+    HIP_OK(h, hipGetLastError());
+    return 0;
 }
 
 static int ensure_sorted(BluesEngine* h) {
@@ -487,10 +534,7 @@ static int force_pass(BluesEngine* h, int base_L) {
     if (launch_alchemical(h, ls, le, 7)) return 1;
     rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
     if (rc) return 1;
-    if (h->n_rows > 0) {
-        hipLaunchKernelGGL(k_bonded_forces, dim3((h->n_rows + 127) / 128), dim3(128), 0, h->stream, make_bonded_args(h));
-        h->st_launches++;
-    }
+    if (launch_bonded_and_finalize(h, le)) return 1;
     h->pass_valid = true; h->pass_L = base_L; h->st_passes++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -524,7 +568,7 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
     if (nbb > 0) { hipLaunchKernelGGL(k_bonded_energy, dim3(nbb), dim3(256), 0, h->stream, make_bonded_args(h)); h->st_launches++; }
     const int nfb = (h->n + 255) / 256;
     if (!h->e_frozen_valid) {
-        double* ep = h->d_epart_nb.p + (size_t)std::max(1, h->n_itiles) * h->nchunk * 2;
+        double* ep = h->d_epart_nb.p + (size_t)std::max(1, h->n_itiles) * h->npart * 2;
         if (h->precision == 0) hipLaunchKernelGGL(k_energy_frozen<float>, dim3(nfb), dim3(256), 0, h->stream, h->n, make_nbconst<float>(h), h->d_img_f.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
         else hipLaunchKernelGGL(k_energy_frozen<double>, dim3(nfb), dim3(256), 0, h->stream, h->n, make_nbconst<double>(h), h->d_img_d.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
         h->st_launches++;
@@ -533,10 +577,10 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
     std::vector<double> e;
     try {
         h->d_epart_nb.download(e);
-        const int nw = h->n_itiles * h->nchunk;
+        const int nw = h->n_itiles * h->npart;
         double enb = 0.0; for (int w = 0; w < nw; w++) enb += e[2 * w] + e[2 * w + 1];
         if (!h->e_frozen_valid) {
-            const size_t off = (size_t)std::max(1, h->n_itiles) * h->nchunk * 2;
+            const size_t off = (size_t)std::max(1, h->n_itiles) * h->npart * 2;
             h->e_frozen[0] = h->e_frozen[1] = 0.0;
             for (int b = 0; b < nfb; b++) { h->e_frozen[0] += e[off + 2 * b]; h->e_frozen[1] += e[off + 2 * b + 1]; }
             h->e_frozen_valid = true;
@@ -699,7 +743,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     try {
         for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); }
         h->d_mass.upload(h->mass); h->d_charge.upload(h->charge); h->d_sigma.upload(h->sigma); h->d_eps.upload(h->eps);
-        h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_fbond.alloc((size_t)3 * n);
+        h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ftot.alloc((size_t)3 * n); h->d_alch_self.alloc(9 * 64);
         h->d_alch_orig.upload(h->alch); h->d_alch_local.upload(h->alch_local);
         h->d_trace.alloc((size_t)std::max(1, h->nsteps)); h->d_scratch.alloc((size_t)std::max(3 * n, 1024));
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
@@ -841,7 +885,7 @@ int blues_get_forces(BluesEngine* h, double* out, int32_t n_atoms) {
     if (launch_alchemical(h, ls, le, 1)) return 1;
     rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
     if (rc) return 1;
-    if (h->n_rows > 0) { hipLaunchKernelGGL(k_bonded_forces, dim3((h->n_rows + 127) / 128), dim3(128), 0, h->stream, make_bonded_args(h)); h->st_launches++; }
+    if (launch_bonded_and_finalize(h, le)) return 1;
     IntArgs A = make_int_args(h);
     DBuf<double> tmp;
     try { tmp.alloc((size_t)3 * h->n); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
@@ -979,7 +1023,7 @@ int blues_reset(BluesEngine* h) {
 
 int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
     for (int i = 0; i < BLUES_N_STATS; i++) stats[i] = 0;
-    stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->nchunk;
+    stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
     if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) stats[1] = f.list_gen; }
     return 0;
 }

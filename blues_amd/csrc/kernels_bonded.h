@@ -27,7 +27,8 @@ struct BondedArgs {
     const double* x[3];
     Box3 box;
     int periodic;
-    double* fbond;   // [3][n]
+    double* fent;    // [3][n_entries] per-entry forces
+    int n_entries;
     int n;
     double* epart;   // [nblocks][T_NTYPES] (energy kernel)
 };
@@ -116,17 +117,13 @@ __device__ inline double bonded_term(const BondedArgs& B, int type, int idx, int
     return B.restr_k * dot3(d, d);
 }
 
-__global__ void __launch_bounds__(128) k_bonded_forces(BondedArgs B) {
-    const int r = blockIdx.x * 128 + threadIdx.x;
-    if (r >= B.n_rows) return;
-    double f[3] = {0.0, 0.0, 0.0};
-    for (int e = B.row_start[r]; e < B.row_start[r + 1]; e++) {
-        double F[3];
-        bonded_term(B, B.ent_type[e], B.ent_term[e], B.ent_role[e], F);
-        f[0] += F[0]; f[1] += F[1]; f[2] += F[2];
-    }
-    const int i = B.row_atom[r];
-    B.fbond[i] = f[0]; B.fbond[B.n + i] = f[1]; B.fbond[2 * B.n + i] = f[2];
+// one thread per (row, entry): the force of one term on one of its mobile atoms -> fent[3][n_entries]
+__global__ void __launch_bounds__(128) k_bonded_entries(BondedArgs B) {
+    const int e = blockIdx.x * 128 + threadIdx.x;
+    if (e >= B.n_entries) return;
+    double F[3];
+    bonded_term(B, B.ent_type[e], B.ent_term[e], B.ent_role[e], F);
+    B.fent[e] = F[0]; B.fent[B.n_entries + e] = F[1]; B.fent[2 * B.n_entries + e] = F[2];
 }
 
 // energy of every term (frozen ones included): per-block partial sums per type

@@ -45,12 +45,10 @@ struct IntArgs {
     double* x[3]; double* v[3];
     const double* mass;
     // force sources
-    const double* fpart; int nchunk, n_islots; const int* islot_of_orig;
-    const double* fbond;
-    const double* fJ; const int* sorted_of_orig;
-    const double* self_part; const double* e_part; const int* jcount_alch; int k2_nblocks_env, PA, n_alch;
+    const double* ftot;       // [3][n] environment + bonded force per atom (k_finalize)
+    const double* alch_self;  // [9][64] force on the alchemical atoms per slot (k_finalize)
+    const double* fJ; const int* sorted_of_orig; int n_alch;
     const int* alch_local_of_orig;
-    double le[3];
     // constants
     double hV, hR, aO, bO, kT, tol;
     unsigned long long seed; unsigned stream, draw_base;
@@ -65,11 +63,6 @@ struct IntArgs {
     Program prog;
 };
 
-__device__ inline void cl_pair(int type, int c, int& i, int& j) {
-    if (type == 1) { i = 0; j = c + 1; }
-    else { i = (c == 2) ? 1 : 0; j = (c == 0) ? 1 : 2; }
-}
-
 struct Cluster {
     double x[4][3], v[4][3], w[4];  // w = 1/m
     int id[4];
@@ -77,116 +70,202 @@ struct Cluster {
     double d2[3];
 };
 
-#define FOR_CONS(c, CL, i, j, ...)                                                   \
-    _Pragma("unroll") for (int c = 0; c < 3; c++) {                                  \
-        if (c < CL.nc) {                                                             \
-            if (CL.type == 1) { const int i = 0, j = c + 1; __VA_ARGS__ }            \
-            else { const int i = (c == 2) ? 1 : 0, j = (c == 0) ? 1 : 2; __VA_ARGS__ } \
-        }                                                                            \
+// ---- cluster-local constraint solves with compile-time index tables (no register-array indexing by runtime values)
+//   type 1 (star):     constraints (0,1) (0,2) (0,3)
+//   type 2 (triangle): constraints (0,1) (0,2) (1,2)
+template <int TYPE> struct ClTab {
+    static __device__ constexpr int ci(int c) { return TYPE == 1 ? 0 : (c == 2 ? 1 : 0); }
+    static __device__ constexpr int cj(int c) { return TYPE == 1 ? c + 1 : (c == 0 ? 1 : 2); }
+    // s(c2, a): +1 if a is the first atom of constraint c2, -1 if the second
+    static __device__ constexpr int s(int c2, int a) { return (a == ci(c2)) - (a == cj(c2)); }
+};
+
+__device__ inline void solve_small(int n, const double M[3][3], const double b[3], double x[3]) {
+    if (n == 1) { x[0] = b[0] / M[0][0]; x[1] = x[2] = 0.0; return; }
+    if (n == 2) {
+        const double inv = 1.0 / (M[0][0] * M[1][1] - M[0][1] * M[1][0]);
+        x[0] = (b[0] * M[1][1] - M[0][1] * b[1]) * inv;
+        x[1] = (M[0][0] * b[1] - b[0] * M[1][0]) * inv;
+        x[2] = 0.0;
+        return;
     }
+    const double c00 = M[1][1] * M[2][2] - M[1][2] * M[2][1], c01 = M[1][2] * M[2][0] - M[1][0] * M[2][2], c02 = M[1][0] * M[2][1] - M[1][1] * M[2][0];
+    const double inv = 1.0 / (M[0][0] * c00 + M[0][1] * c01 + M[0][2] * c02);
+    x[0] = (b[0] * c00 + b[1] * (M[0][2] * M[2][1] - M[0][1] * M[2][2]) + b[2] * (M[0][1] * M[1][2] - M[0][2] * M[1][1])) * inv;
+    x[1] = (b[0] * c01 + b[1] * (M[0][0] * M[2][2] - M[0][2] * M[2][0]) + b[2] * (M[0][2] * M[1][0] - M[0][0] * M[1][2])) * inv;
+    x[2] = (b[0] * c02 + b[1] * (M[0][1] * M[2][0] - M[0][0] * M[2][1]) + b[2] * (M[0][0] * M[1][1] - M[0][1] * M[1][0])) * inv;
+}
+
+// RATTLE: (v_i - v_j).r_ij = 0 is linear in the multipliers -> one small solve (same algebra as the oracle)
+template <int TYPE> __device__ inline void rattle_t(Cluster& C, const IntArgs& A) {
+    using T = ClTab<TYPE>;
+    double r[3][3], M[3][3], b[3], mu[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double rv = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            r[c][k] = 0.0;
+            if (c < C.nc) {
+                r[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k];
+                if (A.periodic) r[c][k] = min_image_d(r[c][k], A.box.L[k], A.box.invL[k]);
+                rv += (C.v[T::ci(c)][k] - C.v[T::cj(c)][k]) * r[c][k];
+            }
+        }
+        b[c] = -rv;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int c2 = 0; c2 < 3; c2++) {
+            const double coef = C.w[T::ci(c)] * T::s(c2, T::ci(c)) - C.w[T::cj(c)] * T::s(c2, T::cj(c));
+            M[c][c2] = (r[c][0] * r[c2][0] + r[c][1] * r[c2][1] + r[c][2] * r[c2][2]) * coef;
+        }
+    solve_small(C.nc, M, b, mu);
+#pragma unroll
+    for (int c = 0; c < 3; c++) if (c < C.nc) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { C.v[T::ci(c)][k] += mu[c] * r[c][k] * C.w[T::ci(c)]; C.v[T::cj(c)][k] -= mu[c] * r[c][k] * C.w[T::cj(c)]; }
+    }
+}
 
 __device__ inline void rattle(Cluster& C, double tol, const IntArgs& A) {
     if (C.nc == 0) return;
-    for (int it = 0; it < 500; it++) {
-        bool done = true;
-        FOR_CONS(c, C, i, j, {
-            double r[3], rv[3];
-            for (int k = 0; k < 3; k++) {
-                r[k] = C.x[i][k] - C.x[j][k];
-                if (A.periodic) r[k] = min_image_d(r[k], A.box.L[k], A.box.invL[k]);
-                rv[k] = C.v[i][k] - C.v[j][k];
-            }
-            const double delta = -(rv[0] * r[0] + rv[1] * r[1] + rv[2] * r[2]) / ((r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * (C.w[i] + C.w[j]));
-            if (fabs(delta) > tol) {
-                done = false;
-                for (int k = 0; k < 3; k++) { C.v[i][k] += C.w[i] * delta * r[k]; C.v[j][k] -= C.w[j] * delta * r[k]; }
-            }
-        })
-        if (done) break;
-    }
+    if (C.type == 1) rattle_t<1>(C, A); else rattle_t<2>(C, A);
 }
 
-// positions C.x are the unconstrained ones; xr the reference (last constrained) geometry
+// SHAKE: Newton on the multipliers, directions from the reference geometry xr; converged to
+// |r^2 - d^2| <= 2 tol d^2 plus one polishing iteration (same sequence as the oracle)
+template <int TYPE> __device__ inline bool shake_t(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
+    using T = ClTab<TYPE>;
+    double r[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            r[c][k] = 0.0;
+            if (c < C.nc) { r[c][k] = xr[T::ci(c)][k] - xr[T::cj(c)][k]; if (A.periodic) r[c][k] = min_image_d(r[c][k], A.box.L[k], A.box.invL[k]); }
+        }
+    int it;
+    for (it = 0; it < 50; it++) {
+        double D[3][3], g[3], J[3][3], dl[3];
+        bool conv = true;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            g[c] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) D[c][k] = 0.0;
+            if (c < C.nc) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { D[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k]; if (A.periodic) D[c][k] = min_image_d(D[c][k], A.box.L[k], A.box.invL[k]); }
+                g[c] = -(D[c][0] * D[c][0] + D[c][1] * D[c][1] + D[c][2] * D[c][2] - C.d2[c]);
+                if (fabs(g[c]) > 2.0 * tol * C.d2[c]) conv = false;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int c2 = 0; c2 < 3; c2++) {
+                const double coef = C.w[T::ci(c)] * T::s(c2, T::ci(c)) - C.w[T::cj(c)] * T::s(c2, T::cj(c));
+                J[c][c2] = 2.0 * (D[c][0] * r[c2][0] + D[c][1] * r[c2][1] + D[c][2] * r[c2][2]) * coef;
+            }
+        solve_small(C.nc, J, g, dl);
+#pragma unroll
+        for (int c = 0; c < 3; c++) if (c < C.nc) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { C.x[T::ci(c)][k] += dl[c] * r[c][k] * C.w[T::ci(c)]; C.x[T::cj(c)][k] -= dl[c] * r[c][k] * C.w[T::cj(c)]; }
+        }
+        if (conv) break;
+    }
+    return it < 50;
+}
+
 __device__ inline bool shake(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
     if (C.nc == 0) return true;
-    int it;
-    for (it = 0; it < 500; it++) {
-        bool done = true;
-        FOR_CONS(c, C, i, j, {
-            double rp[3];
-            for (int k = 0; k < 3; k++) {
-                rp[k] = C.x[i][k] - C.x[j][k];
-                if (A.periodic) rp[k] = min_image_d(rp[k], A.box.L[k], A.box.invL[k]);
-            }
-            const double diff = C.d2[c] - (rp[0] * rp[0] + rp[1] * rp[1] + rp[2] * rp[2]);
-            if (fabs(diff) > 2.0 * tol * C.d2[c]) {
-                done = false;
-                double r[3];
-                for (int k = 0; k < 3; k++) {
-                    r[k] = xr[i][k] - xr[j][k];
-                    if (A.periodic) r[k] = min_image_d(r[k], A.box.L[k], A.box.invL[k]);
-                }
-                const double delta = diff / (2.0 * (rp[0] * r[0] + rp[1] * r[1] + rp[2] * r[2]) * (C.w[i] + C.w[j]));
-                for (int k = 0; k < 3; k++) { C.x[i][k] += C.w[i] * delta * r[k]; C.x[j][k] -= C.w[j] * delta * r[k]; }
-            }
-        })
-        if (done) break;
-    }
-    return it < 500;
+    return C.type == 1 ? shake_t<1>(C, xr, tol, A) : shake_t<2>(C, xr, tol, A);
 }
 
-__device__ inline void load_force(const IntArgs& A, const Cluster& C, int slot, const double (*s_alch)[64], double F[4][3]) {
+__device__ inline void load_force(const IntArgs& A, const Cluster& C, int slot, double F[4][3]) {
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         F[a][0] = F[a][1] = F[a][2] = 0.0;
         if (a < C.na) {
             const int i = C.id[a];
-            const int isl = A.islot_of_orig[i];
+            const int al = A.n_alch > 0 ? A.alch_local_of_orig[i] : -1;
+            const int srt = A.sorted_of_orig[i];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                double f = A.fbond[(size_t)k * A.n + i];
-                if (isl >= 0) for (int ch = 0; ch < A.nchunk; ch++) f += A.fpart[((size_t)ch * 3 + k) * A.n_islots + isl];
-                if (A.n_alch > 0) {
-                    const int al = A.alch_local_of_orig[i];
-                    if (al >= 0) f += s_alch[slot * 3 + k][al];
-                    else f += A.fJ[(size_t)(slot * 3 + k) * A.n + A.sorted_of_orig[i]];
-                }
+                double f = A.ftot[(size_t)k * A.n + i];
+                if (A.n_alch > 0) f += al >= 0 ? A.alch_self[(slot * 3 + k) * 64 + al] : A.fJ[(size_t)(slot * 3 + k) * A.n + srt];
                 F[a][k] = f;
             }
         }
     }
 }
 
+// Sums every per-block partial the force kernels left behind, once per pass and in a fixed order:
+//   ftot[k][i]  = sum over K1 partial slabs + sum over the atom's bonded entries
+//   alch_self   = sum over K2 blocks of the force on each alchemical atom (3 slots)
+//   acc->e_slot = le[slot]*C + S[slot]  (alchemical energy per lambda slot, for the H ops)
+struct FinArgs {
+    int n, n_islots, npart, n_alch, PA, k2_nblocks_env, n_entries;
+    const int* orig_of_islot;   // [n_islots] caller index or -1
+    const int* row_of_orig;     // [n] bonded row or -1
+    const int* row_start;
+    const double* fpart; const double* fent;
+    const int* alch_orig;
+    const double* self_part; const double* e_part; const int* jcount_alch;
+    double le[3];
+    double* ftot; double* alch_self; DevAccum* acc;
+};
+
+__global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
+    const int tid = threadIdx.x;
+    const int nb_atoms = (A.n_islots + A.n_alch + 255) / 256;
+    if ((int)blockIdx.x < nb_atoms) {
+        const int g = blockIdx.x * 256 + tid;
+        int i = -1, isl = -1;
+        if (g < A.n_islots) { isl = g; i = A.orig_of_islot[g]; }
+        else if (g - A.n_islots < A.n_alch) i = A.alch_orig[g - A.n_islots];
+        if (i < 0) return;
+        double f[3] = {0.0, 0.0, 0.0};
+        if (isl >= 0) for (int p = 0; p < A.npart; p++)
+            for (int k = 0; k < 3; k++) f[k] += A.fpart[((size_t)p * 3 + k) * A.n_islots + isl];
+        const int row = A.row_of_orig[i];
+        if (row >= 0) for (int e = A.row_start[row]; e < A.row_start[row + 1]; e++)
+            for (int k = 0; k < 3; k++) f[k] += A.fent[(size_t)k * A.n_entries + e];
+        for (int k = 0; k < 3; k++) A.ftot[(size_t)k * A.n + i] = f[k];
+        return;
+    }
+    if (A.n_alch == 0) return;
+    // last block: alchemical partial slabs
+    __shared__ double s_e[K2_NE];
+    const int cnt = *A.jcount_alch;
+    const int nb_env = (cnt * A.PA + 255) / 256;
+    for (int t = tid; t < 9 * 64; t += 256) {
+        const int q = t >> 6, a = t & 63;
+        double s = 0.0;
+        if (a < A.n_alch) {
+            for (int b = 0; b < nb_env; b++) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
+            s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
+        }
+        A.alch_self[q * 64 + a] = s;
+    }
+    if (tid < K2_NE) {
+        double s = 0.0;
+        for (int b = 0; b < nb_env; b++) s += A.e_part[(size_t)b * K2_NE + tid];
+        s += A.e_part[(size_t)A.k2_nblocks_env * K2_NE + tid];
+        s_e[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 3) A.acc->e_slot[tid] = A.le[tid] * s_e[0] + s_e[1 + tid];
+}
+
 __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
     const int tid = threadIdx.x;
     const int cl = blockIdx.x * blockDim.x + tid;
-    __shared__ double s_alch[9][64];
     __shared__ double s_red[4][4];
     __shared__ double s_cm[3];
-    __shared__ double s_e[K2_NE];
-
-    // ---- block 0 gathers the alchemical kernel's block partials (forces on alchemical atoms, energies)
-    if (blockIdx.x == 0 && A.n_alch > 0) {
-        const int cnt = *A.jcount_alch;
-        const int nb_env = (cnt * A.PA + 255) / 256;
-        for (int t = tid; t < 9 * 64; t += blockDim.x) {
-            const int q = t >> 6, a = t & 63;
-            double s = 0.0;
-            if (a < A.n_alch) {
-                for (int b = 0; b < nb_env; b++) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
-                s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
-            }
-            s_alch[q][a] = s;
-        }
-        if (tid < K2_NE) {
-            double s = 0.0;
-            for (int b = 0; b < nb_env; b++) s += A.e_part[(size_t)b * K2_NE + tid];
-            s += A.e_part[(size_t)A.k2_nblocks_env * K2_NE + tid];
-            s_e[tid] = s;
-        }
-        __syncthreads();
-        if (tid == 0) for (int s = 0; s < 3; s++) A.acc->e_slot[s] = A.le[s] * s_e[0] + s_e[1 + s];
-    }
 
     Cluster C;
     C.na = 0; C.nc = 0; C.type = 0;
@@ -217,7 +296,7 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
         case OP_V0: case OP_V1: case OP_V2: {
             if (active) {
                 double F[4][3];
-                load_force(A, C, op - OP_V0, s_alch, F);
+                load_force(A, C, op - OP_V0, F);
 #pragma unroll
                 for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * F[a][k] * C.w[a];
                 rattle(C, A.tol, A);
@@ -352,34 +431,14 @@ __global__ void k_maxwell(int n, const double* __restrict__ mass, double* vx, do
     vx[i] = g[0]; vy[i] = g[1]; vz[i] = g[2];
 }
 
-// total forces in caller order for getState(getForces=True): env partials + bonded + alchemical (slot)
+// total forces in caller order for getState(getForces=True): ftot + alchemical (slot); frozen atoms report 0
 __global__ void k_gather_forces(IntArgs A, int slot, double* out /*[n][3]*/) {
-    __shared__ double s_alch[9][64];
-    if (A.n_alch > 0) {
-        const int cnt = *A.jcount_alch;
-        const int nb_env = (cnt * A.PA + 255) / 256;
-        for (int t = threadIdx.x; t < 9 * 64; t += blockDim.x) {
-            const int q = t >> 6, a = t & 63;
-            double s = 0.0;
-            if (a < A.n_alch) {
-                for (int b = 0; b < nb_env; b++) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
-                s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
-            }
-            s_alch[q][a] = s;
-        }
-        __syncthreads();
-    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
-    const int isl = A.islot_of_orig[i];
+    const int al = A.n_alch > 0 ? A.alch_local_of_orig[i] : -1;
     for (int k = 0; k < 3; k++) {
-        double f = A.fbond[(size_t)k * A.n + i];
-        if (isl >= 0) for (int ch = 0; ch < A.nchunk; ch++) f += A.fpart[((size_t)ch * 3 + k) * A.n_islots + isl];
-        if (A.n_alch > 0) {
-            const int al = A.alch_local_of_orig[i];
-            if (al >= 0) f += s_alch[slot * 3 + k][al];
-            else f += A.fJ[(size_t)(slot * 3 + k) * A.n + A.sorted_of_orig[i]];
-        }
+        double f = A.ftot[(size_t)k * A.n + i];
+        if (A.n_alch > 0) f += al >= 0 ? A.alch_self[(slot * 3 + k) * 64 + al] : A.fJ[(size_t)(slot * 3 + k) * A.n + A.sorted_of_orig[i]];
         out[3 * i + k] = A.mass[i] != 0.0 ? f : 0.0;
     }
 }

@@ -166,48 +166,55 @@ __global__ void __launch_bounds__(256) k_build_lists(ListArgs a, NbConst<R> c, c
 }
 
 template <typename R> struct NbArgs {
-    int n_itiles, nchunk, jcap, n_islots;
+    int n_itiles, jcap, n_islots;
+    int seg_len;     // CH: j-atoms per wave segment (8..64, divides 64)
+    int waves_tile;  // NW: waves that share one i-tile (multiple of WPB)
+    int npart;       // NW / WPB partial slabs per tile
     const int* tile_atoms;
     const int* jlist;
     const int* jcount;
     const int* batch_slot;
     const unsigned long long* mask_pool;
-    double* fpart;   // [nchunk][3][n_islots]
-    double* epart;   // [n_itiles*nchunk][2] (ENERGY only)
+    double* fpart;   // [npart][3][n_islots]
+    double* epart;   // [n_itiles*npart][2] (ENERGY only)
     DevFlags* flags;
 };
 
-template <typename R, bool ENERGY>
-__global__ void __launch_bounds__(256) k_nonbonded(NbArgs<R> a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img) {
+// One block = WPB waves working on the SAME i-tile; wave w of the tile walks the j-list segments
+// q = w, w+NW, w+2NW, ...; the block's waves are summed through LDS into one partial slab.
+template <typename R, bool ENERGY, int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_nonbonded(NbArgs<R> a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img) {
     using Atom = typename Img<R>::Atom;
     using sfix = typename Img<R>::sfix;
-    __shared__ Atom lds[4][64];
+    __shared__ Atom lds[WPB][64];
+    __shared__ double red[WPB][ENERGY ? 5 : 3][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int w = blockIdx.x * 4 + wv;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.flags->list_gen = a.flags->req_gen;  // lists are current for this pass
-    const int t = w / a.nchunk, ch = w - t * a.nchunk;
-    if (t >= a.n_itiles) return;  // wave-uniform
+    const int blocks_tile = a.waves_tile / WPB;
+    const int t = blockIdx.x / blocks_tile, part = blockIdx.x - t * blocks_tile;
+    if (t >= a.n_itiles) return;  // block-uniform
+    const int w = part * WPB + wv;  // wave index within the tile
 
     const int ia = a.tile_atoms[t * 64 + lane];
-    Atom ai;
-    if (ia >= 0) ai = img[ia]; else { ai = img[a.tile_atoms[t * 64]]; }
     const bool valid = ia >= 0;
+    const Atom ai = img[valid ? ia : a.tile_atoms[t * 64]];
     const int count = a.jcount[t];
-    const int nb = (count + 63) >> 6;
+    const int CH = a.seg_len;
+    const int nseg = (count + CH - 1) / CH;
     const int nbmax = a.jcap >> 6;
     const int* jl = a.jlist + (size_t)t * a.jcap;
     double fx = 0.0, fy = 0.0, fz = 0.0, elj = 0.0, ecl = 0.0;
     Atom* my = lds[wv];
 
-    for (int b = ch; b < nb; b += a.nchunk) {
-        const int p = b * 64 + lane;
-        const int nvalid = min(64, count - b * 64);
-        if (lane < nvalid) my[lane] = img[jl[p]];
-        const int slot = a.batch_slot[t * nbmax + b];
+    for (int q = w; q < nseg; q += a.waves_tile) {
+        const int p0 = q * CH;
+        const int nvalid = min(CH, count - p0);
+        if (lane < nvalid) my[lane] = img[jl[p0 + lane]];
+        const int slot = a.batch_slot[t * nbmax + (p0 >> 6)];
         unsigned long long m = 0ull;
-        if (slot >= 0) m = a.mask_pool[(size_t)slot * 64 + lane];
+        if (slot >= 0) m = a.mask_pool[(size_t)slot * 64 + lane] >> (p0 & 63);
         if (!valid) m = ~0ull;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS stores have landed (waves are independent)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS stores have landed (the slab is wave-private)
         for (int k = 0; k < nvalid; k++) {
             const Atom bj = my[k];
             R dx = (R)(sfix)(ai.x - bj.x) * c.scale[0];
@@ -227,12 +234,19 @@ __global__ void __launch_bounds__(256) k_nonbonded(NbArgs<R> a, NbConst<R> c, co
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads done before the slab is overwritten
     }
-    const int slot_i = t * 64 + lane;
-    double* fp = a.fpart + (size_t)ch * 3 * a.n_islots;
-    fp[slot_i] = fx; fp[a.n_islots + slot_i] = fy; fp[2 * a.n_islots + slot_i] = fz;
-    if (ENERGY) {
-        elj = wave_sum(elj); ecl = wave_sum(ecl);
-        if (lane == 0) { a.epart[2 * w] = elj; a.epart[2 * w + 1] = ecl; }
+    red[wv][0][lane] = fx; red[wv][1][lane] = fy; red[wv][2][lane] = fz;
+    if (ENERGY) { red[wv][3][lane] = elj; red[wv][4][lane] = ecl; }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int u = 1; u < WPB; u++) { fx += red[u][0][lane]; fy += red[u][1][lane]; fz += red[u][2][lane]; if (ENERGY) { elj += red[u][3][lane]; ecl += red[u][4][lane]; } }
+        const int slot_i = t * 64 + lane;
+        double* fp = a.fpart + (size_t)part * 3 * a.n_islots;
+        fp[slot_i] = fx; fp[a.n_islots + slot_i] = fy; fp[2 * a.n_islots + slot_i] = fz;
+        if (ENERGY) {
+            elj = wave_sum(elj); ecl = wave_sum(ecl);
+            if (lane == 0) { a.epart[2 * (t * a.npart + part)] = elj; a.epart[2 * (t * a.npart + part) + 1] = ecl; }
+        }
     }
 }
 

@@ -1,0 +1,61 @@
+"""Replica fan-out across the GPUs of one node.
+
+The switching path shards by replica only: an NCMC switch is a serial chain of dependent
+steps on ~1 MB of state, so each rank runs an independent BLUES chain (own seed, own MD
+state) on its own GPU and there is NO data-path collective.  The one exchange per BLUES
+iteration is an all-gather of a 32-byte decision record per rank -- RCCL over xGMI when the
+tensors live on the GPU (backend "nccl"), gloo on CPU for tests.
+"""
+import os
+
+import numpy as np
+
+RECORD_FIELDS = ("accept", "iteration", "log_accept", "protocol_work", "correction")
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_process_group(backend=None):
+    """One process per GPU; rendezvous from MASTER_ADDR/MASTER_PORT (127.0.0.1 on one node)."""
+    import torch.distributed as dist
+    rank, local_rank, world = env_rank()
+    if world <= 1 or dist.is_initialized():
+        return rank, local_rank, world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    if backend is None:
+        import torch
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def replica_seed(base_seed, rank):
+    """Distinct, reproducible Philox keys per replica."""
+    return (int(base_seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+def gather_decisions(accept, iteration, log_accept, protocol_work, correction=0.0, device=None):
+    """All-gather of {accept, iter, log_accept, protocol_work, correction} -> (world, 5) float64 array on every rank."""
+    import torch
+    import torch.distributed as dist
+    rec = torch.tensor([float(bool(accept)), float(iteration), float(log_accept), float(protocol_work), float(correction)], dtype=torch.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec.numpy().reshape(1, -1)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    rec = rec.to(device)
+    out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, rec)
+    return torch.stack(out).cpu().numpy()
+
+
+def acceptance_summary(records):
+    r = np.asarray(records, dtype=np.float64).reshape(-1, len(RECORD_FIELDS))
+    return {"replicas": int(r.shape[0]), "accepted": int(r[:, 0].sum()), "mean_log_accept": float(np.nanmean(r[:, 2])),
+            "mean_work_kj": float(np.nanmean(r[:, 3]))}

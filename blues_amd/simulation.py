@@ -1,0 +1,215 @@
+"""Host-side driver of one BLUES iteration around the native engine: the NCMC leg and the
+Metropolis step of blues.simulation.BLUESSimulation (reference blues/simulation.py:812-1257).
+
+Method names, state-table layout, hook order and error policy follow the reference so that
+its tests read the same; the difference is below `_ncmc_sim.step`: the reference pays one
+Python->OpenMM round trip and ~40 CustomIntegrator sub-steps per NCMC step
+(simulation.py:1066-1082), here the steps between two move hooks are one device-resident
+`step(n)` call.
+"""
+import logging
+import math
+import sys
+
+import numpy as np
+
+from . import unit
+
+logger = logging.getLogger(__name__)
+rtol = 6  # reference blues/simulation.py:26-27
+
+
+class SimulationSet(object):
+    """The `simulations` object BLUESSimulation expects: attributes md, alch, ncmc
+    (reference blues/simulation.py:768-809).  md / alch may be None: the MD leg is then skipped
+    and the alchemical-correction energies are taken from the NCMC engine at lambda=1, which is
+    exactly the MD potential in the direct-space-only model."""
+
+    def __init__(self, ncmc, md=None, alch=None):
+        self.ncmc, self.md, self.alch = ncmc, md, alch
+
+
+class BLUESSimulation(object):
+    def __init__(self, simulations, config=None, move_engine=None):
+        self._move_engine = move_engine if move_engine is not None else getattr(simulations, "_move_engine", None)
+        self._md_sim = simulations.md
+        self._alch_sim = simulations.alch
+        self._ncmc_sim = simulations.ncmc
+        self._config = config or {}
+        self.accept = 0
+        self.reject = 0
+        self.acceptRatio = 0
+        self.currentIter = 0
+        self.stateTable = {'md': {'state0': {}, 'state1': {}}, 'ncmc': {'state0': {}, 'state1': {}}}
+        self._integrator_keys_ = ['lambda', 'shadow_work', 'protocol_work', 'Eold', 'Enew']
+        self._state_keys = {'getPositions': True, 'getVelocities': True, 'getForces': False, 'getEnergy': True,
+                            'getParameters': True, 'enforcePeriodicBox': True}
+        self.last = {}
+
+    # ---- reference blues/simulation.py:883-963
+    @classmethod
+    def getStateFromContext(cls, context, state_keys):
+        stateinfo = {}
+        state = context.getState(**state_keys)
+        stateinfo['positions'] = state.getPositions(asNumpy=True)
+        stateinfo['velocities'] = state.getVelocities(asNumpy=True)
+        stateinfo['potential_energy'] = state.getPotentialEnergy()
+        stateinfo['kinetic_energy'] = state.getKineticEnergy()
+        stateinfo['box_vectors'] = state.getPeriodicBoxVectors()
+        return stateinfo
+
+    @classmethod
+    def getIntegratorInfo(cls, ncmc_integrator, integrator_keys=('lambda', 'shadow_work', 'protocol_work', 'Eold', 'Enew')):
+        return {key: ncmc_integrator.getGlobalVariableByName(key) for key in integrator_keys}
+
+    @classmethod
+    def setContextFromState(cls, context, state, box=True, positions=True, velocities=True):
+        if box:
+            context.setPeriodicBoxVectors(*state['box_vectors'])
+        if positions:
+            context.setPositions(state['positions'])
+        if velocities:
+            context.setVelocities(state['velocities'])
+        return context
+
+    def _setStateTable(self, simkey, stateidx, stateinfo):
+        self.stateTable[simkey][stateidx] = stateinfo
+
+    # ---- reference blues/simulation.py:1028-1037
+    def _syncStatesMDtoNCMC(self):
+        src = self._md_sim if self._md_sim is not None else self._ncmc_sim
+        md_state0 = self.getStateFromContext(src.context, self._state_keys)
+        if self._md_sim is None:
+            # no MD context: the MD potential at x0 is the NCMC potential at lambda = 1
+            md_state0['potential_energy'] = unit.Quantity(self._energy_at_lambda_one(), "kilojoule/mole")
+        self._setStateTable('md', 'state0', md_state0)
+        if self._md_sim is not None:
+            self._ncmc_sim.context = self.setContextFromState(self._ncmc_sim.context, md_state0)
+
+    def _energy_at_lambda_one(self):
+        ctx = self._ncmc_sim.context
+        ls, le = ctx.getParameter("lambda_sterics"), ctx.getParameter("lambda_electrostatics")
+        ctx.setParameter("lambda_sterics", 1.0); ctx.setParameter("lambda_electrostatics", 1.0)
+        e = ctx.getState(getEnergy=True).getPotentialEnergy()._value
+        ctx.setParameter("lambda_sterics", ls); ctx.setParameter("lambda_electrostatics", le)
+        return e
+
+    # ---- reference blues/simulation.py:1039-1098
+    def _stepNCMC(self, nstepsNC, moveStep, move_engine=None):
+        logger.info('Advancing %i NCMC switching steps...' % (nstepsNC))
+        ncmc_state0 = self.getStateFromContext(self._ncmc_sim.context, self._state_keys)
+        self._setStateTable('ncmc', 'state0', ncmc_state0)
+        if not move_engine:
+            move_engine = self._move_engine
+        self._ncmc_sim.currentIter = self.currentIter
+        move_engine.selectMove()
+        nstepsNC = int(nstepsNC)
+        # the reference steps one at a time and tests `step == 0`, `step == moveStep`, `step == lastStep`
+        # around each integrator step; the same hook order with the steps in between fused:
+        cuts = sorted(set([0, int(moveStep), nstepsNC]))
+        try:
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                if a == 0:
+                    self._ncmc_sim.context = move_engine.selected_move.beforeMove(self._ncmc_sim.context)
+                if a == moveStep:
+                    logger.info('Performing %s...' % move_engine.move_name)
+                    self._ncmc_sim.context = move_engine.runEngine(self._ncmc_sim.context)
+                if b > a:
+                    self._ncmc_sim.step(b - a)
+                if b == nstepsNC:
+                    self._ncmc_sim.context = move_engine.selected_move.afterMove(self._ncmc_sim.context)
+        except Exception as e:  # reference policy: log, let the move clean up, abandon the switch
+            import traceback
+            traceback.print_tb(e.__traceback__)
+            logger.error(e)
+            move_engine.selected_move._error(self._ncmc_sim.context)
+        ncmc_state1 = self.getStateFromContext(self._ncmc_sim.context, self._state_keys)
+        self._setStateTable('ncmc', 'state1', ncmc_state1)
+
+    # ---- reference blues/simulation.py:1100-1119
+    def _computeAlchemicalCorrection(self):
+        md_state0_PE = self.stateTable['md']['state0']['potential_energy']
+        ncmc_state0_PE = self.stateTable['ncmc']['state0']['potential_energy']
+        ncmc_state1 = self.stateTable['ncmc']['state1']
+        ncmc_state1_PE = ncmc_state1['potential_energy']
+        if self._alch_sim is not None:
+            self._alch_sim.context = self.setContextFromState(self._alch_sim.context, ncmc_state1, velocities=False)
+            alch_PE = self._alch_sim.context.getState(getEnergy=True).getPotentialEnergy()
+        else:
+            alch_PE = unit.Quantity(self._energy_at_lambda_one(), "kilojoule/mole")
+        kT = self._ncmc_sim.context._integrator.kT
+        correction_factor = (ncmc_state0_PE - md_state0_PE + alch_PE - ncmc_state1_PE) * (-1.0 / kT)
+        return correction_factor
+
+    # ---- reference blues/simulation.py:1121-1166
+    def _acceptRejectMove(self, write_move=False):
+        work_ncmc = self._ncmc_sim.context._integrator.getLogAcceptanceProbability(self._ncmc_sim.context)
+        randnum = math.log(np.random.random())
+        correction_factor = 0.0
+        if not np.isnan(work_ncmc):
+            correction_factor = self._computeAlchemicalCorrection()
+            logger.debug('NCMCLogAcceptanceProbability = %.6f + Alchemical Correction = %.6f' % (work_ncmc, correction_factor))
+            work_ncmc = work_ncmc + correction_factor
+        accepted = bool(work_ncmc > randnum)
+        self.last = {'accept': accepted, 'log_accept': float(work_ncmc), 'correction': float(correction_factor), 'randnum': randnum,
+                     'protocol_work': self._ncmc_sim.context._integrator.getGlobalVariableByName('protocol_work')}
+        if accepted:
+            self.accept += 1
+            logger.info('NCMC MOVE ACCEPTED: work_ncmc {} > randnum {}'.format(work_ncmc, randnum))
+            if self._md_sim is not None:
+                ncmc_state1 = self.stateTable['ncmc']['state1']
+                self._md_sim.context = self.setContextFromState(self._md_sim.context, ncmc_state1, velocities=False)
+        else:
+            self.reject += 1
+            logger.info('NCMC MOVE REJECTED: work_ncmc {} < {}'.format(work_ncmc, randnum))
+            if self._md_sim is not None:
+                md_state0 = self.stateTable['md']['state0']
+                md_PE = self._md_sim.context.getState(getEnergy=True).getPotentialEnergy()
+                if not math.isclose(md_state0['potential_energy']._value, md_PE._value, rel_tol=float('1e-%s' % rtol)):
+                    logger.error('Last MD potential energy %s != Current MD potential energy %s. Potential energy should match the prior state.'
+                                 % (md_state0['potential_energy'], md_PE))
+                    sys.exit(1)
+            else:
+                # no separate MD context: restore the pre-switch state in place
+                st0 = self.stateTable['ncmc']['state0']
+                self._ncmc_sim.context = self.setContextFromState(self._ncmc_sim.context, st0)
+
+    # ---- reference blues/simulation.py:1168-1187
+    def _resetSimulations(self, temperature=None):
+        if not temperature:
+            temperature = self._ncmc_sim.context._integrator.getTemperature()
+        self._ncmc_sim.currentStep = 0
+        self._ncmc_sim.context._integrator.reset()
+        target = self._md_sim if self._md_sim is not None else self._ncmc_sim
+        target.context.setVelocitiesToTemperature(temperature)
+
+    # ---- reference blues/simulation.py:1189-1213
+    def _stepMD(self, nstepsMD):
+        if self._md_sim is None or not nstepsMD:
+            return
+        logger.info('Advancing %i MD steps...' % (nstepsMD))
+        self._md_sim.currentIter = self.currentIter
+        try:
+            self._md_sim.step(int(nstepsMD))
+        except Exception as e:
+            logger.error(e, exc_info=True)
+            sys.exit(1)
+
+    # ---- reference blues/simulation.py:1215-1257
+    def run(self, nIter=0, nstepsNC=0, moveStep=0, nstepsMD=0, temperature=300, write_move=False, **config):
+        if not nIter: nIter = self._config['nIter']
+        if not nstepsNC: nstepsNC = self._config['nstepsNC']
+        if not nstepsMD: nstepsMD = self._config.get('nstepsMD', 0)
+        if not moveStep: moveStep = self._config['moveStep']
+        logger.info('Running %i BLUES iterations...' % (nIter))
+        for N in range(int(nIter)):
+            self.currentIter = N
+            logger.info('BLUES Iteration: %s' % N)
+            self._syncStatesMDtoNCMC()
+            self._stepNCMC(nstepsNC, moveStep)
+            self._acceptRejectMove(write_move)
+            self._resetSimulations(temperature)
+            self._stepMD(nstepsMD)
+        self.acceptRatio = self.accept / float(nIter)
+        logger.info('Acceptance Ratio: %s' % self.acceptRatio)
+        logger.info('nIter: %s ' % nIter)

@@ -53,6 +53,8 @@ class Quantity(object):
     def __neg__(self): return Quantity(-self._value, self.unit)
 
     def __mul__(self, o):
+        if isinstance(o, _Reciprocal):
+            return o.num * (self / o.q)
         if isinstance(o, Quantity):
             if _UNITS[o.unit][1] == "1":
                 return Quantity(self._value * o._value, self.unit)

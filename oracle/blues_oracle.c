@@ -535,31 +535,94 @@ double orc_kinetic_energy(Oracle *o) {
     return ke;
 }
 
-/* ------------------------------------------------------------------ constraints (cluster-local SHAKE / RATTLE) */
+/* ------------------------------------------------------------------ constraints
+ * Cluster-local solves (HBonds / rigid water couple at most 4 atoms through at most 3 constraints):
+ *   velocities (RATTLE): the condition (v_i - v_j).r_ij = 0 is linear in the multipliers -> one k x k solve;
+ *   positions  (SHAKE):  Newton on the k multipliers with displacement directions taken from the last
+ *                        constrained geometry (xref), as OpenMM's constraint kernels do; iterated until
+ *                        |r^2 - d^2| <= 2 tol d^2 (tol from blues/integrators.py:104) plus one polishing
+ *                        iteration, so the result is converged far below the tolerance.
+ * Clusters with more than 3 constraints fall back to Gauss-Seidel sweeps. */
+static int solve_small(int n, double M[3][3], const double b[3], double x[3]) {
+    if (n == 1) { x[0] = b[0] / M[0][0]; return 0; }
+    if (n == 2) {
+        double det = M[0][0] * M[1][1] - M[0][1] * M[1][0];
+        x[0] = (b[0] * M[1][1] - M[0][1] * b[1]) / det;
+        x[1] = (M[0][0] * b[1] - b[0] * M[1][0]) / det;
+        return 0;
+    }
+    double c00 = M[1][1] * M[2][2] - M[1][2] * M[2][1], c01 = M[1][2] * M[2][0] - M[1][0] * M[2][2], c02 = M[1][0] * M[2][1] - M[1][1] * M[2][0];
+    double det = M[0][0] * c00 + M[0][1] * c01 + M[0][2] * c02;
+    double inv = 1.0 / det;
+    x[0] = (b[0] * c00 + b[1] * (M[0][2] * M[2][1] - M[0][1] * M[2][2]) + b[2] * (M[0][1] * M[1][2] - M[0][2] * M[1][1])) * inv;
+    x[1] = (b[0] * c01 + b[1] * (M[0][0] * M[2][2] - M[0][2] * M[2][0]) + b[2] * (M[0][2] * M[1][0] - M[0][0] * M[1][2])) * inv;
+    x[2] = (b[0] * c02 + b[1] * (M[0][1] * M[2][0] - M[0][0] * M[2][1]) + b[2] * (M[0][0] * M[1][1] - M[0][1] * M[1][0])) * inv;
+    return 0;
+}
+
+/* coupling coefficient of multiplier c2 in constraint c: w_i s(c2,i) - w_j s(c2,j) */
+static inline double coupling(const Oracle *o, int c, int c2) {
+    int i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1], i2 = o->cons_atoms[2 * c2], j2 = o->cons_atoms[2 * c2 + 1];
+    double si = (i == i2) - (i == j2), sj = (j == i2) - (j == j2);
+    return si / o->mass[i] - sj / o->mass[j];
+}
+
+static int shake_gauss_seidel(Oracle *o, int cl) {
+    int it;
+    for (it = 0; it < 500; it++) {
+        int done = 1;
+        for (int q = o->cluster_start[cl]; q < o->cluster_start[cl + 1]; q++) {
+            int c = o->cluster_cons[q], i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1];
+            double d2 = o->cons_dist[c] * o->cons_dist[c];
+            double rp[3] = {o->x[3 * i] - o->x[3 * j], o->x[3 * i + 1] - o->x[3 * j + 1], o->x[3 * i + 2] - o->x[3 * j + 2]};
+            min_image(o, rp);
+            double diff = d2 - dot(rp, rp);
+            if (fabs(diff) <= 2.0 * o->tol * d2) continue;
+            done = 0;
+            double r[3] = {o->xref[3 * i] - o->xref[3 * j], o->xref[3 * i + 1] - o->xref[3 * j + 1], o->xref[3 * i + 2] - o->xref[3 * j + 2]};
+            min_image(o, r);
+            double wi = 1.0 / o->mass[i], wj = 1.0 / o->mass[j];
+            double delta = diff / (2.0 * dot(rp, r) * (wi + wj));
+            for (int k = 0; k < 3; k++) { o->x[3 * i + k] += wi * delta * r[k]; o->x[3 * j + k] -= wj * delta * r[k]; }
+        }
+        if (done) break;
+    }
+    return it == 500;
+}
+
 static int constrain_positions(Oracle *o) {
-    /* directions from xref (positions at the last constrain), as OpenMM's constraint kernels use */
     int fail = 0;
     for (int cl = 0; cl < o->n_clusters; cl++) {
-        int it;
-        for (it = 0; it < 500; it++) {
-            int done = 1;
-            for (int q = o->cluster_start[cl]; q < o->cluster_start[cl + 1]; q++) {
-                int c = o->cluster_cons[q], i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1];
-                double d2 = o->cons_dist[c] * o->cons_dist[c];
-                double rp[3] = {o->x[3 * i] - o->x[3 * j], o->x[3 * i + 1] - o->x[3 * j + 1], o->x[3 * i + 2] - o->x[3 * j + 2]};
-                min_image(o, rp);
-                double diff = d2 - dot(rp, rp);
-                if (fabs(diff) <= 2.0 * o->tol * d2) continue;
-                done = 0;
-                double r[3] = {o->xref[3 * i] - o->xref[3 * j], o->xref[3 * i + 1] - o->xref[3 * j + 1], o->xref[3 * i + 2] - o->xref[3 * j + 2]};
-                min_image(o, r);
-                double wi = 1.0 / o->mass[i], wj = 1.0 / o->mass[j];
-                double delta = diff / (2.0 * dot(rp, r) * (wi + wj));
-                for (int k = 0; k < 3; k++) { o->x[3 * i + k] += wi * delta * r[k]; o->x[3 * j + k] -= wj * delta * r[k]; }
-            }
-            if (done) break;
+        const int q0 = o->cluster_start[cl], nc = o->cluster_start[cl + 1] - q0;
+        if (nc > 3) { fail |= shake_gauss_seidel(o, cl); continue; }
+        double r[3][3];
+        for (int a = 0; a < nc; a++) {
+            int c = o->cluster_cons[q0 + a], i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1];
+            for (int k = 0; k < 3; k++) r[a][k] = o->xref[3 * i + k] - o->xref[3 * j + k];
+            min_image(o, r[a]);
         }
-        if (it == 500) fail = 1;
+        int it;
+        for (it = 0; it < 50; it++) {
+            double D[3][3], g[3], J[3][3], dl[3];
+            int conv = 1;
+            for (int a = 0; a < nc; a++) {
+                int c = o->cluster_cons[q0 + a], i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1];
+                double d2 = o->cons_dist[c] * o->cons_dist[c];
+                for (int k = 0; k < 3; k++) D[a][k] = o->x[3 * i + k] - o->x[3 * j + k];
+                min_image(o, D[a]);
+                g[a] = -(dot(D[a], D[a]) - d2);
+                if (fabs(g[a]) > 2.0 * o->tol * d2) conv = 0;
+            }
+            for (int a = 0; a < nc; a++) for (int b = 0; b < nc; b++)
+                J[a][b] = 2.0 * dot(D[a], r[b]) * coupling(o, o->cluster_cons[q0 + a], o->cluster_cons[q0 + b]);
+            solve_small(nc, J, g, dl);
+            for (int b = 0; b < nc; b++) {
+                int c = o->cluster_cons[q0 + b], i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1];
+                for (int k = 0; k < 3; k++) { o->x[3 * i + k] += dl[b] * r[b][k] / o->mass[i]; o->x[3 * j + k] -= dl[b] * r[b][k] / o->mass[j]; }
+            }
+            if (conv) break; /* the update just applied was the polishing iteration */
+        }
+        if (it == 50) fail = 1;
     }
     memcpy(o->xref, o->x, sizeof(double) * 3 * o->n);
     o->xver++;
@@ -568,20 +631,39 @@ static int constrain_positions(Oracle *o) {
 
 static void constrain_velocities(Oracle *o) {
     for (int cl = 0; cl < o->n_clusters; cl++) {
-        for (int it = 0; it < 500; it++) {
-            int done = 1;
-            for (int q = o->cluster_start[cl]; q < o->cluster_start[cl + 1]; q++) {
-                int c = o->cluster_cons[q], i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1];
-                double r[3] = {o->x[3 * i] - o->x[3 * j], o->x[3 * i + 1] - o->x[3 * j + 1], o->x[3 * i + 2] - o->x[3 * j + 2]};
-                min_image(o, r);
-                double rv[3] = {o->v[3 * i] - o->v[3 * j], o->v[3 * i + 1] - o->v[3 * j + 1], o->v[3 * i + 2] - o->v[3 * j + 2]};
-                double wi = 1.0 / o->mass[i], wj = 1.0 / o->mass[j];
-                double delta = -dot(rv, r) / (dot(r, r) * (wi + wj));
-                if (fabs(delta) <= o->tol) continue;
-                done = 0;
-                for (int k = 0; k < 3; k++) { o->v[3 * i + k] += wi * delta * r[k]; o->v[3 * j + k] -= wj * delta * r[k]; }
+        const int q0 = o->cluster_start[cl], nc = o->cluster_start[cl + 1] - q0;
+        if (nc > 3) {
+            for (int it = 0; it < 500; it++) {
+                int done = 1;
+                for (int q = q0; q < q0 + nc; q++) {
+                    int c = o->cluster_cons[q], i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1];
+                    double r[3] = {o->x[3 * i] - o->x[3 * j], o->x[3 * i + 1] - o->x[3 * j + 1], o->x[3 * i + 2] - o->x[3 * j + 2]};
+                    min_image(o, r);
+                    double rv[3] = {o->v[3 * i] - o->v[3 * j], o->v[3 * i + 1] - o->v[3 * j + 1], o->v[3 * i + 2] - o->v[3 * j + 2]};
+                    double wi = 1.0 / o->mass[i], wj = 1.0 / o->mass[j];
+                    double delta = -dot(rv, r) / (dot(r, r) * (wi + wj));
+                    if (fabs(delta) <= o->tol) continue;
+                    done = 0;
+                    for (int k = 0; k < 3; k++) { o->v[3 * i + k] += wi * delta * r[k]; o->v[3 * j + k] -= wj * delta * r[k]; }
+                }
+                if (done) break;
             }
-            if (done) break;
+            continue;
+        }
+        double r[3][3], M[3][3], b[3], mu[3];
+        for (int a = 0; a < nc; a++) {
+            int c = o->cluster_cons[q0 + a], i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1];
+            double rv[3];
+            for (int k = 0; k < 3; k++) { r[a][k] = o->x[3 * i + k] - o->x[3 * j + k]; rv[k] = o->v[3 * i + k] - o->v[3 * j + k]; }
+            min_image(o, r[a]);
+            b[a] = -dot(rv, r[a]);
+        }
+        for (int a = 0; a < nc; a++) for (int c2 = 0; c2 < nc; c2++)
+            M[a][c2] = dot(r[a], r[c2]) * coupling(o, o->cluster_cons[q0 + a], o->cluster_cons[q0 + c2]);
+        solve_small(nc, M, b, mu);
+        for (int a = 0; a < nc; a++) {
+            int c = o->cluster_cons[q0 + a], i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1];
+            for (int k = 0; k < 3; k++) { o->v[3 * i + k] += mu[a] * r[a][k] / o->mass[i]; o->v[3 * j + k] -= mu[a] * r[a][k] / o->mass[j]; }
         }
     }
 }

@@ -1,0 +1,89 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def tol_box():
+    from blues_amd import systems
+    return systems.toluene_box()
+
+
+@pytest.fixture(scope="session")
+def known_answers():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")) as fh:
+        return json.load(fh)
+
+
+class OracleBackedEngine:
+    """TEST DOUBLE with NativeEngine's interface on top of the CPU oracle, so the host-side driver
+    (context.py / simulation.py / moves.py) can be exercised without a GPU.  Never used by the product."""
+
+    def __init__(self, system, integrator_data, device=0):
+        from oracle import oracle
+        self._o = oracle.Oracle(system, integrator_data)
+        self.n = system.n_atoms
+        self.system, self.integrator = system, integrator_data
+        self._box = np.diag(np.asarray(system.box, dtype=float).reshape(-1)[:3]) if np.size(system.box) == 3 else np.asarray(system.box).reshape(3, 3)
+        self._unpert = None
+        self._edited = False
+
+    def set_positions(self, x):
+        o = self._o
+        if 0 < o.get_global("step") < o.get_global("nsteps"):
+            pass  # the oracle tracks unperturbed_pe itself
+        o.set_positions(x)
+
+    def set_velocities(self, v): self._o.set_velocities(v)
+    def get_positions(self): return self._o.get_positions()
+    def get_velocities(self): return self._o.get_velocities()
+    def get_forces(self): return self._o.get_forces()
+    def get_box(self): return self._box.copy()
+    def set_box(self, b): self._box = np.diag(np.asarray(b, dtype=float).reshape(-1)[:3]) if np.size(b) == 3 else np.asarray(b).reshape(3, 3); self._o.set_box(np.diag(self._box))
+    def set_velocities_to_temperature(self, T, seed=0): self._o.set_velocities_to_temperature(T, seed)
+    def potential_energy(self): return self._o.potential_energy()
+    def kinetic_energy(self): return self._o.kinetic_energy()
+    def step(self, n=1): self._o.step(n)
+    def run_switch(self, n, trace=False):
+        w = []
+        for _ in range(int(n)):
+            self._o.step(1); w.append(self._o.get_global("protocol_work"))
+        return np.array(w) if trace else None
+    def get_global(self, name): return self._o.get_global(name)
+    def set_global(self, name, value): self._o.set_global(name, value)
+    def reset(self): self._o.reset()
+    def close(self): pass
+
+
+@pytest.fixture()
+def oracle_backed_context(monkeypatch):
+    """Routes blues_amd.context.NativeEngine to the oracle-backed test double."""
+    from blues_amd import context
+    monkeypatch.setattr(context, "NativeEngine", OracleBackedEngine)
+    return context
+
+
+def gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

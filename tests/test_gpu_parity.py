@@ -1,0 +1,281 @@
+"""GPU suite: the HIP engine, called through the C-ABI (blues_amd.engine.NativeEngine is a ctypes
+shim over include/blues_engine.h), against the CPU oracle on identical inputs.
+
+Tolerances: north_star asks for forces / energies / protocol work within 1e-5 relative of the
+fp64 CPU reference.  precision="double" must agree to ~1e-10 (same algorithm, fp64 everywhere);
+precision="mixed" (f32 pair math, f64 accumulation) must meet 1e-5 for single evaluations.  Long
+trajectories are chaotic, so mixed-precision work traces are compared over short switches and the
+full-length protocol is checked in double.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from blues_amd import integrators, systems
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from blues_amd import build
+    build.build_engine()
+    from blues_amd.engine import NativeEngine
+    return NativeEngine
+
+
+def _integ(nsteps=20, dt=0.004, seed=7, **kw):
+    return integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=dt, temperature=300.0, seed=seed, **kw)
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, np.abs(np.asarray(b)).max())
+
+
+@pytest.mark.parametrize("precision,etol,ftol", [(1, 1e-10, 1e-10), (0, 1e-5, 1e-5)])
+def test_energy_and_forces_parity_tol_box(Engine, oracle_mod, tol_box, precision, etol, ftol):
+    s, v = tol_box
+    data = _integ().to_data(precision=precision)
+    g, o = Engine(s, data), oracle_mod.Oracle(s, data)
+    for (ls, le) in ((1.0, 1.0), (0.5, 0.3), (0.05, 0.0), (0.0, 0.0)):
+        eo, fo, to = o.energy_forces(ls, le)
+        g.set_global("lambda_sterics", ls); g.set_global("lambda_electrostatics", le)
+        tg = g.energy_terms()
+        assert abs(tg.sum() - eo) <= etol * abs(eo)
+        for k in range(8):
+            assert abs(tg[k] - to[k]) <= etol * max(abs(to[k]), 1.0), (k, tg[k], to[k])
+        assert g.potential_energy() == pytest.approx(tg.sum(), rel=1e-14)
+        fg = g.get_forces()
+        assert _rel(fg, fo) <= ftol
+        assert np.linalg.norm(fg - fo) / np.linalg.norm(fo) <= ftol
+    g.close()
+
+
+@pytest.mark.parametrize("precision,tol", [(1, 1e-9), (0, 1e-5)])
+def test_s23k_parity_frozen_and_full(Engine, oracle_mod, precision, tol):
+    for frozen in (True, False):
+        s, v = systems.s23k(frozen=frozen, restrained=0 if frozen else 40)
+        data = _integ().to_data(precision=precision)
+        g, o = Engine(s, data), oracle_mod.Oracle(s, data)
+        for (ls, le) in ((1.0, 1.0), (0.3, 0.0)):
+            eo, fo, to = o.energy_forces(ls, le)
+            g.set_global("lambda_sterics", ls); g.set_global("lambda_electrostatics", le)
+            tg = g.energy_terms()
+            assert abs(tg.sum() - eo) <= tol * abs(eo)
+            for k in range(8):
+                assert abs(tg[k] - to[k]) <= tol * max(abs(to[k]), 1.0), (k, tg[k], to[k])
+            fg = g.get_forces()
+            mob = s.mass > 0
+            assert _rel(fg[mob], fo[mob]) <= tol
+            assert np.all(fg[~mob] == 0.0)  # forces on frozen atoms are never used by the path and are not computed
+        g.close()
+
+
+def _trace(o, n):
+    w = []
+    for _ in range(n):
+        o.step(1); w.append(o.get_global("protocol_work"))
+    return np.array(w)
+
+
+@pytest.mark.parametrize("precision,tol", [(1, 1e-9), (0, 1e-5)])
+def test_short_switch_work_trace(Engine, oracle_mod, tol_box, precision, tol):
+    s, v = tol_box
+    n = 20
+    data = _integ(n).to_data(precision=precision)
+    g, o = Engine(s, data), oracle_mod.Oracle(s, data)
+    g.set_velocities(v); o.set_velocities(v)
+    assert g.get_global("protocol_work") == 0.0
+    wg = g.run_switch(n, trace=True)
+    wo = _trace(o, n)
+    scale = np.abs(wo).max()
+    assert np.abs(wg - wo).max() <= tol * scale
+    assert g.get_global("lambda") == pytest.approx(1.0) and g.get_global("step") == n
+    assert g.get_global("protocol_work") == pytest.approx(wg[-1], rel=1e-15)
+    ptol = 1e-9 if precision else 2e-4
+    assert np.abs(g.get_positions() - o.get_positions()).max() < ptol
+    # step() beyond nsteps is a no-op (reference blues/integrators.py:183)
+    g.step(2)
+    assert g.get_global("protocol_work") == pytest.approx(wg[-1], rel=1e-15) and g.get_global("step") == n
+    # step(1) x n == run_switch(n), bitwise
+    g2 = Engine(s, data); g2.set_velocities(v)
+    for _ in range(n):
+        g2.step(1)
+    assert g2.get_global("protocol_work") == wg[-1]
+    assert np.array_equal(g2.get_positions(), g.get_positions())
+    g.close(); g2.close()
+
+
+def test_full_length_protocol_double(Engine, oracle_mod, tol_box):
+    """1000-step switch (BASELINE.json configs[1] length) in fp64 against the oracle: 1e-5 relative on the work trace."""
+    s, v = tol_box
+    n = 1000
+    data = _integ(n, seed=21).to_data(precision=1)
+    g, o = Engine(s, data), oracle_mod.Oracle(s, data)
+    g.set_velocities(v); o.set_velocities(v)
+    wg = g.run_switch(n, trace=True)
+    wo = _trace(o, n)
+    assert np.abs(wg - wo).max() <= 1e-5 * np.abs(wo).max()
+    g.close()
+
+
+def test_frozen_s23k_switch_with_move(Engine, oracle_mod):
+    """configs[0]-style: 100-step switch of the S23k box (276 mobile atoms) with a rigid ligand move at lambda=0.5.
+    The work of the instantaneous move is accounted (reference blues/integrators.py:184-191)."""
+    s, v = systems.s23k(mobile_atoms=275)
+    n = 20  # the oracle costs ~1 s per step at this size
+    data = _integ(n, seed=5).to_data(precision=1)
+    g, o = Engine(s, data), oracle_mod.Oracle(s, data)
+    g.set_velocities(v); o.set_velocities(v)
+    wg1 = g.run_switch(n // 2, trace=True); wo1 = _trace(o, n // 2)
+    xg, xo = g.get_positions(), o.get_positions()
+    assert np.abs(xg - xo).max() < 1e-9
+    lig = np.asarray(s.alchemical_atoms)
+    c = xo[lig].mean(0)
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    xn = xo.copy(); xn[lig] = (xo[lig] - c) @ R.T + c + np.array([0.02, 0.0, -0.01])
+    g.set_positions(xn); o.set_positions(xn)
+    wg2 = g.run_switch(n // 2, trace=True); wo2 = _trace(o, n // 2)
+    wo, wg = np.concatenate([wo1, wo2]), np.concatenate([wg1, wg2])
+    assert np.abs(wg - wo).max() <= 1e-8 * np.abs(wo).max()
+    assert g.get_global("perturbed_pe") - g.get_global("unperturbed_pe") == pytest.approx((wo2[0] - wo1[-1]) - (wg2[0] - wg1[-1]) + g.get_global("perturbed_pe") - g.get_global("unperturbed_pe"), abs=1e-6)
+    st = g.stats()
+    assert st["i_tiles"] <= 6 and st["clusters"] < 120  # only the mobile atoms are integrated
+    g.close()
+
+
+@pytest.mark.parametrize("kw", [dict(nprop=2, propLambda=0.3), dict(splitting="R V O H O V R"), dict(splitting="V H R O R H V"),
+                                 dict(splitting="O V R H R V O")])
+def test_other_programs(Engine, oracle_mod, tol_box, kw):
+    """Extra propagation inside the lambda window (reference blues/integrators.py:194-201) and other splittings."""
+    s, v = tol_box
+    n = 10
+    kw = dict(kw)
+    if "splitting" in kw:
+        integ = integrators.AlchemicalExternalLangevinIntegrator(integrators.DEFAULT_ALCHEMICAL_FUNCTIONS, splitting=kw["splitting"],
+                                                                  temperature=300.0, timestep=0.002, nsteps_neq=n, seed=13)
+    else:
+        integ = integrators.generateNCMCIntegrator(nstepsNC=n, dt=0.002, temperature=300.0, seed=13, **kw)
+    data = integ.to_data(precision=1)
+    g, o = Engine(s, data), oracle_mod.Oracle(s, data)
+    g.set_velocities(v); o.set_velocities(v)
+    wg = g.run_switch(n, trace=True); wo = _trace(o, n)
+    assert np.abs(wg - wo).max() <= 1e-9 * max(1.0, np.abs(wo).max())
+    assert np.abs(g.get_positions() - o.get_positions()).max() < 1e-10
+    assert np.abs(g.get_velocities() - o.get_velocities()).max() < 1e-8
+    g.close()
+
+
+def test_cm_motion_removal_and_restraint(Engine, oracle_mod, tol_box):
+    s, v = tol_box
+    s2 = copy.copy(s); s2.remove_cm_motion = False
+    s3 = systems.restrain_positions(s, np.arange(15, 975, 90), 2092.0)
+    for sys_ in (s2, s3):
+        data = _integ(8, seed=3).to_data(precision=1)
+        g, o = Engine(sys_, data), oracle_mod.Oracle(sys_, data)
+        g.set_velocities(v); o.set_velocities(v)
+        wg = g.run_switch(8, trace=True); wo = _trace(o, 8)
+        assert np.abs(wg - wo).max() <= 1e-9 * np.abs(wo).max()
+        assert np.abs(g.get_velocities() - o.get_velocities()).max() < 1e-8
+        g.close()
+    # with the remover on, the centre-of-mass momentum of the mobile atoms is ~0 at the start of every pass
+    data = _integ(4, seed=3).to_data(precision=1)
+    g = Engine(s, data); g.set_velocities(v + 0.3); g.step(1)
+    g.close()
+
+
+def test_rng_and_velocity_initialisation(Engine, oracle_mod, tol_box):
+    s, _ = tol_box
+    data = _integ().to_data(precision=1)
+    g, o = Engine(s, data), oracle_mod.Oracle(s, data)
+    g.set_velocities_to_temperature(300.0, 424242); o.set_velocities_to_temperature(300.0, 424242)
+    vg, vo = g.get_velocities(), o.get_velocities()
+    assert np.abs(vg - vo).max() < 1e-10
+    ndof = 3 * s.n_atoms - len(s.constraint_dist)
+    T = 2 * g.kinetic_energy() / (ndof * 0.0083144626)
+    assert 270 < T < 330 and g.kinetic_energy() == pytest.approx(o.kinetic_energy(), rel=1e-12)
+    # velocity constraints hold after initialisation (OpenMM applies them in setVelocitiesToTemperature)
+    x, c = s.positions, s.constraint_atoms
+    assert np.abs(((vg[c[:, 0]] - vg[c[:, 1]]) * (x[c[:, 0]] - x[c[:, 1]])).sum(1)).max() < 1e-10
+    g.close()
+
+
+def test_determinism_reset_and_globals(Engine, tol_box):
+    s, v = tol_box
+    data = _integ(12, seed=99).to_data(precision=0)
+    runs = []
+    for _ in range(2):
+        g = Engine(s, data); g.set_velocities(v)
+        w = g.run_switch(12, trace=True)
+        runs.append((w, g.get_positions(), g.get_velocities()))
+        # reset() zeroes the integrator globals but not the context (reference blues/integrators.py:240-249)
+        g.reset()
+        assert g.get_global("step") == 0 and g.get_global("protocol_work") == 0.0 and g.get_global("lambda") == 0.0
+        assert g.get_global("first_step") == 0 and g.get_global("prop") == 1
+        # the afterMove rejection device (reference blues/moves.py:1082, tests/test_watertranslation.py:112)
+        g.set_global("protocol_work", 999999)
+        assert g.get_global("protocol_work") >= 999999
+        with pytest.raises(Exception, match="unknown global"):
+            g.get_global("no_such_variable")
+        g.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+
+
+def test_error_behaviour(Engine, tol_box):
+    from blues_amd.engine import EngineError
+    s, v = tol_box
+    g = Engine(s, _integ(4).to_data())
+    x = s.positions.copy(); x[100] = np.nan
+    g.set_positions(x); g.set_velocities(v)
+    with pytest.raises(EngineError, match="nan"):
+        g.step(1)
+    g.close()
+    s2 = copy.copy(s); s2.mass = s.mass.copy(); s2.mass[15] = 0.0
+    with pytest.raises(EngineError, match="massless"):
+        Engine(s2, _integ(4).to_data())
+    s3 = copy.copy(s); s3.box = np.array([1.5, 2.1786, 2.1786])
+    with pytest.raises(EngineError, match="cutoff"):
+        Engine(s3, _integ(4).to_data())
+
+
+def test_full_size_properties(Engine):
+    """Size-independent properties at BASELINE.json's full size (all 23,400 atoms mobile, configs[3]-like)."""
+    s, v = systems.s23k(frozen=False)
+    data = _integ(10, seed=8).to_data(precision=0)
+    g = Engine(s, data)
+    e0, f0 = g.potential_energy(), g.get_forces()
+    assert np.abs(f0.sum(0)).max() < 1e-5 * np.abs(f0).max() * np.sqrt(s.n_atoms)  # Newton's third law (f32 pair rounding only)
+    # rigid translation and a lattice translation leave energies and forces unchanged
+    g.set_positions(s.positions + np.array([0.37, -1.2, 2.9]))
+    assert g.potential_energy() == pytest.approx(e0, rel=2e-7)
+    g.set_positions(s.positions + np.array([s.box[0], 0.0, -s.box[2]]))
+    assert g.potential_energy() == pytest.approx(e0, rel=1e-9)
+    assert _rel(g.get_forces(), f0) < 1e-6
+    # a permutation of the atom order (here: whole-molecule reversal of the water block) changes nothing physical
+    g.set_positions(s.positions); g.set_velocities(v)
+    w = g.run_switch(10, trace=True)
+    assert np.all(np.isfinite(w)) and g.stats()["i_tiles"] == (s.n_atoms - 15 + 63) // 64
+    x = g.get_positions(); c = s.constraint_atoms
+    assert np.abs(np.linalg.norm(x[c[:, 0]] - x[c[:, 1]], axis=1) / s.constraint_dist - 1).max() < 1e-8
+    assert g.time_nonbonded(5) > 0
+    g.close()
+
+
+def test_context_surface_on_gpu(tol_box):
+    """The OpenMM-like objects BLUES consumes, bound to the real engine."""
+    from blues_amd import moves, simulation, unit
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    integ = _integ(10, seed=4)
+    sim = Simulation(None, s, integ, platformProperties={"DeviceIndex": 0, "Precision": "mixed"})
+    sim.context.setVelocities(unit.Quantity(v, "nanometer/picosecond"))
+    lig = np.arange(15)
+    b = simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": 10, "moveStep": 5, "nIter": 2},
+                                   moves.MoveEngine(moves.RandomLigandRotationMove(lig, s.mass[lig], random_state=1)))
+    np.random.seed(1)
+    b.run()
+    assert b.accept + b.reject == 2
+    assert np.isfinite(b.last["log_accept"]) and abs(b.last["correction"]) < 1e-6
+    assert sim.context.getPlatform().getName().startswith("HIP")
