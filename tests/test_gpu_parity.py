@@ -107,16 +107,33 @@ def test_short_switch_work_trace(Engine, oracle_mod, tol_box, precision, tol):
     g.close(); g2.close()
 
 
-def test_full_length_protocol_double(Engine, oracle_mod, tol_box):
-    """1000-step switch (BASELINE.json configs[1] length) in fp64 against the oracle: 1e-5 relative on the work trace."""
+@pytest.mark.parametrize("precision,seg,tol", [(1, 100, 1e-7), (0, 10, 1e-5)])
+def test_full_length_protocol_teacher_forced(Engine, oracle_mod, tol_box, precision, seg, tol):
+    """1000-step switch (BASELINE.json configs[1] length).  A liquid is chaotic (errors grow ~e^(7/ps t), measured),
+    so two correct fp64 implementations drift apart pointwise over 4 ps; the whole lambda protocol is therefore
+    checked segment by segment: the GPU state is re-synchronised to the oracle's at each segment start and the
+    protocol-work increments of every segment must agree to `tol` of the work scale."""
     s, v = tol_box
     n = 1000
-    data = _integ(n, seed=21).to_data(precision=1)
+    data = _integ(n, seed=21).to_data(precision=precision)
     g, o = Engine(s, data), oracle_mod.Oracle(s, data)
     g.set_velocities(v); o.set_velocities(v)
-    wg = g.run_switch(n, trace=True)
-    wo = _trace(o, n)
-    assert np.abs(wg - wo).max() <= 1e-5 * np.abs(wo).max()
+    scale, worst = 0.0, 0.0
+    wg_prev = wo_prev = 0.0
+    for start in range(0, n, seg):
+        if start:
+            g.set_positions(o.get_positions()); g.set_velocities(o.get_velocities())
+        wg = g.run_switch(seg, trace=True)
+        wo = _trace(o, seg)
+        dg = np.diff(np.concatenate([[wg_prev], wg])); do = np.diff(np.concatenate([[wo_prev], wo]))
+        if start:  # the re-sync is itself an "instantaneous move": its work U(x_oracle)-U(x_gpu) lands in the first increment
+            dg[0] -= g.get_global("perturbed_pe") - g.get_global("unperturbed_pe")
+        worst = max(worst, np.abs(np.cumsum(dg) - np.cumsum(do)).max())
+        scale = max(scale, np.abs(wo).max())
+        wg_prev, wo_prev = wg[-1], wo[-1]
+    assert scale > 10.0
+    assert worst <= tol * scale, (worst, scale)
+    assert g.get_global("lambda") == pytest.approx(1.0) and g.get_global("step") == n
     g.close()
 
 
