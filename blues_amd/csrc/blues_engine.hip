@@ -85,7 +85,7 @@ struct BluesEngine {
     std::vector<int> alch;               // caller indices
     std::vector<int> alch_local;         // [n] -> local index or -1
     int nb_method = 1; double cutoff = 1, alpha = 0, sc_alpha = 0.5;
-    int annih_elec = 1, annih_ster = 0, remove_cm = 0;
+    int annih_elec = 1, annih_ster = 0, remove_cm = 0, check_env_excl = 0;
     double skin = 0.12;
     // ---- integrator
     double dt = 0, temperature = 0, gamma = 1, kT = 0, tol = 1e-8;
@@ -115,11 +115,12 @@ struct BluesEngine {
     // ---- device buffers
     DBuf<double> d_x[3], d_v[3], d_xbuild[3], d_mass, d_charge, d_sigma, d_eps;
     DBuf<AtomF> d_img_f; DBuf<AtomD> d_img_d;
-    DBuf<int> d_sorted_of_orig, d_orig_of_sorted, d_tile_atoms, d_jlist, d_jcount, d_batch_slot, d_pool_count, d_ex_start, d_ex_idx, d_islot;
+    DBuf<int> d_sorted_of_orig, d_orig_of_sorted, d_tile_atoms, d_jlist, d_jstage, d_jcount, d_batch_slot, d_pool_count, d_ex_start, d_ex_idx, d_islot;
     DBuf<unsigned long long> d_mask_pool;
     DBuf<DevFlags> d_flags; DBuf<DevAccum> d_acc;
     DBuf<double> d_fpart, d_epart_nb, d_fJ, d_self_part, d_e_part, d_fent, d_ftot, d_alch_self, d_epart_b, d_cm_part, d_trace, d_scratch;
-    DBuf<int> d_orig_of_islot, d_row_of_orig;
+    DBuf<int> d_orig_of_islot, d_row_of_orig, d_mobile_atoms, d_mobile_index, d_exc_owner;
+    DBuf<double> d_noise; unsigned noise_draw_base = 0; int n_noise = 0; bool noise_valid = false;
     DBuf<int> d_alch_orig, d_alch_local, d_exc_start, d_exc_partner; DBuf<double> d_exc_params;
     DBuf<int> d_cl_atoms, d_cl_type, d_cl_nc; DBuf<double> d_cl_dist;
     // bonded
@@ -279,9 +280,9 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
     int total_terms = 0; for (int ty = 0; ty < T_NTYPES; ty++) total_terms += h->n_terms[ty];
     h->d_epart_b.alloc((size_t)((total_terms + 255) / 256 + 1) * T_NTYPES);
     // alchemical exception rows
-    std::vector<int> es(1, 0), ep; std::vector<double> epar;
-    for (size_t a = 0; a < h->alch.size(); a++) { ep.insert(ep.end(), arow_partner[a].begin(), arow_partner[a].end()); epar.insert(epar.end(), arow_par[a].begin(), arow_par[a].end()); es.push_back((int)ep.size()); }
-    h->d_exc_start.upload(es); h->d_exc_partner.upload(ep); h->d_exc_params.upload(epar);
+    std::vector<int> es(1, 0), ep, eo; std::vector<double> epar;
+    for (size_t a = 0; a < h->alch.size(); a++) { eo.insert(eo.end(), arow_partner[a].size(), h->alch[a]); ep.insert(ep.end(), arow_partner[a].begin(), arow_partner[a].end()); epar.insert(epar.end(), arow_par[a].begin(), arow_par[a].end()); es.push_back((int)ep.size()); }
+    h->d_exc_start.upload(es); h->d_exc_partner.upload(ep); h->d_exc_owner.upload(eo); h->d_exc_params.upload(epar);
     return 0;
 }
 
@@ -328,7 +329,7 @@ static int sort_and_tile(BluesEngine* h) {
         if (const char* e = getenv("BLUES_SEG")) CH = std::max(8, std::min(64, atoi(e)));
         int NW = std::max(1, std::min(jcap / CH, (8192 + nit - 1) / nit));
         int WPB = h->precision == 0 ? 16 : 8;
-        while (WPB > 1 && (WPB > NW || nit * (NW / WPB) < 512)) WPB >>= 1;
+        while (WPB > 1 && (WPB > NW || nit * NW / WPB < 64)) WPB >>= 1;
         if (const char* e = getenv("BLUES_WPB")) WPB = std::max(1, std::min(h->precision == 0 ? 16 : 8, atoi(e)));
         NW = std::max(WPB, (NW / WPB) * WPB);
         h->seg_len = CH; h->waves_tile = NW; h->wpb = WPB; h->npart = NW / WPB;
@@ -371,7 +372,7 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_sorted_of_orig.upload(h->h_sorted_of_orig); h->d_orig_of_sorted.upload(h->h_orig_of_sorted);
         h->d_tile_atoms.upload(tile_atoms); h->d_islot.upload(islot);
         h->d_ex_start.upload(ex_start); h->d_ex_idx.upload(ex_idx);
-        h->d_jlist.alloc((size_t)nt * jcap); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
+        h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * 4 * jcap); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
         h->d_mask_pool.alloc((size_t)h->pool_cap * 64); h->d_pool_count.alloc(1);
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
         h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 + 2 * ((n + 255) / 256));
@@ -398,6 +399,7 @@ static IntArgs make_int_args(BluesEngine* h) {
     const double hO = h->dt / std::max(1, h->n_O);
     A.aO = std::exp(-h->gamma * hO); A.bO = std::sqrt(1.0 - std::exp(-2.0 * h->gamma * hO));
     A.kT = h->kT; A.tol = h->tol; A.seed = h->seed; A.stream = (unsigned)h->replica * 4u; A.draw_base = h->prog_draw_base;
+    A.noise = h->d_noise.p; A.mobile_index = h->d_mobile_index.p; A.n_mobile = (int)h->mobile.size(); A.n_noise = h->noise_valid ? h->n_noise : 0; A.noise_draw_base = h->noise_draw_base;
     A.box = make_box(h); A.periodic = h->nb_method == BLUES_NB_PME_DIRECT;
     A.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; A.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
     A.half_skin2 = 0.25 * h->skin * h->skin; A.flags = h->d_flags.p; A.pool_count = h->d_pool_count.p;
@@ -428,14 +430,14 @@ static int emit(BluesEngine* h, int op) {
 template <typename R> static int launch_lists(BluesEngine* h, int force) {
     ListArgs a; memset(&a, 0, sizeof a);
     a.n = h->n; a.n_tiles = h->n_tiles; a.n_itiles = h->n_itiles; a.jcap = h->jcap; a.pool_cap = h->pool_cap;
-    a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p;
+    a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jstage = h->d_jstage.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p;
     a.mask_pool = h->d_mask_pool.p; a.pool_count = h->d_pool_count.p; a.ex_start = h->d_ex_start.p; a.ex_idx = h->d_ex_idx.p; a.flags = h->d_flags.p;
     for (int k = 0; k < 3; k++) { a.x[k] = h->d_x[k].p; a.xbuild[k] = h->d_xbuild[k].p; }
     a.fJ = h->d_fJ.p; a.n_fJ = 9 * h->n;
     if (force) HIP_OK(h, hipMemsetAsync(h->d_pool_count.p, 0, sizeof(int), h->stream));
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
-    hipLaunchKernelGGL(k_build_lists<R>, dim3(std::max(1, h->n_tiles)), dim3(256), 0, h->stream, a, make_nbconst<R>(h), img, force);
+    hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 32), dim3(256), 0, h->stream, a, make_nbconst<R>(h), img, force);
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -476,9 +478,9 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
     A.orig_of_sorted = h->d_orig_of_sorted.p; A.sorted_of_orig = h->d_sorted_of_orig.p;
     for (int k = 0; k < 3; k++) A.x[k] = h->d_x[k].p;
     A.charge = h->d_charge.p; A.sigma = h->d_sigma.p; A.eps = h->d_eps.p; A.ex_start = h->d_ex_start.p; A.ex_idx = h->d_ex_idx.p;
-    A.exc_start = h->d_exc_start.p; A.exc_partner = h->d_exc_partner.p; A.exc_params = h->d_exc_params.p;
+    A.exc_start = h->d_exc_start.p; A.exc_partner = h->d_exc_partner.p; A.exc_owner = h->d_exc_owner.p; A.exc_params = h->d_exc_params.p;
     A.box = make_box(h); A.rc2 = h->cutoff * h->cutoff; A.alpha = h->alpha; A.sc_alpha = h->sc_alpha;
-    A.pme = h->nb_method == BLUES_NB_PME_DIRECT; A.annih_elec = h->annih_elec; A.annih_ster = h->annih_ster; A.slot_mask = slot_mask;
+    A.pme = h->nb_method == BLUES_NB_PME_DIRECT; A.annih_elec = h->annih_elec; A.annih_ster = h->annih_ster; A.slot_mask = slot_mask; A.check_env_excl = h->check_env_excl;
     for (int s = 0; s < 3; s++) { A.ls[s] = ls[s]; A.le[s] = le[s]; }
     A.fJ = h->d_fJ.p; A.self_part = h->d_self_part.p; A.e_part = h->d_e_part.p;
     hipLaunchKernelGGL(k_alchemical, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->stream, A);
@@ -495,13 +497,20 @@ static BondedArgs make_bonded_args(BluesEngine* h) {
     B.restr_k = h->restr_k;
     for (int k = 0; k < 3; k++) B.x[k] = h->d_x[k].p;
     B.box = make_box(h); B.periodic = h->nb_method == BLUES_NB_PME_DIRECT; B.fent = h->d_fent.p; B.n_entries = h->n_entries; B.n = h->n; B.epart = h->d_epart_b.p;
+    B.n_mobile = (int)h->mobile.size(); B.n_noise = h->n_noise; B.mobile_atoms = h->d_mobile_atoms.p; B.noise = h->d_noise.p;
+    B.seed = h->seed; B.stream = (unsigned)h->replica * 4u; B.draw_base = h->h_draw; B.n_entry_blocks = (h->n_entries + 127) / 128;
     return B;
 }
 
-static int launch_bonded_and_finalize(BluesEngine* h, const double le[3]) {
-    if (h->n_entries > 0) {
-        hipLaunchKernelGGL(k_bonded_entries, dim3((h->n_entries + 127) / 128), dim3(128), 0, h->stream, make_bonded_args(h));
-        h->st_launches++;
+static int launch_bonded_and_finalize(BluesEngine* h, const double le[3], bool with_noise) {
+    {
+        BondedArgs B = make_bonded_args(h);
+        const int nb_noise = with_noise ? ((int)h->mobile.size() * h->n_noise + 127) / 128 : 0;
+        if (with_noise) { h->noise_draw_base = h->h_draw; h->noise_valid = true; }
+        if (B.n_entry_blocks + nb_noise > 0) {
+            hipLaunchKernelGGL(k_bonded_entries, dim3(B.n_entry_blocks + nb_noise), dim3(128), 0, h->stream, B);
+            h->st_launches++;
+        }
     }
     FinArgs F; memset(&F, 0, sizeof F);
     F.n = h->n; F.n_islots = h->n_islots; F.npart = h->npart; F.n_alch = (int)h->alch.size(); F.PA = h->PA; F.k2_nblocks_env = h->k2_nblocks_env; F.n_entries = h->n_entries;
@@ -510,8 +519,8 @@ static int launch_bonded_and_finalize(BluesEngine* h, const double le[3]) {
     F.self_part = h->d_self_part.p; F.e_part = h->d_e_part.p; F.jcount_alch = h->d_jcount.p + h->n_itiles;
     for (int s = 0; s < 3; s++) F.le[s] = le[s];
     F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p;
-    const int nb_atoms = (h->n_islots + F.n_alch + 255) / 256;
-    hipLaunchKernelGGL(k_finalize, dim3(nb_atoms + 1), dim3(256), 0, h->stream, F);
+    const int nblk = h->n_islots / 64 + (F.n_alch > 0 ? 1 + 9 + 1 : 0);
+    hipLaunchKernelGGL(k_finalize, dim3(std::max(1, nblk)), dim3(256), 0, h->stream, F);
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -534,7 +543,7 @@ static int force_pass(BluesEngine* h, int base_L) {
     if (launch_alchemical(h, ls, le, 7)) return 1;
     rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
     if (rc) return 1;
-    if (launch_bonded_and_finalize(h, le)) return 1;
+    if (launch_bonded_and_finalize(h, le, true)) return 1;
     h->pass_valid = true; h->pass_L = base_L; h->st_passes++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -721,6 +730,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     if (h->alch.size() > 64) E_FAIL(h, "more than 64 alchemical atoms is not supported yet");
     h->alch_local.assign(n, -1);
     for (size_t a = 0; a < h->alch.size(); a++) h->alch_local[h->alch[a]] = (int)a;
+    for (int a : h->alch) for (int p : h->excl[a]) if (h->alch_local[p] < 0) h->check_env_excl = 1;
     h->total_mass = 0.0;
     for (int i = 0; i < n; i++) if (h->mass[i] != 0.0) { h->mobile.push_back(i); h->total_mass += h->mass[i]; }
     // integrator
@@ -747,6 +757,12 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
         h->d_alch_orig.upload(h->alch); h->d_alch_local.upload(h->alch_local);
         h->d_trace.alloc((size_t)std::max(1, h->nsteps)); h->d_scratch.alloc((size_t)std::max(3 * n, 1024));
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    {
+        std::vector<int> mi(n, -1);
+        for (size_t m = 0; m < h->mobile.size(); m++) mi[h->mobile[m]] = (int)m;
+        try { h->d_mobile_atoms.upload(h->mobile); h->d_mobile_index.upload(mi); h->n_noise = std::max(1, h->n_O);
+              h->d_noise.alloc((size_t)h->n_noise * 3 * std::max<size_t>(1, h->mobile.size())); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    }
     if (build_clusters(h, s)) return 1;
     try { if (build_bonded(h, s)) return 1; } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     return 0;
@@ -885,7 +901,7 @@ int blues_get_forces(BluesEngine* h, double* out, int32_t n_atoms) {
     if (launch_alchemical(h, ls, le, 1)) return 1;
     rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
     if (rc) return 1;
-    if (launch_bonded_and_finalize(h, le)) return 1;
+    if (launch_bonded_and_finalize(h, le, false)) return 1;
     IntArgs A = make_int_args(h);
     DBuf<double> tmp;
     try { tmp.alloc((size_t)3 * h->n); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }

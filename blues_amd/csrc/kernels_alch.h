@@ -33,10 +33,12 @@ struct AlchArgs {
     // alchemical exceptions as rows per alchemical atom: partner (caller index) and parameters
     const int* exc_start;       // [n_alch+1]
     const int* exc_partner;
+    const int* exc_owner;       // caller index of the alchemical atom owning the entry
     const double* exc_params;   // [3*] chargeProd, sigma, epsilon
     Box3 box;
     double rc2, alpha, sc_alpha;
     int pme, annih_elec, annih_ster, slot_mask;
+    int check_env_excl;  // 0 when no alchemical atom has an excluded non-alchemical partner (free ligand)
     double ls[3], le[3];
     double* fJ;         // [3 slots][3][n] force on environment atoms by sorted index
     double* self_part;  // [nblocks][3 slots][3][64]
@@ -75,7 +77,7 @@ __global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) {
             double d[3];
             for (int k = 0; k < 3; k++) d[k] = min_image_d(A.x[k][ao] - A.x[k][jo], A.box.L[k], A.box.invL[k]);
             const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-            if (r2 < A.rc2 && !excluded_sorted(A.ex_start, A.ex_idx, A.sorted_of_orig[ao], jsrt)) {
+            if (r2 < A.rc2 && !(A.check_env_excl && excluded_sorted(A.ex_start, A.ex_idx, A.sorted_of_orig[ao], jsrt))) {
                 const double sig = 0.5 * (A.sigma[ao] + A.sigma[jo]), eps = sqrt(A.eps[ao] * A.eps[jo]);
                 const double qq = A.charge[ao] * A.charge[jo];
                 double fc;
@@ -140,14 +142,16 @@ __global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) {
                 }
         }
         __syncthreads();
-        // ---- exceptions that involve alchemical atoms: one thread per alchemical atom row
-        double h[3][3];
+        // ---- exceptions that involve alchemical atoms: one thread per (row, entry), rows summed from LDS in order
+        __shared__ double s_exc[9][256];
+        const int n_exc_ent = A.exc_start[A.n_alch];
+        for (int e0 = 0; e0 < n_exc_ent; e0 += 256) {
+            const int q = e0 + tid;
+            double h[3][3];
 #pragma unroll
-        for (int s = 0; s < 3; s++) { h[s][0] = h[s][1] = h[s][2] = 0.0; }
-        if (tid < A.n_alch) {
-            const int ao = A.alch_orig[tid];
-            for (int q = A.exc_start[tid]; q < A.exc_start[tid + 1]; q++) {
-                const int po = A.exc_partner[q];
+            for (int s = 0; s < 3; s++) { h[s][0] = h[s][1] = h[s][2] = 0.0; }
+            if (q < n_exc_ent) {
+                const int ao = A.exc_owner[q], po = A.exc_partner[q];
                 const double qq = A.exc_params[3 * q], sig = A.exc_params[3 * q + 1], eps = A.exc_params[3 * q + 2];
                 double d[3];
                 for (int k = 0; k < 3; k++) d[k] = min_image_d(A.x[k][ao] - A.x[k][po], A.box.L[k], A.box.invL[k]);
@@ -161,13 +165,21 @@ __global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) {
                     double fs = fl;
                     if (A.annih_ster) e[1 + s] += 0.5 * softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
                     const double ft = fs + (A.annih_elec ? A.le[s] : 1.0) * fc;
-                    h[s][0] += ft * d[0]; h[s][1] += ft * d[1]; h[s][2] += ft * d[2];
+                    h[s][0] = ft * d[0]; h[s][1] = ft * d[1]; h[s][2] = ft * d[2];
                 }
             }
 #pragma unroll
             for (int s = 0; s < 3; s++)
 #pragma unroll
-                for (int k = 0; k < 3; k++) s_self[0][s * 3 + k][tid] += h[s][k];
+                for (int k = 0; k < 3; k++) s_exc[s * 3 + k][tid] = h[s][k];
+            __syncthreads();
+            if (tid < A.n_alch) {
+                const int lo = max(A.exc_start[tid], e0), hi = min(A.exc_start[tid + 1], e0 + 256);
+                for (int u = lo; u < hi; u++)
+#pragma unroll
+                    for (int qq2 = 0; qq2 < 9; qq2++) s_self[0][qq2][tid] += s_exc[qq2][u - e0];
+            }
+            __syncthreads();
         }
         __syncthreads();
         if (tid < 64) {

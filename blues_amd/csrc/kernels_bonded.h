@@ -31,6 +31,11 @@ struct BondedArgs {
     int n_entries;
     int n;
     double* epart;   // [nblocks][T_NTYPES] (energy kernel)
+    // Gaussian noise for the next O substeps, generated here (extra blocks of the same launch) so that the
+    // log/sqrt/sincos of the Box-Muller transform are off the integrator's serial per-cluster path
+    int n_mobile, n_noise; const int* mobile_atoms; double* noise;  // noise[(d*3+k)*n_mobile + m]
+    unsigned long long seed; unsigned stream, draw_base;
+    int n_entry_blocks;
 };
 
 __device__ inline void mi3(const BondedArgs& B, double d[3]) {
@@ -117,8 +122,19 @@ __device__ inline double bonded_term(const BondedArgs& B, int type, int idx, int
     return B.restr_k * dot3(d, d);
 }
 
-// one thread per (row, entry): the force of one term on one of its mobile atoms -> fent[3][n_entries]
+// one thread per (row, entry): the force of one term on one of its mobile atoms -> fent[3][n_entries];
+// blocks past n_entry_blocks draw the N(0,1) numbers of the coming O substeps (counter-based, so they can be
+// produced before the velocities they will be applied to exist).
 __global__ void __launch_bounds__(128) k_bonded_entries(BondedArgs B) {
+    if ((int)blockIdx.x >= B.n_entry_blocks) {
+        const int g = (blockIdx.x - B.n_entry_blocks) * 128 + threadIdx.x;
+        if (g >= B.n_mobile * B.n_noise) return;
+        const int d = g / B.n_mobile, m = g - d * B.n_mobile;
+        double z[3];
+        gaussians3(B.seed, B.stream, B.draw_base + (unsigned)d, (unsigned)B.mobile_atoms[m], z);
+        for (int k = 0; k < 3; k++) B.noise[(size_t)(d * 3 + k) * B.n_mobile + m] = z[k];
+        return;
+    }
     const int e = blockIdx.x * 128 + threadIdx.x;
     if (e >= B.n_entries) return;
     double F[3];

@@ -52,6 +52,7 @@ struct IntArgs {
     // constants
     double hV, hR, aO, bO, kT, tol;
     unsigned long long seed; unsigned stream, draw_base;
+    const double* noise; const int* mobile_index; int n_mobile, n_noise; unsigned noise_draw_base;  // precomputed N(0,1), see k_bonded_entries
     Box3 box; int periodic;
     // tile image refresh + list validity
     AtomF* img_f; AtomD* img_d;
@@ -219,43 +220,70 @@ struct FinArgs {
     double* ftot; double* alch_self; DevAccum* acc;
 };
 
+// grid: [0, n_itiles) one block per i-tile | [n_itiles, +nb_alch_atoms) alchemical atoms' bonded rows |
+//       then 9 blocks (one per slot x component) for the alchemical self-force slabs | 1 block for the energies.
+// Every sum is spread over the 4 waves of a block with 4 loads in flight per lane, then combined in LDS in a
+// fixed order (deterministic, and no chain of dependent global loads).
 __global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
-    const int tid = threadIdx.x;
-    const int nb_atoms = (A.n_islots + A.n_alch + 255) / 256;
-    if ((int)blockIdx.x < nb_atoms) {
-        const int g = blockIdx.x * 256 + tid;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_itiles = A.n_islots / 64;
+    const int nb_alch_atoms = A.n_alch > 0 ? 1 : 0;
+    __shared__ double red[4][3][64];
+    int blk = blockIdx.x;
+    if (blk < n_itiles + nb_alch_atoms) {
         int i = -1, isl = -1;
-        if (g < A.n_islots) { isl = g; i = A.orig_of_islot[g]; }
-        else if (g - A.n_islots < A.n_alch) i = A.alch_orig[g - A.n_islots];
-        if (i < 0) return;
+        if (blk < n_itiles) { isl = blk * 64 + lane; i = A.orig_of_islot[isl]; }
+        else if (lane < A.n_alch) i = A.alch_orig[lane];
         double f[3] = {0.0, 0.0, 0.0};
-        if (isl >= 0) for (int p = 0; p < A.npart; p++)
-            for (int k = 0; k < 3; k++) f[k] += A.fpart[((size_t)p * 3 + k) * A.n_islots + isl];
-        const int row = A.row_of_orig[i];
-        if (row >= 0) for (int e = A.row_start[row]; e < A.row_start[row + 1]; e++)
-            for (int k = 0; k < 3; k++) f[k] += A.fent[(size_t)k * A.n_entries + e];
-        for (int k = 0; k < 3; k++) A.ftot[(size_t)k * A.n + i] = f[k];
+        if (i >= 0) {
+            if (isl >= 0) {
+                int p = wv;
+                for (; p + 12 < A.npart; p += 16) {  // 4 partials x 3 components in flight
+                    double t[4][3];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) t[u][k] = A.fpart[((size_t)(p + 4 * u) * 3 + k) * A.n_islots + isl];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
+                }
+                for (; p < A.npart; p += 4)
+                    for (int k = 0; k < 3; k++) f[k] += A.fpart[((size_t)p * 3 + k) * A.n_islots + isl];
+            }
+            const int row = A.row_of_orig[i];
+            if (row >= 0) for (int e = A.row_start[row] + wv; e < A.row_start[row + 1]; e += 4)
+                for (int k = 0; k < 3; k++) f[k] += A.fent[(size_t)k * A.n_entries + e];
+        }
+        red[wv][0][lane] = f[0]; red[wv][1][lane] = f[1]; red[wv][2][lane] = f[2];
+        __syncthreads();
+        if (wv == 0 && i >= 0)
+            for (int k = 0; k < 3; k++) A.ftot[(size_t)k * A.n + i] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
         return;
     }
     if (A.n_alch == 0) return;
-    // last block: alchemical partial slabs
-    __shared__ double s_e[K2_NE];
+    blk -= n_itiles + nb_alch_atoms;
     const int cnt = *A.jcount_alch;
     const int nb_env = (cnt * A.PA + 255) / 256;
-    for (int t = tid; t < 9 * 64; t += 256) {
-        const int q = t >> 6, a = t & 63;
-        double s = 0.0;
-        if (a < A.n_alch) {
-            for (int b = 0; b < nb_env; b++) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
-            s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
+    if (blk < 9) {  // slab q = slot*3 + component: wave wv sums alchemical atoms a = wv, wv+4, ... over the K2 blocks
+        const int q = blk;
+        for (int a = wv; a < 64; a += 4) {
+            double s = 0.0;
+            if (a < A.n_alch) {
+                for (int b = lane; b < nb_env; b += 64) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
+                if (lane == 0) s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
+                s = wave_sum(s);
+            }
+            if (lane == 0) A.alch_self[q * 64 + a] = s;
         }
-        A.alch_self[q * 64 + a] = s;
+        return;
     }
-    if (tid < K2_NE) {
+    __shared__ double s_e[K2_NE];
+    for (int q = wv; q < K2_NE; q += 4) {
         double s = 0.0;
-        for (int b = 0; b < nb_env; b++) s += A.e_part[(size_t)b * K2_NE + tid];
-        s += A.e_part[(size_t)A.k2_nblocks_env * K2_NE + tid];
-        s_e[tid] = s;
+        for (int b = lane; b < nb_env; b += 64) s += A.e_part[(size_t)b * K2_NE + q];
+        if (lane == 0) s += A.e_part[(size_t)A.k2_nblocks_env * K2_NE + q];
+        s = wave_sum(s);
+        if (lane == 0) s_e[q] = s;
     }
     __syncthreads();
     if (tid < 3) A.acc->e_slot[tid] = A.le[tid] * s_e[0] + s_e[1 + tid];
@@ -323,7 +351,11 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
 #pragma unroll
                 for (int a = 0; a < 4; a++) if (a < C.na) {
                     double g[3];
-                    gaussians3(A.seed, A.stream, draw, (unsigned)C.id[a], g);
+                    const unsigned nd = draw - A.noise_draw_base;
+                    if (nd < (unsigned)A.n_noise) {
+                        const int m = A.mobile_index[C.id[a]];
+                        for (int k = 0; k < 3; k++) g[k] = A.noise[(size_t)(nd * 3 + k) * A.n_mobile + m];
+                    } else gaussians3(A.seed, A.stream, draw, (unsigned)C.id[a], g);
                     const double s = sqrt(A.kT * C.w[a]);
                     for (int k = 0; k < 3; k++) C.v[a][k] = A.aO * C.v[a][k] + A.bO * s * g[k];
                 }

@@ -35,6 +35,7 @@ struct ListArgs {
     int n, n_tiles, n_itiles, jcap, pool_cap;
     const int* tile_atoms;   // [n_tiles*64] sorted atom index or -1
     int* jlist;              // [n_tiles*jcap]
+    int* jstage;             // [n_tiles*4*jcap] per-wave staging for the ordered compaction
     int* jcount;             // [n_tiles]
     int* batch_slot;         // [n_tiles*(jcap/64)]
     unsigned long long* mask_pool;  // [pool_cap*64]
@@ -57,11 +58,14 @@ __global__ void __launch_bounds__(256) k_build_lists(ListArgs a, NbConst<R> c, c
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int t = blockIdx.x;
     // ---- shared bookkeeping: remember where the lists were built, clear alchemical env forces
-    for (int i = blockIdx.x * 256 + tid; i < a.n; i += gridDim.x * 256) {
-        a.xbuild[0][i] = a.x[0][i]; a.xbuild[1][i] = a.x[1][i]; a.xbuild[2][i] = a.x[2][i];
+    if (t >= a.n_tiles) {  // helper blocks: bookkeeping that must not sit on a tile block's critical path
+        const int hb = t - a.n_tiles, nh = gridDim.x - a.n_tiles;
+        for (int i = hb * 256 + tid; i < a.n; i += nh * 256) {
+            a.xbuild[0][i] = a.x[0][i]; a.xbuild[1][i] = a.x[1][i]; a.xbuild[2][i] = a.x[2][i];
+        }
+        for (int i = hb * 256 + tid; i < a.n_fJ; i += nh * 256) a.fJ[i] = 0.0;
+        return;
     }
-    for (int i = blockIdx.x * 256 + tid; i < a.n_fJ; i += gridDim.x * 256) a.fJ[i] = 0.0;
-    if (t >= a.n_tiles) return;
 
     __shared__ ufix s_cfix[3];
     __shared__ double s_half[3];
@@ -93,35 +97,50 @@ __global__ void __launch_bounds__(256) k_build_lists(ListArgs a, NbConst<R> c, c
     const ufix cf[3] = {s_cfix[0], s_cfix[1], s_cfix[2]};
     const double hf[3] = {s_half[0], s_half[1], s_half[2]};
 
-    // ---- ordered stream compaction of every atom within cutoff+skin of the box
+    // ---- ordered stream compaction of every atom within cutoff+skin of the box.  Each wave scans its own
+    // contiguous quarter of the (Hilbert-sorted) atoms with no block barrier inside the loop and stages
+    // its hits; the quarters are then concatenated in order, so the list stays ascending.
     int* jl = a.jlist + (size_t)t * a.jcap;
-    for (int base = 0; base < a.n; base += 256) {
-        int j = base + tid;
+    int* stage = a.jstage + ((size_t)t * 4 + wv) * a.jcap;
+    const float cfs[3] = {(float)c.dscale[0], (float)c.dscale[1], (float)c.dscale[2]};
+    const float hfl[3] = {(float)hf[0] * 1.00001f + 1e-6f, (float)hf[1] * 1.00001f + 1e-6f, (float)hf[2] * 1.00001f + 1e-6f};
+    const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f;
+    const int quarter = (((a.n + 3) / 4) + 63) & ~63;
+    const int j_end = min(a.n, (wv + 1) * quarter);
+    int wcount = 0;
+    for (int base = wv * quarter; base < j_end; base += 64) {
+        const int j = base + lane;
         bool pass = false;
-        if (j < a.n) {
+        if (j < j_end) {
             const typename Img<R>::Atom aj = img[j];
-            double d2 = 0.0;
-            ufix pj[3] = {aj.x, aj.y, aj.z};
+            const ufix pj[3] = {aj.x, aj.y, aj.z};
+            float d2 = 0.0f;
+#pragma unroll
             for (int k = 0; k < 3; k++) {
-                double d = fabs((double)(sfix)(pj[k] - cf[k]) * c.dscale[k]) - hf[k];
-                d = d > 0.0 ? d : 0.0;
-                d2 += d * d;
+                float d = fabsf((float)(sfix)(pj[k] - cf[k]) * cfs[k]) - hfl[k];
+                d = fmaxf(d, 0.0f);
+                d2 = fmaf(d, d, d2);
             }
-            pass = d2 < c.rlist2 && !(aj.flags & FLAG_ALCH);
+            pass = d2 < rl2 && !(aj.flags & FLAG_ALCH);
         }
-        unsigned long long b = __ballot(pass);
-        if (lane == 0) s_wcount[wv] = __popcll(b);
-        __syncthreads();
-        int off = s_total;
-        for (int w = 0; w < wv; w++) off += s_wcount[w];
+        const unsigned long long bal = __ballot(pass);
         if (pass) {
-            int pos = off + __popcll(b & ((1ull << lane) - 1ull));
-            if (pos < a.jcap) jl[pos] = j;
+            const int pos = wcount + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < a.jcap) stage[pos] = j;
         }
-        __syncthreads();
-        if (tid == 0) s_total += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
-        __syncthreads();
+        wcount += __popcll(bal);
     }
+    if (lane == 0) s_wcount[wv] = wcount;
+    __syncthreads();
+    {
+        int off = 0;
+        for (int w = 0; w < wv; w++) off += s_wcount[w];
+        const int mine = min(wcount, a.jcap);
+        for (int k = lane; k < mine; k += 64) if (off + k < a.jcap) jl[off + k] = stage[k];
+        if (tid == 0) s_total = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+    }
+    __threadfence_block();
+    __syncthreads();
     int count = s_total;
     if (count > a.jcap) { if (tid == 0) a.flags->list_overflow = 1; count = a.jcap; }
     if (tid == 0) a.jcount[t] = count;
