@@ -75,8 +75,11 @@ static uint32_t hilbert3(uint32_t x, uint32_t y, uint32_t z, int bits) {
 struct BluesEngine {
     std::string err;
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, cur = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr, evJ1 = nullptr, evJ2 = nullptr;
+    hipGraphExec_t gexec = nullptr; int graph_units = 16; bool graph_valid = false, use_graph = false, graph_fork = false;
+    DevCtrl* ctrl_arg = nullptr; DevCtrl host_ctrl;
+    int64_t st_graph_steps = 0;
     // ---- system (host copies, caller order)
     int n = 0;
     double box[3] = {0, 0, 0};
@@ -86,7 +89,7 @@ struct BluesEngine {
     std::vector<int> alch_local;         // [n] -> local index or -1
     int nb_method = 1; double cutoff = 1, alpha = 0, sc_alpha = 0.5;
     int annih_elec = 1, annih_ster = 0, remove_cm = 0, check_env_excl = 0;
-    double skin = 0.12;
+    double skin = 0.12; bool skin_from_env = false;
     // ---- integrator
     double dt = 0, temperature = 0, gamma = 1, kT = 0, tol = 1e-8;
     int nsteps = 0, nprop = 1, n_lambda = 0, precision = 0;
@@ -109,6 +112,7 @@ struct BluesEngine {
     std::vector<HostCluster> clusters;
     int n_itiles = 0, n_tiles = 0, jcap = 0, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0;
     int seg_len = 64, waves_tile = 4, wpb = 4, npart = 1;  // K1 decomposition
+    bool fuse_forces = false;
     int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
     double total_mass = 0;
@@ -117,7 +121,7 @@ struct BluesEngine {
     DBuf<AtomF> d_img_f; DBuf<AtomD> d_img_d;
     DBuf<int> d_sorted_of_orig, d_orig_of_sorted, d_tile_atoms, d_jlist, d_jstage, d_jcount, d_batch_slot, d_pool_count, d_ex_start, d_ex_idx, d_islot;
     DBuf<unsigned long long> d_mask_pool;
-    DBuf<DevFlags> d_flags; DBuf<DevAccum> d_acc;
+    DBuf<DevFlags> d_flags; DBuf<DevAccum> d_acc; DBuf<DevCtrl> d_ctrl; DBuf<double> d_tab_ls, d_tab_le;
     DBuf<double> d_fpart, d_epart_nb, d_fJ, d_self_part, d_e_part, d_fent, d_ftot, d_alch_self, d_epart_b, d_cm_part, d_trace, d_scratch;
     DBuf<int> d_orig_of_islot, d_row_of_orig, d_mobile_atoms, d_mobile_index, d_exc_owner;
     DBuf<double> d_noise; unsigned noise_draw_base = 0; int n_noise = 0; bool noise_valid = false;
@@ -134,9 +138,9 @@ struct BluesEngine {
     std::vector<int> h_sorted_of_orig, h_orig_of_sorted;
 
     ~BluesEngine() {
-        if (ev0) hipEventDestroy(ev0);
-        if (ev1) hipEventDestroy(ev1);
-        if (stream) hipStreamDestroy(stream);
+        if (gexec) hipGraphExecDestroy(gexec);
+        for (hipEvent_t e : {ev0, ev1, evFork, evJ1, evJ2}) if (e) hipEventDestroy(e);
+        for (hipStream_t q : {stream, s1, s2}) if (q) hipStreamDestroy(q);
     }
 };
 
@@ -310,6 +314,12 @@ static int sort_and_tile(BluesEngine* h) {
     if (!h->alch.empty()) { for (size_t a = 0; a < 64; a++) tile_atoms.push_back(a < h->alch.size() ? h->h_sorted_of_orig[h->alch[a]] : -1); }
     if (h->n_tiles == 0) { tile_atoms.assign(64, -1); }
     h->n_islots = std::max(1, h->n_itiles) * 64;
+    // Verlet skin: a small i-set is latency-bound (longer j-lists cost nothing, rebuilds do); a large one is
+    // throughput-bound (every extra j costs pair evaluations)
+    if (!h->skin_from_env) {
+        h->skin = h->n_itiles <= 32 ? 0.3 : 0.12;
+        for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) h->skin = std::max(0.0, 0.5 * h->box[k] - h->cutoff - 1e-6);
+    }
     // capacities
     const double rl = h->cutoff + h->skin;
     const double vol = h->box[0] * h->box[1] * h->box[2], rho = n / vol;
@@ -326,11 +336,14 @@ static int sort_and_tile(BluesEngine* h) {
         const double est_count = std::min<double>(jcap, est / 1.5);
         int CH = 64;
         while (CH > 8 && nit * (est_count / CH) < 4096.0) CH >>= 1;
-        if (const char* e = getenv("BLUES_SEG")) CH = std::max(8, std::min(64, atoi(e)));
+        if (const char* e = getenv("BLUES_SEG")) CH = std::max(4, std::min(64, atoi(e)));
         int NW = std::max(1, std::min(jcap / CH, (8192 + nit - 1) / nit));
         int WPB = h->precision == 0 ? 16 : 8;
         while (WPB > 1 && (WPB > NW || nit * NW / WPB < 64)) WPB >>= 1;
         if (const char* e = getenv("BLUES_WPB")) WPB = std::max(1, std::min(h->precision == 0 ? 16 : 8, atoi(e)));
+        h->fuse_forces = nit <= 32;  // small i-set: every force kernel is latency-bound -> one fused launch
+        if (const char* e = getenv("BLUES_FUSE")) h->fuse_forces = atoi(e) != 0;
+        if (h->fuse_forces) { WPB = 4; NW = std::max(NW, 4); }
         NW = std::max(WPB, (NW / WPB) * WPB);
         h->seg_len = CH; h->waves_tile = NW; h->wpb = WPB; h->npart = NW / WPB;
     }
@@ -381,7 +394,7 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_self_part.alloc((size_t)(h->k2_nblocks_env + 1) * 9 * 64); h->d_e_part.alloc((size_t)(h->k2_nblocks_env + 1) * K2_NE);
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     h->hx_sort = h->hx;
-    h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->e_frozen_valid = false;
+    h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->e_frozen_valid = false; h->graph_valid = false;
     return 0;
 }
 
@@ -395,16 +408,17 @@ static IntArgs make_int_args(BluesEngine* h) {
     A.ftot = h->d_ftot.p; A.alch_self = h->d_alch_self.p;
     A.fJ = h->d_fJ.p; A.sorted_of_orig = h->d_sorted_of_orig.p; A.n_alch = (int)h->alch.size();
     A.alch_local_of_orig = h->d_alch_local.p;
-    A.hV = h->dt / std::max(1, h->n_V); A.hR = h->dt / std::max(1, h->n_R);
+    A.hV = h->dt / std::max(1, h->n_V); A.hR = h->dt / std::max(1, h->n_R); A.inv_hR = 1.0 / A.hR;
     const double hO = h->dt / std::max(1, h->n_O);
     A.aO = std::exp(-h->gamma * hO); A.bO = std::sqrt(1.0 - std::exp(-2.0 * h->gamma * hO));
     A.kT = h->kT; A.tol = h->tol; A.seed = h->seed; A.stream = (unsigned)h->replica * 4u; A.draw_base = h->prog_draw_base;
     A.noise = h->d_noise.p; A.mobile_index = h->d_mobile_index.p; A.n_mobile = (int)h->mobile.size(); A.n_noise = h->noise_valid ? h->n_noise : 0; A.noise_draw_base = h->noise_draw_base;
-    A.box = make_box(h); A.periodic = h->nb_method == BLUES_NB_PME_DIRECT;
+    A.box = make_box(h); A.periodic = h->nb_method == BLUES_NB_PME_DIRECT; A.cl_periodic = 0;
     A.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; A.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
     A.half_skin2 = 0.25 * h->skin * h->skin; A.flags = h->d_flags.p; A.pool_count = h->d_pool_count.p;
     A.total_mass = h->total_mass; A.cm_part = h->d_cm_part.p; A.cm_nblocks = h->int_blocks;
-    A.acc = h->d_acc.p; A.work_trace = h->tracing ? h->d_trace.p : nullptr; A.trace_index = h->prog_trace;
+    A.acc = h->d_acc.p; A.work_trace = (h->tracing || h->ctrl_arg) ? h->d_trace.p : nullptr; A.trace_index = h->prog_trace;
+    A.ctrl = h->ctrl_arg;
     A.prog = h->prog;
     return A;
 }
@@ -412,7 +426,7 @@ static IntArgs make_int_args(BluesEngine* h) {
 static int flush_program(BluesEngine* h) {
     if (h->prog.n == 0) return 0;
     IntArgs A = make_int_args(h);
-    hipLaunchKernelGGL(k_integrate, dim3(h->int_blocks), dim3(h->int_threads), 0, h->stream, A);
+    hipLaunchKernelGGL(k_integrate, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
     h->st_launches++;
     h->prog.n = 0; h->prog_trace = -1; h->prog_draw_base = h->h_draw;
     HIP_OK(h, hipGetLastError());
@@ -437,7 +451,7 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
     if (force) HIP_OK(h, hipMemsetAsync(h->d_pool_count.p, 0, sizeof(int), h->stream));
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
-    hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 32), dim3(256), 0, h->stream, a, make_nbconst<R>(h), img, force);
+    hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 32), dim3(256), 0, h->cur, a, make_nbconst<R>(h), img, force);
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -445,15 +459,20 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
 
 template <typename R, bool ENERGY, int WPB> static void launch_nb_wpb(BluesEngine* h, const NbArgs<R>& a, const typename Img<R>::Atom* img) {
     const int blocks = std::max(1, h->n_itiles) * (h->waves_tile / WPB);
-    hipLaunchKernelGGL((k_nonbonded<R, ENERGY, WPB>), dim3(blocks), dim3(WPB * 64), 0, h->stream, a, make_nbconst<R>(h), img);
+    hipLaunchKernelGGL((k_nonbonded<R, ENERGY, WPB>), dim3(blocks), dim3(WPB * 64), 0, h->cur, a, make_nbconst<R>(h), img);
 }
 
-template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
+template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
     NbArgs<R> a; memset(&a, 0, sizeof a);
     a.n_itiles = h->n_itiles; a.jcap = h->jcap; a.n_islots = h->n_islots;
     a.seg_len = h->seg_len; a.waves_tile = h->waves_tile; a.npart = h->npart;
     a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p; a.mask_pool = h->d_mask_pool.p;
     a.fpart = h->d_fpart.p; a.epart = h->d_epart_nb.p; a.flags = h->d_flags.p;
+    return a;
+}
+
+template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
+    NbArgs<R> a = make_nb_args<R>(h);
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
     switch (h->wpb) {
@@ -470,8 +489,18 @@ template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
     return 0;
 }
 
+static AlchArgs make_alch_args(BluesEngine* h, const double ls[3], const double le[3], int slot_mask);
+
 static int launch_alchemical(BluesEngine* h, const double ls[3], const double le[3], int slot_mask) {
     if (h->alch.empty()) return 0;
+    AlchArgs A = make_alch_args(h, ls, le, slot_mask);
+    hipLaunchKernelGGL(k_alchemical, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->cur, A);
+    h->st_launches++;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+static AlchArgs make_alch_args(BluesEngine* h, const double ls[3], const double le[3], int slot_mask) {
     AlchArgs A; memset(&A, 0, sizeof A);
     A.n = h->n; A.n_alch = (int)h->alch.size(); A.PA = h->PA; A.jcap = h->jcap; A.nblocks_env = h->k2_nblocks_env;
     A.alch_orig = h->d_alch_orig.p; A.jlist = h->d_jlist.p + (size_t)h->n_itiles * h->jcap; A.jcount = h->d_jcount.p + h->n_itiles;
@@ -482,11 +511,8 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
     A.box = make_box(h); A.rc2 = h->cutoff * h->cutoff; A.alpha = h->alpha; A.sc_alpha = h->sc_alpha;
     A.pme = h->nb_method == BLUES_NB_PME_DIRECT; A.annih_elec = h->annih_elec; A.annih_ster = h->annih_ster; A.slot_mask = slot_mask; A.check_env_excl = h->check_env_excl;
     for (int s = 0; s < 3; s++) { A.ls[s] = ls[s]; A.le[s] = le[s]; }
-    A.fJ = h->d_fJ.p; A.self_part = h->d_self_part.p; A.e_part = h->d_e_part.p;
-    hipLaunchKernelGGL(k_alchemical, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->stream, A);
-    h->st_launches++;
-    HIP_OK(h, hipGetLastError());
-    return 0;
+    A.fJ = h->d_fJ.p; A.self_part = h->d_self_part.p; A.e_part = h->d_e_part.p; A.ctrl = h->ctrl_arg;
+    return A;
 }
 
 static BondedArgs make_bonded_args(BluesEngine* h) {
@@ -498,29 +524,54 @@ static BondedArgs make_bonded_args(BluesEngine* h) {
     for (int k = 0; k < 3; k++) B.x[k] = h->d_x[k].p;
     B.box = make_box(h); B.periodic = h->nb_method == BLUES_NB_PME_DIRECT; B.fent = h->d_fent.p; B.n_entries = h->n_entries; B.n = h->n; B.epart = h->d_epart_b.p;
     B.n_mobile = (int)h->mobile.size(); B.n_noise = h->n_noise; B.mobile_atoms = h->d_mobile_atoms.p; B.noise = h->d_noise.p;
-    B.seed = h->seed; B.stream = (unsigned)h->replica * 4u; B.draw_base = h->h_draw; B.n_entry_blocks = (h->n_entries + 127) / 128;
+    B.seed = h->seed; B.stream = (unsigned)h->replica * 4u; B.draw_base = h->h_draw; B.n_entry_blocks = (h->n_entries + 127) / 128; B.ctrl = h->ctrl_arg;
     return B;
 }
 
-static int launch_bonded_and_finalize(BluesEngine* h, const double le[3], bool with_noise) {
-    {
-        BondedArgs B = make_bonded_args(h);
-        const int nb_noise = with_noise ? ((int)h->mobile.size() * h->n_noise + 127) / 128 : 0;
-        if (with_noise) { h->noise_draw_base = h->h_draw; h->noise_valid = true; }
-        if (B.n_entry_blocks + nb_noise > 0) {
-            hipLaunchKernelGGL(k_bonded_entries, dim3(B.n_entry_blocks + nb_noise), dim3(128), 0, h->stream, B);
-            h->st_launches++;
-        }
+static int launch_bonded(BluesEngine* h, bool with_noise) {
+    BondedArgs B = make_bonded_args(h);
+    const int nb_noise = with_noise ? ((int)h->mobile.size() * h->n_noise + 127) / 128 : 0;
+    if (with_noise) { h->noise_draw_base = h->h_draw; h->noise_valid = true; }
+    if (B.n_entry_blocks + nb_noise > 0) {
+        hipLaunchKernelGGL(k_bonded_entries, dim3(B.n_entry_blocks + nb_noise), dim3(128), 0, h->cur, B);
+        h->st_launches++;
     }
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+static int launch_finalize(BluesEngine* h, const double le[3]) {
     FinArgs F; memset(&F, 0, sizeof F);
     F.n = h->n; F.n_islots = h->n_islots; F.npart = h->npart; F.n_alch = (int)h->alch.size(); F.PA = h->PA; F.k2_nblocks_env = h->k2_nblocks_env; F.n_entries = h->n_entries;
     F.orig_of_islot = h->d_orig_of_islot.p; F.row_of_orig = h->d_row_of_orig.p; F.row_start = h->d_row_start.p;
     F.fpart = h->d_fpart.p; F.fent = h->d_fent.p; F.alch_orig = h->d_alch_orig.p;
     F.self_part = h->d_self_part.p; F.e_part = h->d_e_part.p; F.jcount_alch = h->d_jcount.p + h->n_itiles;
     for (int s = 0; s < 3; s++) F.le[s] = le[s];
-    F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p;
+    F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p; F.ctrl = h->ctrl_arg;
     const int nblk = h->n_islots / 64 + (F.n_alch > 0 ? 1 + 9 + 1 : 0);
-    hipLaunchKernelGGL(k_finalize, dim3(std::max(1, nblk)), dim3(256), 0, h->stream, F);
+    hipLaunchKernelGGL(k_finalize, dim3(std::max(1, nblk)), dim3(256), 0, h->cur, F);
+    h->st_launches++;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+static int launch_bonded_and_finalize(BluesEngine* h, const double le[3], bool with_noise) {
+    if (launch_bonded(h, with_noise)) return 1;
+    return launch_finalize(h, le);
+}
+
+template <typename R> static int launch_forces_fused(BluesEngine* h, const double ls[3], const double le[3]) {
+    NbArgs<R> a = make_nb_args<R>(h);
+    const typename Img<R>::Atom* img;
+    if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
+    AlchArgs A = make_alch_args(h, ls, le, 7);
+    BondedArgs B = make_bonded_args(h);
+    B.n_entry_blocks = (h->n_entries + 255) / 256;
+    const int nb1 = std::max(1, h->n_itiles) * (h->waves_tile / 4);
+    const int nb2 = h->alch.empty() ? 0 : h->k2_nblocks_env + 1;
+    const int nb3 = B.n_entry_blocks + ((int)h->mobile.size() * h->n_noise + 255) / 256;
+    h->noise_draw_base = h->h_draw; h->noise_valid = true;
+    hipLaunchKernelGGL(k_forces_fused<R>, dim3(nb1 + nb2 + nb3), dim3(256), 0, h->cur, a, make_nbconst<R>(h), img, A, B, nb1, nb2);
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -540,10 +591,16 @@ static int force_pass(BluesEngine* h, int base_L) {
     int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced) : launch_lists<double>(h, h->lists_forced);
     h->lists_forced = false;
     if (rc) return 1;
-    if (launch_alchemical(h, ls, le, 7)) return 1;
-    rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
-    if (rc) return 1;
-    if (launch_bonded_and_finalize(h, le, true)) return 1;
+    if (h->fuse_forces && h->wpb == 4) {
+        rc = h->precision == 0 ? launch_forces_fused<float>(h, ls, le) : launch_forces_fused<double>(h, ls, le);
+        if (rc) return 1;
+        if (launch_finalize(h, le)) return 1;
+    } else {
+        if (launch_alchemical(h, ls, le, 7)) return 1;
+        rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
+        if (rc) return 1;
+        if (launch_bonded_and_finalize(h, le, true)) return 1;
+    }
     h->pass_valid = true; h->pass_L = base_L; h->st_passes++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -667,10 +724,107 @@ static int splitting_pass(BluesEngine* h) {
     return 0;
 }
 
+// ---- hipGraph path for the steady state of "H V R O R V H" (nprop = 1): one unit = [integrate | lists |
+// (alchemical || nonbonded || bonded+noise) | finalize]; the three force kernels are forked onto side streams
+// so they overlap, and launch gaps shrink to in-graph dependencies.  Step-dependent values come from DevCtrl.
+static std::vector<Program> steady_programs(const BluesEngine* h) {
+    std::vector<Program> out;
+    Program p; p.n = 0;
+    auto add = [&](int op) { p.ops[p.n++] = (unsigned char)op; };
+    add(OP_V0); add(OP_H01); add(OP_END);
+    if (h->remove_cm) {
+        if (h->int_blocks == 1) add(OP_CM_BLOCK);
+        else { add(OP_CM_REDUCE); out.push_back(p); p.n = 0; add(OP_CM_APPLY); }
+    }
+    add(OP_H12); add(OP_V2); add(OP_R); add(OP_O); add(OP_R);
+    out.push_back(p);
+    return out;
+}
+
+static int capture_graph(BluesEngine* h) {
+    if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    h->graph_valid = false;
+    const Program saved = h->prog; const int saved_trace = h->prog_trace; const unsigned saved_base = h->prog_draw_base;
+    const bool saved_nv = h->noise_valid; const unsigned saved_nb = h->noise_draw_base;
+    const int64_t saved_launches = h->st_launches;
+    h->ctrl_arg = h->d_ctrl.p;
+    const std::vector<Program> progs = steady_programs(h);
+    const double dummy[3] = {1.0, 1.0, 1.0};
+    int rc = 0;
+    hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { h->ctrl_arg = nullptr; E_FAIL(h, "hipStreamBeginCapture: %s", hipGetErrorString(e)); }
+    for (int u = 0; u < h->graph_units && !rc; u++) {
+        h->cur = h->stream;
+        for (const Program& p : progs) {
+            h->prog = p;
+            IntArgs A = make_int_args(h);
+            hipLaunchKernelGGL(k_integrate, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
+        }
+        rc |= h->precision == 0 ? launch_lists<float>(h, 0) : launch_lists<double>(h, 0);
+        if (h->graph_fork) {
+            rc |= hipEventRecord(h->evFork, h->stream) != hipSuccess;
+            rc |= hipStreamWaitEvent(h->s1, h->evFork, 0) != hipSuccess;
+            rc |= hipStreamWaitEvent(h->s2, h->evFork, 0) != hipSuccess;
+            h->cur = h->s1; rc |= launch_alchemical(h, dummy, dummy, 7);
+            h->cur = h->s2; rc |= launch_bonded(h, true);
+            h->cur = h->stream; rc |= h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
+            rc |= hipEventRecord(h->evJ1, h->s1) != hipSuccess;
+            rc |= hipEventRecord(h->evJ2, h->s2) != hipSuccess;
+            rc |= hipStreamWaitEvent(h->stream, h->evJ1, 0) != hipSuccess;
+            rc |= hipStreamWaitEvent(h->stream, h->evJ2, 0) != hipSuccess;
+        } else {
+            rc |= launch_alchemical(h, dummy, dummy, 7);
+            rc |= h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
+            rc |= launch_bonded(h, true);
+        }
+        rc |= launch_finalize(h, dummy);
+    }
+    hipGraph_t graph = nullptr;
+    e = hipStreamEndCapture(h->stream, &graph);
+    h->cur = h->stream; h->ctrl_arg = nullptr;
+    h->prog = saved; h->prog_trace = saved_trace; h->prog_draw_base = saved_base; h->noise_valid = saved_nv; h->noise_draw_base = saved_nb;
+    h->st_launches = saved_launches;
+    if (rc || e != hipSuccess || !graph) { if (graph) hipGraphDestroy(graph); E_FAIL(h, "graph capture failed: %s", hipGetErrorString(e)); }
+    e = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) { h->gexec = nullptr; E_FAIL(h, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    h->graph_valid = true;
+    return 0;
+}
+
+// returns the number of whole steps advanced through graph replays (0 if the state is not the steady state)
+static int try_graph_steps(BluesEngine* h, int max_steps) {
+    if (!h->use_graph || h->split != "HVRORVH" || h->nprop != 1) return 0;
+    if (h->h_step < 1 || !h->pass_valid || h->x_edited || h->h_first_step < 1) return 0;
+    if (h->prog.n != 3 || h->prog.ops[0] != OP_V0 || h->prog.ops[1] != OP_H01 || h->prog.ops[2] != OP_END) return 0;
+    if (h->pass_L != 2 * h->h_step - 1 || h->h_lambda_step != 2 * h->h_step || h->lists_forced) return 0;
+    int count = std::min(max_steps, h->nsteps - h->h_step);
+    count -= count % h->graph_units;
+    if (count <= 0) return 0;
+    if (!h->graph_valid && capture_graph(h)) return -1;
+    DevCtrl& c = h->host_ctrl;
+    c.kint = 0; c.kpass = 0; c.L0 = h->pass_L; c.draw0 = h->h_draw; c.trace0 = h->prog_trace; c.n_lambda = h->n_lambda;
+    c.tab_ls = h->d_tab_ls.p; c.tab_le = h->d_tab_le.p;
+    if (hipMemcpyAsync(h->d_ctrl.p, &c, sizeof c, hipMemcpyHostToDevice, h->stream) != hipSuccess) { h->err = "ctrl upload failed"; return -1; }
+    for (int r = 0; r < count / h->graph_units; r++)
+        if (hipGraphLaunch(h->gexec, h->stream) != hipSuccess) { h->err = "hipGraphLaunch failed"; return -1; }
+    h->h_step += count; h->h_lambda_step += 2 * count; h->h_lambda = (double)h->h_lambda_step / h->n_lambda;
+    h->cur_ls = h->tab_ls[h->h_lambda_step]; h->cur_le = h->tab_le[h->h_lambda_step];
+    h->h_draw += (unsigned)count; h->pass_L += 2 * count;
+    h->prog_trace = h->h_step - 1; h->prog_draw_base = h->h_draw; h->noise_draw_base = h->h_draw; h->noise_valid = true;
+    h->st_passes += count; h->st_launches += (int64_t)count * 6; h->st_graph_steps += count;
+    return count;
+}
+
 // reference blues/integrators.py:159-209
 static int do_steps(BluesEngine* h, int nsteps) {
     if (ensure_sorted(h)) return 1;
     for (int s = 0; s < nsteps; s++) {
+        {
+            const int adv = try_graph_steps(h, nsteps - s);
+            if (adv < 0) return 1;
+            if (adv > 0) { s += adv - 1; continue; }
+        }
         if (h->h_step == 0) {  // first call after construction / reset
             if (flush_program(h)) return 1;
             if (emit(h, OP_PREP)) return 1;
@@ -716,7 +870,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     h->box[0] = s->box[0]; h->box[1] = s->box[4]; h->box[2] = s->box[8];
     h->nb_method = s->nonbonded_method; h->cutoff = s->cutoff; h->alpha = s->ewald_alpha; h->sc_alpha = s->softcore_alpha;
     for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * h->cutoff) E_FAIL(h, "box edge %g < 2*cutoff", h->box[k]);
-    if (const char* sk = getenv("BLUES_SKIN")) h->skin = atof(sk);
+    if (const char* sk = getenv("BLUES_SKIN")) { h->skin = atof(sk); h->skin_from_env = true; }
     for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) h->skin = std::max(0.0, 0.5 * h->box[k] - h->cutoff - 1e-6);
     h->annih_elec = s->annihilate_electrostatics; h->annih_ster = s->annihilate_sterics; h->remove_cm = s->remove_cm_motion;
     h->mass.assign(s->mass, s->mass + n); h->charge.assign(s->charge, s->charge + n); h->sigma.assign(s->sigma, s->sigma + n); h->eps.assign(s->epsilon, s->epsilon + n);
@@ -749,11 +903,16 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     h->prog.n = 0;
     HIP_OK(h, hipSetDevice(h->device));
     HIP_OK(h, hipStreamCreate(&h->stream));
+    HIP_OK(h, hipStreamCreate(&h->s1)); HIP_OK(h, hipStreamCreate(&h->s2)); h->cur = h->stream;
     HIP_OK(h, hipEventCreate(&h->ev0)); HIP_OK(h, hipEventCreate(&h->ev1));
+    HIP_OK(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ1, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ2, hipEventDisableTiming));
+    if (const char* g = getenv("BLUES_GRAPH")) h->use_graph = atoi(g) != 0;
+    if (const char* g = getenv("BLUES_GRAPH_UNITS")) h->graph_units = std::max(1, atoi(g));
+    if (const char* g = getenv("BLUES_GRAPH_FORK")) h->graph_fork = atoi(g) != 0;
     try {
         for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); }
         h->d_mass.upload(h->mass); h->d_charge.upload(h->charge); h->d_sigma.upload(h->sigma); h->d_eps.upload(h->eps);
-        h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ftot.alloc((size_t)3 * n); h->d_alch_self.alloc(9 * 64);
+        h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ctrl.alloc(1); h->d_tab_ls.upload(h->tab_ls); h->d_tab_le.upload(h->tab_le); h->d_ftot.alloc((size_t)3 * n); h->d_alch_self.alloc(9 * 64);
         h->d_alch_orig.upload(h->alch); h->d_alch_local.upload(h->alch_local);
         h->d_trace.alloc((size_t)std::max(1, h->nsteps)); h->d_scratch.alloc((size_t)std::max(3 * n, 1024));
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
@@ -819,9 +978,16 @@ int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
     HIP_OK(h, hipStreamSynchronize(h->stream));
     bool frozen_moved = !h->have_positions;
     if (h->have_positions) for (int i = 0; i < h->n && !frozen_moved; i++) if (h->mass[i] == 0.0 && h->alch_local[i] < 0)
-        for (int k = 0; k < 3; k++) if (h->hx[3 * i + k] != xyz[3 * i + k]) { frozen_moved = true; break; }
+        for (int k = 0; k < 3; k++) if (h->hx[3 * i + k] != xyz[3 * i + k]) { frozen_moved = true; break; }  // frozen atoms are never in clusters, so hx holds them verbatim
     h->hx.assign(xyz, xyz + 3 * (size_t)h->n);
-    if (upload_xyz(h, xyz, h->d_x)) return 1;
+    // store every constraint cluster as one whole periodic image (a lattice translation of single atoms is
+    // physically a no-op); the cluster solves in k_integrate then need no minimum-image arithmetic
+    for (const HostCluster& c : h->clusters) for (int a = 1; a < 4; a++) if (c.atoms[a] >= 0)
+        for (int k = 0; k < 3; k++) {
+            double d = h->hx[3 * c.atoms[a] + k] - h->hx[3 * c.atoms[0] + k];
+            h->hx[3 * c.atoms[a] + k] -= h->box[k] * std::nearbyint(d / h->box[k]);
+        }
+    if (upload_xyz(h, h->hx.data(), h->d_x)) return 1;
     h->have_positions = true; h->x_edited = true; h->pass_valid = false;
     if (frozen_moved) h->e_frozen_valid = false;
     // re-sort when never sorted or when atoms have drifted far from where the tiles were formed

@@ -43,6 +43,19 @@ template <> struct Img<double> {
 
 struct Box3 { double L[3]; double invL[3]; };
 
+// Device-resident step counters for hipGraph replays of the steady-state NCMC step: a captured graph has
+// its kernel arguments frozen, so everything that changes from step to step is derived from here.
+//   integrate reads kint and publishes kpass = kint+1 for the force kernels that follow it;
+//   finalize (last kernel of a unit) publishes kint = kpass for the next integrate.
+struct DevCtrl {
+    int kint, kpass;       // unit counters (never read and written inside the same kernel)
+    int L0;                // lambda index of slot 0 of the force pass that precedes unit 0
+    unsigned draw0;        // O-substep draw index used by unit 0
+    int trace0;            // work-trace slot written by unit 0
+    int n_lambda;
+    const double* tab_ls; const double* tab_le;  // [n_lambda+1]
+};
+
 // ---------------------------------------------------------------- Philox4x32-10 (same stream as oracle/blues_oracle.c)
 __host__ __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

@@ -43,6 +43,7 @@ struct AlchArgs {
     double* fJ;         // [3 slots][3][n] force on environment atoms by sorted index
     double* self_part;  // [nblocks][3 slots][3][64]
     double* e_part;     // [nblocks][K2_NE]
+    const DevCtrl* ctrl; // non-null in graph replays: lambda slots come from the device tables
 };
 
 __device__ inline bool excluded_sorted(const int* ex_start, const int* ex_idx, int a_sorted, int j_sorted) {
@@ -51,7 +52,12 @@ __device__ inline bool excluded_sorted(const int* ex_start, const int* ex_idx, i
     return ex;
 }
 
-__global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) {
+__device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id) {
+    if (A.ctrl) {
+        const int L = A.ctrl->L0 + 2 * A.ctrl->kpass;
+#pragma unroll
+        for (int s = 0; s < 3; s++) { const int Ls = min(L + s, A.ctrl->n_lambda); A.ls[s] = A.ctrl->tab_ls[Ls]; A.le[s] = A.ctrl->tab_le[Ls]; }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int PA = A.PA;
     const int a = tid & (PA - 1);
@@ -64,11 +70,11 @@ __global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) {
 #pragma unroll
     for (int q = 0; q < K2_NE; q++) e[q] = 0.0;
 
-    const bool env_block = blockIdx.x < A.nblocks_env;
+    const bool env_block = block_id < A.nblocks_env;
     if (env_block) {
         const int count = *A.jcount;
-        if ((blockIdx.x * 256) / PA >= count) return;  // nothing to do; the integrator sums only the used blocks
-        const int js = (blockIdx.x * 256 + tid) / PA;
+        if ((block_id * 256) / PA >= count) return;  // nothing to do; the integrator sums only the used blocks
+        const int js = (block_id * 256 + tid) / PA;
         const bool valid = js < count && a < A.n_alch;
         int jsrt = -1;
         if (valid) {
@@ -185,13 +191,13 @@ __global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) {
         if (tid < 64) {
 #pragma unroll
             for (int q = 0; q < 9; q++)
-                A.self_part[((size_t)blockIdx.x * 9 + q) * 64 + tid] = (tid < A.n_alch) ? s_self[0][q][tid] : 0.0;
+                A.self_part[((size_t)block_id * 9 + q) * 64 + tid] = (tid < A.n_alch) ? s_self[0][q][tid] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < K2_NE; q++) e[q] = wave_sum(e[q]);
         if (lane == 0) for (int q = 0; q < K2_NE; q++) s_e[wv][q] = e[q];
         __syncthreads();
-        if (tid < K2_NE) A.e_part[(size_t)blockIdx.x * K2_NE + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
+        if (tid < K2_NE) A.e_part[(size_t)block_id * K2_NE + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
         return;
     }
 
@@ -213,8 +219,10 @@ __global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) {
         for (int q = 0; q < 9; q++) {
             double v = 0.0;
             if (tid < PA) v = s_self[0][q][tid] + s_self[1][q][tid] + s_self[2][q][tid] + s_self[3][q][tid];
-            A.self_part[((size_t)blockIdx.x * 9 + q) * 64 + tid] = v;
+            A.self_part[((size_t)block_id * 9 + q) * 64 + tid] = v;
         }
     }
-    if (tid < K2_NE) A.e_part[(size_t)blockIdx.x * K2_NE + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
+    if (tid < K2_NE) A.e_part[(size_t)block_id * K2_NE + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
 }
+
+__global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) { alchemical_body(A, blockIdx.x); }

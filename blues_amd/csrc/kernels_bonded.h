@@ -36,6 +36,7 @@ struct BondedArgs {
     int n_mobile, n_noise; const int* mobile_atoms; double* noise;  // noise[(d*3+k)*n_mobile + m]
     unsigned long long seed; unsigned stream, draw_base;
     int n_entry_blocks;
+    const DevCtrl* ctrl;
 };
 
 __device__ inline void mi3(const BondedArgs& B, double d[3]) {
@@ -125,22 +126,25 @@ __device__ inline double bonded_term(const BondedArgs& B, int type, int idx, int
 // one thread per (row, entry): the force of one term on one of its mobile atoms -> fent[3][n_entries];
 // blocks past n_entry_blocks draw the N(0,1) numbers of the coming O substeps (counter-based, so they can be
 // produced before the velocities they will be applied to exist).
-__global__ void __launch_bounds__(128) k_bonded_entries(BondedArgs B) {
-    if ((int)blockIdx.x >= B.n_entry_blocks) {
-        const int g = (blockIdx.x - B.n_entry_blocks) * 128 + threadIdx.x;
+__device__ __forceinline__ void bonded_entries_body(const BondedArgs& B, const int block_id, const int nthreads) {
+    if (block_id >= B.n_entry_blocks) {
+        const int g = (block_id - B.n_entry_blocks) * nthreads + threadIdx.x;
         if (g >= B.n_mobile * B.n_noise) return;
         const int d = g / B.n_mobile, m = g - d * B.n_mobile;
         double z[3];
-        gaussians3(B.seed, B.stream, B.draw_base + (unsigned)d, (unsigned)B.mobile_atoms[m], z);
+        const unsigned base = B.ctrl ? B.ctrl->draw0 + (unsigned)B.ctrl->kpass : B.draw_base;
+        gaussians3(B.seed, B.stream, base + (unsigned)d, (unsigned)B.mobile_atoms[m], z);
         for (int k = 0; k < 3; k++) B.noise[(size_t)(d * 3 + k) * B.n_mobile + m] = z[k];
         return;
     }
-    const int e = blockIdx.x * 128 + threadIdx.x;
+    const int e = block_id * nthreads + threadIdx.x;
     if (e >= B.n_entries) return;
     double F[3];
     bonded_term(B, B.ent_type[e], B.ent_term[e], B.ent_role[e], F);
     B.fent[e] = F[0]; B.fent[B.n_entries + e] = F[1]; B.fent[2 * B.n_entries + e] = F[2];
 }
+
+__global__ void __launch_bounds__(128) k_bonded_entries(BondedArgs B) { bonded_entries_body(B, blockIdx.x, 128); }
 
 // energy of every term (frozen ones included): per-block partial sums per type
 __global__ void __launch_bounds__(256) k_bonded_energy(BondedArgs B) {

@@ -15,6 +15,7 @@
 #include "device_common.h"
 #include "kernels_alch.h"
 #include "kernels_nb.h"
+#include "kernels_bonded.h"
 
 enum {
     OP_V0 = 0, OP_V1, OP_V2,   // v += hV f/m with the alchemical force of slot 0/1/2, then RATTLE
@@ -50,10 +51,10 @@ struct IntArgs {
     const double* fJ; const int* sorted_of_orig; int n_alch;
     const int* alch_local_of_orig;
     // constants
-    double hV, hR, aO, bO, kT, tol;
+    double hV, hR, inv_hR, aO, bO, kT, tol;
     unsigned long long seed; unsigned stream, draw_base;
     const double* noise; const int* mobile_index; int n_mobile, n_noise; unsigned noise_draw_base;  // precomputed N(0,1), see k_bonded_entries
-    Box3 box; int periodic;
+    Box3 box; int periodic; int cl_periodic;  // cl_periodic = 0: every cluster is stored as one whole image
     // tile image refresh + list validity
     AtomF* img_f; AtomD* img_d;
     const double* xbuild[3]; double half_skin2;
@@ -61,6 +62,7 @@ struct IntArgs {
     // COM removal
     double total_mass; double* cm_part; int cm_nblocks;
     DevAccum* acc; double* work_trace; int trace_index;
+    DevCtrl* ctrl;
     Program prog;
 };
 
@@ -109,7 +111,7 @@ template <int TYPE> __device__ inline void rattle_t(Cluster& C, const IntArgs& A
             r[c][k] = 0.0;
             if (c < C.nc) {
                 r[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k];
-                if (A.periodic) r[c][k] = min_image_d(r[c][k], A.box.L[k], A.box.invL[k]);
+                if (A.cl_periodic) r[c][k] = min_image_d(r[c][k], A.box.L[k], A.box.invL[k]);
                 rv += (C.v[T::ci(c)][k] - C.v[T::cj(c)][k]) * r[c][k];
             }
         }
@@ -145,12 +147,12 @@ template <int TYPE> __device__ inline bool shake_t(Cluster& C, const double xr[4
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             r[c][k] = 0.0;
-            if (c < C.nc) { r[c][k] = xr[T::ci(c)][k] - xr[T::cj(c)][k]; if (A.periodic) r[c][k] = min_image_d(r[c][k], A.box.L[k], A.box.invL[k]); }
+            if (c < C.nc) { r[c][k] = xr[T::ci(c)][k] - xr[T::cj(c)][k]; if (A.cl_periodic) r[c][k] = min_image_d(r[c][k], A.box.L[k], A.box.invL[k]); }
         }
     int it;
     for (it = 0; it < 50; it++) {
         double D[3][3], g[3], J[3][3], dl[3];
-        bool conv = true;
+        bool conv = true, tight = true;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             g[c] = 0.0;
@@ -158,11 +160,13 @@ template <int TYPE> __device__ inline bool shake_t(Cluster& C, const double xr[4
             for (int k = 0; k < 3; k++) D[c][k] = 0.0;
             if (c < C.nc) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) { D[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k]; if (A.periodic) D[c][k] = min_image_d(D[c][k], A.box.L[k], A.box.invL[k]); }
+                for (int k = 0; k < 3; k++) { D[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k]; if (A.cl_periodic) D[c][k] = min_image_d(D[c][k], A.box.L[k], A.box.invL[k]); }
                 g[c] = -(D[c][0] * D[c][0] + D[c][1] * D[c][1] + D[c][2] * D[c][2] - C.d2[c]);
                 if (fabs(g[c]) > 2.0 * tol * C.d2[c]) conv = false;
+                if (fabs(g[c]) > 1e-13 * C.d2[c]) tight = false;
             }
         }
+        if (tight) break;
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -218,6 +222,7 @@ struct FinArgs {
     const double* self_part; const double* e_part; const int* jcount_alch;
     double le[3];
     double* ftot; double* alch_self; DevAccum* acc;
+    DevCtrl* ctrl;
 };
 
 // grid: [0, n_itiles) one block per i-tile | [n_itiles, +nb_alch_atoms) alchemical atoms' bonded rows |
@@ -226,6 +231,12 @@ struct FinArgs {
 // fixed order (deterministic, and no chain of dependent global loads).
 __global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (A.ctrl) {
+        const int L = A.ctrl->L0 + 2 * A.ctrl->kpass;
+#pragma unroll
+        for (int s = 0; s < 3; s++) A.le[s] = A.ctrl->tab_le[min(L + s, A.ctrl->n_lambda)];
+        if (blockIdx.x == 0 && tid == 0) A.ctrl->kint = A.ctrl->kpass;  // nothing in this kernel reads kint
+    }
     const int n_itiles = A.n_islots / 64;
     const int nb_alch_atoms = A.n_alch > 0 ? 1 : 0;
     __shared__ double red[4][3][64];
@@ -291,6 +302,11 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
 
 __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
     const int tid = threadIdx.x;
+    if (A.ctrl) {
+        const int u = A.ctrl->kint;
+        A.draw_base = A.ctrl->draw0 + (unsigned)u; A.noise_draw_base = A.draw_base; A.trace_index = A.ctrl->trace0 + u;
+        if (blockIdx.x == 0 && tid == 0) A.ctrl->kpass = u + 1;  // nothing in this kernel reads kpass
+    }
     const int cl = blockIdx.x * blockDim.x + tid;
     __shared__ double s_red[4][4];
     __shared__ double s_cm[3];
@@ -317,16 +333,43 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
     }
     bool moved = false, ok = true;
     unsigned draw = A.draw_base;
+    // issue the loads of everything the program will need up front (independent of each other), so their
+    // latency overlaps instead of being paid op by op on this wave's serial path
+    int idxA = -1, idxB = -1, idxO = -1;
+    for (int q = 0; q < A.prog.n; q++) {
+        const int op = A.prog.ops[q];
+        if (op <= OP_V2) { if (idxA < 0) idxA = q; else if (idxB < 0) idxB = q; }
+        if (op == OP_O && idxO < 0) idxO = q;
+    }
+    double FA[4][3], FB[4][3], G0[4][3];
+    if (active && idxA >= 0) load_force(A, C, A.prog.ops[idxA] - OP_V0, FA);
+    if (active && idxB >= 0) load_force(A, C, A.prog.ops[idxB] - OP_V0, FB);
+    const bool pre_noise = active && idxO >= 0 && (draw - A.noise_draw_base) < (unsigned)A.n_noise;
+    if (pre_noise) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) if (a < C.na) {
+            const int m = A.mobile_index[C.id[a]];
+            for (int k = 0; k < 3; k++) G0[a][k] = A.noise[(size_t)((draw - A.noise_draw_base) * 3 + k) * A.n_mobile + m];
+        }
+    }
 
     for (int op_i = 0; op_i < A.prog.n; op_i++) {
         const int op = A.prog.ops[op_i];
         switch (op) {
         case OP_V0: case OP_V1: case OP_V2: {
             if (active) {
-                double F[4][3];
-                load_force(A, C, op - OP_V0, F);
+                if (op_i == idxA) {
 #pragma unroll
-                for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * F[a][k] * C.w[a];
+                    for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * FA[a][k] * C.w[a];
+                } else if (op_i == idxB) {
+#pragma unroll
+                    for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * FB[a][k] * C.w[a];
+                } else {
+                    double F[4][3];
+                    load_force(A, C, op - OP_V0, F);
+#pragma unroll
+                    for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * F[a][k] * C.w[a];
+                }
                 rattle(C, A.tol, A);
             }
         } break;
@@ -341,7 +384,7 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
                 }
                 ok &= shake(C, xr, A.tol, A);
 #pragma unroll
-                for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += (C.x[a][k] - x1[a][k]) / A.hR;
+                for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += (C.x[a][k] - x1[a][k]) * A.inv_hR;
                 rattle(C, A.tol, A);
                 moved = true;
             }
@@ -352,7 +395,9 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
                 for (int a = 0; a < 4; a++) if (a < C.na) {
                     double g[3];
                     const unsigned nd = draw - A.noise_draw_base;
-                    if (nd < (unsigned)A.n_noise) {
+                    if (pre_noise && op_i == idxO) {
+                        for (int k = 0; k < 3; k++) g[k] = G0[a][k];
+                    } else if (nd < (unsigned)A.n_noise) {
                         const int m = A.mobile_index[C.id[a]];
                         for (int k = 0; k < 3; k++) g[k] = A.noise[(size_t)(nd * 3 + k) * A.n_mobile + m];
                     } else gaussians3(A.seed, A.stream, draw, (unsigned)C.id[a], g);
@@ -473,4 +518,16 @@ __global__ void k_gather_forces(IntArgs A, int slot, double* out /*[n][3]*/) {
         if (A.n_alch > 0) f += al >= 0 ? A.alch_self[(slot * 3 + k) * 64 + al] : A.fJ[(size_t)(slot * 3 + k) * A.n + A.sorted_of_orig[i]];
         out[3 * i + k] = A.mass[i] != 0.0 ? f : 0.0;
     }
+}
+
+// The three force kernels of a pass are independent of each other; when the i-set is small they are all
+// latency-bound, so one launch with block-role dispatch runs them side by side on different CUs and saves
+// two kernel boundaries:  blocks [0,nb1) nonbonded | [nb1,nb1+nb2) alchemical | the rest bonded entries + noise.
+template <typename R>
+__global__ void __launch_bounds__(256) k_forces_fused(NbArgs<R> a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img,
+                                                      AlchArgs A, BondedArgs B, int nb1, int nb2) {
+    const int b = blockIdx.x;
+    if (b < nb1) { nonbonded_body<R, false, 4>(a, c, img, b); return; }
+    if (b < nb1 + nb2) { alchemical_body(A, b - nb1); return; }
+    bonded_entries_body(B, b - nb1 - nb2, 256);
 }

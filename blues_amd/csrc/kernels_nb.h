@@ -202,15 +202,15 @@ template <typename R> struct NbArgs {
 // One block = WPB waves working on the SAME i-tile; wave w of the tile walks the j-list segments
 // q = w, w+NW, w+2NW, ...; the block's waves are summed through LDS into one partial slab.
 template <typename R, bool ENERGY, int WPB>
-__global__ void __launch_bounds__(WPB * 64) k_nonbonded(NbArgs<R> a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img) {
+__device__ __forceinline__ void nonbonded_body(const NbArgs<R>& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int block_id) {
     using Atom = typename Img<R>::Atom;
     using sfix = typename Img<R>::sfix;
     __shared__ Atom lds[WPB][64];
     __shared__ double red[WPB][ENERGY ? 5 : 3][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.flags->list_gen = a.flags->req_gen;  // lists are current for this pass
+    if (block_id == 0 && threadIdx.x == 0) a.flags->list_gen = a.flags->req_gen;  // lists are current for this pass
     const int blocks_tile = a.waves_tile / WPB;
-    const int t = blockIdx.x / blocks_tile, part = blockIdx.x - t * blocks_tile;
+    const int t = block_id / blocks_tile, part = block_id - t * blocks_tile;
     if (t >= a.n_itiles) return;  // block-uniform
     const int w = part * WPB + wv;  // wave index within the tile
 
@@ -267,6 +267,11 @@ __global__ void __launch_bounds__(WPB * 64) k_nonbonded(NbArgs<R> a, NbConst<R> 
             if (lane == 0) { a.epart[2 * (t * a.npart + part)] = elj; a.epart[2 * (t * a.npart + part) + 1] = ecl; }
         }
     }
+}
+
+template <typename R, bool ENERGY, int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_nonbonded(NbArgs<R> a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img) {
+    nonbonded_body<R, ENERGY, WPB>(a, c, img, blockIdx.x);
 }
 
 // One-off: LJ + Coulomb energy among FROZEN environment atoms (constant while they and the box

@@ -604,7 +604,7 @@ static int constrain_positions(Oracle *o) {
         int it;
         for (it = 0; it < 50; it++) {
             double D[3][3], g[3], J[3][3], dl[3];
-            int conv = 1;
+            int conv = 1, tight = 1;
             for (int a = 0; a < nc; a++) {
                 int c = o->cluster_cons[q0 + a], i = o->cons_atoms[2 * c], j = o->cons_atoms[2 * c + 1];
                 double d2 = o->cons_dist[c] * o->cons_dist[c];
@@ -612,7 +612,9 @@ static int constrain_positions(Oracle *o) {
                 min_image(o, D[a]);
                 g[a] = -(dot(D[a], D[a]) - d2);
                 if (fabs(g[a]) > 2.0 * o->tol * d2) conv = 0;
+                if (fabs(g[a]) > 1e-13 * d2) tight = 0;
             }
+            if (tight) break; /* already converged to rounding: nothing to polish */
             for (int a = 0; a < nc; a++) for (int b = 0; b < nc; b++)
                 J[a][b] = 2.0 * dot(D[a], r[b]) * coupling(o, o->cluster_cons[q0 + a], o->cluster_cons[q0 + b]);
             solve_small(nc, J, g, dl);
