@@ -121,12 +121,12 @@ struct BluesEngine {
     DBuf<AtomF> d_img_f; DBuf<AtomD> d_img_d;
     DBuf<int> d_sorted_of_orig, d_orig_of_sorted, d_tile_atoms, d_jlist, d_jstage, d_jcount, d_batch_slot, d_pool_count, d_ex_start, d_ex_idx, d_islot;
     DBuf<unsigned long long> d_mask_pool;
-    DBuf<DevFlags> d_flags; DBuf<DevAccum> d_acc; DBuf<DevCtrl> d_ctrl; DBuf<double> d_tab_ls, d_tab_le;
+    DBuf<DevFlags> d_flags; DBuf<DevAccum> d_acc; DBuf<DevCtrl> d_ctrl; DBuf<double> d_tab_ls, d_tab_le; DBuf<long long> d_stamps;
     DBuf<double> d_fpart, d_epart_nb, d_fJ, d_self_part, d_e_part, d_fent, d_ftot, d_alch_self, d_epart_b, d_cm_part, d_trace, d_scratch;
     DBuf<int> d_orig_of_islot, d_row_of_orig, d_mobile_atoms, d_mobile_index, d_exc_owner;
     DBuf<double> d_noise; unsigned noise_draw_base = 0; int n_noise = 0; bool noise_valid = false;
     DBuf<int> d_alch_orig, d_alch_local, d_exc_start, d_exc_partner; DBuf<double> d_exc_params;
-    DBuf<int> d_cl_atoms, d_cl_type, d_cl_nc; DBuf<double> d_cl_dist;
+    DBuf<int> d_cl_atoms, d_cl_type, d_cl_nc, d_cl_alch, d_cl_mobile, d_cl_sorted; DBuf<double> d_cl_dist;
     // bonded
     DBuf<int> d_row_atom, d_row_start, d_ent_type, d_ent_term, d_ent_role;
     DBuf<int> d_term_atoms[T_NTYPES]; DBuf<double> d_term_params[T_NTYPES];
@@ -223,8 +223,19 @@ static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
         HostCluster hc; hc.atoms[0] = i; hc.atoms[1] = hc.atoms[2] = hc.atoms[3] = -1; hc.type = 0; hc.nc = 0; hc.dist[0] = hc.dist[1] = hc.dist[2] = 0;
         push(hc);
     }
-    h->clusters = alch_first; h->clusters.insert(h->clusters.end(), rest.begin(), rest.end());
-    if (alch_first.size() > 128) E_FAIL(h, "too many alchemical constraint clusters");
+    // a wave executes the star and the triangle solver one after the other if it holds both kinds, so group
+    // the clusters by kind and start each kind on a wave boundary (padding slots hold empty clusters)
+    {
+        std::vector<HostCluster> all = alch_first; all.insert(all.end(), rest.begin(), rest.end());
+        HostCluster empty; for (int a = 0; a < 4; a++) empty.atoms[a] = -1; empty.type = 0; empty.nc = 0; empty.dist[0] = empty.dist[1] = empty.dist[2] = 0;
+        h->clusters.clear();
+        for (int kind : {1, 0, 2}) {
+            bool any = false;
+            for (const HostCluster& c : all) if (c.type == kind) { h->clusters.push_back(c); any = true; }
+            if (any) while (h->clusters.size() % 64) h->clusters.push_back(empty);
+        }
+        while (!h->clusters.empty() && h->clusters.back().atoms[0] < 0) h->clusters.pop_back();
+    }
     const int ncl = (int)h->clusters.size();
     std::vector<int> ca(ncl * 4), ct(ncl), cn(ncl); std::vector<double> cd(ncl * 3);
     for (int c = 0; c < ncl; c++) {
@@ -233,6 +244,12 @@ static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
         for (int q = 0; q < 3; q++) cd[c * 3 + q] = h->clusters[c].dist[q];
     }
     h->d_cl_atoms.upload(ca); h->d_cl_type.upload(ct); h->d_cl_nc.upload(cn); h->d_cl_dist.upload(cd);
+    {
+        std::vector<int> cal(ncl * 4, -1), cmo(ncl * 4, 0), mi(n, 0);
+        for (size_t m = 0; m < h->mobile.size(); m++) mi[h->mobile[m]] = (int)m;
+        for (int c = 0; c < ncl * 4; c++) if (ca[c] >= 0) { cal[c] = h->alch_local[ca[c]]; cmo[c] = mi[ca[c]]; }
+        h->d_cl_alch.upload(cal); h->d_cl_mobile.upload(cmo); h->d_cl_sorted.alloc((size_t)ncl * 4);
+    }
     h->int_threads = ncl <= 256 ? std::max(128, ((ncl + 63) / 64) * 64) : 256;
     h->int_blocks = std::max(1, (ncl + h->int_threads - 1) / h->int_threads);
     h->d_cm_part.alloc((size_t)h->int_blocks * 3);
@@ -383,6 +400,9 @@ static int sort_and_tile(BluesEngine* h) {
     try {
         if (h->precision == 0) h->d_img_f.upload(imf); else h->d_img_d.upload(imd);
         h->d_sorted_of_orig.upload(h->h_sorted_of_orig); h->d_orig_of_sorted.upload(h->h_orig_of_sorted);
+        { std::vector<int> cs(h->clusters.size() * 4, 0);
+          for (size_t c = 0; c < h->clusters.size(); c++) for (int a = 0; a < 4; a++) if (h->clusters[c].atoms[a] >= 0) cs[c * 4 + a] = h->h_sorted_of_orig[h->clusters[c].atoms[a]];
+          h->d_cl_sorted.upload(cs); }
         h->d_tile_atoms.upload(tile_atoms); h->d_islot.upload(islot);
         h->d_ex_start.upload(ex_start); h->d_ex_idx.upload(ex_idx);
         h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * 4 * jcap); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
@@ -402,7 +422,7 @@ static int sort_and_tile(BluesEngine* h) {
 static IntArgs make_int_args(BluesEngine* h) {
     IntArgs A; memset(&A, 0, sizeof A);
     A.n = h->n; A.n_clusters = (int)h->clusters.size();
-    A.cl_atoms = h->d_cl_atoms.p; A.cl_type = h->d_cl_type.p; A.cl_nc = h->d_cl_nc.p; A.cl_dist = h->d_cl_dist.p;
+    A.cl_atoms = h->d_cl_atoms.p; A.cl_alch = h->d_cl_alch.p; A.cl_mobile = h->d_cl_mobile.p; A.cl_sorted = h->d_cl_sorted.p; A.cl_type = h->d_cl_type.p; A.cl_nc = h->d_cl_nc.p; A.cl_dist = h->d_cl_dist.p;
     for (int k = 0; k < 3; k++) { A.x[k] = h->d_x[k].p; A.v[k] = h->d_v[k].p; A.xbuild[k] = h->d_xbuild[k].p; }
     A.mass = h->d_mass.p;
     A.ftot = h->d_ftot.p; A.alch_self = h->d_alch_self.p;
@@ -418,7 +438,7 @@ static IntArgs make_int_args(BluesEngine* h) {
     A.half_skin2 = 0.25 * h->skin * h->skin; A.flags = h->d_flags.p; A.pool_count = h->d_pool_count.p;
     A.total_mass = h->total_mass; A.cm_part = h->d_cm_part.p; A.cm_nblocks = h->int_blocks;
     A.acc = h->d_acc.p; A.work_trace = (h->tracing || h->ctrl_arg) ? h->d_trace.p : nullptr; A.trace_index = h->prog_trace;
-    A.ctrl = h->ctrl_arg;
+    A.ctrl = h->ctrl_arg; A.stamps = h->d_stamps.p;
     A.prog = h->prog;
     return A;
 }
@@ -544,7 +564,7 @@ static int launch_finalize(BluesEngine* h, const double le[3]) {
     FinArgs F; memset(&F, 0, sizeof F);
     F.n = h->n; F.n_islots = h->n_islots; F.npart = h->npart; F.n_alch = (int)h->alch.size(); F.PA = h->PA; F.k2_nblocks_env = h->k2_nblocks_env; F.n_entries = h->n_entries;
     F.orig_of_islot = h->d_orig_of_islot.p; F.row_of_orig = h->d_row_of_orig.p; F.row_start = h->d_row_start.p;
-    F.fpart = h->d_fpart.p; F.fent = h->d_fent.p; F.alch_orig = h->d_alch_orig.p;
+    F.fpart = h->d_fpart.p; F.fent = h->d_fent.p; F.fJ = h->d_fJ.p; F.sorted_of_orig = h->d_sorted_of_orig.p; F.alch_orig = h->d_alch_orig.p;
     F.self_part = h->d_self_part.p; F.e_part = h->d_e_part.p; F.jcount_alch = h->d_jcount.p + h->n_itiles;
     for (int s = 0; s < 3; s++) F.le[s] = le[s];
     F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p; F.ctrl = h->ctrl_arg;
@@ -912,7 +932,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     try {
         for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); }
         h->d_mass.upload(h->mass); h->d_charge.upload(h->charge); h->d_sigma.upload(h->sigma); h->d_eps.upload(h->eps);
-        h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ctrl.alloc(1); h->d_tab_ls.upload(h->tab_ls); h->d_tab_le.upload(h->tab_le); h->d_ftot.alloc((size_t)3 * n); h->d_alch_self.alloc(9 * 64);
+        h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ctrl.alloc(1); h->d_stamps.alloc(64); h->d_tab_ls.upload(h->tab_ls); h->d_tab_le.upload(h->tab_le); h->d_ftot.alloc((size_t)9 * n); h->d_alch_self.alloc(9 * 64);
         h->d_alch_orig.upload(h->alch); h->d_alch_local.upload(h->alch_local);
         h->d_trace.alloc((size_t)std::max(1, h->nsteps)); h->d_scratch.alloc((size_t)std::max(3 * n, 1024));
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
@@ -944,6 +964,9 @@ int blues_engine_destroy(BluesEngine* h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+#ifdef BLUES_STAMP
+    { std::vector<long long> st; h->d_stamps.download(st); fprintf(stderr, "[stamps] last integrate launch, cycles per op:"); for (int i = 1; i < 40 && st[i] > 0; i++) fprintf(stderr, " %lld", st[i] - st[i - 1]); fprintf(stderr, "\n"); }
+#endif
     delete h;
     return 0;
 }

@@ -40,13 +40,17 @@ struct DevAccum {
 struct IntArgs {
     int n, n_clusters;
     const int* cl_atoms;    // [ncl*4] caller index or -1
+    const int* cl_alch;     // [ncl*4] local alchemical index or -1
+    const int* cl_mobile;   // [ncl*4] index into the mobile list (noise buffer)
+    const int* cl_sorted;   // [ncl*4] index into the tile image
     const int* cl_type;     // 0 single, 1 star (atom 0 = centre), 2 triangle
     const int* cl_nc;       // constraints in the cluster
     const double* cl_dist;  // [ncl*3]
     double* x[3]; double* v[3];
     const double* mass;
     // force sources
-    const double* ftot;       // [3][n] environment + bonded force per atom (k_finalize)
+    const double* ftot;       // [3 slots][3][n] total force on each mobile non-alchemical atom per lambda slot; slot 0 also
+                              // carries the bonded force of alchemical atoms (k_finalize)
     const double* alch_self;  // [9][64] force on the alchemical atoms per slot (k_finalize)
     const double* fJ; const int* sorted_of_orig; int n_alch;
     const int* alch_local_of_orig;
@@ -63,12 +67,13 @@ struct IntArgs {
     double total_mass; double* cm_part; int cm_nblocks;
     DevAccum* acc; double* work_trace; int trace_index;
     DevCtrl* ctrl;
+    long long* stamps;  // debug builds (-DBLUES_STAMP): cycle stamp of thread 0 at every op boundary
     Program prog;
 };
 
 struct Cluster {
     double x[4][3], v[4][3], w[4];  // w = 1/m
-    int id[4];
+    int id[4], al[4];
     int na, nc, type;
     double d2[3];
 };
@@ -196,13 +201,10 @@ __device__ inline void load_force(const IntArgs& A, const Cluster& C, int slot, 
         F[a][0] = F[a][1] = F[a][2] = 0.0;
         if (a < C.na) {
             const int i = C.id[a];
-            const int al = A.n_alch > 0 ? A.alch_local_of_orig[i] : -1;
-            const int srt = A.sorted_of_orig[i];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                double f = A.ftot[(size_t)k * A.n + i];
-                if (A.n_alch > 0) f += al >= 0 ? A.alch_self[(slot * 3 + k) * 64 + al] : A.fJ[(size_t)(slot * 3 + k) * A.n + srt];
-                F[a][k] = f;
+                if (C.al[a] >= 0) F[a][k] = A.ftot[(size_t)k * A.n + i] + A.alch_self[(slot * 3 + k) * 64 + C.al[a]];
+                else F[a][k] = A.ftot[(size_t)(slot * 3 + k) * A.n + i];
             }
         }
     }
@@ -217,7 +219,7 @@ struct FinArgs {
     const int* orig_of_islot;   // [n_islots] caller index or -1
     const int* row_of_orig;     // [n] bonded row or -1
     const int* row_start;
-    const double* fpart; const double* fent;
+    const double* fpart; const double* fent; const double* fJ; const int* sorted_of_orig;
     const int* alch_orig;
     const double* self_part; const double* e_part; const int* jcount_alch;
     double le[3];
@@ -267,8 +269,17 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
         }
         red[wv][0][lane] = f[0]; red[wv][1][lane] = f[1]; red[wv][2][lane] = f[2];
         __syncthreads();
-        if (wv == 0 && i >= 0)
-            for (int k = 0; k < 3; k++) A.ftot[(size_t)k * A.n + i] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+        if (wv == 0 && i >= 0) {
+            const int srt = A.sorted_of_orig[i];
+            for (int k = 0; k < 3; k++) {
+                const double f = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+                if (isl >= 0 && A.n_alch > 0) {
+                    for (int sl = 0; sl < 3; sl++) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f + A.fJ[(size_t)(sl * 3 + k) * A.n + srt];
+                } else if (isl >= 0) {
+                    for (int sl = 0; sl < 3; sl++) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f;
+                } else A.ftot[(size_t)k * A.n + i] = f;  // alchemical atom: bonded part; integrator adds alch_self[slot]
+            }
+        }
         return;
     }
     if (A.n_alch == 0) return;
@@ -318,7 +329,7 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
         C.type = A.cl_type[cl]; C.nc = A.cl_nc[cl];
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-            C.id[a] = A.cl_atoms[cl * 4 + a];
+            C.id[a] = A.cl_atoms[cl * 4 + a]; C.al[a] = A.cl_alch[cl * 4 + a];
             if (C.id[a] >= 0) {
                 C.na = a + 1;
                 for (int k = 0; k < 3; k++) { C.x[a][k] = A.x[k][C.id[a]]; C.v[a][k] = A.v[k][C.id[a]]; }
@@ -333,43 +344,21 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
     }
     bool moved = false, ok = true;
     unsigned draw = A.draw_base;
-    // issue the loads of everything the program will need up front (independent of each other), so their
-    // latency overlaps instead of being paid op by op on this wave's serial path
-    int idxA = -1, idxB = -1, idxO = -1;
-    for (int q = 0; q < A.prog.n; q++) {
-        const int op = A.prog.ops[q];
-        if (op <= OP_V2) { if (idxA < 0) idxA = q; else if (idxB < 0) idxB = q; }
-        if (op == OP_O && idxO < 0) idxO = q;
-    }
-    double FA[4][3], FB[4][3], G0[4][3];
-    if (active && idxA >= 0) load_force(A, C, A.prog.ops[idxA] - OP_V0, FA);
-    if (active && idxB >= 0) load_force(A, C, A.prog.ops[idxB] - OP_V0, FB);
-    const bool pre_noise = active && idxO >= 0 && (draw - A.noise_draw_base) < (unsigned)A.n_noise;
-    if (pre_noise) {
-#pragma unroll
-        for (int a = 0; a < 4; a++) if (a < C.na) {
-            const int m = A.mobile_index[C.id[a]];
-            for (int k = 0; k < 3; k++) G0[a][k] = A.noise[(size_t)((draw - A.noise_draw_base) * 3 + k) * A.n_mobile + m];
-        }
-    }
-
+#ifdef BLUES_STAMP
+    if (cl == 0 && A.stamps) A.stamps[0] = clock64();
+#endif
     for (int op_i = 0; op_i < A.prog.n; op_i++) {
         const int op = A.prog.ops[op_i];
+#ifdef BLUES_STAMP
+        if (cl == 0 && A.stamps) A.stamps[1 + op_i] = clock64();
+#endif
         switch (op) {
         case OP_V0: case OP_V1: case OP_V2: {
             if (active) {
-                if (op_i == idxA) {
+                double F[4][3];
+                load_force(A, C, op - OP_V0, F);
 #pragma unroll
-                    for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * FA[a][k] * C.w[a];
-                } else if (op_i == idxB) {
-#pragma unroll
-                    for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * FB[a][k] * C.w[a];
-                } else {
-                    double F[4][3];
-                    load_force(A, C, op - OP_V0, F);
-#pragma unroll
-                    for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * F[a][k] * C.w[a];
-                }
+                for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * F[a][k] * C.w[a];
                 rattle(C, A.tol, A);
             }
         } break;
@@ -395,10 +384,8 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
                 for (int a = 0; a < 4; a++) if (a < C.na) {
                     double g[3];
                     const unsigned nd = draw - A.noise_draw_base;
-                    if (pre_noise && op_i == idxO) {
-                        for (int k = 0; k < 3; k++) g[k] = G0[a][k];
-                    } else if (nd < (unsigned)A.n_noise) {
-                        const int m = A.mobile_index[C.id[a]];
+                    if (nd < (unsigned)A.n_noise) {
+                        const int m = A.cl_mobile[cl * 4 + a];
                         for (int k = 0; k < 3; k++) g[k] = A.noise[(size_t)(nd * 3 + k) * A.n_mobile + m];
                     } else gaussians3(A.seed, A.stream, draw, (unsigned)C.id[a], g);
                     const double s = sqrt(A.kT * C.w[a]);
@@ -462,6 +449,9 @@ _Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 
         }
     }
 
+#ifdef BLUES_STAMP
+    if (cl == 0 && A.stamps) A.stamps[1 + A.prog.n] = clock64();
+#endif
     if (!active) return;
     // ---- write back, refresh the fixed-point image, check list validity
     bool need_rebuild = false, bad = false;
@@ -476,13 +466,16 @@ _Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 
                 need_rebuild |= d2 > A.half_skin2;
                 unsigned long long u[3];
                 to_fixed(C.x[a], A.box, u);
-                const int s = A.sorted_of_orig[i];
+                const int s = A.cl_sorted[cl * 4 + a];
                 if (A.img_f) { A.img_f[s].x = (unsigned)((u[0] + 0x80000000ull) >> 32); A.img_f[s].y = (unsigned)((u[1] + 0x80000000ull) >> 32); A.img_f[s].z = (unsigned)((u[2] + 0x80000000ull) >> 32); }
                 else { A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
             }
         }
     }
     if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; *A.pool_count = 0; }
+#ifdef BLUES_STAMP
+    if (cl == 0 && A.stamps) A.stamps[2 + A.prog.n] = clock64();
+#endif
     if (bad) A.flags->nan_flag = 1;
     if (!ok) A.flags->constraint_fail = 1;
 }
@@ -508,14 +501,13 @@ __global__ void k_maxwell(int n, const double* __restrict__ mass, double* vx, do
     vx[i] = g[0]; vy[i] = g[1]; vz[i] = g[2];
 }
 
-// total forces in caller order for getState(getForces=True): ftot + alchemical (slot); frozen atoms report 0
+// total forces in caller order for getState(getForces=True); frozen atoms report 0
 __global__ void k_gather_forces(IntArgs A, int slot, double* out /*[n][3]*/) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
     const int al = A.n_alch > 0 ? A.alch_local_of_orig[i] : -1;
     for (int k = 0; k < 3; k++) {
-        double f = A.ftot[(size_t)k * A.n + i];
-        if (A.n_alch > 0) f += al >= 0 ? A.alch_self[(slot * 3 + k) * 64 + al] : A.fJ[(size_t)(slot * 3 + k) * A.n + A.sorted_of_orig[i]];
+        double f = al >= 0 ? A.ftot[(size_t)k * A.n + i] + A.alch_self[(slot * 3 + k) * 64 + al] : A.ftot[(size_t)(slot * 3 + k) * A.n + i];
         out[3 * i + k] = A.mass[i] != 0.0 ? f : 0.0;
     }
 }
