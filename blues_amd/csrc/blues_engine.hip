@@ -360,7 +360,7 @@ static int sort_and_tile(BluesEngine* h) {
         if (const char* e = getenv("BLUES_WPB")) WPB = std::max(1, std::min(h->precision == 0 ? 16 : 8, atoi(e)));
         h->fuse_forces = nit <= 32;  // small i-set: every force kernel is latency-bound -> one fused launch
         if (const char* e = getenv("BLUES_FUSE")) h->fuse_forces = atoi(e) != 0;
-        if (h->fuse_forces) { WPB = 4; NW = std::max(NW, 4); }
+        if (h->fuse_forces) { WPB = 4; NW = std::max(4, NW / 3); }  // ~3 segments per wave: as long as the alchemical role
         NW = std::max(WPB, (NW / WPB) * WPB);
         h->seg_len = CH; h->waves_tile = NW; h->wpb = WPB; h->npart = NW / WPB;
     }
@@ -414,7 +414,7 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_self_part.alloc((size_t)(h->k2_nblocks_env + 1) * 9 * 64); h->d_e_part.alloc((size_t)(h->k2_nblocks_env + 1) * K2_NE);
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     h->hx_sort = h->hx;
-    h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->e_frozen_valid = false; h->graph_valid = false;
+    h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->graph_valid = false;
     return 0;
 }
 
@@ -1016,13 +1016,16 @@ int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
     // re-sort when never sorted or when atoms have drifted far from where the tiles were formed
     bool resort = !h->sorted_ok;
     if (!resort) {
-        double worst = 0.0;
+        // tiles are formed from the mobile non-alchemical atoms: re-sort when one of THEM has wandered far from where
+        // its tile was formed, or when a sizeable part of the whole system has (j-list locality)
+        double worst_i = 0.0; int far = 0;
         for (int i = 0; i < h->n; i++) {
             double d2 = 0.0;
             for (int k = 0; k < 3; k++) { double d = h->hx[3 * i + k] - h->hx_sort[3 * i + k]; d -= h->box[k] * std::nearbyint(d / h->box[k]); d2 += d * d; }
-            worst = std::max(worst, d2);
+            if (h->mass[i] != 0.0 && h->alch_local[i] < 0) worst_i = std::max(worst_i, d2);
+            if (d2 > 0.5 * 0.5) far++;
         }
-        resort = worst > 0.25 * 0.25;
+        resort = worst_i > 0.4 * 0.4 || far > h->n / 10;
     }
     if (resort) { h->sorted_ok = false; if (sort_and_tile(h)) return 1; }
     else {

@@ -464,11 +464,9 @@ _Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 
                 double d2 = 0.0;
                 for (int k = 0; k < 3; k++) { A.x[k][i] = C.x[a][k]; const double d = C.x[a][k] - A.xbuild[k][i]; d2 += d * d; }
                 need_rebuild |= d2 > A.half_skin2;
-                unsigned long long u[3];
-                to_fixed(C.x[a], A.box, u);
                 const int s = A.cl_sorted[cl * 4 + a];
-                if (A.img_f) { A.img_f[s].x = (unsigned)((u[0] + 0x80000000ull) >> 32); A.img_f[s].y = (unsigned)((u[1] + 0x80000000ull) >> 32); A.img_f[s].z = (unsigned)((u[2] + 0x80000000ull) >> 32); }
-                else { A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
+                if (A.img_f) { unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2]; }
+                else { unsigned long long u[3]; to_fixed(C.x[a], A.box, u); A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
             }
         }
     }

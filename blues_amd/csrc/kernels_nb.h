@@ -315,6 +315,9 @@ __global__ void __launch_bounds__(256) k_energy_frozen(int n, NbConst<R> c, cons
     }
 }
 
+__device__ inline void to_fixed32(const double p[3], const Box3& box, unsigned u[3]);
+__device__ inline void to_fixed(const double p[3], const Box3& box, unsigned long long u[3]);
+
 // Refresh the fixed-point tile image from the fp64 master positions (all atoms).
 template <typename R>
 __global__ void k_pack_positions(int n, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
@@ -324,14 +327,20 @@ __global__ void k_pack_positions(int n, const double* __restrict__ x, const doub
     if (i >= n) return;
     const double p[3] = {x[i], y[i], z[i]};
     ufix f[3];
-    for (int k = 0; k < 3; k++) {
-        double fr = p[k] * box.invL[k]; fr -= floor(fr);
-        if (fr >= 1.0) fr = 0.0;
-        unsigned long long u = (unsigned long long)(fr * 18446744073709551616.0);
-        if (sizeof(ufix) == 4) f[k] = (ufix)((u + 0x80000000ull) >> 32); else f[k] = (ufix)u;
-    }
+    if (sizeof(ufix) == 4) { unsigned u[3]; to_fixed32(p, box, u); f[0] = (ufix)u[0]; f[1] = (ufix)u[1]; f[2] = (ufix)u[2]; }
+    else { unsigned long long u[3]; to_fixed(p, box, u); f[0] = (ufix)u[0]; f[1] = (ufix)u[1]; f[2] = (ufix)u[2]; }
     const int s = sorted_of_orig[i];
     img[s].x = f[0]; img[s].y = f[1]; img[s].z = f[2];
+}
+
+// 32-bit variant with native conversions: floor(fr*2^32 + 0.5) mod 2^32 == (floor(fr*2^64) + 2^31) >> 32
+__device__ inline void to_fixed32(const double p[3], const Box3& box, unsigned u[3]) {
+    for (int k = 0; k < 3; k++) {
+        double fr = p[k] * box.invL[k]; fr -= floor(fr);
+        double t = fr * 4294967296.0 + 0.5;
+        if (t >= 4294967296.0) t -= 4294967296.0;
+        u[k] = (unsigned)t;
+    }
 }
 
 __device__ inline void to_fixed(const double p[3], const Box3& box, unsigned long long u[3]) {
