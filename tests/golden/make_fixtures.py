@@ -126,6 +126,33 @@ def make_known_answers():
     print("wrote", out)
 
 
+def make_oracle_vectors():
+    """Regression vectors: oracle outputs on the committed toluene box (inputs = blues_amd/data/tol_box.npz).
+    They are NOT reference values (the reference has none); they freeze the oracle so that
+    a silent change of the checker itself is caught, and give the GPU suite committed numbers to hit."""
+    s, v = systems.toluene_box()
+    from blues_amd import integrators
+    data = integrators.generateNCMCIntegrator(nstepsNC=20, dt=0.004, temperature=300.0, seed=7).to_data()
+    o = oracle.Oracle(s, data); o.set_velocities(v)
+    out = {"_note": "oracle (fp64 CPU restatement) outputs on blues_amd/data/tol_box.npz; generated by tests/golden/make_fixtures.py",
+           "integrator": {"nstepsNC": 20, "dt": 0.004, "temperature": 300.0, "seed": 7}, "energies": [], "work_trace": []}
+    sel = [0, 3, 7, 14, 15, 16, 500, 974]
+    for (ls, le) in ((1.0, 1.0), (0.5, 0.3), (0.05, 0.0), (0.0, 0.0)):
+        e, f, t = o.energy_forces(ls, le)
+        out["energies"].append({"lambda_sterics": ls, "lambda_electrostatics": le, "total": e, "terms": t.tolist(),
+                                "force_atoms": sel, "forces": f[sel].tolist(), "force_norm": float(np.linalg.norm(f))})
+    for k in range(20):
+        o.step(1); out["work_trace"].append(o.get_global("protocol_work"))
+    x = o.get_positions()
+    out["final_positions_atoms"] = sel; out["final_positions"] = x[sel].tolist()
+    path = os.path.join(ROOT, "tests", "golden", "tol_box_oracle_vectors.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     make_known_answers()
-    make_tol_box()
+    if "--vectors-only" not in sys.argv:
+        make_tol_box()
+    make_oracle_vectors()

@@ -295,3 +295,27 @@ def test_context_surface_on_gpu(tol_box):
     assert b.accept + b.reject == 2
     assert np.isfinite(b.last["log_accept"]) and abs(b.last["correction"]) < 1e-6
     assert sim.context.getPlatform().getName().startswith("HIP")
+
+
+@pytest.mark.parametrize("precision,tol", [(1, 1e-9), (0, 1e-5)])
+def test_committed_golden_vectors(Engine, tol_box, precision, tol):
+    """The engine against the committed vectors of tests/golden/tol_box_oracle_vectors.json (no oracle at run time)."""
+    import json, os
+    s, v = tol_box
+    with open(os.path.join(os.path.dirname(__file__), "golden", "tol_box_oracle_vectors.json")) as fh:
+        vec = json.load(fh)
+    ic = vec["integrator"]
+    data = integrators.generateNCMCIntegrator(nstepsNC=ic["nstepsNC"], dt=ic["dt"], temperature=ic["temperature"], seed=ic["seed"]).to_data(precision=precision)
+    g = Engine(s, data); g.set_velocities(v)
+    for rec in vec["energies"]:
+        g.set_global("lambda_sterics", rec["lambda_sterics"]); g.set_global("lambda_electrostatics", rec["lambda_electrostatics"])
+        t = g.energy_terms()
+        assert abs(t.sum() - rec["total"]) <= tol * abs(rec["total"])
+        f = g.get_forces()
+        fr = np.array(rec["forces"])
+        assert np.abs(f[rec["force_atoms"]] - fr).max() <= tol * rec["force_norm"] / np.sqrt(s.n_atoms) * 30
+    g.set_global("lambda_sterics", 1.0); g.set_global("lambda_electrostatics", 1.0)
+    w = g.run_switch(ic["nstepsNC"], trace=True)
+    wref = np.array(vec["work_trace"])
+    assert np.abs(w - wref).max() <= tol * np.abs(wref).max()
+    g.close()

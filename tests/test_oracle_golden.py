@@ -248,3 +248,23 @@ def test_extra_propagation_and_other_splittings(oracle_mod, tol_box):
     o2.set_velocities(v)
     o2.step(10)
     assert o2.get_global("lambda") == pytest.approx(1.0) and np.isfinite(o2.get_global("protocol_work"))
+
+
+def test_oracle_regression_vectors(oracle_mod, tol_box):
+    """The committed oracle vectors (tests/golden/tol_box_oracle_vectors.json) are reproduced bit-for-bit-ish (1e-12)."""
+    import json, os
+    s, v = tol_box
+    with open(os.path.join(os.path.dirname(__file__), "golden", "tol_box_oracle_vectors.json")) as fh:
+        vec = json.load(fh)
+    ic = vec["integrator"]
+    data = integrators.generateNCMCIntegrator(nstepsNC=ic["nstepsNC"], dt=ic["dt"], temperature=ic["temperature"], seed=ic["seed"]).to_data()
+    o = oracle_mod.Oracle(s, data); o.set_velocities(v)
+    for rec in vec["energies"]:
+        e, f, t = o.energy_forces(rec["lambda_sterics"], rec["lambda_electrostatics"])
+        assert e == pytest.approx(rec["total"], rel=1e-12)
+        assert np.allclose(t, rec["terms"], rtol=1e-11, atol=1e-9)
+        assert np.allclose(f[rec["force_atoms"]], rec["forces"], rtol=1e-10, atol=1e-8)
+    w = []
+    for _ in range(ic["nstepsNC"]):
+        o.step(1); w.append(o.get_global("protocol_work"))
+    assert np.allclose(w, vec["work_trace"], rtol=1e-10, atol=1e-10)
