@@ -104,6 +104,7 @@ class SystemData:
     positions: np.ndarray = None         # (n,3) nm, optional initial coordinates
     residue_of_atom: np.ndarray = None   # optional bookkeeping for host-side selections
     names: list = None
+    extras: dict = None                  # oracle-only test extras (custom forces of the ethylene known-answer system); ignored by the engine
 
     @property
     def n_atoms(self):

@@ -147,3 +147,44 @@ def generateNCMCIntegrator(nstepsNC=None, alchemical_functions=None, splitting="
     return AlchemicalExternalLangevinIntegrator(
         alchemical_functions=alchemical_functions, splitting=splitting, temperature=temperature, nsteps_neq=nstepsNC,
         timestep=dt, nprop=nprop, prop_lambda=propLambda, seed=kwargs.get("seed", 0))
+
+
+class LangevinIntegrator(object):
+    """openmm.LangevinIntegrator(temperature, frictionCoeff, stepSize) stand-in for the MD leg
+    (reference blues/simulation.py:629-648).  Splitting token 'L' = OpenMM's Langevin step:
+    v' = a v + (1-a)/gamma f/m + sqrt(kT(1-a^2)/m) xi ; x' = x + dt v' ; constrain ; v = (x'-x)/dt."""
+
+    def __init__(self, temperature, frictionCoeff, stepSize, seed=0):
+        self._temperature = unit.value_in(temperature, "kelvin")
+        self._collision_rate = unit.value_in(frictionCoeff, "1/picosecond")
+        self._timestep = unit.value_in(stepSize, "picosecond")
+        self._seed = int(seed)
+        self._engine = None
+        self._constraint_tolerance = 1e-5  # OpenMM's LangevinIntegrator default
+
+    @property
+    def kT(self):
+        return unit.Quantity(KB * self._temperature, "kilojoule/mole")
+
+    def getTemperature(self): return unit.Quantity(self._temperature, "kelvin")
+    def getStepSize(self): return unit.Quantity(self._timestep, "picosecond")
+    def getFriction(self): return unit.Quantity(self._collision_rate, "1/picosecond")
+    def setRandomNumberSeed(self, seed): self._seed = int(seed)
+    def getRandomNumberSeed(self): return self._seed
+    def setConstraintTolerance(self, tol): self._constraint_tolerance = float(tol)
+
+    def to_data(self, replica=0, precision=0):
+        return IntegratorData(timestep=self._timestep, temperature=self._temperature, nsteps_neq=2 ** 30, lambda_sterics=np.array([1.0]),
+                              lambda_electrostatics=np.array([1.0]), splitting="L", collision_rate=self._collision_rate, nprop=1,
+                              prop_lambda_min=2.0, prop_lambda_max=-1.0, constraint_tolerance=self._constraint_tolerance,
+                              seed=self._seed, replica=replica, precision=precision)
+
+    def _bind(self, engine): self._engine = engine
+
+    def step(self, n):
+        if self._engine is None:
+            raise RuntimeError("integrator is not bound to a context")
+        self._engine.step(int(n))
+
+    def getGlobalVariableByName(self, name):
+        return self._engine.get_global(name)

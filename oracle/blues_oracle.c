@@ -91,6 +91,10 @@ struct Oracle {
     double cache_ls, cache_le, cache_E;
     int cache_valid;
     long n_evals;
+    /* oracle-only extras for the reference's ethylene known-answer system (tests/data/ethylene_system.xml) */
+    int custom_pair_mode;       /* 1: CustomNonbondedForce 'q/(r^2) + 4*epsilon*((sigma/r)^12-(sigma/r)^6)' between set1 (non-alchemical)
+                                   and set2 (alchemical) atoms, sigma scaled by lambda_sterics, epsilon by lambda_electrostatics */
+    int n_centroid; int cb_n1[4], cb_n2[4]; int cb_i1[4][8], cb_i2[4][8]; double cb_w1[4][8], cb_w2[4][8], cb_k[4];
     /* cell list scratch */
     int *cell_head, *cell_next;
     int ncell[3];
@@ -256,10 +260,10 @@ Oracle *orc_create(const BluesSystemDesc *s, const BluesIntegratorDesc *it) {
     o->n_split = 0;
     for (const char *p = it->splitting; *p; p++) {
         if (*p == ' ') continue;
-        if (*p != 'R' && *p != 'V' && *p != 'O' && *p != 'H') { snprintf(g_err, sizeof g_err, "unsupported splitting token '%c'", *p); orc_destroy(o); return NULL; }
+        if (*p != 'R' && *p != 'V' && *p != 'O' && *p != 'H' && *p != 'L') { snprintf(g_err, sizeof g_err, "unsupported splitting token '%c'", *p); orc_destroy(o); return NULL; }
         if (o->n_split >= MAX_SPLIT - 1) { snprintf(g_err, sizeof g_err, "splitting too long"); orc_destroy(o); return NULL; }
         o->split[o->n_split++] = *p;
-        if (*p == 'R') o->n_R++; else if (*p == 'V') o->n_V++; else if (*p == 'O') o->n_O++; else o->n_H++;
+        if (*p == 'R') o->n_R++; else if (*p == 'V') o->n_V++; else if (*p == 'O') o->n_O++; else if (*p == 'H') o->n_H++;
     }
     if (o->n_lambda_steps != o->nsteps * o->n_H) { snprintf(g_err, sizeof g_err, "n_lambda_steps must be nsteps_neq * n_H"); orc_destroy(o); return NULL; }
     o->tab_ls = dup_mem(it->lambda_sterics, sizeof(double) * (o->n_lambda_steps + 1));
@@ -356,6 +360,16 @@ static inline void nb_pair(const Oracle *o, int i, int j, double ls, double le, 
     int pme = o->nb_method == BLUES_NB_PME_DIRECT;
     if (pme && r2 >= o->cutoff * o->cutoff) return;
     if (is_excluded(o, i, j)) return;
+    if (o->custom_pair_mode == 1) { /* ethylene_system.xml:52: interaction group set1 x set2 only */
+        if (o->is_alch[i] == o->is_alch[j]) return;
+        double q = o->charge[i] * o->charge[j];
+        double sg = 0.5 * (o->sigma[i] + o->sigma[j]) * ls, ep = sqrt(o->eps[i] * o->eps[j]) * le;
+        double sr2 = sg * sg / r2, sr6 = sr2 * sr2 * sr2;
+        T[6] += q / r2; T[5] += 4.0 * ep * (sr6 * sr6 - sr6);
+        double fsc = 2.0 * q / (r2 * r2) + 4.0 * ep * (12.0 * sr6 * sr6 - 6.0 * sr6) / r2;
+        if (F) for (int k = 0; k < 3; k++) { F[3 * i + k] += fsc * d[k]; F[3 * j + k] -= fsc * d[k]; }
+        return;
+    }
     double sig = 0.5 * (o->sigma[i] + o->sigma[j]), eps = sqrt(o->eps[i] * o->eps[j]), qq = o->charge[i] * o->charge[j];
     int ai = o->is_alch[i], aj = o->is_alch[j];
     double fs, fc, fscale;
@@ -491,6 +505,18 @@ static void bonded(const Oracle *o, double *F, double *T) {
             for (int c = 0; c < 3; c++) {
                 F[3 * i + c] += fi[c]; F[3 * j + c] -= fi[c] - sv[c]; F[3 * k + c] -= fl[c] + sv[c]; F[3 * l + c] += fl[c];
             }
+        }
+    }
+    /* CustomCentroidBondForce '0.5*k*distance(g1,g2)^2' (ethylene_system.xml:94-112), oracle-only */
+    for (int b = 0; b < o->n_centroid; b++) {
+        double c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, W1 = 0, W2 = 0;
+        for (int q = 0; q < o->cb_n1[b]; q++) { W1 += o->cb_w1[b][q]; for (int k = 0; k < 3; k++) c1[k] += o->cb_w1[b][q] * x[3 * o->cb_i1[b][q] + k]; }
+        for (int q = 0; q < o->cb_n2[b]; q++) { W2 += o->cb_w2[b][q]; for (int k = 0; k < 3; k++) c2[k] += o->cb_w2[b][q] * x[3 * o->cb_i2[b][q] + k]; }
+        double d[3]; for (int k = 0; k < 3; k++) d[k] = c1[k] / W1 - c2[k] / W2;
+        T[7] += 0.5 * o->cb_k[b] * dot(d, d);
+        if (F) {
+            for (int q = 0; q < o->cb_n1[b]; q++) for (int k = 0; k < 3; k++) F[3 * o->cb_i1[b][q] + k] -= o->cb_k[b] * d[k] * o->cb_w1[b][q] / W1;
+            for (int q = 0; q < o->cb_n2[b]; q++) for (int k = 0; k < 3; k++) F[3 * o->cb_i2[b][q] + k] += o->cb_k[b] * d[k] * o->cb_w2[b][q] / W2;
         }
     }
     /* k_restr*periodicdistance(x,y,z,x0,y0,z0)^2  (reference blues/simulation.py:347) */
@@ -721,6 +747,40 @@ static void step_O(Oracle *o) {
     o->g.heat += orc_kinetic_energy(o) - ke0;
 }
 
+/* OpenMM LangevinIntegrator step (the MD leg, reference blues/simulation.py:647):
+ *   v' = a v + (1-a)/gamma f/m + sqrt(kT (1-a^2)/m) xi ;  x' = x + dt v' ; constrain x' ; v = (x'-x)/dt */
+static void step_L(Oracle *o) {
+    cached_energy(o);
+    const double a = exp(-o->gamma * o->dt), fs = o->gamma == 0.0 ? o->dt : (1.0 - a) / o->gamma, ns = sqrt(1.0 - a * a);
+    int n3 = 3 * o->n;
+    double *x0 = malloc(sizeof(double) * n3);
+    memcpy(x0, o->x, sizeof(double) * n3);
+    for (int i = 0; i < o->n; i++) if (o->mass[i] != 0.0) {
+        double g[3]; orc_gaussians(o->seed, o->replica * 4u, o->draw, (uint32_t)i, g);
+        double w = 1.0 / o->mass[i], sd = sqrt(o->kT * w);
+        for (int k = 0; k < 3; k++) {
+            o->v[3 * i + k] = a * o->v[3 * i + k] + fs * w * o->f[3 * i + k] + ns * sd * g[k];
+            o->x[3 * i + k] += o->dt * o->v[3 * i + k];
+        }
+    }
+    o->draw++;
+    memcpy(o->xref, x0, sizeof(double) * n3);
+    constrain_positions(o);
+    for (int i = 0; i < o->n; i++) if (o->mass[i] != 0.0) for (int k = 0; k < 3; k++) o->v[3 * i + k] = (o->x[3 * i + k] - x0[3 * i + k]) / o->dt;
+    free(x0);
+}
+
+void orc_set_custom_pair_mode(Oracle *o, int mode) { o->custom_pair_mode = mode; o->cache_valid = 0; }
+int orc_add_centroid_bond(Oracle *o, int n1, const int *i1, const double *w1, int n2, const int *i2, const double *w2, double k) {
+    if (o->n_centroid >= 4 || n1 > 8 || n2 > 8) return 1;
+    int b = o->n_centroid++;
+    o->cb_n1[b] = n1; o->cb_n2[b] = n2; o->cb_k[b] = k;
+    for (int q = 0; q < n1; q++) { o->cb_i1[b][q] = i1[q]; o->cb_w1[b][q] = w1[q]; }
+    for (int q = 0; q < n2; q++) { o->cb_i2[b][q] = i2[q]; o->cb_w2[b][q] = w2[q]; }
+    o->cache_valid = 0;
+    return 0;
+}
+
 static void update_alchemical_parameters(Oracle *o, int lambda_step) {
     o->g.lambda_sterics = o->tab_ls[lambda_step];
     o->g.lambda_electrostatics = o->tab_le[lambda_step];
@@ -747,6 +807,7 @@ static void splitting_pass(Oracle *o) {
         case 'R': step_R(o); break;
         case 'O': step_O(o); break;
         case 'H': step_H(o); break;
+        case 'L': step_L(o); break;
         }
     }
 }

@@ -57,6 +57,11 @@ void orc_reset(Oracle *o);
 /* number of full (x, lambda) energy/force evaluations performed so far */
 long orc_num_evaluations(Oracle *o);
 
+/* oracle-only extras needed to restate the reference's ethylene known-answer system
+ * (blues/tests/data/ethylene_system.xml: CustomNonbondedForce interaction group + CustomCentroidBondForce) */
+void orc_set_custom_pair_mode(Oracle *o, int mode);
+int orc_add_centroid_bond(Oracle *o, int n1, const int *i1, const double *w1, int n2, const int *i2, const double *w2, double k);
+
 /* plain steepest-descent relaxation with constraints (used to prepare fixtures) */
 double orc_minimize(Oracle *o, int max_iter, double step0);
 

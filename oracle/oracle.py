@@ -46,6 +46,8 @@ def lib():
         L.orc_set_global.argtypes = [H, C.c_char_p, C.c_double]; L.orc_set_global.restype = C.c_int
         L.orc_reset.argtypes = [H]; L.orc_reset.restype = None
         L.orc_num_evaluations.argtypes = [H]; L.orc_num_evaluations.restype = C.c_long
+        L.orc_set_custom_pair_mode.argtypes = [H, C.c_int]; L.orc_set_custom_pair_mode.restype = None
+        L.orc_add_centroid_bond.argtypes = [H, C.c_int, C.POINTER(C.c_int), _dp, C.c_int, C.POINTER(C.c_int), _dp, C.c_double]; L.orc_add_centroid_bond.restype = C.c_int
         L.orc_minimize.argtypes = [H, C.c_int, C.c_double]; L.orc_minimize.restype = C.c_double
         L.orc_default_lambda_sterics.argtypes = [C.c_double]; L.orc_default_lambda_sterics.restype = C.c_double
         L.orc_default_lambda_electrostatics.argtypes = [C.c_double]; L.orc_default_lambda_electrostatics.restype = C.c_double
@@ -134,6 +136,15 @@ class Oracle:
 
     def num_evaluations(self):
         return self._L.orc_num_evaluations(self._h)
+
+    def set_custom_pair_mode(self, mode):
+        self._L.orc_set_custom_pair_mode(self._h, int(mode))
+
+    def add_centroid_bond(self, idx1, w1, idx2, w2, k):
+        i1 = (C.c_int * len(idx1))(*idx1); i2 = (C.c_int * len(idx2))(*idx2)
+        a1 = np.ascontiguousarray(w1, dtype=np.float64); a2 = np.ascontiguousarray(w2, dtype=np.float64)
+        if self._L.orc_add_centroid_bond(self._h, len(idx1), i1, _ptr(a1), len(idx2), i2, _ptr(a2), float(k)):
+            raise RuntimeError("too many centroid bonds")
 
     def minimize(self, max_iter=200, step0=0.01):
         return self._L.orc_minimize(self._h, int(max_iter), float(step0))

@@ -40,6 +40,11 @@ class OracleBackedEngine:
     def __init__(self, system, integrator_data, device=0):
         from oracle import oracle
         self._o = oracle.Oracle(system, integrator_data)
+        ex = getattr(system, "extras", None) or {}
+        if ex.get("custom_pair_mode"):
+            self._o.set_custom_pair_mode(ex["custom_pair_mode"])
+        for cb in ex.get("centroid_bonds", []):
+            self._o.add_centroid_bond(*cb)
         self.n = system.n_atoms
         self.system, self.integrator = system, integrator_data
         self._box = np.diag(np.asarray(system.box, dtype=float).reshape(-1)[:3]) if np.size(system.box) == 3 else np.asarray(system.box).reshape(3, 3)

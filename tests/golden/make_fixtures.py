@@ -126,6 +126,47 @@ def make_known_answers():
     print("wrote", out)
 
 
+def make_ethylene_fixture():
+    """Flat JSON form of the data files behind the reference's only result-pinning test of this path
+    (blues/tests/data/ethylene_system.xml, ethylene_structure.pdb; blues/tests/test_ethylene.py)."""
+    import xml.etree.ElementTree as ET
+    root = ET.parse(os.path.join(REF, "ethylene_system.xml")).getroot()
+    box = [float(root.find("PeriodicBoxVectors").find(t).get(a)) for t, a in (("A", "x"), ("B", "y"), ("C", "z"))]
+    masses = [float(p.get("mass")) for p in root.find("Particles")]
+    cons = [[int(c.get("p1")), int(c.get("p2")), float(c.get("d"))] for c in root.find("Constraints")]
+    out = {"_source": "blues/tests/data/ethylene_system.xml + ethylene_structure.pdb (reference test fixtures)",
+           "box": box, "masses": masses, "constraints": cons}
+    for f in root.find("Forces"):
+        t = f.get("type")
+        if t == "HarmonicBondForce":
+            out["bonds"] = [[int(b.get("p1")), int(b.get("p2")), float(b.get("d")), float(b.get("k"))] for b in f.find("Bonds")]
+        elif t == "HarmonicAngleForce":
+            out["angles"] = [[int(b.get("p1")), int(b.get("p2")), int(b.get("p3")), float(b.get("a")), float(b.get("k"))] for b in f.find("Angles")]
+        elif t == "PeriodicTorsionForce":
+            out["torsions"] = [[int(b.get("p1")), int(b.get("p2")), int(b.get("p3")), int(b.get("p4")), int(b.get("periodicity")), float(b.get("phase")), float(b.get("k"))] for b in f.find("Torsions")]
+        elif t == "CustomNonbondedForce":
+            out["custom_nonbonded"] = {"energy": f.get("energy"), "method": int(f.get("method")),
+                                       "particles": [[float(p.get("param1")), float(p.get("param2")), float(p.get("param3")), float(p.get("param4"))] for p in f.find("Particles")],
+                                       "set1": [int(p.get("index")) for p in f.find("InteractionGroups")[0].find("Set1")],
+                                       "set2": [int(p.get("index")) for p in f.find("InteractionGroups")[0].find("Set2")]}
+        elif t == "CustomCentroidBondForce":
+            groups = [[[int(p.get("p")), p.get("weight")] for p in g] for g in f.find("Groups")]
+            out["centroid_bond"] = {"energy": f.get("energy"), "groups": groups, "k": float(f.find("Bonds")[0].get("param1"))}
+    pos = []
+    for line in open(os.path.join(REF, "ethylene_structure.pdb")):
+        if line.startswith(("ATOM", "HETATM")):
+            pos.append([float(line[30:38]) * 0.1, float(line[38:46]) * 0.1, float(line[46:54]) * 0.1])
+    out["positions_nm"] = pos
+    # parameters of the test itself, blues/tests/test_ethylene.py:31-43, 79, 107-115, 152
+    out["test"] = {"temperature": 200.0, "dt": 0.001, "friction": 1.0, "nIter": 100, "nstepsMD": 20, "nstepsNC": 20, "moveStep": 10,
+                   "repeats": 5, "reportInterval": 5, "alchemical_atoms": [2, 3, 4, 5, 6, 7], "splitting": "H V R O R V H",
+                   "distance_atoms": [0, 2], "distance_cut_nm": 0.49, "populations": [0.25, 0.75], "md_reset_temperature": 300.0}
+    path = os.path.join(ROOT, "tests", "golden", "ethylene_system.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("wrote", path)
+
+
 def make_oracle_vectors():
     """Regression vectors: oracle outputs on the committed toluene box (inputs = blues_amd/data/tol_box.npz).
     They are NOT reference values (the reference has none); they freeze the oracle so that
@@ -153,6 +194,7 @@ def make_oracle_vectors():
 
 if __name__ == "__main__":
     make_known_answers()
+    make_ethylene_fixture()
     if "--vectors-only" not in sys.argv:
         make_tol_box()
     make_oracle_vectors()
