@@ -94,7 +94,7 @@ struct BluesEngine {
     double dt = 0, temperature = 0, gamma = 1, kT = 0, tol = 1e-8;
     int nsteps = 0, nprop = 1, n_lambda = 0, precision = 0;
     double prop_min = 0, prop_max = 0;
-    std::string split; int n_R = 0, n_V = 0, n_O = 0, n_H = 0;
+    std::string split; int n_R = 0, n_V = 0, n_O = 0, n_H = 0, n_L = 0;
     std::vector<double> tab_ls, tab_le;
     uint64_t seed = 0; int replica = 0;
     // ---- mirrored control state
@@ -431,6 +431,7 @@ static IntArgs make_int_args(BluesEngine* h) {
     A.hV = h->dt / std::max(1, h->n_V); A.hR = h->dt / std::max(1, h->n_R); A.inv_hR = 1.0 / A.hR;
     const double hO = h->dt / std::max(1, h->n_O);
     A.aO = std::exp(-h->gamma * hO); A.bO = std::sqrt(1.0 - std::exp(-2.0 * h->gamma * hO));
+    A.dtL = h->dt; A.aL = std::exp(-h->gamma * h->dt); A.fsL = h->gamma == 0.0 ? h->dt : (1.0 - A.aL) / h->gamma; A.nsL = std::sqrt(1.0 - A.aL * A.aL);
     A.kT = h->kT; A.tol = h->tol; A.seed = h->seed; A.stream = (unsigned)h->replica * 4u; A.draw_base = h->prog_draw_base;
     A.noise = h->d_noise.p; A.mobile_index = h->d_mobile_index.p; A.n_mobile = (int)h->mobile.size(); A.n_noise = h->noise_valid ? h->n_noise : 0; A.noise_draw_base = h->noise_draw_base;
     A.box = make_box(h); A.periodic = h->nb_method == BLUES_NB_PME_DIRECT; A.cl_periodic = 0;
@@ -457,7 +458,7 @@ static int emit(BluesEngine* h, int op) {
     if (h->prog.n == 0) h->prog_draw_base = h->h_draw;
     if (h->prog.n >= MAX_OPS) { if (flush_program(h)) return 1; h->prog_draw_base = h->h_draw; }
     h->prog.ops[h->prog.n++] = (unsigned char)op;
-    if (op == OP_O) h->h_draw++;
+    if (op == OP_O || op == OP_L) h->h_draw++;
     return 0;
 }
 
@@ -630,9 +631,16 @@ static int check_flags(BluesEngine* h) {
     HIP_OK(h, hipStreamSynchronize(h->stream));
     DevFlags f;
     HIP_OK(h, hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost));
+    if (f.nan_flag || f.list_overflow || f.constraint_fail) {
+        // report once and stay usable: BLUES catches the exception, lets the move clean up and carries on with
+        // the next iteration (reference blues/simulation.py:1088-1094), exactly as after an OpenMMException
+        DevFlags z = f; z.nan_flag = 0; z.list_overflow = 0; z.constraint_fail = 0;
+        hipMemcpy(h->d_flags.p, &z, sizeof z, hipMemcpyHostToDevice);
+        h->pass_valid = false; h->lists_forced = true;
+    }
     if (f.nan_flag) E_FAIL(h, "Particle coordinate is nan");
     if (f.list_overflow) E_FAIL(h, "neighbour list capacity exceeded (jcap=%d)", h->jcap);
-    if (f.constraint_fail) E_FAIL(h, "constraint solver did not converge");
+    if (f.constraint_fail) E_FAIL(h, "constraint solver did not converge (the step is unstable)");
     return 0;
 }
 
@@ -729,6 +737,12 @@ static int splitting_pass(BluesEngine* h) {
         } break;
         case 'R': if (emit(h, OP_R)) return 1; h->pass_valid = false; break;
         case 'O': if (emit(h, OP_O)) return 1; break;
+        case 'L': {
+            if (need_pass(h, h->h_lambda_step, h->h_lambda_step)) return 1;
+            if (h->h_lambda_step != h->pass_L) { if (flush_program(h)) return 1; if (force_pass(h, h->h_lambda_step)) return 1; }
+            if (emit(h, OP_L)) return 1;
+            h->pass_valid = false;
+        } break;
         case 'H': {
             if (h->h_prop != 1) break;  // reference blues/integrators.py:217
             const int L = h->h_lambda_step;
@@ -913,9 +927,9 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     h->prop_min = it->prop_lambda_min; h->prop_max = it->prop_lambda_max; h->seed = it->seed; h->replica = it->replica; h->precision = it->precision;
     for (const char* p = it->splitting; *p; p++) {
         if (*p == ' ') continue;
-        if (*p != 'R' && *p != 'V' && *p != 'O' && *p != 'H') E_FAIL(h, "unsupported splitting token '%c'", *p);
+        if (*p != 'R' && *p != 'V' && *p != 'O' && *p != 'H' && *p != 'L') E_FAIL(h, "unsupported splitting token '%c'", *p);
         h->split.push_back(*p);
-        if (*p == 'R') h->n_R++; else if (*p == 'V') h->n_V++; else if (*p == 'O') h->n_O++; else h->n_H++;
+        if (*p == 'R') h->n_R++; else if (*p == 'V') h->n_V++; else if (*p == 'O') h->n_O++; else if (*p == 'H') h->n_H++; else h->n_L++;
     }
     if (h->n_lambda != h->nsteps * h->n_H) E_FAIL(h, "n_lambda_steps must equal nsteps_neq * (number of H in splitting)");
     h->tab_ls.assign(it->lambda_sterics, it->lambda_sterics + h->n_lambda + 1);
@@ -939,7 +953,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     {
         std::vector<int> mi(n, -1);
         for (size_t m = 0; m < h->mobile.size(); m++) mi[h->mobile[m]] = (int)m;
-        try { h->d_mobile_atoms.upload(h->mobile); h->d_mobile_index.upload(mi); h->n_noise = std::max(1, h->n_O);
+        try { h->d_mobile_atoms.upload(h->mobile); h->d_mobile_index.upload(mi); h->n_noise = std::max(1, h->n_O + h->n_L);
               h->d_noise.alloc((size_t)h->n_noise * 3 * std::max<size_t>(1, h->mobile.size())); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     }
     if (build_clusters(h, s)) return 1;

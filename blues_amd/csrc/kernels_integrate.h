@@ -28,6 +28,7 @@ enum {
     OP_CM_REDUCE,              // write this block's momentum partial (last op of a launch)
     OP_CM_APPLY,               // subtract total momentum / total mass (first op of the next launch)
     OP_RATTLE,                 // velocity constraints only (setVelocitiesToTemperature)
+    OP_L,                      // OpenMM LangevinIntegrator step (MD leg): v' = a v + (1-a)/g f/m + sqrt(kT(1-a^2)/m) xi; x' = x + dt v'; SHAKE; v = (x'-x)/dt
 };
 
 #define MAX_OPS 24
@@ -56,6 +57,7 @@ struct IntArgs {
     const int* alch_local_of_orig;
     // constants
     double hV, hR, inv_hR, aO, bO, kT, tol;
+    double dtL, aL, fsL, nsL;  // OP_L coefficients
     unsigned long long seed; unsigned stream, draw_base;
     const double* noise; const int* mobile_index; int n_mobile, n_noise; unsigned noise_draw_base;  // precomputed N(0,1), see k_bonded_entries
     Box3 box; int periodic; int cl_periodic;  // cl_periodic = 0: every cluster is stored as one whole image
@@ -392,6 +394,37 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
                     for (int k = 0; k < 3; k++) C.v[a][k] = A.aO * C.v[a][k] + A.bO * s * g[k];
                 }
                 rattle(C, A.tol, A);
+            }
+            draw++;
+        } break;
+        case OP_L: {
+            if (active) {
+                double F[4][3], x0[4][3];
+                load_force(A, C, 0, F);
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) x0[a][k] = C.x[a][k];
+                    if (a < C.na) {
+                        double g[3];
+                        const unsigned nd = draw - A.noise_draw_base;
+                        if (nd < (unsigned)A.n_noise) {
+                            const int m = A.cl_mobile[cl * 4 + a];
+                            for (int k = 0; k < 3; k++) g[k] = A.noise[(size_t)(nd * 3 + k) * A.n_mobile + m];
+                        } else gaussians3(A.seed, A.stream, draw, (unsigned)C.id[a], g);
+                        const double sd = sqrt(A.kT * C.w[a]);
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            C.v[a][k] = A.aL * C.v[a][k] + A.fsL * C.w[a] * F[a][k] + A.nsL * sd * g[k];
+                            C.x[a][k] += A.dtL * C.v[a][k];
+                        }
+                    }
+                }
+                ok &= shake(C, x0, A.tol, A);
+                const double inv_dt = 1.0 / A.dtL;
+#pragma unroll
+                for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] = (C.x[a][k] - x0[a][k]) * inv_dt;
+                moved = true;
             }
             draw++;
         } break;

@@ -319,3 +319,50 @@ def test_committed_golden_vectors(Engine, tol_box, precision, tol):
     wref = np.array(vec["work_trace"])
     assert np.abs(w - wref).max() <= tol * np.abs(wref).max()
     g.close()
+
+
+def test_md_leg_openmm_langevin(Engine, oracle_mod, tol_box):
+    """The MD leg: OpenMM's LangevinIntegrator step on the non-alchemical system, all atoms mobile."""
+    s, v = tol_box
+    md = copy.copy(s); md.alchemical_atoms = np.zeros(0, np.int32)
+    integ = integrators.LangevinIntegrator(300.0, 1.0, 0.004, seed=17)
+    integ.setConstraintTolerance(1e-8)
+    data = integ.to_data(precision=1)
+    g, o = Engine(md, data), oracle_mod.Oracle(md, data)
+    g.set_velocities(v); o.set_velocities(v)
+    assert g.potential_energy() == pytest.approx(o.energy_forces(1.0, 1.0)[0], rel=1e-12)
+    g.step(25); o.step(25)
+    assert np.abs(g.get_positions() - o.get_positions()).max() < 1e-9
+    assert np.abs(g.get_velocities() - o.get_velocities()).max() < 1e-7
+    x, c = g.get_positions(), md.constraint_atoms
+    assert np.abs(np.linalg.norm(x[c[:, 0]] - x[c[:, 1]], axis=1) / md.constraint_dist - 1).max() < 1e-8
+    ndof = 3 * md.n_atoms - len(md.constraint_dist)
+    T = 2 * g.kinetic_energy() / (ndof * 0.0083144626)
+    assert 250 < T < 350
+    g.close()
+
+
+def test_full_blues_iteration_on_gpu(tol_box):
+    """NCMC leg + Metropolis + MD leg, all on the engine, through the driver mirror (reference BLUESSimulation.run)."""
+    from blues_amd import moves, simulation, unit
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    md_sys = copy.copy(s); md_sys.alchemical_atoms = np.zeros(0, np.int32)
+    ncmc = Simulation(None, s, _integ(10, seed=4))
+    md = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.004, seed=5))
+    alch = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.004, seed=6))
+    for sim in (ncmc, md, alch):
+        sim.context.setVelocities(unit.Quantity(v, "nanometer/picosecond"))
+    lig = np.arange(15)
+    b = simulation.BLUESSimulation(simulation.SimulationSet(ncmc, md=md, alch=alch), {"nstepsNC": 10, "moveStep": 5, "nIter": 2, "nstepsMD": 10},
+                                   moves.MoveEngine(moves.RandomLigandRotationMove(lig, s.mass[lig], random_state=2)))
+    np.random.seed(3)
+    x0 = md.context.getState(getPositions=True).getPositions(asNumpy=True)._value.copy()
+    # a 10-step protocol is far too fast for a 15-atom ligand: the random rotation lands on waters, the work explodes
+    # and the switch may even become unstable -- the engine then raises like OpenMM would, the driver logs it, calls
+    # move._error and carries on (reference blues/simulation.py:1088-1094); either way the move must end up rejected
+    b.run()
+    assert b.accept + b.reject == 2 and md.currentStep == 20 and b.accept == 0
+    assert abs(b.last["correction"]) < 1e-5   # U_md == U_alch(lambda=1) in the direct-space-only model
+    x1 = md.context.getState(getPositions=True).getPositions(asNumpy=True)._value
+    assert np.not_equal(x0, x1).all()          # reference blues/tests/test_simulation.py: positions change after _stepMD
