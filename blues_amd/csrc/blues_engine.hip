@@ -123,7 +123,7 @@ struct BluesEngine {
     DBuf<unsigned long long> d_mask_pool;
     DBuf<DevFlags> d_flags; DBuf<DevAccum> d_acc; DBuf<DevCtrl> d_ctrl; DBuf<double> d_tab_ls, d_tab_le; DBuf<long long> d_stamps;
     DBuf<double> d_fpart, d_epart_nb, d_fJ, d_self_part, d_e_part, d_fent, d_ftot, d_alch_self, d_epart_b, d_cm_part, d_trace, d_scratch;
-    DBuf<int> d_orig_of_islot, d_row_of_orig, d_mobile_atoms, d_mobile_index, d_exc_owner;
+    DBuf<int> d_orig_of_islot, d_row_of_orig, d_mobile_atoms, d_mobile_index, d_exc_owner, d_exc_is_env;
     DBuf<double> d_noise; unsigned noise_draw_base = 0; int n_noise = 0; bool noise_valid = false;
     DBuf<int> d_alch_orig, d_alch_local, d_exc_start, d_exc_partner; DBuf<double> d_exc_params;
     DBuf<int> d_cl_atoms, d_cl_type, d_cl_nc, d_cl_alch, d_cl_mobile, d_cl_sorted; DBuf<double> d_cl_dist;
@@ -272,8 +272,10 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
         else if (is_alch(i) && is_alch(j)) {
             arow_partner[h->alch_local[i]].push_back(j); for (int q = 0; q < 3; q++) arow_par[h->alch_local[i]].push_back(p[q]);
             arow_partner[h->alch_local[j]].push_back(i); for (int q = 0; q < 3; q++) arow_par[h->alch_local[j]].push_back(p[q]);
-        } else if (p[0] != 0.0 || p[2] != 0.0)
-            E_FAIL(h, "1-4 exception between an alchemical and a non-alchemical atom (%d-%d) is not supported yet", i, j);
+        } else if (p[0] != 0.0 || p[2] != 0.0) {  // alchemical x environment: one row entry on the alchemical side
+            const int a = is_alch(i) ? i : j, e2 = is_alch(i) ? j : i;
+            arow_partner[h->alch_local[a]].push_back(e2); for (int q = 0; q < 3; q++) arow_par[h->alch_local[a]].push_back(p[q]);
+        }
     }
     for (int r = 0; r < s->n_restraints; r++) { ta[T_RESTR].push_back(s->restraint_atoms[r]); for (int q = 0; q < 3; q++) tp[T_RESTR].push_back(s->restraint_x0[3 * r + q]); }
     h->restr_k = s->restraint_k;
@@ -303,6 +305,7 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
     // alchemical exception rows
     std::vector<int> es(1, 0), ep, eo; std::vector<double> epar;
     for (size_t a = 0; a < h->alch.size(); a++) { eo.insert(eo.end(), arow_partner[a].size(), h->alch[a]); ep.insert(ep.end(), arow_partner[a].begin(), arow_partner[a].end()); epar.insert(epar.end(), arow_par[a].begin(), arow_par[a].end()); es.push_back((int)ep.size()); }
+    { std::vector<int> ie(ep.size()); for (size_t q = 0; q < ep.size(); q++) ie[q] = h->alch_local[ep[q]] < 0; h->d_exc_is_env.upload(ie); }
     h->d_exc_start.upload(es); h->d_exc_partner.upload(ep); h->d_exc_owner.upload(eo); h->d_exc_params.upload(epar);
     return 0;
 }
@@ -528,7 +531,7 @@ static AlchArgs make_alch_args(BluesEngine* h, const double ls[3], const double 
     A.orig_of_sorted = h->d_orig_of_sorted.p; A.sorted_of_orig = h->d_sorted_of_orig.p;
     for (int k = 0; k < 3; k++) A.x[k] = h->d_x[k].p;
     A.charge = h->d_charge.p; A.sigma = h->d_sigma.p; A.eps = h->d_eps.p; A.ex_start = h->d_ex_start.p; A.ex_idx = h->d_ex_idx.p;
-    A.exc_start = h->d_exc_start.p; A.exc_partner = h->d_exc_partner.p; A.exc_owner = h->d_exc_owner.p; A.exc_params = h->d_exc_params.p;
+    A.exc_start = h->d_exc_start.p; A.exc_partner = h->d_exc_partner.p; A.exc_owner = h->d_exc_owner.p; A.exc_is_env = h->d_exc_is_env.p; A.exc_params = h->d_exc_params.p;
     A.box = make_box(h); A.rc2 = h->cutoff * h->cutoff; A.alpha = h->alpha; A.sc_alpha = h->sc_alpha;
     A.pme = h->nb_method == BLUES_NB_PME_DIRECT; A.annih_elec = h->annih_elec; A.annih_ster = h->annih_ster; A.slot_mask = slot_mask; A.check_env_excl = h->check_env_excl;
     for (int s = 0; s < 3; s++) { A.ls[s] = ls[s]; A.le[s] = le[s]; }

@@ -34,6 +34,7 @@ struct AlchArgs {
     const int* exc_start;       // [n_alch+1]
     const int* exc_partner;
     const int* exc_owner;       // caller index of the alchemical atom owning the entry
+    const int* exc_is_env;      // 1: the partner is a non-alchemical atom (handled by the env thread of that pair)
     const double* exc_params;   // [3*] chargeProd, sigma, epsilon
     Box3 box;
     double rc2, alpha, sc_alpha;
@@ -83,7 +84,8 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
             double d[3];
             for (int k = 0; k < 3; k++) d[k] = min_image_d(A.x[k][ao] - A.x[k][jo], A.box.L[k], A.box.invL[k]);
             const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-            if (r2 < A.rc2 && !(A.check_env_excl && excluded_sorted(A.ex_start, A.ex_idx, A.sorted_of_orig[ao], jsrt))) {
+            const bool excl = A.check_env_excl && excluded_sorted(A.ex_start, A.ex_idx, A.sorted_of_orig[ao], jsrt);
+            if (!excl && r2 < A.rc2) {
                 const double sig = 0.5 * (A.sigma[ao] + A.sigma[jo]), eps = sqrt(A.eps[ao] * A.eps[jo]);
                 const double qq = A.charge[ao] * A.charge[jo];
                 double fc;
@@ -95,6 +97,24 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
                     e[1 + s] = softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
                     const double ft = fs + A.le[s] * fc;
                     f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                }
+            } else if (excl) {
+                // excluded pair: if it is a 1-4 exception between this alchemical atom and an environment atom it is
+                // evaluated here with its own parameters (softcore LJ scaled by lambda_sterics, bare Coulomb scaled by
+                // lambda_electrostatics, no cutoff -- SURVEY.md Appendix B), so both atoms get their force through the
+                // same reductions as a regular pair
+                for (int q = A.exc_start[a]; q < A.exc_start[a + 1]; q++) {
+                    if (A.exc_partner[q] != jo) continue;
+                    const double qq = A.exc_params[3 * q], sig = A.exc_params[3 * q + 1], eps = A.exc_params[3 * q + 2];
+                    double fc;
+                    e[0] = coulomb_d(r2, qq, 0.0, false, &fc);
+#pragma unroll
+                    for (int s = 0; s < 3; s++) {
+                        double fs;
+                        e[1 + s] = softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
+                        const double ft = fs + A.le[s] * fc;
+                        f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                    }
                 }
             }
         }
@@ -156,7 +176,7 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
             double h[3][3];
 #pragma unroll
             for (int s = 0; s < 3; s++) { h[s][0] = h[s][1] = h[s][2] = 0.0; }
-            if (q < n_exc_ent) {
+            if (q < n_exc_ent && !A.exc_is_env[q]) {
                 const int ao = A.exc_owner[q], po = A.exc_partner[q];
                 const double qq = A.exc_params[3 * q], sig = A.exc_params[3 * q + 1], eps = A.exc_params[3 * q + 2];
                 double d[3];

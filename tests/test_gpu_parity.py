@@ -366,3 +366,27 @@ def test_full_blues_iteration_on_gpu(tol_box):
     assert abs(b.last["correction"]) < 1e-5   # U_md == U_alch(lambda=1) in the direct-space-only model
     x1 = md.context.getState(getPositions=True).getPositions(asNumpy=True)._value
     assert np.not_equal(x0, x1).all()          # reference blues/tests/test_simulation.py: positions change after _stepMD
+
+
+@pytest.mark.parametrize("precision,tol", [(1, 1e-9), (0, 1e-5)])
+def test_alchemical_subset_of_a_molecule(Engine, oracle_mod, tol_box, precision, tol):
+    """configs[4]-style region: only PART of the solute is alchemical (here the methyl group of toluene), so there are
+    exclusions and 1-4 exceptions between alchemical and environment atoms (openmmtools moves those to scaled
+    CustomBondForces -- SURVEY.md Appendix B); annihilate_sterics on/off both covered."""
+    s, v = tol_box
+    for annih in (False, True):
+        sub = copy.copy(s); sub.alchemical_atoms = np.array([0, 7, 8, 9], np.int32); sub.annihilate_sterics = annih
+        data = _integ(12, seed=31).to_data(precision=precision)
+        g, o = Engine(sub, data), oracle_mod.Oracle(sub, data)
+        for (ls, le) in ((1.0, 1.0), (0.4, 0.25), (0.0, 0.0)):
+            eo, fo, to = o.energy_forces(ls, le)
+            g.set_global("lambda_sterics", ls); g.set_global("lambda_electrostatics", le)
+            tg = g.energy_terms()
+            for k in range(8):
+                assert abs(tg[k] - to[k]) <= tol * max(abs(to[k]), 1.0), (annih, ls, le, k, tg[k], to[k])
+            assert _rel(g.get_forces(), fo) <= tol
+        g.set_global("lambda_sterics", 1.0); g.set_global("lambda_electrostatics", 1.0)
+        g.set_velocities(v); o.set_velocities(v)
+        wg = g.run_switch(12, trace=True); wo = _trace(o, 12)
+        assert np.abs(wg - wo).max() <= tol * max(1.0, np.abs(wo).max())
+        g.close()
