@@ -28,11 +28,22 @@ def build_engine(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> libblues_hip.so; returns the library path."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB_PATH, os.path.join(CSRC, "blues_engine.hip")]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # one builder at a time: with one process per GPU every rank may get here together
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():
+                return LIB_PATH
+            tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+            cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                   "-o", tmp, os.path.join(CSRC, "blues_engine.hip")]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

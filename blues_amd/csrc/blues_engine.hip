@@ -112,7 +112,7 @@ struct BluesEngine {
     std::vector<HostCluster> clusters;
     int n_itiles = 0, n_tiles = 0, jcap = 0, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0;
     int seg_len = 64, waves_tile = 4, wpb = 4, npart = 1;  // K1 decomposition
-    bool fuse_forces = false;
+    bool fuse_forces = false, fast_step = true;
     int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
     double total_mass = 0;
@@ -127,6 +127,7 @@ struct BluesEngine {
     DBuf<double> d_noise; unsigned noise_draw_base = 0; int n_noise = 0; bool noise_valid = false;
     DBuf<int> d_alch_orig, d_alch_local, d_exc_start, d_exc_partner; DBuf<double> d_exc_params;
     DBuf<int> d_cl_atoms, d_cl_type, d_cl_nc, d_cl_alch, d_cl_mobile, d_cl_sorted; DBuf<double> d_cl_dist;
+    DBuf<ClusterRec> d_recs; std::vector<ClusterRec> h_recs;
     // bonded
     DBuf<int> d_row_atom, d_row_start, d_ent_type, d_ent_term, d_ent_role;
     DBuf<int> d_term_atoms[T_NTYPES]; DBuf<double> d_term_params[T_NTYPES];
@@ -249,6 +250,17 @@ static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
         for (size_t m = 0; m < h->mobile.size(); m++) mi[h->mobile[m]] = (int)m;
         for (int c = 0; c < ncl * 4; c++) if (ca[c] >= 0) { cal[c] = h->alch_local[ca[c]]; cmo[c] = mi[ca[c]]; }
         h->d_cl_alch.upload(cal); h->d_cl_mobile.upload(cmo); h->d_cl_sorted.alloc((size_t)ncl * 4);
+        h->h_recs.assign(ncl, ClusterRec());
+        for (int c = 0; c < ncl; c++) {
+            ClusterRec& r = h->h_recs[c]; memset(&r, 0, sizeof r);
+            r.type = ct[c]; r.nc = cn[c]; r.na = 0;
+            for (int a = 0; a < 4; a++) {
+                r.atoms[a] = ca[c * 4 + a]; r.alch[a] = cal[c * 4 + a]; r.mobile[a] = cmo[c * 4 + a]; r.sorted[a] = 0;
+                if (r.atoms[a] >= 0) { r.na = a + 1; r.w[a] = 1.0 / h->mass[r.atoms[a]]; }
+            }
+            for (int q = 0; q < 3; q++) r.dist[q] = cd[c * 3 + q];
+        }
+        h->d_recs.upload(h->h_recs);
     }
     h->int_threads = ncl <= 256 ? std::max(128, ((ncl + 63) / 64) * 64) : 256;
     h->int_blocks = std::max(1, (ncl + h->int_threads - 1) / h->int_threads);
@@ -405,7 +417,9 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_sorted_of_orig.upload(h->h_sorted_of_orig); h->d_orig_of_sorted.upload(h->h_orig_of_sorted);
         { std::vector<int> cs(h->clusters.size() * 4, 0);
           for (size_t c = 0; c < h->clusters.size(); c++) for (int a = 0; a < 4; a++) if (h->clusters[c].atoms[a] >= 0) cs[c * 4 + a] = h->h_sorted_of_orig[h->clusters[c].atoms[a]];
-          h->d_cl_sorted.upload(cs); }
+          h->d_cl_sorted.upload(cs);
+          for (size_t c = 0; c < h->clusters.size(); c++) for (int a = 0; a < 4; a++) h->h_recs[c].sorted[a] = cs[c * 4 + a];
+          h->d_recs.upload(h->h_recs); }
         h->d_tile_atoms.upload(tile_atoms); h->d_islot.upload(islot);
         h->d_ex_start.upload(ex_start); h->d_ex_idx.upload(ex_idx);
         h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * 4 * jcap); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
@@ -425,7 +439,7 @@ static int sort_and_tile(BluesEngine* h) {
 static IntArgs make_int_args(BluesEngine* h) {
     IntArgs A; memset(&A, 0, sizeof A);
     A.n = h->n; A.n_clusters = (int)h->clusters.size();
-    A.cl_atoms = h->d_cl_atoms.p; A.cl_alch = h->d_cl_alch.p; A.cl_mobile = h->d_cl_mobile.p; A.cl_sorted = h->d_cl_sorted.p; A.cl_type = h->d_cl_type.p; A.cl_nc = h->d_cl_nc.p; A.cl_dist = h->d_cl_dist.p;
+    A.recs = h->d_recs.p;
     for (int k = 0; k < 3; k++) { A.x[k] = h->d_x[k].p; A.v[k] = h->d_v[k].p; A.xbuild[k] = h->d_xbuild[k].p; }
     A.mass = h->d_mass.p;
     A.ftot = h->d_ftot.p; A.alch_self = h->d_alch_self.p;
@@ -450,7 +464,15 @@ static IntArgs make_int_args(BluesEngine* h) {
 static int flush_program(BluesEngine* h) {
     if (h->prog.n == 0) return 0;
     IntArgs A = make_int_args(h);
-    hipLaunchKernelGGL(k_integrate, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
+    // the steady-state program of "H V R O R V H" has a straight-line specialisation (same arithmetic)
+    static const unsigned char P_CM[9] = {OP_V0, OP_H01, OP_END, OP_CM_BLOCK, OP_H12, OP_V2, OP_R, OP_O, OP_R};
+    static const unsigned char P_NC[8] = {OP_V0, OP_H01, OP_END, OP_H12, OP_V2, OP_R, OP_O, OP_R};
+    if (h->fast_step && h->prog.n == 9 && !memcmp(h->prog.ops, P_CM, 9))
+        hipLaunchKernelGGL(k_step_default<true>, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
+    else if (h->fast_step && h->prog.n == 8 && !memcmp(h->prog.ops, P_NC, 8))
+        hipLaunchKernelGGL(k_step_default<false>, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
+    else
+        hipLaunchKernelGGL(k_integrate, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
     h->st_launches++;
     h->prog.n = 0; h->prog_trace = -1; h->prog_draw_base = h->h_draw;
     HIP_OK(h, hipGetLastError());
@@ -944,6 +966,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     HIP_OK(h, hipEventCreate(&h->ev0)); HIP_OK(h, hipEventCreate(&h->ev1));
     HIP_OK(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ1, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ2, hipEventDisableTiming));
     if (const char* g = getenv("BLUES_GRAPH")) h->use_graph = atoi(g) != 0;
+    if (const char* g = getenv("BLUES_FAST_STEP")) h->fast_step = atoi(g) != 0;
     if (const char* g = getenv("BLUES_GRAPH_UNITS")) h->graph_units = std::max(1, atoi(g));
     if (const char* g = getenv("BLUES_GRAPH_FORK")) h->graph_fork = atoi(g) != 0;
     try {

@@ -38,15 +38,21 @@ struct DevAccum {
     double protocol_work, dE_last, e_slot[3], heat;
 };
 
+// one packed record per cluster slot: everything the thread needs to know about its cluster arrives with a few
+// wide contiguous loads instead of a dozen dependent gathers
+struct ClusterRec {
+    int atoms[4];    // caller index or -1
+    int alch[4];     // local alchemical index or -1
+    int mobile[4];   // index into the mobile list (noise buffer)
+    int sorted[4];   // index into the tile image
+    int type, nc, na, pad;
+    double dist[3];
+    double w[4];     // 1/mass (0 for empty slots)
+};
+
 struct IntArgs {
     int n, n_clusters;
-    const int* cl_atoms;    // [ncl*4] caller index or -1
-    const int* cl_alch;     // [ncl*4] local alchemical index or -1
-    const int* cl_mobile;   // [ncl*4] index into the mobile list (noise buffer)
-    const int* cl_sorted;   // [ncl*4] index into the tile image
-    const int* cl_type;     // 0 single, 1 star (atom 0 = centre), 2 triangle
-    const int* cl_nc;       // constraints in the cluster
-    const double* cl_dist;  // [ncl*3]
+    const ClusterRec* recs;
     double* x[3]; double* v[3];
     const double* mass;
     // force sources
@@ -90,7 +96,7 @@ template <int TYPE> struct ClTab {
     static __device__ constexpr int s(int c2, int a) { return (a == ci(c2)) - (a == cj(c2)); }
 };
 
-__device__ inline void solve_small(int n, const double M[3][3], const double b[3], double x[3]) {
+__device__ __forceinline__ void solve_small(int n, const double M[3][3], const double b[3], double x[3]) {
     if (n == 1) { x[0] = b[0] / M[0][0]; x[1] = x[2] = 0.0; return; }
     if (n == 2) {
         const double inv = 1.0 / (M[0][0] * M[1][1] - M[0][1] * M[1][0]);
@@ -107,7 +113,7 @@ __device__ inline void solve_small(int n, const double M[3][3], const double b[3
 }
 
 // RATTLE: (v_i - v_j).r_ij = 0 is linear in the multipliers -> one small solve (same algebra as the oracle)
-template <int TYPE> __device__ inline void rattle_t(Cluster& C, const IntArgs& A) {
+template <int TYPE> __device__ __forceinline__ void rattle_t(Cluster& C, const IntArgs& A) {
     using T = ClTab<TYPE>;
     double r[3][3], M[3][3], b[3], mu[3];
 #pragma unroll
@@ -118,7 +124,6 @@ template <int TYPE> __device__ inline void rattle_t(Cluster& C, const IntArgs& A
             r[c][k] = 0.0;
             if (c < C.nc) {
                 r[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k];
-                if (A.cl_periodic) r[c][k] = min_image_d(r[c][k], A.box.L[k], A.box.invL[k]);
                 rv += (C.v[T::ci(c)][k] - C.v[T::cj(c)][k]) * r[c][k];
             }
         }
@@ -139,14 +144,14 @@ template <int TYPE> __device__ inline void rattle_t(Cluster& C, const IntArgs& A
     }
 }
 
-__device__ inline void rattle(Cluster& C, double tol, const IntArgs& A) {
+__device__ __forceinline__ void rattle(Cluster& C, double tol, const IntArgs& A) {
     if (C.nc == 0) return;
     if (C.type == 1) rattle_t<1>(C, A); else rattle_t<2>(C, A);
 }
 
 // SHAKE: Newton on the multipliers, directions from the reference geometry xr; converged to
 // |r^2 - d^2| <= 2 tol d^2 plus one polishing iteration (same sequence as the oracle)
-template <int TYPE> __device__ inline bool shake_t(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
+template <int TYPE> __device__ __forceinline__ bool shake_t(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
     using T = ClTab<TYPE>;
     double r[3][3];
 #pragma unroll
@@ -154,7 +159,7 @@ template <int TYPE> __device__ inline bool shake_t(Cluster& C, const double xr[4
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             r[c][k] = 0.0;
-            if (c < C.nc) { r[c][k] = xr[T::ci(c)][k] - xr[T::cj(c)][k]; if (A.cl_periodic) r[c][k] = min_image_d(r[c][k], A.box.L[k], A.box.invL[k]); }
+            if (c < C.nc) { r[c][k] = xr[T::ci(c)][k] - xr[T::cj(c)][k]; }
         }
     int it;
     for (it = 0; it < 50; it++) {
@@ -167,7 +172,7 @@ template <int TYPE> __device__ inline bool shake_t(Cluster& C, const double xr[4
             for (int k = 0; k < 3; k++) D[c][k] = 0.0;
             if (c < C.nc) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) { D[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k]; if (A.cl_periodic) D[c][k] = min_image_d(D[c][k], A.box.L[k], A.box.invL[k]); }
+                for (int k = 0; k < 3; k++) { D[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k]; }
                 g[c] = -(D[c][0] * D[c][0] + D[c][1] * D[c][1] + D[c][2] * D[c][2] - C.d2[c]);
                 if (fabs(g[c]) > 2.0 * tol * C.d2[c]) conv = false;
                 if (fabs(g[c]) > 1e-13 * C.d2[c]) tight = false;
@@ -192,12 +197,12 @@ template <int TYPE> __device__ inline bool shake_t(Cluster& C, const double xr[4
     return it < 50;
 }
 
-__device__ inline bool shake(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
+__device__ __forceinline__ bool shake(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
     if (C.nc == 0) return true;
     return C.type == 1 ? shake_t<1>(C, xr, tol, A) : shake_t<2>(C, xr, tol, A);
 }
 
-__device__ inline void load_force(const IntArgs& A, const Cluster& C, int slot, double F[4][3]) {
+__device__ __forceinline__ void load_force(const IntArgs& A, const Cluster& C, int slot, double F[4][3]) {
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         F[a][0] = F[a][1] = F[a][2] = 0.0;
@@ -325,27 +330,27 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
     __shared__ double s_cm[3];
 
     Cluster C;
-    C.na = 0; C.nc = 0; C.type = 0;
     const bool active = cl < A.n_clusters;
-    if (active) {
-        C.type = A.cl_type[cl]; C.nc = A.cl_nc[cl];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            C.id[a] = A.cl_atoms[cl * 4 + a]; C.al[a] = A.cl_alch[cl * 4 + a];
-            if (C.id[a] >= 0) {
-                C.na = a + 1;
-                for (int k = 0; k < 3; k++) { C.x[a][k] = A.x[k][C.id[a]]; C.v[a][k] = A.v[k][C.id[a]]; }
-                C.w[a] = 1.0 / A.mass[C.id[a]];
-            } else {
-                for (int k = 0; k < 3; k++) { C.x[a][k] = 0.0; C.v[a][k] = 0.0; }
-                C.w[a] = 0.0;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) { const double d = A.cl_dist[cl * 3 + c]; C.d2[c] = d * d; }
-    }
+    ClusterRec R;
+    if (active) R = A.recs[cl];
+    else { for (int a = 0; a < 4; a++) { R.atoms[a] = -1; R.alch[a] = -1; R.mobile[a] = 0; R.sorted[a] = 0; R.w[a] = 0.0; } R.type = 0; R.nc = 0; R.na = 0; R.dist[0] = R.dist[1] = R.dist[2] = 0.0; }
+    C.na = R.na; C.nc = R.nc; C.type = R.type;
     bool moved = false, ok = true;
     unsigned draw = A.draw_base;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int i = max(R.atoms[a], 0);
+        C.id[a] = R.atoms[a]; C.al[a] = R.alch[a]; C.w[a] = R.w[a];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) C.d2[c] = R.dist[c] * R.dist[c];
+#pragma unroll
+    for (int a = 0; a < 4; a++) if (a >= C.na) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { C.x[a][k] = 0.0; C.v[a][k] = 0.0; }
+    }
 #ifdef BLUES_STAMP
     if (cl == 0 && A.stamps) A.stamps[0] = clock64();
 #endif
@@ -360,7 +365,9 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
                 double F[4][3];
                 load_force(A, C, op - OP_V0, F);
 #pragma unroll
-                for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * F[a][k] * C.w[a];
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * F[a][k] * C.w[a];
                 rattle(C, A.tol, A);
             }
         } break;
@@ -387,7 +394,7 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
                     double g[3];
                     const unsigned nd = draw - A.noise_draw_base;
                     if (nd < (unsigned)A.n_noise) {
-                        const int m = A.cl_mobile[cl * 4 + a];
+                        const int m = R.mobile[a];
                         for (int k = 0; k < 3; k++) g[k] = A.noise[(size_t)(nd * 3 + k) * A.n_mobile + m];
                     } else gaussians3(A.seed, A.stream, draw, (unsigned)C.id[a], g);
                     const double s = sqrt(A.kT * C.w[a]);
@@ -409,7 +416,7 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
                         double g[3];
                         const unsigned nd = draw - A.noise_draw_base;
                         if (nd < (unsigned)A.n_noise) {
-                            const int m = A.cl_mobile[cl * 4 + a];
+                            const int m = R.mobile[a];
                             for (int k = 0; k < 3; k++) g[k] = A.noise[(size_t)(nd * 3 + k) * A.n_mobile + m];
                         } else gaussians3(A.seed, A.stream, draw, (unsigned)C.id[a], g);
                         const double sd = sqrt(A.kT * C.w[a]);
@@ -497,7 +504,7 @@ _Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 
                 double d2 = 0.0;
                 for (int k = 0; k < 3; k++) { A.x[k][i] = C.x[a][k]; const double d = C.x[a][k] - A.xbuild[k][i]; d2 += d * d; }
                 need_rebuild |= d2 > A.half_skin2;
-                const int s = A.cl_sorted[cl * 4 + a];
+                const int s = R.sorted[a];
                 if (A.img_f) { unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2]; }
                 else { unsigned long long u[3]; to_fixed(C.x[a], A.box, u); A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
             }
@@ -553,4 +560,134 @@ __global__ void __launch_bounds__(256) k_forces_fused(NbArgs<R> a, NbConst<R> c,
     if (b < nb1) { nonbonded_body<R, false, 4>(a, c, img, b); return; }
     if (b < nb1 + nb2) { alchemical_body(A, b - nb1); return; }
     bonded_entries_body(B, b - nb1 - nb2, 256);
+}
+
+// ---- straight-line specialisation of the steady-state program of "H V R O R V H":
+//        V(slot0) H(0->1) END [CM] H(1->2) V(slot2) R O R
+// Same device functions and arithmetic as the interpreter above (bitwise identical results), but with no op
+// dispatch the compiler sees one basic-block chain: every gather is issued at the top and waited for once, which is
+// what this latency-bound kernel needs (the interpreter spent >65 % of its wave cycles in s_waitcnt).
+template <bool CM>
+__global__ void __launch_bounds__(256) k_step_default(IntArgs A) {
+    const int tid = threadIdx.x;
+    const int cl = blockIdx.x * blockDim.x + tid;
+    if (A.ctrl) {
+        const int u = A.ctrl->kint;
+        A.draw_base = A.ctrl->draw0 + (unsigned)u; A.noise_draw_base = A.draw_base; A.trace_index = A.ctrl->trace0 + u;
+        if (blockIdx.x == 0 && tid == 0) A.ctrl->kpass = u + 1;
+    }
+    __shared__ double s_red[4][4];
+    __shared__ double s_cm[3];
+    const bool active = cl < A.n_clusters;
+    ClusterRec R;
+    if (active) R = A.recs[cl];
+    else { for (int a = 0; a < 4; a++) { R.atoms[a] = -1; R.alch[a] = -1; R.mobile[a] = 0; R.sorted[a] = 0; R.w[a] = 0.0; } R.type = 0; R.nc = 0; R.na = 0; R.dist[0] = R.dist[1] = R.dist[2] = 0.0; }
+    Cluster C;
+    C.na = R.na; C.nc = R.nc; C.type = R.type;
+    const unsigned nd0 = A.draw_base - A.noise_draw_base;
+    const bool pre_noise = nd0 < (unsigned)A.n_noise;
+    double FA[4][3], FB[4][3], G0[4][3], XB[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int i = max(R.atoms[a], 0), al = R.alch[a], alc = max(al, 0);
+        C.id[a] = R.atoms[a]; C.al[a] = al; C.w[a] = R.w[a];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; XB[a][k] = A.xbuild[k][i];
+            const double fa0 = A.ftot[(size_t)((al >= 0 ? 0 : 0) + k) * A.n + i];
+            const double fb0 = A.ftot[(size_t)((al >= 0 ? 0 : 6) + k) * A.n + i];
+            const double sa = A.alch_self[(0 + k) * 64 + alc], sb = A.alch_self[(6 + k) * 64 + alc];
+            FA[a][k] = fa0 + (al >= 0 ? sa : 0.0);
+            FB[a][k] = fb0 + (al >= 0 ? sb : 0.0);
+            G0[a][k] = pre_noise ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) C.d2[c] = R.dist[c] * R.dist[c];
+    bool ok = true;
+    // V(slot 0), finishing the previous step
+    if (active) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * FA[a][k] * C.w[a];
+        rattle(C, A.tol, A);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        const double dE = A.acc->e_slot[1] - A.acc->e_slot[0];
+        A.acc->protocol_work += dE; A.acc->dE_last = dE;
+        if (A.work_trace) A.work_trace[A.trace_index] = A.acc->protocol_work;
+    }
+    if (CM) {
+        double p[3] = {0.0, 0.0, 0.0};
+        if (active) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) p[k] += C.v[a][k] / C.w[a];
+        }
+        for (int k = 0; k < 3; k++) { p[k] = wave_sum(p[k]); if ((tid & 63) == 0) s_red[tid >> 6][k] = p[k]; }
+        __syncthreads();
+        if (tid < 3) { double s = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += s_red[w][tid]; s_cm[tid] = s / A.total_mass; }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] -= s_cm[k];
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        const double dE = A.acc->e_slot[2] - A.acc->e_slot[1];
+        A.acc->protocol_work += dE; A.acc->dE_last = dE;
+    }
+    bool need_rebuild = false, bad = false;
+    if (active) {
+        // V(slot 2)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * FB[a][k] * C.w[a];
+        rattle(C, A.tol, A);
+        for (int half = 0; half < 2; half++) {
+            // R
+            double xr[4][3], x1[4][3];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) { xr[a][k] = C.x[a][k]; if (a < C.na) C.x[a][k] += A.hR * C.v[a][k]; x1[a][k] = C.x[a][k]; }
+            ok &= shake(C, xr, A.tol, A);
+#pragma unroll
+            for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += (C.x[a][k] - x1[a][k]) * A.inv_hR;
+            rattle(C, A.tol, A);
+            if (half == 0) {
+                // O
+#pragma unroll
+                for (int a = 0; a < 4; a++) if (a < C.na) {
+                    double g[3];
+                    if (pre_noise) { for (int k = 0; k < 3; k++) g[k] = G0[a][k]; }
+                    else gaussians3(A.seed, A.stream, A.draw_base, (unsigned)C.id[a], g);
+                    const double s = sqrt(A.kT * C.w[a]);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) C.v[a][k] = A.aO * C.v[a][k] + A.bO * s * g[k];
+                }
+                rattle(C, A.tol, A);
+            }
+        }
+        // write back, refresh the image, list validity
+#pragma unroll
+        for (int a = 0; a < 4; a++) if (a < C.na) {
+            const int i = C.id[a];
+            double d2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                A.v[k][i] = C.v[a][k]; A.x[k][i] = C.x[a][k];
+                bad |= !(C.x[a][k] == C.x[a][k]) || !(C.v[a][k] == C.v[a][k]);
+                const double d = C.x[a][k] - XB[a][k]; d2 += d * d;
+            }
+            need_rebuild |= d2 > A.half_skin2;
+            const int s = R.sorted[a];
+            if (A.img_f) { unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2]; }
+            else { unsigned long long u[3]; to_fixed(C.x[a], A.box, u); A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
+        }
+        if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; *A.pool_count = 0; }
+        if (bad) A.flags->nan_flag = 1;
+        if (!ok) A.flags->constraint_fail = 1;
+    }
 }
