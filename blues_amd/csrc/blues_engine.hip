@@ -128,6 +128,8 @@ struct BluesEngine {
     DBuf<int> d_alch_orig, d_alch_local, d_exc_start, d_exc_partner; DBuf<double> d_exc_params;
     DBuf<int> d_cl_atoms, d_cl_type, d_cl_nc, d_cl_alch, d_cl_mobile, d_cl_sorted; DBuf<double> d_cl_dist;
     DBuf<ClusterRec> d_recs; std::vector<ClusterRec> h_recs;
+    DBuf<AlchJRec> d_jrec; DBuf<AlchARec> d_arec;
+    DBuf<FinRec> d_finrecs; std::vector<int> h_row_of_orig, h_row_start;
     // bonded
     DBuf<int> d_row_atom, d_row_start, d_ent_type, d_ent_term, d_ent_role;
     DBuf<int> d_term_atoms[T_NTYPES]; DBuf<double> d_term_params[T_NTYPES];
@@ -309,7 +311,7 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
         row_start.push_back((int)et.size());
     }
     h->n_rows = (int)row_atom.size(); h->n_entries = (int)et.size();
-    { std::vector<int> row_of(h->n, -1); for (int r = 0; r < h->n_rows; r++) row_of[row_atom[r]] = r; h->d_row_of_orig.upload(row_of); }
+    { std::vector<int> row_of(h->n, -1); for (int r = 0; r < h->n_rows; r++) row_of[row_atom[r]] = r; h->d_row_of_orig.upload(row_of); h->h_row_of_orig = row_of; h->h_row_start = row_start; }
     h->d_fent.alloc((size_t)3 * std::max(1, h->n_entries));
     h->d_row_atom.upload(row_atom); h->d_row_start.upload(row_start); h->d_ent_type.upload(et); h->d_ent_term.upload(ei); h->d_ent_role.upload(er);
     int total_terms = 0; for (int ty = 0; ty < T_NTYPES; ty++) total_terms += h->n_terms[ty];
@@ -422,11 +424,24 @@ static int sort_and_tile(BluesEngine* h) {
           h->d_recs.upload(h->h_recs); }
         h->d_tile_atoms.upload(tile_atoms); h->d_islot.upload(islot);
         h->d_ex_start.upload(ex_start); h->d_ex_idx.upload(ex_idx);
+        h->d_jrec.alloc((size_t)jcap);
+        { std::vector<AlchARec> ar(h->alch.size());
+          for (size_t a2 = 0; a2 < h->alch.size(); a2++) { AlchARec& r = ar[a2]; const int ao = h->alch[a2]; r.ao = ao; r.asrt = h->h_sorted_of_orig[ao]; r.pad = 0; r.sig = h->sigma[ao]; r.eps = h->eps[ao]; r.q = h->charge[ao];
+            r.has_env_excl = 0; for (int p2 : h->excl[ao]) if (h->alch_local[p2] < 0) r.has_env_excl = 1; }
+          h->d_arec.upload(ar); }
         h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * 4 * jcap); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
         h->d_mask_pool.alloc((size_t)h->pool_cap * 64); h->d_pool_count.alloc(1);
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
         h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 + 2 * ((n + 255) / 256));
-        { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi); }
+        { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi);
+          std::vector<FinRec> fr(h->n_islots + 64);
+          auto fill = [&](FinRec& r, int atom) {
+              r.atom = atom; r.sorted = 0; r.e0 = r.e1 = 0;
+              if (atom >= 0) { r.sorted = h->h_sorted_of_orig[atom]; const int row = h->h_row_of_orig[atom]; if (row >= 0) { r.e0 = h->h_row_start[row]; r.e1 = h->h_row_start[row + 1]; } }
+          };
+          for (int q = 0; q < h->n_islots; q++) fill(fr[q], ooi[q]);
+          for (int a = 0; a < 64; a++) fill(fr[h->n_islots + a], a < (int)h->alch.size() ? h->alch[a] : -1);
+          h->d_finrecs.upload(fr); }
         h->d_fJ.alloc((size_t)9 * n);
         h->d_self_part.alloc((size_t)(h->k2_nblocks_env + 1) * 9 * 64); h->d_e_part.alloc((size_t)(h->k2_nblocks_env + 1) * K2_NE);
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
@@ -494,6 +509,7 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
     a.mask_pool = h->d_mask_pool.p; a.pool_count = h->d_pool_count.p; a.ex_start = h->d_ex_start.p; a.ex_idx = h->d_ex_idx.p; a.flags = h->d_flags.p;
     for (int k = 0; k < 3; k++) { a.x[k] = h->d_x[k].p; a.xbuild[k] = h->d_xbuild[k].p; }
     a.fJ = h->d_fJ.p; a.n_fJ = 9 * h->n;
+    a.alch_jrec = h->alch.empty() ? nullptr : (void*)h->d_jrec.p; a.p_sigma = h->d_sigma.p; a.p_eps = h->d_eps.p; a.p_charge = h->d_charge.p;
     if (force) HIP_OK(h, hipMemsetAsync(h->d_pool_count.p, 0, sizeof(int), h->stream));
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
@@ -548,6 +564,7 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
 
 static AlchArgs make_alch_args(BluesEngine* h, const double ls[3], const double le[3], int slot_mask) {
     AlchArgs A; memset(&A, 0, sizeof A);
+    A.jrec = h->d_jrec.p; A.arec = h->d_arec.p;
     A.n = h->n; A.n_alch = (int)h->alch.size(); A.PA = h->PA; A.jcap = h->jcap; A.nblocks_env = h->k2_nblocks_env;
     A.alch_orig = h->d_alch_orig.p; A.jlist = h->d_jlist.p + (size_t)h->n_itiles * h->jcap; A.jcount = h->d_jcount.p + h->n_itiles;
     A.orig_of_sorted = h->d_orig_of_sorted.p; A.sorted_of_orig = h->d_sorted_of_orig.p;
@@ -589,12 +606,12 @@ static int launch_bonded(BluesEngine* h, bool with_noise) {
 static int launch_finalize(BluesEngine* h, const double le[3]) {
     FinArgs F; memset(&F, 0, sizeof F);
     F.n = h->n; F.n_islots = h->n_islots; F.npart = h->npart; F.n_alch = (int)h->alch.size(); F.PA = h->PA; F.k2_nblocks_env = h->k2_nblocks_env; F.n_entries = h->n_entries;
-    F.orig_of_islot = h->d_orig_of_islot.p; F.row_of_orig = h->d_row_of_orig.p; F.row_start = h->d_row_start.p;
+    F.recs = h->d_finrecs.p; F.orig_of_islot = h->d_orig_of_islot.p; F.row_of_orig = h->d_row_of_orig.p; F.row_start = h->d_row_start.p;
     F.fpart = h->d_fpart.p; F.fent = h->d_fent.p; F.fJ = h->d_fJ.p; F.sorted_of_orig = h->d_sorted_of_orig.p; F.alch_orig = h->d_alch_orig.p;
     F.self_part = h->d_self_part.p; F.e_part = h->d_e_part.p; F.jcount_alch = h->d_jcount.p + h->n_itiles;
     for (int s = 0; s < 3; s++) F.le[s] = le[s];
     F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p; F.ctrl = h->ctrl_arg;
-    const int nblk = h->n_islots / 64 + (F.n_alch > 0 ? 1 + 9 + 1 : 0);
+    const int nblk = h->n_islots / 64 + (F.n_alch > 0 ? 1 + 9 * ((F.n_alch + 3) / 4) + 1 : 0);
     hipLaunchKernelGGL(k_finalize, dim3(std::max(1, nblk)), dim3(256), 0, h->cur, F);
     h->st_launches++;
     HIP_OK(h, hipGetLastError());

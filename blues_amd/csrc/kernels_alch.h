@@ -20,7 +20,12 @@
 
 #define K2_NE 6  // energy partials per block: C_scaled, S0, S1, S2, const_lj, const_coul
 
+// packed per-entry records so the pair thread needs two dependent loads (record -> position) instead of four
+struct AlchJRec { int jo, jsrt; double sig, eps, q; };   // one per entry of the alchemical tile's j-list (written at list build)
+struct AlchARec { int ao, asrt, has_env_excl, pad; double sig, eps, q; };  // one per alchemical atom (static)
+
 struct AlchArgs {
+    const AlchJRec* jrec; const AlchARec* arec;
     int n, n_alch, PA, jcap, nblocks_env;
     const int* alch_orig;       // [n_alch]
     const int* jlist;           // j-list of the alchemical tile (sorted indices)
@@ -79,15 +84,17 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
         const bool valid = js < count && a < A.n_alch;
         int jsrt = -1;
         if (valid) {
-            jsrt = A.jlist[js];
-            const int jo = A.orig_of_sorted[jsrt], ao = A.alch_orig[a];
+            const AlchJRec J = A.jrec[js];
+            const AlchARec Ar = A.arec[a];
+            jsrt = J.jsrt;
+            const int jo = J.jo, ao = Ar.ao;
             double d[3];
             for (int k = 0; k < 3; k++) d[k] = min_image_d(A.x[k][ao] - A.x[k][jo], A.box.L[k], A.box.invL[k]);
             const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-            const bool excl = A.check_env_excl && excluded_sorted(A.ex_start, A.ex_idx, A.sorted_of_orig[ao], jsrt);
+            const bool excl = Ar.has_env_excl && excluded_sorted(A.ex_start, A.ex_idx, Ar.asrt, jsrt);
             if (!excl && r2 < A.rc2) {
-                const double sig = 0.5 * (A.sigma[ao] + A.sigma[jo]), eps = sqrt(A.eps[ao] * A.eps[jo]);
-                const double qq = A.charge[ao] * A.charge[jo];
+                const double sig = 0.5 * (Ar.sig + J.sig), eps = sqrt(Ar.eps * J.eps);
+                const double qq = Ar.q * J.q;
                 double fc;
                 const double ec = coulomb_d(r2, qq, A.alpha, A.pme != 0, &fc);
                 e[0] = ec;
@@ -125,7 +132,7 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const double fj = seg_sum(f[s][k], PA);
-                if (a == 0 && js < count) A.fJ[(size_t)(s * 3 + k) * A.n + A.jlist[js]] = -fj;
+                if (a == 0 && js < count) A.fJ[(size_t)(s * 3 + k) * A.n + jsrt] = -fj;
             }
         }
     } else {

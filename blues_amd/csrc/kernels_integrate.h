@@ -221,8 +221,12 @@ __device__ __forceinline__ void load_force(const IntArgs& A, const Cluster& C, i
 //   ftot[k][i]  = sum over K1 partial slabs + sum over the atom's bonded entries
 //   alch_self   = sum over K2 blocks of the force on each alchemical atom (3 slots)
 //   acc->e_slot = le[slot]*C + S[slot]  (alchemical energy per lambda slot, for the H ops)
+// per-slot record of k_finalize: one 16-byte load replaces the chain islot -> atom -> row -> row_start
+struct FinRec { int atom, sorted, e0, e1; };  // caller index (-1: empty), image index, bonded entry range
+
 struct FinArgs {
     int n, n_islots, npart, n_alch, PA, k2_nblocks_env, n_entries;
+    const FinRec* recs;         // [n_islots + 64]: i-slots, then the alchemical atoms
     const int* orig_of_islot;   // [n_islots] caller index or -1
     const int* row_of_orig;     // [n] bonded row or -1
     const int* row_start;
@@ -251,13 +255,27 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
     __shared__ double red[4][3][64];
     int blk = blockIdx.x;
     if (blk < n_itiles + nb_alch_atoms) {
-        int i = -1, isl = -1;
-        if (blk < n_itiles) { isl = blk * 64 + lane; i = A.orig_of_islot[isl]; }
-        else if (lane < A.n_alch) i = A.alch_orig[lane];
+        const int isl = blk < n_itiles ? blk * 64 + lane : -1;
+        const FinRec rec = A.recs[blk < n_itiles ? isl : A.n_islots + lane];
+        const int i = rec.atom;
         double f[3] = {0.0, 0.0, 0.0};
+        double fj[3][3];  // alchemical force on this (environment) atom per slot: requested now, used after the reduction
+#pragma unroll
+        for (int sl = 0; sl < 3; sl++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) fj[sl][k] = (wv == 0 && i >= 0 && isl >= 0 && A.n_alch > 0) ? A.fJ[(size_t)(sl * 3 + k) * A.n + rec.sorted] : 0.0;
         if (i >= 0) {
             if (isl >= 0) {
                 int p = wv;
+                for (; p + 28 < A.npart; p += 32) {  // 8 partials x 3 components in flight
+                    double t[8][3];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) t[u][k] = A.fpart[((size_t)(p + 4 * u) * 3 + k) * A.n_islots + isl];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
+                }
                 for (; p + 12 < A.npart; p += 16) {  // 4 partials x 3 components in flight
                     double t[4][3];
 #pragma unroll
@@ -270,18 +288,23 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
                 for (; p < A.npart; p += 4)
                     for (int k = 0; k < 3; k++) f[k] += A.fpart[((size_t)p * 3 + k) * A.n_islots + isl];
             }
-            const int row = A.row_of_orig[i];
-            if (row >= 0) for (int e = A.row_start[row] + wv; e < A.row_start[row + 1]; e += 4)
-                for (int k = 0; k < 3; k++) f[k] += A.fent[(size_t)k * A.n_entries + e];
+            for (int e = rec.e0 + wv; e < rec.e1; e += 32) {  // up to 8 bonded entries x 3 components in flight
+                double t[8][3];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) t[u][k] = (e + 4 * u < rec.e1) ? A.fent[(size_t)k * A.n_entries + e + 4 * u] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
+            }
         }
         red[wv][0][lane] = f[0]; red[wv][1][lane] = f[1]; red[wv][2][lane] = f[2];
         __syncthreads();
         if (wv == 0 && i >= 0) {
-            const int srt = A.sorted_of_orig[i];
             for (int k = 0; k < 3; k++) {
                 const double f = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
                 if (isl >= 0 && A.n_alch > 0) {
-                    for (int sl = 0; sl < 3; sl++) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f + A.fJ[(size_t)(sl * 3 + k) * A.n + srt];
+                    for (int sl = 0; sl < 3; sl++) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f + fj[sl][k];
                 } else if (isl >= 0) {
                     for (int sl = 0; sl < 3; sl++) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f;
                 } else A.ftot[(size_t)k * A.n + i] = f;  // alchemical atom: bonded part; integrator adds alch_self[slot]
@@ -293,15 +316,14 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
     blk -= n_itiles + nb_alch_atoms;
     const int cnt = *A.jcount_alch;
     const int nb_env = (cnt * A.PA + 255) / 256;
-    if (blk < 9) {  // slab q = slot*3 + component: wave wv sums alchemical atoms a = wv, wv+4, ... over the K2 blocks
-        const int q = blk;
-        for (int a = wv; a < 64; a += 4) {
-            double s = 0.0;
-            if (a < A.n_alch) {
-                for (int b = lane; b < nb_env; b += 64) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
-                if (lane == 0) s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
-                s = wave_sum(s);
-            }
+    const int na4 = (A.n_alch + 3) / 4;
+    if (blk < 9 * na4) {  // slab q = slot*3 + component, 4 alchemical atoms per block: one wave per (q, atom)
+        const int q = blk / na4, a = (blk - q * na4) * 4 + wv;
+        double s = 0.0;
+        if (a < A.n_alch) {
+            for (int b = lane; b < nb_env; b += 64) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
+            if (lane == 0) s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
+            s = wave_sum(s);
             if (lane == 0) A.alch_self[q * 64 + a] = s;
         }
         return;

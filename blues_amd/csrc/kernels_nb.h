@@ -36,6 +36,8 @@ struct ListArgs {
     const int* tile_atoms;   // [n_tiles*64] sorted atom index or -1
     int* jlist;              // [n_tiles*jcap]
     int* jstage;             // [n_tiles*4*jcap] per-wave staging for the ordered compaction
+    void* alch_jrec;         // AlchJRec[jcap] for the alchemical tile (kernels_alch.h), or null
+    const double* p_sigma; const double* p_eps; const double* p_charge;  // caller order
     int* jcount;             // [n_tiles]
     int* batch_slot;         // [n_tiles*(jcap/64)]
     unsigned long long* mask_pool;  // [pool_cap*64]
@@ -148,7 +150,16 @@ __global__ void __launch_bounds__(256) k_build_lists(ListArgs a, NbConst<R> c, c
     const int nbmax = a.jcap >> 6;
     for (int b = tid; b < nbmax; b += 256) { s_need[b] = 0; a.batch_slot[t * nbmax + b] = -1; }
     __syncthreads();
-    if (alch_tile) return;  // the alchemical kernel checks exclusions itself
+    if (alch_tile) {  // the alchemical kernel checks exclusions itself; give it packed per-entry records
+        struct JR { int jo, jsrt; double sig, eps, q; };
+        JR* jr = (JR*)a.alch_jrec;
+        if (jr) for (int k = tid; k < count; k += 256) {
+            const int js = jl[k], jo = img[js].orig;
+            JR r; r.jo = jo; r.jsrt = js; r.sig = a.p_sigma[jo]; r.eps = a.p_eps[jo]; r.q = a.p_charge[jo];
+            jr[k] = r;
+        }
+        return;
+    }
 
     // ---- exclusion bitmasks: one 64x64 bit tile per (i-tile, j-batch) that holds an excluded pair
     const int ia = a.tile_atoms[t * 64 + lane];
