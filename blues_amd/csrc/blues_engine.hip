@@ -113,6 +113,7 @@ struct BluesEngine {
     int n_itiles = 0, n_tiles = 0, jcap = 0, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0;
     int seg_len = 64, waves_tile = 4, wpb = 4, npart = 1;  // K1 decomposition
     bool fuse_forces = false, fast_step = true;
+    int k1_iw = 64;  // i-atoms per wave in the nonbonded kernel: 64 = classic tile kernel, 8/16 = sub-tile throughput kernel
     int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
     double total_mass = 0;
@@ -380,6 +381,17 @@ static int sort_and_tile(BluesEngine* h) {
         if (h->fuse_forces) { WPB = 4; NW = std::max(4, NW / 3); }  // ~3 segments per wave: as long as the alchemical role
         NW = std::max(WPB, (NW / WPB) * WPB);
         h->seg_len = CH; h->waves_tile = NW; h->wpb = WPB; h->npart = NW / WPB;
+        h->k1_iw = 64;
+        if (!h->fuse_forces && h->precision == 0) {
+            h->k1_iw = 8;
+            if (const char* e = getenv("BLUES_IW")) h->k1_iw = atoi(e);
+            if (h->k1_iw != 8 && h->k1_iw != 16 && h->k1_iw != 32) h->k1_iw = 64;
+        }
+        if (h->k1_iw != 64) {
+            int NC = 4;
+            if (const char* e = getenv("BLUES_NC")) NC = std::max(1, atoi(e));
+            h->waves_tile = NC; h->npart = NC; h->wpb = 4; h->seg_len = 64;
+        }
     }
     h->pool_cap = nt * 12 + 64;
     h->PA = 1; while (h->PA < (int)h->alch.size()) h->PA <<= 1;
@@ -432,7 +444,7 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * 4 * jcap); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
         h->d_mask_pool.alloc((size_t)h->pool_cap * 64); h->d_pool_count.alloc(1);
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
-        h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 + 2 * ((n + 255) / 256));
+        h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_iw != 64 ? 64 / h->k1_iw : 1) + 2 * ((n + 255) / 256));
         { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi);
           std::vector<FinRec> fr(h->n_islots + 64);
           auto fill = [&](FinRec& r, int atom) {
@@ -533,8 +545,25 @@ template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
     return a;
 }
 
+template <bool ENERGY> static void launch_nb_sub(BluesEngine* h, const NbArgs<float>& a) {
+    const int subs = 64 / h->k1_iw;
+    const int waves = std::max(1, h->n_itiles) * subs * h->waves_tile;
+    const dim3 grid((waves + 3) / 4), block(256);
+    if (h->k1_iw == 8) hipLaunchKernelGGL((k_nonbonded_sub<ENERGY, 8>), grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
+    else if (h->k1_iw == 16) hipLaunchKernelGGL((k_nonbonded_sub<ENERGY, 16>), grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
+    else hipLaunchKernelGGL((k_nonbonded_sub<ENERGY, 32>), grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
+}
+
 template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
     NbArgs<R> a = make_nb_args<R>(h);
+    if constexpr (sizeof(R) == 4) {
+        if (h->k1_iw != 64) {
+            launch_nb_sub<ENERGY>(h, a);
+            h->st_launches++;
+            HIP_OK(h, hipGetLastError());
+            return 0;
+        }
+    }
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
     switch (h->wpb) {
@@ -704,7 +733,7 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
     if (nbb > 0) { hipLaunchKernelGGL(k_bonded_energy, dim3(nbb), dim3(256), 0, h->stream, make_bonded_args(h)); h->st_launches++; }
     const int nfb = (h->n + 255) / 256;
     if (!h->e_frozen_valid) {
-        double* ep = h->d_epart_nb.p + (size_t)std::max(1, h->n_itiles) * h->npart * 2;
+        double* ep = h->d_epart_nb.p + (size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_iw != 64 ? 64 / h->k1_iw : 1);
         if (h->precision == 0) hipLaunchKernelGGL(k_energy_frozen<float>, dim3(nfb), dim3(256), 0, h->stream, h->n, make_nbconst<float>(h), h->d_img_f.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
         else hipLaunchKernelGGL(k_energy_frozen<double>, dim3(nfb), dim3(256), 0, h->stream, h->n, make_nbconst<double>(h), h->d_img_d.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
         h->st_launches++;
@@ -713,10 +742,10 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
     std::vector<double> e;
     try {
         h->d_epart_nb.download(e);
-        const int nw = h->n_itiles * h->npart;
+        const int nw = h->n_itiles * h->npart * (h->k1_iw != 64 ? 64 / h->k1_iw : 1);
         double enb = 0.0; for (int w = 0; w < nw; w++) enb += e[2 * w] + e[2 * w + 1];
         if (!h->e_frozen_valid) {
-            const size_t off = (size_t)std::max(1, h->n_itiles) * h->npart * 2;
+            const size_t off = (size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_iw != 64 ? 64 / h->k1_iw : 1);
             h->e_frozen[0] = h->e_frozen[1] = 0.0;
             for (int b = 0; b < nfb; b++) { h->e_frozen[0] += e[off + 2 * b]; h->e_frozen[1] += e[off + 2 * b + 1]; }
             h->e_frozen_valid = true;

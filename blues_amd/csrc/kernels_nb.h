@@ -285,6 +285,87 @@ __global__ void __launch_bounds__(WPB * 64) k_nonbonded(NbArgs<R> a, NbConst<R> 
     nonbonded_body<R, ENERGY, WPB>(a, c, img, blockIdx.x);
 }
 
+// ---- throughput variant for large i-sets (mixed precision): a wave owns a SUB-tile of IW i-atoms and JL = 64/IW
+// j-lanes, lane = (jl, i).  With 64 i-atoms per wave nearly every j has SOME lane in range, so the pair body (70+
+// VALU ops) runs for all 64 lanes although only ~23 % of the pairs are inside the cutoff; with 8 i-atoms x 8
+// consecutive (Hilbert-sorted) j-atoms many wave-iterations have no pair in range and are skipped by the exec-mask
+// branch.  j-batches are staged in a wave-private, bank-conflict-free LDS image ({x,y,z,q} 16 B + {hs,se} 8 B).
+template <bool ENERGY, int IW>
+__global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<float> c, const AtomF* __restrict__ img) {
+    constexpr int JL = 64 / IW, SUBS = 64 / IW;
+    struct P4 { uint32_t x, y, z; float q; };
+    struct P2 { float hs, se; };
+    __shared__ P4 lp[4][64];
+    __shared__ P2 lq[4][64];
+    __shared__ uint32_t lf[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.flags->list_gen = a.flags->req_gen;
+    const int NC = a.waves_tile;
+    const int W = blockIdx.x * 4 + wv;
+    const int t = W / (SUBS * NC);
+    if (t >= a.n_itiles) return;  // wave-uniform
+    const int rem = W - t * SUBS * NC, sub = rem / NC, ch = rem - sub * NC;
+    const int il = lane & (IW - 1), jl = lane / IW;
+    const int islot = t * 64 + sub * IW + il;
+    const int ia = a.tile_atoms[islot];
+    const bool valid = ia >= 0;
+    const AtomF ai = img[valid ? ia : a.tile_atoms[t * 64]];
+    const int count = a.jcount[t];
+    const int nb = (count + 63) >> 6;
+    const int nbmax = a.jcap >> 6;
+    const int* jlst = a.jlist + (size_t)t * a.jcap;
+    double fx = 0.0, fy = 0.0, fz = 0.0, elj = 0.0, ecl = 0.0;
+    P4* mp = lp[wv]; P2* mq = lq[wv]; uint32_t* mf = lf[wv];
+
+    for (int b = ch; b < nb; b += NC) {
+        const int p0 = b * 64;
+        const int nvalid = min(64, count - p0);
+        if (lane < nvalid) {
+            const AtomF aj = img[jlst[p0 + lane]];
+            P4 v4; v4.x = aj.x; v4.y = aj.y; v4.z = aj.z; v4.q = aj.q; mp[lane] = v4;
+            P2 v2; v2.hs = aj.hs; v2.se = aj.se; mq[lane] = v2;
+            if (ENERGY) mf[lane] = aj.flags;
+        }
+        const int slot = a.batch_slot[t * nbmax + b];
+        unsigned long long m = 0ull;
+        if (slot >= 0) m = a.mask_pool[(size_t)slot * 64 + sub * IW + il];
+        if (!valid) m = ~0ull;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int ngroups = (nvalid + JL - 1) / JL;
+        for (int g = 0; g < ngroups; g++) {
+            const int k = g * JL + jl;
+            const P4 bj = mp[k];
+            float dx = (float)(int32_t)(ai.x - bj.x) * c.scale[0];
+            float dy = (float)(int32_t)(ai.y - bj.y) * c.scale[1];
+            float dz = (float)(int32_t)(ai.z - bj.z) * c.scale[2];
+            float r2 = dx * dx + dy * dy + dz * dz;
+            const bool in = (k < nvalid) && (r2 < c.rc2) && !((m >> k) & 1ull);
+            if (in) {
+                const P2 bp = mq[k];
+                float e1, e2;
+                float fs = pair_regular<float>(r2, ai.q * bj.q, ai.hs + bp.hs, ai.se * bp.se, c.alpha, &e1, &e2);
+                fx += (double)(fs * dx); fy += (double)(fs * dy); fz += (double)(fs * dz);
+                if (ENERGY) {
+                    const double wgt = (mf[k] & FLAG_MOBILE) ? 0.5 : 1.0;
+                    elj += wgt * (double)e1; ecl += wgt * (double)e2;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // sum over the j-lanes of each i-atom
+#pragma unroll
+    for (int off = IW; off < 64; off <<= 1) { fx += __shfl_xor(fx, off, 64); fy += __shfl_xor(fy, off, 64); fz += __shfl_xor(fz, off, 64); }
+    if (jl == 0) {
+        double* fp = a.fpart + (size_t)ch * 3 * a.n_islots;
+        fp[islot] = fx; fp[a.n_islots + islot] = fy; fp[2 * a.n_islots + islot] = fz;
+    }
+    if (ENERGY) {
+        elj = wave_sum(elj); ecl = wave_sum(ecl);
+        if (lane == 0) { a.epart[2 * W] = elj; a.epart[2 * W + 1] = ecl; }
+    }
+}
+
 // One-off: LJ + Coulomb energy among FROZEN environment atoms (constant while they and the box
 // stay put).  Brute force over the sorted image; partial sums per block.
 template <typename R>
