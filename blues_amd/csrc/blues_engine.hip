@@ -388,7 +388,7 @@ static int sort_and_tile(BluesEngine* h) {
             if (h->k1_iw != 8 && h->k1_iw != 16 && h->k1_iw != 32) h->k1_iw = 64;
         }
         if (h->k1_iw != 64) {
-            int NC = 4;
+            int NC = 8;
             if (const char* e = getenv("BLUES_NC")) NC = std::max(1, atoi(e));
             h->waves_tile = NC; h->npart = NC; h->wpb = 4; h->seg_len = 64;
         }

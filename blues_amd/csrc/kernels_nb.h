@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<
         if (!valid) m = ~0ull;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int ngroups = (nvalid + JL - 1) / JL;
+        float bx = 0.0f, by = 0.0f, bz = 0.0f;  // per-batch partial force (at most IW terms per lane), folded into fp64 below
         for (int g = 0; g < ngroups; g++) {
             const int k = g * JL + jl;
             const P4 bj = mp[k];
@@ -344,13 +345,14 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<
                 const P2 bp = mq[k];
                 float e1, e2;
                 float fs = pair_regular<float>(r2, ai.q * bj.q, ai.hs + bp.hs, ai.se * bp.se, c.alpha, &e1, &e2);
-                fx += (double)(fs * dx); fy += (double)(fs * dy); fz += (double)(fs * dz);
+                bx = fmaf(fs, dx, bx); by = fmaf(fs, dy, by); bz = fmaf(fs, dz, bz);
                 if (ENERGY) {
                     const double wgt = (mf[k] & FLAG_MOBILE) ? 0.5 : 1.0;
                     elj += wgt * (double)e1; ecl += wgt * (double)e2;
                 }
             }
         }
+        fx += (double)bx; fy += (double)by; fz += (double)bz;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // sum over the j-lanes of each i-atom
