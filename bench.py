@@ -122,8 +122,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # dominant kernel: the direct-space nonbonded kernel, timed alone with HIP events on the engine's stream
+    # the kernel north_star prices against the HBM roofline: the direct-space nonbonded kernel, timed alone with HIP
+    # events on the engine's own stream (blues_time_nonbonded)
     k1_us = eng.time_nonbonded(50)
+    traffic = None
+    try:  # HBM-side bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md says how they were taken)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            pmc = json.load(fh).get(args.workload)
+        if pmc:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     if rank == 0:
         n_atoms = system.n_atoms
         ms_per_step = 1e3 * elapsed / args.steps
@@ -138,7 +147,7 @@ def main():
                        % (args.workload, n_atoms, int((system.mass > 0).sum()), nsteps),
                        "parallelism": "replica-per-gpu x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_nonbonded<float,false>", "usec_per_launch": k1_us,
+                         "traffic": traffic, "kernel": "k_nonbonded (direct-space LJ + erfc Coulomb)", "usec_per_launch": k1_us,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ATOM * n_atoms},
             "engine": {"force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,
                        "kernel_launches_per_switch": (st1["kernel_launches"] - st0["kernel_launches"]) / args.steps,
