@@ -390,3 +390,30 @@ def test_alchemical_subset_of_a_molecule(Engine, oracle_mod, tol_box, precision,
         wg = g.run_switch(12, trace=True); wo = _trace(o, 12)
         assert np.abs(wg - wo).max() <= tol * max(1.0, np.abs(wo).max())
         g.close()
+
+
+def test_thermostat_and_constraints_long_run(Engine, tol_box):
+    """Physics check that does not involve the oracle: 3000 Langevin steps (12 ps) of the 975-atom box at 4 fs keep the
+    kinetic temperature at 300 K (equipartition over 3N - Nc degrees of freedom), the constraints at 1e-8 and the
+    centre-of-mass momentum of the CM-removed system at zero -- for both the BAOAB-like 'V R O R V' and OpenMM's 'L' step."""
+    s, v = tol_box
+    ndof = 3 * s.n_atoms - len(s.constraint_dist) - 3
+    for split in ("V R O R V", "L"):
+        integ = integrators.AlchemicalExternalLangevinIntegrator({"lambda_sterics": "1", "lambda_electrostatics": "1"}, splitting="V R O R V",
+                                                                  temperature=300.0, timestep=0.004, nsteps_neq=2 ** 30, seed=77) if split != "L" else \
+            integrators.LangevinIntegrator(300.0, 1.0, 0.004, seed=78)
+        g = Engine(s, integ.to_data(precision=0)); g.set_velocities(v)
+        temps = []
+        for blk in range(30):
+            g.step(100)
+            temps.append(2 * g.kinetic_energy() / (ndof * 0.0083144626))
+        T = np.mean(temps[5:])
+        assert abs(T - 300.0) < 6.0, (split, T)          # OpenMM's leapfrog-style 'L' reads a few K low at 4 fs, as in OpenMM itself
+        x, vv, c = g.get_positions(), g.get_velocities(), s.constraint_atoms
+        assert np.abs(np.linalg.norm(x[c[:, 0]] - x[c[:, 1]], axis=1) / s.constraint_dist - 1).max() < 1e-7
+        # the remover zeroes the total momentum at the head of every pass; what is left at the end of a step is the
+        # momentum injected by that step's thermostat noise: sqrt(sum m kT (1 - exp(-2 gamma dt))) ~ 12 amu nm/ps here
+        p = (s.mass[:, None] * vv).sum(0)
+        assert np.abs(p).max() < 6.0 * np.sqrt(s.mass.sum() * 0.0083144626 * 300.0 * (1.0 - np.exp(-2 * 0.004)))
+        assert g.stats()["list_generation"] > 5        # the lists were rebuilt on the device along the way
+        g.close()
