@@ -130,6 +130,7 @@ struct BluesEngine {
     DBuf<int> d_cl_atoms, d_cl_type, d_cl_nc, d_cl_alch, d_cl_mobile, d_cl_sorted; DBuf<double> d_cl_dist;
     DBuf<ClusterRec> d_recs; std::vector<ClusterRec> h_recs;
     DBuf<AlchJRec> d_jrec; DBuf<AlchARec> d_arec;
+    DBuf<double> d_mom_part; bool vel_clean = false, pass_valid_for_l = true;  // velocities unchanged since the last force pass (momentum partials valid)
     DBuf<FinRec> d_finrecs; std::vector<int> h_row_of_orig, h_row_start;
     // bonded
     DBuf<int> d_row_atom, d_row_start, d_ent_type, d_ent_term, d_ent_role;
@@ -455,7 +456,7 @@ static int sort_and_tile(BluesEngine* h) {
           for (int a = 0; a < 64; a++) fill(fr[h->n_islots + a], a < (int)h->alch.size() ? h->alch[a] : -1);
           h->d_finrecs.upload(fr); }
         h->d_fJ.alloc((size_t)9 * n);
-        h->d_self_part.alloc((size_t)(h->k2_nblocks_env + 1) * 9 * 64); h->d_e_part.alloc((size_t)(h->k2_nblocks_env + 1) * K2_NE);
+        h->d_self_part.alloc((size_t)(h->k2_nblocks_env + 1) * 9 * 64); h->d_e_part.alloc((size_t)(h->k2_nblocks_env + 1) * K2_NP); h->d_mom_part.alloc((size_t)(h->n_islots / 64 + 2) * 6);
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     h->hx_sort = h->hx;
     h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->graph_valid = false;
@@ -482,6 +483,7 @@ static IntArgs make_int_args(BluesEngine* h) {
     A.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; A.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
     A.half_skin2 = 0.25 * h->skin * h->skin; A.flags = h->d_flags.p; A.pool_count = h->d_pool_count.p;
     A.total_mass = h->total_mass; A.cm_part = h->d_cm_part.p; A.cm_nblocks = h->int_blocks;
+    A.mom_part = h->d_mom_part.p; A.n_mom = h->n_islots / 64 + 2;
     A.acc = h->d_acc.p; A.work_trace = (h->tracing || h->ctrl_arg) ? h->d_trace.p : nullptr; A.trace_index = h->prog_trace;
     A.ctrl = h->ctrl_arg; A.stamps = h->d_stamps.p;
     A.prog = h->prog;
@@ -492,14 +494,25 @@ static int flush_program(BluesEngine* h) {
     if (h->prog.n == 0) return 0;
     IntArgs A = make_int_args(h);
     // the steady-state program of "H V R O R V H" has a straight-line specialisation (same arithmetic)
-    static const unsigned char P_CM[9] = {OP_V0, OP_H01, OP_END, OP_CM_BLOCK, OP_H12, OP_V2, OP_R, OP_O, OP_R};
+    static const unsigned char P_CM[9] = {OP_V0, OP_H01, OP_END, OP_CM_PART, OP_H12, OP_V2, OP_R, OP_O, OP_R};
     static const unsigned char P_NC[8] = {OP_V0, OP_H01, OP_END, OP_H12, OP_V2, OP_R, OP_O, OP_R};
+    static const unsigned char P_MD_CM[2] = {OP_CM_PART, OP_L};
+    static const unsigned char P_MD_NC[1] = {OP_L};
+    bool has_part = false;
+    for (int q = 0; q < h->prog.n; q++) has_part |= h->prog.ops[q] == OP_CM_PART;
     if (h->fast_step && h->prog.n == 9 && !memcmp(h->prog.ops, P_CM, 9))
         hipLaunchKernelGGL(k_step_default<true>, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
     else if (h->fast_step && h->prog.n == 8 && !memcmp(h->prog.ops, P_NC, 8))
         hipLaunchKernelGGL(k_step_default<false>, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
-    else
+    else if (h->fast_step && h->prog.n == 2 && !memcmp(h->prog.ops, P_MD_CM, 2))
+        hipLaunchKernelGGL(k_step_md<true>, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
+    else if (h->fast_step && h->prog.n == 1 && !memcmp(h->prog.ops, P_MD_NC, 1) && h->pass_valid_for_l)
+        hipLaunchKernelGGL(k_step_md<false>, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
+    else {
+        if (has_part) E_FAIL(h, "internal: OP_CM_PART outside a specialised program");
         hipLaunchKernelGGL(k_integrate, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
+    }
+    h->vel_clean = false;
     h->st_launches++;
     h->prog.n = 0; h->prog_trace = -1; h->prog_draw_base = h->h_draw;
     HIP_OK(h, hipGetLastError());
@@ -640,6 +653,8 @@ static int launch_finalize(BluesEngine* h, const double le[3]) {
     F.self_part = h->d_self_part.p; F.e_part = h->d_e_part.p; F.jcount_alch = h->d_jcount.p + h->n_itiles;
     for (int s = 0; s < 3; s++) F.le[s] = le[s];
     F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p; F.ctrl = h->ctrl_arg;
+    for (int k = 0; k < 3; k++) F.v[k] = h->d_v[k].p;
+    F.mass = h->d_mass.p; F.mom_part = h->d_mom_part.p;
     const int nblk = h->n_islots / 64 + (F.n_alch > 0 ? 1 + 9 * ((F.n_alch + 3) / 4) + 1 : 0);
     hipLaunchKernelGGL(k_finalize, dim3(std::max(1, nblk)), dim3(256), 0, h->cur, F);
     h->st_launches++;
@@ -693,7 +708,7 @@ static int force_pass(BluesEngine* h, int base_L) {
         if (rc) return 1;
         if (launch_bonded_and_finalize(h, le, true)) return 1;
     }
-    h->pass_valid = true; h->pass_L = base_L; h->st_passes++;
+    h->pass_valid = true; h->pass_L = base_L; h->st_passes++; h->vel_clean = true;
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -760,7 +775,7 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
             const int cnt = jc[h->n_itiles], nb_env = (cnt * h->PA + 255) / 256;
             h->d_e_part.download(e);
             double s[K2_NE] = {0, 0, 0, 0, 0, 0};
-            for (int b = 0; b <= h->k2_nblocks_env; b++) { if (b >= nb_env && b != h->k2_nblocks_env) continue; for (int q = 0; q < K2_NE; q++) s[q] += e[(size_t)b * K2_NE + q]; }
+            for (int b = 0; b <= h->k2_nblocks_env; b++) { if (b >= nb_env && b != h->k2_nblocks_env) continue; for (int q = 0; q < K2_NE; q++) s[q] += e[(size_t)b * K2_NP + q]; }
             T[5] = s[1] + s[4]; T[6] = h->cur_le * s[0] + s[5];
         }
     } catch (std::string& msg) { E_FAIL(h, "%s", msg.c_str()); }
@@ -786,6 +801,11 @@ static int add_work(BluesEngine* h, double delta) {
 
 static int emit_cm(BluesEngine* h) {
     if (!h->remove_cm) return 0;
+    if (h->fast_step && h->vel_clean && h->pass_valid) {
+        const bool after_finish = h->prog.n == 3 && h->prog.ops[0] == OP_V0 && h->prog.ops[1] == OP_H01 && h->prog.ops[2] == OP_END && h->split == "HVRORVH" && h->nprop == 1 && h->h_step < h->nsteps - 0;
+        const bool md_head = h->prog.n == 0 && h->split == "L" && !h->tracing;
+        if (after_finish || md_head) return emit(h, OP_CM_PART);
+    }
     if (h->int_blocks == 1) return emit(h, OP_CM_BLOCK);
     if (emit(h, OP_CM_REDUCE)) return 1;
     if (flush_program(h)) return 1;
@@ -799,6 +819,9 @@ static int need_pass(BluesEngine* h, int lo, int hi) {  // need slots covering L
 }
 
 static int splitting_pass(BluesEngine* h) {
+    if (h->remove_cm && !h->pass_valid && !h->split.empty() && h->split[0] == 'L') {
+        if (need_pass(h, h->h_lambda_step, h->h_lambda_step)) return 1;  // forces do not depend on velocities: evaluate them first
+    }
     if (emit_cm(h)) return 1;
     for (char c : h->split) {
         switch (c) {
@@ -951,9 +974,11 @@ static int do_steps(BluesEngine* h, int nsteps) {
             if (splitting_pass(h)) return 1;
             if (h->h_lambda > h->prop_min && h->h_lambda <= h->prop_max)
                 while (h->h_prop < h->nprop) { h->h_prop++; if (splitting_pass(h)) return 1; }
-            if (h->prog_trace >= 0) { if (flush_program(h)) return 1; }
-            if (emit(h, OP_END)) return 1;
-            h->prog_trace = h->h_step;
+            if (h->n_H > 0 || h->tracing) {  // END only records the work trace; a plain MD integrator has no protocol work
+                if (h->prog_trace >= 0) { if (flush_program(h)) return 1; }
+                if (emit(h, OP_END)) return 1;
+                h->prog_trace = h->h_step;
+            }
             h->h_step++; h->h_prop = 1;
         }
     }
@@ -1129,6 +1154,7 @@ int blues_set_velocities(BluesEngine* h, const double* xyz, int32_t n_atoms) {
     HIP_OK(h, hipSetDevice(h->device));
     if (flush_program(h)) return 1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
+    h->vel_clean = false;
     return upload_xyz(h, xyz, h->d_v);
 }
 
@@ -1195,6 +1221,7 @@ int blues_set_velocities_to_temperature(BluesEngine* h, double temperature, uint
     if (flush_program(h)) return 1;
     hipLaunchKernelGGL(k_maxwell, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->n, h->d_mass.p, h->d_v[0].p, h->d_v[1].p, h->d_v[2].p, KB_KJ * temperature, (unsigned long long)seed, (unsigned)h->replica * 4u + 1u);
     h->st_launches++;
+    h->vel_clean = false;
     if (emit(h, OP_RATTLE)) return 1;
     if (flush_program(h)) return 1;
     return check_flags(h);

@@ -19,6 +19,7 @@
 #include "device_common.h"
 
 #define K2_NE 6  // energy partials per block: C_scaled, S0, S1, S2, const_lj, const_coul
+#define K2_NP 9  // K2_NE + the block's total slot-0 force on the alchemical atoms (x,y,z), for the momentum bookkeeping
 
 // packed per-entry records so the pair thread needs two dependent loads (record -> position) instead of four
 struct AlchJRec { int jo, jsrt; double sig, eps, q; };   // one per entry of the alchemical tile's j-list (written at list build)
@@ -48,7 +49,7 @@ struct AlchArgs {
     double ls[3], le[3];
     double* fJ;         // [3 slots][3][n] force on environment atoms by sorted index
     double* self_part;  // [nblocks][3 slots][3][64]
-    double* e_part;     // [nblocks][K2_NE]
+    double* e_part;     // [nblocks][K2_NP]
     const DevCtrl* ctrl; // non-null in graph replays: lambda slots come from the device tables
 };
 
@@ -224,7 +225,8 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
         for (int q = 0; q < K2_NE; q++) e[q] = wave_sum(e[q]);
         if (lane == 0) for (int q = 0; q < K2_NE; q++) s_e[wv][q] = e[q];
         __syncthreads();
-        if (tid < K2_NE) A.e_part[(size_t)block_id * K2_NE + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
+        if (tid < K2_NE) A.e_part[(size_t)block_id * K2_NP + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
+        if (wv == 0) for (int k = 0; k < 3; k++) { const double t = wave_sum(lane < A.n_alch ? s_self[0][k][lane] : 0.0); if (lane == 0) A.e_part[(size_t)block_id * K2_NP + K2_NE + k] = t; }
         return;
     }
 
@@ -249,7 +251,12 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
             A.self_part[((size_t)block_id * 9 + q) * 64 + tid] = v;
         }
     }
-    if (tid < K2_NE) A.e_part[(size_t)block_id * K2_NE + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
+    if (tid < K2_NE) A.e_part[(size_t)block_id * K2_NP + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
+    if (wv == 0) for (int k = 0; k < 3; k++) {
+        const double v = lane < PA ? s_self[0][k][lane] + s_self[1][k][lane] + s_self[2][k][lane] + s_self[3][k][lane] : 0.0;
+        const double t = wave_sum(v);
+        if (lane == 0) A.e_part[(size_t)block_id * K2_NP + K2_NE + k] = t;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) { alchemical_body(A, blockIdx.x); }

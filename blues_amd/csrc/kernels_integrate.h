@@ -28,6 +28,7 @@ enum {
     OP_CM_REDUCE,              // write this block's momentum partial (last op of a launch)
     OP_CM_APPLY,               // subtract total momentum / total mass (first op of the next launch)
     OP_RATTLE,                 // velocity constraints only (setVelocitiesToTemperature)
+    OP_CM_PART,                // CMMotionRemover from the momentum partials of k_finalize (only inside the specialised step kernels)
     OP_L,                      // OpenMM LangevinIntegrator step (MD leg): v' = a v + (1-a)/g f/m + sqrt(kT(1-a^2)/m) xi; x' = x + dt v'; SHAKE; v = (x'-x)/dt
 };
 
@@ -73,6 +74,7 @@ struct IntArgs {
     DevFlags* flags; int* pool_count;
     // COM removal
     double total_mass; double* cm_part; int cm_nblocks;
+    const double* mom_part; int n_mom;  // momentum partials written by k_finalize (see FinArgs)
     DevAccum* acc; double* work_trace; int trace_index;
     DevCtrl* ctrl;
     long long* stamps;  // debug builds (-DBLUES_STAMP): cycle stamp of thread 0 at every op boundary
@@ -236,6 +238,9 @@ struct FinArgs {
     double le[3];
     double* ftot; double* alch_self; DevAccum* acc;
     DevCtrl* ctrl;
+    // momentum bookkeeping for CMMotionRemover without a grid-wide reduction inside the step kernel:
+    // mom_part[block][0..2] = sum m v, [3..5] = sum of the slot-0 force, over the block's atoms
+    const double* v[3]; const double* mass; double* mom_part;
 };
 
 // grid: [0, n_itiles) one block per i-tile | [n_itiles, +nb_alch_atoms) alchemical atoms' bonded rows |
@@ -310,6 +315,17 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
                 } else A.ftot[(size_t)k * A.n + i] = f;  // alchemical atom: bonded part; integrator adds alch_self[slot]
             }
         }
+        if (wv == 0) {
+            double pm[6];
+            const double m = i >= 0 ? A.mass[i] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                pm[k] = i >= 0 ? m * A.v[k][i] : 0.0;
+                pm[3 + k] = i >= 0 ? red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane] + ((isl >= 0 && A.n_alch > 0) ? fj[0][k] : 0.0) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 6; q++) { pm[q] = wave_sum(pm[q]); if (lane == 0) A.mom_part[(size_t)blk * 6 + q] = pm[q]; }
+        }
         return;
     }
     if (A.n_alch == 0) return;
@@ -328,16 +344,17 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
         }
         return;
     }
-    __shared__ double s_e[K2_NE];
-    for (int q = wv; q < K2_NE; q += 4) {
+    __shared__ double s_e[K2_NP];
+    for (int q = wv; q < K2_NP; q += 4) {
         double s = 0.0;
-        for (int b = lane; b < nb_env; b += 64) s += A.e_part[(size_t)b * K2_NE + q];
-        if (lane == 0) s += A.e_part[(size_t)A.k2_nblocks_env * K2_NE + q];
+        for (int b = lane; b < nb_env; b += 64) s += A.e_part[(size_t)b * K2_NP + q];
+        if (lane == 0) s += A.e_part[(size_t)A.k2_nblocks_env * K2_NP + q];
         s = wave_sum(s);
         if (lane == 0) s_e[q] = s;
     }
     __syncthreads();
     if (tid < 3) A.acc->e_slot[tid] = A.le[tid] * s_e[0] + s_e[1 + tid];
+    if (tid < 6) A.mom_part[(size_t)(n_itiles + 1) * 6 + tid] = tid < 3 ? 0.0 : s_e[K2_NE + tid - 3];  // alchemical pair force on the alchemical atoms
 }
 
 __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
@@ -641,11 +658,11 @@ __global__ void __launch_bounds__(256) k_step_default(IntArgs A) {
         if (A.work_trace) A.work_trace[A.trace_index] = A.acc->protocol_work;
     }
     if (CM) {
+        // total momentum after the finishing kick = sum m v (before this launch) + hV * sum F(slot 0): both sums were left
+        // behind per block by k_finalize, so no grid-wide reduction of the kicked velocities is needed here
         double p[3] = {0.0, 0.0, 0.0};
-        if (active) {
-#pragma unroll
-            for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) p[k] += C.v[a][k] / C.w[a];
-        }
+        for (int q = tid; q < A.n_mom; q += blockDim.x)
+            for (int k = 0; k < 3; k++) p[k] += A.mom_part[(size_t)q * 6 + k] + A.hV * A.mom_part[(size_t)q * 6 + 3 + k];
         for (int k = 0; k < 3; k++) { p[k] = wave_sum(p[k]); if ((tid & 63) == 0) s_red[tid >> 6][k] = p[k]; }
         __syncthreads();
         if (tid < 3) { double s = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += s_red[w][tid]; s_cm[tid] = s / A.total_mass; }
@@ -712,4 +729,83 @@ __global__ void __launch_bounds__(256) k_step_default(IntArgs A) {
         if (bad) A.flags->nan_flag = 1;
         if (!ok) A.flags->constraint_fail = 1;
     }
+}
+
+// ---- straight-line specialisation of one MD-leg step: [CM] L   (OpenMM LangevinIntegrator)
+template <bool CM>
+__global__ void __launch_bounds__(256) k_step_md(IntArgs A) {
+    const int tid = threadIdx.x;
+    const int cl = blockIdx.x * blockDim.x + tid;
+    __shared__ double s_red[4][4];
+    __shared__ double s_cm[3];
+    const bool active = cl < A.n_clusters;
+    ClusterRec R;
+    if (active) R = A.recs[cl];
+    else { for (int a = 0; a < 4; a++) { R.atoms[a] = -1; R.alch[a] = -1; R.mobile[a] = 0; R.sorted[a] = 0; R.w[a] = 0.0; } R.type = 0; R.nc = 0; R.na = 0; R.dist[0] = R.dist[1] = R.dist[2] = 0.0; }
+    Cluster C;
+    C.na = R.na; C.nc = R.nc; C.type = R.type;
+    const unsigned nd0 = A.draw_base - A.noise_draw_base;
+    const bool pre_noise = nd0 < (unsigned)A.n_noise;
+    double F[4][3], G0[4][3], XB[4][3], x0[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int i = max(R.atoms[a], 0), al = R.alch[a], alc = max(al, 0);
+        C.id[a] = R.atoms[a]; C.al[a] = al; C.w[a] = R.w[a];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; XB[a][k] = A.xbuild[k][i];
+            F[a][k] = A.ftot[(size_t)k * A.n + i] + (al >= 0 ? A.alch_self[k * 64 + alc] : 0.0);
+            G0[a][k] = pre_noise ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) C.d2[c] = R.dist[c] * R.dist[c];
+    if (CM) {
+        double p[3] = {0.0, 0.0, 0.0};
+        for (int q = tid; q < A.n_mom; q += blockDim.x) for (int k = 0; k < 3; k++) p[k] += A.mom_part[(size_t)q * 6 + k];
+        for (int k = 0; k < 3; k++) { p[k] = wave_sum(p[k]); if ((tid & 63) == 0) s_red[tid >> 6][k] = p[k]; }
+        __syncthreads();
+        if (tid < 3) { double s = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += s_red[w][tid]; s_cm[tid] = s / A.total_mass; }
+        __syncthreads();
+    }
+    if (!active) return;
+    bool ok = true, need_rebuild = false, bad = false;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) x0[a][k] = C.x[a][k];
+        if (a < C.na) {
+            double g[3];
+            if (pre_noise) { for (int k = 0; k < 3; k++) g[k] = G0[a][k]; }
+            else gaussians3(A.seed, A.stream, A.draw_base, (unsigned)C.id[a], g);
+            const double sd = sqrt(A.kT * C.w[a]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double v0 = C.v[a][k] - (CM ? s_cm[k] : 0.0);
+                C.v[a][k] = A.aL * v0 + A.fsL * C.w[a] * F[a][k] + A.nsL * sd * g[k];
+                C.x[a][k] += A.dtL * C.v[a][k];
+            }
+        }
+    }
+    ok &= shake(C, x0, A.tol, A);
+    const double inv_dt = 1.0 / A.dtL;
+#pragma unroll
+    for (int a = 0; a < 4; a++) if (a < C.na) {
+        const int i = C.id[a];
+        double d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            C.v[a][k] = (C.x[a][k] - x0[a][k]) * inv_dt;
+            A.v[k][i] = C.v[a][k]; A.x[k][i] = C.x[a][k];
+            bad |= !(C.x[a][k] == C.x[a][k]) || !(C.v[a][k] == C.v[a][k]);
+            const double d = C.x[a][k] - XB[a][k]; d2 += d * d;
+        }
+        need_rebuild |= d2 > A.half_skin2;
+        const int s = R.sorted[a];
+        if (A.img_f) { unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2]; }
+        else { unsigned long long u[3]; to_fixed(C.x[a], A.box, u); A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
+    }
+    if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; *A.pool_count = 0; }
+    if (bad) A.flags->nan_flag = 1;
+    if (!ok) A.flags->constraint_fail = 1;
 }

@@ -98,12 +98,13 @@ def test_short_switch_work_trace(Engine, oracle_mod, tol_box, precision, tol):
     # step() beyond nsteps is a no-op (reference blues/integrators.py:183)
     g.step(2)
     assert g.get_global("protocol_work") == pytest.approx(wg[-1], rel=1e-15) and g.get_global("step") == n
-    # step(1) x n == run_switch(n), bitwise
+    # step(1) x n == run_switch(n) up to rounding: the fused launch takes the centre-of-mass momentum from the per-block
+    # partials k_finalize leaves behind (sum m v + hV sum F), the call-by-call path from the kicked velocities themselves
     g2 = Engine(s, data); g2.set_velocities(v)
     for _ in range(n):
         g2.step(1)
-    assert g2.get_global("protocol_work") == wg[-1]
-    assert np.array_equal(g2.get_positions(), g.get_positions())
+    assert g2.get_global("protocol_work") == pytest.approx(wg[-1], rel=1e-11)
+    assert np.abs(g2.get_positions() - g.get_positions()).max() < (1e-11 if precision else 1e-9)
     g.close(); g2.close()
 
 
