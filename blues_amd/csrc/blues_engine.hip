@@ -112,7 +112,7 @@ struct BluesEngine {
     std::vector<HostCluster> clusters;
     int n_itiles = 0, n_tiles = 0, jcap = 0, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0;
     int seg_len = 64, waves_tile = 4, wpb = 4, npart = 1;  // K1 decomposition
-    bool fuse_forces = false, fast_step = true;
+    bool fuse_forces = false, fast_step = true, fuse_big = false;  // fuse_big: measured slower (the alchemical role's 140 VGPRs and 36 KB LDS cap the occupancy of the nonbonded role)
     int k1_iw = 64;  // i-atoms per wave in the nonbonded kernel: 64 = classic tile kernel, 8/16 = sub-tile throughput kernel
     int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
@@ -684,6 +684,25 @@ template <typename R> static int launch_forces_fused(BluesEngine* h, const doubl
     return 0;
 }
 
+static int launch_forces_fused_sub(BluesEngine* h, const double ls[3], const double le[3]) {
+    NbArgs<float> a = make_nb_args<float>(h);
+    AlchArgs A = make_alch_args(h, ls, le, 7);
+    BondedArgs B = make_bonded_args(h);
+    B.n_entry_blocks = (h->n_entries + 255) / 256;
+    const int subs = 64 / h->k1_iw;
+    const int nb1 = (std::max(1, h->n_itiles) * subs * h->waves_tile + 3) / 4;
+    const int nb2 = h->alch.empty() ? 0 : h->k2_nblocks_env + 1;
+    const int nb3 = B.n_entry_blocks + ((int)h->mobile.size() * h->n_noise + 255) / 256;
+    h->noise_draw_base = h->h_draw; h->noise_valid = true;
+    const dim3 grid(nb1 + nb2 + nb3), block(256);
+    if (h->k1_iw == 8) hipLaunchKernelGGL(k_forces_fused_sub<8>, grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p, A, B, nb1, nb2);
+    else if (h->k1_iw == 16) hipLaunchKernelGGL(k_forces_fused_sub<16>, grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p, A, B, nb1, nb2);
+    else hipLaunchKernelGGL(k_forces_fused_sub<32>, grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p, A, B, nb1, nb2);
+    h->st_launches++;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
 static int ensure_sorted(BluesEngine* h) {
     if (!h->have_positions) E_FAIL(h, "positions have not been set");
     if (!h->sorted_ok) return sort_and_tile(h);
@@ -701,6 +720,9 @@ static int force_pass(BluesEngine* h, int base_L) {
     if (h->fuse_forces && h->wpb == 4) {
         rc = h->precision == 0 ? launch_forces_fused<float>(h, ls, le) : launch_forces_fused<double>(h, ls, le);
         if (rc) return 1;
+        if (launch_finalize(h, le)) return 1;
+    } else if (h->k1_iw != 64 && h->precision == 0 && h->fuse_big) {
+        if (launch_forces_fused_sub(h, ls, le)) return 1;
         if (launch_finalize(h, le)) return 1;
     } else {
         if (launch_alchemical(h, ls, le, 7)) return 1;
@@ -1038,6 +1060,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     HIP_OK(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ1, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ2, hipEventDisableTiming));
     if (const char* g = getenv("BLUES_GRAPH")) h->use_graph = atoi(g) != 0;
     if (const char* g = getenv("BLUES_FAST_STEP")) h->fast_step = atoi(g) != 0;
+    if (const char* g = getenv("BLUES_FUSE_BIG")) h->fuse_big = atoi(g) != 0;
     if (const char* g = getenv("BLUES_GRAPH_UNITS")) h->graph_units = std::max(1, atoi(g));
     if (const char* g = getenv("BLUES_GRAPH_FORK")) h->graph_fork = atoi(g) != 0;
     try {

@@ -809,3 +809,14 @@ __global__ void __launch_bounds__(256) k_step_md(IntArgs A) {
     if (bad) A.flags->nan_flag = 1;
     if (!ok) A.flags->constraint_fail = 1;
 }
+
+// the same role dispatch around the sub-tile throughput kernel (large i-sets): the alchemical and bonded blocks are
+// queued behind the nonbonded ones and fill CUs as those drain, instead of costing two more launches
+template <int IW>
+__global__ void __launch_bounds__(256) k_forces_fused_sub(NbArgs<float> a, NbConst<float> c, const AtomF* __restrict__ img,
+                                                          AlchArgs A, BondedArgs B, int nb1, int nb2) {
+    const int b = blockIdx.x;
+    if (b < nb2) { alchemical_body(A, b); return; }             // the longest-latency blocks first
+    if (b < nb2 + nb1) { nonbonded_sub_body<false, IW>(a, c, img, b - nb2); return; }
+    bonded_entries_body(B, b - nb1 - nb2, 256);
+}
