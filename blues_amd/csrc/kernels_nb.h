@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(WPB * 64) k_nonbonded(NbArgs<R> a, NbConst<R> 
 // consecutive (Hilbert-sorted) j-atoms many wave-iterations have no pair in range and are skipped by the exec-mask
 // branch.  j-batches are staged in a wave-private, bank-conflict-free LDS image ({x,y,z,q} 16 B + {hs,se} 8 B).
 template <bool ENERGY, int IW>
-__global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<float> c, const AtomF* __restrict__ img) {
+__device__ __forceinline__ void nonbonded_sub_body(const NbArgs<float>& a, const NbConst<float>& c, const AtomF* __restrict__ img, const int block_id) {
     constexpr int JL = 64 / IW, SUBS = 64 / IW;
     struct P4 { uint32_t x, y, z; float q; };
     struct P2 { float hs, se; };
@@ -299,9 +299,9 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<
     __shared__ P2 lq[4][64];
     __shared__ uint32_t lf[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.flags->list_gen = a.flags->req_gen;
+    if (block_id == 0 && threadIdx.x == 0) a.flags->list_gen = a.flags->req_gen;
     const int NC = a.waves_tile;
-    const int W = blockIdx.x * 4 + wv;
+    const int W = block_id * 4 + wv;
     const int t = W / (SUBS * NC);
     if (t >= a.n_itiles) return;  // wave-uniform
     const int rem = W - t * SUBS * NC, sub = rem / NC, ch = rem - sub * NC;
@@ -366,6 +366,11 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<
         elj = wave_sum(elj); ecl = wave_sum(ecl);
         if (lane == 0) { a.epart[2 * W] = elj; a.epart[2 * W + 1] = ecl; }
     }
+}
+
+template <bool ENERGY, int IW>
+__global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<float> c, const AtomF* __restrict__ img) {
+    nonbonded_sub_body<ENERGY, IW>(a, c, img, blockIdx.x);
 }
 
 // One-off: LJ + Coulomb energy among FROZEN environment atoms (constant while they and the box

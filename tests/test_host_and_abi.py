@@ -235,3 +235,28 @@ def test_simulation_step_reporters(oracle_backed_context, tol_box):
     # positional form used by reference blues/moves.py:1218
     st = sim.context.getState(True, True, False, True, True, False)
     assert st.getPositions(asNumpy=True)._value.shape == (975, 3) and "lambda_sterics" in st.getParameters()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/blues_engine.h must be consumable from C (the boundary is a C-ABI, not C++): compile a C99 translation
+    unit that uses every entry point's prototype, and link it against the engine library when that exists."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "abi_user.c"
+    calls = "\n".join("    (void)&%s;" % name for name in _abi.ENGINE_SYMBOLS)
+    src.write_text('#include "blues_engine.h"\n#include <stddef.h>\nint main(void) {\n    BluesSystemDesc s; BluesIntegratorDesc i; BluesEngine *h = NULL;\n'
+                   '    (void)s; (void)i; (void)h;\n%s\n    return blues_abi_version() == BLUES_ABI_VERSION ? 0 : 1;\n}\n' % calls)
+    obj = tmp_path / "abi_user.o"
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(obj)])
+    # struct layout agreed between C and the ctypes mirror
+    probe = tmp_path / "sizes.c"
+    probe.write_text('#include "blues_engine.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void) { printf("%zu %zu %zu %zu\\n", sizeof(BluesSystemDesc), sizeof(BluesIntegratorDesc), '
+                     'offsetof(BluesSystemDesc, remove_cm_motion), offsetof(BluesIntegratorDesc, precision)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).split()
+    assert int(out[0]) == ctypes.sizeof(_abi.BluesSystemDesc) and int(out[1]) == ctypes.sizeof(_abi.BluesIntegratorDesc)
+    assert int(out[2]) == _abi.BluesSystemDesc.remove_cm_motion.offset and int(out[3]) == _abi.BluesIntegratorDesc.precision.offset
