@@ -418,3 +418,71 @@ def test_thermostat_and_constraints_long_run(Engine, tol_box):
         assert np.abs(p).max() < 6.0 * np.sqrt(s.mass.sum() * 0.0083144626 * 300.0 * (1.0 - np.exp(-2 * 0.004)))
         assert g.stats()["list_generation"] > 5        # the lists were rebuilt on the device along the way
         g.close()
+
+
+def _driver_run(engine_factory, system, vel, move_factory, nsteps, seed, precision="double", dt=0.002):
+    """One _stepNCMC + Metropolis test through the driver mirror on the given engine; returns the decision record."""
+    from unittest import mock
+    from blues_amd import context, moves, simulation, unit
+    integ = _integ(nsteps, dt=dt, seed=seed)
+    # engine_factory=None -> the shipped HIP engine; otherwise the test double replaces it for the duration of the constructor only
+    with mock.patch.object(context, "NativeEngine", engine_factory or context.NativeEngine):
+        sim = context.Simulation(None, system, integ, precision=precision)
+    sim.context.setVelocities(unit.Quantity(vel, "nanometer/picosecond"))
+    np.random.seed(seed)
+    b = simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": 1}, moves.MoveEngine(move_factory()))
+    b._syncStatesMDtoNCMC()
+    b._stepNCMC(nsteps, nsteps // 2)
+    b._acceptRejectMove()
+    return b.last, b.stateTable["ncmc"]["state1"]["positions"]._value.copy(), b.stateTable["ncmc"]["state1"]["potential_energy"]._value
+
+
+def test_driver_end_to_end_water_move(Engine, tol_box):
+    """configs[3] in miniature: WaterTranslationMove (swap at step 0, sphere translation at lambda = 0.5, radius check at the
+    end), nothing frozen, positional restraints -- the same driver with the same seeds on the HIP engine and on the oracle."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from conftest import OracleBackedEngine
+    from test_moves_configs import water_system
+    from blues_amd import moves
+    w, v, waters = water_system(tol_box)
+    mk = lambda: moves.WaterTranslationMove(waters, np.arange(15), w.mass[:15], radius=0.9)
+
+    class Outside(moves.WaterTranslationMove):
+        """Places the water 10 % beyond the sphere so that afterMove must force the rejection (reference blues/moves.py:1082);
+        in the reference this happens when the water diffuses out during the second half of the protocol."""
+        def _random_sphere_point(self, radius, origin):
+            d = super()._random_sphere_point(radius, origin) - origin
+            return origin + d / np.linalg.norm(d) * radius * 1.1
+    mk_out = lambda: Outside(waters, np.arange(15), w.mass[:15], radius=0.9)
+    # Short protocols that insert onto overlapping waters blow up physically (in OpenMM too); the seeds are ones where they do not.
+    for factory, nsteps, seed in ((mk, 60, 15), (mk_out, 60, 9), (mk_out, 60, 7)):
+        rg, xg, eg = _driver_run(None, w, v, factory, nsteps, seed=seed, dt=0.001)
+        ro, xo, eo = _driver_run(OracleBackedEngine, w, v, factory, nsteps, seed=seed, dt=0.001)
+        assert rg["accept"] == ro["accept"]
+        assert rg["protocol_work"] == pytest.approx(ro["protocol_work"], rel=1e-8, abs=1e-7)
+        assert rg["log_accept"] == pytest.approx(ro["log_accept"], rel=1e-8, abs=1e-7)
+        assert np.abs(xg - xo).max() < 1e-8 and eg == pytest.approx(eo, rel=1e-10)
+        assert (ro["protocol_work"] >= 999999) == (factory is mk_out)
+
+
+def test_driver_end_to_end_rotation_and_torsion(Engine, tol_box):
+    """configs[0]/[4] in miniature: ligand rotation on the fully alchemical toluene, and a methyl torsion move with only the
+    methyl group alchemical (alchemical-environment exceptions active)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from conftest import OracleBackedEngine
+    from blues_amd import moves
+    s, v = tol_box
+    lig = np.arange(15)
+    mk = lambda: moves.RandomLigandRotationMove(lig, s.mass[lig], random_state=8)
+    rg, xg, eg = _driver_run(None, s, v, mk, 12, seed=5)
+    ro, xo, eo = _driver_run(OracleBackedEngine, s, v, mk, 12, seed=5)
+    assert rg["accept"] == ro["accept"] and rg["protocol_work"] == pytest.approx(ro["protocol_work"], rel=1e-8, abs=1e-7)
+    assert np.abs(xg - xo).max() < 1e-8
+    sub = copy.copy(s); sub.alchemical_atoms = np.array([0, 7, 8, 9], np.int32)
+    mk2 = lambda: moves.TorsionRotationMove((1, 0), [7, 8, 9], random_state=9)
+    rg, xg, eg = _driver_run(None, sub, v, mk2, 12, seed=6)
+    ro, xo, eo = _driver_run(OracleBackedEngine, sub, v, mk2, 12, seed=6)
+    assert rg["accept"] == ro["accept"] and rg["protocol_work"] == pytest.approx(ro["protocol_work"], rel=1e-8, abs=1e-7)
+    assert np.abs(xg - xo).max() < 1e-8 and eg == pytest.approx(eo, rel=1e-10)
