@@ -222,6 +222,14 @@ def declare_engine_prototypes(lib):
         "blues_reset": ([H], C.c_int),
         "blues_get_stats": ([H, C.POINTER(C.c_int64)], C.c_int),
         "blues_time_nonbonded": ([H, C.c_int32, _dp], C.c_int),
+        "blues_batch_create": ([C.POINTER(H), C.c_int32, C.POINTER(H)], C.c_int),
+        "blues_batch_destroy": ([H], C.c_int),
+        "blues_batch_last_error": ([H], C.c_char_p),
+        "blues_batch_size": ([H], C.c_int),
+        "blues_batch_step": ([H, C.c_int32, _dp, C.POINTER(C.c_int32)], C.c_int),
+        "blues_batch_set_active": ([H, C.POINTER(C.c_int32)], C.c_int),
+        "blues_batch_get_stats": ([H, C.POINTER(C.c_int64)], C.c_int),
+        "blues_batch_time_nonbonded": ([H, C.c_int32, _dp], C.c_int),
     }
     for name, (args, res) in protos.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
@@ -236,4 +244,6 @@ ENGINE_SYMBOLS = (
     "blues_get_velocities", "blues_get_forces", "blues_get_box", "blues_set_velocities_to_temperature",
     "blues_get_energy", "blues_get_energy_terms", "blues_step", "blues_run_switch", "blues_get_global",
     "blues_set_global", "blues_reset", "blues_get_stats", "blues_time_nonbonded",
+    "blues_batch_create", "blues_batch_destroy", "blues_batch_last_error", "blues_batch_size", "blues_batch_step", "blues_batch_set_active",
+    "blues_batch_get_stats", "blues_batch_time_nonbonded",
 )

@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libblues_hip.so")
-SOURCES = ["blues_engine.hip", "device_common.h", "kernels_nb.h", "kernels_alch.h", "kernels_bonded.h", "kernels_integrate.h"]
+SOURCES = ["blues_engine.hip", "device_common.h", "kernels_nb.h", "kernels_alch.h", "kernels_bonded.h", "kernels_integrate.h", "kernels_batch.h"]
 
 
 def hipcc_path():

@@ -149,22 +149,30 @@ class Simulation(object):
     def minimizeEnergy(self, tolerance=None, maxIterations=0):
         raise NotImplementedError("energy minimisation is outside the NCMC switching path (tests only in the reference)")
 
+    def _plan_chunk(self, end):
+        """Steps that can be taken before the next reporter is due (at most up to `end`), and the reporters asked."""
+        chunk = end - self.currentStep
+        due = []
+        for r in self.reporters:
+            nxt = r.describeNextReport(self)
+            due.append((r, nxt))
+            if 0 < nxt[0] < chunk:
+                chunk = nxt[0]
+        return chunk, due
+
+    def _commit_chunk(self, chunk, due):
+        self.currentStep += chunk
+        self.context._time += chunk * self.integrator._timestep
+        for r, nxt in due:
+            if nxt[0] == chunk:
+                st = self.context.getState(getPositions=bool(nxt[1]), getVelocities=bool(nxt[2]), getForces=bool(nxt[3]),
+                                           getEnergy=bool(nxt[4]), getParameters=True)
+                r.report(self, st)
+
     def step(self, steps):
         """app.Simulation.step (reference blues/simulation.py:1082): advance, honouring reporter intervals."""
         end = self.currentStep + int(steps)
         while self.currentStep < end:
-            chunk = end - self.currentStep
-            due = []
-            for r in self.reporters:
-                nxt = r.describeNextReport(self)
-                due.append((r, nxt))
-                if 0 < nxt[0] < chunk:
-                    chunk = nxt[0]
+            chunk, due = self._plan_chunk(end)
             self.integrator.step(chunk)
-            self.currentStep += chunk
-            self.context._time += chunk * self.integrator._timestep
-            for r, nxt in due:
-                if nxt[0] == chunk:
-                    st = self.context.getState(getPositions=bool(nxt[1]), getVelocities=bool(nxt[2]), getForces=bool(nxt[3]),
-                                               getEnergy=bool(nxt[4]), getParameters=True)
-                    r.report(self, st)
+            self._commit_chunk(chunk, due)

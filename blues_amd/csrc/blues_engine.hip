@@ -28,6 +28,7 @@
 #include "kernels_bonded.h"
 #include "kernels_integrate.h"
 #include "kernels_nb.h"
+#include "kernels_batch.h"
 
 static thread_local std::string g_create_error;
 
@@ -72,9 +73,15 @@ static uint32_t hilbert3(uint32_t x, uint32_t y, uint32_t z, int bits) {
     return key;
 }
 
+struct BluesBatch;
+
 struct BluesEngine {
     std::string err;
     int device = 0;
+    // replica batching (see BluesBatch below): while the batch is in lock step the leader's launches cover every
+    // replica (gridDim.y) and the other members only advance their mirrored control state
+    BluesBatch* batch = nullptr; int batch_index = -1; hipStream_t own_stream = nullptr;
+    uint64_t args_epoch = 1;  // bumped whenever a device buffer referenced by the argument records is (re)allocated
     hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, cur = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr, evJ1 = nullptr, evJ2 = nullptr;
     hipGraphExec_t gexec = nullptr; int graph_units = 16; bool graph_valid = false, use_graph = false, graph_fork = false;
@@ -151,6 +158,27 @@ struct BluesEngine {
 
 #define E_FAIL(h, ...) do { char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__); (h)->err = _b; return 1; } while (0)
 #define HIP_OK(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) { E_FAIL(h, "%s: %s", #call, hipGetErrorString(_e)); } } while (0)
+
+// ------------------------------------------------------------------ replica batch
+// R congruent engines (same topology and protocol; own coordinates, velocities, Philox stream) that share one HIP
+// stream.  In lock step every launch of the stepping path is issued once, by the leader, with gridDim.y = R; the
+// per-replica argument records live in HBM (kernels_batch.h).  A step in which the members' mirrored control states
+// differ (e.g. one replica's move edited positions and another's did not) falls back to per-replica launches.
+struct BluesBatch {
+    std::string err;
+    std::vector<BluesEngine*> eng;
+    std::vector<char> failed;           // per call: members whose host-side stepping raised an error
+    std::vector<char> active, rec_active;  // caller's mask (blues_batch_set_active) / what the device records currently say
+    std::vector<uint64_t> seen_epoch;
+    BluesEngine* leader = nullptr;
+    bool lockstep = false;
+    DBuf<RepNb<float>> d_nb_f; DBuf<RepNb<double>> d_nb_d; DBuf<RepCore> d_core;
+    int64_t st_lockstep_steps = 0, st_fallback_steps = 0;
+    int R() const { return (int)eng.size(); }
+};
+static inline bool batch_dry(const BluesEngine* h) { return h->batch && h->batch->lockstep && h->batch->leader != h; }
+static inline bool batch_lead(const BluesEngine* h) { return h->batch && h->batch->lockstep && h->batch->leader == h; }
+template <typename R> static const RepNb<R>* batch_reps_nb(const BluesBatch* b) { if constexpr (sizeof(R) == 4) return b->d_nb_f.p; else return b->d_nb_d.p; }
 
 static Box3 make_box(const BluesEngine* h) {
     Box3 b; for (int k = 0; k < 3; k++) { b.L[k] = h->box[k]; b.invL[k] = 1.0 / h->box[k]; } return b;
@@ -460,6 +488,7 @@ static int sort_and_tile(BluesEngine* h) {
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     h->hx_sort = h->hx;
     h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->graph_valid = false;
+    h->args_epoch++;
     return 0;
 }
 
@@ -500,17 +529,26 @@ static int flush_program(BluesEngine* h) {
     static const unsigned char P_MD_NC[1] = {OP_L};
     bool has_part = false;
     for (int q = 0; q < h->prog.n; q++) has_part |= h->prog.ops[q] == OP_CM_PART;
-    if (h->fast_step && h->prog.n == 9 && !memcmp(h->prog.ops, P_CM, 9))
-        hipLaunchKernelGGL(k_step_default<true>, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
-    else if (h->fast_step && h->prog.n == 8 && !memcmp(h->prog.ops, P_NC, 8))
-        hipLaunchKernelGGL(k_step_default<false>, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
-    else if (h->fast_step && h->prog.n == 2 && !memcmp(h->prog.ops, P_MD_CM, 2))
-        hipLaunchKernelGGL(k_step_md<true>, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
-    else if (h->fast_step && h->prog.n == 1 && !memcmp(h->prog.ops, P_MD_NC, 1) && h->pass_valid_for_l)
-        hipLaunchKernelGGL(k_step_md<false>, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
-    else {
+    const dim3 grid(h->int_blocks, batch_lead(h) ? h->batch->R() : 1), block(h->int_threads);
+    IntDyn D; D.draw_base = A.draw_base; D.noise_draw_base = A.noise_draw_base; D.n_noise = A.n_noise; D.trace_index = A.trace_index; D.tracing = A.work_trace != nullptr; D.prog = A.prog;
+    const RepCore* reps = h->batch ? h->batch->d_core.p : nullptr;
+    const bool lead = batch_lead(h), dry = batch_dry(h);
+    if (h->fast_step && h->prog.n == 9 && !memcmp(h->prog.ops, P_CM, 9)) {
+        if (lead) hipLaunchKernelGGL(k_step_default_b<true>, grid, block, 0, h->cur, reps, D);
+        else if (!dry) hipLaunchKernelGGL(k_step_default<true>, grid, block, 0, h->cur, A);
+    } else if (h->fast_step && h->prog.n == 8 && !memcmp(h->prog.ops, P_NC, 8)) {
+        if (lead) hipLaunchKernelGGL(k_step_default_b<false>, grid, block, 0, h->cur, reps, D);
+        else if (!dry) hipLaunchKernelGGL(k_step_default<false>, grid, block, 0, h->cur, A);
+    } else if (h->fast_step && h->prog.n == 2 && !memcmp(h->prog.ops, P_MD_CM, 2)) {
+        if (lead) hipLaunchKernelGGL(k_step_md_b<true>, grid, block, 0, h->cur, reps, D);
+        else if (!dry) hipLaunchKernelGGL(k_step_md<true>, grid, block, 0, h->cur, A);
+    } else if (h->fast_step && h->prog.n == 1 && !memcmp(h->prog.ops, P_MD_NC, 1) && h->pass_valid_for_l) {
+        if (lead) hipLaunchKernelGGL(k_step_md_b<false>, grid, block, 0, h->cur, reps, D);
+        else if (!dry) hipLaunchKernelGGL(k_step_md<false>, grid, block, 0, h->cur, A);
+    } else {
         if (has_part) E_FAIL(h, "internal: OP_CM_PART outside a specialised program");
-        hipLaunchKernelGGL(k_integrate, dim3(h->int_blocks), dim3(h->int_threads), 0, h->cur, A);
+        if (lead) hipLaunchKernelGGL(k_integrate_b, grid, block, 0, h->cur, reps, D);
+        else if (!dry) hipLaunchKernelGGL(k_integrate, grid, block, 0, h->cur, A);
     }
     h->vel_clean = false;
     h->st_launches++;
@@ -527,7 +565,7 @@ static int emit(BluesEngine* h, int op) {
     return 0;
 }
 
-template <typename R> static int launch_lists(BluesEngine* h, int force) {
+static ListArgs make_list_args(BluesEngine* h) {
     ListArgs a; memset(&a, 0, sizeof a);
     a.n = h->n; a.n_tiles = h->n_tiles; a.n_itiles = h->n_itiles; a.jcap = h->jcap; a.pool_cap = h->pool_cap;
     a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jstage = h->d_jstage.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p;
@@ -535,10 +573,20 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
     for (int k = 0; k < 3; k++) { a.x[k] = h->d_x[k].p; a.xbuild[k] = h->d_xbuild[k].p; }
     a.fJ = h->d_fJ.p; a.n_fJ = 9 * h->n;
     a.alch_jrec = h->alch.empty() ? nullptr : (void*)h->d_jrec.p; a.p_sigma = h->d_sigma.p; a.p_eps = h->d_eps.p; a.p_charge = h->d_charge.p;
-    if (force) HIP_OK(h, hipMemsetAsync(h->d_pool_count.p, 0, sizeof(int), h->stream));
+    return a;
+}
+
+template <typename R> static int launch_lists(BluesEngine* h, int force) {
+    const ListArgs a = make_list_args(h);
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
-    hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 32), dim3(256), 0, h->cur, a, make_nbconst<R>(h), img, force);
+    if (batch_lead(h)) {
+        if (force) for (int r = 0; r < h->batch->R(); r++) if (!h->batch->failed[r]) HIP_OK(h, hipMemsetAsync(h->batch->eng[r]->d_pool_count.p, 0, sizeof(int), h->cur));
+        hipLaunchKernelGGL(k_build_lists_b<R>, dim3(h->n_tiles + 32, h->batch->R()), dim3(256), 0, h->cur, batch_reps_nb<R>(h->batch), force);
+    } else if (!batch_dry(h)) {
+        if (force) HIP_OK(h, hipMemsetAsync(h->d_pool_count.p, 0, sizeof(int), h->cur));
+        hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 32), dim3(256), 0, h->cur, a, make_nbconst<R>(h), img, force);
+    }
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -546,7 +594,8 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
 
 template <typename R, bool ENERGY, int WPB> static void launch_nb_wpb(BluesEngine* h, const NbArgs<R>& a, const typename Img<R>::Atom* img) {
     const int blocks = std::max(1, h->n_itiles) * (h->waves_tile / WPB);
-    hipLaunchKernelGGL((k_nonbonded<R, ENERGY, WPB>), dim3(blocks), dim3(WPB * 64), 0, h->cur, a, make_nbconst<R>(h), img);
+    if (batch_lead(h)) hipLaunchKernelGGL((k_nonbonded_b<R, ENERGY, WPB>), dim3(blocks, h->batch->R()), dim3(WPB * 64), 0, h->cur, batch_reps_nb<R>(h->batch));
+    else if (!batch_dry(h)) hipLaunchKernelGGL((k_nonbonded<R, ENERGY, WPB>), dim3(blocks), dim3(WPB * 64), 0, h->cur, a, make_nbconst<R>(h), img);
 }
 
 template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
@@ -561,7 +610,15 @@ template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
 template <bool ENERGY> static void launch_nb_sub(BluesEngine* h, const NbArgs<float>& a) {
     const int subs = 64 / h->k1_iw;
     const int waves = std::max(1, h->n_itiles) * subs * h->waves_tile;
-    const dim3 grid((waves + 3) / 4), block(256);
+    const dim3 grid((waves + 3) / 4, batch_lead(h) ? h->batch->R() : 1), block(256);
+    if (batch_dry(h)) return;
+    if (batch_lead(h)) {
+        const RepNb<float>* reps = h->batch->d_nb_f.p;
+        if (h->k1_iw == 8) hipLaunchKernelGGL((k_nonbonded_sub_b<ENERGY, 8>), grid, block, 0, h->cur, reps);
+        else if (h->k1_iw == 16) hipLaunchKernelGGL((k_nonbonded_sub_b<ENERGY, 16>), grid, block, 0, h->cur, reps);
+        else hipLaunchKernelGGL((k_nonbonded_sub_b<ENERGY, 32>), grid, block, 0, h->cur, reps);
+        return;
+    }
     if (h->k1_iw == 8) hipLaunchKernelGGL((k_nonbonded_sub<ENERGY, 8>), grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
     else if (h->k1_iw == 16) hipLaunchKernelGGL((k_nonbonded_sub<ENERGY, 16>), grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
     else hipLaunchKernelGGL((k_nonbonded_sub<ENERGY, 32>), grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
@@ -594,11 +651,13 @@ template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
 }
 
 static AlchArgs make_alch_args(BluesEngine* h, const double ls[3], const double le[3], int slot_mask);
+static AlchDyn make_alch_dyn(const AlchArgs& A) { AlchDyn d; for (int s = 0; s < 3; s++) { d.ls[s] = A.ls[s]; d.le[s] = A.le[s]; } d.slot_mask = A.slot_mask; return d; }
 
 static int launch_alchemical(BluesEngine* h, const double ls[3], const double le[3], int slot_mask) {
     if (h->alch.empty()) return 0;
     AlchArgs A = make_alch_args(h, ls, le, slot_mask);
-    hipLaunchKernelGGL(k_alchemical, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->cur, A);
+    if (batch_lead(h)) hipLaunchKernelGGL(k_alchemical_b, dim3(h->k2_nblocks_env + 1, h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, make_alch_dyn(A));
+    else if (!batch_dry(h)) hipLaunchKernelGGL(k_alchemical, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->cur, A);
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -638,14 +697,16 @@ static int launch_bonded(BluesEngine* h, bool with_noise) {
     const int nb_noise = with_noise ? ((int)h->mobile.size() * h->n_noise + 127) / 128 : 0;
     if (with_noise) { h->noise_draw_base = h->h_draw; h->noise_valid = true; }
     if (B.n_entry_blocks + nb_noise > 0) {
-        hipLaunchKernelGGL(k_bonded_entries, dim3(B.n_entry_blocks + nb_noise), dim3(128), 0, h->cur, B);
+        BondedDyn D; D.draw_base = B.draw_base; D.n_entry_blocks = B.n_entry_blocks;
+        if (batch_lead(h)) hipLaunchKernelGGL(k_bonded_entries_b, dim3(B.n_entry_blocks + nb_noise, h->batch->R()), dim3(128), 0, h->cur, h->batch->d_core.p, D);
+        else if (!batch_dry(h)) hipLaunchKernelGGL(k_bonded_entries, dim3(B.n_entry_blocks + nb_noise), dim3(128), 0, h->cur, B);
         h->st_launches++;
     }
     HIP_OK(h, hipGetLastError());
     return 0;
 }
 
-static int launch_finalize(BluesEngine* h, const double le[3]) {
+static FinArgs make_fin_args(BluesEngine* h, const double le[3]) {
     FinArgs F; memset(&F, 0, sizeof F);
     F.n = h->n; F.n_islots = h->n_islots; F.npart = h->npart; F.n_alch = (int)h->alch.size(); F.PA = h->PA; F.k2_nblocks_env = h->k2_nblocks_env; F.n_entries = h->n_entries;
     F.recs = h->d_finrecs.p; F.orig_of_islot = h->d_orig_of_islot.p; F.row_of_orig = h->d_row_of_orig.p; F.row_start = h->d_row_start.p;
@@ -655,8 +716,15 @@ static int launch_finalize(BluesEngine* h, const double le[3]) {
     F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p; F.ctrl = h->ctrl_arg;
     for (int k = 0; k < 3; k++) F.v[k] = h->d_v[k].p;
     F.mass = h->d_mass.p; F.mom_part = h->d_mom_part.p;
+    return F;
+}
+
+static int launch_finalize(BluesEngine* h, const double le[3]) {
+    FinArgs F = make_fin_args(h, le);
     const int nblk = h->n_islots / 64 + (F.n_alch > 0 ? 1 + 9 * ((F.n_alch + 3) / 4) + 1 : 0);
-    hipLaunchKernelGGL(k_finalize, dim3(std::max(1, nblk)), dim3(256), 0, h->cur, F);
+    FinDyn FD; for (int s = 0; s < 3; s++) FD.le[s] = le[s];
+    if (batch_lead(h)) hipLaunchKernelGGL(k_finalize_b, dim3(std::max(1, nblk), h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, FD);
+    else if (!batch_dry(h)) hipLaunchKernelGGL(k_finalize, dim3(std::max(1, nblk)), dim3(256), 0, h->cur, F);
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -678,7 +746,9 @@ template <typename R> static int launch_forces_fused(BluesEngine* h, const doubl
     const int nb2 = h->alch.empty() ? 0 : h->k2_nblocks_env + 1;
     const int nb3 = B.n_entry_blocks + ((int)h->mobile.size() * h->n_noise + 255) / 256;
     h->noise_draw_base = h->h_draw; h->noise_valid = true;
-    hipLaunchKernelGGL(k_forces_fused<R>, dim3(nb1 + nb2 + nb3), dim3(256), 0, h->cur, a, make_nbconst<R>(h), img, A, B, nb1, nb2);
+    BondedDyn BD; BD.draw_base = B.draw_base; BD.n_entry_blocks = B.n_entry_blocks;
+    if (batch_lead(h)) hipLaunchKernelGGL(k_forces_fused_b<R>, dim3(nb1 + nb2 + nb3, h->batch->R()), dim3(256), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->d_core.p, make_alch_dyn(A), BD, nb1, nb2);
+    else if (!batch_dry(h)) hipLaunchKernelGGL(k_forces_fused<R>, dim3(nb1 + nb2 + nb3), dim3(256), 0, h->cur, a, make_nbconst<R>(h), img, A, B, nb1, nb2);
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -694,10 +764,18 @@ static int launch_forces_fused_sub(BluesEngine* h, const double ls[3], const dou
     const int nb2 = h->alch.empty() ? 0 : h->k2_nblocks_env + 1;
     const int nb3 = B.n_entry_blocks + ((int)h->mobile.size() * h->n_noise + 255) / 256;
     h->noise_draw_base = h->h_draw; h->noise_valid = true;
-    const dim3 grid(nb1 + nb2 + nb3), block(256);
-    if (h->k1_iw == 8) hipLaunchKernelGGL(k_forces_fused_sub<8>, grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p, A, B, nb1, nb2);
-    else if (h->k1_iw == 16) hipLaunchKernelGGL(k_forces_fused_sub<16>, grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p, A, B, nb1, nb2);
-    else hipLaunchKernelGGL(k_forces_fused_sub<32>, grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p, A, B, nb1, nb2);
+    const dim3 grid(nb1 + nb2 + nb3, batch_lead(h) ? h->batch->R() : 1), block(256);
+    if (batch_lead(h)) {
+        BondedDyn BD; BD.draw_base = B.draw_base; BD.n_entry_blocks = B.n_entry_blocks;
+        const AlchDyn AD = make_alch_dyn(A);
+        if (h->k1_iw == 8) hipLaunchKernelGGL(k_forces_fused_sub_b<8>, grid, block, 0, h->cur, h->batch->d_nb_f.p, h->batch->d_core.p, AD, BD, nb1, nb2);
+        else if (h->k1_iw == 16) hipLaunchKernelGGL(k_forces_fused_sub_b<16>, grid, block, 0, h->cur, h->batch->d_nb_f.p, h->batch->d_core.p, AD, BD, nb1, nb2);
+        else hipLaunchKernelGGL(k_forces_fused_sub_b<32>, grid, block, 0, h->cur, h->batch->d_nb_f.p, h->batch->d_core.p, AD, BD, nb1, nb2);
+    } else if (!batch_dry(h)) {
+        if (h->k1_iw == 8) hipLaunchKernelGGL(k_forces_fused_sub<8>, grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p, A, B, nb1, nb2);
+        else if (h->k1_iw == 16) hipLaunchKernelGGL(k_forces_fused_sub<16>, grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p, A, B, nb1, nb2);
+        else hipLaunchKernelGGL(k_forces_fused_sub<32>, grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p, A, B, nb1, nb2);
+    }
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -967,6 +1045,48 @@ static int try_graph_steps(BluesEngine* h, int max_steps) {
 }
 
 // reference blues/integrators.py:159-209
+// One NCMC step = head (everything that may differ between the replicas of a batch: the first-step block and the
+// work of an instantaneous Move, which needs a synchronous total energy) + body (the splitting passes; identical
+// control flow for replicas in the same mirrored state, so a batch issues it once).
+static int step_head(BluesEngine* h) {
+    if (h->h_step == 0) {  // first call after construction / reset
+        if (flush_program(h)) return 1;
+        if (emit(h, OP_PREP)) return 1;
+        if (flush_program(h)) return 1;
+        h->pass_valid = false;
+        HIP_OK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(DevAccum), h->stream));
+        h->h_lambda = 0.0; h->h_lambda_step = 0; h->cur_ls = h->tab_ls[0]; h->cur_le = h->tab_le[0];
+        h->h_perturbed = h->h_unperturbed = 0.0; h->unpert_valid = false;
+    }
+    if (h->h_step < h->nsteps) {
+        if (h->h_first_step < 1) { h->h_first_step = 1; }
+        else if (h->x_edited && h->unpert_valid) {  // work done by an instantaneous Move (integrators.py:184-191)
+            double E;
+            if (total_energy(h, &E)) return 1;
+            h->h_perturbed = E;
+            if (add_work(h, h->h_perturbed - h->h_unperturbed)) return 1;
+        }
+        h->x_edited = false; h->unpert_valid = false;
+    }
+    return 0;
+}
+
+static int step_body(BluesEngine* h) {
+    if (h->h_step < h->nsteps) {
+        if (splitting_pass(h)) return 1;
+        if (h->h_lambda > h->prop_min && h->h_lambda <= h->prop_max)
+            while (h->h_prop < h->nprop) { h->h_prop++; if (splitting_pass(h)) return 1; }
+        if (h->n_H > 0 || h->tracing) {  // END only records the work trace; a plain MD integrator has no protocol work
+            if (h->prog_trace >= 0) { if (flush_program(h)) return 1; }
+            if (emit(h, OP_END)) return 1;
+            h->prog_trace = h->h_step;
+        }
+        h->h_step++; h->h_prop = 1;
+    }
+    return 0;
+}
+
+// reference blues/integrators.py:159-209
 static int do_steps(BluesEngine* h, int nsteps) {
     if (ensure_sorted(h)) return 1;
     for (int s = 0; s < nsteps; s++) {
@@ -975,36 +1095,124 @@ static int do_steps(BluesEngine* h, int nsteps) {
             if (adv < 0) return 1;
             if (adv > 0) { s += adv - 1; continue; }
         }
-        if (h->h_step == 0) {  // first call after construction / reset
-            if (flush_program(h)) return 1;
-            if (emit(h, OP_PREP)) return 1;
-            if (flush_program(h)) return 1;
-            h->pass_valid = false;
-            HIP_OK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(DevAccum), h->stream));
-            h->h_lambda = 0.0; h->h_lambda_step = 0; h->cur_ls = h->tab_ls[0]; h->cur_le = h->tab_le[0];
-            h->h_perturbed = h->h_unperturbed = 0.0; h->unpert_valid = false;
-        }
-        if (h->h_step < h->nsteps) {
-            if (h->h_first_step < 1) { h->h_first_step = 1; }
-            else if (h->x_edited && h->unpert_valid) {  // work done by an instantaneous Move (integrators.py:184-191)
-                double E;
-                if (total_energy(h, &E)) return 1;
-                h->h_perturbed = E;
-                if (add_work(h, h->h_perturbed - h->h_unperturbed)) return 1;
-            }
-            h->x_edited = false; h->unpert_valid = false;
-            if (splitting_pass(h)) return 1;
-            if (h->h_lambda > h->prop_min && h->h_lambda <= h->prop_max)
-                while (h->h_prop < h->nprop) { h->h_prop++; if (splitting_pass(h)) return 1; }
-            if (h->n_H > 0 || h->tracing) {  // END only records the work trace; a plain MD integrator has no protocol work
-                if (h->prog_trace >= 0) { if (flush_program(h)) return 1; }
-                if (emit(h, OP_END)) return 1;
-                h->prog_trace = h->h_step;
-            }
-            h->h_step++; h->h_prop = 1;
-        }
+        if (step_head(h)) return 1;
+        if (step_body(h)) return 1;
     }
     return flush_program(h);
+}
+
+// ------------------------------------------------------------------ replica batch: host side
+// Everything the control flow of step_body / flush_program reads that can change at run time.  Two members with
+// equal signatures issue the same launch sequence with the same launch-to-launch arguments.
+struct BatchSig {
+    int h_step, h_lambda_step, h_prop, h_first_step, pass_L, prog_n, prog_trace, nprop;
+    unsigned h_draw, prog_draw_base, noise_draw_base;
+    unsigned char pass_valid, lists_forced, vel_clean, noise_valid, tracing, sorted_ok, pass_valid_for_l, have_positions;
+    unsigned char ops[MAX_OPS];
+};
+static BatchSig batch_sig(const BluesEngine* h) {
+    BatchSig g; memset(&g, 0, sizeof g);
+    g.h_step = h->h_step; g.h_lambda_step = h->h_lambda_step; g.h_prop = h->h_prop; g.h_first_step = h->h_first_step; g.pass_L = h->pass_valid ? h->pass_L : 0;
+    g.prog_n = h->prog.n; g.prog_trace = h->prog_trace; g.nprop = h->nprop;
+    g.h_draw = h->h_draw; g.prog_draw_base = h->prog.n ? h->prog_draw_base : 0; g.noise_draw_base = h->noise_valid ? h->noise_draw_base : 0;
+    g.pass_valid = h->pass_valid; g.lists_forced = h->lists_forced; g.vel_clean = h->vel_clean; g.noise_valid = h->noise_valid; g.tracing = h->tracing;
+    g.sorted_ok = h->sorted_ok; g.pass_valid_for_l = h->pass_valid_for_l; g.have_positions = h->have_positions;
+    for (int q = 0; q < h->prog.n; q++) g.ops[q] = h->prog.ops[q];
+    return g;
+}
+
+// static shape of a member: launch geometry and protocol.  All members must agree.
+static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const char** why) {
+#define BC(f) if (a->f != b->f) { *why = #f; return false; }
+    BC(device) BC(n) BC(precision) BC(nsteps) BC(nprop) BC(n_lambda) BC(split) BC(remove_cm) BC(dt) BC(gamma) BC(kT) BC(tol) BC(prop_min) BC(prop_max)
+    BC(n_itiles) BC(n_tiles) BC(jcap) BC(n_islots) BC(pool_cap) BC(PA) BC(k2_nblocks_env) BC(seg_len) BC(waves_tile) BC(wpb) BC(npart)
+    BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k1_iw) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
+    BC(cutoff) BC(alpha) BC(sc_alpha) BC(annih_elec) BC(annih_ster) BC(nb_method) BC(restr_k) BC(total_mass)
+    BC(box[0]) BC(box[1]) BC(box[2])
+#undef BC
+    if (a->clusters.size() != b->clusters.size()) { *why = "constraint clusters"; return false; }
+    if (a->mobile != b->mobile) { *why = "mobile atoms"; return false; }
+    if (a->alch != b->alch) { *why = "alchemical atoms"; return false; }
+    if (a->tab_ls != b->tab_ls || a->tab_le != b->tab_le) { *why = "lambda schedule"; return false; }
+    for (int ty = 0; ty < T_NTYPES; ty++) if (a->n_terms[ty] != b->n_terms[ty]) { *why = "bonded terms"; return false; }
+    return true;
+}
+
+static int batch_refresh_args(BluesBatch* B) {
+    bool dirty = false;
+    for (int r = 0; r < B->R(); r++) dirty |= B->seen_epoch[r] != B->eng[r]->args_epoch || B->rec_active[r] != (char)(B->active[r] && !B->failed[r]);
+    if (!dirty) return 0;
+    const double one[3] = {1.0, 1.0, 1.0};
+    std::vector<RepCore> core(B->R()); std::vector<RepNb<float>> nf; std::vector<RepNb<double>> nd;
+    const bool single = B->eng[0]->precision == 0;
+    if (single) nf.resize(B->R()); else nd.resize(B->R());
+    for (int r = 0; r < B->R(); r++) {
+        BluesEngine* h = B->eng[r];
+        B->rec_active[r] = (char)(B->active[r] && !B->failed[r]);
+        core[r].active = B->rec_active[r];
+        if (single) nf[r].active = B->rec_active[r]; else nd[r].active = B->rec_active[r];
+        if (!h->sorted_ok) { core[r].active = 0; if (single) nf[r].active = 0; else nd[r].active = 0; continue; }  // buffers not laid out (its sort failed): never touched
+        core[r].al = make_alch_args(h, one, one, 7); core[r].bo = make_bonded_args(h); core[r].fin = make_fin_args(h, one); core[r].in = make_int_args(h);
+        core[r].in.work_trace = h->d_trace.p;  // the launch decides whether it is written (IntDyn.tracing)
+        core[r].in.n_noise = h->n_noise;
+        if (single) { nf[r].L = make_list_args(h); nf[r].nb = make_nb_args<float>(h); nf[r].c = make_nbconst<float>(h); nf[r].img = h->d_img_f.p; }
+        else { nd[r].L = make_list_args(h); nd[r].nb = make_nb_args<double>(h); nd[r].c = make_nbconst<double>(h); nd[r].img = h->d_img_d.p; }
+        B->seen_epoch[r] = h->args_epoch;
+    }
+    // the records may be in use by launches still in flight
+    if (hipStreamSynchronize(B->leader ? B->leader->stream : B->eng[0]->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
+    try { B->d_core.upload(core); if (single) B->d_nb_f.upload(nf); else B->d_nb_d.upload(nd); } catch (std::string& e) { B->err = e; return 1; }
+    return 0;
+}
+
+// Advances every member by n_steps.  status[r] != 0: member r raised (message via blues_last_error(engine r)); the
+// others are unaffected.  Returns non-zero only for errors of the batch itself (B->err).
+static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status) {
+    const int R = B->R();
+    // failed[r] doubles as "skip this member": inactive members start out skipped (status stays 0)
+    B->failed.assign(R, 0);
+    for (int r = 0; r < R; r++) { status[r] = 0; B->eng[r]->tracing = tracing; if (!B->active[r]) B->failed[r] = 1; }
+    auto fail = [&](int r) { B->failed[r] = 1; status[r] = 1; };
+    for (int r = 0; r < R; r++) if (!B->failed[r] && ensure_sorted(B->eng[r])) fail(r);
+    auto pick_leader = [&]() { B->leader = nullptr; for (int r = 0; r < R; r++) if (!B->failed[r]) { B->leader = B->eng[r]; break; } };
+    pick_leader();
+    if (!B->leader) return 0;
+    for (int r = 0; r < R; r++) if (!B->failed[r]) {
+        const char* why = "";
+        if (!batch_congruent(B->leader, B->eng[r], &why)) { B->err = std::string("replicas of a batch must be congruent; they differ in ") + why; return 1; }
+    }
+    if (batch_refresh_args(B)) return 1;
+    // phase(f): run f on every live member, in lock step when their signatures agree
+    auto phase = [&](int (*f)(BluesEngine*)) {
+        pick_leader();
+        if (!B->leader) return;
+        const BatchSig lead = batch_sig(B->leader);
+        bool uniform = true;
+        for (int r = 0; r < R && uniform; r++) if (!B->failed[r]) { const BatchSig g = batch_sig(B->eng[r]); uniform = !memcmp(&g, &lead, sizeof g); }
+        if (uniform) {
+            B->lockstep = true;
+            for (int r = 0; r < R; r++) if (!B->failed[r] && f(B->eng[r])) {
+                // a host-side failure of the leader leaves the shared launch sequence incomplete: every member is affected
+                if (B->eng[r] == B->leader) { for (int q = 0; q < R; q++) if (!B->failed[q]) { if (q != r) B->eng[q]->err = "batch leader failed: " + B->leader->err; fail(q); } }
+                else fail(r);
+            }
+            B->lockstep = false;
+            B->st_lockstep_steps++;
+        } else {
+            for (int r = 0; r < R; r++) if (!B->failed[r] && f(B->eng[r])) fail(r);
+            B->st_fallback_steps++;
+        }
+    };
+    for (int s = 0; s < n_steps; s++) {
+        for (int r = 0; r < R; r++) if (!B->failed[r] && step_head(B->eng[r])) fail(r);
+        if (batch_refresh_args(B)) return 1;   // a head may have re-sorted (it cannot today; cheap to keep correct)
+        phase(step_body);
+    }
+    phase(flush_program);
+    for (int r = 0; r < R; r++) B->eng[r]->tracing = false;
+    B->leader = B->eng[0];
+    for (int r = 0; r < R; r++) if (!B->failed[r] && check_flags(B->eng[r])) fail(r);
+    return 0;
 }
 
 // ------------------------------------------------------------------ C-ABI
@@ -1094,9 +1302,20 @@ int blues_engine_create(const BluesSystemDesc* s, const BluesIntegratorDesc* it,
     return 0;
 }
 
+static void batch_detach_all(BluesBatch* B) {
+    if (!B) return;
+    for (BluesEngine* m : B->eng) if (m) {
+        hipStreamSynchronize(m->stream);
+        if (m->own_stream) { m->stream = m->own_stream; m->cur = m->own_stream; m->own_stream = nullptr; }
+        m->batch = nullptr; m->batch_index = -1;
+    }
+    B->eng.clear(); B->leader = nullptr; B->lockstep = false;
+}
+
 int blues_engine_destroy(BluesEngine* h) {
     if (!h) return 0;
     hipSetDevice(h->device);
+    if (h->batch) batch_detach_all(h->batch);  // a batch does not outlive any of its members
     hipStreamSynchronize(h->stream);
 #ifdef BLUES_STAMP
     { std::vector<long long> st; h->d_stamps.download(st); fprintf(stderr, "[stamps] last integrate launch, cycles per op:"); for (int i = 1; i < 40 && st[i] > 0; i++) fprintf(stderr, " %lld", st[i] - st[i - 1]); fprintf(stderr, "\n"); }
@@ -1388,6 +1607,97 @@ int blues_time_nonbonded(BluesEngine* h, int32_t reps, double* usec) {
     HIP_OK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *usec = 1000.0 * ms / std::max(1, reps);
     return check_flags(h);
+}
+
+// ---- replica batch (include/blues_engine.h, "Replica batches")
+static thread_local std::string g_batch_create_error;
+
+const char* blues_batch_last_error(const BluesBatch* b) { return b ? b->err.c_str() : g_batch_create_error.c_str(); }
+
+int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** out) {
+    if (count <= 0 || !engines || !out) { g_batch_create_error = "a batch needs at least one engine"; return 2; }
+    for (int r = 0; r < count; r++) {
+        if (!engines[r]) { g_batch_create_error = "null engine handle"; return 2; }
+        if (engines[r]->batch) { g_batch_create_error = "engine already belongs to a batch"; return 2; }
+        if (engines[r]->device != engines[0]->device) { g_batch_create_error = "all engines of a batch must live on the same device"; return 2; }
+        for (int q = 0; q < r; q++) if (engines[q] == engines[r]) { g_batch_create_error = "duplicate engine handle"; return 2; }
+    }
+    BluesBatch* B = new BluesBatch();
+    hipSetDevice(engines[0]->device);
+    for (int r = 0; r < count; r++) {
+        BluesEngine* m = engines[r];
+        if (flush_program(m) || hipStreamSynchronize(m->stream) != hipSuccess) { g_batch_create_error = "could not drain engine stream: " + m->err; batch_detach_all(B); delete B; return 1; }
+        B->eng.push_back(m); m->batch = B; m->batch_index = r;
+        if (r > 0) { m->own_stream = m->stream; m->stream = engines[0]->stream; m->cur = m->stream; }
+        m->use_graph = false;  // graph replays carry per-engine frozen arguments
+    }
+    B->seen_epoch.assign(count, 0); B->failed.assign(count, 0); B->active.assign(count, 1); B->rec_active.assign(count, 0); B->leader = engines[0];
+    *out = B;
+    return 0;
+}
+
+int blues_batch_destroy(BluesBatch* b) {
+    if (!b) return 0;
+    if (!b->eng.empty()) hipSetDevice(b->eng[0]->device);
+    batch_detach_all(b);
+    delete b;
+    return 0;
+}
+
+int blues_batch_size(const BluesBatch* b) { return b ? b->R() : 0; }
+
+int blues_batch_set_active(BluesBatch* b, const int32_t* mask) {
+    if (!b || b->eng.empty()) return 2;
+    for (int r = 0; r < b->R(); r++) b->active[r] = mask ? (mask[r] != 0) : 1;
+    return 0;
+}
+
+int blues_batch_step(BluesBatch* b, int32_t n_steps, double* work_trace, int32_t* status) {
+    if (!b || b->eng.empty()) { if (b) b->err = "the batch has been dissolved (one of its engines was destroyed)"; return 2; }
+    if (hipSetDevice(b->eng[0]->device) != hipSuccess) { b->err = "hipSetDevice failed"; return 1; }
+    const int R = b->R();
+    std::vector<int> st(R, 0), first(R, 0);
+    for (int r = 0; r < R; r++) first[r] = b->eng[r]->h_step;
+    const int rc = batch_do_steps(b, n_steps, work_trace != nullptr, st.data());
+    if (status) for (int r = 0; r < R; r++) status[r] = st[r];
+    if (rc) return rc;
+    if (work_trace) for (int r = 0; r < R; r++) {
+        BluesEngine* h = b->eng[r];
+        double* wt = work_trace + (size_t)r * n_steps;
+        const int done = st[r] ? 0 : h->h_step - first[r];
+        if (done > 0 && hipMemcpy(wt, h->d_trace.p + first[r], sizeof(double) * done, hipMemcpyDeviceToHost) != hipSuccess) { b->err = "work trace download failed"; return 1; }
+        for (int i = std::max(done, 0); i < n_steps; i++) wt[i] = done > 0 ? wt[done - 1] : 0.0;
+    }
+    return 0;
+}
+
+int blues_batch_get_stats(BluesBatch* b, int64_t stats[4]) {
+    stats[0] = b->st_lockstep_steps; stats[1] = b->st_fallback_steps; stats[2] = b->R(); stats[3] = 0;
+    return 0;
+}
+
+// average duration of one batched nonbonded launch (all replicas), HIP events on the batch's stream
+int blues_batch_time_nonbonded(BluesBatch* b, int32_t reps, double* usec) {
+    if (!b || b->eng.empty()) return 2;
+    BluesEngine* h = b->eng[0];
+    if (hipSetDevice(h->device) != hipSuccess) { b->err = "hipSetDevice failed"; return 1; }
+    for (BluesEngine* m : b->eng) { if (flush_program(m) || ensure_sorted(m)) { b->err = m->err; return 1; } m->pass_valid = false; }
+    b->failed.assign(b->R(), 0); b->active.assign(b->R(), 1);
+    if (batch_refresh_args(b)) return 1;
+    b->leader = h; b->lockstep = true;
+    int rc = h->precision == 0 ? launch_lists<float>(h, 1) : launch_lists<double>(h, 1);
+    for (int w = 0; w < 3 && !rc; w++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
+    if (!rc && hipEventRecord(h->ev0, h->stream) != hipSuccess) rc = 1;
+    for (int r = 0; r < reps && !rc; r++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
+    if (!rc && hipEventRecord(h->ev1, h->stream) != hipSuccess) rc = 1;
+    b->lockstep = false;
+    for (BluesEngine* m : b->eng) m->lists_forced = false;
+    if (rc || hipEventSynchronize(h->ev1) != hipSuccess) { b->err = "timing launch failed: " + h->err; return 1; }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    *usec = 1000.0 * ms / std::max(1, reps);
+    for (BluesEngine* m : b->eng) if (check_flags(m)) { b->err = m->err; return 1; }
+    return 0;
 }
 
 }  // extern "C"

@@ -1,0 +1,138 @@
+// kernels_batch.h -- replica-batched launches: one launch advances R independent NCMC replicas.
+//
+// One replica of the flagship system is ~1 MB of state and a few hundred mobile atoms: every kernel of
+// its step is latency-bound and occupies a few percent of the MI355X's 256 CUs.  Independent BLUES chains
+// (the path shards by replica) therefore share launches: gridDim.y = number of replicas,
+// blockIdx.y selects the replica's argument record from an array in HBM, blockIdx.x keeps its meaning
+// inside the replica.  The bodies are the very device functions the single-replica kernels run, so a
+// batched replica is bitwise identical to the same replica advanced alone.
+//
+// Replicas of one batch advance in lock step (same step program, same lambda index, same draw counter),
+// so everything that changes from launch to launch is common to the batch and travels as ordinary
+// kernel arguments (the *Dyn structs); everything that differs between replicas (buffers, Philox stream)
+// is static and lives in the per-replica records, refreshed only when a replica re-sorts its atoms.
+#pragma once
+#include "kernels_integrate.h"
+
+template <typename R> struct RepNb {   // precision-dependent part of a replica's argument record
+    int active;   // 0: the member sits this launch out (its blocks return at once)
+    ListArgs L; NbArgs<R> nb; NbConst<R> c; const typename Img<R>::Atom* img;
+};
+struct RepCore {
+    int active;
+    AlchArgs al; BondedArgs bo; FinArgs fin; IntArgs in;
+};
+
+struct AlchDyn { double ls[3], le[3]; int slot_mask; };
+struct BondedDyn { unsigned draw_base; int n_entry_blocks; };
+struct FinDyn { double le[3]; };
+struct IntDyn { unsigned draw_base, noise_draw_base; int n_noise, trace_index, tracing; Program prog; };
+
+__device__ __forceinline__ void apply_dyn(AlchArgs& A, const AlchDyn& d) {
+#pragma unroll
+    for (int s = 0; s < 3; s++) { A.ls[s] = d.ls[s]; A.le[s] = d.le[s]; }
+    A.slot_mask = d.slot_mask; A.ctrl = nullptr;
+}
+__device__ __forceinline__ void apply_dyn(BondedArgs& B, const BondedDyn& d) { B.draw_base = d.draw_base; B.n_entry_blocks = d.n_entry_blocks; B.ctrl = nullptr; }
+__device__ __forceinline__ void apply_dyn(FinArgs& F, const FinDyn& d) {
+#pragma unroll
+    for (int s = 0; s < 3; s++) F.le[s] = d.le[s];
+    F.ctrl = nullptr;
+}
+__device__ __forceinline__ void apply_dyn(IntArgs& A, const IntDyn& d) {
+    A.draw_base = d.draw_base; A.noise_draw_base = d.noise_draw_base; A.n_noise = d.n_noise; A.trace_index = d.trace_index;
+    if (!d.tracing) A.work_trace = nullptr;
+    A.ctrl = nullptr;
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) k_build_lists_b(const RepNb<R>* __restrict__ reps, int force) {
+    const RepNb<R>& rp = reps[blockIdx.y];
+    if (!rp.active) return;
+    const ListArgs a = rp.L; const NbConst<R> c = rp.c;
+    build_lists_body<R>(a, c, rp.img, force);
+}
+
+template <typename R, bool ENERGY, int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_nonbonded_b(const RepNb<R>* __restrict__ reps) {
+    const RepNb<R>& rp = reps[blockIdx.y];
+    if (!rp.active) return;
+    const NbArgs<R> a = rp.nb; const NbConst<R> c = rp.c;
+    nonbonded_body<R, ENERGY, WPB>(a, c, rp.img, blockIdx.x);
+}
+
+template <bool ENERGY, int IW>
+__global__ void __launch_bounds__(256) k_nonbonded_sub_b(const RepNb<float>* __restrict__ reps) {
+    const RepNb<float>& rp = reps[blockIdx.y];
+    if (!rp.active) return;
+    const NbArgs<float> a = rp.nb; const NbConst<float> c = rp.c;
+    nonbonded_sub_body<ENERGY, IW>(a, c, rp.img, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(256) k_alchemical_b(const RepCore* __restrict__ reps, AlchDyn d) {
+    if (!reps[blockIdx.y].active) return;
+    AlchArgs A = reps[blockIdx.y].al; apply_dyn(A, d);
+    alchemical_body(A, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(128) k_bonded_entries_b(const RepCore* __restrict__ reps, BondedDyn d) {
+    if (!reps[blockIdx.y].active) return;
+    BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, d);
+    bonded_entries_body(B, blockIdx.x, 128);
+}
+
+__global__ void __launch_bounds__(256) k_finalize_b(const RepCore* __restrict__ reps, FinDyn d) {
+    if (!reps[blockIdx.y].active) return;
+    FinArgs F = reps[blockIdx.y].fin; apply_dyn(F, d);
+    finalize_body(F);
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) k_forces_fused_b(const RepNb<R>* __restrict__ rnb, const RepCore* __restrict__ reps, AlchDyn da, BondedDyn db, int nb1, int nb2) {
+    if (!reps[blockIdx.y].active) return;
+    const int b = blockIdx.x;
+    if (b < nb1) {
+        const RepNb<R>& rp = rnb[blockIdx.y];
+        const NbArgs<R> a = rp.nb; const NbConst<R> c = rp.c;
+        nonbonded_body<R, false, 4>(a, c, rp.img, b);
+        return;
+    }
+    if (b < nb1 + nb2) { AlchArgs A = reps[blockIdx.y].al; apply_dyn(A, da); alchemical_body(A, b - nb1); return; }
+    BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, db);
+    bonded_entries_body(B, b - nb1 - nb2, 256);
+}
+
+template <int IW>
+__global__ void __launch_bounds__(256) k_forces_fused_sub_b(const RepNb<float>* __restrict__ rnb, const RepCore* __restrict__ reps, AlchDyn da, BondedDyn db, int nb1, int nb2) {
+    if (!reps[blockIdx.y].active) return;
+    const int b = blockIdx.x;
+    if (b < nb2) { AlchArgs A = reps[blockIdx.y].al; apply_dyn(A, da); alchemical_body(A, b); return; }
+    if (b < nb2 + nb1) {
+        const RepNb<float>& rp = rnb[blockIdx.y];
+        const NbArgs<float> a = rp.nb; const NbConst<float> c = rp.c;
+        nonbonded_sub_body<false, IW>(a, c, rp.img, b - nb2);
+        return;
+    }
+    BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, db);
+    bonded_entries_body(B, b - nb1 - nb2, 256);
+}
+
+__global__ void __launch_bounds__(256) k_integrate_b(const RepCore* __restrict__ reps, IntDyn d) {
+    if (!reps[blockIdx.y].active) return;
+    IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d);
+    integrate_body(A, d.prog);
+}
+
+template <bool CM>
+__global__ void __launch_bounds__(256) k_step_default_b(const RepCore* __restrict__ reps, IntDyn d) {
+    if (!reps[blockIdx.y].active) return;
+    IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d);
+    step_default_body<CM>(A);
+}
+
+template <bool CM>
+__global__ void __launch_bounds__(256) k_step_md_b(const RepCore* __restrict__ reps, IntDyn d) {
+    if (!reps[blockIdx.y].active) return;
+    IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d);
+    step_md_body<CM>(A);
+}

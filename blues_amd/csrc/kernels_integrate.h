@@ -247,7 +247,7 @@ struct FinArgs {
 //       then 9 blocks (one per slot x component) for the alchemical self-force slabs | 1 block for the energies.
 // Every sum is spread over the 4 waves of a block with 4 loads in flight per lane, then combined in LDS in a
 // fixed order (deterministic, and no chain of dependent global loads).
-__global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
+__device__ __forceinline__ void finalize_body(FinArgs& A) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (A.ctrl) {
         const int L = A.ctrl->L0 + 2 * A.ctrl->kpass;
@@ -357,7 +357,11 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs A) {
     if (tid < 6) A.mom_part[(size_t)(n_itiles + 1) * 6 + tid] = tid < 3 ? 0.0 : s_e[K2_NE + tid - 3];  // alchemical pair force on the alchemical atoms
 }
 
-__global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
+__global__ void __launch_bounds__(256) k_finalize(FinArgs A) { finalize_body(A); }
+
+// `prog` is passed beside A so that the batched launch (kernels_batch.h) can hand over the shared program from its own
+// kernel arguments while A is a per-replica copy
+__device__ __forceinline__ void integrate_body(IntArgs& A, const Program& prog) {
     const int tid = threadIdx.x;
     if (A.ctrl) {
         const int u = A.ctrl->kint;
@@ -393,8 +397,8 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) {
 #ifdef BLUES_STAMP
     if (cl == 0 && A.stamps) A.stamps[0] = clock64();
 #endif
-    for (int op_i = 0; op_i < A.prog.n; op_i++) {
-        const int op = A.prog.ops[op_i];
+    for (int op_i = 0; op_i < prog.n; op_i++) {
+        const int op = prog.ops[op_i];
 #ifdef BLUES_STAMP
         if (cl == 0 && A.stamps) A.stamps[1 + op_i] = clock64();
 #endif
@@ -529,7 +533,7 @@ _Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 
     }
 
 #ifdef BLUES_STAMP
-    if (cl == 0 && A.stamps) A.stamps[1 + A.prog.n] = clock64();
+    if (cl == 0 && A.stamps) A.stamps[1 + prog.n] = clock64();
 #endif
     if (!active) return;
     // ---- write back, refresh the fixed-point image, check list validity
@@ -551,11 +555,13 @@ _Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 
     }
     if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; *A.pool_count = 0; }
 #ifdef BLUES_STAMP
-    if (cl == 0 && A.stamps) A.stamps[2 + A.prog.n] = clock64();
+    if (cl == 0 && A.stamps) A.stamps[2 + prog.n] = clock64();
 #endif
     if (bad) A.flags->nan_flag = 1;
     if (!ok) A.flags->constraint_fail = 1;
 }
+
+__global__ void __launch_bounds__(256) k_integrate(IntArgs A) { integrate_body(A, A.prog); }
 
 // kinetic energy: per-block partials of sum 0.5 m v^2 over mobile atoms
 __global__ void __launch_bounds__(256) k_kinetic(int n, const double* __restrict__ mass, const double* vx, const double* vy, const double* vz, double* part) {
@@ -607,7 +613,7 @@ __global__ void __launch_bounds__(256) k_forces_fused(NbArgs<R> a, NbConst<R> c,
 // dispatch the compiler sees one basic-block chain: every gather is issued at the top and waited for once, which is
 // what this latency-bound kernel needs (the interpreter spent >65 % of its wave cycles in s_waitcnt).
 template <bool CM>
-__global__ void __launch_bounds__(256) k_step_default(IntArgs A) {
+__device__ __forceinline__ void step_default_body(IntArgs& A) {
     const int tid = threadIdx.x;
     const int cl = blockIdx.x * blockDim.x + tid;
     if (A.ctrl) {
@@ -731,9 +737,12 @@ __global__ void __launch_bounds__(256) k_step_default(IntArgs A) {
     }
 }
 
+template <bool CM>
+__global__ void __launch_bounds__(256) k_step_default(IntArgs A) { step_default_body<CM>(A); }
+
 // ---- straight-line specialisation of one MD-leg step: [CM] L   (OpenMM LangevinIntegrator)
 template <bool CM>
-__global__ void __launch_bounds__(256) k_step_md(IntArgs A) {
+__device__ __forceinline__ void step_md_body(IntArgs& A) {
     const int tid = threadIdx.x;
     const int cl = blockIdx.x * blockDim.x + tid;
     __shared__ double s_red[4][4];
@@ -809,6 +818,9 @@ __global__ void __launch_bounds__(256) k_step_md(IntArgs A) {
     if (bad) A.flags->nan_flag = 1;
     if (!ok) A.flags->constraint_fail = 1;
 }
+
+template <bool CM>
+__global__ void __launch_bounds__(256) k_step_md(IntArgs A) { step_md_body<CM>(A); }
 
 // the same role dispatch around the sub-tile throughput kernel (large i-sets): the alchemical and bonded blocks are
 // queued behind the nonbonded ones and fill CUs as those drain, instead of costing two more launches

@@ -53,7 +53,7 @@ struct ListArgs {
 };
 
 template <typename R>
-__global__ void __launch_bounds__(256) k_build_lists(ListArgs a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, int force) {
+__device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force) {
     using sfix = typename Img<R>::sfix;
     using ufix = typename Img<R>::ufix;
     if (!force && a.flags->list_gen == a.flags->req_gen) return;
@@ -193,6 +193,11 @@ __global__ void __launch_bounds__(256) k_build_lists(ListArgs a, NbConst<R> c, c
             __syncthreads();
         }
     }
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) k_build_lists(ListArgs a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, int force) {
+    build_lists_body<R>(a, c, img, force);
 }
 
 template <typename R> struct NbArgs {

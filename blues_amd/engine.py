@@ -109,3 +109,63 @@ class NativeEngine:
 
     def time_nonbonded(self, reps=20):
         u = C.c_double(); self._check(self._lib.blues_time_nonbonded(self._h, int(reps), C.byref(u))); return u.value
+
+
+class NativeBatch:
+    """Replica batch (include/blues_engine.h, "Replica batches"): congruent engines on one GPU whose integrator steps
+    share every kernel launch.  Each engine keeps its own interface; only stepping goes through here."""
+
+    def __init__(self, engines):
+        self._lib = load()
+        self.engines = list(engines)
+        arr = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+        h = C.c_void_p()
+        rc = self._lib.blues_batch_create(arr, len(self.engines), C.byref(h))
+        if rc:
+            raise EngineError(self._lib.blues_batch_last_error(None).decode())
+        self._h = h
+
+    def __len__(self):
+        return len(self.engines)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.blues_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, n=1, trace=False, raise_errors=True, active=None):
+        """integrator.step(n) on every member (or on those with active[r] true; the others are left untouched).  Returns
+        (errors, traces): errors[r] is None or the EngineError member r raised; with raise_errors the first one is
+        raised instead (single-replica behaviour)."""
+        R = len(self.engines)
+        mask = (C.c_int32 * R)(*[1 if (active is None or active[r]) else 0 for r in range(R)])
+        if self._lib.blues_batch_set_active(self._h, mask):
+            raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
+        status = (C.c_int32 * R)()
+        w = np.zeros((R, int(n))) if trace else None
+        rc = self._lib.blues_batch_step(self._h, int(n), w.ctypes.data_as(_dp) if trace else None, status)
+        if rc:
+            raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
+        errors = [EngineError(self._lib.blues_last_error(e._h).decode()) if status[r] else None for r, e in enumerate(self.engines)]
+        if raise_errors:
+            for err in errors:
+                if err is not None:
+                    raise err
+        return errors, w
+
+    def stats(self):
+        s = (C.c_int64 * 4)()
+        self._lib.blues_batch_get_stats(self._h, s)
+        return {"lockstep_steps": s[0], "fallback_steps": s[1], "replicas": s[2]}
+
+    def time_nonbonded(self, reps=20):
+        u = C.c_double()
+        if self._lib.blues_batch_time_nonbonded(self._h, int(reps), C.byref(u)):
+            raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
+        return u.value

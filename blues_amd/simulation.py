@@ -95,7 +95,10 @@ class BLUESSimulation(object):
         return e
 
     # ---- reference blues/simulation.py:1039-1098
-    def _stepNCMC(self, nstepsNC, moveStep, move_engine=None):
+    def _ncmc_plan(self, nstepsNC, moveStep, move_engine=None):
+        """The body of _stepNCMC as a generator: runs the hooks and YIELDS the number of integrator steps to take next;
+        whoever drives it advances the NCMC simulation by that many steps (alone: _stepNCMC below; for several replicas
+        sharing launches: BatchedBLUESSimulation) and throws a stepping error back in, where the reference's policy applies."""
         logger.info('Advancing %i NCMC switching steps...' % (nstepsNC))
         ncmc_state0 = self.getStateFromContext(self._ncmc_sim.context, self._state_keys)
         self._setStateTable('ncmc', 'state0', ncmc_state0)
@@ -115,7 +118,7 @@ class BLUESSimulation(object):
                     logger.info('Performing %s...' % move_engine.move_name)
                     self._ncmc_sim.context = move_engine.runEngine(self._ncmc_sim.context)
                 if b > a:
-                    self._ncmc_sim.step(b - a)
+                    yield b - a
                 if b == nstepsNC:
                     self._ncmc_sim.context = move_engine.selected_move.afterMove(self._ncmc_sim.context)
         except Exception as e:  # reference policy: log, let the move clean up, abandon the switch
@@ -125,6 +128,20 @@ class BLUESSimulation(object):
             move_engine.selected_move._error(self._ncmc_sim.context)
         ncmc_state1 = self.getStateFromContext(self._ncmc_sim.context, self._state_keys)
         self._setStateTable('ncmc', 'state1', ncmc_state1)
+
+    def _stepNCMC(self, nstepsNC, moveStep, move_engine=None):
+        plan = self._ncmc_plan(nstepsNC, moveStep, move_engine)
+        try:
+            n = next(plan)
+            while True:
+                try:
+                    self._ncmc_sim.step(n)
+                except Exception as e:
+                    n = plan.throw(e)
+                else:
+                    n = plan.send(None)
+        except StopIteration:
+            pass
 
     # ---- reference blues/simulation.py:1100-1119
     def _computeAlchemicalCorrection(self):
@@ -213,3 +230,100 @@ class BLUESSimulation(object):
         self.acceptRatio = self.accept / float(nIter)
         logger.info('Acceptance Ratio: %s' % self.acceptRatio)
         logger.info('nIter: %s ' % nIter)
+
+
+class BatchedBLUESSimulation(object):
+    """R independent BLUES chains on ONE GPU advanced in lock step (DESIGN.md "Replica batches").
+
+    Every chain is an ordinary BLUESSimulation (own SimulationSet, MoveEngine, state table, acceptance counters) --
+    exactly what R separate reference processes would hold.  The only thing shared is the integrator stepping: the
+    NCMC engines form one native batch (and the MD engines another), so `step(n)` is one kernel launch sequence for all
+    chains.  Hooks, state exchange and the Metropolis test run per chain, in chain order."""
+
+    def __init__(self, chains):
+        from .engine import NativeBatch
+        self.chains = list(chains)
+        if not self.chains:
+            raise ValueError("no chains")
+        self._ncmc_batch = NativeBatch([c._ncmc_sim.context._engine for c in self.chains])
+        self._md_batch = None
+        if all(c._md_sim is not None for c in self.chains):
+            self._md_batch = NativeBatch([c._md_sim.context._engine for c in self.chains])
+        elif any(c._md_sim is not None for c in self.chains):
+            raise ValueError("either every chain has an MD simulation or none has")
+
+    def close(self):
+        for b in (self._ncmc_batch, self._md_batch):
+            if b is not None:
+                b.close()
+
+    @staticmethod
+    def _advance(batch, sims, wanted):
+        """Advance sims[r] by wanted[r] steps (missing key: the member sits this one out).  Returns {r: error}."""
+        errors = {}
+        left = dict(wanted)
+        while left:
+            plans = {r: sims[r]._plan_chunk(sims[r].currentStep + left[r]) for r in left}
+            n = min(p[0] for p in plans.values())
+            errs, _ = batch.step(n, active=[r in left for r in range(len(sims))], raise_errors=False)
+            for r in list(left):
+                if errs[r] is not None:
+                    errors[r] = errs[r]
+                    del left[r]
+                    continue
+                sims[r]._commit_chunk(n, plans[r][1])
+                left[r] -= n
+                if left[r] <= 0:
+                    del left[r]
+        return errors
+
+    def _stepNCMC(self, nstepsNC, moveStep):
+        sims = [c._ncmc_sim for c in self.chains]
+        plans, wanted = {}, {}
+        for r, c in enumerate(self.chains):
+            plans[r] = c._ncmc_plan(nstepsNC, moveStep)
+            try:
+                wanted[r] = next(plans[r])
+            except StopIteration:
+                pass
+        while wanted:
+            errors = self._advance(self._ncmc_batch, sims, wanted)
+            nxt = {}
+            for r in wanted:
+                try:
+                    nxt[r] = plans[r].throw(errors[r]) if r in errors else plans[r].send(None)
+                except StopIteration:
+                    pass
+            wanted = nxt
+
+    def _stepMD(self, nstepsMD):
+        if self._md_batch is None or not nstepsMD:
+            return
+        sims = [c._md_sim for c in self.chains]
+        for r, c in enumerate(self.chains):
+            sims[r].currentIter = c.currentIter
+        errors = self._advance(self._md_batch, sims, {r: int(nstepsMD) for r in range(len(sims))})
+        for r, e in errors.items():  # reference blues/simulation.py:1207-1213: an MD failure is fatal
+            logger.error(e, exc_info=True)
+            sys.exit(1)
+
+    def run(self, nIter=0, nstepsNC=0, moveStep=0, nstepsMD=0, temperature=300, write_move=False, on_iteration=None, **config):
+        cfg = self.chains[0]._config
+        if not nIter: nIter = cfg['nIter']
+        if not nstepsNC: nstepsNC = cfg['nstepsNC']
+        if not nstepsMD: nstepsMD = cfg.get('nstepsMD', 0)
+        if not moveStep: moveStep = cfg['moveStep']
+        for N in range(int(nIter)):
+            for c in self.chains:
+                c.currentIter = N
+                c._syncStatesMDtoNCMC()
+            self._stepNCMC(nstepsNC, moveStep)
+            for c in self.chains:
+                c._acceptRejectMove(write_move)
+            if on_iteration is not None:
+                on_iteration(N, [c.last for c in self.chains])
+            for c in self.chains:
+                c._resetSimulations(temperature)
+            self._stepMD(nstepsMD)
+        for c in self.chains:
+            c.acceptRatio = c.accept / float(nIter)

@@ -167,6 +167,42 @@ int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
  * on the engine's own stream; returns mean microseconds per launch. */
 int blues_time_nonbonded(BluesEngine *h, int32_t reps, double *usec_per_launch);
 
+/* ---- Replica batches ------------------------------------------------------
+ * BLUES chains are independent (reference examples run one
+ * BLUESSimulation per process), and one replica of the 23k-atom system keeps
+ * only a few percent of an MI355X busy.  A batch makes `count` congruent
+ * engines on ONE device (same topology and protocol; own coordinates,
+ * velocities and Philox stream) share every launch of integrator.step(n):
+ * gridDim.y = count.  Each engine keeps its full C-ABI above (moves and
+ * state queries stay per replica, as in the reference where they go through
+ * each Simulation's own context); only stepping goes through the batch.
+ * Results are bitwise identical to stepping each engine alone.
+ *
+ * blues_batch_step = integrator.step(n_steps) on every member (reference
+ * blues/simulation.py:1082, once per replica).  status[r] != 0 means member r
+ * raised (what would be an OpenMMException out of its step(); message via
+ * blues_last_error(engines[r])); the other members are unaffected, matching
+ * the reference's per-simulation error policy (simulation.py:1088-1094).
+ * work_trace: [count][n_steps] per-step protocol work in kJ/mol, or NULL.
+ * The return value is non-zero only for failures of the batch itself
+ * (blues_batch_last_error).  Destroying a member dissolves the batch. */
+typedef struct BluesBatch BluesBatch;
+int blues_batch_create(BluesEngine *const *engines, int32_t count, BluesBatch **out);
+int blues_batch_destroy(BluesBatch *b);
+const char *blues_batch_last_error(const BluesBatch *b);
+int blues_batch_size(const BluesBatch *b);
+int blues_batch_step(BluesBatch *b, int32_t n_steps, double *work_trace, int32_t *status);
+/* mask[r] == 0: member r sits out the following blues_batch_step calls (its
+ * state is left untouched) -- a chain whose switch was abandoned after an
+ * exception must not be advanced further (simulation.py:1088-1094).
+ * NULL = everyone. */
+int blues_batch_set_active(BluesBatch *b, const int32_t *mask);
+/* [0] steps issued in lock step (one launch for all members) [1] steps that
+ * fell back to per-member launches [2] members */
+int blues_batch_get_stats(BluesBatch *b, int64_t stats[4]);
+/* as blues_time_nonbonded, for one batched launch covering all members */
+int blues_batch_time_nonbonded(BluesBatch *b, int32_t reps, double *usec_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,235 @@
+"""Replica batches (include/blues_engine.h "Replica batches"): R congruent engines on one GPU share every
+launch of integrator.step(n).  The batched kernels run the same device functions as the single-replica ones, so the bar
+is BITWISE identity with the same replicas advanced alone -- plus the oracle for one of them."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import gpu_available
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not gpu_available(), reason="needs a GPU")]
+
+from blues_amd import integrators, moves, simulation, systems, unit  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from blues_amd import build
+    build.build_engine()
+    from blues_amd.engine import NativeEngine
+    return NativeEngine
+
+
+def _integ(nsteps, seed, dt=0.004, **kw):
+    return integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=dt, temperature=300.0, seed=seed, **kw)
+
+
+def _replica_inputs(s, v, R):
+    """Distinct velocities / Philox keys per replica, same topology."""
+    rng = np.random.RandomState(11)
+    out = []
+    for r in range(R):
+        vr = v * (1.0 + 0.05 * r) + 0.01 * rng.standard_normal(v.shape) * (s.mass[:, None] > 0)
+        out.append(vr)
+    return out
+
+
+def _make(Engine, s, vels, nsteps, precision, split=None, nprop=1):
+    engs = []
+    for r, vr in enumerate(vels):
+        if split is None:
+            integ = _integ(nsteps, seed=100 + r)
+        else:
+            integ = integrators.AlchemicalExternalLangevinIntegrator(
+                {"lambda_sterics": "min(1, (1/0.3)*abs(lambda-0.5))",
+                 "lambda_electrostatics": "step(0.2-lambda) - 1/0.2*lambda*step(0.2-lambda) + 1/0.2*(lambda-0.8)*step(lambda-0.8)"},
+                splitting=split, temperature=300.0, timestep=0.002, nsteps_neq=nsteps, nprop=nprop, prop_lambda=0.3, seed=100 + r)
+        d = integ.to_data(precision=precision, replica=r)
+        g = Engine(s, d)
+        g.set_velocities(vr)
+        engs.append(g)
+    return engs
+
+
+def _state(g):
+    return g.get_positions(), g.get_velocities(), g.get_global("protocol_work")
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_batch_is_bitwise_identical_to_solo(Engine, tol_box, precision):
+    from blues_amd.engine import NativeBatch
+    s, v = tol_box
+    R, n = 3, 24
+    vels = _replica_inputs(s, v, R)
+    solo = _make(Engine, s, vels, n, precision)
+    # three calls: where a call ends the pending program is flushed, which regroups the ops into launches (and so the
+    # summation order of the CM remover) -- same grouping on both sides
+    ws = [np.concatenate([g.run_switch(5, trace=True), g.run_switch(7, trace=True), g.run_switch(n - 12, trace=True)]) for g in solo]
+    bat = _make(Engine, s, vels, n, precision)
+    B = NativeBatch(bat)
+    _, w1 = B.step(5, trace=True)
+    _, w2 = B.step(7, trace=True)
+    _, w3 = B.step(n - 12, trace=True)
+    wb = np.concatenate([w1, w2, w3], axis=1)
+    st = B.stats()
+    assert st["replicas"] == R and st["fallback_steps"] == 0 and st["lockstep_steps"] > 0
+    for r in range(R):
+        assert np.array_equal(wb[r], ws[r]), (r, np.abs(wb[r] - ws[r]).max())
+        xs, vs, _ = _state(solo[r]); xb, vb, _ = _state(bat[r])
+        assert np.array_equal(xs, xb) and np.array_equal(vs, vb)
+    assert not np.array_equal(ws[0], ws[1])      # the replicas really are different trajectories
+    B.close()
+    for g in solo + bat:
+        g.close()
+
+
+def test_batch_vs_oracle(Engine, tol_box, oracle_mod):
+    from blues_amd.engine import NativeBatch
+    s, v = tol_box
+    R, n = 2, 10
+    vels = _replica_inputs(s, v, R)
+    bat = _make(Engine, s, vels, n, 1)
+    B = NativeBatch(bat)
+    _, wb = B.step(n, trace=True)
+    for r in range(R):
+        o = oracle_mod.Oracle(s, _integ(n, seed=100 + r).to_data(precision=1, replica=r))
+        o.set_velocities(vels[r])
+        wo = []
+        for _ in range(n):
+            o.step(1); wo.append(o.get_global("protocol_work"))
+        assert np.allclose(wb[r], wo, rtol=1e-9, atol=1e-9)
+        assert np.abs(bat[r].get_positions() - o.get_positions()).max() < 1e-10
+    B.close()
+
+
+def test_batch_with_frozen_atoms_and_moves(Engine, tol_box):
+    """The flagship shape in miniature (most atoms frozen -> fused force launch) with a position edit of only SOME
+    replicas in the middle: that step cannot be issued in lock step and must fall back, with identical results."""
+    from blues_amd.engine import NativeBatch
+    s, v = tol_box
+    lig = np.arange(15)
+    near = systems.nearest_molecules(s, lig, 120, exclude_idx=lig)
+    sf = systems.freeze_except(s, np.concatenate([lig, near]))
+    vf = v * (sf.mass[:, None] > 0)
+    R, n = 4, 16
+    vels = _replica_inputs(sf, vf, R)
+    rot = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+
+    def edit(g):
+        x = g.get_positions(); c = x[lig].mean(0); x[lig] = (x[lig] - c) @ rot.T + c; g.set_positions(x)
+
+    def run(engs, stepper):
+        stepper(n // 2)
+        for r, g in enumerate(engs):
+            if r % 2 == 0:
+                edit(g)
+        stepper(n - n // 2)
+
+    solo = _make(Engine, sf, vels, n, 0)
+    run(solo, lambda k: [g.step(k) for g in solo])
+    bat = _make(Engine, sf, vels, n, 0)
+    B = NativeBatch(bat)
+    run(bat, lambda k: B.step(k))
+    st = B.stats()
+    assert st["fallback_steps"] >= 1 and st["lockstep_steps"] >= n - 4
+    for r in range(R):
+        xs, vs, w_s = _state(solo[r]); xb, vb, w_b = _state(bat[r])
+        assert np.array_equal(xs, xb) and np.array_equal(vs, vb) and w_s == w_b, r
+    B.close()
+
+
+def test_batch_other_programs_and_inactive_members(Engine, tol_box):
+    """General op interpreter (another splitting, nprop > 1) through the batch; a member masked out is left untouched."""
+    from blues_amd.engine import NativeBatch
+    s, v = tol_box
+    R, n = 3, 10
+    vels = _replica_inputs(s, v, R)
+    solo = _make(Engine, s, vels, n, 1, split="V R H O R V", nprop=2)
+    for g in solo:
+        g.step(n)
+    bat = _make(Engine, s, vels, n, 1, split="V R H O R V", nprop=2)
+    B = NativeBatch(bat)
+    x1_before = bat[1].get_positions()
+    B.step(4, active=[True, False, True])
+    assert np.array_equal(bat[1].get_positions(), x1_before) and bat[1].get_global("step") == 0
+    B.step(n - 4, active=[True, False, True])
+    B.step(n)                       # members 0 and 2 are at the end of their protocol (no-ops); member 1 runs its n steps
+    for r in range(R):
+        xs, vs, w_s = _state(solo[r]); xb, vb, w_b = _state(bat[r])
+        assert np.array_equal(xs, xb) and np.array_equal(vs, vb) and w_s == w_b, r
+    B.close()
+
+
+def test_batch_member_failure_is_isolated(Engine, tol_box):
+    """One replica blows up (atoms placed on top of each other): its status is set and its message readable, the others
+    finish with the results they have alone (reference policy: per-simulation exception, blues/simulation.py:1088-1094)."""
+    from blues_amd.engine import NativeBatch, EngineError
+    s, v = tol_box
+    R, n = 3, 12
+    vels = _replica_inputs(s, v, R)
+    solo = _make(Engine, s, vels, n, 0)
+    for r in (0, 2):
+        solo[r].step(n)
+    bat = _make(Engine, s, vels, n, 0)
+    x = bat[1].get_positions(); x[18] = x[21] + 1e-4; x[19] = x[22] + 1e-4; bat[1].set_positions(x)   # two waters superposed
+    B = NativeBatch(bat)
+    errors, _ = B.step(n, raise_errors=False)
+    assert errors[0] is None and errors[2] is None
+    assert isinstance(errors[1], EngineError) and ("nan" in str(errors[1]).lower() or "constraint" in str(errors[1]).lower())
+    for r in (0, 2):
+        assert np.array_equal(solo[r].get_positions(), bat[r].get_positions())
+    for g in bat:
+        g.reset()
+    bat[1].set_positions(x)
+    with pytest.raises(EngineError):
+        B.step(n)   # raise_errors=True surfaces the member's exception, as integrator.step would
+    B.close()
+
+
+def test_batched_blues_driver_matches_separate_chains(Engine, tol_box):
+    """BatchedBLUESSimulation (lock-step chains) against the same chains run one after the other through BLUESSimulation."""
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    lig = np.arange(15)
+    R, nsteps, nIter = 3, 12, 2
+    vels = _replica_inputs(s, v, R)
+
+    def chain(r):
+        integ = _integ(nsteps, seed=500 + r, dt=0.002)
+        sim = Simulation(None, s, integ, precision="double", replica=r)
+        sim.context.setVelocities(unit.Quantity(vels[r], "nanometer/picosecond"))
+        mover = moves.MoveEngine(moves.RandomLigandRotationMove(lig, s.mass[lig], random_state=70 + r))
+        return simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": nIter}, mover)
+
+    # setVelocitiesToTemperature and the Metropolis draw use numpy's global stream: pinned per (chain, iteration) below
+    sep = [chain(r) for r in range(R)]
+    sep_records = []
+    for r, c in enumerate(sep):
+        recs = []
+        for N in range(nIter):
+            np.random.seed(1000 * r + N)
+            c.currentIter = N
+            c._syncStatesMDtoNCMC(); c._stepNCMC(nsteps, nsteps // 2); c._acceptRejectMove(); recs.append(dict(c.last))
+            np.random.seed(5000 + 1000 * r + N)
+            c._resetSimulations(300.0)
+        sep_records.append(recs)
+
+    bat = [chain(r) for r in range(R)]
+    B = simulation.BatchedBLUESSimulation(bat)
+    for N in range(nIter):
+        for r, c in enumerate(bat):
+            c.currentIter = N
+            c._syncStatesMDtoNCMC()
+        B._stepNCMC(nsteps, nsteps // 2)
+        for r, c in enumerate(bat):
+            np.random.seed(1000 * r + N)
+            c._acceptRejectMove()
+            assert c.last["protocol_work"] == sep_records[r][N]["protocol_work"]
+            assert c.last["log_accept"] == sep_records[r][N]["log_accept"] and c.last["accept"] == sep_records[r][N]["accept"]
+            np.random.seed(5000 + 1000 * r + N)
+            c._resetSimulations(300.0)
+    for r in range(R):
+        assert np.array_equal(sep[r]._ncmc_sim.context._engine.get_positions(), bat[r]._ncmc_sim.context._engine.get_positions())
+        assert sep[r].accept == bat[r].accept and sep[r].reject == bat[r].reject
+    B.close()
