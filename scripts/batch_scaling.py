@@ -20,7 +20,7 @@ for R in a.R:
     for r in range(R):
         integ = integrators.generateNCMCIntegrator(nstepsNC=a.nsteps + 50, dt=0.004, temperature=300.0, seed=replica_seed(1234, r))
         g = NativeEngine(system, integ.to_data(precision=0, replica=r))
-        g.set_velocities(vel * (1.0 + 0.02 * rng.standard_normal((system.n_atoms, 1))))
+        g.set_velocities(vel)
         engs.append(g)
     B = NativeBatch(engs)
     B.step(50)

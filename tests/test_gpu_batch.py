@@ -56,8 +56,17 @@ def _state(g):
     return g.get_positions(), g.get_velocities(), g.get_global("protocol_work")
 
 
+@pytest.fixture(params=["0", "1"])
+def same_decomposition(request, monkeypatch):
+    """A batch picks its launch decomposition for R replicas (fused force launch only while the whole batch is small), which
+    changes the order of the partial force sums.  Pinning the choice makes solo and batched runs comparable bit for bit --
+    once with the fused launch, once with the separate kernels."""
+    monkeypatch.setenv("BLUES_FUSE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("precision", [0, 1])
-def test_batch_is_bitwise_identical_to_solo(Engine, tol_box, precision):
+def test_batch_is_bitwise_identical_to_solo(Engine, tol_box, precision, same_decomposition):
     from blues_amd.engine import NativeBatch
     s, v = tol_box
     R, n = 3, 24
@@ -84,6 +93,51 @@ def test_batch_is_bitwise_identical_to_solo(Engine, tol_box, precision):
         g.close()
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+def test_batch_large_iset_unfused_path(Engine, tol_box, precision):
+    """More than 32 i-tiles: the force pass is separate launches (alchemical / sub-tile nonbonded / bonded / finalize) and
+    the step kernel spans several blocks -- the other half of the batched kernels."""
+    from blues_amd.engine import NativeBatch
+    s, v = tol_box
+    big = systems.tile_system(s, (1, 1, 3))
+    vb_ = np.concatenate([v, v, v])
+    R, n = 2, 8
+    vels = _replica_inputs(big, vb_, R)
+    solo = _make(Engine, big, vels, n, precision)
+    assert solo[0].stats()["i_tiles"] > 32
+    ws = [g.run_switch(n, trace=True) for g in solo]
+    bat = _make(Engine, big, vels, n, precision)
+    B = NativeBatch(bat)
+    _, wb = B.step(n, trace=True)
+    assert B.stats()["fallback_steps"] == 0
+    for r in range(R):
+        assert np.array_equal(wb[r], ws[r]), (r, np.abs(wb[r] - ws[r]).max())
+        xs, vs, _ = _state(solo[r]); xb, vb, _ = _state(bat[r])
+        assert np.array_equal(xs, xb) and np.array_equal(vs, vb)
+    B.close()
+
+
+def test_batch_default_policy_matches_solo_to_rounding(Engine, tol_box):
+    """No pinning: the batch may choose another decomposition than a lone engine; results then agree to summation-order
+    rounding (fp64 mode), not bit for bit."""
+    from blues_amd.engine import NativeBatch
+    s, v = tol_box
+    R, n = 4, 12
+    vels = _replica_inputs(s, v, R)
+    solo = _make(Engine, s, vels, n, 1)
+    ws = [g.run_switch(n, trace=True) for g in solo]
+    bat = _make(Engine, s, vels, n, 1)
+    B = NativeBatch(bat)
+    _, wb = B.step(n, trace=True)
+    for r in range(R):
+        assert np.allclose(wb[r], ws[r], rtol=1e-10, atol=1e-10)
+        assert np.abs(solo[r].get_positions() - bat[r].get_positions()).max() < 1e-11
+    B.close()
+    # leaving the batch restores the lone-engine layout: the members keep working on their own
+    for g in bat:
+        g.reset(); g.step(2)
+
+
 def test_batch_vs_oracle(Engine, tol_box, oracle_mod):
     from blues_amd.engine import NativeBatch
     s, v = tol_box
@@ -103,7 +157,7 @@ def test_batch_vs_oracle(Engine, tol_box, oracle_mod):
     B.close()
 
 
-def test_batch_with_frozen_atoms_and_moves(Engine, tol_box):
+def test_batch_with_frozen_atoms_and_moves(Engine, tol_box, same_decomposition):
     """The flagship shape in miniature (most atoms frozen -> fused force launch) with a position edit of only SOME
     replicas in the middle: that step cannot be issued in lock step and must fall back, with identical results."""
     from blues_amd.engine import NativeBatch
@@ -139,7 +193,7 @@ def test_batch_with_frozen_atoms_and_moves(Engine, tol_box):
     B.close()
 
 
-def test_batch_other_programs_and_inactive_members(Engine, tol_box):
+def test_batch_other_programs_and_inactive_members(Engine, tol_box, same_decomposition):
     """General op interpreter (another splitting, nprop > 1) through the batch; a member masked out is left untouched."""
     from blues_amd.engine import NativeBatch
     s, v = tol_box
@@ -161,7 +215,7 @@ def test_batch_other_programs_and_inactive_members(Engine, tol_box):
     B.close()
 
 
-def test_batch_member_failure_is_isolated(Engine, tol_box):
+def test_batch_member_failure_is_isolated(Engine, tol_box, same_decomposition):
     """One replica blows up (atoms placed on top of each other): its status is set and its message readable, the others
     finish with the results they have alone (reference policy: per-simulation exception, blues/simulation.py:1088-1094)."""
     from blues_amd.engine import NativeBatch, EngineError
@@ -187,7 +241,7 @@ def test_batch_member_failure_is_isolated(Engine, tol_box):
     B.close()
 
 
-def test_batched_blues_driver_matches_separate_chains(Engine, tol_box):
+def test_batched_blues_driver_matches_separate_chains(Engine, tol_box, same_decomposition):
     """BatchedBLUESSimulation (lock-step chains) against the same chains run one after the other through BLUESSimulation."""
     from blues_amd.context import Simulation
     s, v = tol_box
