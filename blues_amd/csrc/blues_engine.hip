@@ -110,7 +110,7 @@ struct BluesEngine {
     unsigned h_draw = 0;
     double cur_ls = 1.0, cur_le = 1.0, h_lambda = 0.0;
     double h_perturbed = 0, h_unperturbed = 0; bool unpert_valid = false, x_edited = false;
-    bool pass_valid = false; int pass_L = 0;
+    bool pass_valid = false; int pass_L = 0, pass_fmask = 7;
     bool have_positions = false, sorted_ok = false, lists_forced = true;
     std::vector<double> hx;        // host copy of the last positions handed in (caller order, [n][3])
     std::vector<double> hx_sort;   // positions at the last sort
@@ -660,8 +660,14 @@ static AlchDyn make_alch_dyn(const AlchArgs& A) { AlchDyn d; for (int s = 0; s <
 static int launch_alchemical(BluesEngine* h, const double ls[3], const double le[3], int slot_mask) {
     if (h->alch.empty()) return 0;
     AlchArgs A = make_alch_args(h, ls, le, slot_mask);
-    if (batch_lead(h)) hipLaunchKernelGGL(k_alchemical_b, dim3(h->k2_nblocks_env + 1, h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, make_alch_dyn(A));
-    else if (!batch_dry(h)) hipLaunchKernelGGL(k_alchemical, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->cur, A);
+    const bool fast = h->precision == 0;
+    if (batch_lead(h)) {
+        if (fast) hipLaunchKernelGGL(k_alchemical_b<true>, dim3(h->k2_nblocks_env + 1, h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, make_alch_dyn(A));
+        else hipLaunchKernelGGL(k_alchemical_b<false>, dim3(h->k2_nblocks_env + 1, h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, make_alch_dyn(A));
+    } else if (!batch_dry(h)) {
+        if (fast) hipLaunchKernelGGL(k_alchemical<true>, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->cur, A);
+        else hipLaunchKernelGGL(k_alchemical<false>, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->cur, A);
+    }
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -710,23 +716,25 @@ static int launch_bonded(BluesEngine* h, bool with_noise) {
     return 0;
 }
 
-static FinArgs make_fin_args(BluesEngine* h, const double le[3]) {
+static FinArgs make_fin_args(BluesEngine* h, const double le[3], int slot_mask = 7) {
     FinArgs F; memset(&F, 0, sizeof F);
     F.n = h->n; F.n_islots = h->n_islots; F.npart = h->npart; F.n_alch = (int)h->alch.size(); F.PA = h->PA; F.k2_nblocks_env = h->k2_nblocks_env; F.n_entries = h->n_entries;
     F.recs = h->d_finrecs.p; F.orig_of_islot = h->d_orig_of_islot.p; F.row_of_orig = h->d_row_of_orig.p; F.row_start = h->d_row_start.p;
     F.fpart = h->d_fpart.p; F.fent = h->d_fent.p; F.fJ = h->d_fJ.p; F.sorted_of_orig = h->d_sorted_of_orig.p; F.alch_orig = h->d_alch_orig.p;
     F.self_part = h->d_self_part.p; F.e_part = h->d_e_part.p; F.jcount_alch = h->d_jcount.p + h->n_itiles;
     for (int s = 0; s < 3; s++) F.le[s] = le[s];
+    F.slot_mask = slot_mask;
     F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p; F.ctrl = h->ctrl_arg;
     for (int k = 0; k < 3; k++) F.v[k] = h->d_v[k].p;
     F.mass = h->d_mass.p; F.mom_part = h->d_mom_part.p;
     return F;
 }
 
-static int launch_finalize(BluesEngine* h, const double le[3]) {
-    FinArgs F = make_fin_args(h, le);
+static int launch_finalize(BluesEngine* h, const double le[3], int slot_mask = 7) {
+    FinArgs F = make_fin_args(h, le, slot_mask);
     const int nblk = h->n_islots / 64 + (F.n_alch > 0 ? 1 + 9 * ((F.n_alch + 3) / 4) + 1 : 0);
     FinDyn FD; for (int s = 0; s < 3; s++) FD.le[s] = le[s];
+    FD.slot_mask = slot_mask;
     if (batch_lead(h)) hipLaunchKernelGGL(k_finalize_b, dim3(std::max(1, nblk), h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, FD);
     else if (!batch_dry(h)) hipLaunchKernelGGL(k_finalize, dim3(std::max(1, nblk)), dim3(256), 0, h->cur, F);
     h->st_launches++;
@@ -734,16 +742,16 @@ static int launch_finalize(BluesEngine* h, const double le[3]) {
     return 0;
 }
 
-static int launch_bonded_and_finalize(BluesEngine* h, const double le[3], bool with_noise) {
+static int launch_bonded_and_finalize(BluesEngine* h, const double le[3], bool with_noise, int slot_mask = 7) {
     if (launch_bonded(h, with_noise)) return 1;
-    return launch_finalize(h, le);
+    return launch_finalize(h, le, slot_mask);
 }
 
 template <typename R> static int launch_forces_fused(BluesEngine* h, const double ls[3], const double le[3]) {
     NbArgs<R> a = make_nb_args<R>(h);
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
-    AlchArgs A = make_alch_args(h, ls, le, 7);
+    AlchArgs A = make_alch_args(h, ls, le, h->pass_fmask);
     BondedArgs B = make_bonded_args(h);
     B.n_entry_blocks = (h->n_entries + 255) / 256;
     const int nb1 = std::max(1, h->n_itiles) * (h->waves_tile / 4);
@@ -760,7 +768,7 @@ template <typename R> static int launch_forces_fused(BluesEngine* h, const doubl
 
 static int launch_forces_fused_sub(BluesEngine* h, const double ls[3], const double le[3]) {
     NbArgs<float> a = make_nb_args<float>(h);
-    AlchArgs A = make_alch_args(h, ls, le, 7);
+    AlchArgs A = make_alch_args(h, ls, le, h->pass_fmask);
     BondedArgs B = make_bonded_args(h);
     B.n_entry_blocks = (h->n_entries + 255) / 256;
     const int subs = 64 / h->k1_iw;
@@ -796,21 +804,28 @@ static int force_pass(BluesEngine* h, int base_L) {
     if (ensure_sorted(h)) return 1;
     double ls[3], le[3];
     for (int s = 0; s < 3; s++) { const int L = std::min(base_L + s, h->n_lambda); ls[s] = h->tab_ls[L]; le[s] = h->tab_le[L]; }
+    // which lambda slots will have their FORCE applied: "H V R O R V H" kicks only at odd lambda indices (after the
+    // first H of a step, before the second), so a pass based at an odd index serves V(slot 0) and V(slot 2), one based
+    // at an even index (first step, or the step after a Move) only V(slot 1).  Energies are always formed for all three.
+    int fmask = 7;
+    if (h->split == "HVRORVH" && h->nprop == 1) fmask = (base_L & 1) ? 5 : 2;
+    if (const char* e = getenv("BLUES_SLOT_MASK")) fmask = atoi(e) & 7;
+    h->pass_fmask = fmask;
     int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced) : launch_lists<double>(h, h->lists_forced);
     h->lists_forced = false;
     if (rc) return 1;
     if (h->fuse_forces && h->wpb == 4) {
         rc = h->precision == 0 ? launch_forces_fused<float>(h, ls, le) : launch_forces_fused<double>(h, ls, le);
         if (rc) return 1;
-        if (launch_finalize(h, le)) return 1;
+        if (launch_finalize(h, le, fmask)) return 1;
     } else if (h->k1_iw != 64 && h->precision == 0 && h->fuse_big) {
         if (launch_forces_fused_sub(h, ls, le)) return 1;
-        if (launch_finalize(h, le)) return 1;
+        if (launch_finalize(h, le, fmask)) return 1;
     } else {
-        if (launch_alchemical(h, ls, le, 7)) return 1;
+        if (launch_alchemical(h, ls, le, fmask)) return 1;
         rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (rc) return 1;
-        if (launch_bonded_and_finalize(h, le, true)) return 1;
+        if (launch_bonded_and_finalize(h, le, true, fmask)) return 1;
     }
     h->pass_valid = true; h->pass_L = base_L; h->st_passes++; h->vel_clean = true;
     HIP_OK(h, hipGetLastError());
@@ -905,7 +920,7 @@ static int add_work(BluesEngine* h, double delta) {
 
 static int emit_cm(BluesEngine* h) {
     if (!h->remove_cm) return 0;
-    if (h->fast_step && h->vel_clean && h->pass_valid) {
+    if (h->fast_step && h->vel_clean && h->pass_valid && (h->pass_fmask & 1)) {  // the momentum partials are built from slot-0 forces
         const bool after_finish = h->prog.n == 3 && h->prog.ops[0] == OP_V0 && h->prog.ops[1] == OP_H01 && h->prog.ops[2] == OP_END && h->split == "HVRORVH" && h->nprop == 1 && h->h_step < h->nsteps - 0;
         const bool md_head = h->prog.n == 0 && h->split == "L" && !h->tracing;
         if (after_finish || md_head) return emit(h, OP_CM_PART);

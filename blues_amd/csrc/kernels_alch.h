@@ -59,6 +59,8 @@ __device__ inline bool excluded_sorted(const int* ex_start, const int* ex_idx, i
     return ex;
 }
 
+// FAST: the mixed-precision mode's math (device_common.h, fast fp64 forms); false = libm forms, the reference-grade path
+template <bool FAST>
 __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id) {
     if (A.ctrl) {
         const int L = A.ctrl->L0 + 2 * A.ctrl->kpass;
@@ -78,12 +80,14 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
     for (int q = 0; q < K2_NE; q++) e[q] = 0.0;
 
     const bool env_block = block_id < A.nblocks_env;
+    bool wave_hit = true;
     if (env_block) {
         const int count = *A.jcount;
         if ((block_id * 256) / PA >= count) return;  // nothing to do; the integrator sums only the used blocks
         const int js = (block_id * 256 + tid) / PA;
         const bool valid = js < count && a < A.n_alch;
         int jsrt = -1;
+        bool hit = false;  // this lane holds a pair term
         if (valid) {
             const AlchJRec J = A.jrec[js];
             const AlchARec Ar = A.arec[a];
@@ -97,14 +101,27 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
                 const double sig = 0.5 * (Ar.sig + J.sig), eps = sqrt(Ar.eps * J.eps);
                 const double qq = Ar.q * J.q;
                 double fc;
-                const double ec = coulomb_d(r2, qq, A.alpha, A.pme != 0, &fc);
-                e[0] = ec;
+                hit = true;
+                if (FAST && A.pme) {
+                    e[0] = coulomb_fast_d(r2, qq, A.alpha, &fc);
+                    double es[3], fs3[3];
+                    softcore_lj3_fast_d(r2, sig, eps, A.ls, A.sc_alpha, es, fs3);
 #pragma unroll
-                for (int s = 0; s < 3; s++) {
-                    double fs;
-                    e[1 + s] = softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
-                    const double ft = fs + A.le[s] * fc;
-                    f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                    for (int s = 0; s < 3; s++) {
+                        e[1 + s] = es[s];
+                        const double ft = fs3[s] + A.le[s] * fc;
+                        f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                    }
+                } else {
+                    const double ec = coulomb_d(r2, qq, A.alpha, A.pme != 0, &fc);
+                    e[0] = ec;
+#pragma unroll
+                    for (int s = 0; s < 3; s++) {
+                        double fs;
+                        e[1 + s] = softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
+                        const double ft = fs + A.le[s] * fc;
+                        f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                    }
                 }
             } else if (excl) {
                 // excluded pair: if it is a 1-4 exception between this alchemical atom and an environment atom it is
@@ -113,6 +130,7 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
                 // same reductions as a regular pair
                 for (int q = A.exc_start[a]; q < A.exc_start[a + 1]; q++) {
                     if (A.exc_partner[q] != jo) continue;
+                    hit = true;
                     const double qq = A.exc_params[3 * q], sig = A.exc_params[3 * q + 1], eps = A.exc_params[3 * q + 2];
                     double fc;
                     e[0] = coulomb_d(r2, qq, 0.0, false, &fc);
@@ -126,13 +144,16 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
                 }
             }
         }
+        // A wave covers 64/PA consecutive (Hilbert-sorted) j's; more than half of the list is out of range of every
+        // alchemical atom at any one time, so whole waves have nothing to add: they publish zeros and skip every reduction.
+        wave_hit = __ballot(hit) != 0ull;
         // force on environment atom j: minus the sum over the PA alchemical lanes
 #pragma unroll
         for (int s = 0; s < 3; s++) {
             if (!((A.slot_mask >> s) & 1)) continue;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const double fj = seg_sum(f[s][k], PA);
+                const double fj = wave_hit ? seg_sum(f[s][k], PA) : 0.0;
                 if (a == 0 && js < count) A.fJ[(size_t)(s * 3 + k) * A.n + jsrt] = -fj;
             }
         }
@@ -231,17 +252,26 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
     }
 
     // ---- env blocks: force on alchemical atom a = sum over the j's of this block
+    if (wave_hit) {
 #pragma unroll
-    for (int s = 0; s < 3; s++)
+        for (int s = 0; s < 3; s++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            double v = f[s][k];
-            for (int off = PA; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            if (lane < PA) s_self[wv][s * 3 + k][lane] = v;
-        }
+            for (int k = 0; k < 3; k++) {
+                double v = 0.0;
+                if ((A.slot_mask >> s) & 1) {   // a slot whose force nobody applies is not reduced (its energy still is)
+                    v = f[s][k];
+                    for (int off = PA; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+                }
+                if (lane < PA) s_self[wv][s * 3 + k][lane] = v;
+            }
 #pragma unroll
-    for (int q = 0; q < K2_NE; q++) e[q] = wave_sum(e[q]);
-    if (lane == 0) for (int q = 0; q < K2_NE; q++) s_e[wv][q] = e[q];
+        for (int q = 0; q < K2_NE; q++) e[q] = wave_sum(e[q]);
+        if (lane == 0) for (int q = 0; q < K2_NE; q++) s_e[wv][q] = e[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 9; q++) if (lane < PA) s_self[wv][q][lane] = 0.0;
+        if (lane == 0) for (int q = 0; q < K2_NE; q++) s_e[wv][q] = 0.0;
+    }
     __syncthreads();
     if (tid < 64) {
 #pragma unroll
@@ -259,4 +289,5 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
     }
 }
 
-__global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) { alchemical_body(A, blockIdx.x); }
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) { alchemical_body<FAST>(A, blockIdx.x); }

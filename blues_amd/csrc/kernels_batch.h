@@ -25,7 +25,7 @@ struct RepCore {
 
 struct AlchDyn { double ls[3], le[3]; int slot_mask; };
 struct BondedDyn { unsigned draw_base; int n_entry_blocks; };
-struct FinDyn { double le[3]; };
+struct FinDyn { double le[3]; int slot_mask; };
 struct IntDyn { unsigned draw_base, noise_draw_base; int n_noise, trace_index, tracing; Program prog; };
 
 __device__ __forceinline__ void apply_dyn(AlchArgs& A, const AlchDyn& d) {
@@ -37,7 +37,7 @@ __device__ __forceinline__ void apply_dyn(BondedArgs& B, const BondedDyn& d) { B
 __device__ __forceinline__ void apply_dyn(FinArgs& F, const FinDyn& d) {
 #pragma unroll
     for (int s = 0; s < 3; s++) F.le[s] = d.le[s];
-    F.ctrl = nullptr;
+    F.slot_mask = d.slot_mask; F.ctrl = nullptr;
 }
 __device__ __forceinline__ void apply_dyn(IntArgs& A, const IntDyn& d) {
     A.draw_base = d.draw_base; A.noise_draw_base = d.noise_draw_base; A.n_noise = d.n_noise; A.trace_index = d.trace_index;
@@ -69,10 +69,11 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub_b(const RepNb<float>* __r
     nonbonded_sub_body<ENERGY, IW>(a, c, rp.img, blockIdx.x);
 }
 
+template <bool FAST>
 __global__ void __launch_bounds__(256) k_alchemical_b(const RepCore* __restrict__ reps, AlchDyn d) {
     if (!reps[blockIdx.y].active) return;
     AlchArgs A = reps[blockIdx.y].al; apply_dyn(A, d);
-    alchemical_body(A, blockIdx.x);
+    alchemical_body<FAST>(A, blockIdx.x);
 }
 
 __global__ void __launch_bounds__(128) k_bonded_entries_b(const RepCore* __restrict__ reps, BondedDyn d) {
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) k_forces_fused_b(const RepNb<R>* __restri
         nonbonded_body<R, false, 4>(a, c, rp.img, b);
         return;
     }
-    if (b < nb1 + nb2) { AlchArgs A = reps[blockIdx.y].al; apply_dyn(A, da); alchemical_body(A, b - nb1); return; }
+    if (b < nb1 + nb2) { AlchArgs A = reps[blockIdx.y].al; apply_dyn(A, da); alchemical_body<sizeof(R) == 4>(A, b - nb1); return; }
     BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, db);
     bonded_entries_body(B, b - nb1 - nb2, 256);
 }
@@ -106,7 +107,7 @@ template <int IW>
 __global__ void __launch_bounds__(256) k_forces_fused_sub_b(const RepNb<float>* __restrict__ rnb, const RepCore* __restrict__ reps, AlchDyn da, BondedDyn db, int nb1, int nb2) {
     if (!reps[blockIdx.y].active) return;
     const int b = blockIdx.x;
-    if (b < nb2) { AlchArgs A = reps[blockIdx.y].al; apply_dyn(A, da); alchemical_body(A, b); return; }
+    if (b < nb2) { AlchArgs A = reps[blockIdx.y].al; apply_dyn(A, da); alchemical_body<true>(A, b); return; }
     if (b < nb2 + nb1) {
         const RepNb<float>& rp = rnb[blockIdx.y];
         const NbArgs<float> a = rp.nb; const NbConst<float> c = rp.c;

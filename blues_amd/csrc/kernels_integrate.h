@@ -236,6 +236,7 @@ struct FinArgs {
     const int* alch_orig;
     const double* self_part; const double* e_part; const int* jcount_alch;
     double le[3];
+    int slot_mask;              // lambda slots whose force will be applied (bit s); the others are neither read nor written
     double* ftot; double* alch_self; DevAccum* acc;
     DevCtrl* ctrl;
     // momentum bookkeeping for CMMotionRemover without a grid-wide reduction inside the step kernel:
@@ -268,7 +269,7 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
 #pragma unroll
         for (int sl = 0; sl < 3; sl++)
 #pragma unroll
-            for (int k = 0; k < 3; k++) fj[sl][k] = (wv == 0 && i >= 0 && isl >= 0 && A.n_alch > 0) ? A.fJ[(size_t)(sl * 3 + k) * A.n + rec.sorted] : 0.0;
+            for (int k = 0; k < 3; k++) fj[sl][k] = (wv == 0 && i >= 0 && isl >= 0 && A.n_alch > 0 && ((A.slot_mask >> sl) & 1)) ? A.fJ[(size_t)(sl * 3 + k) * A.n + rec.sorted] : 0.0;
         if (i >= 0) {
             if (isl >= 0) {
                 int p = wv;
@@ -309,9 +310,9 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
             for (int k = 0; k < 3; k++) {
                 const double f = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
                 if (isl >= 0 && A.n_alch > 0) {
-                    for (int sl = 0; sl < 3; sl++) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f + fj[sl][k];
+                    for (int sl = 0; sl < 3; sl++) if ((A.slot_mask >> sl) & 1) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f + fj[sl][k];
                 } else if (isl >= 0) {
-                    for (int sl = 0; sl < 3; sl++) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f;
+                    for (int sl = 0; sl < 3; sl++) if ((A.slot_mask >> sl) & 1) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f;
                 } else A.ftot[(size_t)k * A.n + i] = f;  // alchemical atom: bonded part; integrator adds alch_self[slot]
             }
         }
@@ -336,7 +337,7 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
     if (blk < 9 * na4) {  // slab q = slot*3 + component, 4 alchemical atoms per block: one wave per (q, atom)
         const int q = blk / na4, a = (blk - q * na4) * 4 + wv;
         double s = 0.0;
-        if (a < A.n_alch) {
+        if (a < A.n_alch && ((A.slot_mask >> (q / 3)) & 1)) {
             for (int b = lane; b < nb_env; b += 64) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
             if (lane == 0) s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
             s = wave_sum(s);
@@ -603,7 +604,7 @@ __global__ void __launch_bounds__(256) k_forces_fused(NbArgs<R> a, NbConst<R> c,
                                                       AlchArgs A, BondedArgs B, int nb1, int nb2) {
     const int b = blockIdx.x;
     if (b < nb1) { nonbonded_body<R, false, 4>(a, c, img, b); return; }
-    if (b < nb1 + nb2) { alchemical_body(A, b - nb1); return; }
+    if (b < nb1 + nb2) { alchemical_body<sizeof(R) == 4>(A, b - nb1); return; }
     bonded_entries_body(B, b - nb1 - nb2, 256);
 }
 
@@ -828,7 +829,7 @@ template <int IW>
 __global__ void __launch_bounds__(256) k_forces_fused_sub(NbArgs<float> a, NbConst<float> c, const AtomF* __restrict__ img,
                                                           AlchArgs A, BondedArgs B, int nb1, int nb2) {
     const int b = blockIdx.x;
-    if (b < nb2) { alchemical_body(A, b); return; }             // the longest-latency blocks first
+    if (b < nb2) { alchemical_body<true>(A, b); return; }             // the longest-latency blocks first
     if (b < nb2 + nb1) { nonbonded_sub_body<false, IW>(a, c, img, b - nb2); return; }
     bonded_entries_body(B, b - nb1 - nb2, 256);
 }
