@@ -147,7 +147,7 @@ struct BluesEngine {
     // pending integrate program
     Program prog; unsigned prog_draw_base = 0; int prog_trace = -1; bool tracing = false;
     // stats
-    int64_t st_passes = 0, st_launches = 0;
+    int64_t st_passes = 0, st_launches = 0, st_resorts = 0;
     std::vector<int> h_sorted_of_orig, h_orig_of_sorted;
 
     ~BluesEngine() {
@@ -389,7 +389,8 @@ static int sort_and_tile(BluesEngine* h) {
     const double rl = h->cutoff + h->skin;
     const double vol = h->box[0] * h->box[1] * h->box[2], rho = n / vol;
     const double a = std::cbrt(64.0 / std::max(rho, 1e-9)) * 1.35;  // tile edge incl. slack for diffusion
-    double est = rho * (a * a * a + 6 * a * a * rl + 3 * M_PI * a * rl * rl + 4.0 / 3.0 * M_PI * rl * rl * rl) * 1.5;
+    double est = rho * (a * a * a + 6 * a * a * rl + 3 * M_PI * a * rl * rl + 4.0 / 3.0 * M_PI * rl * rl * rl) * 1.8;
+    if (const char* e = getenv("BLUES_JCAP_SCALE")) est *= atof(e);   // tests: shrink the capacity to exercise the re-sort path
     int jcap = (int)std::min<double>(n, est);
     jcap = std::max(64, ((jcap + 63) / 64) * 64);
     jcap = std::min(jcap, 16384);
@@ -398,7 +399,7 @@ static int sort_and_tile(BluesEngine* h) {
     const int nt = std::max(1, h->n_tiles);
     {   // K1 decomposition: segments of seg_len j-atoms, waves_tile waves per i-tile in blocks of wpb waves
         const int nit = std::max(1, h->n_itiles);
-        const double est_count = std::min<double>(jcap, est / 1.5);
+        const double est_count = std::min<double>(jcap, est / 1.8);
         int CH = 64;
         while (CH > 8 && nit * (est_count / CH) < 4096.0) CH >>= 1;
         if (const char* e = getenv("BLUES_SEG")) CH = std::max(4, std::min(64, atoi(e)));
@@ -474,7 +475,7 @@ static int sort_and_tile(BluesEngine* h) {
           for (size_t a2 = 0; a2 < h->alch.size(); a2++) { AlchARec& r = ar[a2]; const int ao = h->alch[a2]; r.ao = ao; r.asrt = h->h_sorted_of_orig[ao]; r.pad = 0; r.sig = h->sigma[ao]; r.eps = h->eps[ao]; r.q = h->charge[ao];
             r.has_env_excl = 0; for (int p2 : h->excl[ao]) if (h->alch_local[p2] < 0) r.has_env_excl = 1; }
           h->d_arec.upload(ar); }
-        h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * 4 * jcap); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
+        h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * LIST_WAVES * ((((n + LIST_WAVES - 1) / LIST_WAVES) + 63) & ~63)); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
         h->d_mask_pool.alloc((size_t)h->pool_cap * 64); h->d_pool_count.alloc(1);
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
         h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_iw != 64 ? 64 / h->k1_iw : 1) + 2 * ((n + 255) / 256));
@@ -586,10 +587,10 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
     if (batch_lead(h)) {
         if (force) for (int r = 0; r < h->batch->R(); r++) if (!h->batch->failed[r]) HIP_OK(h, hipMemsetAsync(h->batch->eng[r]->d_pool_count.p, 0, sizeof(int), h->cur));
-        hipLaunchKernelGGL(k_build_lists_b<R>, dim3(h->n_tiles + 32, h->batch->R()), dim3(256), 0, h->cur, batch_reps_nb<R>(h->batch), force);
+        hipLaunchKernelGGL(k_build_lists_b<R>, dim3(h->n_tiles + 8, h->batch->R()), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), force);
     } else if (!batch_dry(h)) {
         if (force) HIP_OK(h, hipMemsetAsync(h->d_pool_count.p, 0, sizeof(int), h->cur));
-        hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 32), dim3(256), 0, h->cur, a, make_nbconst<R>(h), img, force);
+        hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 8), dim3(LIST_THREADS), 0, h->cur, a, make_nbconst<R>(h), img, force);
     }
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
@@ -847,6 +848,23 @@ static int check_flags(BluesEngine* h) {
     if (f.list_overflow) E_FAIL(h, "neighbour list capacity exceeded (jcap=%d)", h->jcap);
     if (f.constraint_fail) E_FAIL(h, "constraint solver did not converge (the step is unstable)");
     return 0;
+}
+
+// The tiles are formed on the host from a spatial sort; as atoms diffuse they spread and their j-lists grow.  The list
+// kernel raises resort_hint when a list nears its capacity; stepping polls it every RESORT_POLL steps (one small
+// read-back) and re-sorts from the positions on the device.  Without this a long all-mobile run ends in list_overflow.
+#define RESORT_POLL 64
+static int relayout(BluesEngine* h);
+static int poll_resort(BluesEngine* h) {
+    if (flush_program(h)) return 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    DevFlags f;
+    HIP_OK(h, hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost));
+    if (!f.resort_hint || f.list_overflow || f.nan_flag || f.constraint_fail) return 0;   // errors are reported by check_flags
+    f.resort_hint = 0;
+    HIP_OK(h, hipMemcpy(h->d_flags.p, &f, sizeof f, hipMemcpyHostToDevice));
+    h->st_resorts++;
+    return relayout(h);
 }
 
 // full potential energy breakdown at the current state and alchemical parameters (on demand; synchronises)
@@ -1114,6 +1132,7 @@ static int do_steps(BluesEngine* h, int nsteps) {
             if (adv < 0) return 1;
             if (adv > 0) { s += adv - 1; continue; }
         }
+        if (h->h_step > 0 && h->h_step % RESORT_POLL == 0 && poll_resort(h)) return 1;
         if (step_head(h)) return 1;
         if (step_body(h)) return 1;
     }
@@ -1223,6 +1242,8 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
         }
     };
     for (int s = 0; s < n_steps; s++) {
+        // same cadence as a lone engine (keyed on each member's own step counter, so results stay identical to solo runs)
+        for (int r = 0; r < R; r++) if (!B->failed[r] && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0 && poll_resort(B->eng[r])) fail(r);
         for (int r = 0; r < R; r++) if (!B->failed[r] && step_head(B->eng[r])) fail(r);
         if (batch_refresh_args(B)) return 1;   // a head may have re-sorted (it cannot today; cheap to keep correct)
         phase(step_body);
@@ -1618,6 +1639,8 @@ int blues_reset(BluesEngine* h) {
 
 int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
     for (int i = 0; i < BLUES_N_STATS; i++) stats[i] = 0;
+    stats[9] = h->st_resorts;
+    if (h->d_jcount.p && h->sorted_ok) { std::vector<int> jc; hipSetDevice(h->device); hipStreamSynchronize(h->stream); try { h->d_jcount.download(jc); for (int c : jc) stats[8] = std::max<int64_t>(stats[8], c); } catch (std::string&) {} }
     stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
     if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) stats[1] = f.list_gen; }
     return 0;

@@ -46,7 +46,7 @@ __device__ __forceinline__ void apply_dyn(IntArgs& A, const IntDyn& d) {
 }
 
 template <typename R>
-__global__ void __launch_bounds__(256) k_build_lists_b(const RepNb<R>* __restrict__ reps, int force) {
+__global__ void __launch_bounds__(LIST_THREADS) k_build_lists_b(const RepNb<R>* __restrict__ reps, int force) {
     const RepNb<R>& rp = reps[blockIdx.y];
     if (!rp.active) return;
     const ListArgs a = rp.L; const NbConst<R> c = rp.c;

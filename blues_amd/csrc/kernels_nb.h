@@ -20,7 +20,8 @@ struct DevFlags {  // device-resident control words
     int list_overflow;           // j-list or mask-pool capacity exceeded
     int constraint_fail;
     int nan_flag;
-    int pad[3];
+    int resort_hint;             // a j-list has grown to within 15 % of its capacity: the tiles have spread, re-sort soon
+    int pad[2];
 };
 
 template <typename R> struct NbConst {
@@ -35,7 +36,7 @@ struct ListArgs {
     int n, n_tiles, n_itiles, jcap, pool_cap;
     const int* tile_atoms;   // [n_tiles*64] sorted atom index or -1
     int* jlist;              // [n_tiles*jcap]
-    int* jstage;             // [n_tiles*4*jcap] per-wave staging for the ordered compaction
+    int* jstage;             // [n_tiles][LIST_WAVES][share] per-wave staging for the ordered compaction (share: see build_lists_body)
     void* alch_jrec;         // AlchJRec[jcap] for the alchemical tile (kernels_alch.h), or null
     const double* p_sigma; const double* p_eps; const double* p_charge;  // caller order
     int* jcount;             // [n_tiles]
@@ -52,6 +53,13 @@ struct ListArgs {
     int n_fJ;
 };
 
+// LIST_WAVES waves share one tile's scan of all n atoms; each wave keeps LIST_PREFETCH independent loads in flight.
+// The scan is a chain of dependent memory round trips (ballot -> running count -> store), so its duration is
+// (n / 64 / LIST_WAVES / LIST_PREFETCH) latencies: 4 waves x 1 load took 60-70 us at n = 23,400; 16 x 4 takes ~12.
+#define LIST_WAVES 16
+#define LIST_PREFETCH 4
+#define LIST_THREADS (LIST_WAVES * 64)
+
 template <typename R>
 __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force) {
     using sfix = typename Img<R>::sfix;
@@ -62,16 +70,16 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     // ---- shared bookkeeping: remember where the lists were built, clear alchemical env forces
     if (t >= a.n_tiles) {  // helper blocks: bookkeeping that must not sit on a tile block's critical path
         const int hb = t - a.n_tiles, nh = gridDim.x - a.n_tiles;
-        for (int i = hb * 256 + tid; i < a.n; i += nh * 256) {
+        for (int i = hb * LIST_THREADS + tid; i < a.n; i += nh * LIST_THREADS) {
             a.xbuild[0][i] = a.x[0][i]; a.xbuild[1][i] = a.x[1][i]; a.xbuild[2][i] = a.x[2][i];
         }
-        for (int i = hb * 256 + tid; i < a.n_fJ; i += nh * 256) a.fJ[i] = 0.0;
+        for (int i = hb * LIST_THREADS + tid; i < a.n_fJ; i += nh * LIST_THREADS) a.fJ[i] = 0.0;
         return;
     }
 
     __shared__ ufix s_cfix[3];
     __shared__ double s_half[3];
-    __shared__ int s_wcount[4];
+    __shared__ int s_wcount[LIST_WAVES];
     __shared__ int s_total;
     __shared__ int s_need[256];
     const bool alch_tile = (t >= a.n_itiles);
@@ -100,22 +108,27 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     const double hf[3] = {s_half[0], s_half[1], s_half[2]};
 
     // ---- ordered stream compaction of every atom within cutoff+skin of the box.  Each wave scans its own
-    // contiguous quarter of the (Hilbert-sorted) atoms with no block barrier inside the loop and stages
-    // its hits; the quarters are then concatenated in order, so the list stays ascending.
+    // contiguous share of the (Hilbert-sorted) atoms with no block barrier inside the loop and stages its
+    // hits; the shares are then concatenated in order, so the list stays ascending.
     int* jl = a.jlist + (size_t)t * a.jcap;
-    int* stage = a.jstage + ((size_t)t * 4 + wv) * a.jcap;
+    const int share = (((a.n + LIST_WAVES - 1) / LIST_WAVES) + 63) & ~63;   // a wave cannot stage more than it scans
+    int* stage = a.jstage + ((size_t)t * LIST_WAVES + wv) * share;
     const float cfs[3] = {(float)c.dscale[0], (float)c.dscale[1], (float)c.dscale[2]};
     const float hfl[3] = {(float)hf[0] * 1.00001f + 1e-6f, (float)hf[1] * 1.00001f + 1e-6f, (float)hf[2] * 1.00001f + 1e-6f};
     const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f;
-    const int quarter = (((a.n + 3) / 4) + 63) & ~63;
-    const int j_end = min(a.n, (wv + 1) * quarter);
+    const int j_end = min(a.n, (wv + 1) * share);
     int wcount = 0;
-    for (int base = wv * quarter; base < j_end; base += 64) {
-        const int j = base + lane;
-        bool pass = false;
-        if (j < j_end) {
-            const typename Img<R>::Atom aj = img[j];
-            const ufix pj[3] = {aj.x, aj.y, aj.z};
+    for (int base = wv * share; base < j_end; base += 64 * LIST_PREFETCH) {
+        ufix px[LIST_PREFETCH], py[LIST_PREFETCH], pz[LIST_PREFETCH]; unsigned fl[LIST_PREFETCH];
+#pragma unroll
+        for (int u = 0; u < LIST_PREFETCH; u++) {   // all loads of the group are issued before the first is consumed
+            const int j = min(base + u * 64 + lane, a.n - 1);
+            px[u] = img[j].x; py[u] = img[j].y; pz[u] = img[j].z; fl[u] = img[j].flags;
+        }
+#pragma unroll
+        for (int u = 0; u < LIST_PREFETCH; u++) {
+            const int j = base + u * 64 + lane;
+            const ufix pj[3] = {px[u], py[u], pz[u]};
             float d2 = 0.0f;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -123,37 +136,34 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
                 d = fmaxf(d, 0.0f);
                 d2 = fmaf(d, d, d2);
             }
-            pass = d2 < rl2 && !(aj.flags & FLAG_ALCH);
+            const bool pass = j < j_end && d2 < rl2 && !(fl[u] & FLAG_ALCH);
+            const unsigned long long bal = __ballot(pass);
+            if (pass) stage[wcount + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+            wcount += __popcll(bal);
         }
-        const unsigned long long bal = __ballot(pass);
-        if (pass) {
-            const int pos = wcount + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < a.jcap) stage[pos] = j;
-        }
-        wcount += __popcll(bal);
     }
     if (lane == 0) s_wcount[wv] = wcount;
     __syncthreads();
     {
         int off = 0;
         for (int w = 0; w < wv; w++) off += s_wcount[w];
-        const int mine = min(wcount, a.jcap);
-        for (int k = lane; k < mine; k += 64) if (off + k < a.jcap) jl[off + k] = stage[k];
-        if (tid == 0) s_total = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+        for (int k = lane; k < wcount; k += 64) if (off + k < a.jcap) jl[off + k] = stage[k];
+        if (tid == 0) { int tot = 0; for (int w = 0; w < LIST_WAVES; w++) tot += s_wcount[w]; s_total = tot; }
     }
     __threadfence_block();
     __syncthreads();
     int count = s_total;
     if (count > a.jcap) { if (tid == 0) a.flags->list_overflow = 1; count = a.jcap; }
+    else if (count > a.jcap - a.jcap / 7 && tid == 0) a.flags->resort_hint = 1;
     if (tid == 0) a.jcount[t] = count;
     const int nb = (count + 63) >> 6;
     const int nbmax = a.jcap >> 6;
-    for (int b = tid; b < nbmax; b += 256) { s_need[b] = 0; a.batch_slot[t * nbmax + b] = -1; }
+    for (int b = tid; b < nbmax; b += LIST_THREADS) { s_need[b] = 0; a.batch_slot[t * nbmax + b] = -1; }
     __syncthreads();
     if (alch_tile) {  // the alchemical kernel checks exclusions itself; give it packed per-entry records
         struct JR { int jo, jsrt; double sig, eps, q; };
         JR* jr = (JR*)a.alch_jrec;
-        if (jr) for (int k = tid; k < count; k += 256) {
+        if (jr) for (int k = tid; k < count; k += LIST_THREADS) {
             const int js = jl[k], jo = img[js].orig;
             JR r; r.jo = jo; r.jsrt = js; r.sig = a.p_sigma[jo]; r.eps = a.p_eps[jo]; r.q = a.p_charge[jo];
             jr[k] = r;
@@ -166,7 +176,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     int e0 = 0, e1 = 0;
     if (ia >= 0) { e0 = a.ex_start[ia]; e1 = a.ex_start[ia + 1]; }
     for (int pass = 0; pass < 2; pass++) {
-        for (int e = e0 + wv; e < e1; e += 4) {
+        for (int e = e0 + wv; e < e1; e += LIST_WAVES) {
             int p = a.ex_idx[e];
             int lo = 0, hi = count;  // binary search p in jl[0..count)
             while (lo < hi) { int mid = (lo + hi) >> 1; if (jl[mid] < p) lo = mid + 1; else hi = mid; }
@@ -177,7 +187,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
         }
         __syncthreads();
         if (pass == 0) {
-            for (int b = tid; b < nb; b += 256) {
+            for (int b = tid; b < nb; b += LIST_THREADS) {
                 if (s_need[b]) {
                     int slot = atomicAdd(a.pool_count, 1);
                     if (slot >= a.pool_cap) { a.flags->list_overflow = 1; slot = 0; }
@@ -185,9 +195,9 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
                 } else s_need[b] = -1;
             }
             __syncthreads();
-            for (int b = 0; b < nb; b++) {
+            for (int b = wv; b < nb; b += LIST_WAVES) {
                 int slot = s_need[b];
-                if (slot >= 0 && tid < 64) a.mask_pool[(size_t)slot * 64 + tid] = 0ull;
+                if (slot >= 0) a.mask_pool[(size_t)slot * 64 + lane] = 0ull;
             }
             __threadfence_block();
             __syncthreads();
@@ -196,7 +206,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
 }
 
 template <typename R>
-__global__ void __launch_bounds__(256) k_build_lists(ListArgs a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, int force) {
+__global__ void __launch_bounds__(LIST_THREADS) k_build_lists(ListArgs a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, int force) {
     build_lists_body<R>(a, c, img, force);
 }
 
