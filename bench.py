@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- NCMC switching-leg throughput of the MI355X-native engine.
 
-A "step" is one pass of the hot path over one batch of synthetic input: one complete
-1000-step NCMC switch (BASELINE.json configs[1]) of the S23k box (23,400 atoms, 15-atom
-alchemical toluene, ~276 mobile atoms emulating freeze_radius 5 A) driven through the
-drop-in boundary exactly as BLUESSimulation drives it: state sync, _stepNCMC with the
-RandomLigandRotationMove at lambda = 0.5, accept/reject, reset.  metric = ns/day of
-switching trajectory, whole job (all ranks); every rank runs an independent replica
-(weak scaling, no data-path collective; one all-gather of accept records per switch).
+A "step" is one pass of the hot path over one batch of synthetic input: one complete 1000-step NCMC switch
+(BASELINE.json configs[1]) of the S23k box (23,400 atoms, 15-atom alchemical toluene, ~276 mobile atoms emulating
+freeze_radius 5 A) for EVERY chain of the batch, driven through the drop-in boundary exactly as BLUESSimulation drives
+it: state sync, _stepNCMC with the RandomLigandRotationMove at lambda = 0.5, accept/reject, reset.
 
-    python bench.py --gpus N --steps K --warmup W
+metric = ns/day of switching trajectory, whole job: the sum over all independent chains on all ranks (SURVEY.md 8d:
+"aggregate over independent replicas").  One chain keeps a few percent of an MI355X busy, so each rank runs
+--replicas R chains as ONE replica batch (every kernel launch covers all R); the single-chain
+rate of the same switch (configs[1] to the letter: one replica on one GPU) is measured too and reported beside it as
+"single_replica".  Ranks are independent (weak scaling, no data-path collective; one all-gather of the accept records
+per switch).
+
+    python bench.py --gpus N --steps K --warmup W [--replicas R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -29,7 +33,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_ATOM = 36.0     # x,y,z + q,sigma,eps read, fx,fy,fz written, per force evaluation
 
 
-def build_replica(rank, local_rank, nsteps, workload):
+def build_chains(rank, local_rank, nsteps, workload, R):
+    """R independent BLUES chains on this rank's GPU: own integrator (Philox key), context, move engine, state table."""
     from blues_amd import integrators, moves, simulation, systems
     from blues_amd.context import Simulation
     from blues_amd.replicas import replica_seed
@@ -37,26 +42,40 @@ def build_replica(rank, local_rank, nsteps, workload):
         system, vel = systems.s23k(frozen=False)
     else:
         system, vel = systems.s23k(mobile_atoms=275, frozen=True)
-    integ = integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=DT_PS, temperature=300.0, seed=replica_seed(1234, rank))
-    sim = Simulation(None, system, integ, device=local_rank, precision="mixed", replica=rank)
     lig = np.asarray(system.alchemical_atoms)
-    mover = moves.MoveEngine(moves.RandomLigandRotationMove(lig, system.mass[lig], random_state=1000 + rank))
-    blues = simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": 1}, mover)
-    sim.context.setVelocities(vel)
-    return system, vel, sim, blues
+    chains = []
+    for c in range(R):
+        gid = rank * R + c   # global chain index
+        integ = integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=DT_PS, temperature=300.0, seed=replica_seed(1234, gid))
+        sim = Simulation(None, system, integ, device=local_rank, precision="mixed", replica=gid)
+        mover = moves.MoveEngine(moves.RandomLigandRotationMove(lig, system.mass[lig], random_state=1000 + gid))
+        chains.append(simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": 1}, mover))
+    return system, vel, chains
 
 
-def one_switch(blues, sim, x0, v0, nsteps, it):
-    from blues_amd.replicas import gather_decisions
-    sim.context.setPositions(x0)
-    sim.context.setVelocities(v0)
-    blues.currentIter = it
-    blues._syncStatesMDtoNCMC()
-    blues._stepNCMC(nsteps, nsteps // 2)
-    blues._acceptRejectMove()
-    rec = gather_decisions(blues.last["accept"], it, blues.last["log_accept"], blues.last["protocol_work"], blues.last["correction"])
-    blues._resetSimulations(300.0)
-    return rec
+def one_switch(driver, chains, x0, v0, nsteps, it, clock):
+    """One BLUES iteration's NCMC leg for every chain: upload -> sync -> switch -> Metropolis -> gather -> reset."""
+    from blues_amd.replicas import gather_decision_block
+    t0 = time.perf_counter()
+    for c in chains:
+        c._ncmc_sim.context.setPositions(x0)
+        c._ncmc_sim.context.setVelocities(v0)
+        c.currentIter = it
+        c._syncStatesMDtoNCMC()
+    t1 = time.perf_counter()
+    if driver is None:
+        chains[0]._stepNCMC(nsteps, nsteps // 2)
+    else:
+        driver._stepNCMC(nsteps, nsteps // 2)
+    t2 = time.perf_counter()
+    for c in chains:
+        c._acceptRejectMove()
+    recs = gather_decision_block([[c.last["accept"], it, c.last["log_accept"], c.last["protocol_work"], c.last["correction"]] for c in chains])
+    for c in chains:
+        c._resetSimulations(300.0)
+    t3 = time.perf_counter()
+    clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2
+    return recs
 
 
 def cpu_baseline(system, vel, nsteps_sample):
@@ -75,20 +94,34 @@ def cpu_baseline(system, vel, nsteps_sample):
             "sample": "%d NCMC steps of the same S23k switch (3 full fp64 energy/force evaluations per step), %.1f s" % (nsteps_sample, dt)}
 
 
+def pmc_traffic(workload, R):
+    """HBM-side bytes per launch of the nonbonded kernel from separate rocprofv3 --pmc passes (profiles/README.md)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        key = "%s_R%d" % (workload, R) if R > 1 else workload
+        return pmc[key]["traffic_bytes_per_launch"] if key in pmc else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--replicas", type=int, default=128, help="independent chains per GPU, advanced as one replica batch")
     ap.add_argument("--nsteps-nc", type=int, default=NSTEPS_NC)
     ap.add_argument("--workload", default="rotmove", choices=["rotmove", "water"])
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-chain measurement")
     args = ap.parse_args()
 
     from blues_amd import build
     build.build_engine()
     import torch
+    from blues_amd import simulation
     from blues_amd.replicas import env_rank, init_process_group
     rank, local_rank, world = env_rank()
     if world > 1:
@@ -101,59 +134,81 @@ def main():
         torch.cuda.synchronize()
 
     torch.cuda.set_device(local_rank)
-    nsteps = args.nsteps_nc
-    system, vel, sim, blues = build_replica(rank, local_rank, nsteps, args.workload)
+    nsteps, R = args.nsteps_nc, max(1, args.replicas)
+    t_setup = time.perf_counter()
+    system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R)
     x0 = system.positions.copy()
     v0 = vel.copy()
+
+    # ---- configs[1] to the letter: ONE chain on the GPU (before the batch exists, so it runs with a lone engine's layout)
+    single = None
+    if rank == 0 and not args.no_single:
+        clock = {"sync": 0.0, "switch": 0.0, "decide": 0.0}
+        one_switch(None, chains[:1], x0, v0, nsteps, 0, clock)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(2):
+            one_switch(None, chains[:1], x0, v0, nsteps, k, clock)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t0) / 2
+        e1 = chains[0]._ncmc_sim.context._engine
+        k1_single = e1.time_nonbonded(50)
+        a1 = ALGO_BYTES_PER_ATOM * system.n_atoms / (k1_single * 1e-6) / 1e9
+        single = {"value": nsteps * DT_PS * 1e-3 / (dt1 / 86400.0), "unit": "ns/day", "ms_per_switch": 1e3 * dt1,
+                  "roofline": {"bound": "hbm", "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
+                               "traffic": pmc_traffic(args.workload, 1), "usec_per_launch": k1_single}}
+
+    driver = simulation.BatchedBLUESSimulation(chains)
+    t_setup = time.perf_counter() - t_setup
+    clock = {"sync": 0.0, "switch": 0.0, "decide": 0.0}
     for w in range(args.warmup):
-        one_switch(blues, sim, x0, v0, nsteps, w)
-    eng = sim.context._engine
-    st0 = eng.stats()
+        one_switch(driver, chains, x0, v0, nsteps, w, clock)
+    engs = [c._ncmc_sim.context._engine for c in chains]
+    st0 = engs[0].stats(); b0 = driver._ncmc_batch.stats()
+    clock = {"sync": 0.0, "switch": 0.0, "decide": 0.0}
     barrier()
     t0 = time.perf_counter()
     recs = []
     for k in range(args.steps):
-        recs.append(one_switch(blues, sim, x0, v0, nsteps, k))
+        recs.append(one_switch(driver, chains, x0, v0, nsteps, k, clock))
     barrier()
     elapsed = time.perf_counter() - t0
-    st1 = eng.stats()
+    st1 = engs[0].stats(); b1 = driver._ncmc_batch.stats()
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
     # the kernel north_star prices against the HBM roofline: the direct-space nonbonded kernel, timed alone with HIP
-    # events on the engine's own stream (blues_time_nonbonded)
-    k1_us = eng.time_nonbonded(50)
-    traffic = None
-    try:  # HBM-side bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md says how they were taken)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            pmc = json.load(fh).get(args.workload)
-        if pmc:
-            traffic = pmc["traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    # events on the batch's own stream; one launch processes all R chains of this rank
+    k1_us = driver._ncmc_batch.time_nonbonded(50)
     if rank == 0:
         n_atoms = system.n_atoms
         ms_per_step = 1e3 * elapsed / args.steps
-        ns_day = world * args.steps * nsteps * DT_PS * 1e-3 / (elapsed / 86400.0)
-        achieved = ALGO_BYTES_PER_ATOM * n_atoms / (k1_us * 1e-6) / 1e9
+        ns_day = world * R * args.steps * nsteps * DT_PS * 1e-3 / (elapsed / 86400.0)
+        algo = ALGO_BYTES_PER_ATOM * n_atoms * R
+        achieved = algo / (k1_us * 1e-6) / 1e9
+        last = np.asarray(recs[-1])
         out = {
-            "metric": "NCMC ns/day (23k-atom toluene box, 1000-step switch, RandomLigandRotationMove)",
+            "metric": "NCMC ns/day (23k-atom toluene box, 1000-step switch, RandomLigandRotationMove), aggregate over independent chains",
             "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 pair math / f64 accumulation, f64 alchemical+integrator", "data": "synthetic",
-            "config": {"workload": "S23k %s: %d atoms, %d mobile, 15 alchemical, nstepsNC=%d, dt=4fs, 1 replica per GPU"
-                       % (args.workload, n_atoms, int((system.mass > 0).sum()), nsteps),
-                       "parallelism": "replica-per-gpu x%d" % world},
+            "config": {"workload": "S23k %s: %d atoms, %d mobile, 15 alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in one replica batch"
+                       % (args.workload, n_atoms, int((system.mass > 0).sum()), nsteps, R),
+                       "replicas_per_gpu": R, "parallelism": "replica-batch x%d per gpu, %d gpu(s)" % (R, world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_nonbonded (direct-space LJ + erfc Coulomb)", "usec_per_launch": k1_us,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ATOM * n_atoms},
-            "engine": {"force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,
-                       "kernel_launches_per_switch": (st1["kernel_launches"] - st0["kernel_launches"]) / args.steps,
+                         "traffic": pmc_traffic(args.workload, R), "kernel": "k_nonbonded*_b (direct-space LJ + erfc Coulomb), one launch = %d chains" % R,
+                         "usec_per_launch": k1_us, "algorithmic_bytes_per_launch": algo},
+            "single_replica": single,
+            "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup,
+                       "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,
                        "list_rebuilds_per_switch": (st1["list_generation"] - st0["list_generation"]) / args.steps,
-                       "i_tiles": st1["i_tiles"], "clusters": st1["clusters"], "jcap": st1["jcap"], "npart": st1["npart"], "seg_len": st1["seg_len"], "wpb": st1["wpb"]},
-            "accept_records_last": np.asarray(recs[-1]).tolist(),
+                       "lockstep_steps_per_switch": (b1["lockstep_steps"] - b0["lockstep_steps"]) / args.steps,
+                       "fallback_steps_per_switch": (b1["fallback_steps"] - b0["fallback_steps"]) / args.steps,
+                       "i_tiles": st1["i_tiles"], "clusters": st1["clusters"], "jcap": st1["jcap"], "max_jcount": st1["max_jcount"]},
+            "accept_records_last": {"chains": int(last.shape[0]), "accepted": int(last[:, 0].sum()),
+                                    "mean_protocol_work_kj": float(np.nanmean(last[:, 3])), "first": last[0].tolist()},
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(system, vel, args.cpu_steps)

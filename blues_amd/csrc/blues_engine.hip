@@ -34,9 +34,11 @@ static thread_local std::string g_create_error;
 
 template <typename T> struct DBuf {
     T* p = nullptr; size_t n = 0;
-    void alloc(size_t count) {
-        release(); n = count;
-        if (hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::string("hipMalloc failed");
+    void alloc(size_t count) {   // zero-filled; an existing buffer of the right size is reused (a re-sort keeps every address)
+        if (!p || count != n) {
+            release(); n = count;
+            if (hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::string("hipMalloc failed");
+        }
         hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
     }
     void upload(const std::vector<T>& h) {
@@ -115,6 +117,7 @@ struct BluesEngine {
     std::vector<double> hx;        // host copy of the last positions handed in (caller order, [n][3])
     std::vector<double> hx_sort;   // positions at the last sort
     double e_frozen[2] = {0, 0}; bool e_frozen_valid = false;
+    double e_cache = 0, e_cache_ls = 0, e_cache_le = 0; bool e_cache_valid = false;  // total potential energy at the current positions
     // ---- derived topology
     std::vector<int> mobile;       // caller indices with mass > 0
     std::vector<HostCluster> clusters;
@@ -171,6 +174,7 @@ struct BluesBatch {
     std::vector<char> failed;           // per call: members whose host-side stepping raised an error
     std::vector<char> active, rec_active;  // caller's mask (blues_batch_set_active) / what the device records currently say
     std::vector<uint64_t> seen_epoch;
+    std::vector<unsigned> rec_delta; BluesEngine* rec_leader = nullptr;   // what the device records currently say
     BluesEngine* leader = nullptr;
     bool lockstep = false;
     DBuf<RepNb<float>> d_nb_f; DBuf<RepNb<double>> d_nb_d; DBuf<RepCore> d_core;
@@ -382,7 +386,7 @@ static int sort_and_tile(BluesEngine* h) {
     // Verlet skin: a small i-set is latency-bound (longer j-lists cost nothing, rebuilds do); a large one is
     // throughput-bound (every extra j costs pair evaluations)
     if (!h->skin_from_env) {
-        h->skin = h->n_itiles <= 32 ? 0.3 : 0.12;
+        h->skin = h->n_itiles * h->batch_R <= 32 ? 0.3 : 0.12;  // batch_R: a large batch is throughput-bound like a large i-set
         for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) h->skin = std::max(0.0, 0.5 * h->box[k] - h->cutoff - 1e-6);
     }
     // capacities
@@ -526,6 +530,7 @@ static IntArgs make_int_args(BluesEngine* h) {
 
 static int flush_program(BluesEngine* h) {
     if (h->prog.n == 0) return 0;
+    h->e_cache_valid = false;   // the launch may move atoms
     IntArgs A = make_int_args(h);
     // the steady-state program of "H V R O R V H" has a straight-line specialisation (same arithmetic)
     static const unsigned char P_CM[9] = {OP_V0, OP_H01, OP_END, OP_CM_PART, OP_H12, OP_V2, OP_R, OP_O, OP_R};
@@ -919,10 +924,15 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
     return 0;
 }
 
+// OpenMM caches the energy of a Context until positions or parameters change; BLUES leans on that (state0 / state1 /
+// the alchemical-correction energies of one switch are evaluated at only two distinct states, simulation.py:1056-1119)
 static int total_energy(BluesEngine* h, double* E) {
+    if (flush_program(h)) return 1;
+    if (h->e_cache_valid && h->e_cache_ls == h->cur_ls && h->e_cache_le == h->cur_le) { *E = h->e_cache; return 0; }
     double T[BLUES_N_ENERGY_TERMS];
     if (energy_terms(h, T)) return 1;
     *E = 0.0; for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) *E += T[t];
+    h->e_cache = *E; h->e_cache_ls = h->cur_ls; h->e_cache_le = h->cur_le; h->e_cache_valid = true;
     return 0;
 }
 
@@ -1152,7 +1162,9 @@ static BatchSig batch_sig(const BluesEngine* h) {
     BatchSig g; memset(&g, 0, sizeof g);
     g.h_step = h->h_step; g.h_lambda_step = h->h_lambda_step; g.h_prop = h->h_prop; g.h_first_step = h->h_first_step; g.pass_L = h->pass_valid ? h->pass_L : 0;
     g.prog_n = h->prog.n; g.prog_trace = h->prog_trace; g.nprop = h->nprop;
-    g.h_draw = h->h_draw; g.prog_draw_base = h->prog.n ? h->prog_draw_base : 0; g.noise_draw_base = h->noise_valid ? h->noise_draw_base : 0;
+    // draw counters enter relative to h_draw: members may have drawn different amounts of noise in the past (the records
+    // carry each member's offset to the leader, RepCore.draw_delta), what must agree is where they stand within the step
+    g.h_draw = 0; g.prog_draw_base = h->prog.n ? h->h_draw - h->prog_draw_base : 0; g.noise_draw_base = h->noise_valid ? h->h_draw - h->noise_draw_base : 0;
     g.pass_valid = h->pass_valid; g.lists_forced = h->lists_forced; g.vel_clean = h->vel_clean; g.noise_valid = h->noise_valid; g.tracing = h->tracing;
     g.sorted_ok = h->sorted_ok; g.pass_valid_for_l = h->pass_valid_for_l; g.have_positions = h->have_positions;
     for (int q = 0; q < h->prog.n; q++) g.ops[q] = h->prog.ops[q];
@@ -1178,7 +1190,9 @@ static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const ch
 
 static int batch_refresh_args(BluesBatch* B) {
     bool dirty = false;
-    for (int r = 0; r < B->R(); r++) dirty |= B->seen_epoch[r] != B->eng[r]->args_epoch || B->rec_active[r] != (char)(B->active[r] && !B->failed[r]);
+    BluesEngine* lead = B->leader ? B->leader : B->eng[0];
+    for (int r = 0; r < B->R(); r++) dirty |= B->seen_epoch[r] != B->eng[r]->args_epoch || B->rec_active[r] != (char)(B->active[r] && !B->failed[r])
+                                              || (!B->failed[r] && B->rec_delta[r] != B->eng[r]->h_draw - lead->h_draw);
     if (!dirty) return 0;
     const double one[3] = {1.0, 1.0, 1.0};
     std::vector<RepCore> core(B->R()); std::vector<RepNb<float>> nf; std::vector<RepNb<double>> nd;
@@ -1188,6 +1202,7 @@ static int batch_refresh_args(BluesBatch* B) {
         BluesEngine* h = B->eng[r];
         B->rec_active[r] = (char)(B->active[r] && !B->failed[r]);
         core[r].active = B->rec_active[r];
+        B->rec_delta[r] = h->h_draw - lead->h_draw; core[r].draw_delta = B->rec_delta[r];
         if (single) nf[r].active = B->rec_active[r]; else nd[r].active = B->rec_active[r];
         if (!h->sorted_ok) { core[r].active = 0; if (single) nf[r].active = 0; else nd[r].active = 0; continue; }  // buffers not laid out (its sort failed): never touched
         core[r].al = make_alch_args(h, one, one, 7); core[r].bo = make_bonded_args(h); core[r].fin = make_fin_args(h, one); core[r].in = make_int_args(h);
@@ -1221,9 +1236,10 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
     }
     if (batch_refresh_args(B)) return 1;
     // phase(f): run f on every live member, in lock step when their signatures agree
-    auto phase = [&](int (*f)(BluesEngine*)) {
+    auto phase = [&](int (*f)(BluesEngine*)) -> int {
         pick_leader();
-        if (!B->leader) return;
+        if (!B->leader) return 0;
+        if (batch_refresh_args(B)) return 1;   // leader change, a member dropped out, a re-sort: cheap no-op otherwise
         const BatchSig lead = batch_sig(B->leader);
         bool uniform = true;
         for (int r = 0; r < R && uniform; r++) if (!B->failed[r]) { const BatchSig g = batch_sig(B->eng[r]); uniform = !memcmp(&g, &lead, sizeof g); }
@@ -1240,15 +1256,15 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
             for (int r = 0; r < R; r++) if (!B->failed[r] && f(B->eng[r])) fail(r);
             B->st_fallback_steps++;
         }
+        return 0;
     };
     for (int s = 0; s < n_steps; s++) {
         // same cadence as a lone engine (keyed on each member's own step counter, so results stay identical to solo runs)
         for (int r = 0; r < R; r++) if (!B->failed[r] && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0 && poll_resort(B->eng[r])) fail(r);
         for (int r = 0; r < R; r++) if (!B->failed[r] && step_head(B->eng[r])) fail(r);
-        if (batch_refresh_args(B)) return 1;   // a head may have re-sorted (it cannot today; cheap to keep correct)
-        phase(step_body);
+        if (phase(step_body)) return 1;
     }
-    phase(flush_program);
+    if (phase(flush_program)) return 1;
     for (int r = 0; r < R; r++) B->eng[r]->tracing = false;
     B->leader = B->eng[0];
     for (int r = 0; r < R; r++) if (!B->failed[r] && check_flags(B->eng[r])) fail(r);
@@ -1417,7 +1433,7 @@ int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
             h->hx[3 * c.atoms[a] + k] -= h->box[k] * std::nearbyint(d / h->box[k]);
         }
     if (upload_xyz(h, h->hx.data(), h->d_x)) return 1;
-    h->have_positions = true; h->x_edited = true; h->pass_valid = false;
+    h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->e_cache_valid = false;
     if (frozen_moved) h->e_frozen_valid = false;
     // re-sort when never sorted or when atoms have drifted far from where the tiles were formed
     bool resort = !h->sorted_ok;
@@ -1431,7 +1447,9 @@ int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
             if (h->mass[i] != 0.0 && h->alch_local[i] < 0) worst_i = std::max(worst_i, d2);
             if (d2 > 0.5 * 0.5) far++;
         }
-        resort = worst_i > 0.4 * 0.4 || far > h->n / 10;
+        // a few wandering i-atoms only stretch their tile's bounding box, and the device notices when that starts to cost
+        // (resort_hint); the host re-sorts when an i-atom is far out or a sizeable part of the system has moved
+        resort = worst_i > 1.0 * 1.0 || far > h->n / 10;
     }
     if (resort) { h->sorted_ok = false; if (sort_and_tile(h)) return 1; }
     else {
@@ -1461,7 +1479,7 @@ int blues_set_box(BluesEngine* h, const double box[9]) {
     HIP_OK(h, hipStreamSynchronize(h->stream));
     h->box[0] = box[0]; h->box[1] = box[4]; h->box[2] = box[8];
     for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) E_FAIL(h, "box edge %g < 2*(cutoff+skin)", h->box[k]);
-    h->sorted_ok = false; h->pass_valid = false; h->e_frozen_valid = false;
+    h->sorted_ok = false; h->pass_valid = false; h->e_frozen_valid = false; h->e_cache_valid = false;
     if (h->have_positions) { if (download_xyz(h, h->hx.data(), h->d_x)) return 1; return sort_and_tile(h); }
     return 0;
 }
@@ -1688,7 +1706,7 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
         m->use_graph = false;  // graph replays carry per-engine frozen arguments
     }
     for (int r = 0; r < count; r++) if (relayout(engines[r])) { g_batch_create_error = "re-layout for the batch failed: " + engines[r]->err; batch_detach_all(B); delete B; return 1; }
-    B->seen_epoch.assign(count, 0); B->failed.assign(count, 0); B->active.assign(count, 1); B->rec_active.assign(count, 0); B->leader = engines[0];
+    B->seen_epoch.assign(count, 0); B->failed.assign(count, 0); B->active.assign(count, 1); B->rec_active.assign(count, 0); B->rec_delta.assign(count, 0); B->leader = engines[0];
     *out = B;
     return 0;
 }

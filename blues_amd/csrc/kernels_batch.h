@@ -20,6 +20,7 @@ template <typename R> struct RepNb {   // precision-dependent part of a replica'
 };
 struct RepCore {
     int active;
+    unsigned draw_delta;   // this member's O-substep draw counter minus the leader's (constant while they advance in lock step)
     AlchArgs al; BondedArgs bo; FinArgs fin; IntArgs in;
 };
 
@@ -33,14 +34,14 @@ __device__ __forceinline__ void apply_dyn(AlchArgs& A, const AlchDyn& d) {
     for (int s = 0; s < 3; s++) { A.ls[s] = d.ls[s]; A.le[s] = d.le[s]; }
     A.slot_mask = d.slot_mask; A.ctrl = nullptr;
 }
-__device__ __forceinline__ void apply_dyn(BondedArgs& B, const BondedDyn& d) { B.draw_base = d.draw_base; B.n_entry_blocks = d.n_entry_blocks; B.ctrl = nullptr; }
+__device__ __forceinline__ void apply_dyn(BondedArgs& B, const BondedDyn& d, unsigned delta) { B.draw_base = d.draw_base + delta; B.n_entry_blocks = d.n_entry_blocks; B.ctrl = nullptr; }
 __device__ __forceinline__ void apply_dyn(FinArgs& F, const FinDyn& d) {
 #pragma unroll
     for (int s = 0; s < 3; s++) F.le[s] = d.le[s];
     F.slot_mask = d.slot_mask; F.ctrl = nullptr;
 }
-__device__ __forceinline__ void apply_dyn(IntArgs& A, const IntDyn& d) {
-    A.draw_base = d.draw_base; A.noise_draw_base = d.noise_draw_base; A.n_noise = d.n_noise; A.trace_index = d.trace_index;
+__device__ __forceinline__ void apply_dyn(IntArgs& A, const IntDyn& d, unsigned delta) {
+    A.draw_base = d.draw_base + delta; A.noise_draw_base = d.noise_draw_base + delta; A.n_noise = d.n_noise; A.trace_index = d.trace_index;
     if (!d.tracing) A.work_trace = nullptr;
     A.ctrl = nullptr;
 }
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) k_alchemical_b(const RepCore* __restrict_
 
 __global__ void __launch_bounds__(128) k_bonded_entries_b(const RepCore* __restrict__ reps, BondedDyn d) {
     if (!reps[blockIdx.y].active) return;
-    BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, d);
+    BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, d, reps[blockIdx.y].draw_delta);
     bonded_entries_body(B, blockIdx.x, 128);
 }
 
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(256) k_forces_fused_b(const RepNb<R>* __restri
         return;
     }
     if (b < nb1 + nb2) { AlchArgs A = reps[blockIdx.y].al; apply_dyn(A, da); alchemical_body<sizeof(R) == 4>(A, b - nb1); return; }
-    BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, db);
+    BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, db, reps[blockIdx.y].draw_delta);
     bonded_entries_body(B, b - nb1 - nb2, 256);
 }
 
@@ -114,26 +115,26 @@ __global__ void __launch_bounds__(256) k_forces_fused_sub_b(const RepNb<float>* 
         nonbonded_sub_body<false, IW>(a, c, rp.img, b - nb2);
         return;
     }
-    BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, db);
+    BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, db, reps[blockIdx.y].draw_delta);
     bonded_entries_body(B, b - nb1 - nb2, 256);
 }
 
 __global__ void __launch_bounds__(256) k_integrate_b(const RepCore* __restrict__ reps, IntDyn d) {
     if (!reps[blockIdx.y].active) return;
-    IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d);
+    IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d, reps[blockIdx.y].draw_delta);
     integrate_body(A, d.prog);
 }
 
 template <bool CM>
 __global__ void __launch_bounds__(256) k_step_default_b(const RepCore* __restrict__ reps, IntDyn d) {
     if (!reps[blockIdx.y].active) return;
-    IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d);
+    IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d, reps[blockIdx.y].draw_delta);
     step_default_body<CM>(A);
 }
 
 template <bool CM>
 __global__ void __launch_bounds__(256) k_step_md_b(const RepCore* __restrict__ reps, IntDyn d) {
     if (!reps[blockIdx.y].active) return;
-    IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d);
+    IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d, reps[blockIdx.y].draw_delta);
     step_md_body<CM>(A);
 }

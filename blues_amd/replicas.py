@@ -55,6 +55,22 @@ def gather_decisions(accept, iteration, log_accept, protocol_work, correction=0.
     return torch.stack(out).cpu().numpy()
 
 
+def gather_decision_block(records, device=None):
+    """The same exchange for a rank that runs several chains in one replica batch: `records` is (R, 5) (RECORD_FIELDS per
+    chain); every rank receives the (world * R, 5) array, rank-major.  Still one collective per BLUES iteration."""
+    import torch
+    import torch.distributed as dist
+    rec = torch.as_tensor(np.asarray(records, dtype=np.float64).reshape(-1, len(RECORD_FIELDS)))
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec.numpy()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    rec = rec.to(device)
+    out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, rec)
+    return torch.cat(out).cpu().numpy()
+
+
 def acceptance_summary(records):
     r = np.asarray(records, dtype=np.float64).reshape(-1, len(RECORD_FIELDS))
     return {"replicas": int(r.shape[0]), "accepted": int(r[:, 0].sum()), "mean_log_accept": float(np.nanmean(r[:, 2])),

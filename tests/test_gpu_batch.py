@@ -287,3 +287,30 @@ def test_batched_blues_driver_matches_separate_chains(Engine, tol_box, same_deco
         assert np.array_equal(sep[r]._ncmc_sim.context._engine.get_positions(), bat[r]._ncmc_sim.context._engine.get_positions())
         assert sep[r].accept == bat[r].accept and sep[r].reject == bat[r].reject
     B.close()
+
+
+def test_members_with_different_histories_still_share_launches(Engine, tol_box, same_decomposition):
+    """A member that has stepped before joining (its noise draw counter is ahead) advances in lock step all the same: the
+    records carry its offset.  Joining re-sorts a member at its current positions, so the member with a past agrees with
+    its solo continuation to summation-order rounding (fp64 mode); the fresh members bit for bit."""
+    from blues_amd.engine import NativeBatch
+    s, v = tol_box
+    R, n = 3, 10
+    vels = _replica_inputs(s, v, R)
+    solo = _make(Engine, s, vels, n, 1)
+    bat = _make(Engine, s, vels, n, 1)
+    for g in (solo[1], bat[1]):        # member 1 has a past: one full protocol, then reset
+        g.step(n); g.reset()
+    for g in solo:
+        g.step(n)
+    B = NativeBatch(bat)
+    B.step(n)
+    st = B.stats()   # the first step differs in more than the counter (member 1 already holds lists and noise): it falls back, the rest is shared
+    assert st["fallback_steps"] <= 2 and st["lockstep_steps"] >= n - 2
+    for r in range(R):
+        xs, vs, w_s = _state(solo[r]); xb, vb, w_b = _state(bat[r])
+        if r == 1:
+            assert np.abs(xs - xb).max() < 1e-10 and np.abs(vs - vb).max() < 1e-8 and w_s == pytest.approx(w_b, rel=1e-9, abs=1e-9)
+        else:
+            assert np.array_equal(xs, xb) and np.array_equal(vs, vb) and w_s == w_b, r
+    B.close()

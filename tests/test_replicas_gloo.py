@@ -19,6 +19,10 @@ def _worker(rank, world, port, out_q):
     assert (r, w) == (rank, world)
     seed = replicas.replica_seed(1234, rank)
     recs = replicas.gather_decisions(accept=(rank == 1), iteration=7, log_accept=-1.5 * (rank + 1), protocol_work=10.0 + rank, correction=0.25)
+    # several chains per rank (a replica batch): one (R, 5) block per rank, gathered rank-major
+    block = np.array([[float(c == rank), 7.0, -0.5 * (3 * rank + c + 1), 20.0 + 3 * rank + c, 0.0] for c in range(3)])
+    blk = replicas.gather_decision_block(block)
+    assert blk.shape == (3 * world, 5) and blk[:, 3].tolist() == [20.0 + i for i in range(3 * world)]
     out_q.put((rank, seed, np.asarray(recs).tolist()))
     dist.barrier()
     dist.destroy_process_group()
@@ -51,3 +55,4 @@ def test_single_process_gather_needs_no_group():
     rec = replicas.gather_decisions(True, 0, -0.5, 3.0)
     assert rec.shape == (1, 5) and rec[0, 0] == 1.0
     assert replicas.replica_seed(1, 0) != replicas.replica_seed(1, 1) != replicas.replica_seed(2, 1)
+    assert replicas.gather_decision_block(np.zeros((4, 5))).shape == (4, 5)
