@@ -56,23 +56,24 @@ def build_chains(rank, local_rank, nsteps, workload, R):
 def one_switch(driver, chains, x0, v0, nsteps, it, clock):
     """One BLUES iteration's NCMC leg for every chain: upload -> sync -> switch -> Metropolis -> gather -> reset."""
     from blues_amd.replicas import gather_decision_block
-    t0 = time.perf_counter()
-    for c in chains:
+    each = driver.for_each_chain if driver is not None else (lambda fn: [fn(r, c) for r, c in enumerate(chains)])
+
+    def sync(r, c):
         c._ncmc_sim.context.setPositions(x0)
         c._ncmc_sim.context.setVelocities(v0)
         c.currentIter = it
         c._syncStatesMDtoNCMC()
+    t0 = time.perf_counter()
+    each(sync)
     t1 = time.perf_counter()
     if driver is None:
         chains[0]._stepNCMC(nsteps, nsteps // 2)
     else:
         driver._stepNCMC(nsteps, nsteps // 2)
     t2 = time.perf_counter()
-    for c in chains:
-        c._acceptRejectMove()
+    each(lambda r, c: c._acceptRejectMove())
     recs = gather_decision_block([[c.last["accept"], it, c.last["log_accept"], c.last["protocol_work"], c.last["correction"]] for c in chains])
-    for c in chains:
-        c._resetSimulations(300.0)
+    each(lambda r, c: c._resetSimulations(300.0))
     t3 = time.perf_counter()
     clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2
     return recs
@@ -111,6 +112,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--replicas", type=int, default=128, help="independent chains per GPU, advanced as one replica batch")
+    ap.add_argument("--workers", type=int, default=16, help="host threads for the per-chain plugin-boundary work")
     ap.add_argument("--nsteps-nc", type=int, default=NSTEPS_NC)
     ap.add_argument("--workload", default="rotmove", choices=["rotmove", "water"])
     ap.add_argument("--cpu-steps", type=int, default=12)
@@ -158,7 +160,7 @@ def main():
                   "roofline": {"bound": "hbm", "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
                                "traffic": pmc_traffic(args.workload, 1), "usec_per_launch": k1_single}}
 
-    driver = simulation.BatchedBLUESSimulation(chains)
+    driver = simulation.BatchedBLUESSimulation(chains, workers=args.workers)
     t_setup = time.perf_counter() - t_setup
     clock = {"sync": 0.0, "switch": 0.0, "decide": 0.0}
     for w in range(args.warmup):
@@ -196,7 +198,7 @@ def main():
             "dtype": "f32 pair math / f64 accumulation, f64 alchemical+integrator", "data": "synthetic",
             "config": {"workload": "S23k %s: %d atoms, %d mobile, 15 alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in one replica batch"
                        % (args.workload, n_atoms, int((system.mass > 0).sum()), nsteps, R),
-                       "replicas_per_gpu": R, "parallelism": "replica-batch x%d per gpu, %d gpu(s)" % (R, world)},
+                       "replicas_per_gpu": R, "host_workers": args.workers, "parallelism": "replica-batch x%d per gpu, %d gpu(s)" % (R, world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload, R), "kernel": "k_nonbonded*_b (direct-space LJ + erfc Coulomb), one launch = %d chains" % R,
                          "usec_per_launch": k1_us, "algorithmic_bytes_per_launch": algo},

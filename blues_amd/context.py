@@ -14,8 +14,9 @@ class State(object):
     """Result of Context.getState (reference blues/simulation.py:904-910)."""
 
     def __init__(self, positions=None, velocities=None, forces=None, potential=None, kinetic=None, box=None, time=0.0,
-                 parameters=None):
+                 parameters=None, snapshot=None):
         self._x, self._v, self._f, self._pe, self._ke, self._box, self._t, self._par = positions, velocities, forces, potential, kinetic, box, time, parameters
+        self._snap = snapshot   # positions / velocities still on the device (engine.DeviceSnapshot); downloaded on demand
 
     @staticmethod
     def _need(v, what):
@@ -24,10 +25,16 @@ class State(object):
         return v
 
     def getPositions(self, asNumpy=False):
+        if self._snap is not None and (self._snap.what & 1):
+            if asNumpy:
+                return unit.DeviceQuantity(self._snap, 1, "nanometer")
+            return unit.Quantity([tuple(r) for r in self._snap.read(1)], "nanometer")
         x = self._need(self._x, "getPositions()")
         return unit.Quantity(x if asNumpy else [tuple(r) for r in x], "nanometer") if not asNumpy else unit.Quantity(x, "nanometer")
 
     def getVelocities(self, asNumpy=False):
+        if self._snap is not None and (self._snap.what & 2):
+            return unit.DeviceQuantity(self._snap, 2, "nanometer/picosecond")
         return unit.Quantity(self._need(self._v, "getVelocities()"), "nanometer/picosecond")
 
     def getForces(self, asNumpy=False):
@@ -83,8 +90,12 @@ class Context(object):
                  enforcePeriodicBox=False, groups=-1):
         """context.getState(...) (reference blues/simulation.py:905, blues/moves.py:292, positional form moves.py:1218)."""
         e = self._engine
-        x = e.get_positions() if getPositions else None
-        v = e.get_velocities() if getVelocities else None
+        x = v = snap = None
+        if (getPositions or getVelocities) and hasattr(e, "snapshot"):
+            snap = e.snapshot(positions=bool(getPositions), velocities=bool(getVelocities))   # stays in HBM until somebody reads it
+        else:
+            x = e.get_positions() if getPositions else None
+            v = e.get_velocities() if getVelocities else None
         f = e.get_forces() if getForces else None
         pe = ke = None
         if getEnergy:
@@ -92,15 +103,23 @@ class Context(object):
         par = None
         if getParameters:
             par = {"lambda_sterics": e.get_global("lambda_sterics"), "lambda_electrostatics": e.get_global("lambda_electrostatics")}
-        return State(x, v, f, pe, ke, e.get_box(), self._time, par)
+        return State(x, v, f, pe, ke, e.get_box(), self._time, par, snapshot=snap)
 
     def setPositions(self, positions):
         """reference blues/simulation.py:960, blues/moves.py:307"""
-        self._engine.set_positions(unit.value_in(positions, "nanometer"))
+        snap = positions.on_device() if isinstance(positions, unit.DeviceQuantity) else None
+        if snap is not None and hasattr(self._engine, "set_positions_from_snapshot"):
+            self._engine.set_positions_from_snapshot(snap)   # a State handed back unchanged: device-to-device
+        else:
+            self._engine.set_positions(unit.value_in(positions, "nanometer"))
 
     def setVelocities(self, velocities):
         """reference blues/simulation.py:962"""
-        self._engine.set_velocities(unit.value_in(velocities, "nanometer/picosecond"))
+        snap = velocities.on_device() if isinstance(velocities, unit.DeviceQuantity) else None
+        if snap is not None and hasattr(self._engine, "set_velocities_from_snapshot"):
+            self._engine.set_velocities_from_snapshot(snap)
+        else:
+            self._engine.set_velocities(unit.value_in(velocities, "nanometer/picosecond"))
 
     def setPeriodicBoxVectors(self, a, b, c):
         """reference blues/simulation.py:958"""

@@ -76,6 +76,17 @@ static uint32_t hilbert3(uint32_t x, uint32_t y, uint32_t z, int bits) {
 }
 
 struct BluesBatch;
+struct BluesEngine;
+
+// openmm.State as BLUES uses it (simulation.py:883-911, 938-963): a copy of positions and velocities taken at one
+// moment, handed back later to setPositions / setVelocities.  Kept in HBM; the host sees it only if it asks.
+struct BluesSnapshot {
+    BluesEngine* owner = nullptr;
+    int n = 0; bool has_x = false, has_v = false;
+    double* x[3] = {nullptr, nullptr, nullptr}; double* v[3] = {nullptr, nullptr, nullptr};
+    double* block = nullptr;   // one allocation: x[0..2], v[0..2]
+    bool e_valid = false; double e = 0, e_ls = 0, e_le = 0;   // potential energy of the captured positions, if it was known
+};
 
 struct BluesEngine {
     std::string err;
@@ -114,7 +125,8 @@ struct BluesEngine {
     double h_perturbed = 0, h_unperturbed = 0; bool unpert_valid = false, x_edited = false;
     bool pass_valid = false; int pass_L = 0, pass_fmask = 7;
     bool have_positions = false, sorted_ok = false, lists_forced = true;
-    std::vector<double> hx;        // host copy of the last positions handed in (caller order, [n][3])
+    std::vector<double> hx;        // host copy of the positions the tiles were last laid out from (caller order, [n][3])
+    std::vector<double> h_stage;   // staging for host transfers
     std::vector<double> hx_sort;   // positions at the last sort
     double e_frozen[2] = {0, 0}; bool e_frozen_valid = false;
     double e_cache = 0, e_cache_ls = 0, e_cache_le = 0; bool e_cache_valid = false;  // total potential energy at the current positions
@@ -130,6 +142,9 @@ struct BluesEngine {
     double total_mass = 0;
     // ---- device buffers
     DBuf<double> d_x[3], d_v[3], d_xbuild[3], d_mass, d_charge, d_sigma, d_eps;
+    DBuf<double> d_x_sort[3], d_stage;   // positions at the last spatial sort; [n][3] staging for host transfers
+    DBuf<unsigned> d_xfer_out;
+    std::vector<struct BluesSnapshot*> snap_pool;   // released snapshots, reused (hipMalloc per getState would dominate)
     DBuf<AtomF> d_img_f; DBuf<AtomD> d_img_d;
     DBuf<int> d_sorted_of_orig, d_orig_of_sorted, d_tile_atoms, d_jlist, d_jstage, d_jcount, d_batch_slot, d_pool_count, d_ex_start, d_ex_idx, d_islot;
     DBuf<unsigned long long> d_mask_pool;
@@ -154,6 +169,7 @@ struct BluesEngine {
     std::vector<int> h_sorted_of_orig, h_orig_of_sorted;
 
     ~BluesEngine() {
+        for (BluesSnapshot* sn : snap_pool) { if (sn->block) hipFree(sn->block); delete sn; }
         if (gexec) hipGraphExecDestroy(gexec);
         for (hipEvent_t e : {ev0, ev1, evFork, evJ1, evJ2}) if (e) hipEventDestroy(e);
         for (hipStream_t q : {stream, s1, s2}) if (q) hipStreamDestroy(q);
@@ -177,7 +193,7 @@ struct BluesBatch {
     std::vector<unsigned> rec_delta; BluesEngine* rec_leader = nullptr;   // what the device records currently say
     BluesEngine* leader = nullptr;
     bool lockstep = false;
-    DBuf<RepNb<float>> d_nb_f; DBuf<RepNb<double>> d_nb_d; DBuf<RepCore> d_core;
+    DBuf<RepNb<float>> d_nb_f; DBuf<RepNb<double>> d_nb_d; DBuf<RepCore> d_core; DBuf<int> d_hints;
     int64_t st_lockstep_steps = 0, st_fallback_steps = 0;
     int R() const { return (int)eng.size(); }
 };
@@ -496,6 +512,8 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_self_part.alloc((size_t)(h->k2_nblocks_env + 1) * 9 * 64); h->d_e_part.alloc((size_t)(h->k2_nblocks_env + 1) * K2_NP); h->d_mom_part.alloc((size_t)(h->n_islots / 64 + 2) * 6);
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     h->hx_sort = h->hx;
+    for (int k = 0; k < 3; k++)   // the master positions on the device are the ones just sorted (every caller uploads / downloads first)
+        if (hipMemcpy(h->d_x_sort[k].p, h->d_x[k].p, sizeof(double) * n, hipMemcpyDeviceToDevice) != hipSuccess) E_FAIL(h, "hipMemcpy D2D failed");
     h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->graph_valid = false;
     h->args_epoch++;
     return 0;
@@ -738,7 +756,7 @@ static FinArgs make_fin_args(BluesEngine* h, const double le[3], int slot_mask =
 
 static int launch_finalize(BluesEngine* h, const double le[3], int slot_mask = 7) {
     FinArgs F = make_fin_args(h, le, slot_mask);
-    const int nblk = h->n_islots / 64 + (F.n_alch > 0 ? 1 + 9 * ((F.n_alch + 3) / 4) + 1 : 0);
+    const int nblk = h->n_islots / 64 + (F.n_alch > 0 ? 1 + 9 + 1 : 0);
     FinDyn FD; for (int s = 0; s < 3; s++) FD.le[s] = le[s];
     FD.slot_mask = slot_mask;
     if (batch_lead(h)) hipLaunchKernelGGL(k_finalize_b, dim3(std::max(1, nblk), h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, FD);
@@ -1259,8 +1277,27 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
         return 0;
     };
     for (int s = 0; s < n_steps; s++) {
-        // same cadence as a lone engine (keyed on each member's own step counter, so results stay identical to solo runs)
-        for (int r = 0; r < R; r++) if (!B->failed[r] && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0 && poll_resort(B->eng[r])) fail(r);
+        // same cadence as a lone engine (keyed on each member's own step counter, so results stay identical to solo runs);
+        // one gathered read-back tells which members (if any) need the per-member treatment
+        {
+            bool due = false;
+            for (int r = 0; r < R; r++) due |= !B->failed[r] && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0;
+            if (due) {
+                pick_leader();
+                if (!B->leader) return 0;
+                if (phase(flush_program)) return 1;
+                if (batch_refresh_args(B)) return 1;
+                std::vector<int> hints;
+                try {
+                    if ((int)B->d_hints.n != R) B->d_hints.alloc(R);
+                    hipLaunchKernelGGL(k_gather_hints_b, dim3((R + 255) / 256), dim3(256), 0, B->leader->stream, B->d_core.p, R, B->d_hints.p);
+                    if (hipStreamSynchronize(B->leader->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
+                    B->d_hints.download(hints);
+                } catch (std::string& e) { B->err = e; return 1; }
+                for (int r = 0; r < R; r++)
+                    if (!B->failed[r] && (hints[r] & 1) && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0 && poll_resort(B->eng[r])) fail(r);
+            }
+        }
         for (int r = 0; r < R; r++) if (!B->failed[r] && step_head(B->eng[r])) fail(r);
         if (phase(step_body)) return 1;
     }
@@ -1328,7 +1365,8 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     if (const char* g = getenv("BLUES_GRAPH_UNITS")) h->graph_units = std::max(1, atoi(g));
     if (const char* g = getenv("BLUES_GRAPH_FORK")) h->graph_fork = atoi(g) != 0;
     try {
-        for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); }
+        for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); h->d_x_sort[k].alloc(n); }
+        h->d_stage.alloc((size_t)3 * n); h->d_xfer_out.alloc(4); h->hx.assign((size_t)3 * n, 0.0);
         h->d_mass.upload(h->mass); h->d_charge.upload(h->charge); h->d_sigma.upload(h->sigma); h->d_eps.upload(h->eps);
         h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ctrl.alloc(1); h->d_stamps.alloc(64); h->d_tab_ls.upload(h->tab_ls); h->d_tab_le.upload(h->tab_le); h->d_ftot.alloc((size_t)9 * n); h->d_alch_self.alloc(9 * 64);
         h->d_alch_orig.upload(h->alch); h->d_alch_local.upload(h->alch_local);
@@ -1393,19 +1431,61 @@ int blues_engine_destroy(BluesEngine* h) {
     return 0;
 }
 
-static int upload_xyz(BluesEngine* h, const double* xyz, DBuf<double>* dst) {
-    std::vector<double> tmp(h->n);
-    for (int k = 0; k < 3; k++) {
-        for (int i = 0; i < h->n; i++) tmp[i] = xyz[3 * i + k];
-        HIP_OK(h, hipMemcpy(dst[k].p, tmp.data(), sizeof(double) * h->n, hipMemcpyHostToDevice));
-    }
+static int upload_xyz(BluesEngine* h, const double* xyz, DBuf<double>* dst) {   // one transfer, device-side de-interleave
+    HIP_OK(h, hipMemcpyAsync(h->d_stage.p, xyz, sizeof(double) * 3 * h->n, hipMemcpyHostToDevice, h->stream));
+    Copy6Args c; memset(&c, 0, sizeof c);
+    c.n = h->n; c.count = 3; c.src_stride = 3; c.dst_stride = 1;
+    for (int k = 0; k < 3; k++) { c.src[k] = h->d_stage.p + k; c.dst[k] = dst[k].p; }
+    hipLaunchKernelGGL(k_copy_arrays, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, c);
+    HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
-static int download_xyz(BluesEngine* h, double* xyz, DBuf<double>* src) {
-    std::vector<double> tmp(h->n);
-    for (int k = 0; k < 3; k++) {
-        HIP_OK(h, hipMemcpy(tmp.data(), src[k].p, sizeof(double) * h->n, hipMemcpyDeviceToHost));
-        for (int i = 0; i < h->n; i++) xyz[3 * i + k] = tmp[i];
+static int download_xyz(BluesEngine* h, double* xyz, DBuf<double>* src) {   // device-side interleave, one transfer
+    Copy6Args c; memset(&c, 0, sizeof c);
+    c.n = h->n; c.count = 3; c.src_stride = 1; c.dst_stride = 3;
+    for (int k = 0; k < 3; k++) { c.src[k] = src[k].p; c.dst[k] = h->d_stage.p + k; }
+    hipLaunchKernelGGL(k_copy_arrays, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, c);
+    HIP_OK(h, hipMemcpyAsync(xyz, h->d_stage.p, sizeof(double) * 3 * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// Shared tail of setPositions: the new coordinates are already on the device (src, SoA stride 1 or interleaved stride 3).
+static int load_positions(BluesEngine* h, const double* const src[3], int stride) {
+    LoadPosArgs a; memset(&a, 0, sizeof a);
+    a.n = h->n; a.stride = stride;
+    for (int k = 0; k < 3; k++) { a.src[k] = src[k]; a.x[k] = h->d_x[k].p; a.x_sort[k] = h->d_x_sort[k].p; }
+    a.mass = h->d_mass.p; a.alch_local = h->d_alch_local.p; a.sorted_of_orig = h->d_sorted_of_orig.p;
+    a.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; a.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
+    a.box = make_box(h); a.out = h->d_xfer_out.p;
+    HIP_OK(h, hipMemsetAsync(h->d_xfer_out.p, 0, 4 * sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(k_load_positions, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, a);
+    h->st_launches++;
+    unsigned out[4];
+    HIP_OK(h, hipMemcpyAsync(out, h->d_xfer_out.p, sizeof out, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->e_cache_valid = false;
+    if (out[0]) h->e_frozen_valid = false;
+    float worst; memcpy(&worst, &out[1], sizeof worst);
+    // tiles are formed from the mobile non-alchemical atoms.  A few wandering i-atoms only stretch their tile's bounding
+    // box, and the device notices when that starts to cost (resort_hint); the host re-sorts when an i-atom is far out
+    // or a sizeable part of the system has moved
+    if (worst > 1.0f || (int)out[2] > h->n / 10) {
+        if (download_xyz(h, h->hx.data(), h->d_x)) return 1;
+        h->sorted_ok = false;
+        return sort_and_tile(h);
+    }
+    h->lists_forced = true;
+    return 0;
+}
+
+// work bookkeeping for instantaneous moves: remember U(x_old, lambda) before overwriting (integrators.py:205)
+static int before_position_edit(BluesEngine* h) {
+    if (flush_program(h)) return 1;
+    if (h->have_positions && h->h_first_step >= 1 && h->h_step > 0 && h->h_step < h->nsteps && !h->unpert_valid) {
+        double E;
+        if (total_energy(h, &E)) return 1;
+        h->h_unperturbed = E; h->unpert_valid = true;
     }
     return 0;
 }
@@ -1413,53 +1493,27 @@ static int download_xyz(BluesEngine* h, double* xyz, DBuf<double>* src) {
 int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
     if (n_atoms != h->n) E_FAIL(h, "expected %d atoms, got %d", h->n, n_atoms);
     HIP_OK(h, hipSetDevice(h->device));
-    if (flush_program(h)) return 1;
-    // work bookkeeping for instantaneous moves: remember U(x_old, lambda) before overwriting (integrators.py:205)
-    if (h->have_positions && h->h_first_step >= 1 && h->h_step > 0 && h->h_step < h->nsteps && !h->unpert_valid) {
-        double E;
-        if (total_energy(h, &E)) return 1;
-        h->h_unperturbed = E; h->unpert_valid = true;
-    }
-    HIP_OK(h, hipStreamSynchronize(h->stream));
-    bool frozen_moved = !h->have_positions;
-    if (h->have_positions) for (int i = 0; i < h->n && !frozen_moved; i++) if (h->mass[i] == 0.0 && h->alch_local[i] < 0)
-        for (int k = 0; k < 3; k++) if (h->hx[3 * i + k] != xyz[3 * i + k]) { frozen_moved = true; break; }  // frozen atoms are never in clusters, so hx holds them verbatim
-    h->hx.assign(xyz, xyz + 3 * (size_t)h->n);
+    if (before_position_edit(h)) return 1;
     // store every constraint cluster as one whole periodic image (a lattice translation of single atoms is
     // physically a no-op); the cluster solves in k_integrate then need no minimum-image arithmetic
+    std::vector<double>& st = h->h_stage;
+    st.assign(xyz, xyz + 3 * (size_t)h->n);
     for (const HostCluster& c : h->clusters) for (int a = 1; a < 4; a++) if (c.atoms[a] >= 0)
         for (int k = 0; k < 3; k++) {
-            double d = h->hx[3 * c.atoms[a] + k] - h->hx[3 * c.atoms[0] + k];
-            h->hx[3 * c.atoms[a] + k] -= h->box[k] * std::nearbyint(d / h->box[k]);
+            double d = st[3 * c.atoms[a] + k] - st[3 * c.atoms[0] + k];
+            st[3 * c.atoms[a] + k] -= h->box[k] * std::nearbyint(d / h->box[k]);
         }
-    if (upload_xyz(h, h->hx.data(), h->d_x)) return 1;
-    h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->e_cache_valid = false;
-    if (frozen_moved) h->e_frozen_valid = false;
-    // re-sort when never sorted or when atoms have drifted far from where the tiles were formed
-    bool resort = !h->sorted_ok;
-    if (!resort) {
-        // tiles are formed from the mobile non-alchemical atoms: re-sort when one of THEM has wandered far from where
-        // its tile was formed, or when a sizeable part of the whole system has (j-list locality)
-        double worst_i = 0.0; int far = 0;
-        for (int i = 0; i < h->n; i++) {
-            double d2 = 0.0;
-            for (int k = 0; k < 3; k++) { double d = h->hx[3 * i + k] - h->hx_sort[3 * i + k]; d -= h->box[k] * std::nearbyint(d / h->box[k]); d2 += d * d; }
-            if (h->mass[i] != 0.0 && h->alch_local[i] < 0) worst_i = std::max(worst_i, d2);
-            if (d2 > 0.5 * 0.5) far++;
-        }
-        // a few wandering i-atoms only stretch their tile's bounding box, and the device notices when that starts to cost
-        // (resort_hint); the host re-sorts when an i-atom is far out or a sizeable part of the system has moved
-        resort = worst_i > 1.0 * 1.0 || far > h->n / 10;
+    if (!h->sorted_ok) {   // first positions (or a box change pending): lay the tiles out from these coordinates
+        HIP_OK(h, hipStreamSynchronize(h->stream));
+        h->hx = st;
+        if (upload_xyz(h, h->hx.data(), h->d_x)) return 1;
+        h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->e_cache_valid = false; h->e_frozen_valid = false;
+        return sort_and_tile(h);
     }
-    if (resort) { h->sorted_ok = false; if (sort_and_tile(h)) return 1; }
-    else {
-        Box3 b = make_box(h);
-        if (h->precision == 0) hipLaunchKernelGGL(k_pack_positions<float>, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->n, h->d_x[0].p, h->d_x[1].p, h->d_x[2].p, h->d_sorted_of_orig.p, h->d_img_f.p, b);
-        else hipLaunchKernelGGL(k_pack_positions<double>, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->n, h->d_x[0].p, h->d_x[1].p, h->d_x[2].p, h->d_sorted_of_orig.p, h->d_img_d.p, b);
-        h->st_launches++;
-        h->lists_forced = true;
-    }
-    return 0;
+    // one interleaved transfer; de-interleaving, image refresh and the re-sort statistics happen on the device
+    HIP_OK(h, hipMemcpyAsync(h->d_stage.p, st.data(), sizeof(double) * 3 * h->n, hipMemcpyHostToDevice, h->stream));
+    const double* src[3] = {h->d_stage.p, h->d_stage.p + 1, h->d_stage.p + 2};
+    return load_positions(h, src, 3);
 }
 
 int blues_set_velocities(BluesEngine* h, const double* xyz, int32_t n_atoms) {
@@ -1680,6 +1734,99 @@ int blues_time_nonbonded(BluesEngine* h, int32_t reps, double* usec) {
     HIP_OK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *usec = 1000.0 * ms / std::max(1, reps);
     return check_flags(h);
+}
+
+// ---- State snapshots (include/blues_engine.h, "Device-resident State")
+int blues_snapshot_capture(BluesEngine* h, int32_t what, BluesSnapshot** out) {
+    if (!out || !(what & 3)) E_FAIL(h, "snapshot: nothing requested");
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    if ((what & 1) && !h->have_positions) E_FAIL(h, "positions have not been set");
+    BluesSnapshot* sn = nullptr;
+    if (!h->snap_pool.empty()) { sn = h->snap_pool.back(); h->snap_pool.pop_back(); }
+    else {
+        sn = new BluesSnapshot(); sn->owner = h; sn->n = h->n;
+        if (hipMalloc((void**)&sn->block, sizeof(double) * 6 * (size_t)h->n) != hipSuccess) { delete sn; E_FAIL(h, "hipMalloc failed"); }
+        for (int k = 0; k < 3; k++) { sn->x[k] = sn->block + (size_t)k * h->n; sn->v[k] = sn->block + (size_t)(3 + k) * h->n; }
+    }
+    sn->has_x = what & 1; sn->has_v = (what & 2) != 0;
+    Copy6Args c; memset(&c, 0, sizeof c);
+    c.n = h->n; c.src_stride = 1; c.dst_stride = 1;
+    if (what & 1) for (int k = 0; k < 3; k++) { c.src[c.count] = h->d_x[k].p; c.dst[c.count++] = sn->x[k]; }
+    if (what & 2) for (int k = 0; k < 3; k++) { c.src[c.count] = h->d_v[k].p; c.dst[c.count++] = sn->v[k]; }
+    hipLaunchKernelGGL(k_copy_arrays, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, c);
+    h->st_launches++;
+    sn->e_valid = (what & 1) && h->e_cache_valid; sn->e = h->e_cache; sn->e_ls = h->e_cache_ls; sn->e_le = h->e_cache_le;
+    HIP_OK(h, hipGetLastError());
+    *out = sn;
+    return 0;
+}
+
+int blues_snapshot_release(BluesSnapshot* sn) {
+    if (!sn) return 0;
+    BluesEngine* h = sn->owner;
+    if (h->snap_pool.size() < 8) { h->snap_pool.push_back(sn); return 0; }
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);   // the copy that filled it, or a restore reading it, may still be queued
+    if (sn->block) hipFree(sn->block);
+    delete sn;
+    return 0;
+}
+
+int blues_snapshot_read(BluesSnapshot* sn, int32_t what, double* out, int32_t n_atoms) {
+    BluesEngine* h = sn->owner;
+    if (n_atoms != sn->n) E_FAIL(h, "expected %d atoms, got %d", sn->n, n_atoms);
+    if (what != 1 && what != 2) E_FAIL(h, "snapshot read: what must be 1 (positions) or 2 (velocities)");
+    if ((what == 1 && !sn->has_x) || (what == 2 && !sn->has_v)) E_FAIL(h, "the snapshot does not hold what was asked for");
+    HIP_OK(h, hipSetDevice(h->device));
+    Copy6Args c; memset(&c, 0, sizeof c);
+    c.n = sn->n; c.count = 3; c.src_stride = 1; c.dst_stride = 3;
+    for (int k = 0; k < 3; k++) { c.src[k] = what == 1 ? sn->x[k] : sn->v[k]; c.dst[k] = h->d_stage.p + k; }
+    hipLaunchKernelGGL(k_copy_arrays, dim3((sn->n + 255) / 256), dim3(256), 0, h->stream, c);
+    HIP_OK(h, hipMemcpyAsync(out, h->d_stage.p, sizeof(double) * 3 * sn->n, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int snapshot_usable(BluesEngine* h, const BluesSnapshot* sn) {
+    if (!sn) E_FAIL(h, "null snapshot");
+    if (sn->n != h->n) E_FAIL(h, "snapshot holds %d atoms, the engine %d", sn->n, h->n);
+    if (sn->owner->device != h->device) E_FAIL(h, "snapshot lives on another device");
+    return 0;
+}
+
+int blues_set_positions_from_snapshot(BluesEngine* h, const BluesSnapshot* sn) {
+    if (snapshot_usable(h, sn)) return 1;
+    if (!sn->has_x) E_FAIL(h, "the snapshot holds no positions");
+    HIP_OK(h, hipSetDevice(h->device));
+    if (before_position_edit(h)) return 1;
+    if (sn->owner->stream != h->stream) HIP_OK(h, hipStreamSynchronize(sn->owner->stream));   // captured on another engine's stream
+    if (!h->sorted_ok) {   // never laid out: take the host route once
+        std::vector<double> tmp((size_t)3 * h->n);
+        if (blues_snapshot_read(const_cast<BluesSnapshot*>(sn), 1, tmp.data(), h->n)) { h->err = sn->owner->err; return 1; }
+        return blues_set_positions(h, tmp.data(), h->n);
+    }
+    const double* src[3] = {sn->x[0], sn->x[1], sn->x[2]};
+    if (load_positions(h, src, 1)) return 1;
+    // the energy that was known for these positions is known again (OpenMM re-evaluates; same value)
+    if (sn->e_valid && sn->owner == h) { h->e_cache = sn->e; h->e_cache_ls = sn->e_ls; h->e_cache_le = sn->e_le; h->e_cache_valid = true; }
+    return 0;
+}
+
+int blues_set_velocities_from_snapshot(BluesEngine* h, const BluesSnapshot* sn) {
+    if (snapshot_usable(h, sn)) return 1;
+    if (!sn->has_v) E_FAIL(h, "the snapshot holds no velocities");
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    if (sn->owner->stream != h->stream) HIP_OK(h, hipStreamSynchronize(sn->owner->stream));
+    Copy6Args c; memset(&c, 0, sizeof c);
+    c.n = h->n; c.count = 3; c.src_stride = 1; c.dst_stride = 1;
+    for (int k = 0; k < 3; k++) { c.src[k] = sn->v[k]; c.dst[k] = h->d_v[k].p; }
+    hipLaunchKernelGGL(k_copy_arrays, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, c);
+    h->st_launches++; h->vel_clean = false;
+    HIP_OK(h, hipGetLastError());
+    if (sn->owner->stream != h->stream) HIP_OK(h, hipStreamSynchronize(h->stream));   // the owner may recycle the buffer on its own stream
+    return 0;
 }
 
 // ---- replica batch (include/blues_engine.h, "Replica batches")

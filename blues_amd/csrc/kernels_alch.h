@@ -48,7 +48,7 @@ struct AlchArgs {
     int check_env_excl;  // 0 when no alchemical atom has an excluded non-alchemical partner (free ligand)
     double ls[3], le[3];
     double* fJ;         // [3 slots][3][n] force on environment atoms by sorted index
-    double* self_part;  // [nblocks][3 slots][3][64]
+    double* self_part;  // [nblocks][3 slots][3][PA]
     double* e_part;     // [nblocks][K2_NP]
     const DevCtrl* ctrl; // non-null in graph replays: lambda slots come from the device tables
 };
@@ -237,10 +237,10 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
             __syncthreads();
         }
         __syncthreads();
-        if (tid < 64) {
+        if (tid < PA) {
 #pragma unroll
             for (int q = 0; q < 9; q++)
-                A.self_part[((size_t)block_id * 9 + q) * 64 + tid] = (tid < A.n_alch) ? s_self[0][q][tid] : 0.0;
+                A.self_part[((size_t)block_id * 9 + q) * PA + tid] = (tid < A.n_alch) ? s_self[0][q][tid] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < K2_NE; q++) e[q] = wave_sum(e[q]);
@@ -273,13 +273,10 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
         if (lane == 0) for (int q = 0; q < K2_NE; q++) s_e[wv][q] = 0.0;
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < PA) {
 #pragma unroll
-        for (int q = 0; q < 9; q++) {
-            double v = 0.0;
-            if (tid < PA) v = s_self[0][q][tid] + s_self[1][q][tid] + s_self[2][q][tid] + s_self[3][q][tid];
-            A.self_part[((size_t)block_id * 9 + q) * 64 + tid] = v;
-        }
+        for (int q = 0; q < 9; q++)
+            A.self_part[((size_t)block_id * 9 + q) * PA + tid] = s_self[0][q][tid] + s_self[1][q][tid] + s_self[2][q][tid] + s_self[3][q][tid];
     }
     if (tid < K2_NE) A.e_part[(size_t)block_id * K2_NP + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
     if (wv == 0) for (int k = 0; k < 3; k++) {

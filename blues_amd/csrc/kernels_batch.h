@@ -138,3 +138,15 @@ __global__ void __launch_bounds__(256) k_step_md_b(const RepCore* __restrict__ r
     IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d, reps[blockIdx.y].draw_delta);
     step_md_body<CM>(A);
 }
+
+// one word per member for the host's periodic poll: bit 0 resort_hint, bit 1 any error flag (one read-back for the batch)
+__global__ void k_gather_hints_b(const RepCore* __restrict__ reps, int R, int* out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    int w = 0;
+    if (reps[r].active) {
+        const DevFlags* f = reps[r].in.flags;
+        w = (f->resort_hint ? 1 : 0) | ((f->list_overflow | f->nan_flag | f->constraint_fail) ? 2 : 0);
+    }
+    out[r] = w;
+}

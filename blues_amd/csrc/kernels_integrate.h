@@ -333,15 +333,22 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
     blk -= n_itiles + nb_alch_atoms;
     const int cnt = *A.jcount_alch;
     const int nb_env = (cnt * A.PA + 255) / 256;
-    const int na4 = (A.n_alch + 3) / 4;
-    if (blk < 9 * na4) {  // slab q = slot*3 + component, 4 alchemical atoms per block: one wave per (q, atom)
-        const int q = blk / na4, a = (blk - q * na4) * 4 + wv;
+    if (blk < 9) {  // slab q = slot*3 + component: thread = (alchemical atom a, block group g); contiguous PA-wide rows
+        const int q = blk, PA = A.PA, NG = 256 / PA;
+        const int a = tid & (PA - 1), g = tid / PA;
+        __shared__ double s_red[256];
         double s = 0.0;
-        if (a < A.n_alch && ((A.slot_mask >> (q / 3)) & 1)) {
-            for (int b = lane; b < nb_env; b += 64) s += A.self_part[((size_t)b * 9 + q) * 64 + a];
-            if (lane == 0) s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * 64 + a];
-            s = wave_sum(s);
-            if (lane == 0) A.alch_self[q * 64 + a] = s;
+        const bool on = (A.slot_mask >> (q / 3)) & 1;
+        if (on) {
+            for (int b = g; b < nb_env; b += NG) s += A.self_part[((size_t)b * 9 + q) * PA + a];
+            if (g == 0) s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * PA + a];
+        }
+        s_red[tid] = s;
+        __syncthreads();
+        if (on && tid < A.n_alch) {
+            double t = 0.0;
+            for (int u = 0; u < NG; u++) t += s_red[u * PA + tid];   // fixed order
+            A.alch_self[q * 64 + tid] = t;
         }
         return;
     }
@@ -563,6 +570,64 @@ _Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 
 }
 
 __global__ void __launch_bounds__(256) k_integrate(IntArgs A) { integrate_body(A, A.prog); }
+
+// ---- state transfer (setPositions / State snapshots): new positions arrive either interleaved from the host
+// ([n][3], stride 3) or as a device-resident snapshot (SoA, stride 1).  One pass writes the master positions, refreshes
+// the fixed-point tile image and gathers what the host needs to decide about re-sorting and cached energies:
+//   out[0] != 0  a frozen environment atom changed (the frozen-frozen energy is stale)
+//   out[1]       max squared displacement of a mobile non-alchemical atom since the last spatial sort (float bits)
+//   out[2]       number of atoms farther than 0.5 nm from where they were sorted
+struct LoadPosArgs {
+    int n, stride;
+    const double* src[3];
+    double* x[3];
+    const double* x_sort[3];
+    const double* mass; const int* alch_local; const int* sorted_of_orig;
+    AtomF* img_f; AtomD* img_d; Box3 box;
+    unsigned* out;
+};
+__global__ void __launch_bounds__(256) k_load_positions(LoadPosArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned changed = 0, far = 0; float worst = 0.0f;
+    if (i < a.n) {
+        double p[3], d2 = 0.0;
+        const bool frozen = a.mass[i] == 0.0 && a.alch_local[i] < 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            p[k] = a.src[k][(size_t)i * a.stride];
+            if (frozen && p[k] != a.x[k][i]) changed = 1;
+            a.x[k][i] = p[k];
+            const double d = min_image_d(p[k] - a.x_sort[k][i], a.box.L[k], a.box.invL[k]);
+            d2 += d * d;
+        }
+        if (a.mass[i] != 0.0 && a.alch_local[i] < 0) worst = (float)d2;
+        far = d2 > 0.25;
+        const int s = a.sorted_of_orig[i];
+        if (a.img_f) { unsigned u[3]; to_fixed32(p, a.box, u); a.img_f[s].x = u[0]; a.img_f[s].y = u[1]; a.img_f[s].z = u[2]; }
+        else { unsigned long long u[3]; to_fixed(p, a.box, u); a.img_d[s].x = u[0]; a.img_d[s].y = u[1]; a.img_d[s].z = u[2]; }
+    }
+    // block-level combine, then one atomic per block and quantity
+    __shared__ unsigned s_c[4], s_f[4]; __shared__ float s_w[4];
+    for (int o = 32; o > 0; o >>= 1) { changed |= __shfl_xor(changed, o, 64); far += __shfl_xor(far, o, 64); worst = fmaxf(worst, __shfl_xor(worst, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = changed; s_f[threadIdx.x >> 6] = far; s_w[threadIdx.x >> 6] = worst; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned c = s_c[0] | s_c[1] | s_c[2] | s_c[3], f = s_f[0] + s_f[1] + s_f[2] + s_f[3];
+        const float w = fmaxf(fmaxf(s_w[0], s_w[1]), fmaxf(s_w[2], s_w[3]));
+        if (c) atomicOr(&a.out[0], 1u);
+        if (w > 0.0f) atomicMax(&a.out[1], __float_as_uint(w));   // non-negative floats order like their bit patterns
+        if (f) atomicAdd(&a.out[2], f);
+    }
+}
+
+// plain copies between engine state and snapshots / the host staging buffer: up to 6 arrays of n doubles in one launch;
+// dst_stride 3 interleaves (device-side transpose for getPositions), src_stride 3 de-interleaves
+struct Copy6Args { int n, count, src_stride, dst_stride; const double* src[6]; double* dst[6]; };
+__global__ void __launch_bounds__(256) k_copy_arrays(Copy6Args a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    for (int q = 0; q < a.count; q++) a.dst[q][(size_t)i * a.dst_stride] = a.src[q][(size_t)i * a.src_stride];
+}
 
 // kinetic energy: per-block partials of sum 0.5 m v^2 over mobile atoms
 __global__ void __launch_bounds__(256) k_kinetic(int n, const double* __restrict__ mass, const double* vx, const double* vy, const double* vz, double* part) {

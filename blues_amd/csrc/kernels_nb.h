@@ -82,7 +82,15 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     __shared__ int s_wcount[LIST_WAVES];
     __shared__ int s_total;
     __shared__ int s_need[256];
+    __shared__ ufix s_ax[64][3];   // alchemical tile: its atoms' positions, for the exact per-atom range test
+    __shared__ int s_na;
     const bool alch_tile = (t >= a.n_itiles);
+    if (alch_tile && wv == 1) {
+        const int ia = a.tile_atoms[t * 64 + lane];
+        if (ia >= 0) { s_ax[lane][0] = img[ia].x; s_ax[lane][1] = img[ia].y; s_ax[lane][2] = img[ia].z; }
+        const unsigned long long have = __ballot(ia >= 0);
+        if (lane == 0) s_na = __popcll(have);   // alchemical atoms fill the tile from slot 0
+    }
 
     // ---- bounding box of the tile in fixed point relative to its first atom
     if (wv == 0) {
@@ -136,7 +144,20 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
                 d = fmaxf(d, 0.0f);
                 d2 = fmaf(d, d, d2);
             }
-            const bool pass = j < j_end && d2 < rl2 && !(fl[u] & FLAG_ALCH);
+            bool pass = j < j_end && d2 < rl2 && !(fl[u] & FLAG_ALCH);
+            if (alch_tile && pass) {
+                // the alchemical kernel spends a thread on every (j, alchemical atom) pair of this list, so the list is
+                // made exact: j stays only if it is within cutoff+skin of at least one alchemical atom (the bounding
+                // box of a 15-atom ligand plus the margin holds ~1.6x as many atoms as that union of spheres)
+                bool near = false;
+                for (int q = 0; q < s_na; q++) {
+                    float e2 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { const float e = (float)(sfix)(pj[k] - s_ax[q][k]) * cfs[k]; e2 = fmaf(e, e, e2); }
+                    near |= e2 < rl2;
+                }
+                pass = near;
+            }
             const unsigned long long bal = __ballot(pass);
             if (pass) stage[wcount + __popcll(bal & ((1ull << lane) - 1ull))] = j;
             wcount += __popcll(bal);

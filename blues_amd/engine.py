@@ -56,6 +56,15 @@ class NativeEngine:
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.n, 3)
         self._check(self._lib.blues_set_velocities(self._h, self._ptr(v), self.n))
 
+    def snapshot(self, positions=True, velocities=True):
+        return DeviceSnapshot(self, (1 if positions else 0) | (2 if velocities else 0))
+
+    def set_positions_from_snapshot(self, snap):
+        self._check(self._lib.blues_set_positions_from_snapshot(self._h, snap._h))
+
+    def set_velocities_from_snapshot(self, snap):
+        self._check(self._lib.blues_set_velocities_from_snapshot(self._h, snap._h))
+
     def set_box(self, box3):
         b = np.zeros(9); b[0], b[4], b[8] = np.asarray(box3, dtype=np.float64).reshape(-1)[[0, 1, 2]] if np.size(box3) == 3 else np.asarray(box3).reshape(3, 3).diagonal()
         self._check(self._lib.blues_set_box(self._h, self._ptr(b)))
@@ -110,6 +119,36 @@ class NativeEngine:
 
     def time_nonbonded(self, reps=20):
         u = C.c_double(); self._check(self._lib.blues_time_nonbonded(self._h, int(reps), C.byref(u))); return u.value
+
+
+class DeviceSnapshot:
+    """openmm.State's positions / velocities kept on the GPU (include/blues_engine.h "Device-resident State")."""
+
+    def __init__(self, engine, what):
+        self.engine, self.what = engine, int(what)
+        h = C.c_void_p()
+        engine._check(engine._lib.blues_snapshot_capture(engine._h, self.what, C.byref(h)))
+        self._h = h
+        self._host = {}
+
+    def read(self, kind):
+        """kind 1: positions, 2: velocities -> (n, 3) float64 (downloaded once)."""
+        if kind not in self._host:
+            out = np.empty((self.engine.n, 3))
+            self.engine._check(self.engine._lib.blues_snapshot_read(self._h, kind, out.ctypes.data_as(_dp), self.engine.n))
+            self._host[kind] = out
+        return self._host[kind]
+
+    def release(self):
+        if getattr(self, "_h", None) and getattr(self.engine, "_h", None):
+            self.engine._lib.blues_snapshot_release(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class NativeBatch:

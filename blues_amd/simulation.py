@@ -30,7 +30,10 @@ class SimulationSet(object):
 
 
 class BLUESSimulation(object):
-    def __init__(self, simulations, config=None, move_engine=None):
+    def __init__(self, simulations, config=None, move_engine=None, rng=None):
+        # the reference draws from numpy's global stream (simulation.py:1133); a private RandomState can be handed in
+        # where several chains are driven from worker threads (BatchedBLUESSimulation)
+        self._rng = rng if rng is not None else np.random
         self._move_engine = move_engine if move_engine is not None else getattr(simulations, "_move_engine", None)
         self._md_sim = simulations.md
         self._alch_sim = simulations.alch
@@ -161,7 +164,7 @@ class BLUESSimulation(object):
     # ---- reference blues/simulation.py:1121-1166
     def _acceptRejectMove(self, write_move=False):
         work_ncmc = self._ncmc_sim.context._integrator.getLogAcceptanceProbability(self._ncmc_sim.context)
-        randnum = math.log(np.random.random())
+        randnum = math.log(self._rng.random_sample())
         correction_factor = 0.0
         if not np.isnan(work_ncmc):
             correction_factor = self._computeAlchemicalCorrection()
@@ -198,7 +201,7 @@ class BLUESSimulation(object):
         self._ncmc_sim.currentStep = 0
         self._ncmc_sim.context._integrator.reset()
         target = self._md_sim if self._md_sim is not None else self._ncmc_sim
-        target.context.setVelocitiesToTemperature(temperature)
+        target.context.setVelocitiesToTemperature(temperature, self._rng.randint(0, 2 ** 31 - 1))
 
     # ---- reference blues/simulation.py:1189-1213
     def _stepMD(self, nstepsMD):
@@ -240,11 +243,21 @@ class BatchedBLUESSimulation(object):
     NCMC engines form one native batch (and the MD engines another), so `step(n)` is one kernel launch sequence for all
     chains.  Hooks, state exchange and the Metropolis test run per chain, in chain order."""
 
-    def __init__(self, chains):
+    def __init__(self, chains, workers=1):
+        """workers > 1: the per-chain host work (hooks, state exchange through the plugin boundary, Metropolis test) of
+        different chains runs on a thread pool -- the C-ABI calls release the GIL and engines are independent objects;
+        each chain then draws from its own RandomState (seeded here, in chain order, from numpy's global stream)."""
         from .engine import NativeBatch
         self.chains = list(chains)
         if not self.chains:
             raise ValueError("no chains")
+        self._pool = None
+        if workers and workers > 1 and len(self.chains) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=min(int(workers), len(self.chains)))
+            for c in self.chains:
+                if c._rng is np.random:
+                    c._rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1))
         self._ncmc_batch = NativeBatch([c._ncmc_sim.context._engine for c in self.chains])
         self._md_batch = None
         if all(c._md_sim is not None for c in self.chains):
@@ -253,9 +266,19 @@ class BatchedBLUESSimulation(object):
             raise ValueError("either every chain has an MD simulation or none has")
 
     def close(self):
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
         for b in (self._ncmc_batch, self._md_batch):
             if b is not None:
                 b.close()
+
+    def for_each_chain(self, fn, indices=None):
+        """[fn(r, chain) for the given chains] -- on the pool when there is one."""
+        idx = list(range(len(self.chains))) if indices is None else list(indices)
+        if self._pool is None or len(idx) < 2:
+            return [fn(r, self.chains[r]) for r in idx]
+        return list(self._pool.map(lambda r: fn(r, self.chains[r]), idx))
 
     @staticmethod
     def _advance(batch, sims, wanted):
@@ -279,22 +302,24 @@ class BatchedBLUESSimulation(object):
 
     def _stepNCMC(self, nstepsNC, moveStep):
         sims = [c._ncmc_sim for c in self.chains]
-        plans, wanted = {}, {}
-        for r, c in enumerate(self.chains):
-            plans[r] = c._ncmc_plan(nstepsNC, moveStep)
+        plans = {r: c._ncmc_plan(nstepsNC, moveStep) for r, c in enumerate(self.chains)}
+        DONE = object()
+
+        def resume(r, err=None, first=False):
             try:
-                wanted[r] = next(plans[r])
+                if first:
+                    return next(plans[r])
+                return plans[r].throw(err) if err is not None else plans[r].send(None)
             except StopIteration:
-                pass
+                return DONE
+
+        got = self.for_each_chain(lambda r, c: resume(r, first=True))
+        wanted = {r: n for r, n in enumerate(got) if n is not DONE}
         while wanted:
             errors = self._advance(self._ncmc_batch, sims, wanted)
-            nxt = {}
-            for r in wanted:
-                try:
-                    nxt[r] = plans[r].throw(errors[r]) if r in errors else plans[r].send(None)
-                except StopIteration:
-                    pass
-            wanted = nxt
+            idx = sorted(wanted)
+            got = self.for_each_chain(lambda r, c: resume(r, errors.get(r)), idx)
+            wanted = {r: n for r, n in zip(idx, got) if n is not DONE}
 
     def _stepMD(self, nstepsMD):
         if self._md_batch is None or not nstepsMD:
@@ -314,16 +339,15 @@ class BatchedBLUESSimulation(object):
         if not nstepsMD: nstepsMD = cfg.get('nstepsMD', 0)
         if not moveStep: moveStep = cfg['moveStep']
         for N in range(int(nIter)):
-            for c in self.chains:
+            def sync(r, c):
                 c.currentIter = N
                 c._syncStatesMDtoNCMC()
+            self.for_each_chain(sync)
             self._stepNCMC(nstepsNC, moveStep)
-            for c in self.chains:
-                c._acceptRejectMove(write_move)
+            self.for_each_chain(lambda r, c: c._acceptRejectMove(write_move))
             if on_iteration is not None:
                 on_iteration(N, [c.last for c in self.chains])
-            for c in self.chains:
-                c._resetSimulations(temperature)
+            self.for_each_chain(lambda r, c: c._resetSimulations(temperature))
             self._stepMD(nstepsMD)
         for c in self.chains:
             c.acceptRatio = c.accept / float(nIter)

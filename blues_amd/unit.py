@@ -83,6 +83,32 @@ class Quantity(object):
     def __format__(self, spec): return format(self._value, spec) + " " + self.unit
 
 
+class DeviceQuantity(Quantity):
+    """A Quantity whose array still lives on the GPU (a State's positions or velocities).  Reading `_value` -- or anything
+    that goes through it -- downloads it once; handed back untouched to Context.setPositions / setVelocities it never
+    leaves the device.  Once it has been read the host copy is authoritative (the caller may have edited it in place)."""
+
+    def __init__(self, snapshot, kind, unit):
+        if unit not in _UNITS:
+            raise ValueError("unknown unit %r" % unit)
+        self.unit = unit
+        self._snapshot, self._kind, self._host = snapshot, kind, None
+
+    @property
+    def _value(self):
+        if self._host is None:
+            self._host = self._snapshot.read(self._kind)
+        return self._host
+
+    @_value.setter
+    def _value(self, v):
+        self._host = v
+
+    def on_device(self):
+        """The untouched device copy, or None once the host has seen (and may have changed) the numbers."""
+        return self._snapshot if self._host is None else None
+
+
 class _Reciprocal(object):
     """number / Quantity, so that `energy * (-1.0 / kT)` (reference blues/simulation.py:1116-1117) is a float."""
 

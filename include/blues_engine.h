@@ -169,6 +169,25 @@ int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
  * on the engine's own stream; returns mean microseconds per launch. */
 int blues_time_nonbonded(BluesEngine *h, int32_t reps, double *usec_per_launch);
 
+/* ---- Device-resident State -------------------------------------------------
+ * BLUES passes whole openmm.State objects around: getStateFromContext takes
+ * positions and velocities three times per iteration (simulation.py:883-911,
+ * 1035, 1056, 1096) only to hand them back unchanged through
+ * setContextFromState (simulation.py:938-963, 1037, 1150-1163).  A snapshot
+ * is that State kept in HBM: capture = device-to-device copy, restore =
+ * setPositions / setVelocities from the copy (same bookkeeping as the host
+ * calls), read = download for a consumer that really wants the numbers (a
+ * Move, a reporter).  `what`: bit 0 positions, bit 1 velocities.  A snapshot
+ * can be restored into any engine of the same size on the same device (the
+ * MD -> NCMC hand-over).  Release every snapshot before destroying the engine
+ * it was captured from. */
+typedef struct BluesSnapshot BluesSnapshot;
+int blues_snapshot_capture(BluesEngine *h, int32_t what, BluesSnapshot **out);
+int blues_snapshot_release(BluesSnapshot *s);
+int blues_snapshot_read(BluesSnapshot *s, int32_t what, double *out_xyz, int32_t n_atoms);
+int blues_set_positions_from_snapshot(BluesEngine *h, const BluesSnapshot *s);
+int blues_set_velocities_from_snapshot(BluesEngine *h, const BluesSnapshot *s);
+
 /* ---- Replica batches ------------------------------------------------------
  * BLUES chains are independent (reference examples run one
  * BLUESSimulation per process), and one replica of the 23k-atom system keeps

