@@ -133,7 +133,7 @@ struct BluesEngine {
     // ---- derived topology
     std::vector<int> mobile;       // caller indices with mass > 0
     std::vector<HostCluster> clusters;
-    int n_itiles = 0, n_tiles = 0, jcap = 0, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0;
+    int n_itiles = 0, n_tiles = 0, jcap = 0, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0, k2_jiter = 1;
     int seg_len = 64, waves_tile = 4, wpb = 4, npart = 1;  // K1 decomposition
     bool fuse_forces = false, fast_step = true, fuse_big = false;  // fuse_big: measured slower (the alchemical role's 140 VGPRs and 36 KB LDS cap the occupancy of the nonbonded role)
     int k1_iw = 64;  // i-atoms per wave in the nonbonded kernel: 64 = classic tile kernel, 8/16 = sub-tile throughput kernel
@@ -146,7 +146,7 @@ struct BluesEngine {
     DBuf<unsigned> d_xfer_out;
     std::vector<struct BluesSnapshot*> snap_pool;   // released snapshots, reused (hipMalloc per getState would dominate)
     DBuf<AtomF> d_img_f; DBuf<AtomD> d_img_d;
-    DBuf<int> d_sorted_of_orig, d_orig_of_sorted, d_tile_atoms, d_jlist, d_jstage, d_jcount, d_batch_slot, d_pool_count, d_ex_start, d_ex_idx, d_islot;
+    DBuf<int> d_sorted_of_orig, d_orig_of_sorted, d_tile_atoms, d_jlist, d_jstage, d_jcount, d_batch_slot, d_ex_start, d_ex_idx, d_islot;
     DBuf<unsigned long long> d_mask_pool;
     DBuf<DevFlags> d_flags; DBuf<DevAccum> d_acc; DBuf<DevCtrl> d_ctrl; DBuf<double> d_tab_ls, d_tab_le; DBuf<long long> d_stamps;
     DBuf<double> d_fpart, d_epart_nb, d_fJ, d_self_part, d_e_part, d_fent, d_ftot, d_alch_self, d_epart_b, d_cm_part, d_trace, d_scratch;
@@ -194,11 +194,15 @@ struct BluesBatch {
     BluesEngine* leader = nullptr;
     bool lockstep = false;
     DBuf<RepNb<float>> d_nb_f; DBuf<RepNb<double>> d_nb_d; DBuf<RepCore> d_core; DBuf<int> d_hints;
+    // list synchronisation: in a large batch some member needs new lists at almost every step, and the launch lasts as long
+    // as one rebuild whoever asks; when they all rebuild together (any request rebuilds all) most steps see no rebuild at all
+    DBuf<int> d_req; bool sync_lists = false;
     int64_t st_lockstep_steps = 0, st_fallback_steps = 0;
     int R() const { return (int)eng.size(); }
 };
 static inline bool batch_dry(const BluesEngine* h) { return h->batch && h->batch->lockstep && h->batch->leader != h; }
 static inline bool batch_lead(const BluesEngine* h) { return h->batch && h->batch->lockstep && h->batch->leader == h; }
+static inline int* batch_req_ptr(const BluesEngine* h) { return h->batch && h->batch->sync_lists ? h->batch->d_req.p : nullptr; }
 template <typename R> static const RepNb<R>* batch_reps_nb(const BluesBatch* b) { if constexpr (sizeof(R) == 4) return b->d_nb_f.p; else return b->d_nb_d.p; }
 
 static Box3 make_box(const BluesEngine* h) {
@@ -447,9 +451,11 @@ static int sort_and_tile(BluesEngine* h) {
             h->waves_tile = NC; h->npart = NC; h->wpb = 4; h->seg_len = 64;
         }
     }
-    h->pool_cap = nt * 12 + 64;
+    h->pool_cap = nt * MASK_QUOTA;
     h->PA = 1; while (h->PA < (int)h->alch.size()) h->PA <<= 1;
-    h->k2_nblocks_env = (jcap * h->PA + 255) / 256;
+    h->k2_jiter = h->n_itiles * h->batch_R <= 32 && h->batch_R < 8 ? 1 : 4;
+    if (const char* e = getenv("BLUES_K2_JITER")) h->k2_jiter = std::max(1, atoi(e));
+    h->k2_nblocks_env = k2_env_blocks(jcap, h->PA, h->k2_jiter);
     // exclusions in sorted space (self included)
     std::vector<int> ex_start(n + 1, 0), ex_idx;
     for (int s = 0; s < n; s++) {
@@ -496,7 +502,7 @@ static int sort_and_tile(BluesEngine* h) {
             r.has_env_excl = 0; for (int p2 : h->excl[ao]) if (h->alch_local[p2] < 0) r.has_env_excl = 1; }
           h->d_arec.upload(ar); }
         h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * LIST_WAVES * ((((n + LIST_WAVES - 1) / LIST_WAVES) + 63) & ~63)); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
-        h->d_mask_pool.alloc((size_t)h->pool_cap * 64); h->d_pool_count.alloc(1);
+        h->d_mask_pool.alloc((size_t)h->pool_cap * 64);
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
         h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_iw != 64 ? 64 / h->k1_iw : 1) + 2 * ((n + 255) / 256));
         { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi);
@@ -537,7 +543,7 @@ static IntArgs make_int_args(BluesEngine* h) {
     A.noise = h->d_noise.p; A.mobile_index = h->d_mobile_index.p; A.n_mobile = (int)h->mobile.size(); A.n_noise = h->noise_valid ? h->n_noise : 0; A.noise_draw_base = h->noise_draw_base;
     A.box = make_box(h); A.periodic = h->nb_method == BLUES_NB_PME_DIRECT; A.cl_periodic = 0;
     A.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; A.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
-    A.half_skin2 = 0.25 * h->skin * h->skin; A.flags = h->d_flags.p; A.pool_count = h->d_pool_count.p;
+    A.half_skin2 = 0.25 * h->skin * h->skin; A.flags = h->d_flags.p; A.batch_req = batch_req_ptr(h);
     A.total_mass = h->total_mass; A.cm_part = h->d_cm_part.p; A.cm_nblocks = h->int_blocks;
     A.mom_part = h->d_mom_part.p; A.n_mom = h->n_islots / 64 + 2;
     A.acc = h->d_acc.p; A.work_trace = (h->tracing || h->ctrl_arg) ? h->d_trace.p : nullptr; A.trace_index = h->prog_trace;
@@ -597,7 +603,7 @@ static ListArgs make_list_args(BluesEngine* h) {
     ListArgs a; memset(&a, 0, sizeof a);
     a.n = h->n; a.n_tiles = h->n_tiles; a.n_itiles = h->n_itiles; a.jcap = h->jcap; a.pool_cap = h->pool_cap;
     a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jstage = h->d_jstage.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p;
-    a.mask_pool = h->d_mask_pool.p; a.pool_count = h->d_pool_count.p; a.ex_start = h->d_ex_start.p; a.ex_idx = h->d_ex_idx.p; a.flags = h->d_flags.p;
+    a.mask_pool = h->d_mask_pool.p; a.batch_req = batch_req_ptr(h); a.ex_start = h->d_ex_start.p; a.ex_idx = h->d_ex_idx.p; a.flags = h->d_flags.p;
     for (int k = 0; k < 3; k++) { a.x[k] = h->d_x[k].p; a.xbuild[k] = h->d_xbuild[k].p; }
     a.fJ = h->d_fJ.p; a.n_fJ = 9 * h->n;
     a.alch_jrec = h->alch.empty() ? nullptr : (void*)h->d_jrec.p; a.p_sigma = h->d_sigma.p; a.p_eps = h->d_eps.p; a.p_charge = h->d_charge.p;
@@ -609,10 +615,8 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
     if (batch_lead(h)) {
-        if (force) for (int r = 0; r < h->batch->R(); r++) if (!h->batch->failed[r]) HIP_OK(h, hipMemsetAsync(h->batch->eng[r]->d_pool_count.p, 0, sizeof(int), h->cur));
         hipLaunchKernelGGL(k_build_lists_b<R>, dim3(h->n_tiles + 8, h->batch->R()), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), force);
     } else if (!batch_dry(h)) {
-        if (force) HIP_OK(h, hipMemsetAsync(h->d_pool_count.p, 0, sizeof(int), h->cur));
         hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 8), dim3(LIST_THREADS), 0, h->cur, a, make_nbconst<R>(h), img, force);
     }
     h->st_launches++;
@@ -631,7 +635,7 @@ template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
     a.n_itiles = h->n_itiles; a.jcap = h->jcap; a.n_islots = h->n_islots;
     a.seg_len = h->seg_len; a.waves_tile = h->waves_tile; a.npart = h->npart;
     a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p; a.mask_pool = h->d_mask_pool.p;
-    a.fpart = h->d_fpart.p; a.epart = h->d_epart_nb.p; a.flags = h->d_flags.p;
+    a.fpart = h->d_fpart.p; a.epart = h->d_epart_nb.p; a.flags = h->d_flags.p; a.batch_req = batch_req_ptr(h);
     return a;
 }
 
@@ -700,7 +704,7 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
 static AlchArgs make_alch_args(BluesEngine* h, const double ls[3], const double le[3], int slot_mask) {
     AlchArgs A; memset(&A, 0, sizeof A);
     A.jrec = h->d_jrec.p; A.arec = h->d_arec.p;
-    A.n = h->n; A.n_alch = (int)h->alch.size(); A.PA = h->PA; A.jcap = h->jcap; A.nblocks_env = h->k2_nblocks_env;
+    A.n = h->n; A.n_alch = (int)h->alch.size(); A.PA = h->PA; A.jcap = h->jcap; A.nblocks_env = h->k2_nblocks_env; A.jiter = h->k2_jiter;
     A.alch_orig = h->d_alch_orig.p; A.jlist = h->d_jlist.p + (size_t)h->n_itiles * h->jcap; A.jcount = h->d_jcount.p + h->n_itiles;
     A.orig_of_sorted = h->d_orig_of_sorted.p; A.sorted_of_orig = h->d_sorted_of_orig.p;
     for (int k = 0; k < 3; k++) A.x[k] = h->d_x[k].p;
@@ -742,7 +746,7 @@ static int launch_bonded(BluesEngine* h, bool with_noise) {
 
 static FinArgs make_fin_args(BluesEngine* h, const double le[3], int slot_mask = 7) {
     FinArgs F; memset(&F, 0, sizeof F);
-    F.n = h->n; F.n_islots = h->n_islots; F.npart = h->npart; F.n_alch = (int)h->alch.size(); F.PA = h->PA; F.k2_nblocks_env = h->k2_nblocks_env; F.n_entries = h->n_entries;
+    F.n = h->n; F.n_islots = h->n_islots; F.npart = h->npart; F.n_alch = (int)h->alch.size(); F.PA = h->PA; F.k2_nblocks_env = h->k2_nblocks_env; F.k2_jiter = h->k2_jiter; F.n_entries = h->n_entries;
     F.recs = h->d_finrecs.p; F.orig_of_islot = h->d_orig_of_islot.p; F.row_of_orig = h->d_row_of_orig.p; F.row_start = h->d_row_start.p;
     F.fpart = h->d_fpart.p; F.fent = h->d_fent.p; F.fJ = h->d_fJ.p; F.sorted_of_orig = h->d_sorted_of_orig.p; F.alch_orig = h->d_alch_orig.p;
     F.self_part = h->d_self_part.p; F.e_part = h->d_e_part.p; F.jcount_alch = h->d_jcount.p + h->n_itiles;
@@ -932,7 +936,7 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
         }
         if (!h->alch.empty()) {
             std::vector<int> jc; h->d_jcount.download(jc);
-            const int cnt = jc[h->n_itiles], nb_env = (cnt * h->PA + 255) / 256;
+            const int cnt = jc[h->n_itiles], nb_env = k2_env_blocks(cnt, h->PA, h->k2_jiter);
             h->d_e_part.download(e);
             double s[K2_NE] = {0, 0, 0, 0, 0, 0};
             for (int b = 0; b <= h->k2_nblocks_env; b++) { if (b >= nb_env && b != h->k2_nblocks_env) continue; for (int q = 0; q < K2_NE; q++) s[q] += e[(size_t)b * K2_NP + q]; }
@@ -1193,7 +1197,7 @@ static BatchSig batch_sig(const BluesEngine* h) {
 static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const char** why) {
 #define BC(f) if (a->f != b->f) { *why = #f; return false; }
     BC(device) BC(n) BC(precision) BC(nsteps) BC(nprop) BC(n_lambda) BC(split) BC(remove_cm) BC(dt) BC(gamma) BC(kT) BC(tol) BC(prop_min) BC(prop_max)
-    BC(n_itiles) BC(n_tiles) BC(jcap) BC(n_islots) BC(pool_cap) BC(PA) BC(k2_nblocks_env) BC(seg_len) BC(waves_tile) BC(wpb) BC(npart)
+    BC(n_itiles) BC(n_tiles) BC(jcap) BC(n_islots) BC(pool_cap) BC(PA) BC(k2_nblocks_env) BC(k2_jiter) BC(seg_len) BC(waves_tile) BC(wpb) BC(npart)
     BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k1_iw) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
     BC(cutoff) BC(alpha) BC(sc_alpha) BC(annih_elec) BC(annih_ster) BC(nb_method) BC(restr_k) BC(total_mass)
     BC(box[0]) BC(box[1]) BC(box[2])
@@ -1714,7 +1718,7 @@ int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
     stats[9] = h->st_resorts;
     if (h->d_jcount.p && h->sorted_ok) { std::vector<int> jc; hipSetDevice(h->device); hipStreamSynchronize(h->stream); try { h->d_jcount.download(jc); for (int c : jc) stats[8] = std::max<int64_t>(stats[8], c); } catch (std::string&) {} }
     stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
-    if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) stats[1] = f.list_gen; }
+    if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) { stats[1] = f.list_gen; stats[10] = f.builds; } }
     return 0;
 }
 
@@ -1853,6 +1857,11 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
         m->use_graph = false;  // graph replays carry per-engine frozen arguments
     }
     for (int r = 0; r < count; r++) if (relayout(engines[r])) { g_batch_create_error = "re-layout for the batch failed: " + engines[r]->err; batch_detach_all(B); delete B; return 1; }
+    // off by default: measured on MI355X at R = 256 it does not pay (with 256 x 276 mobile atoms SOME atom crosses skin/2
+    // every ~3 steps, and rebuilding all members at once costs about what one rebuild per step did: 669 vs 678 us/step)
+    B->sync_lists = false;
+    if (const char* e = getenv("BLUES_BATCH_SYNC_LISTS")) B->sync_lists = atoi(e) != 0;
+    try { B->d_req.alloc(1); } catch (std::string& e) { g_batch_create_error = e; batch_detach_all(B); delete B; return 1; }
     B->seen_epoch.assign(count, 0); B->failed.assign(count, 0); B->active.assign(count, 1); B->rec_active.assign(count, 0); B->rec_delta.assign(count, 0); B->leader = engines[0];
     *out = B;
     return 0;

@@ -20,6 +20,9 @@
 
 #define K2_NE 6  // energy partials per block: C_scaled, S0, S1, S2, const_lj, const_coul
 #define K2_NP 9  // K2_NE + the block's total slot-0 force on the alchemical atoms (x,y,z), for the momentum bookkeeping
+// env blocks needed for `count` list entries when a block walks `jiter` groups of 256/PA j's (see alchemical_body): 1 for a
+// lone replica (shortest dependent chain per block), 4 in a large batch (reductions amortised, 4x fewer partials)
+__host__ __device__ inline int k2_env_blocks(int count, int PA, int jiter) { const int jpb = (256 / PA) * jiter; return (count + jpb - 1) / jpb; }
 
 // packed per-entry records so the pair thread needs two dependent loads (record -> position) instead of four
 struct AlchJRec { int jo, jsrt; double sig, eps, q; };   // one per entry of the alchemical tile's j-list (written at list build)
@@ -27,7 +30,7 @@ struct AlchARec { int ao, asrt, has_env_excl, pad; double sig, eps, q; };  // on
 
 struct AlchArgs {
     const AlchJRec* jrec; const AlchARec* arec;
-    int n, n_alch, PA, jcap, nblocks_env;
+    int n, n_alch, PA, jcap, nblocks_env, jiter;
     const int* alch_orig;       // [n_alch]
     const int* jlist;           // j-list of the alchemical tile (sorted indices)
     const int* jcount;          // -> its count
@@ -82,81 +85,100 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
     const bool env_block = block_id < A.nblocks_env;
     bool wave_hit = true;
     if (env_block) {
+        // An env block covers A.jiter groups of 256/PA consecutive j's; a thread keeps its alchemical atom a and walks one
+        // j per group.  The force on j is reduced over the PA lanes per group; the force on a and the energies accumulate
+        // in registers across the groups and are reduced once per block.
         const int count = *A.jcount;
-        if ((block_id * 256) / PA >= count) return;  // nothing to do; the integrator sums only the used blocks
-        const int js = (block_id * 256 + tid) / PA;
-        const bool valid = js < count && a < A.n_alch;
-        int jsrt = -1;
-        bool hit = false;  // this lane holds a pair term
-        if (valid) {
-            const AlchJRec J = A.jrec[js];
-            const AlchARec Ar = A.arec[a];
-            jsrt = J.jsrt;
-            const int jo = J.jo, ao = Ar.ao;
-            double d[3];
-            for (int k = 0; k < 3; k++) d[k] = min_image_d(A.x[k][ao] - A.x[k][jo], A.box.L[k], A.box.invL[k]);
-            const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-            const bool excl = Ar.has_env_excl && excluded_sorted(A.ex_start, A.ex_idx, Ar.asrt, jsrt);
-            if (!excl && r2 < A.rc2) {
-                const double sig = 0.5 * (Ar.sig + J.sig), eps = sqrt(Ar.eps * J.eps);
-                const double qq = Ar.q * J.q;
-                double fc;
-                hit = true;
-                if (FAST && A.pme) {
-                    e[0] = coulomb_fast_d(r2, qq, A.alpha, &fc);
-                    double es[3], fs3[3];
-                    softcore_lj3_fast_d(r2, sig, eps, A.ls, A.sc_alpha, es, fs3);
+        const int jpg = 256 / PA, j0 = block_id * jpg * A.jiter;
+        if (j0 >= count) return;  // nothing to do; finalize sums only the used blocks
+        AlchARec Ar; Ar.ao = 0; Ar.asrt = 0; Ar.has_env_excl = 0; Ar.sig = Ar.eps = Ar.q = 0.0;
+        if (a < A.n_alch) Ar = A.arec[a];
+        double xa[3] = {0.0, 0.0, 0.0};
+        if (a < A.n_alch) for (int k = 0; k < 3; k++) xa[k] = A.x[k][Ar.ao];
+        double fa[3][3];
 #pragma unroll
-                    for (int s = 0; s < 3; s++) {
-                        e[1 + s] = es[s];
-                        const double ft = fs3[s] + A.le[s] * fc;
-                        f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
-                    }
-                } else {
-                    const double ec = coulomb_d(r2, qq, A.alpha, A.pme != 0, &fc);
-                    e[0] = ec;
+        for (int s = 0; s < 3; s++) { fa[s][0] = fa[s][1] = fa[s][2] = 0.0; }
+        wave_hit = false;
+        for (int it = 0; it < A.jiter; it++) {
+            const int js = j0 + it * jpg + tid / PA;
+            if (j0 + it * jpg >= count) break;   // block-uniform
+            const bool valid = js < count && a < A.n_alch;
+            int jsrt = -1;
+            bool hit = false;  // this lane holds a pair term
 #pragma unroll
-                    for (int s = 0; s < 3; s++) {
-                        double fs;
-                        e[1 + s] = softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
-                        const double ft = fs + A.le[s] * fc;
-                        f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
-                    }
-                }
-            } else if (excl) {
-                // excluded pair: if it is a 1-4 exception between this alchemical atom and an environment atom it is
-                // evaluated here with its own parameters (softcore LJ scaled by lambda_sterics, bare Coulomb scaled by
-                // lambda_electrostatics, no cutoff -- SURVEY.md Appendix B), so both atoms get their force through the
-                // same reductions as a regular pair
-                for (int q = A.exc_start[a]; q < A.exc_start[a + 1]; q++) {
-                    if (A.exc_partner[q] != jo) continue;
-                    hit = true;
-                    const double qq = A.exc_params[3 * q], sig = A.exc_params[3 * q + 1], eps = A.exc_params[3 * q + 2];
+            for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = 0.0; }
+            if (valid) {
+                const AlchJRec J = A.jrec[js];
+                jsrt = J.jsrt;
+                const int jo = J.jo;
+                double d[3];
+                for (int k = 0; k < 3; k++) d[k] = min_image_d(xa[k] - A.x[k][jo], A.box.L[k], A.box.invL[k]);
+                const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                const bool excl = Ar.has_env_excl && excluded_sorted(A.ex_start, A.ex_idx, Ar.asrt, jsrt);
+                if (!excl && r2 < A.rc2) {
+                    const double sig = 0.5 * (Ar.sig + J.sig), eps = sqrt(Ar.eps * J.eps);
+                    const double qq = Ar.q * J.q;
                     double fc;
-                    e[0] = coulomb_d(r2, qq, 0.0, false, &fc);
+                    hit = true;
+                    if (FAST && A.pme) {
+                        e[0] += coulomb_fast_d(r2, qq, A.alpha, &fc);
+                        double es[3], fs3[3];
+                        softcore_lj3_fast_d(r2, sig, eps, A.ls, A.sc_alpha, es, fs3);
 #pragma unroll
-                    for (int s = 0; s < 3; s++) {
-                        double fs;
-                        e[1 + s] = softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
-                        const double ft = fs + A.le[s] * fc;
-                        f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                        for (int s = 0; s < 3; s++) {
+                            e[1 + s] += es[s];
+                            const double ft = fs3[s] + A.le[s] * fc;
+                            f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                        }
+                    } else {
+                        e[0] += coulomb_d(r2, qq, A.alpha, A.pme != 0, &fc);
+#pragma unroll
+                        for (int s = 0; s < 3; s++) {
+                            double fs;
+                            e[1 + s] += softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
+                            const double ft = fs + A.le[s] * fc;
+                            f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                        }
+                    }
+                } else if (excl) {
+                    // excluded pair: if it is a 1-4 exception between this alchemical atom and an environment atom it is
+                    // evaluated here with its own parameters (softcore LJ scaled by lambda_sterics, bare Coulomb scaled by
+                    // lambda_electrostatics, no cutoff -- SURVEY.md Appendix B), so both atoms get their force through the
+                    // same reductions as a regular pair
+                    for (int q = A.exc_start[a]; q < A.exc_start[a + 1]; q++) {
+                        if (A.exc_partner[q] != jo) continue;
+                        hit = true;
+                        const double qq = A.exc_params[3 * q], sig = A.exc_params[3 * q + 1], eps = A.exc_params[3 * q + 2];
+                        double fc;
+                        e[0] += coulomb_d(r2, qq, 0.0, false, &fc);
+#pragma unroll
+                        for (int s = 0; s < 3; s++) {
+                            double fs;
+                            e[1 + s] += softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
+                            const double ft = fs + A.le[s] * fc;
+                            f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                        }
                     }
                 }
             }
-        }
-        // A wave covers 64/PA consecutive (Hilbert-sorted) j's; more than half of the list is out of range of every
-        // alchemical atom at any one time, so whole waves have nothing to add: they publish zeros and skip every reduction.
-        wave_hit = __ballot(hit) != 0ull;
-        // force on environment atom j: minus the sum over the PA alchemical lanes
+            // A wave covers 64/PA consecutive (Hilbert-sorted) j's per group; part of the list is out of range of every
+            // alchemical atom at any one time: such a group publishes zeros and skips its reductions.
+            const bool group_hit = __ballot(hit) != 0ull;
+            wave_hit |= group_hit;
+            // force on environment atom j: minus the sum over the PA alchemical lanes
 #pragma unroll
-        for (int s = 0; s < 3; s++) {
-            if (!((A.slot_mask >> s) & 1)) continue;
+            for (int s = 0; s < 3; s++) {
+                if (!((A.slot_mask >> s) & 1)) continue;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const double fj = wave_hit ? seg_sum(f[s][k], PA) : 0.0;
-                if (a == 0 && js < count) A.fJ[(size_t)(s * 3 + k) * A.n + jsrt] = -fj;
+                for (int k = 0; k < 3; k++) {
+                    const double fj = group_hit ? seg_sum(f[s][k], PA) : 0.0;
+                    if (a == 0 && js < count) A.fJ[(size_t)(s * 3 + k) * A.n + jsrt] = -fj;
+                    fa[s][k] += f[s][k];
+                }
             }
         }
+#pragma unroll
+        for (int s = 0; s < 3; s++) { f[s][0] = fa[s][0]; f[s][1] = fa[s][1]; f[s][2] = fa[s][2]; }
     } else {
         // ---- alchemical x alchemical pairs: thread (a2, b) with b fastest
         const int rows_per_iter = 256 / PA;

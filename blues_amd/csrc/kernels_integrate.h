@@ -71,7 +71,7 @@ struct IntArgs {
     // tile image refresh + list validity
     AtomF* img_f; AtomD* img_d;
     const double* xbuild[3]; double half_skin2;
-    DevFlags* flags; int* pool_count;
+    DevFlags* flags; int* batch_req;   // batch_req: see ListArgs (null outside a list-synchronised batch)
     // COM removal
     double total_mass; double* cm_part; int cm_nblocks;
     const double* mom_part; int n_mom;  // momentum partials written by k_finalize (see FinArgs)
@@ -227,7 +227,7 @@ __device__ __forceinline__ void load_force(const IntArgs& A, const Cluster& C, i
 struct FinRec { int atom, sorted, e0, e1; };  // caller index (-1: empty), image index, bonded entry range
 
 struct FinArgs {
-    int n, n_islots, npart, n_alch, PA, k2_nblocks_env, n_entries;
+    int n, n_islots, npart, n_alch, PA, k2_nblocks_env, k2_jiter, n_entries;
     const FinRec* recs;         // [n_islots + 64]: i-slots, then the alchemical atoms
     const int* orig_of_islot;   // [n_islots] caller index or -1
     const int* row_of_orig;     // [n] bonded row or -1
@@ -332,7 +332,7 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
     if (A.n_alch == 0) return;
     blk -= n_itiles + nb_alch_atoms;
     const int cnt = *A.jcount_alch;
-    const int nb_env = (cnt * A.PA + 255) / 256;
+    const int nb_env = k2_env_blocks(cnt, A.PA, A.k2_jiter);
     if (blk < 9) {  // slab q = slot*3 + component: thread = (alchemical atom a, block group g); contiguous PA-wide rows
         const int q = blk, PA = A.PA, NG = 256 / PA;
         const int a = tid & (PA - 1), g = tid / PA;
@@ -561,7 +561,7 @@ _Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 
             }
         }
     }
-    if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; *A.pool_count = 0; }
+    if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; if (A.batch_req) *A.batch_req = 1; }
 #ifdef BLUES_STAMP
     if (cl == 0 && A.stamps) A.stamps[2 + prog.n] = clock64();
 #endif
@@ -797,7 +797,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
             if (A.img_f) { unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2]; }
             else { unsigned long long u[3]; to_fixed(C.x[a], A.box, u); A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
         }
-        if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; *A.pool_count = 0; }
+        if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; if (A.batch_req) *A.batch_req = 1; }
         if (bad) A.flags->nan_flag = 1;
         if (!ok) A.flags->constraint_fail = 1;
     }
@@ -880,7 +880,7 @@ __device__ __forceinline__ void step_md_body(IntArgs& A) {
         if (A.img_f) { unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2]; }
         else { unsigned long long u[3]; to_fixed(C.x[a], A.box, u); A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
     }
-    if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; *A.pool_count = 0; }
+    if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; if (A.batch_req) *A.batch_req = 1; }
     if (bad) A.flags->nan_flag = 1;
     if (!ok) A.flags->constraint_fail = 1;
 }

@@ -21,7 +21,8 @@ struct DevFlags {  // device-resident control words
     int constraint_fail;
     int nan_flag;
     int resort_hint;             // a j-list has grown to within 15 % of its capacity: the tiles have spread, re-sort soon
-    int pad[2];
+    int builds;                  // list builds executed (own requests, forced ones and batch-synchronised ones)
+    int pad[1];
 };
 
 template <typename R> struct NbConst {
@@ -41,8 +42,8 @@ struct ListArgs {
     const double* p_sigma; const double* p_eps; const double* p_charge;  // caller order
     int* jcount;             // [n_tiles]
     int* batch_slot;         // [n_tiles*(jcap/64)]
-    unsigned long long* mask_pool;  // [pool_cap*64]
-    int* pool_count;
+    unsigned long long* mask_pool;  // [n_tiles][MASK_QUOTA][64]: a tile's masks live in its own region (no shared counter to reset)
+    const int* batch_req;    // replica batches: "some member asked for a rebuild" -> every member rebuilds with it (or null)
     const int* ex_start;     // [n+1] exclusion CSR in sorted index space (self included)
     const int* ex_idx;
     DevFlags* flags;
@@ -56,6 +57,7 @@ struct ListArgs {
 // LIST_WAVES waves share one tile's scan of all n atoms; each wave keeps LIST_PREFETCH independent loads in flight.
 // The scan is a chain of dependent memory round trips (ballot -> running count -> store), so its duration is
 // (n / 64 / LIST_WAVES / LIST_PREFETCH) latencies: 4 waves x 1 load took 60-70 us at n = 23,400; 16 x 4 takes ~12.
+#define MASK_QUOTA 24   // exclusion-mask tiles per i-tile (j-batches that hold an excluded pair; a handful in practice)
 #define LIST_WAVES 16
 #define LIST_PREFETCH 4
 #define LIST_THREADS (LIST_WAVES * 64)
@@ -64,7 +66,7 @@ template <typename R>
 __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force) {
     using sfix = typename Img<R>::sfix;
     using ufix = typename Img<R>::ufix;
-    if (!force && a.flags->list_gen == a.flags->req_gen) return;
+    if (!force && a.flags->list_gen == a.flags->req_gen && !(a.batch_req && *a.batch_req)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int t = blockIdx.x;
     // ---- shared bookkeeping: remember where the lists were built, clear alchemical env forces
@@ -84,6 +86,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     __shared__ int s_need[256];
     __shared__ ufix s_ax[64][3];   // alchemical tile: its atoms' positions, for the exact per-atom range test
     __shared__ int s_na;
+    __shared__ int s_nmask;
     const bool alch_tile = (t >= a.n_itiles);
     if (alch_tile && wv == 1) {
         const int ia = a.tile_atoms[t * 64 + lane];
@@ -109,7 +112,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
                 s_half[k] = 0.5 * (hi - lo) + 2.0 * c.dscale[k];
             }
         }
-        if (lane == 0) s_total = 0;
+        if (lane == 0) { s_total = 0; s_nmask = 0; }
     }
     __syncthreads();
     const ufix cf[3] = {s_cfix[0], s_cfix[1], s_cfix[2]};
@@ -174,6 +177,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     __threadfence_block();
     __syncthreads();
     int count = s_total;
+    if (t == 0 && tid == 0) a.flags->builds++;
     if (count > a.jcap) { if (tid == 0) a.flags->list_overflow = 1; count = a.jcap; }
     else if (count > a.jcap - a.jcap / 7 && tid == 0) a.flags->resort_hint = 1;
     if (tid == 0) a.jcount[t] = count;
@@ -210,8 +214,9 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
         if (pass == 0) {
             for (int b = tid; b < nb; b += LIST_THREADS) {
                 if (s_need[b]) {
-                    int slot = atomicAdd(a.pool_count, 1);
-                    if (slot >= a.pool_cap) { a.flags->list_overflow = 1; slot = 0; }
+                    int slot = atomicAdd(&s_nmask, 1);
+                    if (slot >= MASK_QUOTA) { a.flags->list_overflow = 1; slot = 0; }
+                    slot += t * MASK_QUOTA;
                     s_need[b] = slot; a.batch_slot[t * nbmax + b] = slot;
                 } else s_need[b] = -1;
             }
@@ -244,6 +249,7 @@ template <typename R> struct NbArgs {
     double* fpart;   // [npart][3][n_islots]
     double* epart;   // [n_itiles*npart][2] (ENERGY only)
     DevFlags* flags;
+    int* batch_req;  // see ListArgs; cleared here (every list block of this pass has read it by now)
 };
 
 // One block = WPB waves working on the SAME i-tile; wave w of the tile walks the j-list segments
@@ -255,7 +261,7 @@ __device__ __forceinline__ void nonbonded_body(const NbArgs<R>& a, const NbConst
     __shared__ Atom lds[WPB][64];
     __shared__ double red[WPB][ENERGY ? 5 : 3][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (block_id == 0 && threadIdx.x == 0) a.flags->list_gen = a.flags->req_gen;  // lists are current for this pass
+    if (block_id == 0 && threadIdx.x == 0) { a.flags->list_gen = a.flags->req_gen; if (a.batch_req) *a.batch_req = 0; }  // lists are current for this pass
     const int blocks_tile = a.waves_tile / WPB;
     const int t = block_id / blocks_tile, part = block_id - t * blocks_tile;
     if (t >= a.n_itiles) return;  // block-uniform
@@ -335,7 +341,7 @@ __device__ __forceinline__ void nonbonded_sub_body(const NbArgs<float>& a, const
     __shared__ P2 lq[4][64];
     __shared__ uint32_t lf[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (block_id == 0 && threadIdx.x == 0) a.flags->list_gen = a.flags->req_gen;
+    if (block_id == 0 && threadIdx.x == 0) { a.flags->list_gen = a.flags->req_gen; if (a.batch_req) *a.batch_req = 0; }
     const int NC = a.waves_tile;
     const int W = block_id * 4 + wv;
     const int t = W / (SUBS * NC);

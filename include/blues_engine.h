@@ -162,7 +162,8 @@ int blues_reset(BluesEngine *h);
 /* engine counters for bench.py / profiling: [0] force passes [1] neighbour
  * rebuilds [2] kernel launches [3] n i-tiles [4] n clusters [5] j-list capacity
  * [6] partial slabs [7] segment length*1000 + waves per block [8] longest
- * j-list at the last rebuild [9] re-sorts of the tile layout */
+ * j-list at the last rebuild [9] re-sorts of the tile layout [10] list
+ * builds executed */
 #define BLUES_N_STATS 12
 int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
 /* time `reps` launches of the dominant nonbonded kernel alone with HIP events

@@ -62,6 +62,7 @@ def same_decomposition(request, monkeypatch):
     changes the order of the partial force sums.  Pinning the choice makes solo and batched runs comparable bit for bit --
     once with the fused launch, once with the separate kernels."""
     monkeypatch.setenv("BLUES_FUSE", request.param)
+    monkeypatch.setenv("BLUES_K2_JITER", "1" if request.param == "1" else "4")   # j-groups per alchemical block: lone-replica / large-batch value
     return request.param
 
 
@@ -368,3 +369,30 @@ def test_device_resident_state_round_trip(Engine, tol_box):
     assert np.array_equal(sim2.context._engine.get_positions(), x1)
     sim2.context.setParameter("lambda_sterics", 0.0); sim2.context.setParameter("lambda_electrostatics", 0.0)   # lambda = 0.5, where state1 was taken
     assert sim2.context.getState(getEnergy=True).getPotentialEnergy()._value == pytest.approx(e1, rel=1e-12)
+
+
+def test_batch_synchronised_list_rebuilds(Engine, tol_box, monkeypatch):
+    """Large batches rebuild every member's neighbour lists together (any member's request rebuilds all): same physics,
+    another summation order.  Forced on here for a small batch: all members then count the same rebuilds, more than a
+    lone replica needs, and agree with their solo runs to rounding (fp64 mode)."""
+    from blues_amd.engine import NativeBatch
+    s, v = tol_box
+    lig = np.arange(15)
+    near = systems.nearest_molecules(s, lig, 150, exclude_idx=lig)
+    sf = systems.freeze_except(s, np.concatenate([lig, near]))
+    vf = v * (sf.mass[:, None] > 0)
+    R, n = 3, 60
+    vels = _replica_inputs(sf, vf, R)
+    monkeypatch.setenv("BLUES_SKIN", "0.08")          # frequent rebuilds within a short run
+    solo = _make(Engine, sf, vels, n, 1)
+    ws = [g.run_switch(n, trace=True) for g in solo]
+    monkeypatch.setenv("BLUES_BATCH_SYNC_LISTS", "1")
+    bat = _make(Engine, sf, vels, n, 1)
+    B = NativeBatch(bat)
+    _, wb = B.step(n, trace=True)
+    builds = [g.stats()["list_builds"] for g in bat]
+    assert len(set(builds)) == 1 and builds[0] >= max(g.stats()["list_builds"] for g in solo) and builds[0] > 3
+    for r in range(R):
+        assert np.allclose(wb[r], ws[r], rtol=1e-9, atol=1e-9)
+        assert np.abs(solo[r].get_positions() - bat[r].get_positions()).max() < 1e-10
+    B.close()
