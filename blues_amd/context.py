@@ -91,15 +91,15 @@ class Context(object):
         """context.getState(...) (reference blues/simulation.py:905, blues/moves.py:292, positional form moves.py:1218)."""
         e = self._engine
         x = v = snap = None
+        pe = ke = None
+        if getEnergy:   # before the snapshot, so that the snapshot carries the energy of its positions
+            pe, ke = e.potential_energy(), e.kinetic_energy()
         if (getPositions or getVelocities) and hasattr(e, "snapshot"):
             snap = e.snapshot(positions=bool(getPositions), velocities=bool(getVelocities))   # stays in HBM until somebody reads it
         else:
             x = e.get_positions() if getPositions else None
             v = e.get_velocities() if getVelocities else None
         f = e.get_forces() if getForces else None
-        pe = ke = None
-        if getEnergy:
-            pe, ke = e.potential_energy(), e.kinetic_energy()
         par = None
         if getParameters:
             par = {"lambda_sterics": e.get_global("lambda_sterics"), "lambda_electrostatics": e.get_global("lambda_electrostatics")}

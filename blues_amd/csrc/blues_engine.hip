@@ -197,9 +197,15 @@ struct BluesBatch {
     // list synchronisation: in a large batch some member needs new lists at almost every step, and the launch lasts as long
     // as one rebuild whoever asks; when they all rebuild together (any request rebuilds all) most steps see no rebuild at all
     DBuf<int> d_req; bool sync_lists = false;
+    // Members keep their own streams for everything that is per replica (moves, state exchange, energies) so that host
+    // threads serving different chains overlap; stepping runs on the batch's stream.  enter: the batch stream waits for
+    // each member's pending work and the members issue into it; leave: the batch stream is drained, members go home.
+    hipStream_t stream = nullptr; bool entered = false;
     int64_t st_lockstep_steps = 0, st_fallback_steps = 0;
     int R() const { return (int)eng.size(); }
 };
+static int batch_enter(BluesBatch* B);
+static void batch_leave(BluesBatch* B);
 static inline bool batch_dry(const BluesEngine* h) { return h->batch && h->batch->lockstep && h->batch->leader != h; }
 static inline bool batch_lead(const BluesEngine* h) { return h->batch && h->batch->lockstep && h->batch->leader == h; }
 static inline int* batch_req_ptr(const BluesEngine* h) { return h->batch && h->batch->sync_lists ? h->batch->d_req.p : nullptr; }
@@ -626,7 +632,7 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
 
 template <typename R, bool ENERGY, int WPB> static void launch_nb_wpb(BluesEngine* h, const NbArgs<R>& a, const typename Img<R>::Atom* img) {
     const int blocks = std::max(1, h->n_itiles) * (h->waves_tile / WPB);
-    if (batch_lead(h)) hipLaunchKernelGGL((k_nonbonded_b<R, ENERGY, WPB>), dim3(blocks, h->batch->R()), dim3(WPB * 64), 0, h->cur, batch_reps_nb<R>(h->batch));
+    if (batch_lead(h)) hipLaunchKernelGGL((k_nonbonded_b<R, ENERGY, WPB>), dim3(blocks * h->batch->R()), dim3(WPB * 64), 0, h->cur, batch_reps_nb<R>(h->batch), blocks, h->batch->R());
     else if (!batch_dry(h)) hipLaunchKernelGGL((k_nonbonded<R, ENERGY, WPB>), dim3(blocks), dim3(WPB * 64), 0, h->cur, a, make_nbconst<R>(h), img);
 }
 
@@ -642,13 +648,15 @@ template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
 template <bool ENERGY> static void launch_nb_sub(BluesEngine* h, const NbArgs<float>& a) {
     const int subs = 64 / h->k1_iw;
     const int waves = std::max(1, h->n_itiles) * subs * h->waves_tile;
-    const dim3 grid((waves + 3) / 4, batch_lead(h) ? h->batch->R() : 1), block(256);
+    const dim3 grid((waves + 3) / 4), block(256);
     if (batch_dry(h)) return;
     if (batch_lead(h)) {
         const RepNb<float>* reps = h->batch->d_nb_f.p;
-        if (h->k1_iw == 8) hipLaunchKernelGGL((k_nonbonded_sub_b<ENERGY, 8>), grid, block, 0, h->cur, reps);
-        else if (h->k1_iw == 16) hipLaunchKernelGGL((k_nonbonded_sub_b<ENERGY, 16>), grid, block, 0, h->cur, reps);
-        else hipLaunchKernelGGL((k_nonbonded_sub_b<ENERGY, 32>), grid, block, 0, h->cur, reps);
+        const int nb = (waves + 3) / 4, nrep = h->batch->R();
+        const dim3 bgrid(nb * nrep);
+        if (h->k1_iw == 8) hipLaunchKernelGGL((k_nonbonded_sub_b<ENERGY, 8>), bgrid, block, 0, h->cur, reps, nb, nrep);
+        else if (h->k1_iw == 16) hipLaunchKernelGGL((k_nonbonded_sub_b<ENERGY, 16>), bgrid, block, 0, h->cur, reps, nb, nrep);
+        else hipLaunchKernelGGL((k_nonbonded_sub_b<ENERGY, 32>), bgrid, block, 0, h->cur, reps, nb, nrep);
         return;
     }
     if (h->k1_iw == 8) hipLaunchKernelGGL((k_nonbonded_sub<ENERGY, 8>), grid, block, 0, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
@@ -690,8 +698,9 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
     AlchArgs A = make_alch_args(h, ls, le, slot_mask);
     const bool fast = h->precision == 0;
     if (batch_lead(h)) {
-        if (fast) hipLaunchKernelGGL(k_alchemical_b<true>, dim3(h->k2_nblocks_env + 1, h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, make_alch_dyn(A));
-        else hipLaunchKernelGGL(k_alchemical_b<false>, dim3(h->k2_nblocks_env + 1, h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, make_alch_dyn(A));
+        const int nb = h->k2_nblocks_env + 1, nrep = h->batch->R();
+        if (fast) hipLaunchKernelGGL(k_alchemical_b<true>, dim3(nb * nrep), dim3(256), 0, h->cur, h->batch->d_core.p, make_alch_dyn(A), nb, nrep);
+        else hipLaunchKernelGGL(k_alchemical_b<false>, dim3(nb * nrep), dim3(256), 0, h->cur, h->batch->d_core.p, make_alch_dyn(A), nb, nrep);
     } else if (!batch_dry(h)) {
         if (fast) hipLaunchKernelGGL(k_alchemical<true>, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->cur, A);
         else hipLaunchKernelGGL(k_alchemical<false>, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->cur, A);
@@ -763,7 +772,10 @@ static int launch_finalize(BluesEngine* h, const double le[3], int slot_mask = 7
     const int nblk = h->n_islots / 64 + (F.n_alch > 0 ? 1 + 9 + 1 : 0);
     FinDyn FD; for (int s = 0; s < 3; s++) FD.le[s] = le[s];
     FD.slot_mask = slot_mask;
-    if (batch_lead(h)) hipLaunchKernelGGL(k_finalize_b, dim3(std::max(1, nblk), h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, FD);
+    if (batch_lead(h)) {
+        if (h->batch->R() >= 8) hipLaunchKernelGGL(k_finalize_b<true>, dim3(std::max(1, nblk), h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, FD);
+        else hipLaunchKernelGGL(k_finalize_b<false>, dim3(std::max(1, nblk), h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p, FD);
+    }
     else if (!batch_dry(h)) hipLaunchKernelGGL(k_finalize, dim3(std::max(1, nblk)), dim3(256), 0, h->cur, F);
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
@@ -1180,6 +1192,22 @@ struct BatchSig {
     unsigned char pass_valid, lists_forced, vel_clean, noise_valid, tracing, sorted_ok, pass_valid_for_l, have_positions;
     unsigned char ops[MAX_OPS];
 };
+static int batch_enter(BluesBatch* B) {
+    if (B->entered) return 0;
+    for (BluesEngine* m : B->eng) {
+        if (hipEventRecord(m->evFork, m->stream) != hipSuccess || hipStreamWaitEvent(B->stream, m->evFork, 0) != hipSuccess) { B->err = "could not order the batch stream after a member's stream"; return 1; }
+        m->own_stream = m->stream; m->stream = B->stream; m->cur = B->stream;
+    }
+    B->entered = true;
+    return 0;
+}
+static void batch_leave(BluesBatch* B) {
+    if (!B->entered) return;
+    hipStreamSynchronize(B->stream);
+    for (BluesEngine* m : B->eng) if (m->own_stream) { m->stream = m->own_stream; m->cur = m->own_stream; m->own_stream = nullptr; }
+    B->entered = false;
+}
+
 static BatchSig batch_sig(const BluesEngine* h) {
     BatchSig g; memset(&g, 0, sizeof g);
     g.h_step = h->h_step; g.h_lambda_step = h->h_lambda_step; g.h_prop = h->h_prop; g.h_first_step = h->h_first_step; g.pass_L = h->pass_valid ? h->pass_L : 0;
@@ -1235,7 +1263,7 @@ static int batch_refresh_args(BluesBatch* B) {
         B->seen_epoch[r] = h->args_epoch;
     }
     // the records may be in use by launches still in flight
-    if (hipStreamSynchronize(B->leader ? B->leader->stream : B->eng[0]->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
+    if (hipStreamSynchronize(B->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
     try { B->d_core.upload(core); if (single) B->d_nb_f.upload(nf); else B->d_nb_d.upload(nd); } catch (std::string& e) { B->err = e; return 1; }
     return 0;
 }
@@ -1414,13 +1442,14 @@ static int relayout(BluesEngine* h) {
 
 static void batch_detach_all(BluesBatch* B) {
     if (!B) return;
+    batch_leave(B);
     for (BluesEngine* m : B->eng) if (m) {
         hipStreamSynchronize(m->stream);
-        if (m->own_stream) { m->stream = m->own_stream; m->cur = m->own_stream; m->own_stream = nullptr; }
         m->batch = nullptr; m->batch_index = -1; m->batch_R = 1;
         relayout(m);
     }
     B->eng.clear(); B->leader = nullptr; B->lockstep = false;
+    if (B->stream) { hipStreamDestroy(B->stream); B->stream = nullptr; }
 }
 
 int blues_engine_destroy(BluesEngine* h) {
@@ -1848,12 +1877,12 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
     }
     BluesBatch* B = new BluesBatch();
     hipSetDevice(engines[0]->device);
+    if (hipStreamCreate(&B->stream) != hipSuccess) { g_batch_create_error = "hipStreamCreate failed"; delete B; return 1; }
     for (int r = 0; r < count; r++) {
         BluesEngine* m = engines[r];
         if (flush_program(m) || hipStreamSynchronize(m->stream) != hipSuccess) { g_batch_create_error = "could not drain engine stream: " + m->err; batch_detach_all(B); delete B; return 1; }
         B->eng.push_back(m); m->batch = B; m->batch_index = r;
         m->batch_R = count;
-        if (r > 0) { m->own_stream = m->stream; m->stream = engines[0]->stream; m->cur = m->stream; }
         m->use_graph = false;  // graph replays carry per-engine frozen arguments
     }
     for (int r = 0; r < count; r++) if (relayout(engines[r])) { g_batch_create_error = "re-layout for the batch failed: " + engines[r]->err; batch_detach_all(B); delete B; return 1; }
@@ -1889,7 +1918,9 @@ int blues_batch_step(BluesBatch* b, int32_t n_steps, double* work_trace, int32_t
     const int R = b->R();
     std::vector<int> st(R, 0), first(R, 0);
     for (int r = 0; r < R; r++) first[r] = b->eng[r]->h_step;
+    if (batch_enter(b)) return 1;
     const int rc = batch_do_steps(b, n_steps, work_trace != nullptr, st.data());
+    batch_leave(b);
     if (status) for (int r = 0; r < R; r++) status[r] = st[r];
     if (rc) return rc;
     if (work_trace) for (int r = 0; r < R; r++) {
@@ -1914,7 +1945,8 @@ int blues_batch_time_nonbonded(BluesBatch* b, int32_t reps, double* usec) {
     if (hipSetDevice(h->device) != hipSuccess) { b->err = "hipSetDevice failed"; return 1; }
     for (BluesEngine* m : b->eng) { if (flush_program(m) || ensure_sorted(m)) { b->err = m->err; return 1; } m->pass_valid = false; }
     b->failed.assign(b->R(), 0); b->active.assign(b->R(), 1);
-    if (batch_refresh_args(b)) return 1;
+    if (batch_enter(b)) return 1;
+    if (batch_refresh_args(b)) { batch_leave(b); return 1; }
     b->leader = h; b->lockstep = true;
     int rc = h->precision == 0 ? launch_lists<float>(h, 1) : launch_lists<double>(h, 1);
     for (int w = 0; w < 3 && !rc; w++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
@@ -1923,10 +1955,11 @@ int blues_batch_time_nonbonded(BluesBatch* b, int32_t reps, double* usec) {
     if (!rc && hipEventRecord(h->ev1, h->stream) != hipSuccess) rc = 1;
     b->lockstep = false;
     for (BluesEngine* m : b->eng) m->lists_forced = false;
-    if (rc || hipEventSynchronize(h->ev1) != hipSuccess) { b->err = "timing launch failed: " + h->err; return 1; }
+    if (rc || hipEventSynchronize(h->ev1) != hipSuccess) { b->err = "timing launch failed: " + h->err; batch_leave(b); return 1; }
     float ms = 0.f;
     hipEventElapsedTime(&ms, h->ev0, h->ev1);
     *usec = 1000.0 * ms / std::max(1, reps);
+    batch_leave(b);
     for (BluesEngine* m : b->eng) if (check_flags(m)) { b->err = m->err; return 1; }
     return 0;
 }

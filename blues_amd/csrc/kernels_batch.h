@@ -24,6 +24,17 @@ struct RepCore {
     AlchArgs al; BondedArgs bo; FinArgs fin; IntArgs in;
 };
 
+// XCD-aware block -> (replica, block-in-replica) map for the kernels that re-read a replica's atoms many times (nonbonded,
+// alchemical).  The 8 XCDs of an MI355X each have their own L2 and take workgroups round-robin by linear id, so with a plain
+// (x = block, y = replica) grid every replica's tile image would be pulled into all eight L2s.  Launched 1-D with nb*R
+// blocks, linear id L runs on XCD L % 8; V = (L % 8) * (total / 8) + L / 8 walks each XCD's share contiguously, and
+// replica = V / nb keeps all blocks of a replica on one XCD (R a multiple of 8; otherwise the identity map).
+__device__ __forceinline__ void batch_decode(int nb, int R, int& rep, int& bx) {
+    const int L = blockIdx.x, total = nb * R;
+    const int V = (R & 7) == 0 ? (L & 7) * (total >> 3) + (L >> 3) : L;
+    rep = V / nb; bx = V - rep * nb;
+}
+
 struct AlchDyn { double ls[3], le[3]; int slot_mask; };
 struct BondedDyn { unsigned draw_base; int n_entry_blocks; };
 struct FinDyn { double le[3]; int slot_mask; };
@@ -55,26 +66,29 @@ __global__ void __launch_bounds__(LIST_THREADS) k_build_lists_b(const RepNb<R>* 
 }
 
 template <typename R, bool ENERGY, int WPB>
-__global__ void __launch_bounds__(WPB * 64) k_nonbonded_b(const RepNb<R>* __restrict__ reps) {
-    const RepNb<R>& rp = reps[blockIdx.y];
+__global__ void __launch_bounds__(WPB * 64) k_nonbonded_b(const RepNb<R>* __restrict__ reps, int nb, int nrep) {
+    int rep, bx; batch_decode(nb, nrep, rep, bx);
+    const RepNb<R>& rp = reps[rep];
     if (!rp.active) return;
     const NbArgs<R> a = rp.nb; const NbConst<R> c = rp.c;
-    nonbonded_body<R, ENERGY, WPB>(a, c, rp.img, blockIdx.x);
+    nonbonded_body<R, ENERGY, WPB>(a, c, rp.img, bx);
 }
 
 template <bool ENERGY, int IW>
-__global__ void __launch_bounds__(256) k_nonbonded_sub_b(const RepNb<float>* __restrict__ reps) {
-    const RepNb<float>& rp = reps[blockIdx.y];
+__global__ void __launch_bounds__(256) k_nonbonded_sub_b(const RepNb<float>* __restrict__ reps, int nb, int nrep) {
+    int rep, bx; batch_decode(nb, nrep, rep, bx);
+    const RepNb<float>& rp = reps[rep];
     if (!rp.active) return;
     const NbArgs<float> a = rp.nb; const NbConst<float> c = rp.c;
-    nonbonded_sub_body<ENERGY, IW>(a, c, rp.img, blockIdx.x);
+    nonbonded_sub_body<ENERGY, IW>(a, c, rp.img, bx);
 }
 
 template <bool FAST>
-__global__ void __launch_bounds__(256) k_alchemical_b(const RepCore* __restrict__ reps, AlchDyn d) {
-    if (!reps[blockIdx.y].active) return;
-    AlchArgs A = reps[blockIdx.y].al; apply_dyn(A, d);
-    alchemical_body<FAST>(A, blockIdx.x);
+__global__ void __launch_bounds__(256) k_alchemical_b(const RepCore* __restrict__ reps, AlchDyn d, int nb, int nrep) {
+    int rep, bx; batch_decode(nb, nrep, rep, bx);
+    if (!reps[rep].active) return;
+    AlchArgs A = reps[rep].al; apply_dyn(A, d);
+    alchemical_body<FAST>(A, bx);
 }
 
 __global__ void __launch_bounds__(128) k_bonded_entries_b(const RepCore* __restrict__ reps, BondedDyn d) {
@@ -83,10 +97,11 @@ __global__ void __launch_bounds__(128) k_bonded_entries_b(const RepCore* __restr
     bonded_entries_body(B, blockIdx.x, 128);
 }
 
+template <bool LEAN>
 __global__ void __launch_bounds__(256) k_finalize_b(const RepCore* __restrict__ reps, FinDyn d) {
     if (!reps[blockIdx.y].active) return;
     FinArgs F = reps[blockIdx.y].fin; apply_dyn(F, d);
-    finalize_body(F);
+    finalize_body<LEAN>(F);
 }
 
 template <typename R>

@@ -248,6 +248,9 @@ struct FinArgs {
 //       then 9 blocks (one per slot x component) for the alchemical self-force slabs | 1 block for the energies.
 // Every sum is spread over the 4 waves of a block with 4 loads in flight per lane, then combined in LDS in a
 // fixed order (deterministic, and no chain of dependent global loads).
+// LEAN: same sums in the same order without the deep load batching -- for replica batches, where thousands of these blocks
+// are resident and occupancy (registers) counts for more than the latency of one block's load chain
+template <bool LEAN>
 __device__ __forceinline__ void finalize_body(FinArgs& A) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (A.ctrl) {
@@ -273,7 +276,7 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
         if (i >= 0) {
             if (isl >= 0) {
                 int p = wv;
-                for (; p + 28 < A.npart; p += 32) {  // 8 partials x 3 components in flight
+                if (!LEAN) for (; p + 28 < A.npart; p += 32) {  // 8 partials x 3 components in flight
                     double t[8][3];
 #pragma unroll
                     for (int u = 0; u < 8; u++)
@@ -282,7 +285,7 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
                 }
-                for (; p + 12 < A.npart; p += 16) {  // 4 partials x 3 components in flight
+                if (!LEAN) for (; p + 12 < A.npart; p += 16) {  // 4 partials x 3 components in flight
                     double t[4][3];
 #pragma unroll
                     for (int u = 0; u < 4; u++)
@@ -294,6 +297,10 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
                 for (; p < A.npart; p += 4)
                     for (int k = 0; k < 3; k++) f[k] += A.fpart[((size_t)p * 3 + k) * A.n_islots + isl];
             }
+            if (LEAN) {
+                for (int e = rec.e0 + wv; e < rec.e1; e += 4)
+                    for (int k = 0; k < 3; k++) f[k] += A.fent[(size_t)k * A.n_entries + e];
+            } else
             for (int e = rec.e0 + wv; e < rec.e1; e += 32) {  // up to 8 bonded entries x 3 components in flight
                 double t[8][3];
 #pragma unroll
@@ -307,11 +314,14 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
         red[wv][0][lane] = f[0]; red[wv][1][lane] = f[1]; red[wv][2][lane] = f[2];
         __syncthreads();
         if (wv == 0 && i >= 0) {
+#pragma unroll
             for (int k = 0; k < 3; k++) {
                 const double f = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
                 if (isl >= 0 && A.n_alch > 0) {
+#pragma unroll
                     for (int sl = 0; sl < 3; sl++) if ((A.slot_mask >> sl) & 1) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f + fj[sl][k];
                 } else if (isl >= 0) {
+#pragma unroll
                     for (int sl = 0; sl < 3; sl++) if ((A.slot_mask >> sl) & 1) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f;
                 } else A.ftot[(size_t)k * A.n + i] = f;  // alchemical atom: bonded part; integrator adds alch_self[slot]
             }
@@ -361,11 +371,15 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
         if (lane == 0) s_e[q] = s;
     }
     __syncthreads();
-    if (tid < 3) A.acc->e_slot[tid] = A.le[tid] * s_e[0] + s_e[1 + tid];
+    // (constant indices only: a runtime index into A -- even a select between its fields -- keeps the whole argument
+    // struct in scratch memory and turns every A.field access of the kernel into a scratch load)
+    if (tid == 0) A.acc->e_slot[0] = A.le[0] * s_e[0] + s_e[1];
+    if (tid == 1) A.acc->e_slot[1] = A.le[1] * s_e[0] + s_e[2];
+    if (tid == 2) A.acc->e_slot[2] = A.le[2] * s_e[0] + s_e[3];
     if (tid < 6) A.mom_part[(size_t)(n_itiles + 1) * 6 + tid] = tid < 3 ? 0.0 : s_e[K2_NE + tid - 3];  // alchemical pair force on the alchemical atoms
 }
 
-__global__ void __launch_bounds__(256) k_finalize(FinArgs A) { finalize_body(A); }
+__global__ void __launch_bounds__(256) k_finalize(FinArgs A) { finalize_body<false>(A); }
 
 // `prog` is passed beside A so that the batched launch (kernels_batch.h) can hand over the shared program from its own
 // kernel arguments while A is a per-replica copy
