@@ -72,11 +72,16 @@ def one_switch(driver, chains, states, nsteps, it, clock):
     from blues_amd.replicas import gather_decision_block
     each = driver.for_each_chain if driver is not None else (lambda fn: [fn(r, c) for r, c in enumerate(chains)])
 
-    def sync(r, c):
+    def hand_over(r, c):
         c._ncmc_sim.context = c.setContextFromState(c._ncmc_sim.context, states[r])
+
+    def sync(r, c):
         c.currentIter = it
         c._syncStatesMDtoNCMC()
     t0 = time.perf_counter()
+    each(hand_over)
+    if driver is not None:
+        driver._ncmc_batch.prefetch_energies()
     each(sync)
     t1 = time.perf_counter()
     if driver is None:

@@ -233,6 +233,7 @@ def declare_engine_prototypes(lib):
         "blues_batch_size": ([H], C.c_int),
         "blues_batch_step": ([H, C.c_int32, _dp, C.POINTER(C.c_int32)], C.c_int),
         "blues_batch_set_active": ([H, C.POINTER(C.c_int32)], C.c_int),
+        "blues_batch_prefetch_energies": ([H, C.c_int32], C.c_int),
         "blues_batch_get_stats": ([H, C.POINTER(C.c_int64)], C.c_int),
         "blues_batch_time_nonbonded": ([H, C.c_int32, _dp], C.c_int),
     }
@@ -251,6 +252,6 @@ ENGINE_SYMBOLS = (
     "blues_set_global", "blues_reset", "blues_get_stats", "blues_time_nonbonded",
     "blues_snapshot_capture", "blues_snapshot_release", "blues_snapshot_read", "blues_set_positions_from_snapshot",
     "blues_set_velocities_from_snapshot",
-    "blues_batch_create", "blues_batch_destroy", "blues_batch_last_error", "blues_batch_size", "blues_batch_step", "blues_batch_set_active",
+    "blues_batch_create", "blues_batch_destroy", "blues_batch_last_error", "blues_batch_size", "blues_batch_step", "blues_batch_set_active", "blues_batch_prefetch_energies",
     "blues_batch_get_stats", "blues_batch_time_nonbonded",
 )

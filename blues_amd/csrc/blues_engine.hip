@@ -130,6 +130,7 @@ struct BluesEngine {
     std::vector<double> hx_sort;   // positions at the last sort
     double e_frozen[2] = {0, 0}; bool e_frozen_valid = false;
     double e_cache = 0, e_cache_ls = 0, e_cache_le = 0; bool e_cache_valid = false;  // total potential energy at the current positions
+    double ke_cache = 0; bool ke_cache_valid = false;
     // ---- derived topology
     std::vector<int> mobile;       // caller indices with mass > 0
     std::vector<HostCluster> clusters;
@@ -201,6 +202,7 @@ struct BluesBatch {
     // threads serving different chains overlap; stepping runs on the batch's stream.  enter: the batch stream waits for
     // each member's pending work and the members issue into it; leave: the batch stream is drained, members go home.
     hipStream_t stream = nullptr; bool entered = false;
+    DBuf<double> d_gather; int64_t st_prefetch_pe = 0, st_prefetch_ke = 0;
     int64_t st_lockstep_steps = 0, st_fallback_steps = 0;
     int R() const { return (int)eng.size(); }
 };
@@ -560,7 +562,7 @@ static IntArgs make_int_args(BluesEngine* h) {
 
 static int flush_program(BluesEngine* h) {
     if (h->prog.n == 0) return 0;
-    h->e_cache_valid = false;   // the launch may move atoms
+    h->e_cache_valid = false; h->ke_cache_valid = false;   // the launch may move atoms
     IntArgs A = make_int_args(h);
     // the steady-state program of "H V R O R V H" has a straight-line specialisation (same arithmetic)
     static const unsigned char P_CM[9] = {OP_V0, OP_H01, OP_END, OP_CM_PART, OP_H12, OP_V2, OP_R, OP_O, OP_R};
@@ -906,11 +908,23 @@ static int poll_resort(BluesEngine* h) {
     return relayout(h);
 }
 
-// full potential energy breakdown at the current state and alchemical parameters (on demand; synchronises)
-static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
+// launch geometry of an energy evaluation (partials per kind)
+struct EnergyShape { int nw, nbb, nfb; size_t off_frozen; };
+static EnergyShape energy_shape(const BluesEngine* h) {
+    EnergyShape g;
+    const int subs = h->k1_iw != 64 ? 64 / h->k1_iw : 1;
+    g.nw = h->n_itiles * h->npart * subs;
+    g.off_frozen = (size_t)std::max(1, h->n_itiles) * h->npart * 2 * subs;
+    int total_terms = 0; for (int ty = 0; ty < T_NTYPES; ty++) total_terms += h->n_terms[ty];
+    g.nbb = (total_terms + 255) / 256; g.nfb = (h->n + 255) / 256;
+    return g;
+}
+
+// the launches of an energy evaluation at the current state and alchemical parameters (lock-step capable: in a batch the
+// leader's launches cover every member that takes part)
+static int energy_launch(BluesEngine* h) {
     if (flush_program(h)) return 1;
     if (ensure_sorted(h)) return 1;
-    for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) T[t] = 0.0;
     double ls[3] = {h->cur_ls, h->cur_ls, h->cur_ls}, le[3] = {h->cur_le, h->cur_le, h->cur_le};
     int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced) : launch_lists<double>(h, h->lists_forced);
     h->lists_forced = false;
@@ -919,42 +933,55 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
     if (launch_alchemical(h, ls, le, 1)) return 1;
     rc = h->precision == 0 ? launch_nonbonded<float, true>(h) : launch_nonbonded<double, true>(h);
     if (rc) return 1;
-    int total_terms = 0; for (int ty = 0; ty < T_NTYPES; ty++) total_terms += h->n_terms[ty];
-    const int nbb = (total_terms + 255) / 256;
-    if (nbb > 0) { hipLaunchKernelGGL(k_bonded_energy, dim3(nbb), dim3(256), 0, h->stream, make_bonded_args(h)); h->st_launches++; }
-    const int nfb = (h->n + 255) / 256;
+    const EnergyShape g = energy_shape(h);
+    if (g.nbb > 0) {
+        if (batch_lead(h)) hipLaunchKernelGGL(k_bonded_energy_b, dim3(g.nbb, h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p);
+        else if (!batch_dry(h)) hipLaunchKernelGGL(k_bonded_energy, dim3(g.nbb), dim3(256), 0, h->cur, make_bonded_args(h));
+        h->st_launches++;
+    }
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+// the host-side sums over the partials, in a fixed order (the same whether they were downloaded one engine at a time or
+// gathered for a whole batch)
+static void energy_sum(BluesEngine* h, const double* enb, const double* eb, int jcount_alch, const double* ep, double T[BLUES_N_ENERGY_TERMS]) {
+    const EnergyShape g = energy_shape(h);
+    for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) T[t] = 0.0;
+    double e_nb = 0.0; for (int w = 0; w < g.nw; w++) e_nb += enb[2 * w] + enb[2 * w + 1];
+    T[3] = e_nb + h->e_frozen[0] + h->e_frozen[1];
+    for (int b = 0; b < g.nbb; b++) { T[0] += eb[b * T_NTYPES + T_BOND]; T[1] += eb[b * T_NTYPES + T_ANGLE]; T[2] += eb[b * T_NTYPES + T_TORSION]; T[4] += eb[b * T_NTYPES + T_EXC]; T[7] += eb[b * T_NTYPES + T_RESTR]; }
+    if (!h->alch.empty()) {
+        const int nb_env = k2_env_blocks(jcount_alch, h->PA, h->k2_jiter);
+        double s[K2_NE] = {0, 0, 0, 0, 0, 0};
+        for (int b = 0; b <= h->k2_nblocks_env; b++) { if (b >= nb_env && b != h->k2_nblocks_env) continue; for (int q = 0; q < K2_NE; q++) s[q] += ep[(size_t)b * K2_NP + q]; }
+        T[5] = s[1] + s[4]; T[6] = h->cur_le * s[0] + s[5];
+    }
+}
+
+// full potential energy breakdown at the current state and alchemical parameters (on demand; synchronises)
+static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
+    if (energy_launch(h)) return 1;
+    const EnergyShape g = energy_shape(h);
     if (!h->e_frozen_valid) {
-        double* ep = h->d_epart_nb.p + (size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_iw != 64 ? 64 / h->k1_iw : 1);
-        if (h->precision == 0) hipLaunchKernelGGL(k_energy_frozen<float>, dim3(nfb), dim3(256), 0, h->stream, h->n, make_nbconst<float>(h), h->d_img_f.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
-        else hipLaunchKernelGGL(k_energy_frozen<double>, dim3(nfb), dim3(256), 0, h->stream, h->n, make_nbconst<double>(h), h->d_img_d.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
+        double* ep = h->d_epart_nb.p + g.off_frozen;
+        if (h->precision == 0) hipLaunchKernelGGL(k_energy_frozen<float>, dim3(g.nfb), dim3(256), 0, h->stream, h->n, make_nbconst<float>(h), h->d_img_f.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
+        else hipLaunchKernelGGL(k_energy_frozen<double>, dim3(g.nfb), dim3(256), 0, h->stream, h->n, make_nbconst<double>(h), h->d_img_d.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
         h->st_launches++;
     }
     if (check_flags(h)) return 1;
-    std::vector<double> e;
+    std::vector<double> enb, eb, ep; std::vector<int> jc;
     try {
-        h->d_epart_nb.download(e);
-        const int nw = h->n_itiles * h->npart * (h->k1_iw != 64 ? 64 / h->k1_iw : 1);
-        double enb = 0.0; for (int w = 0; w < nw; w++) enb += e[2 * w] + e[2 * w + 1];
+        h->d_epart_nb.download(enb);
         if (!h->e_frozen_valid) {
-            const size_t off = (size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_iw != 64 ? 64 / h->k1_iw : 1);
             h->e_frozen[0] = h->e_frozen[1] = 0.0;
-            for (int b = 0; b < nfb; b++) { h->e_frozen[0] += e[off + 2 * b]; h->e_frozen[1] += e[off + 2 * b + 1]; }
+            for (int b = 0; b < g.nfb; b++) { h->e_frozen[0] += enb[g.off_frozen + 2 * b]; h->e_frozen[1] += enb[g.off_frozen + 2 * b + 1]; }
             h->e_frozen_valid = true;
         }
-        T[3] = enb + h->e_frozen[0] + h->e_frozen[1];
-        if (nbb > 0) {
-            h->d_epart_b.download(e);
-            for (int b = 0; b < nbb; b++) { T[0] += e[b * T_NTYPES + T_BOND]; T[1] += e[b * T_NTYPES + T_ANGLE]; T[2] += e[b * T_NTYPES + T_TORSION]; T[4] += e[b * T_NTYPES + T_EXC]; T[7] += e[b * T_NTYPES + T_RESTR]; }
-        }
-        if (!h->alch.empty()) {
-            std::vector<int> jc; h->d_jcount.download(jc);
-            const int cnt = jc[h->n_itiles], nb_env = k2_env_blocks(cnt, h->PA, h->k2_jiter);
-            h->d_e_part.download(e);
-            double s[K2_NE] = {0, 0, 0, 0, 0, 0};
-            for (int b = 0; b <= h->k2_nblocks_env; b++) { if (b >= nb_env && b != h->k2_nblocks_env) continue; for (int q = 0; q < K2_NE; q++) s[q] += e[(size_t)b * K2_NP + q]; }
-            T[5] = s[1] + s[4]; T[6] = h->cur_le * s[0] + s[5];
-        }
+        if (g.nbb > 0) h->d_epart_b.download(eb);
+        if (!h->alch.empty()) { h->d_jcount.download(jc); h->d_e_part.download(ep); }
     } catch (std::string& msg) { E_FAIL(h, "%s", msg.c_str()); }
+    energy_sum(h, enb.data(), eb.data(), h->alch.empty() ? 0 : jc[h->n_itiles], ep.data(), T);
     return 0;
 }
 
@@ -1268,6 +1295,99 @@ static int batch_refresh_args(BluesBatch* B) {
     return 0;
 }
 
+// Total potential and/or kinetic energy of every active member with batched launches and ONE read-back; the values land in
+// the members' energy caches, where the per-member getState / setPositions bookkeeping that follows finds them (the
+// reference asks each Context separately: simulation.py:908-909).  Sums are formed on the host from the same partials in
+// the same order as a lone evaluation.  Members that cannot take part (other alchemical parameters than the rest, a
+// pending one-off frozen-frozen energy) are simply left for their own on-demand evaluation.
+static int batch_prefetch(BluesBatch* B, int what) {
+    const int R = B->R();
+    if (R == 0) return 0;
+    std::vector<char> live(R), need(R, 0);
+    for (int r = 0; r < R; r++) live[r] = B->active[r] && !B->failed[r] && B->eng[r]->have_positions && B->eng[r]->sorted_ok;
+    BluesEngine* lead = nullptr;
+    for (int r = 0; r < R; r++) if (live[r]) { lead = B->eng[r]; break; }
+    if (!lead) return 0;
+    for (int r = 0; r < R; r++) if (B->active[r] && !B->failed[r] && !live[r]) return 0;   // a member without a layout yet: everybody evaluates on demand
+    const bool was_entered = B->entered;
+    bool ok = true;
+    if (what & 1) {
+        int n_need = 0, n_live = 0;
+        for (int r = 0; r < R; r++) if (live[r] && !B->eng[r]->e_frozen_valid) {   // one-off constant of a member: its own evaluation
+            double E;
+            if (total_energy(B->eng[r], &E)) { B->failed[r] = 1; live[r] = 0; }
+        }
+        for (int r = 0; r < R; r++) if (live[r]) {
+            BluesEngine* m = B->eng[r];
+            n_live++;
+            need[r] = !(m->e_cache_valid && m->e_cache_ls == m->cur_ls && m->e_cache_le == m->cur_le);
+            n_need += need[r];
+        }
+        bool uniform = n_need == n_live && n_need > 1;   // (a partial set would have to mask the others out of the launches)
+        for (int r = 0; r < R && uniform; r++) if (live[r]) {
+            const BluesEngine* m = B->eng[r];
+            uniform = m->e_frozen_valid && m->cur_ls == lead->cur_ls && m->cur_le == lead->cur_le && m->lists_forced == lead->lists_forced && m->prog.n == 0;
+            const char* why = "";
+            uniform = uniform && batch_congruent(lead, m, &why);
+        }
+        if (uniform) {
+            if (batch_enter(B)) return 1;
+            B->leader = lead;
+            if (batch_refresh_args(B)) { if (!was_entered) batch_leave(B); return 1; }
+            B->lockstep = true;
+            for (int r = 0; r < R && ok; r++) if (live[r]) ok = energy_launch(B->eng[r]) == 0;
+            B->lockstep = false;
+            const EnergyShape g = energy_shape(lead);
+            const int n_nb = 2 * g.nw, n_b = g.nbb * T_NTYPES, n_al = lead->alch.empty() ? 0 : (lead->k2_nblocks_env + 1) * K2_NP, stride = n_nb + n_b + n_al + 1;
+            std::vector<double> slab; std::vector<int> hints;
+            try {
+                if (ok) {
+                    if (B->d_gather.n != (size_t)R * stride) B->d_gather.alloc((size_t)R * stride);
+                    if ((int)B->d_hints.n != R) B->d_hints.alloc(R);
+                    if (lead->precision == 0) hipLaunchKernelGGL(k_gather_energy_parts_b<float>, dim3(R), dim3(256), 0, B->stream, B->d_nb_f.p, B->d_core.p, n_nb, n_b, n_al, stride, B->d_gather.p);
+                    else hipLaunchKernelGGL(k_gather_energy_parts_b<double>, dim3(R), dim3(256), 0, B->stream, B->d_nb_d.p, B->d_core.p, n_nb, n_b, n_al, stride, B->d_gather.p);
+                    hipLaunchKernelGGL(k_gather_hints_b, dim3((R + 255) / 256), dim3(256), 0, B->stream, B->d_core.p, R, B->d_hints.p);
+                    ok = hipStreamSynchronize(B->stream) == hipSuccess;
+                    if (ok) { B->d_gather.download(slab); B->d_hints.download(hints); }
+                }
+            } catch (std::string& e) { B->err = e; ok = false; }
+            if (ok) for (int r = 0; r < R; r++) if (live[r] && !(hints[r] & 2)) {   // a member with an error flag keeps no cached value: its own call will report
+                BluesEngine* m = B->eng[r];
+                const double* o = slab.data() + (size_t)r * stride;
+                double T[BLUES_N_ENERGY_TERMS], E = 0.0;
+                energy_sum(m, o, o + n_nb, (int)o[n_nb + n_b + n_al], o + n_nb + n_b, T);
+                for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) E += T[t];
+                m->e_cache = E; m->e_cache_ls = m->cur_ls; m->e_cache_le = m->cur_le; m->e_cache_valid = true;
+            }
+            B->st_prefetch_pe++;
+        }
+    }
+    if (ok && (what & 2)) {
+        bool any = false;
+        for (int r = 0; r < R; r++) if (live[r]) any |= !B->eng[r]->ke_cache_valid;
+        if (any) {
+            if (batch_enter(B)) return 1;
+            for (int r = 0; r < R && ok; r++) if (live[r]) ok = flush_program(B->eng[r]) == 0;   // (nothing pending in the usual call sites)
+            B->leader = lead;
+            if (ok && batch_refresh_args(B)) ok = false;
+            std::vector<double> ke;
+            try {
+                if (ok) {
+                    if (B->d_gather.n < (size_t)R) B->d_gather.alloc((size_t)R);
+                    hipLaunchKernelGGL(k_kinetic_b, dim3(R), dim3(256), 0, B->stream, B->d_core.p, B->d_gather.p);
+                    ok = hipStreamSynchronize(B->stream) == hipSuccess;
+                    if (ok) { ke.resize(R); ok = hipMemcpy(ke.data(), B->d_gather.p, sizeof(double) * R, hipMemcpyDeviceToHost) == hipSuccess; }
+                }
+            } catch (std::string& e) { B->err = e; ok = false; }
+            if (ok) for (int r = 0; r < R; r++) if (live[r]) { B->eng[r]->ke_cache = ke[r]; B->eng[r]->ke_cache_valid = true; }
+            B->st_prefetch_ke++;
+        }
+    }
+    if (!was_entered) batch_leave(B);
+    if (!ok && B->err.empty()) B->err = "energy prefetch failed: " + lead->err;
+    return ok ? 0 : 1;
+}
+
 // Advances every member by n_steps.  status[r] != 0: member r raised (message via blues_last_error(engine r)); the
 // others are unaffected.  Returns non-zero only for errors of the batch itself (B->err).
 static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status) {
@@ -1329,6 +1449,11 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
                 for (int r = 0; r < R; r++)
                     if (!B->failed[r] && (hints[r] & 1) && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0 && poll_resort(B->eng[r])) fail(r);
             }
+        }
+        {   // the work of an instantaneous Move needs U(x_moved) of every member that was edited: evaluate them together
+            int edited = 0;
+            for (int r = 0; r < R; r++) if (!B->failed[r]) { const BluesEngine* m = B->eng[r]; edited += m->h_step > 0 && m->h_step < m->nsteps && m->h_first_step >= 1 && m->x_edited && m->unpert_valid; }
+            if (edited > 1 && batch_prefetch(B, 1)) return 1;
         }
         for (int r = 0; r < R; r++) if (!B->failed[r] && step_head(B->eng[r])) fail(r);
         if (phase(step_body)) return 1;
@@ -1554,7 +1679,7 @@ int blues_set_velocities(BluesEngine* h, const double* xyz, int32_t n_atoms) {
     HIP_OK(h, hipSetDevice(h->device));
     if (flush_program(h)) return 1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    h->vel_clean = false;
+    h->vel_clean = false; h->ke_cache_valid = false;
     return upload_xyz(h, xyz, h->d_v);
 }
 
@@ -1621,7 +1746,7 @@ int blues_set_velocities_to_temperature(BluesEngine* h, double temperature, uint
     if (flush_program(h)) return 1;
     hipLaunchKernelGGL(k_maxwell, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->n, h->d_mass.p, h->d_v[0].p, h->d_v[1].p, h->d_v[2].p, KB_KJ * temperature, (unsigned long long)seed, (unsigned)h->replica * 4u + 1u);
     h->st_launches++;
-    h->vel_clean = false;
+    h->vel_clean = false; h->ke_cache_valid = false;
     if (emit(h, OP_RATTLE)) return 1;
     if (flush_program(h)) return 1;
     return check_flags(h);
@@ -1632,6 +1757,7 @@ int blues_get_energy(BluesEngine* h, double* potential, double* kinetic) {
     if (potential) { if (total_energy(h, potential)) return 1; }
     if (kinetic) {
         if (flush_program(h)) return 1;
+        if (h->ke_cache_valid) { *kinetic = h->ke_cache; return 0; }
         const int nb = (h->n + 255) / 256;
         hipLaunchKernelGGL(k_kinetic, dim3(nb), dim3(256), 0, h->stream, h->n, h->d_mass.p, h->d_v[0].p, h->d_v[1].p, h->d_v[2].p, h->d_scratch.p);
         h->st_launches++;
@@ -1639,7 +1765,7 @@ int blues_get_energy(BluesEngine* h, double* potential, double* kinetic) {
         std::vector<double> part(nb);
         HIP_OK(h, hipMemcpy(part.data(), h->d_scratch.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
         double ke = 0.0; for (double p : part) ke += p;
-        *kinetic = ke;
+        *kinetic = ke; h->ke_cache = ke; h->ke_cache_valid = true;
     }
     return 0;
 }
@@ -1856,7 +1982,7 @@ int blues_set_velocities_from_snapshot(BluesEngine* h, const BluesSnapshot* sn) 
     c.n = h->n; c.count = 3; c.src_stride = 1; c.dst_stride = 1;
     for (int k = 0; k < 3; k++) { c.src[k] = sn->v[k]; c.dst[k] = h->d_v[k].p; }
     hipLaunchKernelGGL(k_copy_arrays, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, c);
-    h->st_launches++; h->vel_clean = false;
+    h->st_launches++; h->vel_clean = false; h->ke_cache_valid = false;
     HIP_OK(h, hipGetLastError());
     if (sn->owner->stream != h->stream) HIP_OK(h, hipStreamSynchronize(h->stream));   // the owner may recycle the buffer on its own stream
     return 0;
@@ -1933,8 +2059,15 @@ int blues_batch_step(BluesBatch* b, int32_t n_steps, double* work_trace, int32_t
     return 0;
 }
 
+int blues_batch_prefetch_energies(BluesBatch* b, int32_t what) {
+    if (!b || b->eng.empty()) { if (b) b->err = "the batch has been dissolved (one of its engines was destroyed)"; return 2; }
+    if (hipSetDevice(b->eng[0]->device) != hipSuccess) { b->err = "hipSetDevice failed"; return 1; }
+    b->failed.assign(b->R(), 0);
+    return batch_prefetch(b, what);
+}
+
 int blues_batch_get_stats(BluesBatch* b, int64_t stats[4]) {
-    stats[0] = b->st_lockstep_steps; stats[1] = b->st_fallback_steps; stats[2] = b->R(); stats[3] = 0;
+    stats[0] = b->st_lockstep_steps; stats[1] = b->st_fallback_steps; stats[2] = b->R(); stats[3] = b->st_prefetch_pe;
     return 0;
 }
 

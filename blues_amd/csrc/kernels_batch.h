@@ -165,3 +165,37 @@ __global__ void k_gather_hints_b(const RepCore* __restrict__ reps, int R, int* o
     }
     out[r] = w;
 }
+
+__global__ void __launch_bounds__(256) k_bonded_energy_b(const RepCore* __restrict__ reps) {
+    if (!reps[blockIdx.y].active) return;
+    const BondedArgs B = reps[blockIdx.y].bo;
+    bonded_energy_body(B);
+}
+
+// kinetic energy of every member: one block each, fixed summation order -> ke[r]
+__global__ void __launch_bounds__(256) k_kinetic_b(const RepCore* __restrict__ reps, double* ke) {
+    const RepCore& rp = reps[blockIdx.x];
+    if (!rp.active) return;
+    const IntArgs& A = rp.in;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < A.n; i += 256) { const double m = A.mass[i]; if (m != 0.0) s += 0.5 * m * (A.v[0][i] * A.v[0][i] + A.v[1][i] * A.v[1][i] + A.v[2][i] * A.v[2][i]); }
+    __shared__ double red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ke[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// energy partials of every member into one slab [R][stride]: nonbonded partials | bonded partials | alchemical partials |
+// the alchemical tile's list length -- one read-back for the whole batch; the host sums them as it does for a lone engine
+template <typename R>
+__global__ void __launch_bounds__(256) k_gather_energy_parts_b(const RepNb<R>* __restrict__ rnb, const RepCore* __restrict__ reps, int n_nb, int n_b, int n_alch, int stride, double* out) {
+    const int r = blockIdx.x;
+    if (!reps[r].active) return;
+    double* o = out + (size_t)r * stride;
+    const double* enb = rnb[r].nb.epart; const double* eb = reps[r].bo.epart; const double* ep = reps[r].al.e_part;
+    for (int k = threadIdx.x; k < n_nb; k += 256) o[k] = enb[k];
+    for (int k = threadIdx.x; k < n_b; k += 256) o[n_nb + k] = eb[k];
+    for (int k = threadIdx.x; k < n_alch; k += 256) o[n_nb + n_b + k] = ep[k];
+    if (threadIdx.x == 0) o[n_nb + n_b + n_alch] = n_alch > 0 ? (double)*reps[r].al.jcount : 0.0;
+}

@@ -147,7 +147,7 @@ __device__ __forceinline__ void bonded_entries_body(const BondedArgs& B, const i
 __global__ void __launch_bounds__(128) k_bonded_entries(BondedArgs B) { bonded_entries_body(B, blockIdx.x, 128); }
 
 // energy of every term (frozen ones included): per-block partial sums per type
-__global__ void __launch_bounds__(256) k_bonded_energy(BondedArgs B) {
+__device__ __forceinline__ void bonded_energy_body(const BondedArgs& B) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     double e[T_NTYPES] = {0, 0, 0, 0, 0};
     int base = 0;
@@ -161,3 +161,5 @@ __global__ void __launch_bounds__(256) k_bonded_energy(BondedArgs B) {
     __syncthreads();
     if (threadIdx.x < T_NTYPES) B.epart[blockIdx.x * T_NTYPES + threadIdx.x] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
 }
+
+__global__ void __launch_bounds__(256) k_bonded_energy(BondedArgs B) { bonded_energy_body(B); }

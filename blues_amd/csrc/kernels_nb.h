@@ -61,6 +61,7 @@ struct ListArgs {
 #define LIST_WAVES 16
 #define LIST_PREFETCH 4
 #define LIST_THREADS (LIST_WAVES * 64)
+#define LIST_LDS 8192      // j-list entries mirrored in LDS for the exclusion searches (longer lists are searched in HBM)
 
 template <typename R>
 __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force) {
@@ -196,37 +197,52 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
         return;
     }
 
-    // ---- exclusion bitmasks: one 64x64 bit tile per (i-tile, j-batch) that holds an excluded pair
+    // ---- exclusion bitmasks: one 64x64 bit tile per (i-tile, j-batch) that holds an excluded pair.
+    // The binary searches run on a copy of the list in LDS (a dozen dependent steps each: ~100 ns instead of a memory
+    // round trip per step) and the positions found in the first pass are kept for the second.
+    __shared__ int s_jl[LIST_LDS];
+    const bool in_lds = count <= LIST_LDS;
+    if (in_lds) for (int k = tid; k < count; k += LIST_THREADS) s_jl[k] = jl[k];
     const int ia = a.tile_atoms[t * 64 + lane];
     int e0 = 0, e1 = 0;
     if (ia >= 0) { e0 = a.ex_start[ia]; e1 = a.ex_start[ia + 1]; }
-    for (int pass = 0; pass < 2; pass++) {
-        for (int e = e0 + wv; e < e1; e += LIST_WAVES) {
-            int p = a.ex_idx[e];
-            int lo = 0, hi = count;  // binary search p in jl[0..count)
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (jl[mid] < p) lo = mid + 1; else hi = mid; }
-            if (lo < count && jl[lo] == p) {
-                if (pass == 0) s_need[lo >> 6] = 1;
-                else atomicOr(&a.mask_pool[(size_t)s_need[lo >> 6] * 64 + lane], 1ull << (lo & 63));
-            }
+    __syncthreads();
+    auto find = [&](int p) {   // position of sorted index p in the list, or -1
+        int lo = 0, hi = count;
+        if (in_lds) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_jl[mid] < p) lo = mid + 1; else hi = mid; } return (lo < count && s_jl[lo] == p) ? lo : -1; }
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (jl[mid] < p) lo = mid + 1; else hi = mid; }
+        return (lo < count && jl[lo] == p) ? lo : -1;
+    };
+    int found0 = -1, found1 = -1;   // first two entries of this lane/wave (exclusion rows are short)
+    {
+        int u = 0;
+        for (int e = e0 + wv; e < e1; e += LIST_WAVES, u++) {
+            const int pos = find(a.ex_idx[e]);
+            if (u == 0) found0 = pos; else if (u == 1) found1 = pos;
+            if (pos >= 0) s_need[pos >> 6] = 1;
         }
-        __syncthreads();
-        if (pass == 0) {
-            for (int b = tid; b < nb; b += LIST_THREADS) {
-                if (s_need[b]) {
-                    int slot = atomicAdd(&s_nmask, 1);
-                    if (slot >= MASK_QUOTA) { a.flags->list_overflow = 1; slot = 0; }
-                    slot += t * MASK_QUOTA;
-                    s_need[b] = slot; a.batch_slot[t * nbmax + b] = slot;
-                } else s_need[b] = -1;
-            }
-            __syncthreads();
-            for (int b = wv; b < nb; b += LIST_WAVES) {
-                int slot = s_need[b];
-                if (slot >= 0) a.mask_pool[(size_t)slot * 64 + lane] = 0ull;
-            }
-            __threadfence_block();
-            __syncthreads();
+    }
+    __syncthreads();
+    for (int b = tid; b < nb; b += LIST_THREADS) {
+        if (s_need[b]) {
+            int slot = atomicAdd(&s_nmask, 1);
+            if (slot >= MASK_QUOTA) { a.flags->list_overflow = 1; slot = 0; }
+            slot += t * MASK_QUOTA;
+            s_need[b] = slot; a.batch_slot[t * nbmax + b] = slot;
+        } else s_need[b] = -1;
+    }
+    __syncthreads();
+    for (int b = wv; b < nb; b += LIST_WAVES) {
+        const int slot = s_need[b];
+        if (slot >= 0) a.mask_pool[(size_t)slot * 64 + lane] = 0ull;
+    }
+    __threadfence_block();
+    __syncthreads();
+    {
+        int u = 0;
+        for (int e = e0 + wv; e < e1; e += LIST_WAVES, u++) {
+            const int pos = u == 0 ? found0 : (u == 1 ? found1 : find(a.ex_idx[e]));
+            if (pos >= 0) atomicOr(&a.mask_pool[(size_t)s_need[pos >> 6] * 64 + lane], 1ull << (pos & 63));
         }
     }
 }

@@ -199,10 +199,17 @@ class NativeBatch:
                     raise err
         return errors, w
 
+    def prefetch_energies(self, potential=True, kinetic=True, active=None):
+        """Evaluate the members' energies with shared launches into their caches (see include/blues_engine.h)."""
+        R = len(self.engines)
+        mask = (C.c_int32 * R)(*[1 if (active is None or active[r]) else 0 for r in range(R)])
+        if self._lib.blues_batch_set_active(self._h, mask) or self._lib.blues_batch_prefetch_energies(self._h, (1 if potential else 0) | (2 if kinetic else 0)):
+            raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
+
     def stats(self):
         s = (C.c_int64 * 4)()
         self._lib.blues_batch_get_stats(self._h, s)
-        return {"lockstep_steps": s[0], "fallback_steps": s[1], "replicas": s[2]}
+        return {"lockstep_steps": s[0], "fallback_steps": s[1], "replicas": s[2], "batched_energy_evaluations": s[3]}
 
     def time_nonbonded(self, reps=20):
         u = C.c_double()

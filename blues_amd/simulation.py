@@ -313,11 +313,15 @@ class BatchedBLUESSimulation(object):
             except StopIteration:
                 return DONE
 
+        # every chain is about to ask its context for energies (state0 here; the unperturbed energy of the move and state1
+        # after each advance): evaluate them for the whole batch at once, the per-chain calls then find them cached
+        self._ncmc_batch.prefetch_energies()
         got = self.for_each_chain(lambda r, c: resume(r, first=True))
         wanted = {r: n for r, n in enumerate(got) if n is not DONE}
         while wanted:
             errors = self._advance(self._ncmc_batch, sims, wanted)
             idx = sorted(wanted)
+            self._ncmc_batch.prefetch_energies(active=[r in wanted and r not in errors for r in range(len(sims))])
             got = self.for_each_chain(lambda r, c: resume(r, errors.get(r)), idx)
             wanted = {r: n for r, n in zip(idx, got) if n is not DONE}
 
@@ -342,6 +346,7 @@ class BatchedBLUESSimulation(object):
             def sync(r, c):
                 c.currentIter = N
                 c._syncStatesMDtoNCMC()
+            (self._md_batch or self._ncmc_batch).prefetch_energies()
             self.for_each_chain(sync)
             self._stepNCMC(nstepsNC, moveStep)
             self.for_each_chain(lambda r, c: c._acceptRejectMove(write_move))

@@ -219,8 +219,16 @@ int blues_batch_step(BluesBatch *b, int32_t n_steps, double *work_trace, int32_t
  * exception must not be advanced further (simulation.py:1088-1094).
  * NULL = everyone. */
 int blues_batch_set_active(BluesBatch *b, const int32_t *mask);
+/* Evaluates the total potential (what bit 0) and / or kinetic (bit 1) energy of
+ * every active member with shared launches and one read-back, and leaves the
+ * values in the members' energy caches: the blues_get_energy /
+ * blues_set_positions calls that follow for each member (state.getPotentialEnergy
+ * at simulation.py:908, the perturbed / unperturbed energies of
+ * integrators.py:184-205) then cost no launch.  Purely an accelerator: results
+ * are those of the per-member calls. */
+int blues_batch_prefetch_energies(BluesBatch *b, int32_t what);
 /* [0] steps issued in lock step (one launch for all members) [1] steps that
- * fell back to per-member launches [2] members */
+ * fell back to per-member launches [2] members [3] batched energy evaluations */
 int blues_batch_get_stats(BluesBatch *b, int64_t stats[4]);
 /* as blues_time_nonbonded, for one batched launch covering all members */
 int blues_batch_time_nonbonded(BluesBatch *b, int32_t reps, double *usec_per_launch);

@@ -20,12 +20,11 @@ res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     fs = glob.glob(out + "/pmc_%s/*/*counter_collection.csv" % c)
     if not fs: continue
-    rows = [r for r in csv.DictReader(open(fs[0])) if "nonbonded" in r["Kernel_Name"] and r["Counter_Name"] == c]
-    # the standalone launches of blues_batch_time_nonbonded come last: 3 warm-up + 50 timed
-    rows = rows[-50:]
+    # the force (non-energy) launches of the batched nonbonded kernel; the standalone ones of blues_batch_time_nonbonded come last
+    rows = [r for r in csv.DictReader(open(fs[0])) if r["Counter_Name"] == c and "nonbonded" in r["Kernel_Name"] and "_b<" in r["Kernel_Name"] and "false" in r["Kernel_Name"]]
     by = {}
-    for r in rows: by.setdefault(r["Dispatch_Id"], 0.0); by[r["Dispatch_Id"]] += float(r["Counter_Value"])
-    vals = list(by.values())
+    for r in rows: by.setdefault(int(r["Dispatch_Id"]), 0.0); by[int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+    vals = [by[i] for i in sorted(by)[-50:]]
     res[c] = {"kernel": rows[0]["Kernel_Name"][:80] if rows else None, "launches": len(vals), "mean_KB": sum(vals) / max(1, len(vals))}
 print("== pmc", json.dumps(res))
 json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1)
