@@ -512,7 +512,7 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * LIST_WAVES * ((((n + LIST_WAVES - 1) / LIST_WAVES) + 63) & ~63)); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
         h->d_mask_pool.alloc((size_t)h->pool_cap * 64);
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
-        h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_iw != 64 ? 64 / h->k1_iw : 1) + 2 * ((n + 255) / 256));
+        h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_iw != 64 ? 64 / h->k1_iw : 1) + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
         { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi);
           std::vector<FinRec> fr(h->n_islots + 64);
           auto fill = [&](FinRec& r, int atom) {
@@ -916,7 +916,7 @@ static EnergyShape energy_shape(const BluesEngine* h) {
     g.nw = h->n_itiles * h->npart * subs;
     g.off_frozen = (size_t)std::max(1, h->n_itiles) * h->npart * 2 * subs;
     int total_terms = 0; for (int ty = 0; ty < T_NTYPES; ty++) total_terms += h->n_terms[ty];
-    g.nbb = (total_terms + 255) / 256; g.nfb = (h->n + 255) / 256;
+    g.nbb = (total_terms + 255) / 256; g.nfb = (h->n + FROZEN_TILE - 1) / FROZEN_TILE;
     return g;
 }
 
