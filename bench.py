@@ -67,7 +67,7 @@ def md_states(chains, x0, v0):
     return out
 
 
-def one_switch(driver, chains, states, nsteps, it, clock):
+def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
     """One BLUES iteration's NCMC leg for every chain: MD->NCMC hand-over -> switch -> Metropolis -> gather -> reset."""
     from blues_amd.replicas import gather_decision_block
     each = driver.for_each_chain if driver is not None else (lambda fn: [fn(r, c) for r, c in enumerate(chains)])
@@ -90,7 +90,9 @@ def one_switch(driver, chains, states, nsteps, it, clock):
         driver._stepNCMC(nsteps, nsteps // 2)
     t2 = time.perf_counter()
     each(lambda r, c: c._acceptRejectMove())
-    recs = gather_decision_block([[c.last["accept"], it, c.last["log_accept"], c.last["protocol_work"], c.last["correction"]] for c in chains])
+    recs = np.array([[c.last["accept"], it, c.last["log_accept"], c.last["protocol_work"], c.last["correction"]] for c in chains], dtype=np.float64)
+    if gather:
+        recs = gather_decision_block(recs)
     each(lambda r, c: c._resetSimulations(300.0))
     t3 = time.perf_counter()
     clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2
@@ -130,7 +132,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--replicas", type=int, default=256, help="independent chains per GPU, advanced as one replica batch")
-    ap.add_argument("--workers", type=int, default=1, help="host threads for the per-chain plugin-boundary work")
+    ap.add_argument("--groups", type=int, default=1, help="the rank's chains form this many replica batches, each driven from its own host thread on its "
+                    "own stream: one group's host phases and latency-bound kernels overlap the others' compute-bound ones (1 = a single batch)")
+    ap.add_argument("--workers", type=int, default=1, help="host threads for the per-chain plugin-boundary work inside a group")
     ap.add_argument("--nsteps-nc", type=int, default=NSTEPS_NC)
     ap.add_argument("--workload", default="rotmove", choices=["rotmove", "water"])
     ap.add_argument("--cpu-steps", type=int, default=12)
@@ -179,23 +183,52 @@ def main():
                   "roofline": {"bound": "hbm", "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
                                "traffic": pmc_traffic(args.workload, 1), "usec_per_launch": k1_single}}
 
-    driver = simulation.BatchedBLUESSimulation(chains, workers=args.workers)
-    states = md_states(chains, x0, v0)
+    G = max(1, min(args.groups, R))
+    bounds = [(g * R) // G for g in range(G + 1)]
+    groups = [chains[bounds[g]:bounds[g + 1]] for g in range(G)]
+    drivers = [simulation.BatchedBLUESSimulation(grp, workers=args.workers) for grp in groups]
+    if G > 1:   # chains driven from different threads draw from their own streams (reproducible whatever the interleaving)
+        for c in chains:
+            c._rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1))
+    gstates = [md_states(grp, x0, v0) for grp in groups]
     t_setup = time.perf_counter() - t_setup
-    clock = {"sync": 0.0, "switch": 0.0, "decide": 0.0}
+    clocks = [{"sync": 0.0, "switch": 0.0, "decide": 0.0} for _ in range(G)]
+
+    def switch_group(g, it):
+        return one_switch(drivers[g], groups[g], gstates[g], nsteps, it, clocks[g], gather=False)
+
+    from blues_amd.replicas import gather_decision_block
+
+    def switch_all(it):
+        return gather_decision_block(np.concatenate([switch_group(g, it) for g in range(G)]))
+
     for w in range(args.warmup):
-        one_switch(driver, chains, states, nsteps, w, clock)
+        switch_all(w)      # on the main thread: every kernel variant has been launched once before threads start
     engs = [c._ncmc_sim.context._engine for c in chains]
-    st0 = engs[0].stats(); b0 = driver._ncmc_batch.stats()
-    clock = {"sync": 0.0, "switch": 0.0, "decide": 0.0}
+    st0 = engs[0].stats(); b0 = [d._ncmc_batch.stats() for d in drivers]
+    for ck in clocks:
+        ck.update({"sync": 0.0, "switch": 0.0, "decide": 0.0})
     barrier()
     t0 = time.perf_counter()
     recs = []
-    for k in range(args.steps):
-        recs.append(one_switch(driver, chains, states, nsteps, k, clock))
+    if G == 1:
+        for k in range(args.steps):
+            recs.append(switch_all(k))
+    else:
+        # the groups run one iteration side by side on their own threads and streams: while they step, one group's
+        # latency-bound kernels (list rebuilds, integrator) overlap another's compute-bound ones.  They are joined every
+        # iteration (letting them drift apart was measured slower: a group's small per-chain operations then queue behind
+        # the other groups' long launches), then the rank performs its one all-gather.
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=G) as pool:
+            for k in range(args.steps):
+                parts = list(pool.map(lambda g: switch_group(g, k), range(G)))
+                recs.append(gather_decision_block(np.concatenate(parts)))
     barrier()
     elapsed = time.perf_counter() - t0
-    st1 = engs[0].stats(); b1 = driver._ncmc_batch.stats()
+    st1 = engs[0].stats(); b1 = [d._ncmc_batch.stats() for d in drivers]
+    clock = {k: max(ck[k] for ck in clocks) for k in clocks[0]}
+    b0 = {k: sum(b[k] for b in b0) / G for k in b0[0]}; b1 = {k: sum(b[k] for b in b1) / G for k in b1[0]}
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,12 +236,13 @@ def main():
 
     # the kernel north_star prices against the HBM roofline: the direct-space nonbonded kernel, timed alone with HIP
     # events on the batch's own stream; one launch processes all R chains of this rank
-    k1_us = driver._ncmc_batch.time_nonbonded(50)
+    k1_us = drivers[0]._ncmc_batch.time_nonbonded(50)
+    R_launch = len(groups[0])
     if rank == 0:
         n_atoms = system.n_atoms
         ms_per_step = 1e3 * elapsed / args.steps
         ns_day = world * R * args.steps * nsteps * DT_PS * 1e-3 / (elapsed / 86400.0)
-        algo = ALGO_BYTES_PER_ATOM * n_atoms * R
+        algo = ALGO_BYTES_PER_ATOM * n_atoms * R_launch
         achieved = algo / (k1_us * 1e-6) / 1e9
         last = np.asarray(recs[-1])
         out = {
@@ -216,11 +250,12 @@ def main():
             "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 pair math / f64 accumulation, f64 alchemical+integrator", "data": "synthetic",
-            "config": {"workload": "S23k %s: %d atoms, %d mobile, 15 alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in one replica batch"
-                       % (args.workload, n_atoms, int((system.mass > 0).sum()), nsteps, R),
-                       "replicas_per_gpu": R, "host_workers": args.workers, "parallelism": "replica-batch x%d per gpu, %d gpu(s)" % (R, world)},
+            "config": {"workload": "S23k %s: %d atoms, %d mobile, 15 alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in %d replica batch(es)"
+                       % (args.workload, n_atoms, int((system.mass > 0).sum()), nsteps, R, G),
+                       "replicas_per_gpu": R, "batches_per_gpu": G, "host_workers": args.workers,
+                       "parallelism": "%d replica batch(es) x %d chains per gpu, %d gpu(s)" % (G, R_launch, world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, R), "kernel": "k_nonbonded*_b (direct-space LJ + erfc Coulomb), one launch = %d chains" % R,
+                         "traffic": pmc_traffic(args.workload, R_launch), "kernel": "k_nonbonded*_b (direct-space LJ + erfc Coulomb), one launch = %d chains (timed alone)" % R_launch,
                          "usec_per_launch": k1_us, "algorithmic_bytes_per_launch": algo},
             "single_replica": single,
             "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup,
