@@ -177,6 +177,12 @@ class Simulation(object):
             due.append((r, nxt))
             if 0 < nxt[0] < chunk:
                 chunk = nxt[0]
+            # a reporter that fires at given frame indices (reference blues/reporters.py:791-796) only says "now" when the
+            # step counter sits ON an index; the reference steps one at a time and asks before every step, so the fused
+            # stepping here must stop at the next index to ask again
+            ahead = [i - self.currentStep for i in (getattr(r, "frame_indices", None) or []) if i > self.currentStep]
+            if ahead and min(ahead) < chunk:
+                chunk = min(ahead)
         return chunk, due
 
     def _commit_chunk(self, chunk, due):

@@ -25,7 +25,7 @@
 __host__ __device__ inline int k2_env_blocks(int count, int PA, int jiter) { const int jpb = (256 / PA) * jiter; return (count + jpb - 1) / jpb; }
 
 // packed per-entry records so the pair thread needs two dependent loads (record -> position) instead of four
-struct AlchJRec { int jo, jsrt; double sig, eps, q; };   // one per entry of the alchemical tile's j-list (written at list build)
+struct AlchJRec { int jo, jsrt; double sig, eps, q; };   // one per entry of the alchemical tile's j-list (written at list build); jsrt bit 30 = j is mobile
 struct AlchARec { int ao, asrt, has_env_excl, pad; double sig, eps, q; };  // one per alchemical atom (static)
 
 struct AlchArgs {
@@ -105,11 +105,12 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
             const bool valid = js < count && a < A.n_alch;
             int jsrt = -1;
             bool hit = false;  // this lane holds a pair term
+            bool j_mobile = false;
 #pragma unroll
             for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = 0.0; }
             if (valid) {
                 const AlchJRec J = A.jrec[js];
-                jsrt = J.jsrt;
+                jsrt = J.jsrt & 0x3fffffff; j_mobile = (J.jsrt >> 30) & 1;
                 const int jo = J.jo;
                 double d[3];
                 for (int k = 0; k < 3; k++) d[k] = min_image_d(xa[k] - A.x[k][jo], A.box.L[k], A.box.invL[k]);
@@ -165,14 +166,16 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
             // alchemical atom at any one time: such a group publishes zeros and skips its reductions.
             const bool group_hit = __ballot(hit) != 0ull;
             wave_hit |= group_hit;
-            // force on environment atom j: minus the sum over the PA alchemical lanes
+            // force on environment atom j: minus the sum over the PA alchemical lanes -- wanted only for MOBILE j (frozen
+            // atoms are never kicked; most of the list is frozen environment, so most groups skip this reduction too)
+            const bool group_fj = __ballot(hit && j_mobile) != 0ull;
 #pragma unroll
             for (int s = 0; s < 3; s++) {
                 if (!((A.slot_mask >> s) & 1)) continue;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const double fj = group_hit ? seg_sum(f[s][k], PA) : 0.0;
-                    if (a == 0 && js < count) A.fJ[(size_t)(s * 3 + k) * A.n + jsrt] = -fj;
+                    const double fj = group_fj ? seg_sum(f[s][k], PA) : 0.0;
+                    if (a == 0 && j_mobile) A.fJ[(size_t)(s * 3 + k) * A.n + jsrt] = -fj;
                     fa[s][k] += f[s][k];
                 }
             }

@@ -191,7 +191,8 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
         JR* jr = (JR*)a.alch_jrec;
         if (jr) for (int k = tid; k < count; k += LIST_THREADS) {
             const int js = jl[k], jo = img[js].orig;
-            JR r; r.jo = jo; r.jsrt = js; r.sig = a.p_sigma[jo]; r.eps = a.p_eps[jo]; r.q = a.p_charge[jo];
+            JR r; r.jo = jo; r.jsrt = js | ((img[js].flags & FLAG_MOBILE) ? 0x40000000 : 0);   // bit 30: j is mobile (its force is wanted)
+            r.sig = a.p_sigma[jo]; r.eps = a.p_eps[jo]; r.q = a.p_charge[jo];
             jr[k] = r;
         }
         return;
