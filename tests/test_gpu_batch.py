@@ -434,3 +434,36 @@ def test_batched_energy_prefetch_equals_per_member_evaluation(Engine, tol_box, s
         assert bat[r].get_global("protocol_work") == ref[r].get_global("protocol_work")
         assert np.array_equal(bat[r].get_positions(), ref[r].get_positions())
     B.close()
+
+
+def test_full_size_batch_of_eight(Engine, oracle_mod, monkeypatch):
+    """The benchmark system (S23k, 276 mobile atoms) in a batch of 8: the member count is a multiple of 8, so the nonbonded
+    and alchemical launches use the XCD-aware block -> replica map; large-batch decomposition (separate force kernels,
+    four j-groups per alchemical block, short skin).  Every member equals its solo run bit for bit (same decomposition
+    pinned for the lone engines), and one member is checked against the oracle."""
+    from blues_amd.engine import NativeBatch
+    s, v = systems.s23k(mobile_atoms=275, frozen=True)
+    for k, val in (("BLUES_FUSE", "0"), ("BLUES_K2_JITER", "4"), ("BLUES_SKIN", "0.12")):
+        monkeypatch.setenv(k, val)
+    R, n = 8, 10
+    rng = np.random.RandomState(5)
+    vels = [v * (1.0 + 0.03 * r) for r in range(R)]
+    solo = _make(Engine, s, vels, n, 0)
+    ws = [g.run_switch(n, trace=True) for g in solo]
+    bat = _make(Engine, s, vels, n, 0)
+    B = NativeBatch(bat)
+    _, wb = B.step(n, trace=True)
+    assert B.stats()["fallback_steps"] == 0
+    for r in range(R):
+        assert np.array_equal(wb[r], ws[r]), (r, np.abs(wb[r] - ws[r]).max())
+        assert np.array_equal(solo[r].get_positions(), bat[r].get_positions())
+    assert len({w[-1] for w in ws}) == R                  # eight different trajectories
+    r = 5
+    o = oracle_mod.Oracle(s, _integ(n, seed=100 + r).to_data(precision=0, replica=r))
+    o.set_velocities(vels[r])
+    wo = []
+    for _ in range(n):
+        o.step(1); wo.append(o.get_global("protocol_work"))
+    assert np.allclose(wb[r], wo, rtol=2e-5, atol=2e-5)     # mixed precision: north_star's 1e-5 relative on the work
+    assert np.abs(bat[r].get_positions() - o.get_positions()).max() < 1e-6
+    B.close()
