@@ -38,17 +38,35 @@ def build_chains(rank, local_rank, nsteps, workload, R):
     from blues_amd import integrators, moves, simulation, systems
     from blues_amd.context import Simulation
     from blues_amd.replicas import replica_seed
-    if workload == "water":  # configs[3]: nothing frozen
-        system, vel = systems.s23k(frozen=False)
+    import copy
+    if workload == "water":
+        # configs[3]: nothing frozen, "backbone" restraints, the alchemical species is one 3-atom water (the first one,
+        # reference blues/moves.py:889) and the move is WaterTranslationMove within 2.0 nm of a reference group (here the
+        # first toluene stands in for the protein selection)
+        base, vel = systems.s23k(frozen=False, restrained=40)
+        system = copy.copy(base)
+        system.alchemical_atoms = np.array([15, 16, 17], np.int32)
+        res = np.asarray(system.residue_of_atom)
+        o_idx = [i for i in range(15, system.n_atoms - 2) if res[i] == res[i + 2] and (i == 0 or res[i - 1] != res[i]) and system.mass[i] > 10.0]
+        waters = [[i, i + 1, i + 2] for i in o_idx]
+        make_move = lambda gid: moves.WaterTranslationMove(waters, np.arange(15), system.mass[:15], radius=2.0)
+    elif workload == "sidechain":
+        # configs[4]: a torsion move on a partially alchemical solute (the methyl group of the first toluene: alchemical-
+        # environment exclusions and 1-4 exceptions active), long protocol
+        system, vel = systems.s23k(mobile_atoms=275, frozen=True)
+        system = copy.copy(system)
+        system.alchemical_atoms = np.array([0, 7, 8, 9], np.int32)
+        make_move = lambda gid: moves.TorsionRotationMove((1, 0), [7, 8, 9], random_state=1000 + gid)
     else:
         system, vel = systems.s23k(mobile_atoms=275, frozen=True)
-    lig = np.asarray(system.alchemical_atoms)
+        lig = np.asarray(system.alchemical_atoms)
+        make_move = lambda gid: moves.RandomLigandRotationMove(lig, system.mass[lig], random_state=1000 + gid)
     chains = []
     for c in range(R):
         gid = rank * R + c   # global chain index
         integ = integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=DT_PS, temperature=300.0, seed=replica_seed(1234, gid))
         sim = Simulation(None, system, integ, device=local_rank, precision="mixed", replica=gid)
-        mover = moves.MoveEngine(moves.RandomLigandRotationMove(lig, system.mass[lig], random_state=1000 + gid))
+        mover = moves.MoveEngine(make_move(gid))
         chains.append(simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": 1}, mover))
     return system, vel, chains
 
@@ -136,7 +154,8 @@ def main():
                     "own stream: one group's host phases and latency-bound kernels overlap the others' compute-bound ones (1 = a single batch)")
     ap.add_argument("--workers", type=int, default=1, help="host threads for the per-chain plugin-boundary work inside a group")
     ap.add_argument("--nsteps-nc", type=int, default=NSTEPS_NC)
-    ap.add_argument("--workload", default="rotmove", choices=["rotmove", "water"])
+    ap.add_argument("--workload", default="rotmove", choices=["rotmove", "water", "sidechain"],
+                    help="rotmove = the benchmark (configs[1]); water / sidechain = full-size runs of configs[3] / configs[4]")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-chain measurement")
@@ -250,8 +269,8 @@ def main():
             "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 pair math / f64 accumulation, f64 alchemical+integrator", "data": "synthetic",
-            "config": {"workload": "S23k %s: %d atoms, %d mobile, 15 alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in %d replica batch(es)"
-                       % (args.workload, n_atoms, int((system.mass > 0).sum()), nsteps, R, G),
+            "config": {"workload": "S23k %s: %d atoms, %d mobile, %d alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in %d replica batch(es)"
+                       % (args.workload, n_atoms, int((system.mass > 0).sum()), len(system.alchemical_atoms), nsteps, R, G),
                        "replicas_per_gpu": R, "batches_per_gpu": G, "host_workers": args.workers,
                        "parallelism": "%d replica batch(es) x %d chains per gpu, %d gpu(s)" % (G, R_launch, world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
