@@ -467,3 +467,40 @@ def test_full_size_batch_of_eight(Engine, oracle_mod, monkeypatch):
     assert np.allclose(wb[r], wo, rtol=2e-5, atol=2e-5)     # mixed precision: north_star's 1e-5 relative on the work
     assert np.abs(bat[r].get_positions() - o.get_positions()).max() < 1e-6
     B.close()
+
+
+def test_batched_full_iterations_with_md_leg(Engine, tol_box, same_decomposition):
+    """BLUESSimulation.run for several chains at once: NCMC leg (replica batch) + Metropolis + MD leg (a second replica batch
+    over the chains' MD engines: the OpenMM LangevinIntegrator step, kernels k_step_md_b) -- against the same chains run one
+    after the other with the same random streams."""
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    md_sys = copy.copy(s); md_sys.alchemical_atoms = np.zeros(0, np.int32)
+    lig = np.array([0, 7, 8, 9])                 # methyl group: torsion moves get accepted now and then even with short protocols
+    sub = copy.copy(s); sub.alchemical_atoms = lig.astype(np.int32)
+    R, nsteps, nmd, nIter = 3, 16, 6, 2
+
+    def chain(r):
+        ncmc = Simulation(None, sub, _integ(nsteps, seed=300 + r, dt=0.002), precision="double", replica=r)
+        md = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=400 + r), precision="double", replica=r)
+        for sim in (ncmc, md):
+            sim.context.setVelocities(unit.Quantity(v * (1.0 + 0.02 * r), "nanometer/picosecond"))
+        mv = moves.MoveEngine(moves.TorsionRotationMove((1, 0), [7, 8, 9], random_state=50 + r))
+        return simulation.BLUESSimulation(simulation.SimulationSet(ncmc, md=md), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": nIter, "nstepsMD": nmd},
+                                          mv, rng=np.random.RandomState(900 + r))
+
+    sep = [chain(r) for r in range(R)]
+    for c in sep:
+        c.run()
+    bat = [chain(r) for r in range(R)]
+    B = simulation.BatchedBLUESSimulation(bat)
+    assert B._md_batch is not None
+    B.run()
+    for r in range(R):
+        assert (bat[r].accept, bat[r].reject) == (sep[r].accept, sep[r].reject) and bat[r].accept + bat[r].reject == nIter
+        assert bat[r].last["protocol_work"] == pytest.approx(sep[r].last["protocol_work"], rel=1e-9, abs=1e-9)
+        xs = sep[r]._md_sim.context._engine.get_positions(); xb = bat[r]._md_sim.context._engine.get_positions()
+        assert np.abs(xs - xb).max() < 1e-9
+        assert bat[r]._md_sim.currentStep == nIter * nmd
+    assert B._md_batch.stats()["lockstep_steps"] >= nIter * nmd - 2
+    B.close()
