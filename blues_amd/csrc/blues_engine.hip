@@ -701,8 +701,12 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
     const bool fast = h->precision == 0;
     if (batch_lead(h)) {
         const int nb = h->k2_nblocks_env + 1, nrep = h->batch->R();
-        if (fast) hipLaunchKernelGGL(k_alchemical_b<true>, dim3(nb * nrep), dim3(256), 0, h->cur, h->batch->d_core.p, make_alch_dyn(A), nb, nrep);
-        else hipLaunchKernelGGL(k_alchemical_b<false>, dim3(nb * nrep), dim3(256), 0, h->cur, h->batch->d_core.p, make_alch_dyn(A), nb, nrep);
+        const AlchDyn D = make_alch_dyn(A);
+        const dim3 g(nb * nrep), b(256);
+#define ALCH_B(F, M) hipLaunchKernelGGL((k_alchemical_b<F, M>), g, b, 0, h->cur, h->batch->d_core.p, D, nb, nrep)
+        if (fast) { if (slot_mask == 5) ALCH_B(true, 5); else if (slot_mask == 2) ALCH_B(true, 2); else ALCH_B(true, -1); }
+        else { if (slot_mask == 5) ALCH_B(false, 5); else if (slot_mask == 2) ALCH_B(false, 2); else ALCH_B(false, -1); }
+#undef ALCH_B
     } else if (!batch_dry(h)) {
         if (fast) hipLaunchKernelGGL(k_alchemical<true>, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->cur, A);
         else hipLaunchKernelGGL(k_alchemical<false>, dim3(h->k2_nblocks_env + 1), dim3(256), 0, h->cur, A);

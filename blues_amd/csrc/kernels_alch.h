@@ -63,8 +63,11 @@ __device__ inline bool excluded_sorted(const int* ex_start, const int* ex_idx, i
 }
 
 // FAST: the mixed-precision mode's math (device_common.h, fast fp64 forms); false = libm forms, the reference-grade path
-template <bool FAST>
+// MASK: the force slot mask known at compile time (5 and 2 are what "H V R O R V H" asks for, see force_pass), so that the
+// force arithmetic, accumulators and reductions of the other slots are not even compiled in; -1 = use A.slot_mask
+template <bool FAST, int MASK = -1>
 __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id) {
+    auto slot_on = [&](int s) -> bool { return MASK >= 0 ? ((MASK >> s) & 1) != 0 : ((A.slot_mask >> s) & 1) != 0; };
     if (A.ctrl) {
         const int L = A.ctrl->L0 + 2 * A.ctrl->kpass;
 #pragma unroll
@@ -128,6 +131,7 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
 #pragma unroll
                         for (int s = 0; s < 3; s++) {
                             e[1 + s] += es[s];
+                            if (MASK >= 0 && !((MASK >> s) & 1)) continue;
                             const double ft = fs3[s] + A.le[s] * fc;
                             f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
                         }
@@ -171,7 +175,7 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
             const bool group_fj = __ballot(hit && j_mobile) != 0ull;
 #pragma unroll
             for (int s = 0; s < 3; s++) {
-                if (!((A.slot_mask >> s) & 1)) continue;
+                if (!slot_on(s)) continue;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const double fj = group_fj ? seg_sum(f[s][k], PA) : 0.0;
@@ -283,7 +287,7 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 double v = 0.0;
-                if ((A.slot_mask >> s) & 1) {   // a slot whose force nobody applies is not reduced (its energy still is)
+                if (slot_on(s)) {   // a slot whose force nobody applies is not reduced (its energy still is)
                     v = f[s][k];
                     for (int off = PA; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
                 }

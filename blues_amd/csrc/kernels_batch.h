@@ -83,12 +83,12 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub_b(const RepNb<float>* __r
     nonbonded_sub_body<ENERGY, IW>(a, c, rp.img, bx);
 }
 
-template <bool FAST>
-__global__ void __launch_bounds__(256) k_alchemical_b(const RepCore* __restrict__ reps, AlchDyn d, int nb, int nrep) {
+template <bool FAST, int MASK>
+__global__ void __launch_bounds__(256, 3) k_alchemical_b(const RepCore* __restrict__ reps, AlchDyn d, int nb, int nrep) {
     int rep, bx; batch_decode(nb, nrep, rep, bx);
     if (!reps[rep].active) return;
     AlchArgs A = reps[rep].al; apply_dyn(A, d);
-    alchemical_body<FAST>(A, bx);
+    alchemical_body<FAST, MASK>(A, bx);
 }
 
 __global__ void __launch_bounds__(128) k_bonded_entries_b(const RepCore* __restrict__ reps, BondedDyn d) {
