@@ -1899,6 +1899,27 @@ int blues_time_nonbonded(BluesEngine* h, int32_t reps, double* usec) {
     return check_flags(h);
 }
 
+// forced neighbour-list rebuild of one engine, timed alone with HIP events (diagnostic: the latency every batched round
+// pays whenever some member rebuilds)
+int blues_time_list_build(BluesEngine* h, int32_t reps, double* usec) {
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    if (ensure_sorted(h)) return 1;
+    int rc = 0;
+    for (int w = 0; w < 2 && !rc; w++) rc = h->precision == 0 ? launch_lists<float>(h, 1) : launch_lists<double>(h, 1);
+    if (rc) return 1;
+    HIP_OK(h, hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < reps && !rc; r++) rc = h->precision == 0 ? launch_lists<float>(h, 1) : launch_lists<double>(h, 1);
+    if (rc) return 1;
+    HIP_OK(h, hipEventRecord(h->ev1, h->stream));
+    HIP_OK(h, hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_OK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *usec = 1000.0 * ms / std::max(1, reps);
+    h->pass_valid = false; h->lists_forced = false;
+    return check_flags(h);
+}
+
 // ---- State snapshots (include/blues_engine.h, "Device-resident State")
 int blues_snapshot_capture(BluesEngine* h, int32_t what, BluesSnapshot** out) {
     if (!out || !(what & 3)) E_FAIL(h, "snapshot: nothing requested");

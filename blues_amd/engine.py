@@ -120,6 +120,9 @@ class NativeEngine:
     def time_nonbonded(self, reps=20):
         u = C.c_double(); self._check(self._lib.blues_time_nonbonded(self._h, int(reps), C.byref(u))); return u.value
 
+    def time_list_build(self, reps=20):
+        u = C.c_double(); self._check(self._lib.blues_time_list_build(self._h, int(reps), C.byref(u))); return u.value
+
 
 class DeviceSnapshot:
     """openmm.State's positions / velocities kept on the GPU (include/blues_engine.h "Device-resident State")."""

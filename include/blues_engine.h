@@ -169,6 +169,8 @@ int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
 /* time `reps` launches of the dominant nonbonded kernel alone with HIP events
  * on the engine's own stream; returns mean microseconds per launch. */
 int blues_time_nonbonded(BluesEngine *h, int32_t reps, double *usec_per_launch);
+/* the same for a forced neighbour-list rebuild */
+int blues_time_list_build(BluesEngine *h, int32_t reps, double *usec_per_launch);
 
 /* ---- Device-resident State -------------------------------------------------
  * BLUES passes whole openmm.State objects around: getStateFromContext takes
