@@ -99,7 +99,7 @@ def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
     t0 = time.perf_counter()
     each(hand_over)
     if driver is not None:
-        driver._ncmc_batch.prefetch_energies()
+        driver._ncmc_batch.prefetch_energies(at_lambda_one=True)
     each(sync)
     t1 = time.perf_counter()
     if driver is None:
@@ -280,6 +280,7 @@ def main():
             "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup,
                        "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,
                        "list_rebuilds_per_switch": (st1["list_generation"] - st0["list_generation"]) / args.steps,
+                       "own_energy_evaluations_per_switch": (st1["own_energy_evaluations"] - st0["own_energy_evaluations"]) / args.steps,
                        "lockstep_steps_per_switch": (b1["lockstep_steps"] - b0["lockstep_steps"]) / args.steps,
                        "fallback_steps_per_switch": (b1["fallback_steps"] - b0["fallback_steps"]) / args.steps,
                        "i_tiles": st1["i_tiles"], "clusters": st1["clusters"], "jcap": st1["jcap"], "max_jcount": st1["max_jcount"]},

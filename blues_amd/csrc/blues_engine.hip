@@ -78,6 +78,22 @@ static uint32_t hilbert3(uint32_t x, uint32_t y, uint32_t z, int bits) {
 struct BluesBatch;
 struct BluesEngine;
 
+// Total potential energy of the current positions for up to two settings of (lambda_sterics, lambda_electrostatics): BLUES
+// asks for the energy at the protocol's current parameters AND at lambda = 1 for the same coordinates
+// (simulation.py:1100-1119; the default lambda_electrostatics function ends at 0.9999999999999998, not 1.0).
+struct ECache {
+    double e[2] = {0, 0}, ls[2] = {0, 0}, le[2] = {0, 0}; bool ok[2] = {false, false}; int last = 0;
+    void clear() { ok[0] = ok[1] = false; }
+    bool any() const { return ok[0] || ok[1]; }
+    bool find(double s_, double e_, double* out) { for (int k = 0; k < 2; k++) if (ok[k] && ls[k] == s_ && le[k] == e_) { if (out) *out = e[k]; last = k; return true; } return false; }
+    void put(double s_, double e_, double val) {
+        int k = -1;
+        for (int q = 0; q < 2; q++) if (ok[q] && ls[q] == s_ && le[q] == e_) k = q;
+        if (k < 0) k = !ok[0] ? 0 : (!ok[1] ? 1 : 1 - last);
+        e[k] = val; ls[k] = s_; le[k] = e_; ok[k] = true; last = k;
+    }
+};
+
 // openmm.State as BLUES uses it (simulation.py:883-911, 938-963): a copy of positions and velocities taken at one
 // moment, handed back later to setPositions / setVelocities.  Kept in HBM; the host sees it only if it asks.
 struct BluesSnapshot {
@@ -85,7 +101,7 @@ struct BluesSnapshot {
     int n = 0; bool has_x = false, has_v = false;
     double* x[3] = {nullptr, nullptr, nullptr}; double* v[3] = {nullptr, nullptr, nullptr};
     double* block = nullptr;   // one allocation: x[0..2], v[0..2]
-    bool e_valid = false; double e = 0, e_ls = 0, e_le = 0;   // potential energy of the captured positions, if it was known
+    ECache ecache;   // potential energies that were known for the captured positions
 };
 
 struct BluesEngine {
@@ -129,7 +145,7 @@ struct BluesEngine {
     std::vector<double> h_stage;   // staging for host transfers
     std::vector<double> hx_sort;   // positions at the last sort
     double e_frozen[2] = {0, 0}; bool e_frozen_valid = false;
-    double e_cache = 0, e_cache_ls = 0, e_cache_le = 0; bool e_cache_valid = false;  // total potential energy at the current positions
+    ECache ecache;  // total potential energy at the current positions
     double ke_cache = 0; bool ke_cache_valid = false;
     // ---- derived topology
     std::vector<int> mobile;       // caller indices with mass > 0
@@ -166,7 +182,7 @@ struct BluesEngine {
     // pending integrate program
     Program prog; unsigned prog_draw_base = 0; int prog_trace = -1; bool tracing = false;
     // stats
-    int64_t st_passes = 0, st_launches = 0, st_resorts = 0;
+    int64_t st_passes = 0, st_launches = 0, st_resorts = 0, st_energy_evals = 0;
     std::vector<int> h_sorted_of_orig, h_orig_of_sorted;
 
     ~BluesEngine() {
@@ -562,7 +578,7 @@ static IntArgs make_int_args(BluesEngine* h) {
 
 static int flush_program(BluesEngine* h) {
     if (h->prog.n == 0) return 0;
-    h->e_cache_valid = false; h->ke_cache_valid = false;   // the launch may move atoms
+    h->ecache.clear(); h->ke_cache_valid = false;   // the launch may move atoms
     IntArgs A = make_int_args(h);
     // the steady-state program of "H V R O R V H" has a straight-line specialisation (same arithmetic)
     static const unsigned char P_CM[9] = {OP_V0, OP_H01, OP_END, OP_CM_PART, OP_H12, OP_V2, OP_R, OP_O, OP_R};
@@ -965,6 +981,7 @@ static void energy_sum(BluesEngine* h, const double* enb, const double* eb, int 
 
 // full potential energy breakdown at the current state and alchemical parameters (on demand; synchronises)
 static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
+    h->st_energy_evals++;
     if (energy_launch(h)) return 1;
     const EnergyShape g = energy_shape(h);
     if (!h->e_frozen_valid) {
@@ -993,11 +1010,11 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
 // the alchemical-correction energies of one switch are evaluated at only two distinct states, simulation.py:1056-1119)
 static int total_energy(BluesEngine* h, double* E) {
     if (flush_program(h)) return 1;
-    if (h->e_cache_valid && h->e_cache_ls == h->cur_ls && h->e_cache_le == h->cur_le) { *E = h->e_cache; return 0; }
+    if (h->ecache.find(h->cur_ls, h->cur_le, E)) return 0;
     double T[BLUES_N_ENERGY_TERMS];
     if (energy_terms(h, T)) return 1;
     *E = 0.0; for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) *E += T[t];
-    h->e_cache = *E; h->e_cache_ls = h->cur_ls; h->e_cache_le = h->cur_le; h->e_cache_valid = true;
+    h->ecache.put(h->cur_ls, h->cur_le, *E);
     return 0;
 }
 
@@ -1315,7 +1332,7 @@ static int batch_prefetch(BluesBatch* B, int what) {
     for (int r = 0; r < R; r++) if (B->active[r] && !B->failed[r] && !live[r]) return 0;   // a member without a layout yet: everybody evaluates on demand
     const bool was_entered = B->entered;
     bool ok = true;
-    if (what & 1) {
+    auto pe_pass = [&]() -> int {   // potential energies at the members' CURRENT alchemical parameters
         int n_need = 0, n_live = 0;
         for (int r = 0; r < R; r++) if (live[r] && !B->eng[r]->e_frozen_valid) {   // one-off constant of a member: its own evaluation
             double E;
@@ -1324,7 +1341,7 @@ static int batch_prefetch(BluesBatch* B, int what) {
         for (int r = 0; r < R; r++) if (live[r]) {
             BluesEngine* m = B->eng[r];
             n_live++;
-            need[r] = !(m->e_cache_valid && m->e_cache_ls == m->cur_ls && m->e_cache_le == m->cur_le);
+            need[r] = !m->ecache.find(m->cur_ls, m->cur_le, nullptr);
             n_need += need[r];
         }
         bool uniform = n_need == n_live && n_need > 1;   // (a partial set would have to mask the others out of the launches)
@@ -1361,10 +1378,19 @@ static int batch_prefetch(BluesBatch* B, int what) {
                 double T[BLUES_N_ENERGY_TERMS], E = 0.0;
                 energy_sum(m, o, o + n_nb, (int)o[n_nb + n_b + n_al], o + n_nb + n_b, T);
                 for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) E += T[t];
-                m->e_cache = E; m->e_cache_ls = m->cur_ls; m->e_cache_le = m->cur_le; m->e_cache_valid = true;
+                m->ecache.put(m->cur_ls, m->cur_le, E);
             }
             B->st_prefetch_pe++;
         }
+        return 0;
+    };
+    if (what & 1) { if (pe_pass()) return 1; }
+    if (ok && (what & 4)) {   // ... and at lambda_sterics = lambda_electrostatics = 1 (what _computeAlchemicalCorrection asks next)
+        std::vector<double> sv(2 * R);
+        for (int r = 0; r < R; r++) { sv[2 * r] = B->eng[r]->cur_ls; sv[2 * r + 1] = B->eng[r]->cur_le; if (live[r]) { B->eng[r]->cur_ls = 1.0; B->eng[r]->cur_le = 1.0; } }
+        const int rc = pe_pass();
+        for (int r = 0; r < R; r++) { B->eng[r]->cur_ls = sv[2 * r]; B->eng[r]->cur_le = sv[2 * r + 1]; }
+        if (rc) return 1;
     }
     if (ok && (what & 2)) {
         bool any = false;
@@ -1626,7 +1652,7 @@ static int load_positions(BluesEngine* h, const double* const src[3], int stride
     unsigned out[4];
     HIP_OK(h, hipMemcpyAsync(out, h->d_xfer_out.p, sizeof out, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->e_cache_valid = false;
+    h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear();
     if (out[0]) h->e_frozen_valid = false;
     float worst; memcpy(&worst, &out[1], sizeof worst);
     // tiles are formed from the mobile non-alchemical atoms.  A few wandering i-atoms only stretch their tile's bounding
@@ -1669,7 +1695,7 @@ int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
         HIP_OK(h, hipStreamSynchronize(h->stream));
         h->hx = st;
         if (upload_xyz(h, h->hx.data(), h->d_x)) return 1;
-        h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->e_cache_valid = false; h->e_frozen_valid = false;
+        h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear(); h->e_frozen_valid = false;
         return sort_and_tile(h);
     }
     // one interleaved transfer; de-interleaving, image refresh and the re-sort statistics happen on the device
@@ -1695,7 +1721,7 @@ int blues_set_box(BluesEngine* h, const double box[9]) {
     HIP_OK(h, hipStreamSynchronize(h->stream));
     h->box[0] = box[0]; h->box[1] = box[4]; h->box[2] = box[8];
     for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) E_FAIL(h, "box edge %g < 2*(cutoff+skin)", h->box[k]);
-    h->sorted_ok = false; h->pass_valid = false; h->e_frozen_valid = false; h->e_cache_valid = false;
+    h->sorted_ok = false; h->pass_valid = false; h->e_frozen_valid = false; h->ecache.clear();
     if (h->have_positions) { if (download_xyz(h, h->hx.data(), h->d_x)) return 1; return sort_and_tile(h); }
     return 0;
 }
@@ -1874,7 +1900,7 @@ int blues_reset(BluesEngine* h) {
 
 int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
     for (int i = 0; i < BLUES_N_STATS; i++) stats[i] = 0;
-    stats[9] = h->st_resorts;
+    stats[9] = h->st_resorts; stats[11] = h->st_energy_evals;
     if (h->d_jcount.p && h->sorted_ok) { std::vector<int> jc; hipSetDevice(h->device); hipStreamSynchronize(h->stream); try { h->d_jcount.download(jc); for (int c : jc) stats[8] = std::max<int64_t>(stats[8], c); } catch (std::string&) {} }
     stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
     if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) { stats[1] = f.list_gen; stats[10] = f.builds; } }
@@ -1940,7 +1966,7 @@ int blues_snapshot_capture(BluesEngine* h, int32_t what, BluesSnapshot** out) {
     if (what & 2) for (int k = 0; k < 3; k++) { c.src[c.count] = h->d_v[k].p; c.dst[c.count++] = sn->v[k]; }
     hipLaunchKernelGGL(k_copy_arrays, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, c);
     h->st_launches++;
-    sn->e_valid = (what & 1) && h->e_cache_valid; sn->e = h->e_cache; sn->e_ls = h->e_cache_ls; sn->e_le = h->e_cache_le;
+    sn->ecache = h->ecache; if (!(what & 1)) sn->ecache.clear();
     HIP_OK(h, hipGetLastError());
     *out = sn;
     return 0;
@@ -1993,7 +2019,7 @@ int blues_set_positions_from_snapshot(BluesEngine* h, const BluesSnapshot* sn) {
     const double* src[3] = {sn->x[0], sn->x[1], sn->x[2]};
     if (load_positions(h, src, 1)) return 1;
     // the energy that was known for these positions is known again (OpenMM re-evaluates; same value)
-    if (sn->e_valid && sn->owner == h) { h->e_cache = sn->e; h->e_cache_ls = sn->e_ls; h->e_cache_le = sn->e_le; h->e_cache_valid = true; }
+    if (sn->owner == h) h->ecache = sn->ecache;
     return 0;
 }
 

@@ -115,7 +115,7 @@ class NativeEngine:
         s = (C.c_int64 * _abi.N_STATS)(); self._check(self._lib.blues_get_stats(self._h, s))
         return {"force_passes": s[0], "list_generation": s[1], "kernel_launches": s[2], "i_tiles": s[3],
                 "clusters": s[4], "jcap": s[5], "npart": s[6], "seg_len": s[7] // 1000, "wpb": s[7] % 1000,
-                "max_jcount": s[8], "resorts": s[9], "list_builds": s[10]}
+                "max_jcount": s[8], "resorts": s[9], "list_builds": s[10], "own_energy_evaluations": s[11]}
 
     def time_nonbonded(self, reps=20):
         u = C.c_double(); self._check(self._lib.blues_time_nonbonded(self._h, int(reps), C.byref(u))); return u.value
@@ -202,11 +202,12 @@ class NativeBatch:
                     raise err
         return errors, w
 
-    def prefetch_energies(self, potential=True, kinetic=True, active=None):
+    def prefetch_energies(self, potential=True, kinetic=True, active=None, at_lambda_one=False):
         """Evaluate the members' energies with shared launches into their caches (see include/blues_engine.h)."""
         R = len(self.engines)
         mask = (C.c_int32 * R)(*[1 if (active is None or active[r]) else 0 for r in range(R)])
-        if self._lib.blues_batch_set_active(self._h, mask) or self._lib.blues_batch_prefetch_energies(self._h, (1 if potential else 0) | (2 if kinetic else 0)):
+        what = (1 if potential else 0) | (2 if kinetic else 0) | (4 if at_lambda_one else 0)
+        if self._lib.blues_batch_set_active(self._h, mask) or self._lib.blues_batch_prefetch_energies(self._h, what):
             raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
 
     def stats(self):

@@ -321,7 +321,8 @@ class BatchedBLUESSimulation(object):
         while wanted:
             errors = self._advance(self._ncmc_batch, sims, wanted)
             idx = sorted(wanted)
-            self._ncmc_batch.prefetch_energies(active=[r in wanted and r not in errors for r in range(len(sims))])
+            # (at_lambda_one: the energies _computeAlchemicalCorrection and _syncStatesMDtoNCMC take at lambda = 1)
+            self._ncmc_batch.prefetch_energies(active=[r in wanted and r not in errors for r in range(len(sims))], at_lambda_one=True)
             got = self.for_each_chain(lambda r, c: resume(r, errors.get(r)), idx)
             wanted = {r: n for r, n in zip(idx, got) if n is not DONE}
 
@@ -346,7 +347,7 @@ class BatchedBLUESSimulation(object):
             def sync(r, c):
                 c.currentIter = N
                 c._syncStatesMDtoNCMC()
-            (self._md_batch or self._ncmc_batch).prefetch_energies()
+            (self._md_batch or self._ncmc_batch).prefetch_energies(at_lambda_one=self._md_batch is None)
             self.for_each_chain(sync)
             self._stepNCMC(nstepsNC, moveStep)
             self.for_each_chain(lambda r, c: c._acceptRejectMove(write_move))

@@ -163,7 +163,8 @@ int blues_reset(BluesEngine *h);
  * rebuilds [2] kernel launches [3] n i-tiles [4] n clusters [5] j-list capacity
  * [6] partial slabs [7] segment length*1000 + waves per block [8] longest
  * j-list at the last rebuild [9] re-sorts of the tile layout [10] list
- * builds executed */
+ * builds executed [11] potential-energy evaluations launched by this engine
+ * alone (those served by blues_batch_prefetch_energies are not counted) */
 #define BLUES_N_STATS 12
 int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
 /* time `reps` launches of the dominant nonbonded kernel alone with HIP events
@@ -222,7 +223,9 @@ int blues_batch_step(BluesBatch *b, int32_t n_steps, double *work_trace, int32_t
  * NULL = everyone. */
 int blues_batch_set_active(BluesBatch *b, const int32_t *mask);
 /* Evaluates the total potential (what bit 0) and / or kinetic (bit 1) energy of
- * every active member with shared launches and one read-back, and leaves the
+ * every active member -- bit 2: also the potential energy with lambda_sterics =
+ * lambda_electrostatics = 1 at the same coordinates (the "alch"/MD energy of
+ * _computeAlchemicalCorrection, simulation.py:1100-1119) -- with shared launches and one read-back, and leaves the
  * values in the members' energy caches: the blues_get_energy /
  * blues_set_positions calls that follow for each member (state.getPotentialEnergy
  * at simulation.py:908, the perturbed / unperturbed energies of
