@@ -36,7 +36,7 @@ class OracleBackedBatch:
                     raise ex
         return errors, None
 
-    def prefetch_energies(self, potential=True, kinetic=True, active=None):
+    def prefetch_energies(self, potential=True, kinetic=True, active=None, at_lambda_one=False):
         pass
 
     def close(self):
