@@ -228,6 +228,8 @@ def declare_engine_prototypes(lib):
         "blues_snapshot_read": ([H, C.c_int32, _dp, C.c_int32], C.c_int),
         "blues_set_positions_from_snapshot": ([H, H], C.c_int),
         "blues_set_velocities_from_snapshot": ([H, H], C.c_int),
+        "blues_snapshot_read_atoms": ([H, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _dp], C.c_int),
+        "blues_set_positions_from_snapshot_edited": ([H, H, C.POINTER(C.c_int32), C.c_int32, _dp], C.c_int),
         "blues_batch_create": ([C.POINTER(H), C.c_int32, C.POINTER(H)], C.c_int),
         "blues_batch_destroy": ([H], C.c_int),
         "blues_batch_last_error": ([H], C.c_char_p),
@@ -252,7 +254,7 @@ ENGINE_SYMBOLS = (
     "blues_get_energy", "blues_get_energy_terms", "blues_step", "blues_run_switch", "blues_get_global",
     "blues_set_global", "blues_reset", "blues_get_stats", "blues_time_nonbonded", "blues_time_list_build",
     "blues_snapshot_capture", "blues_snapshot_release", "blues_snapshot_read", "blues_set_positions_from_snapshot",
-    "blues_set_velocities_from_snapshot",
+    "blues_set_velocities_from_snapshot", "blues_snapshot_read_atoms", "blues_set_positions_from_snapshot_edited",
     "blues_batch_create", "blues_batch_destroy", "blues_batch_last_error", "blues_batch_size", "blues_batch_step", "blues_batch_set_active", "blues_batch_prefetch_energies",
     "blues_batch_get_stats", "blues_batch_time_nonbonded",
 )

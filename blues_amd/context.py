@@ -109,9 +109,14 @@ class Context(object):
         """reference blues/simulation.py:960, blues/moves.py:307"""
         snap = positions.on_device() if isinstance(positions, unit.DeviceQuantity) else None
         if snap is not None and hasattr(self._engine, "set_positions_from_snapshot"):
-            self._engine.set_positions_from_snapshot(snap)   # a State handed back unchanged: device-to-device
-        else:
-            self._engine.set_positions(unit.value_in(positions, "nanometer"))
+            idx, rows = positions.pending_edits()
+            if len(idx) == 0:
+                self._engine.set_positions_from_snapshot(snap)   # a State handed back unchanged: device-to-device
+                return
+            f = 1.0 / unit.Quantity(1.0, "nanometer").value_in_unit(positions.unit)   # the Quantity's unit -> nm
+            if self._engine.set_positions_from_snapshot_edited(snap, idx, rows * f):  # a few atoms edited by a Move
+                return
+        self._engine.set_positions(unit.value_in(positions, "nanometer"))
 
     def setVelocities(self, velocities):
         """reference blues/simulation.py:962"""

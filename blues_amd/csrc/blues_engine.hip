@@ -161,6 +161,7 @@ struct BluesEngine {
     DBuf<double> d_x[3], d_v[3], d_xbuild[3], d_mass, d_charge, d_sigma, d_eps;
     DBuf<double> d_x_sort[3], d_stage;   // positions at the last spatial sort; [n][3] staging for host transfers
     DBuf<unsigned> d_xfer_out;
+    DBuf<int> d_edit_idx; DBuf<double> d_edit_xyz;   // a Move's edit of a few atoms (blues_set_positions_from_snapshot_edited)
     std::vector<struct BluesSnapshot*> snap_pool;   // released snapshots, reused (hipMalloc per getState would dominate)
     DBuf<AtomF> d_img_f; DBuf<AtomD> d_img_d;
     DBuf<int> d_sorted_of_orig, d_orig_of_sorted, d_tile_atoms, d_jlist, d_jstage, d_jcount, d_batch_slot, d_ex_start, d_ex_idx, d_islot;
@@ -1639,7 +1640,7 @@ static int download_xyz(BluesEngine* h, double* xyz, DBuf<double>* src) {   // d
 }
 
 // Shared tail of setPositions: the new coordinates are already on the device (src, SoA stride 1 or interleaved stride 3).
-static int load_positions(BluesEngine* h, const double* const src[3], int stride) {
+static int load_positions(BluesEngine* h, const double* const src[3], int stride, int n_edit = 0) {
     LoadPosArgs a; memset(&a, 0, sizeof a);
     a.n = h->n; a.stride = stride;
     for (int k = 0; k < 3; k++) { a.src[k] = src[k]; a.x[k] = h->d_x[k].p; a.x_sort[k] = h->d_x_sort[k].p; }
@@ -1649,6 +1650,14 @@ static int load_positions(BluesEngine* h, const double* const src[3], int stride
     HIP_OK(h, hipMemsetAsync(h->d_xfer_out.p, 0, 4 * sizeof(unsigned), h->stream));
     hipLaunchKernelGGL(k_load_positions, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, a);
     h->st_launches++;
+    if (n_edit > 0) {   // the edit list is already in d_edit_idx / d_edit_xyz
+        EditPosArgs e; memset(&e, 0, sizeof e);
+        e.n_edit = n_edit; e.idx = h->d_edit_idx.p; e.xyz = h->d_edit_xyz.p;
+        for (int k = 0; k < 3; k++) { e.x[k] = h->d_x[k].p; e.x_sort[k] = h->d_x_sort[k].p; }
+        e.mass = a.mass; e.alch_local = a.alch_local; e.sorted_of_orig = a.sorted_of_orig; e.img_f = a.img_f; e.img_d = a.img_d; e.box = a.box; e.out = a.out;
+        hipLaunchKernelGGL(k_edit_positions, dim3((n_edit + 63) / 64), dim3(64), 0, h->stream, e);
+        h->st_launches++;
+    }
     unsigned out[4];
     HIP_OK(h, hipMemcpyAsync(out, h->d_xfer_out.p, sizeof out, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
@@ -2020,6 +2029,60 @@ int blues_set_positions_from_snapshot(BluesEngine* h, const BluesSnapshot* sn) {
     if (load_positions(h, src, 1)) return 1;
     // the energy that was known for these positions is known again (OpenMM re-evaluates; same value)
     if (sn->owner == h) h->ecache = sn->ecache;
+    return 0;
+}
+
+// setPositions with a State's positions in which a Move changed a few atoms (positions[i] = ... on the still device-resident
+// array): the unchanged coordinates are restored device to device, the edited ones travel.  Returns 3 (and does nothing)
+// when an edited atom shares a constraint cluster with an atom that is not edited -- the cluster would have to be made
+// whole with coordinates only the device has; the caller then takes the plain host route.
+int blues_set_positions_from_snapshot_edited(BluesEngine* h, const BluesSnapshot* sn, const int32_t* idx, int32_t n_idx, const double* xyz) {
+    if (snapshot_usable(h, sn)) return 1;
+    if (!sn->has_x) E_FAIL(h, "the snapshot holds no positions");
+    if (n_idx <= 0) return blues_set_positions_from_snapshot(h, sn);
+    if (!h->sorted_ok) return 3;
+    std::vector<int> pos_of(h->n, -1);
+    for (int e = 0; e < n_idx; e++) { if (idx[e] < 0 || idx[e] >= h->n) E_FAIL(h, "edited atom %d out of range", idx[e]); pos_of[idx[e]] = e; }
+    std::vector<double> ed(xyz, xyz + 3 * (size_t)n_idx);
+    for (const HostCluster& c : h->clusters) {
+        int inside = 0, total = 0;
+        for (int a = 0; a < 4; a++) if (c.atoms[a] >= 0) { total++; inside += pos_of[c.atoms[a]] >= 0; }
+        if (inside == 0) continue;
+        if (inside != total) return 3;
+        for (int a = 1; a < 4; a++) if (c.atoms[a] >= 0)   // one whole periodic image per cluster, as blues_set_positions stores them
+            for (int k = 0; k < 3; k++) {
+                const double d = ed[3 * pos_of[c.atoms[a]] + k] - ed[3 * pos_of[c.atoms[0]] + k];
+                ed[3 * pos_of[c.atoms[a]] + k] -= h->box[k] * std::nearbyint(d / h->box[k]);
+            }
+    }
+    HIP_OK(h, hipSetDevice(h->device));
+    if (before_position_edit(h)) return 1;
+    if (sn->owner->stream != h->stream) HIP_OK(h, hipStreamSynchronize(sn->owner->stream));
+    try {
+        if ((int)h->d_edit_idx.n < n_idx) { h->d_edit_idx.alloc(n_idx); h->d_edit_xyz.alloc((size_t)3 * n_idx); }
+    } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    HIP_OK(h, hipMemcpyAsync(h->d_edit_idx.p, idx, sizeof(int) * n_idx, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->d_edit_xyz.p, ed.data(), sizeof(double) * 3 * n_idx, hipMemcpyHostToDevice, h->stream));
+    const double* src[3] = {sn->x[0], sn->x[1], sn->x[2]};
+    return load_positions(h, src, 1, n_idx);   // (synchronises before `ed` goes out of scope)
+}
+
+// positions / velocities of a few atoms of a snapshot (a Move that reads positions[indices] of a device-resident State)
+int blues_snapshot_read_atoms(BluesSnapshot* sn, int32_t what, const int32_t* idx, int32_t n_idx, double* out) {
+    BluesEngine* h = sn->owner;
+    if (what != 1 && what != 2) E_FAIL(h, "snapshot read: what must be 1 (positions) or 2 (velocities)");
+    if ((what == 1 && !sn->has_x) || (what == 2 && !sn->has_v)) E_FAIL(h, "the snapshot does not hold what was asked for");
+    if (n_idx <= 0) return 0;
+    for (int e = 0; e < n_idx; e++) if (idx[e] < 0 || idx[e] >= sn->n) E_FAIL(h, "atom %d out of range", idx[e]);
+    HIP_OK(h, hipSetDevice(h->device));
+    try {
+        if ((int)h->d_edit_idx.n < n_idx) { h->d_edit_idx.alloc(n_idx); h->d_edit_xyz.alloc((size_t)3 * n_idx); }
+    } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    HIP_OK(h, hipMemcpyAsync(h->d_edit_idx.p, idx, sizeof(int) * n_idx, hipMemcpyHostToDevice, h->stream));
+    double* const* s = what == 1 ? sn->x : sn->v;
+    hipLaunchKernelGGL(k_gather_atoms, dim3((n_idx + 63) / 64), dim3(64), 0, h->stream, n_idx, h->d_edit_idx.p, s[0], s[1], s[2], h->d_edit_xyz.p);
+    HIP_OK(h, hipMemcpyAsync(out, h->d_edit_xyz.p, sizeof(double) * 3 * n_idx, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -634,6 +634,46 @@ __global__ void __launch_bounds__(256) k_load_positions(LoadPosArgs a) {
     }
 }
 
+// a few atoms of the positions just loaded are overwritten (a Move's edit of a State handed back otherwise unchanged):
+// one thread per edited atom; same statistics as k_load_positions, for the new coordinates
+struct EditPosArgs {
+    int n_edit; const int* idx; const double* xyz;   // [n_edit], [n_edit][3]
+    double* x[3]; const double* x_sort[3];
+    const double* mass; const int* alch_local; const int* sorted_of_orig;
+    AtomF* img_f; AtomD* img_d; Box3 box;
+    unsigned* out;
+};
+__global__ void __launch_bounds__(64) k_edit_positions(EditPosArgs a) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= a.n_edit) return;
+    const int i = a.idx[e];
+    double p[3], d2 = 0.0;
+    const bool frozen = a.mass[i] == 0.0 && a.alch_local[i] < 0;
+    bool changed = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        p[k] = a.xyz[3 * e + k];
+        changed |= p[k] != a.x[k][i];
+        a.x[k][i] = p[k];
+        const double d = min_image_d(p[k] - a.x_sort[k][i], a.box.L[k], a.box.invL[k]);
+        d2 += d * d;
+    }
+    if (frozen && changed) atomicOr(&a.out[0], 1u);
+    if (a.mass[i] != 0.0 && a.alch_local[i] < 0) atomicMax(&a.out[1], __float_as_uint((float)d2));
+    if (d2 > 0.25) atomicAdd(&a.out[2], 1u);
+    const int s = a.sorted_of_orig[i];
+    if (a.img_f) { unsigned u[3]; to_fixed32(p, a.box, u); a.img_f[s].x = u[0]; a.img_f[s].y = u[1]; a.img_f[s].z = u[2]; }
+    else { unsigned long long u[3]; to_fixed(p, a.box, u); a.img_d[s].x = u[0]; a.img_d[s].y = u[1]; a.img_d[s].z = u[2]; }
+}
+
+// gather of a few atoms' coordinates (snapshot or live) into a dense [n][3] buffer
+__global__ void __launch_bounds__(64) k_gather_atoms(int n_idx, const int* idx, const double* s0, const double* s1, const double* s2, double* out) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= n_idx) return;
+    const int i = idx[e];
+    out[3 * e] = s0[i]; out[3 * e + 1] = s1[i]; out[3 * e + 2] = s2[i];
+}
+
 // plain copies between engine state and snapshots / the host staging buffer: up to 6 arrays of n doubles in one launch;
 // dst_stride 3 interleaves (device-side transpose for getPositions), src_stride 3 de-interleaves
 struct Copy6Args { int n, count, src_stride, dst_stride; const double* src[6]; double* dst[6]; };

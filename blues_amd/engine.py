@@ -62,6 +62,17 @@ class NativeEngine:
     def set_positions_from_snapshot(self, snap):
         self._check(self._lib.blues_set_positions_from_snapshot(self._h, snap._h))
 
+    def set_positions_from_snapshot_edited(self, snap, indices, xyz):
+        """The snapshot's positions with a few atoms replaced.  False: not applicable (an edited atom is constrained to an
+        unedited one) -- nothing was done, use set_positions."""
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        x = np.ascontiguousarray(xyz, dtype=np.float64).reshape(len(idx), 3)
+        rc = self._lib.blues_set_positions_from_snapshot_edited(self._h, snap._h, idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx), x.ctypes.data_as(_dp))
+        if rc == 3:
+            return False
+        self._check(rc)
+        return True
+
     def set_velocities_from_snapshot(self, snap):
         self._check(self._lib.blues_set_velocities_from_snapshot(self._h, snap._h))
 
@@ -141,6 +152,15 @@ class DeviceSnapshot:
             self.engine._check(self.engine._lib.blues_snapshot_read(self._h, kind, out.ctypes.data_as(_dp), self.engine.n))
             self._host[kind] = out
         return self._host[kind]
+
+    def read_atoms(self, kind, indices):
+        """Coordinates (kind 1) or velocities (2) of a few atoms -> (len(indices), 3)."""
+        if kind in self._host:
+            return self._host[kind][np.asarray(indices, dtype=np.int64)].copy()
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        out = np.empty((len(idx), 3))
+        self.engine._check(self.engine._lib.blues_snapshot_read_atoms(self._h, kind, idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx), out.ctypes.data_as(_dp)))
+        return out
 
     def release(self):
         if getattr(self, "_h", None) and getattr(self.engine, "_h", None):

@@ -70,18 +70,19 @@ class RandomLigandRotationMove(Move):
         return (coordinates * masses).sum(0) / masses.sum()
 
     def move(self, context):
+        """reference blues/moves.py:278-310, statement for statement: the State's positions are indexed and assigned through
+        the Quantity (which, on this engine, moves only the ligand's coordinates between device and host)."""
         positions = context.getState(getPositions=True).getPositions(asNumpy=True)
-        x = positions._value
-        self.positions = x[self.atom_indices]
+        self.positions = positions[self.atom_indices]._value
         self.center_of_mass = self.getCenterOfMass(self.positions, self.masses)
         reduced_pos = self.positions - self.center_of_mass
         rand_quat = uniform_quaternion(self.random_state)
         rand_rotation_matrix = rotation_matrix_from_quaternion(rand_quat)
         rot_move = numpy.dot(reduced_pos, rand_rotation_matrix) + self.center_of_mass
         for index, atomidx in enumerate(self.atom_indices):
-            x[atomidx] = rot_move[index]
-        context.setPositions(unit.Quantity(x, "nanometer"))
-        self.positions = x[self.atom_indices]
+            positions[atomidx] = rot_move[index]
+        context.setPositions(positions)
+        self.positions = positions[self.atom_indices]._value
         return context
 
 

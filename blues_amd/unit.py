@@ -86,27 +86,78 @@ class Quantity(object):
 class DeviceQuantity(Quantity):
     """A Quantity whose array still lives on the GPU (a State's positions or velocities).  Reading `_value` -- or anything
     that goes through it -- downloads it once; handed back untouched to Context.setPositions / setVelocities it never
-    leaves the device.  Once it has been read the host copy is authoritative (the caller may have edited it in place)."""
+    leaves the device.  What a Move typically does to positions -- read `q[indices]`, assign `q[i] = xyz` -- is served
+    without the full array: the few atoms are fetched, the assignments are remembered and applied on the device when the
+    Quantity is handed to setPositions.  Once `_value` has been read the host copy is authoritative."""
 
     def __init__(self, snapshot, kind, unit):
         if unit not in _UNITS:
             raise ValueError("unknown unit %r" % unit)
         self.unit = unit
         self._snapshot, self._kind, self._host = snapshot, kind, None
+        self._edits = {}   # atom index -> (3,) values in this Quantity's unit, while the array is still on the device
 
     @property
     def _value(self):
         if self._host is None:
-            self._host = self._snapshot.read(self._kind)
+            self._host = self._snapshot.read(self._kind).copy()
+            for i, row in self._edits.items():
+                self._host[i] = row
+            self._edits = {}
         return self._host
 
     @_value.setter
     def _value(self, v):
         self._host = v
+        self._edits = {}
 
     def on_device(self):
         """The untouched device copy, or None once the host has seen (and may have changed) the numbers."""
         return self._snapshot if self._host is None else None
+
+    def pending_edits(self):
+        """(indices, values) assigned while the array was still on the device."""
+        idx = sorted(self._edits)
+        return np.asarray(idx, dtype=np.int64), (np.array([self._edits[i] for i in idx], dtype=np.float64).reshape(-1, 3))
+
+    @staticmethod
+    def _atoms(k):
+        """int / 1-D integer sequence -> (index array, is_scalar); None for anything else (slices, masks, tuples)."""
+        if isinstance(k, (int, np.integer)):
+            return np.array([int(k)], dtype=np.int64), True
+        if isinstance(k, (list, np.ndarray)):
+            a = np.asarray(k)
+            if a.ndim == 1 and a.dtype.kind in "iu":
+                return a.astype(np.int64), False
+        return None
+
+    def __getitem__(self, k):
+        sel = self._atoms(k) if self._host is None else None
+        if sel is None:
+            return Quantity(self._value[k], self.unit)
+        idx, scalar = sel
+        n = self._snapshot.engine.n
+        idx = np.where(idx < 0, idx + n, idx)
+        rows = self._snapshot.read_atoms(self._kind, idx)
+        for j, i in enumerate(idx):
+            if int(i) in self._edits:
+                rows[j] = self._edits[int(i)]
+        return Quantity(rows[0] if scalar else rows, self.unit)
+
+    def __setitem__(self, k, v):
+        sel = self._atoms(k) if self._host is None else None
+        if sel is None:
+            self._value[k] = self._same(v)
+            return
+        idx, scalar = sel
+        n = self._snapshot.engine.n
+        vals = np.asarray(self._same(v), dtype=np.float64)
+        vals = np.broadcast_to(vals.reshape(-1, 3) if vals.size != 3 or not scalar else vals.reshape(1, 3), (len(idx), 3))
+        for j, i in enumerate(idx):
+            self._edits[int(i) + (n if i < 0 else 0)] = vals[j].copy()
+
+    def __len__(self):
+        return self._snapshot.engine.n if self._host is None else len(self._host)
 
 
 class _Reciprocal(object):

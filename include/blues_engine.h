@@ -191,6 +191,13 @@ int blues_snapshot_release(BluesSnapshot *s);
 int blues_snapshot_read(BluesSnapshot *s, int32_t what, double *out_xyz, int32_t n_atoms);
 int blues_set_positions_from_snapshot(BluesEngine *h, const BluesSnapshot *s);
 int blues_set_velocities_from_snapshot(BluesEngine *h, const BluesSnapshot *s);
+/* A Move reads a few atoms of a State and writes them back (positions[idx],
+ * positions[i] = ..., reference blues/moves.py:292-307): the few atoms travel,
+ * the rest is restored device to device.  _edited returns 3 without doing
+ * anything when an edited atom is constrained to an unedited one (take the
+ * plain blues_set_positions route then). */
+int blues_snapshot_read_atoms(BluesSnapshot *s, int32_t what, const int32_t *idx, int32_t n_idx, double *out_xyz);
+int blues_set_positions_from_snapshot_edited(BluesEngine *h, const BluesSnapshot *s, const int32_t *idx, int32_t n_idx, const double *xyz_nm);
 
 /* ---- Replica batches ------------------------------------------------------
  * BLUES chains are independent (reference examples run one

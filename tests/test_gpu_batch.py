@@ -504,3 +504,44 @@ def test_batched_full_iterations_with_md_leg(Engine, tol_box, same_decomposition
         assert bat[r]._md_sim.currentStep == nIter * nmd
     assert B._md_batch.stats()["lockstep_steps"] >= nIter * nmd - 2
     B.close()
+
+
+def test_move_style_edits_of_a_device_resident_state(Engine, tol_box):
+    """What a Move does (reference blues/moves.py:292-307): read positions[indices], assign positions[i] = xyz, hand the
+    Quantity to setPositions.  On this engine only the touched atoms travel; the result equals the plain host route, also
+    when the edit cannot be applied on the device (an edited atom constrained to an unedited one -> host fallback)."""
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    mk = lambda: Simulation(None, s, _integ(16, seed=21, dt=0.002), precision="double")
+    a, b = mk(), mk()
+    for sim in (a, b):
+        sim.context.setVelocities(unit.Quantity(v, "nanometer/picosecond")); sim.step(4)
+    lig = list(range(15))
+    rot = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    # device route
+    q = a.context.getState(getPositions=True).getPositions(asNumpy=True)
+    sub = q[lig]._value
+    assert sub.shape == (15, 3) and q.on_device() is not None
+    assert np.array_equal(q[3]._value, sub[3]) and len(q) == s.n_atoms
+    new = (sub - sub.mean(0)) @ rot.T + sub.mean(0)
+    for k, i in enumerate(lig):
+        q[i] = new[k]
+    assert np.array_equal(q[lig]._value, new) and q.on_device() is not None        # reads see the pending assignments
+    launches = a.context._engine.stats()["kernel_launches"]
+    a.context.setPositions(q)
+    assert q.on_device() is not None                                                # never materialised
+    # host route on the twin
+    x = b.context._engine.get_positions(); x[lig] = new
+    b.context.setPositions(unit.Quantity(x, "nanometer"))
+    assert np.array_equal(a.context._engine.get_positions(), b.context._engine.get_positions())
+    a.step(6); b.step(6)
+    assert np.array_equal(a.context._engine.get_positions(), b.context._engine.get_positions())
+    assert a.integrator.getGlobalVariableByName("protocol_work") == b.integrator.getGlobalVariableByName("protocol_work")
+    # an edit that splits a constraint cluster (one hydrogen of a water): applied through the host fallback, same outcome
+    q = a.context.getState(getPositions=True).getPositions(asNumpy=True)
+    h_new = q[16]._value + np.array([0.001, 0.0, 0.0])
+    q[16] = h_new
+    a.context.setPositions(q)
+    x = b.context._engine.get_positions(); x[16] = h_new
+    b.context.setPositions(unit.Quantity(x, "nanometer"))
+    assert np.array_equal(a.context._engine.get_positions(), b.context._engine.get_positions())
