@@ -545,3 +545,51 @@ def test_move_style_edits_of_a_device_resident_state(Engine, tol_box):
     x = b.context._engine.get_positions(); x[16] = h_new
     b.context.setPositions(unit.Quantity(x, "nanometer"))
     assert np.array_equal(a.context._engine.get_positions(), b.context._engine.get_positions())
+
+
+def test_full_protocol_full_size_batch_properties(Engine, monkeypatch):
+    """BASELINE.json configs[1] at full size in a batch: eight chains of the S23k system through the whole 1000-step protocol
+    with the ligand rotated at lambda = 0.5.  Size-independent properties: every chain ends at lambda = 1 with finite work,
+    constraints satisfied, no frozen atom moved, the alchemical parameters back at (1, ~1); and -- determinism across the
+    batched and the lone code path -- one chain reproduces its 1000-step solo trajectory bit for bit."""
+    from blues_amd.engine import NativeBatch
+    s, v = systems.s23k(mobile_atoms=275, frozen=True)
+    for k, val in (("BLUES_FUSE", "0"), ("BLUES_K2_JITER", "4"), ("BLUES_SKIN", "0.12")):
+        monkeypatch.setenv(k, val)
+    R, n = 8, 1000
+    lig = np.arange(15)
+    rot = np.array([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+
+    def rotate(g):
+        x = g.get_positions(); c = x[lig].mean(0); x[lig] = (x[lig] - c) @ rot.T + c; g.set_positions(x)
+
+    vels = [v * (1.0 + 0.02 * r) for r in range(R)]
+    bat = _make(Engine, s, vels, n, 0)
+    B = NativeBatch(bat)
+    B.step(n // 2)
+    for g in bat:
+        rotate(g)
+    errors, _ = B.step(n - n // 2, raise_errors=False)
+    assert all(e is None for e in errors)
+    st = B.stats()
+    assert st["lockstep_steps"] >= n - 2 and st["batched_energy_evaluations"] >= 1       # the perturbed energies were taken together
+    frozen = s.mass == 0.0
+    works = []
+    for g in bat:
+        assert g.get_global("step") == n and g.get_global("lambda") == 1.0
+        assert g.get_global("lambda_sterics") == 1.0 and abs(g.get_global("lambda_electrostatics") - 1.0) < 1e-12
+        w = g.get_global("protocol_work"); works.append(w)
+        assert np.isfinite(w) and abs(w) < 1e5
+        x = g.get_positions(); c = s.constraint_atoms; m = s.mass[c[:, 0]] > 0
+        assert np.abs(np.linalg.norm(x[c[m, 0]] - x[c[m, 1]], axis=1) / s.constraint_dist[m] - 1).max() < 1e-7
+        assert np.array_equal(x[frozen], s.positions[frozen])
+        assert np.isfinite(g.potential_energy()) and np.isfinite(g.kinetic_energy())
+    assert len(set(works)) == R
+    solo = _make(Engine, s, vels[3:4], n, 0)[0]       # chain 3 alone (its Philox stream is replica index 0 there: rebuild with the right one)
+    solo.close()
+    from blues_amd import integrators as _i
+    solo = Engine(s, _integ(n, seed=103).to_data(precision=0, replica=3)); solo.set_velocities(vels[3])
+    solo.step(n // 2); rotate(solo); solo.step(n - n // 2)
+    assert solo.get_global("protocol_work") == works[3]
+    assert np.array_equal(solo.get_positions(), bat[3].get_positions())
+    B.close()
