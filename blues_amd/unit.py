@@ -137,11 +137,14 @@ class DeviceQuantity(Quantity):
             return Quantity(self._value[k], self.unit)
         idx, scalar = sel
         n = self._snapshot.engine.n
-        idx = np.where(idx < 0, idx + n, idx)
-        rows = self._snapshot.read_atoms(self._kind, idx)
-        for j, i in enumerate(idx):
-            if int(i) in self._edits:
-                rows[j] = self._edits[int(i)]
+        idx = [int(i) + (n if i < 0 else 0) for i in idx]
+        if all(i in self._edits for i in idx):      # everything asked for was assigned here: no device round trip
+            rows = np.array([self._edits[i] for i in idx], dtype=np.float64).reshape(-1, 3)
+        else:
+            rows = self._snapshot.read_atoms(self._kind, idx)
+            for j, i in enumerate(idx):
+                if i in self._edits:
+                    rows[j] = self._edits[i]
         return Quantity(rows[0] if scalar else rows, self.unit)
 
     def __setitem__(self, k, v):
@@ -151,8 +154,12 @@ class DeviceQuantity(Quantity):
             return
         idx, scalar = sel
         n = self._snapshot.engine.n
-        vals = np.asarray(self._same(v), dtype=np.float64)
-        vals = np.broadcast_to(vals.reshape(-1, 3) if vals.size != 3 or not scalar else vals.reshape(1, 3), (len(idx), 3))
+        vals = np.array(self._same(v), dtype=np.float64)
+        if scalar:
+            i = int(idx[0])
+            self._edits[i + (n if i < 0 else 0)] = vals.reshape(3)
+            return
+        vals = np.broadcast_to(vals.reshape(-1, 3), (len(idx), 3))
         for j, i in enumerate(idx):
             self._edits[int(i) + (n if i < 0 else 0)] = vals[j].copy()
 
