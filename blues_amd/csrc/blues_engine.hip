@@ -2147,7 +2147,7 @@ int blues_batch_destroy(BluesBatch* b) {
 int blues_batch_size(const BluesBatch* b) { return b ? b->R() : 0; }
 
 int blues_batch_set_active(BluesBatch* b, const int32_t* mask) {
-    if (!b || b->eng.empty()) return 2;
+    if (!b || b->eng.empty()) { if (b) b->err = "the batch has been dissolved (one of its engines was destroyed)"; return 2; }
     for (int r = 0; r < b->R(); r++) b->active[r] = mask ? (mask[r] != 0) : 1;
     return 0;
 }

@@ -593,3 +593,26 @@ def test_full_protocol_full_size_batch_properties(Engine, monkeypatch):
     assert solo.get_global("protocol_work") == works[3]
     assert np.array_equal(solo.get_positions(), bat[3].get_positions())
     B.close()
+
+
+def test_batch_rejects_incongruent_members_and_misuse(Engine, tol_box):
+    """Members must share topology and protocol; an engine belongs to one batch at a time; a dissolved batch says so."""
+    from blues_amd.engine import NativeBatch, EngineError
+    s, v = tol_box
+    a = Engine(s, _integ(10, seed=1).to_data(precision=0, replica=0)); a.set_velocities(v)
+    b = Engine(s, _integ(12, seed=2).to_data(precision=0, replica=1)); b.set_velocities(v)      # another protocol length
+    B = NativeBatch([a, b])
+    with pytest.raises(EngineError, match="congruent"):
+        B.step(2)
+    with pytest.raises(EngineError, match="already belongs"):
+        NativeBatch([a])
+    B.close()
+    a.step(2); b.step(2)                       # both usable on their own again
+    c = Engine(s, _integ(10, seed=3).to_data(precision=0, replica=2)); c.set_velocities(v)
+    B2 = NativeBatch([a, c])
+    B2.step(3)
+    assert a.get_global("step") == 5 and c.get_global("step") == 3      # members need not be at the same step (that round falls back)
+    c.close()                                  # destroying a member dissolves the batch
+    with pytest.raises(EngineError, match="dissolved"):
+        B2.step(1)
+    B2.close(); a.step(1)
