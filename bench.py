@@ -144,6 +144,66 @@ def pmc_traffic(workload, R):
         return None
 
 
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment) BEFORE this process touches the GPU -- the parent never initialises HIP,
+    never re-execs, only waits.  Rank 0 prints the one JSON line on the inherited stdout.  Returns non-zero if any rank
+    failed (the others are then terminated: a dead rank would leave them waiting in a collective)."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   BLUES_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def launch_check(args):
+    """CPU-only check of the launch path (tests/test_bench_launcher.py): rendezvous, the per-iteration all-gather of the
+    accept records and the max-over-ranks timing reduction on the gloo backend, no engine, no GPU."""
+    import torch
+    import torch.distributed as dist
+    from blues_amd.replicas import env_rank, gather_decision_block, init_process_group
+    rank, local_rank, world = env_rank()
+    if world > 1:
+        init_process_group("gloo")
+    block = np.array([[1.0, 0.0, -0.5 * (rank + 1), 10.0 + rank, 0.0]] * 2)
+    recs = gather_decision_block(block)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "records": int(recs.shape[0]), "work": recs[:, 3].tolist(), "max_rank_time": float(t.item())}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +219,21 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-chain measurement")
+    ap.add_argument("--launch-check", action="store_true", help="CPU-only check of the N-rank launch path (gloo, no engine)")
     args = ap.parse_args()
+
+    # ---- N ranks: either a launcher (torch.distributed.run) already started us as one of them, or we start them ourselves
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not args.launch_check:
+            from blues_amd import build
+            build.build_engine()      # hipcc only (no GPU call): compile once here instead of N times behind a lock
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if env_world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a line whose n_gpus is not what was asked for\n" % (args.gpus, env_world))
+        sys.exit(2)
+    if args.launch_check:
+        sys.exit(launch_check(args))
 
     from blues_amd import build
     build.build_engine()

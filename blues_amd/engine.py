@@ -77,7 +77,12 @@ class NativeEngine:
         self._check(self._lib.blues_set_velocities_from_snapshot(self._h, snap._h))
 
     def set_box(self, box3):
-        b = np.zeros(9); b[0], b[4], b[8] = np.asarray(box3, dtype=np.float64).reshape(-1)[[0, 1, 2]] if np.size(box3) == 3 else np.asarray(box3).reshape(3, 3).diagonal()
+        # a full 3x3 matrix goes through as it is: the C side rejects non-orthorhombic boxes (include/blues_engine.h)
+        b = np.zeros(9)
+        if np.size(box3) == 3:
+            b[0], b[4], b[8] = np.asarray(box3, dtype=np.float64).reshape(-1)
+        else:
+            b[:] = np.asarray(box3, dtype=np.float64).reshape(9)
         self._check(self._lib.blues_set_box(self._h, self._ptr(b)))
 
     def get_positions(self):

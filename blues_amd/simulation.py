@@ -112,7 +112,9 @@ class BLUESSimulation(object):
         nstepsNC = int(nstepsNC)
         # the reference steps one at a time and tests `step == 0`, `step == moveStep`, `step == lastStep`
         # around each integrator step; the same hook order with the steps in between fused:
-        cuts = sorted(set([0, int(moveStep), nstepsNC]))
+        # (the reference's loop never moves and never steps past nstepsNC when moveStep lies outside [0, nstepsNC))
+        moveStep = int(moveStep)
+        cuts = sorted(set([0, nstepsNC] + ([moveStep] if 0 <= moveStep < nstepsNC else [])))
         try:
             for a, b in zip(cuts[:-1], cuts[1:]):
                 if a == 0:

@@ -139,7 +139,10 @@ double orc_default_lambda_electrostatics(double l) {
     return lep_step(0.2 - l) - 1.0 / 0.2 * l * lep_step(0.2 - l) + 1.0 / 0.2 * (l - 0.8) * lep_step(l - 0.8);
 }
 
-static double round4(double x) { return round(x * 1e4) / 1e4; }
+/* Python's round(x, 4): the decimal string of the EXACT binary value, correctly rounded to 4 places (half-to-even on
+ * the exact value), read back.  round(x*1e4)/1e4 differs where x*1e4 rounds onto a tie (0.5-0.12345 -> 0.3765, not
+ * 0.3766) -- found by running the reference's own _get_prop_lambda text (tests/golden/make_reference_vectors.py). */
+static double round4(double x) { char b[64]; snprintf(b, sizeof b, "%.4f", x); return strtod(b, NULL); }
 
 /* reference blues/integrators.py:147-157 */
 void orc_get_prop_lambda(double prop_lambda, double out[2]) {

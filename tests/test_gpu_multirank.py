@@ -1,0 +1,63 @@
+"""GPU suite, multi-rank part (needs >= 2 GPUs; skipped on the 1-GPU box): the one exchange of the path -- the all-gather
+of accept records -- over RCCL (backend "nccl"), and bench.py's own N-rank launch."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()   # counting devices does not initialise the GPU in this process
+
+
+_WORKER = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from blues_amd import replicas
+rank, local_rank, world = replicas.init_process_group("nccl")
+assert dist.get_backend() == "nccl"
+block = np.array([[float(c == rank), 3.0, -0.5 * (2 * rank + c + 1), 20.0 + 2 * rank + c, 0.0] for c in range(2)])
+out = replicas.gather_decision_block(block)
+assert out.shape == (2 * world, 5) and out[:, 3].tolist() == [20.0 + i for i in range(2 * world)], out
+one = replicas.gather_decisions(rank == 1, 3, -1.0 - rank, 5.0 + rank)
+assert one.shape == (world, 5) and one[:, 3].tolist() == [5.0 + r for r in range(world)]
+dist.barrier(); torch.cuda.synchronize()
+if rank == 0:
+    print(json.dumps({"ok": True, "world": world}))
+dist.destroy_process_group()
+"""
+
+
+def test_gather_decision_block_over_rccl():
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs")
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    assert json.loads(outs[0][0].strip().splitlines()[-1]) == {"ok": True, "world": 2}
+
+
+def test_bench_gpus_2_reports_two_ranks():
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--replicas", "8",
+                        "--nsteps-nc", "20", "--no-cpu", "--no-single"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["accept_records_last"]["chains"] == 16 and np.isfinite(out["value"])

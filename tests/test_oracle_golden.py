@@ -42,6 +42,57 @@ def test_default_lambda_functions_golden(oracle_mod, known_answers):
     assert d.lambda_sterics[0] == 1.0 and d.lambda_electrostatics[20] == pytest.approx(1.0)
 
 
+@pytest.fixture(scope="module")
+def reference_vectors():
+    """Outputs of the reference's OWN function text (ast-extracted and executed by tests/golden/make_reference_vectors.py)."""
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_function_vectors.json")) as fh:
+        return json.load(fh)
+
+
+def test_calculate_ncmc_steps_reference_executed(oracle_mod, reference_vectors):
+    """blues/utils.py:89-145 run over 1,512 inputs: product host logic and the oracle's C restatement must agree exactly."""
+    import logging
+    logging.getLogger("blues_amd.utils").setLevel(logging.CRITICAL)
+    cases = reference_vectors["calculateNCMCSteps"]["cases"]
+    assert len(cases) > 1000
+    n_exit = 0
+    for c in cases:
+        kw = dict(nstepsNC=c["nstepsNC"], nprop=c["nprop"], propLambda=c["propLambda"])
+        if "exit" in c:
+            n_exit += 1
+            with pytest.raises(SystemExit):
+                utils.calculateNCMCSteps(**kw)
+            assert oracle_mod.calculate_ncmc_steps(c["nstepsNC"], c["nprop"], c["propLambda"])[0] == -1
+            continue
+        got = utils.calculateNCMCSteps(**kw)
+        assert [got["nstepsNC"], got["propSteps"], got["moveStep"]] == c["expect"], c
+        assert list(oracle_mod.calculate_ncmc_steps(c["nstepsNC"], c["nprop"], c["propLambda"])) == c["expect"], c
+    assert n_exit > 0
+
+
+def test_prop_lambda_reference_executed(oracle_mod, reference_vectors):
+    """blues/integrators.py:147-157 run over 168 inputs (incl. the round(.., 4) edge cases)."""
+    for c in reference_vectors["get_prop_lambda"]["cases"]:
+        assert list(integrators.get_prop_lambda(c["prop_lambda"])) == c["expect"], c
+        assert list(oracle_mod.get_prop_lambda(c["prop_lambda"])) == c["expect"], c
+
+
+def test_default_protocol_reference_executed(oracle_mod, reference_vectors):
+    """The default alchemical_functions strings and splitting of generateNCMCIntegrator (blues/simulation.py:654-660),
+    evaluated on a 2,033-point lambda grid: the product's Lepton evaluator, its defaults and the oracle's C forms."""
+    d = reference_vectors["generateNCMCIntegrator_defaults"]
+    assert d["splitting"] == integrators.generateNCMCIntegrator(nstepsNC=10)._splitting
+    assert sorted(integrators.DEFAULT_ALCHEMICAL_FUNCTIONS) == d["parameters"]
+    fs = lepton.compile_expression(integrators.DEFAULT_ALCHEMICAL_FUNCTIONS["lambda_sterics"])
+    fe = lepton.compile_expression(integrators.DEFAULT_ALCHEMICAL_FUNCTIONS["lambda_electrostatics"])
+    t = d["table"]
+    for lam, s, e in zip(t["lambda"], t["lambda_sterics"], t["lambda_electrostatics"]):
+        assert fs(**{"lambda": lam}) == s and fe(**{"lambda": lam}) == e      # same IEEE operations in the same order
+        assert oracle_mod.default_lambda_sterics(lam) == pytest.approx(s, abs=1e-15)
+        assert oracle_mod.default_lambda_electrostatics(lam) == pytest.approx(e, abs=4e-15)
+
+
 def test_integrator_attributes_golden(known_answers):
     """reference blues/tests/test_simulation.py:262-289"""
     ka = known_answers["integrator_attributes"]
