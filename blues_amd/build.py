@@ -5,7 +5,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libblues_hip.so")
+LIB_PATH = os.environ.get("BLUES_LIB_PATH") or os.path.join(CSRC, "libblues_hip.so")   # (override: development builds with other compiler flags)
 SOURCES = ["blues_engine.hip", "device_common.h", "kernels_nb.h", "kernels_alch.h", "kernels_bonded.h", "kernels_integrate.h", "kernels_batch.h"]
 
 
@@ -17,6 +17,8 @@ def hipcc_path():
 
 
 def is_stale():
+    if os.environ.get("BLUES_LIB_PATH"):
+        return False
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -154,6 +155,15 @@ struct BluesEngine {
     int seg_len = 64, waves_tile = 4, wpb = 4, npart = 1;  // K1 decomposition
     bool fuse_forces = false, fast_step = true, fuse_big = false;  // fuse_big: measured slower (the alchemical role's 140 VGPRs and 36 KB LDS cap the occupancy of the nonbonded role)
     int k1_iw = 64;  // i-atoms per wave in the nonbonded kernel: 64 = classic tile kernel, 8/16 = sub-tile throughput kernel
+    int k1_mode = 0;  // 0: tile kernel (lane = i-atom), 1: sub-tile kernel, 2: per-atom Verlet lists + LDS tile image (nonbonded_atom_body)
+    int acap = 0;     // capacity of one atom's list (mode 2)
+    // layout shape of the per-atom-list mode.  A lone engine derives (S, jcap) from its own geometry at every re-sort; members
+    // of a batch must stay congruent, so the batch fixes the shape for all of them (shape_S > 0) and re-plans it for
+    // everybody when some member's list outgrows it (shape_overflow)
+    int hint_count = 0;   // list length that raises resort_hint
+    int shape_S = 0, shape_jcap = 0; bool shape_overflow = false, forbid_atom = false; double shape_need = 0.0;
+    int S = 1, n_lists = 0;   // S consecutive i-tiles share one j-list (mode 2; 1 otherwise); n_lists = ceil(n_itiles / S)
+    DBuf<unsigned short> d_alist; DBuf<int> d_acount;
     int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
     double total_mass = 0;
@@ -220,7 +230,7 @@ struct BluesBatch {
     // each member's pending work and the members issue into it; leave: the batch stream is drained, members go home.
     hipStream_t stream = nullptr; bool entered = false;
     DBuf<double> d_gather; int64_t st_prefetch_pe = 0, st_prefetch_ke = 0;
-    int64_t st_lockstep_steps = 0, st_fallback_steps = 0;
+    int64_t st_lockstep_steps = 0, st_fallback_steps = 0, st_replans = 0;
     int R() const { return (int)eng.size(); }
 };
 static int batch_enter(BluesBatch* B);
@@ -424,9 +434,8 @@ static int sort_and_tile(BluesEngine* h) {
     }
     h->n_itiles = ((int)tile_atoms.size() + 63) / 64;
     tile_atoms.resize((size_t)h->n_itiles * 64, -1);
-    h->n_tiles = h->n_itiles + (h->alch.empty() ? 0 : 1);
     if (!h->alch.empty()) { for (size_t a = 0; a < 64; a++) tile_atoms.push_back(a < h->alch.size() ? h->h_sorted_of_orig[h->alch[a]] : -1); }
-    if (h->n_tiles == 0) { tile_atoms.assign(64, -1); }
+    if (tile_atoms.empty()) { tile_atoms.assign(64, -1); }
     h->n_islots = std::max(1, h->n_itiles) * 64;
     // Verlet skin: a small i-set is latency-bound (longer j-lists cost nothing, rebuilds do); a large one is
     // throughput-bound (every extra j costs pair evaluations)
@@ -445,7 +454,6 @@ static int sort_and_tile(BluesEngine* h) {
     jcap = std::min(jcap, 16384);
     if (((n + 63) / 64) * 64 <= jcap) jcap = ((n + 63) / 64) * 64;
     h->jcap = jcap;
-    const int nt = std::max(1, h->n_tiles);
     {   // K1 decomposition: segments of seg_len j-atoms, waves_tile waves per i-tile in blocks of wpb waves
         const int nit = std::max(1, h->n_itiles);
         const double est_count = std::min<double>(jcap, est / 1.8);
@@ -475,7 +483,77 @@ static int sort_and_tile(BluesEngine* h) {
             if (const char* e = getenv("BLUES_NC")) NC = std::max(1, atoi(e));
             h->waves_tile = NC; h->npart = NC; h->wpb = 4; h->seg_len = 64;
         }
+        // throughput regime in mixed precision: per-atom Verlet lists over an LDS-resident image of the j-list
+        // (nonbonded_atom_body).  S consecutive i-tiles share one list / one image; S and the list capacity come from the
+        // geometry: the list holds what lies within cutoff+skin of the group's bounding sphere.
+        h->k1_mode = h->k1_iw != 64 ? 1 : 0;
+        h->S = 1; h->acap = 0;
+        bool want_atom = h->k1_mode == 1;
+        if (const char* e = getenv("BLUES_K1_MODE")) { if (atoi(e) == 1) want_atom = false; }
+        if (h->forbid_atom) want_atom = false;
+        if (want_atom && h->n_itiles > 0) {
+            auto group_est = [&](int S) {   // largest expected list length over the groups of S tiles
+                double worst = 0.0;
+                for (int g0 = 0; g0 < h->n_itiles; g0 += S) {
+                    double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+                    std::vector<std::array<double, 3>> pts;
+                    const int first = h->h_orig_of_sorted[tile_atoms[(size_t)g0 * 64]];
+                    for (int q = g0 * 64; q < std::min(h->n_itiles, g0 + S) * 64; q++) {
+                        if (tile_atoms[q] < 0) continue;
+                        const int o = h->h_orig_of_sorted[tile_atoms[q]];
+                        std::array<double, 3> d;
+                        for (int k = 0; k < 3; k++) { d[k] = h->hx[3 * o + k] - h->hx[3 * first + k]; d[k] -= h->box[k] * std::nearbyint(d[k] / h->box[k]); lo[k] = std::min(lo[k], d[k]); hi[k] = std::max(hi[k], d[k]); }
+                        pts.push_back(d);
+                    }
+                    double r2 = 0.0;
+                    for (auto& d : pts) { double q2 = 0.0; for (int k = 0; k < 3; k++) { const double e = d[k] - 0.5 * (lo[k] + hi[k]); q2 += e * e; } r2 = std::max(r2, q2); }
+                    const double rs = std::sqrt(r2) + rl;
+                    const double box_v = (hi[0] - lo[0] + 2 * rl) * (hi[1] - lo[1] + 2 * rl) * (hi[2] - lo[2] + 2 * rl);
+                    worst = std::max(worst, rho * std::min(4.0 / 3.0 * M_PI * rs * rs * rs, box_v));
+                }
+                return worst;
+            };
+            double slack = 1.5;    // room for the i-atoms to spread before the next re-sort (a re-sort is asked for at 1.25x)
+            if (const char* e = getenv("BLUES_JCAP_SCALE")) slack *= atof(e);
+            const int lds_max = 6400;     // list entries whose image (24 B each) fits the 160 KB of LDS beside the kernel's statics
+            double best_cost = 1e300; int best_S = 0, best_cap = 0;
+            h->shape_overflow = false;
+            if (h->shape_S > 0) {   // member of a batch: the batch's shape, as long as this member's lists fit it
+                best_S = std::min(h->shape_S, std::max(1, h->n_itiles)); best_cap = h->shape_jcap;
+                h->shape_need = group_est(best_S);
+                if (h->shape_need * 1.1 + 64 > best_cap) h->shape_overflow = true;   // a re-sort (asked for at 90 % of the capacity) that does not make room
+                if (getenv("BLUES_DEBUG_LISTS")) fprintf(stderr, "[shape] member %d: S=%d need %.0f cap %d hint %d overflow %d\n", h->batch_index, best_S, h->shape_need, best_cap, h->hint_count, (int)h->shape_overflow);
+            } else {
+                for (int S : {1, 2, 3, 4, 5, 6, 8, 12, 16}) {
+                    if (S > 1 && S > h->n_itiles) continue;
+                    const double need = group_est(S);
+                    // Two capacities only: 3,328 entries (an 80 KB image: two workgroups per CU) or 6,400 (the whole LDS, one
+                    // workgroup per CU).  Quantised so that a chain gets the same capacity -- hence re-sorts at the same steps --
+                    // alone and inside a batch (whose capacity follows its largest member): their bitwise identity rests on it.
+                    if (need * 1.3 + 64 > lds_max) continue;
+                    const bool one_wg = need * 1.3 + 64 > 3328;
+                    int cap = one_wg ? lds_max : 3328;
+                    if (slack != 1.5) cap = std::max(64, (((int)(cap * slack / 1.5) + 63) / 64) * 64);   // tests shrink it to exercise the re-sort path
+                    const double cost = need / (std::min(S, h->n_itiles) * 64.0) * (one_wg ? 1.3 : 1.0);   // staging work per i-atom
+                    if (cost < best_cost) { best_cost = cost; best_S = S; best_cap = cap; }
+                }
+                if (const char* e = getenv("BLUES_LIST_GROUP")) { const int S = std::max(1, std::min(16, atoi(e))); best_S = S; best_cap = group_est(S) * 1.3 + 64 > 3328 ? lds_max : 3328; }
+                if (best_S > 0) h->shape_need = group_est(best_S);
+            }
+            if (best_S > 0 && best_cap < 32768) {
+                h->k1_mode = 2; h->S = best_S; jcap = std::min(best_cap, ((n + 63) / 64) * 64); h->jcap = jcap;
+                h->waves_tile = 1; h->npart = 1; h->wpb = 4; h->seg_len = 64;
+                double cap = rho * 4.0 / 3.0 * M_PI * rl * rl * rl * 1.7;   // mean neighbour count within cutoff+skin, with slack for dense regions
+                if (const char* e = getenv("BLUES_ACAP_SCALE")) cap *= atof(e);
+                h->acap = std::min(jcap, std::max(64, (((int)cap + 63) / 64) * 64));
+            }
+        }
     }
+    h->hint_count = h->k1_mode == 2 ? h->jcap - h->jcap / 10 : h->jcap - h->jcap / 7;
+    h->n_lists = (std::max(1, h->n_itiles) + h->S - 1) / h->S;
+    if (h->n_itiles == 0) h->n_lists = 0;
+    h->n_tiles = h->n_lists + (h->alch.empty() ? 0 : 1);
+    const int nt = std::max(1, h->n_tiles);
     h->pool_cap = nt * MASK_QUOTA;
     h->PA = 1; while (h->PA < (int)h->alch.size()) h->PA <<= 1;
     h->k2_jiter = h->n_itiles * h->batch_R <= 32 && h->batch_R < 8 ? 1 : 4;
@@ -529,7 +607,8 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * LIST_WAVES * ((((n + LIST_WAVES - 1) / LIST_WAVES) + 63) & ~63)); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
         h->d_mask_pool.alloc((size_t)h->pool_cap * 64);
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
-        h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_iw != 64 ? 64 / h->k1_iw : 1) + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
+        if (h->k1_mode == 2) { h->d_alist.alloc((size_t)h->n_islots * h->acap); h->d_acount.alloc(h->n_islots); }
+        h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1)) + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
         { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi);
           std::vector<FinRec> fr(h->n_islots + 64);
           auto fill = [&](FinRec& r, int atom) {
@@ -632,6 +711,8 @@ static ListArgs make_list_args(BluesEngine* h) {
     for (int k = 0; k < 3; k++) { a.x[k] = h->d_x[k].p; a.xbuild[k] = h->d_xbuild[k].p; }
     a.fJ = h->d_fJ.p; a.n_fJ = 9 * h->n;
     a.alch_jrec = h->alch.empty() ? nullptr : (void*)h->d_jrec.p; a.p_sigma = h->d_sigma.p; a.p_eps = h->d_eps.p; a.p_charge = h->d_charge.p;
+    if (h->k1_mode == 2) { a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap; }
+    a.S = h->S; a.n_lists = h->n_lists; a.hint_count = h->hint_count; a.no_sphere = getenv("BLUES_NO_SPHERE") != nullptr;
     return a;
 }
 
@@ -643,6 +724,24 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
         hipLaunchKernelGGL(k_build_lists_b<R>, dim3(h->n_tiles + 2, h->batch->R()), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), force);
     } else if (!batch_dry(h)) {
         hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 2), dim3(LIST_THREADS), 0, h->cur, a, make_nbconst<R>(h), img, force);
+    }
+    if (h->k1_mode == 2 && h->n_itiles > 0) {
+        // second kernel of a rebuild (same gate): the atoms' own lists, one block per i-tile; the group's list lives in
+        // dynamic LDS there (positions 12 B + index 4 B + exclusion bitmap 8 B per entry)
+        const size_t lds = (size_t)h->jcap * 24;
+        if (!batch_dry(h)) {
+            static thread_local size_t lds_set[2] = {0, 0};
+            const bool lead = batch_lead(h);
+            if (lds > lds_set[lead]) {
+                hipError_t e = lead ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_atom_lists_b<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                    : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_atom_lists<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) E_FAIL(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
+                lds_set[lead] = lds;
+            }
+            if (lead) hipLaunchKernelGGL(k_build_atom_lists_b<R>, dim3(h->n_itiles, h->batch->R()), dim3(LIST_THREADS), lds, h->cur, batch_reps_nb<R>(h->batch), force);
+            else hipLaunchKernelGGL(k_build_atom_lists<R>, dim3(h->n_itiles), dim3(LIST_THREADS), lds, h->cur, a, make_nbconst<R>(h), img, force);
+        }
+        h->st_launches++;
     }
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
@@ -661,7 +760,27 @@ template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
     a.seg_len = h->seg_len; a.waves_tile = h->waves_tile; a.npart = h->npart;
     a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p; a.mask_pool = h->d_mask_pool.p;
     a.fpart = h->d_fpart.p; a.epart = h->d_epart_nb.p; a.flags = h->d_flags.p; a.batch_req = batch_req_ptr(h);
+    if (h->k1_mode == 2) { a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap; }
+    a.S = h->S; a.n_lists = h->n_lists;
     return a;
+}
+
+// per-atom-list kernel: one 1024-thread workgroup per i-tile, the tile's j-image in dynamic LDS (24 B per list entry)
+template <bool ENERGY> static int launch_nb_atom(BluesEngine* h, const NbArgs<float>& a) {
+    const size_t lds = (size_t)h->jcap * 24;
+    static thread_local size_t lds_set[2][2] = {{0, 0}, {0, 0}};   // [batched][ENERGY]: largest dynamic-LDS size the kernel was opened for
+    const bool lead = batch_lead(h);
+    if (batch_dry(h)) return 0;
+    if (lds > lds_set[lead][ENERGY]) {
+        hipError_t e = lead ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nonbonded_atom_b<ENERGY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                            : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nonbonded_atom<ENERGY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) E_FAIL(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
+        lds_set[lead][ENERGY] = lds;
+    }
+    const int nb = std::max(1, h->n_lists);
+    if (lead) hipLaunchKernelGGL((k_nonbonded_atom_b<ENERGY>), dim3(nb * h->batch->R()), dim3(1024), lds, h->cur, h->batch->d_nb_f.p, nb, h->batch->R());
+    else hipLaunchKernelGGL((k_nonbonded_atom<ENERGY>), dim3(nb), dim3(1024), lds, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
+    return 0;
 }
 
 template <bool ENERGY> static void launch_nb_sub(BluesEngine* h, const NbArgs<float>& a) {
@@ -686,6 +805,12 @@ template <bool ENERGY> static void launch_nb_sub(BluesEngine* h, const NbArgs<fl
 template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
     NbArgs<R> a = make_nb_args<R>(h);
     if constexpr (sizeof(R) == 4) {
+        if (h->k1_mode == 2) {
+            if (launch_nb_atom<ENERGY>(h, a)) return 1;
+            h->st_launches++;
+            HIP_OK(h, hipGetLastError());
+            return 0;
+        }
         if (h->k1_iw != 64) {
             launch_nb_sub<ENERGY>(h, a);
             h->st_launches++;
@@ -737,7 +862,7 @@ static AlchArgs make_alch_args(BluesEngine* h, const double ls[3], const double 
     AlchArgs A; memset(&A, 0, sizeof A);
     A.jrec = h->d_jrec.p; A.arec = h->d_arec.p;
     A.n = h->n; A.n_alch = (int)h->alch.size(); A.PA = h->PA; A.jcap = h->jcap; A.nblocks_env = h->k2_nblocks_env; A.jiter = h->k2_jiter;
-    A.alch_orig = h->d_alch_orig.p; A.jlist = h->d_jlist.p + (size_t)h->n_itiles * h->jcap; A.jcount = h->d_jcount.p + h->n_itiles;
+    A.alch_orig = h->d_alch_orig.p; A.jlist = h->d_jlist.p + (size_t)h->n_lists * h->jcap; A.jcount = h->d_jcount.p + h->n_lists;
     A.orig_of_sorted = h->d_orig_of_sorted.p; A.sorted_of_orig = h->d_sorted_of_orig.p;
     for (int k = 0; k < 3; k++) A.x[k] = h->d_x[k].p;
     A.charge = h->d_charge.p; A.sigma = h->d_sigma.p; A.eps = h->d_eps.p; A.ex_start = h->d_ex_start.p; A.ex_idx = h->d_ex_idx.p;
@@ -781,7 +906,7 @@ static FinArgs make_fin_args(BluesEngine* h, const double le[3], int slot_mask =
     F.n = h->n; F.n_islots = h->n_islots; F.npart = h->npart; F.n_alch = (int)h->alch.size(); F.PA = h->PA; F.k2_nblocks_env = h->k2_nblocks_env; F.k2_jiter = h->k2_jiter; F.n_entries = h->n_entries;
     F.recs = h->d_finrecs.p; F.orig_of_islot = h->d_orig_of_islot.p; F.row_of_orig = h->d_row_of_orig.p; F.row_start = h->d_row_start.p;
     F.fpart = h->d_fpart.p; F.fent = h->d_fent.p; F.fJ = h->d_fJ.p; F.sorted_of_orig = h->d_sorted_of_orig.p; F.alch_orig = h->d_alch_orig.p;
-    F.self_part = h->d_self_part.p; F.e_part = h->d_e_part.p; F.jcount_alch = h->d_jcount.p + h->n_itiles;
+    F.self_part = h->d_self_part.p; F.e_part = h->d_e_part.p; F.jcount_alch = h->d_jcount.p + h->n_lists;
     for (int s = 0; s < 3; s++) F.le[s] = le[s];
     F.slot_mask = slot_mask;
     F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p; F.ctrl = h->ctrl_arg;
@@ -881,7 +1006,7 @@ static int force_pass(BluesEngine* h, int base_L) {
         rc = h->precision == 0 ? launch_forces_fused<float>(h, ls, le) : launch_forces_fused<double>(h, ls, le);
         if (rc) return 1;
         if (launch_finalize(h, le, fmask)) return 1;
-    } else if (h->k1_iw != 64 && h->precision == 0 && h->fuse_big) {
+    } else if (h->k1_mode == 1 && h->precision == 0 && h->fuse_big) {
         if (launch_forces_fused_sub(h, ls, le)) return 1;
         if (launch_finalize(h, le, fmask)) return 1;
     } else {
@@ -917,12 +1042,14 @@ static int check_flags(BluesEngine* h) {
 // read-back) and re-sorts from the positions on the device.  Without this a long all-mobile run ends in list_overflow.
 #define RESORT_POLL 64
 static int relayout(BluesEngine* h);
+static int batch_plan_shape(BluesBatch* B, bool fresh);
 static int poll_resort(BluesEngine* h) {
     if (flush_program(h)) return 1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     DevFlags f;
     HIP_OK(h, hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost));
     if (!f.resort_hint || f.list_overflow || f.nan_flag || f.constraint_fail) return 0;   // errors are reported by check_flags
+    if (getenv("BLUES_DEBUG_LISTS")) { std::vector<int> jc; h->d_jcount.download(jc); fprintf(stderr, "[resort] member %d step %d jcount[0]=%d hint_count %d jcap %d\n", h->batch_index, h->h_step, jc.empty() ? -1 : jc[0], h->hint_count, h->jcap); }
     f.resort_hint = 0;
     HIP_OK(h, hipMemcpy(h->d_flags.p, &f, sizeof f, hipMemcpyHostToDevice));
     h->st_resorts++;
@@ -933,8 +1060,8 @@ static int poll_resort(BluesEngine* h) {
 struct EnergyShape { int nw, nbb, nfb; size_t off_frozen; };
 static EnergyShape energy_shape(const BluesEngine* h) {
     EnergyShape g;
-    const int subs = h->k1_iw != 64 ? 64 / h->k1_iw : 1;
-    g.nw = h->n_itiles * h->npart * subs;
+    const int subs = h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1);   // mode 2: one (LJ, Coulomb) pair per tile
+    g.nw = (h->k1_mode == 2 ? h->n_lists : h->n_itiles) * h->npart * subs;
     g.off_frozen = (size_t)std::max(1, h->n_itiles) * h->npart * 2 * subs;
     int total_terms = 0; for (int ty = 0; ty < T_NTYPES; ty++) total_terms += h->n_terms[ty];
     g.nbb = (total_terms + 255) / 256; g.nfb = (h->n + FROZEN_TILE - 1) / FROZEN_TILE;
@@ -1003,7 +1130,7 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
         if (g.nbb > 0) h->d_epart_b.download(eb);
         if (!h->alch.empty()) { h->d_jcount.download(jc); h->d_e_part.download(ep); }
     } catch (std::string& msg) { E_FAIL(h, "%s", msg.c_str()); }
-    energy_sum(h, enb.data(), eb.data(), h->alch.empty() ? 0 : jc[h->n_itiles], ep.data(), T);
+    energy_sum(h, enb.data(), eb.data(), h->alch.empty() ? 0 : jc[h->n_lists], ep.data(), T);
     return 0;
 }
 
@@ -1275,7 +1402,7 @@ static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const ch
 #define BC(f) if (a->f != b->f) { *why = #f; return false; }
     BC(device) BC(n) BC(precision) BC(nsteps) BC(nprop) BC(n_lambda) BC(split) BC(remove_cm) BC(dt) BC(gamma) BC(kT) BC(tol) BC(prop_min) BC(prop_max)
     BC(n_itiles) BC(n_tiles) BC(jcap) BC(n_islots) BC(pool_cap) BC(PA) BC(k2_nblocks_env) BC(k2_jiter) BC(seg_len) BC(waves_tile) BC(wpb) BC(npart)
-    BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k1_iw) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
+    BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k1_iw) BC(k1_mode) BC(acap) BC(S) BC(n_lists) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
     BC(cutoff) BC(alpha) BC(sc_alpha) BC(annih_elec) BC(annih_ster) BC(nb_method) BC(restr_k) BC(total_mass)
     BC(box[0]) BC(box[1]) BC(box[2])
 #undef BC
@@ -1479,6 +1606,15 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
                 } catch (std::string& e) { B->err = e; return 1; }
                 for (int r = 0; r < R; r++)
                     if (!B->failed[r] && (hints[r] & 1) && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0 && poll_resort(B->eng[r])) fail(r);
+                {   // a member whose lists have outgrown the batch's layout shape: a new shape for everybody (rare)
+                    bool over = false;
+                    for (int r = 0; r < R; r++) over |= !B->failed[r] && B->eng[r]->shape_overflow;
+                    if (over) {
+                        if (hipStreamSynchronize(B->leader->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
+                        if (batch_plan_shape(B, false)) return 1;
+                        B->st_replans++;
+                    }
+                }
             }
         }
         {   // the work of an instantaneous Move needs U(x_moved) of every member that was edited: evaluate them together
@@ -1596,12 +1732,49 @@ static int relayout(BluesEngine* h) {
     return sort_and_tile(h);
 }
 
+// One layout shape for all members of a batch in the per-atom-list mode (k1_mode 2), where the number of tiles per list and the
+// list capacity follow from the geometry: the leader's S (or the next smaller one whose lists fit the LDS), and a capacity
+// that holds the largest member's lists with room for the i-atoms to spread.  fresh: start from the members' own choices.
+static int batch_plan_shape(BluesBatch* B, bool fresh) {
+    if (B->eng.empty()) return 0;
+    auto fail = [&](BluesEngine* m) { B->err = "re-layout for the batch failed: " + m->err; return 1; };
+    if (fresh) for (BluesEngine* m : B->eng) { m->shape_S = 0; m->shape_jcap = 0; m->forbid_atom = false; if (relayout(m)) return fail(m); }
+    BluesEngine* lead = B->eng[0];
+    if (lead->k1_mode != 2) {   // the other modes size everything from the density: congruent by construction
+        for (BluesEngine* m : B->eng) if (m->k1_mode == 2) { m->forbid_atom = true; if (relayout(m)) return fail(m); }
+        return 0;
+    }
+    const int lds_max = 6400;
+    static const int cand[] = {16, 12, 8, 6, 5, 4, 3, 2, 1};
+    int S = lead->S;
+    for (;;) {
+        double need = 0.0;
+        for (BluesEngine* m : B->eng) {
+            if (m->k1_mode != 2 || m->S != S) { m->shape_S = S; m->shape_jcap = lds_max; if (relayout(m)) return fail(m); }
+            need = std::max(need, m->shape_need);
+        }
+        const int cap = need * 1.3 + 64 <= 3328 ? 3328 : (need * 1.3 + 64 <= lds_max ? lds_max : lds_max + 64);   // the two capacities of sort_and_tile
+        if (cap <= lds_max) {
+            for (BluesEngine* m : B->eng) if (m->shape_S != S || m->shape_jcap != cap || m->jcap != cap || m->shape_overflow) { m->shape_S = S; m->shape_jcap = cap; if (relayout(m)) return fail(m); }
+            return 0;
+        }
+        int next = 0;
+        for (int c : cand) if (c < S) { next = c; break; }
+        if (!next) {   // not even one tile per list fits: the bitmask kernels for everybody
+            for (BluesEngine* m : B->eng) { m->forbid_atom = true; m->shape_S = 0; m->shape_jcap = 0; if (relayout(m)) return fail(m); }
+            return 0;
+        }
+        S = next;
+    }
+}
+
 static void batch_detach_all(BluesBatch* B) {
     if (!B) return;
     batch_leave(B);
     for (BluesEngine* m : B->eng) if (m) {
         hipStreamSynchronize(m->stream);
         m->batch = nullptr; m->batch_index = -1; m->batch_R = 1;
+        m->shape_S = 0; m->shape_jcap = 0; m->forbid_atom = false;
         relayout(m);
     }
     B->eng.clear(); B->leader = nullptr; B->lockstep = false;
@@ -1911,6 +2084,11 @@ int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
     for (int i = 0; i < BLUES_N_STATS; i++) stats[i] = 0;
     stats[9] = h->st_resorts; stats[11] = h->st_energy_evals;
     if (h->d_jcount.p && h->sorted_ok) { std::vector<int> jc; hipSetDevice(h->device); hipStreamSynchronize(h->stream); try { h->d_jcount.download(jc); for (int c : jc) stats[8] = std::max<int64_t>(stats[8], c); } catch (std::string&) {} }
+    if (getenv("BLUES_DEBUG_LISTS") && h->k1_mode == 2 && h->d_acount.p) {
+        std::vector<int> ac; h->d_acount.download(ac); std::vector<int> jc2; h->d_jcount.download(jc2);
+        fprintf(stderr, "[lists] S=%d n_lists=%d jcap=%d acap=%d jcount:", h->S, h->n_lists, h->jcap, h->acap); for (int c : jc2) fprintf(stderr, " %d", c);
+        fprintf(stderr, "\n[lists] acount:"); for (size_t i = 0; i < ac.size(); i++) fprintf(stderr, " %d", ac[i]); fprintf(stderr, "\n");
+    }
     stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
     if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) { stats[1] = f.list_gen; stats[10] = f.builds; } }
     return 0;
@@ -1931,6 +2109,9 @@ int blues_time_nonbonded(BluesEngine* h, int32_t reps, double* usec) {
     float ms = 0.f;
     HIP_OK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *usec = 1000.0 * ms / std::max(1, reps);
+#ifdef BLUES_STAMP
+    { long long st[32]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nb_stamps), sizeof st); fprintf(stderr, "[stamps] nonbonded_atom (cycles since start):"); for (int i = 17; i < 28; i++) fprintf(stderr, " %lld", st[i] - st[16]); fprintf(stderr, "\n"); }
+#endif
     return check_flags(h);
 }
 
@@ -1952,6 +2133,9 @@ int blues_time_list_build(BluesEngine* h, int32_t reps, double* usec) {
     HIP_OK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *usec = 1000.0 * ms / std::max(1, reps);
     h->pass_valid = false; h->lists_forced = false;
+#ifdef BLUES_STAMP
+    { long long st[32]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nb_stamps), sizeof st); fprintf(stderr, "[stamps] list build (cycles since start):"); for (int i = 1; i < 9; i++) fprintf(stderr, " %lld", st[i] - st[0]); fprintf(stderr, "\n"); }
+#endif
     return check_flags(h);
 }
 
@@ -2125,7 +2309,7 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
         m->batch_R = count;
         m->use_graph = false;  // graph replays carry per-engine frozen arguments
     }
-    for (int r = 0; r < count; r++) if (relayout(engines[r])) { g_batch_create_error = "re-layout for the batch failed: " + engines[r]->err; batch_detach_all(B); delete B; return 1; }
+    if (batch_plan_shape(B, true)) { g_batch_create_error = B->err; batch_detach_all(B); delete B; return 1; }
     // off by default: measured on MI355X at R = 256 it does not pay (with 256 x 276 mobile atoms SOME atom crosses skin/2
     // every ~3 steps, and rebuilding all members at once costs about what one rebuild per step did: 669 vs 678 us/step)
     B->sync_lists = false;

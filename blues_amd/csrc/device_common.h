@@ -221,6 +221,23 @@ __device__ inline double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// the same sum with the four in-row levels on DPP (no LDS round trips): quad xor 1, quad xor 2, row_half_mirror, row_mirror
+// leave the 16-lane row sum in every lane of the row; the two cross-row levels go through __shfl_xor.  Fixed order.
+template <int CTRL> __device__ __forceinline__ double dpp_add_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = dpp_add_d<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add_d<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add_d<0x141>(v);   // row_half_mirror
+    v = dpp_add_d<0x140>(v);   // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
 __device__ inline double seg_sum(double v, int width) {  // sum over aligned groups of `width` lanes (power of two)
     for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;

@@ -65,6 +65,14 @@ __global__ void __launch_bounds__(LIST_THREADS) k_build_lists_b(const RepNb<R>* 
     build_lists_body<R>(a, c, rp.img, force);
 }
 
+template <typename R>
+__global__ void __launch_bounds__(LIST_THREADS) k_build_atom_lists_b(const RepNb<R>* __restrict__ reps, int force) {
+    const RepNb<R>& rp = reps[blockIdx.y];
+    if (!rp.active) return;
+    const ListArgs a = rp.L; const NbConst<R> c = rp.c;
+    build_atom_lists_body<R>(a, c, rp.img, force);
+}
+
 template <typename R, bool ENERGY, int WPB>
 __global__ void __launch_bounds__(WPB * 64) k_nonbonded_b(const RepNb<R>* __restrict__ reps, int nb, int nrep) {
     int rep, bx; batch_decode(nb, nrep, rep, bx);
@@ -81,6 +89,15 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub_b(const RepNb<float>* __r
     if (!rp.active) return;
     const NbArgs<float> a = rp.nb; const NbConst<float> c = rp.c;
     nonbonded_sub_body<ENERGY, IW>(a, c, rp.img, bx);
+}
+
+template <bool ENERGY>
+__global__ void __launch_bounds__(1024) k_nonbonded_atom_b(const RepNb<float>* __restrict__ reps, int nb, int nrep) {
+    int rep, bx; batch_decode(nb, nrep, rep, bx);
+    const RepNb<float>& rp = reps[rep];
+    if (!rp.active) return;
+    const NbArgs<float> a = rp.nb; const NbConst<float> c = rp.c;
+    nonbonded_atom_body<ENERGY>(a, c, rp.img, bx);
 }
 
 template <bool FAST, int MASK>

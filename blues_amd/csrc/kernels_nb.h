@@ -15,6 +15,13 @@
 #pragma once
 #include "device_common.h"
 
+#ifdef BLUES_STAMP
+__device__ long long g_nb_stamps[32];   // dev builds: s_memtime of thread 0 of block 0 at phase boundaries ([0..15] list build, [16..31] force kernel)
+#define NB_STAMP(cond, i) do { if (cond) g_nb_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NB_STAMP(cond, i) do { } while (0)
+#endif
+
 struct DevFlags {  // device-resident control words
     unsigned list_gen, req_gen;  // neighbour lists are current iff equal
     int list_overflow;           // j-list or mask-pool capacity exceeded
@@ -34,7 +41,7 @@ template <typename R> struct NbConst {
 };
 
 struct ListArgs {
-    int n, n_tiles, n_itiles, jcap, pool_cap;
+    int n, n_tiles, n_itiles, jcap, pool_cap;   // n_tiles: list blocks = n_lists (+1 with alchemical atoms)
     const int* tile_atoms;   // [n_tiles*64] sorted atom index or -1
     int* jlist;              // [n_tiles*jcap]
     int* jstage;             // [n_tiles][LIST_WAVES][share] per-wave staging for the ordered compaction (share: see build_lists_body)
@@ -52,6 +59,14 @@ struct ListArgs {
     double* xbuild[3];
     double* fJ;              // [9*n] alchemical forces on environment atoms, zeroed on rebuild
     int n_fJ;
+    // per-atom Verlet lists (nonbonded_atom_body): for every i-slot the LOCAL indices (positions in its tile's j-list) of
+    // the atoms within cutoff+skin, exclusions already removed; bit 15 = that j is mobile (energy weight 1/2).  Null: not built.
+    unsigned short* alist;   // [n_islots][acap]
+    int* acount;             // [n_islots]
+    int acap;
+    int no_sphere;           // development: bounding-box test only
+    int hint_count;          // a list longer than this raises resort_hint (the i-atoms have spread: re-derive the layout)
+    int S, n_lists;          // S consecutive i-tiles share one j-list (1 in the bitmask modes); n_lists = ceil(n_itiles / S), the alchemical tile's list comes after them
 };
 
 // LIST_WAVES waves share one tile's scan of all n atoms; each wave keeps LIST_PREFETCH independent loads in flight.
@@ -61,6 +76,7 @@ struct ListArgs {
 #define LIST_WAVES 16
 #define LIST_PREFETCH 4
 #define LIST_THREADS (LIST_WAVES * 64)
+#define EXK_MAX 64       // excluded partners of one i-atom that can sit in its tile's list (+ sentinel); per-atom-list mode
 #define LIST_LDS 8192      // j-list entries mirrored in LDS for the exclusion searches (longer lists are searched in HBM)
 
 template <typename R>
@@ -88,32 +104,54 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     __shared__ ufix s_ax[64][3];   // alchemical tile: its atoms' positions, for the exact per-atom range test
     __shared__ int s_na;
     __shared__ int s_nmask;
-    const bool alch_tile = (t >= a.n_itiles);
+    const bool alch_tile = (t >= a.n_lists);
+    // the i-atoms this list serves: tiles [tile0, tile0 + ntile) (the alchemical tile: one tile, index n_itiles)
+    const int tile0 = alch_tile ? a.n_itiles : t * a.S;
+    const int ntile = alch_tile ? 1 : min(a.S, a.n_itiles - tile0);
+    NB_STAMP(t == 0 && tid == 0, 0);
     if (alch_tile && wv == 1) {
-        const int ia = a.tile_atoms[t * 64 + lane];
+        const int ia = a.tile_atoms[tile0 * 64 + lane];
         if (ia >= 0) { s_ax[lane][0] = img[ia].x; s_ax[lane][1] = img[ia].y; s_ax[lane][2] = img[ia].z; }
         const unsigned long long have = __ballot(ia >= 0);
         if (lane == 0) s_na = __popcll(have);   // alchemical atoms fill the tile from slot 0
     }
 
-    // ---- bounding box of the tile in fixed point relative to its first atom
-    if (wv == 0) {
-        int ia = a.tile_atoms[t * 64 + lane];
-        int i0 = a.tile_atoms[t * 64];
-        ufix ref[3] = {img[i0].x, img[i0].y, img[i0].z};
-        ufix p[3] = {ref[0], ref[1], ref[2]};
-        if (ia >= 0) { p[0] = img[ia].x; p[1] = img[ia].y; p[2] = img[ia].z; }
+    // ---- bounding box AND bounding sphere of the list's i-atoms, in fixed point relative to their first atom: a thread per
+    // i-slot (ntile <= 16); an atom can only be within range of some i-atom if it is within cutoff+skin of both
+    __shared__ double s_lo[LIST_WAVES][3], s_hi[LIST_WAVES][3], s_r2[LIST_WAVES];
+    __shared__ double s_mid[3], s_rad;
+    {
+        const int i0 = a.tile_atoms[tile0 * 64];
+        const ufix ref[3] = {img[i0].x, img[i0].y, img[i0].z};
+        const int ia = tid < ntile * 64 ? a.tile_atoms[tile0 * 64 + tid] : -1;
+        double off[3] = {0.0, 0.0, 0.0};
+        if (ia >= 0) { off[0] = (double)(sfix)(img[ia].x - ref[0]) * c.dscale[0]; off[1] = (double)(sfix)(img[ia].y - ref[1]) * c.dscale[1]; off[2] = (double)(sfix)(img[ia].z - ref[2]) * c.dscale[2]; }
+#pragma unroll
         for (int k = 0; k < 3; k++) {
-            double off = (double)(sfix)(p[k] - ref[k]) * c.dscale[k];
-            double lo = off, hi = off;
+            double lo = off[k], hi = off[k];   // empty slots sit on the first atom: neutral
             for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
-            if (lane == 0) {
-                double mid = 0.5 * (lo + hi);
+            if (lane == 0) { s_lo[wv][k] = lo; s_hi[wv][k] = hi; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {   // (constant indices: a runtime index into ref[] would put it in scratch memory)
+                double lo = s_lo[0][k], hi = s_hi[0][k];
+                for (int w = 1; w < LIST_WAVES; w++) { lo = fmin(lo, s_lo[w][k]); hi = fmax(hi, s_hi[w][k]); }
+                const double mid = 0.5 * (lo + hi);
+                s_mid[k] = mid;
                 s_cfix[k] = ref[k] + (ufix)(sfix)llrint(mid / c.dscale[k]);
                 s_half[k] = 0.5 * (hi - lo) + 2.0 * c.dscale[k];
             }
         }
-        if (lane == 0) { s_total = 0; s_nmask = 0; }
+        if (tid == 0) { s_total = 0; s_nmask = 0; }
+        __syncthreads();
+        double r2 = 0.0;
+        if (ia >= 0) { const double dx = off[0] - s_mid[0], dy = off[1] - s_mid[1], dz = off[2] - s_mid[2]; r2 = dx * dx + dy * dy + dz * dz; }
+        for (int o = 32; o > 0; o >>= 1) r2 = fmax(r2, __shfl_xor(r2, o, 64));
+        if (lane == 0) s_r2[wv] = r2;
+        __syncthreads();
+        if (tid == 0) { double m = 0.0; for (int w = 0; w < LIST_WAVES; w++) m = fmax(m, s_r2[w]); s_rad = sqrt(m) + 4.0 * (c.dscale[0] + c.dscale[1] + c.dscale[2]); }
     }
     __syncthreads();
     const ufix cf[3] = {s_cfix[0], s_cfix[1], s_cfix[2]};
@@ -122,12 +160,15 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     // ---- ordered stream compaction of every atom within cutoff+skin of the box.  Each wave scans its own
     // contiguous share of the (Hilbert-sorted) atoms with no block barrier inside the loop and stages its
     // hits; the shares are then concatenated in order, so the list stays ascending.
+    NB_STAMP(t == 0 && tid == 0, 1);
     int* jl = a.jlist + (size_t)t * a.jcap;
     const int share = (((a.n + LIST_WAVES - 1) / LIST_WAVES) + 63) & ~63;   // a wave cannot stage more than it scans
     int* stage = a.jstage + ((size_t)t * LIST_WAVES + wv) * share;
     const float cfs[3] = {(float)c.dscale[0], (float)c.dscale[1], (float)c.dscale[2]};
     const float hfl[3] = {(float)hf[0] * 1.00001f + 1e-6f, (float)hf[1] * 1.00001f + 1e-6f, (float)hf[2] * 1.00001f + 1e-6f};
     const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f;
+    const float rsph = ((float)s_rad * 1.00001f + 1e-6f + sqrtf(rl2));
+    const float rs2 = a.no_sphere ? __builtin_inff() : rsph * rsph * 1.0001f;
     const int j_end = min(a.n, (wv + 1) * share);
     int wcount = 0;
     for (int base = wv * share; base < j_end; base += 64 * LIST_PREFETCH) {
@@ -141,14 +182,16 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
         for (int u = 0; u < LIST_PREFETCH; u++) {
             const int j = base + u * 64 + lane;
             const ufix pj[3] = {px[u], py[u], pz[u]};
-            float d2 = 0.0f;
+            float d2 = 0.0f, o2 = 0.0f;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                float d = fabsf((float)(sfix)(pj[k] - cf[k]) * cfs[k]) - hfl[k];
+                const float o = (float)(sfix)(pj[k] - cf[k]) * cfs[k];
+                o2 = fmaf(o, o, o2);
+                float d = fabsf(o) - hfl[k];
                 d = fmaxf(d, 0.0f);
                 d2 = fmaf(d, d, d2);
             }
-            bool pass = j < j_end && d2 < rl2 && !(fl[u] & FLAG_ALCH);
+            bool pass = j < j_end && d2 < rl2 && o2 < rs2 && !(fl[u] & FLAG_ALCH);
             if (alch_tile && pass) {
                 // the alchemical kernel spends a thread on every (j, alchemical atom) pair of this list, so the list is
                 // made exact: j stays only if it is within cutoff+skin of at least one alchemical atom (the bounding
@@ -168,7 +211,9 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
         }
     }
     if (lane == 0) s_wcount[wv] = wcount;
+    NB_STAMP(t == 0 && tid == 0, 2);
     __syncthreads();
+    NB_STAMP(t == 0 && tid == 0, 3);
     {
         int off = 0;
         for (int w = 0; w < wv; w++) off += s_wcount[w];
@@ -180,7 +225,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     int count = s_total;
     if (t == 0 && tid == 0) a.flags->builds++;
     if (count > a.jcap) { if (tid == 0) a.flags->list_overflow = 1; count = a.jcap; }
-    else if (count > a.jcap - a.jcap / 7 && tid == 0) a.flags->resort_hint = 1;
+    else if (count > a.hint_count && tid == 0) a.flags->resort_hint = 1;
     if (tid == 0) a.jcount[t] = count;
     const int nb = (count + 63) >> 6;
     const int nbmax = a.jcap >> 6;
@@ -198,10 +243,13 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
         return;
     }
 
+    NB_STAMP(t == 0 && tid == 0, 4);
+    if (a.alist) return;   // per-atom-list mode: exclusions are dropped when build_atom_lists_body forms the atoms' lists -- no bitmask tiles
+    __shared__ int s_jl[LIST_LDS];
+
     // ---- exclusion bitmasks: one 64x64 bit tile per (i-tile, j-batch) that holds an excluded pair.
     // The binary searches run on a copy of the list in LDS (a dozen dependent steps each: ~100 ns instead of a memory
     // round trip per step) and the positions found in the first pass are kept for the second.
-    __shared__ int s_jl[LIST_LDS];
     const bool in_lds = count <= LIST_LDS;
     if (in_lds) for (int k = tid; k < count; k += LIST_THREADS) s_jl[k] = jl[k];
     const int ia = a.tile_atoms[t * 64 + lane];
@@ -253,6 +301,115 @@ __global__ void __launch_bounds__(LIST_THREADS) k_build_lists(ListArgs a, NbCons
     build_lists_body<R>(a, c, img, force);
 }
 
+// ---- per-atom Verlet lists (second kernel of a rebuild, per-atom-list mode): one block per i-TILE; wave wv serves the
+// i-slots wv, wv+16, wv+32, wv+48.  The list of the tile's group is staged in LDS (positions as floats relative to the
+// tile's first atom; sorted index + mobile bit) and walked once per wave, every lane testing one candidate against the wave's
+// four i-atoms (wave-uniform); hits are compacted in list order (ballot + prefix count), so an atom's list is ascending in
+// the local index and consecutive lanes of the force kernel read neighbouring LDS addresses.  Exclusions: each i-atom's
+// excluded partners are looked up in the list once (binary search) and set bits in an LDS bitmap [slot][chunk]; the running
+// counts live in vector registers (v_bcnt / v_mbcnt) -- a CU has ONE scalar ALU for its 16 waves, and the first version of
+// this loop, which kept them in scalar registers, was bound by it.
+// The pair kernel tests r < cutoff itself; what must hold here is "within cutoff+skin now" (float, with margin).
+template <typename R>
+__device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force) {
+    using sfix = typename Img<R>::sfix;
+    using ufix = typename Img<R>::ufix;
+    if (!force && a.flags->list_gen == a.flags->req_gen && !(a.batch_req && *a.batch_req)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t = blockIdx.x;
+    if (t >= a.n_itiles) return;
+    const int l = t / a.S;
+    const int count = a.jcount[l];
+    const int* jl = a.jlist + (size_t)l * a.jcap;
+    const int nch = (count + 63) >> 6;
+    extern __shared__ __align__(16) unsigned char list_smem[];
+    float* sx = reinterpret_cast<float*>(list_smem); float* sy = sx + a.jcap; float* sz = sy + a.jcap;
+    int* s_jm = reinterpret_cast<int*>(sz + a.jcap);                              // sorted index | mobile << 30
+    unsigned long long* s_bm = reinterpret_cast<unsigned long long*>(s_jm + a.jcap);   // [64][jcap / 64] excluded candidates of each slot
+    const int nchmax = a.jcap >> 6;
+    const float cfs[3] = {(float)c.dscale[0], (float)c.dscale[1], (float)c.dscale[2]};
+    const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f;
+    NB_STAMP(t == 0 && tid == 0, 5);
+    const int i0 = a.tile_atoms[t * 64];
+    const ufix ref[3] = {img[i0].x, img[i0].y, img[i0].z};
+    for (int k = tid; k < count; k += LIST_THREADS) {
+        const int js = jl[k];
+        const ufix qx = img[js].x, qy = img[js].y, qz = img[js].z; const unsigned fl = img[js].flags;
+        s_jm[k] = js | ((fl & FLAG_MOBILE) ? 0x40000000 : 0);
+        sx[k] = (float)(sfix)(qx - ref[0]) * cfs[0]; sy[k] = (float)(sfix)(qy - ref[1]) * cfs[1]; sz[k] = (float)(sfix)(qz - ref[2]) * cfs[2];
+    }
+    for (int k = tid; k < 64 * nchmax; k += LIST_THREADS) s_bm[k] = 0ull;
+    __syncthreads();
+    NB_STAMP(t == 0 && tid == 0, 6);
+    int ia4[4]; float pi4[4][3], rl4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int slot = wv + LIST_WAVES * u;
+        ia4[u] = __builtin_amdgcn_readfirstlane(a.tile_atoms[t * 64 + slot]);
+        const int iq = ia4[u] >= 0 ? ia4[u] : 0;
+        pi4[u][0] = (float)(sfix)(img[iq].x - ref[0]) * cfs[0]; pi4[u][1] = (float)(sfix)(img[iq].y - ref[1]) * cfs[1]; pi4[u][2] = (float)(sfix)(img[iq].z - ref[2]) * cfs[2];
+        rl4[u] = ia4[u] >= 0 ? rl2 : -1.0f;   // an empty slot passes nobody
+        const int e0 = ia4[u] >= 0 ? a.ex_start[iq] : 0, e1 = ia4[u] >= 0 ? a.ex_start[iq + 1] : 0;
+        for (int q = lane; q < e1 - e0; q += 64) {
+            const int p = a.ex_idx[e0 + q];
+            int lo = 0, hi = count;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((s_jm[mid] & 0x3FFFFFFF) < p) lo = mid + 1; else hi = mid; }
+            if (lo < count && (s_jm[lo] & 0x3FFFFFFF) == p) atomicOr(&s_bm[slot * nchmax + (lo >> 6)], 1ull << (lo & 63));
+        }
+    }
+    __syncthreads();
+    NB_STAMP(t == 0 && tid == 0, 7);
+    int cntv[4] = {0, 0, 0, 0};
+    unsigned short* out4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) out4[u] = a.alist + ((size_t)t * 64 + wv + LIST_WAVES * u) * a.acap;
+    const float INF = __builtin_inff();
+    const int acap1 = a.acap - 1;
+    // both positions are relative to the tile's first atom (each one a minimum image OF THAT ATOM): their difference is the
+    // minimum image of the pair only while the list's extent stays below half a box edge, hence the explicit wrap below
+    const float boxf[3] = {(float)(c.dscale[0] * 4294967296.0 * (sizeof(ufix) == 8 ? 4294967296.0 : 1.0)), (float)(c.dscale[1] * 4294967296.0 * (sizeof(ufix) == 8 ? 4294967296.0 : 1.0)), (float)(c.dscale[2] * 4294967296.0 * (sizeof(ufix) == 8 ? 4294967296.0 : 1.0))};
+    const float iboxf[3] = {1.0f / boxf[0], 1.0f / boxf[1], 1.0f / boxf[2]};
+    for (int ch = 0; ch < nch; ch++) {
+        const int k = ch * 64 + lane, kk = min(k, count - 1);
+        const float x = sx[kk], y = sy[kk], z = sz[kk];
+        const unsigned short ent = (unsigned short)(k | ((s_jm[kk] & 0x40000000) ? 0x8000 : 0));
+        const float kinf = k < count ? 0.0f : INF;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned long long bm = s_bm[(wv + LIST_WAVES * u) * nchmax + ch];   // same address in every lane: broadcast
+            float dx = x - pi4[u][0], dy = y - pi4[u][1], dz = z - pi4[u][2];
+            dx -= boxf[0] * rintf(dx * iboxf[0]); dy -= boxf[1] * rintf(dy * iboxf[1]); dz -= boxf[2] * rintf(dz * iboxf[2]);
+            float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + kinf;
+            d2 = ((bm >> lane) & 1ull) ? INF : d2;
+            const bool pass = d2 < rl4[u];
+            const unsigned long long bal = __ballot(pass);
+            const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
+            const int pos = cntv[u] + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
+            // running count on the vector ALU.  gfx950 needs two wait states between a VALU write of an SGPR / VCC (the
+            // compare behind the ballot) and a VALU read of it as an operand; the compiler inserts them for its own
+            // instructions but not around inline assembly (without the s_nop the counts came out stale)
+            int c2;
+            asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c2) : "s"(blo), "s"(bhi), "v"(cntv[u]));
+            cntv[u] = c2;
+            if (pass) out4[u][min(pos, acap1)] = ent;   // on overflow (flagged below) the surplus lands on the last entry
+        }
+    }
+    NB_STAMP(t == 0 && tid == 0, 8);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (lane == 0) {
+            a.acount[t * 64 + wv + LIST_WAVES * u] = min(cntv[u], a.acap);
+            if (cntv[u] > a.acap) a.flags->list_overflow = 1;
+            else if (cntv[u] > a.acap - a.acap / 8) a.flags->resort_hint = 1;   // (a re-sort re-derives the capacities)
+        }
+    }
+}
+
+template <typename R>
+__global__ void __launch_bounds__(LIST_THREADS) k_build_atom_lists(ListArgs a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, int force) {
+    build_atom_lists_body<R>(a, c, img, force);
+}
+
 template <typename R> struct NbArgs {
     int n_itiles, jcap, n_islots;
     int seg_len;     // CH: j-atoms per wave segment (8..64, divides 64)
@@ -267,6 +424,8 @@ template <typename R> struct NbArgs {
     double* epart;   // [n_itiles*npart][2] (ENERGY only)
     DevFlags* flags;
     int* batch_req;  // see ListArgs; cleared here (every list block of this pass has read it by now)
+    const unsigned short* alist; const int* acount; int acap;   // per-atom lists (ListArgs), nonbonded_atom_body only
+    int S, n_lists;                                                // tiles per j-list, number of lists (ListArgs)
 };
 
 // One block = WPB waves working on the SAME i-tile; wave w of the tile walks the j-list segments
@@ -430,6 +589,123 @@ __device__ __forceinline__ void nonbonded_sub_body(const NbArgs<float>& a, const
 template <bool ENERGY, int IW>
 __global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<float> c, const AtomF* __restrict__ img) {
     nonbonded_sub_body<ENERGY, IW>(a, c, img, blockIdx.x);
+}
+
+// ---- per-atom Verlet lists + LDS-resident tile image (mixed precision; the kernel of the replica-batched benchmark path).
+// The sub-tile kernel above tests every i-atom of an 8-atom group against every atom near the 64-atom TILE: at the
+// benchmark's density one tested pair in nine is inside the cutoff, and 46 % of its instructions are range checks.  Here
+// the tile's j-list is staged into LDS ONCE per workgroup ({x,y,z,q} 16 B + {sigma/2, 2 sqrt(eps)} 8 B per atom), and a wave
+// walks the exact neighbour list of ONE i-atom at a time (list built with the tile lists, skin as margin), lane = one
+// neighbour, gathered from LDS by its 15-bit local index: 7 tested pairs in 10 are inside the cutoff, exclusions were
+// removed when the list was built, and the i-atom lives in scalar registers.  Per-lane fp32 partial sums are folded into fp64
+// every 4 iterations; the 64 lanes are then summed in fp64 in a fixed order (bitwise reproducible; no atomics).
+#define NB_ATOM_U 12   // list entries per lane requested together (768 neighbours per round)
+template <bool ENERGY>
+__device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, const NbConst<float>& c, const AtomF* __restrict__ img, const int t) {   // t: list (group of S i-tiles)
+    struct P4 { uint32_t x, y, z; float q; };
+    struct P2 { float hs, se; };
+    extern __shared__ __align__(16) unsigned char nb_smem[];
+    P4* lp = reinterpret_cast<P4*>(nb_smem);
+    P2* lq = reinterpret_cast<P2*>(nb_smem + (size_t)a.jcap * sizeof(P4));
+    __shared__ double s_e[16][2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    if (t == 0 && tid == 0) { a.flags->list_gen = a.flags->req_gen; if (a.batch_req) *a.batch_req = 0; }  // lists are current for this pass
+    if (t >= a.n_lists) return;
+    const int count = a.jcount[t];
+    const int* jlst = a.jlist + (size_t)t * a.jcap;
+    const int slot0 = t * a.S * 64, nslot = min(a.S, a.n_itiles - t * a.S) * 64;   // the i-slots this list serves
+    // An atom's whole list is requested up front (NB_ATOM_U wave-loads of 64 entries, all in flight together) and ONE ATOM
+    // AHEAD: the next atom's entries travel while the current atom is computed, the first atom's while the image is staged.
+    // (With one load per iteration, or with all waves requesting and waiting in step, the list stream ran at HBM latency.)
+    unsigned entn[NB_ATOM_U]; int cntn = 0, ian = -1;
+    auto request = [&](int s) {
+        ian = -1; cntn = 0;
+        if (s < nslot) {
+            ian = __builtin_amdgcn_readfirstlane(a.tile_atoms[slot0 + s]);
+            if (ian >= 0) {
+                cntn = __builtin_amdgcn_readfirstlane(a.acount[slot0 + s]);
+                const unsigned short* lst = a.alist + (size_t)(slot0 + s) * a.acap;
+#pragma unroll
+                for (int u = 0; u < NB_ATOM_U; u++) { const int q = u * 64 + lane; entn[u] = q < cntn ? (unsigned)lst[q] : 0u; }
+            }
+        }
+    };
+    NB_STAMP(t == 0 && tid == 0, 16);
+    request(wv);
+    NB_STAMP(t == 0 && tid == 0, 17);
+    for (int k = tid; k < count; k += blockDim.x) {
+        const AtomF aj = img[jlst[k]];
+        P4 v4; v4.x = aj.x; v4.y = aj.y; v4.z = aj.z; v4.q = aj.q; lp[k] = v4;
+        P2 v2; v2.hs = aj.hs; v2.se = aj.se; lq[k] = v2;
+    }
+    NB_STAMP(t == 0 && tid == 0, 18);
+    __syncthreads();
+    NB_STAMP(t == 0 && tid == 0, 19);
+    double elj = 0.0, ecl = 0.0;
+    for (int s = wv; s < nslot; s += nw) {
+        const int islot = slot0 + s;
+        const int ia = ian, cnt = cntn;
+        unsigned ent[NB_ATOM_U];
+#pragma unroll
+        for (int u = 0; u < NB_ATOM_U; u++) ent[u] = entn[u];
+        request(s + nw);
+        if (ia < 0) continue;   // wave-uniform; empty slots are never read back (FinRec.atom < 0)
+        const uint32_t ix = __builtin_amdgcn_readfirstlane(img[ia].x), iy = __builtin_amdgcn_readfirstlane(img[ia].y), iz = __builtin_amdgcn_readfirstlane(img[ia].z);
+        const float iq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].q)));
+        const float ihs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].hs)));
+        const float ise = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].se)));
+        const unsigned short* lst = a.alist + (size_t)islot * a.acap;
+        double fx = 0.0, fy = 0.0, fz = 0.0;
+        float bx = 0.0f, by = 0.0f, bz = 0.0f;
+        auto pair = [&](unsigned e, bool have) {
+            const unsigned idx = have ? (e & 0x7FFFu) : 0u;
+            const P4 bj = lp[idx];
+            const P2 bp = lq[idx];
+            const float dx = (float)(int32_t)(ix - bj.x) * c.scale[0];
+            const float dy = (float)(int32_t)(iy - bj.y) * c.scale[1];
+            const float dz = (float)(int32_t)(iz - bj.z) * c.scale[2];
+            const float r2 = dx * dx + dy * dy + dz * dz;
+            const bool in = have && (r2 < c.rc2);
+            float e1, e2;
+            float fs = pair_regular<float>(r2, iq * bj.q, ihs + bp.hs, ise * bp.se, c.alpha, &e1, &e2);
+            fs = in ? fs : 0.0f;   // select, not a branch: ~70 % of the lanes are in range, the body would run anyway
+            bx = fmaf(fs, dx, bx); by = fmaf(fs, dy, by); bz = fmaf(fs, dz, bz);
+            if (ENERGY) {
+                if (in) { const double wgt = (e & 0x8000u) ? 0.5 : 1.0; elj += wgt * (double)e1; ecl += wgt * (double)e2; }
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < NB_ATOM_U; u++) {
+            if (u * 64 >= cnt) break;   // wave-uniform
+            pair(ent[u], u * 64 + lane < cnt);
+            if ((u & 3) == 3) { fx += (double)bx; fy += (double)by; fz += (double)bz; bx = by = bz = 0.0f; }
+        }
+        for (int base = 64 * NB_ATOM_U; base < cnt; base += 64) {   // lists longer than the prefetch window (dense regions)
+            const bool have = base + lane < cnt;
+            pair(have ? (unsigned)lst[base + lane] : 0u, have);
+            fx += (double)bx; fy += (double)by; fz += (double)bz; bx = by = bz = 0.0f;
+        }
+        NB_STAMP(t == 0 && tid == 0, 20 + min(2 * (s / nw), 6));
+        fx += (double)bx; fy += (double)by; fz += (double)bz;
+        fx = wave_sum_dpp(fx); fy = wave_sum_dpp(fy); fz = wave_sum_dpp(fz);
+        if (lane == 0) { a.fpart[islot] = fx; a.fpart[a.n_islots + islot] = fy; a.fpart[2 * a.n_islots + islot] = fz; }
+        NB_STAMP(t == 0 && tid == 0, 21 + min(2 * (s / nw), 6));
+    }
+    if (ENERGY) {
+        elj = wave_sum(elj); ecl = wave_sum(ecl);
+        if (lane == 0) { s_e[wv][0] = elj; s_e[wv][1] = ecl; }
+        __syncthreads();
+        if (tid == 0) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int w = 0; w < nw; w++) { s0 += s_e[w][0]; s1 += s_e[w][1]; }
+            a.epart[2 * t] = s0; a.epart[2 * t + 1] = s1;
+        }
+    }
+}
+
+template <bool ENERGY>
+__global__ void __launch_bounds__(1024) k_nonbonded_atom(NbArgs<float> a, NbConst<float> c, const AtomF* __restrict__ img) {
+    nonbonded_atom_body<ENERGY>(a, c, img, blockIdx.x);
 }
 
 // One-off: LJ + Coulomb energy among FROZEN environment atoms (constant while they and the box stay put).

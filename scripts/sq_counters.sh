@@ -4,7 +4,7 @@ tag=$1; R=${2:-256}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/sq_$tag; rm -rf $out; mkdir -p $out
 i=0
-for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD"; do
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD" "SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/g$i -- python3 scripts/batch_scaling.py --nsteps 60 $R > $out/g$i.log 2>&1
 done
@@ -26,3 +26,5 @@ for n, cs in sorted(agg.items()):
         vals = vals[len(vals) // 2:]
         print("   %-22s %14.0f  (mean of %d launches)" % (c, sum(vals) / len(vals), len(vals)))
 PY
+
+rm -rf gpurun_out/sq_$tag/g*/
