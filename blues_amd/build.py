@@ -38,7 +38,9 @@ def build_engine(force=False, verbose=False):
             if not force and not is_stale():
                 return LIB_PATH
             tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-            cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+            # -fno-slp-vectorize: the SLP pass packs pairs of fp32 operations into v_pk_* instructions, which issue at half rate on
+            # gfx950 (scripts/valu_issue.hip) and cost extra moves: the pair kernel runs 10 % faster without it (profiles/README.md)
+            cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
                    "-o", tmp, os.path.join(CSRC, "blues_engine.hip")]
             if verbose:
                 print(" ".join(cmd))

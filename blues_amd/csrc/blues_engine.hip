@@ -721,7 +721,7 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
     if (batch_lead(h)) {
-        hipLaunchKernelGGL(k_build_lists_b<R>, dim3(h->n_tiles + 2, h->batch->R()), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), force);
+        hipLaunchKernelGGL(k_build_lists_b<R>, dim3((h->n_tiles + 2) * h->batch->R()), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->R(), h->n_tiles + 2, force);
     } else if (!batch_dry(h)) {
         hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 2), dim3(LIST_THREADS), 0, h->cur, a, make_nbconst<R>(h), img, force);
     }
@@ -738,7 +738,7 @@ template <typename R> static int launch_lists(BluesEngine* h, int force) {
                 if (e != hipSuccess) E_FAIL(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
                 lds_set[lead] = lds;
             }
-            if (lead) hipLaunchKernelGGL(k_build_atom_lists_b<R>, dim3(h->n_itiles, h->batch->R()), dim3(LIST_THREADS), lds, h->cur, batch_reps_nb<R>(h->batch), force);
+            if (lead) hipLaunchKernelGGL(k_build_atom_lists_b<R>, dim3(h->n_itiles * h->batch->R()), dim3(LIST_THREADS), lds, h->cur, batch_reps_nb<R>(h->batch), h->batch->R(), h->n_itiles, force);
             else hipLaunchKernelGGL(k_build_atom_lists<R>, dim3(h->n_itiles), dim3(LIST_THREADS), lds, h->cur, a, make_nbconst<R>(h), img, force);
         }
         h->st_launches++;

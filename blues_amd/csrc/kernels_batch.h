@@ -57,20 +57,50 @@ __device__ __forceinline__ void apply_dyn(IntArgs& A, const IntDyn& d, unsigned 
     A.ctrl = nullptr;
 }
 
+// Active-first block map of the rebuild kernels.  In a large batch a few members rebuild their lists in any given round; with
+// (block, replica) grids their blocks land wherever the replica index puts them and pile up on the same CUs (one 1024-thread
+// block with its LDS fits a CU at a time) while most CUs only retire blocks that exit at once -- the launch then lasts two
+// or three block times.  Here the grid is 1-D and block b serves block (b % bpc) of the (b / bpc)-th member THAT REBUILDS:
+// the working blocks come first and spread evenly over the chip.  Returns false for a block with nothing to do.
 template <typename R>
-__global__ void __launch_bounds__(LIST_THREADS) k_build_lists_b(const RepNb<R>* __restrict__ reps, int force) {
-    const RepNb<R>& rp = reps[blockIdx.y];
-    if (!rp.active) return;
-    const ListArgs a = rp.L; const NbConst<R> c = rp.c;
-    build_lists_body<R>(a, c, rp.img, force);
+__device__ __forceinline__ bool rebuild_slot(const RepNb<R>* __restrict__ reps, int nrep, int force, int bpc, int& rep, int& bx) {
+    const int b = blockIdx.x, want = b / bpc; bx = b - want * bpc;
+    if (nrep > LIST_THREADS) { rep = want; return want < nrep && reps[want].active; }   // (one thread per member below)
+    __shared__ int s_cnt[LIST_WAVES]; __shared__ int s_pick;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    bool act = false;
+    if (tid < nrep && reps[tid].active) {
+        const ListArgs& L = reps[tid].L;
+        act = force || L.flags->list_gen != L.flags->req_gen || (L.batch_req && *L.batch_req);
+    }
+    const unsigned long long bal = __ballot(act);
+    if (lane == 0) s_cnt[wv] = __popcll(bal);
+    if (tid == 0) s_pick = -1;
+    __syncthreads();
+    int rank = __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wv; w++) rank += s_cnt[w];
+    if (act && rank == want) s_pick = tid;
+    __syncthreads();
+    rep = s_pick;
+    return rep >= 0;
 }
 
 template <typename R>
-__global__ void __launch_bounds__(LIST_THREADS) k_build_atom_lists_b(const RepNb<R>* __restrict__ reps, int force) {
-    const RepNb<R>& rp = reps[blockIdx.y];
-    if (!rp.active) return;
+__global__ void __launch_bounds__(LIST_THREADS) k_build_lists_b(const RepNb<R>* __restrict__ reps, int nrep, int bpc, int force) {
+    int rep, bx;
+    if (!rebuild_slot<R>(reps, nrep, force, bpc, rep, bx)) return;
+    const RepNb<R>& rp = reps[rep];
     const ListArgs a = rp.L; const NbConst<R> c = rp.c;
-    build_atom_lists_body<R>(a, c, rp.img, force);
+    build_lists_body<R>(a, c, rp.img, force, bx, bpc);
+}
+
+template <typename R>
+__global__ void __launch_bounds__(LIST_THREADS) k_build_atom_lists_b(const RepNb<R>* __restrict__ reps, int nrep, int bpc, int force) {
+    int rep, bx;
+    if (!rebuild_slot<R>(reps, nrep, force, bpc, rep, bx)) return;
+    const RepNb<R>& rp = reps[rep];
+    const ListArgs a = rp.L; const NbConst<R> c = rp.c;
+    build_atom_lists_body<R>(a, c, rp.img, force, bx);
 }
 
 template <typename R, bool ENERGY, int WPB>

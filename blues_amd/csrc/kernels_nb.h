@@ -80,15 +80,14 @@ struct ListArgs {
 #define LIST_LDS 8192      // j-list entries mirrored in LDS for the exclusion searches (longer lists are searched in HBM)
 
 template <typename R>
-__device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force) {
+__device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force, const int t, const int nblocks) {
     using sfix = typename Img<R>::sfix;
     using ufix = typename Img<R>::ufix;
     if (!force && a.flags->list_gen == a.flags->req_gen && !(a.batch_req && *a.batch_req)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int t = blockIdx.x;
     // ---- shared bookkeeping: remember where the lists were built, clear alchemical env forces
     if (t >= a.n_tiles) {  // helper blocks: bookkeeping that must not sit on a tile block's critical path
-        const int hb = t - a.n_tiles, nh = gridDim.x - a.n_tiles;
+        const int hb = t - a.n_tiles, nh = nblocks - a.n_tiles;
         for (int i = hb * LIST_THREADS + tid; i < a.n; i += nh * LIST_THREADS) {
             a.xbuild[0][i] = a.x[0][i]; a.xbuild[1][i] = a.x[1][i]; a.xbuild[2][i] = a.x[2][i];
         }
@@ -298,7 +297,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
 
 template <typename R>
 __global__ void __launch_bounds__(LIST_THREADS) k_build_lists(ListArgs a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, int force) {
-    build_lists_body<R>(a, c, img, force);
+    build_lists_body<R>(a, c, img, force, blockIdx.x, gridDim.x);
 }
 
 // ---- per-atom Verlet lists (second kernel of a rebuild, per-atom-list mode): one block per i-TILE; wave wv serves the
@@ -311,12 +310,11 @@ __global__ void __launch_bounds__(LIST_THREADS) k_build_lists(ListArgs a, NbCons
 // this loop, which kept them in scalar registers, was bound by it.
 // The pair kernel tests r < cutoff itself; what must hold here is "within cutoff+skin now" (float, with margin).
 template <typename R>
-__device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force) {
+__device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force, const int t) {
     using sfix = typename Img<R>::sfix;
     using ufix = typename Img<R>::ufix;
     if (!force && a.flags->list_gen == a.flags->req_gen && !(a.batch_req && *a.batch_req)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int t = blockIdx.x;
     if (t >= a.n_itiles) return;
     const int l = t / a.S;
     const int count = a.jcount[l];
@@ -407,7 +405,7 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
 
 template <typename R>
 __global__ void __launch_bounds__(LIST_THREADS) k_build_atom_lists(ListArgs a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, int force) {
-    build_atom_lists_body<R>(a, c, img, force);
+    build_atom_lists_body<R>(a, c, img, force, blockIdx.x);
 }
 
 template <typename R> struct NbArgs {

@@ -364,7 +364,9 @@ def test_full_blues_iteration_on_gpu(tol_box):
     # move._error and carries on (reference blues/simulation.py:1088-1094); either way the move must end up rejected
     b.run()
     assert b.accept + b.reject == 2 and md.currentStep == 20 and b.accept == 0
-    assert abs(b.last["correction"]) < 1e-5   # U_md == U_alch(lambda=1) in the direct-space-only model
+    # U_md == U_alch(lambda=1) in the direct-space-only model -- to the rounding of the mixed-precision pair sums: the two contexts
+    # evaluate the ligand's pairs on different kernels (fp64 alchemical kernel / fp32 pair kernel), 1e-9 of the 12,000 kJ/mol total
+    assert abs(b.last["correction"]) < 1e-4
     x1 = md.context.getState(getPositions=True).getPositions(asNumpy=True)._value
     assert np.not_equal(x0, x1).all()          # reference blues/tests/test_simulation.py: positions change after _stepMD
 
