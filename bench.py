@@ -133,15 +133,46 @@ def cpu_baseline(system, vel, nsteps_sample):
             "sample": "%d NCMC steps of the same S23k switch (3 full fp64 energy/force evaluations per step), %.1f s" % (nsteps_sample, dt)}
 
 
-def pmc_traffic(workload, R):
-    """HBM-side bytes per launch of the nonbonded kernel from separate rocprofv3 --pmc passes (profiles/README.md)."""
+def kernel_source_sha():
+    """Identifies the build of the nonbonded kernel the PMC evidence was taken on (profiles/*pmc*.json carry the same hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels_nb.h", "device_common.h", "kernels_batch.h"):
+        with open(os.path.join(ROOT, "blues_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_evidence(workload, R):
+    """Counters of the batched nonbonded kernel from separate rocprofv3 --pmc passes (scripts/pmc_nb.sh -> profiles/).  They
+    cannot be collected inside this run; they are only reported when they were taken on THIS build of the kernel (source
+    hash) and this workload / batch size -- otherwise null, never a stale number."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            pmc = json.load(fh)
-        key = "%s_R%d" % (workload, R) if R > 1 else workload
-        return pmc[key]["traffic_bytes_per_launch"] if key in pmc else None
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_nonbonded.json")) as fh:
+            table = json.load(fh)
+        e = table.get("%s_R%d" % (workload, R))
+        if e and e.get("source_sha") == kernel_source_sha():
+            return e
     except Exception:
-        return None
+        pass
+    return None
+
+
+def in_range_counts(system):
+    """Host-side census for the byte counts SURVEY.md 8(d) asks for beside the nominal one: environment atoms within the cutoff
+    of some mobile non-alchemical atom (what a mobile-only pass must read), and the in-range pairs of those atoms."""
+    from scipy.spatial import cKDTree
+    x = np.mod(system.positions, system.box)
+    alch = np.zeros(system.n_atoms, bool); alch[np.asarray(system.alchemical_atoms)] = True
+    i_atoms = np.nonzero((system.mass > 0) & ~alch)[0]
+    others = np.nonzero(~alch)[0]
+    tree = cKDTree(x[others], boxsize=system.box)
+    nb = tree.query_ball_point(x[i_atoms], system.cutoff)
+    touched = set()
+    pairs = 0
+    for l in nb:
+        touched.update(l); pairs += len(l) - 1    # (minus the atom itself; bonded exclusions are a handful per atom)
+    return len(i_atoms), len(touched), pairs
 
 
 def _free_port():
@@ -273,8 +304,9 @@ def main():
         k1_single = e1.time_nonbonded(50)
         a1 = ALGO_BYTES_PER_ATOM * system.n_atoms / (k1_single * 1e-6) / 1e9
         single = {"value": nsteps * DT_PS * 1e-3 / (dt1 / 86400.0), "unit": "ns/day", "ms_per_switch": 1e3 * dt1,
-                  "roofline": {"bound": "hbm", "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic(args.workload, 1), "usec_per_launch": k1_single}}
+                  "roofline": {"bound": "latency", "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
+                               "traffic": None, "usec_per_launch": k1_single,
+                               "note": "one chain keeps a few of the 256 CUs busy: every kernel of its step is latency-bound (DESIGN.md section 4)"}}
 
     G = max(1, min(args.groups, R))
     bounds = [(g * R) // G for g in range(G + 1)]
@@ -338,18 +370,50 @@ def main():
         algo = ALGO_BYTES_PER_ATOM * n_atoms * R_launch
         achieved = algo / (k1_us * 1e-6) / 1e9
         last = np.asarray(recs[-1])
+        # ---- roofline block of the dominant kernel.  north_star prices it against HBM with 36 B per atom per force evaluation
+        # over ALL atoms; the kernel computes forces for the mobile atoms only, so the byte count of what such a pass has to touch
+        # is given beside it, and so is the limit that actually binds (VALU issue), each from counters taken on this build.
+        n_i, n_touched, n_pairs = in_range_counts(system)
+        mob_bytes = (24.0 * n_touched + 12.0 * n_i) * R_launch
+        ev = pmc_evidence(args.workload, R_launch)
+        est = engs[0].stats()
+        secs = k1_us * 1e-6
+        roofline = {"bound": "valu" if ev else "valu (counters not taken on this build: see profiles/README.md)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "kernel": "%s (direct-space LJ + erfc Coulomb; one launch = %d chains, timed alone with HIP events)" % ({0: "k_nonbonded_b", 1: "k_nonbonded_sub_b", 2: "k_nonbonded_atom_b"}[est["nonbonded_kernel"]], R_launch),
+                    "usec_per_launch": k1_us, "algorithmic_bytes_per_launch": algo,
+                    "algorithmic_bytes_definition": "36 B x all %d atoms x %d chains (SURVEY.md 8d: nominal, defined on all atoms)" % (n_atoms, R_launch),
+                    "traffic": ev["traffic_bytes_per_launch"] if ev and "traffic_bytes_per_launch" in ev else None,
+                    "mobile_only": {"algorithmic_bytes": mob_bytes, "achieved": mob_bytes / secs / 1e9, "frac": mob_bytes / secs / 1e9 / HBM_PEAK_GBS,
+                                    "definition": "24 B x %d environment atoms within the cutoff of a mobile atom + 12 B x %d mobile atoms, per chain" % (n_touched, n_i)},
+                    "pairs": {"in_range_per_launch": n_pairs * R_launch, "listed_per_launch": est["atom_list_entries"] * R_launch,
+                              "lane_efficiency": n_pairs / max(1.0, 64.0 * est["atom_list_iterations"]) if est["atom_list_iterations"] else None,
+                              "note": "lane efficiency = pairs inside the cutoff / (wave iterations x 64 lanes) of the per-atom lists (chain 0, at its last rebuild)"}}
+        if ev:
+            c = ev["counters_per_launch"]
+            insts = c.get("SQ_INSTS_VALU")
+            if insts:
+                peak = 1024 * 2.4e9 / 2.0    # SIMDs x clock / 2 cycles per wave64 instruction (scripts/valu_issue.hip: 1.03 T/s reached with plain v_fma_f32)
+                v = {"insts_per_launch": insts, "issue_rate": insts / secs, "peak": peak, "frac": insts / secs / peak, "unit": "wave-instructions/s"}
+                if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+                    # quad-cycles x 4, summed over the 1024 SIMDs, against the busy cycles of the launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+                    v["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+                if c.get("SQ_INSTS_VALU_TRANS_F32"):
+                    v["transcendental_insts_per_launch"] = c["SQ_INSTS_VALU_TRANS_F32"]
+                roofline["valu"] = v
+            roofline["pmc_source"] = {"file": "profiles/r02_pmc_nonbonded.json", "source_sha": ev["source_sha"], "kernel": ev["kernel"]}
         out = {
             "metric": "NCMC ns/day (23k-atom toluene box, 1000-step switch, RandomLigandRotationMove), aggregate over independent chains",
             "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 pair math / f64 accumulation, f64 alchemical+integrator", "data": "synthetic",
+            "data_note": "every chain starts every switch from the same coordinates and velocities (its Philox stream differs): rebuild statistics are those of the first 4 ps from one geometry",
+            "nonbonded_method": "PME direct space" if not getattr(system, "reciprocal", False) else "PME direct + reciprocal space",
             "config": {"workload": "S23k %s: %d atoms, %d mobile, %d alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in %d replica batch(es)"
                        % (args.workload, n_atoms, int((system.mass > 0).sum()), len(system.alchemical_atoms), nsteps, R, G),
                        "replicas_per_gpu": R, "batches_per_gpu": G, "host_workers": args.workers,
                        "parallelism": "%d replica batch(es) x %d chains per gpu, %d gpu(s)" % (G, R_launch, world)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, R_launch), "kernel": "k_nonbonded*_b (direct-space LJ + erfc Coulomb), one launch = %d chains (timed alone)" % R_launch,
-                         "usec_per_launch": k1_us, "algorithmic_bytes_per_launch": algo},
+            "roofline": roofline,
             "single_replica": single,
             "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup,
                        "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,

@@ -13,7 +13,7 @@ ABI_VERSION = 1
 NB_NOCUTOFF = 0
 NB_PME_DIRECT = 1
 N_ENERGY_TERMS = 8
-N_STATS = 12
+N_STATS = 16
 ENERGY_TERM_NAMES = ("bonds", "angles", "torsions", "nonbonded", "exceptions", "alch_sterics",
                      "alch_electrostatics", "restraint")
 

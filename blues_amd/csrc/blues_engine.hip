@@ -2089,6 +2089,11 @@ int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
         fprintf(stderr, "[lists] S=%d n_lists=%d jcap=%d acap=%d jcount:", h->S, h->n_lists, h->jcap, h->acap); for (int c : jc2) fprintf(stderr, " %d", c);
         fprintf(stderr, "\n[lists] acount:"); for (size_t i = 0; i < ac.size(); i++) fprintf(stderr, " %d", ac[i]); fprintf(stderr, "\n");
     }
+    stats[12] = h->k1_mode; stats[13] = h->S;
+    if (h->k1_mode == 2 && h->d_acount.p && h->sorted_ok) {
+        std::vector<int> ac; hipSetDevice(h->device); hipStreamSynchronize(h->stream);
+        try { h->d_acount.download(ac); for (int c : ac) { stats[14] += c; stats[15] += (c + 63) / 64; } } catch (std::string&) {}
+    }
     stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
     if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) { stats[1] = f.list_gen; stats[10] = f.builds; } }
     return 0;

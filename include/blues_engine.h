@@ -164,8 +164,11 @@ int blues_reset(BluesEngine *h);
  * [6] partial slabs [7] segment length*1000 + waves per block [8] longest
  * j-list at the last rebuild [9] re-sorts of the tile layout [10] list
  * builds executed [11] potential-energy evaluations launched by this engine
- * alone (those served by blues_batch_prefetch_energies are not counted) */
-#define BLUES_N_STATS 12
+ * alone (those served by blues_batch_prefetch_energies are not counted)
+ * [12] nonbonded kernel in use: 0 tile kernel, 1 sub-tile kernel, 2 per-atom
+ * lists over an LDS image [13] i-tiles per j-list [14] entries of all per-atom
+ * lists at the last rebuild [15] 64-entry wave iterations they take */
+#define BLUES_N_STATS 16
 int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
 /* time `reps` launches of the dominant nonbonded kernel alone with HIP events
  * on the engine's own stream; returns mean microseconds per launch. */
