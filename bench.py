@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_ATOM = 36.0     # x,y,z + q,sigma,eps read, fx,fy,fz written, per force evaluation
 
 
-def build_chains(rank, local_rank, nsteps, workload, R):
+def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False):
     """R independent BLUES chains on this rank's GPU: own integrator (Philox key), context, move engine, state table."""
     from blues_amd import integrators, moves, simulation, systems
     from blues_amd.context import Simulation
@@ -61,6 +61,8 @@ def build_chains(rank, local_rank, nsteps, workload, R):
         system, vel = systems.s23k(mobile_atoms=275, frozen=True)
         lig = np.asarray(system.alchemical_atoms)
         make_move = lambda gid: moves.RandomLigandRotationMove(lig, system.mass[lig], random_state=1000 + gid)
+    if reciprocal:   # nonbondedMethod=PME in full: mesh + self + excluded-pair + dispersion terms
+        system = systems.with_reciprocal_space(system)
     chains = []
     for c in range(R):
         gid = rank * R + c   # global chain index
@@ -250,6 +252,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-chain measurement")
+    ap.add_argument("--reciprocal", action="store_true", help="PME in full: reciprocal-space mesh, self, excluded-pair and dispersion terms on top of the direct-space sum "
+                    "(the switching path north_star names is the direct-space one; this adds SURVEY.md 8f.2)")
     ap.add_argument("--launch-check", action="store_true", help="CPU-only check of the N-rank launch path (gloo, no engine)")
     args = ap.parse_args()
 
@@ -284,7 +288,7 @@ def main():
     torch.cuda.set_device(local_rank)
     nsteps, R = args.nsteps_nc, max(1, args.replicas)
     t_setup = time.perf_counter()
-    system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R)
+    system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R, reciprocal=args.reciprocal)
     x0 = system.positions.copy()
     v0 = vel.copy()
 
@@ -408,7 +412,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 pair math / f64 accumulation, f64 alchemical+integrator", "data": "synthetic",
             "data_note": "every chain starts every switch from the same coordinates and velocities (its Philox stream differs): rebuild statistics are those of the first 4 ps from one geometry",
-            "nonbonded_method": "PME direct space" if not getattr(system, "reciprocal", False) else "PME direct + reciprocal space",
+            "nonbonded_method": "PME direct space only" if system.nonbonded_method == 1 else "PME direct + reciprocal space (mesh %dx%dx%d, order %d), dispersion correction %s" % (tuple(system.pme_grid) + (system.pme_order, "on" if system.dispersion_correction else "off")),
             "config": {"workload": "S23k %s: %d atoms, %d mobile, %d alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in %d replica batch(es)"
                        % (args.workload, n_atoms, int((system.mass > 0).sum()), len(system.alchemical_atoms), nsteps, R, G),
                        "replicas_per_gpu": R, "batches_per_gpu": G, "host_workers": args.workers,

@@ -9,13 +9,14 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NB_NOCUTOFF = 0
 NB_PME_DIRECT = 1
-N_ENERGY_TERMS = 8
+NB_PME = 2
+N_ENERGY_TERMS = 10
 N_STATS = 16
 ENERGY_TERM_NAMES = ("bonds", "angles", "torsions", "nonbonded", "exceptions", "alch_sterics",
-                     "alch_electrostatics", "restraint")
+                     "alch_electrostatics", "restraint", "reciprocal", "dispersion_correction")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -38,6 +39,7 @@ class BluesSystemDesc(C.Structure):
         ("cutoff", C.c_double), ("ewald_alpha", C.c_double), ("softcore_alpha", C.c_double),
         ("annihilate_electrostatics", C.c_int32), ("annihilate_sterics", C.c_int32),
         ("remove_cm_motion", C.c_int32),
+        ("pme_grid", C.c_int32 * 3), ("pme_order", C.c_int32), ("dispersion_correction", C.c_int32),
     ]
 
 
@@ -101,6 +103,9 @@ class SystemData:
     annihilate_electrostatics: bool = True
     annihilate_sterics: bool = False
     remove_cm_motion: bool = False
+    pme_grid: tuple = (0, 0, 0)          # NB_PME: mesh of the reciprocal sum
+    pme_order: int = 5
+    dispersion_correction: bool = True   # NB_PME: OpenMM's NonbondedForce default
     positions: np.ndarray = None         # (n,3) nm, optional initial coordinates
     residue_of_atom: np.ndarray = None   # optional bookkeeping for host-side selections
     names: list = None
@@ -151,6 +156,9 @@ class SystemData:
         d.annihilate_electrostatics = int(bool(self.annihilate_electrostatics))
         d.annihilate_sterics = int(bool(self.annihilate_sterics))
         d.remove_cm_motion = int(bool(self.remove_cm_motion))
+        for k in range(3):
+            d.pme_grid[k] = int(self.pme_grid[k])
+        d.pme_order = int(self.pme_order); d.dispersion_correction = int(bool(self.dispersion_correction))
         return d, keep
 
 

@@ -13,7 +13,7 @@ import re
 
 import numpy as np
 
-from ._abi import NB_PME_DIRECT, SystemData
+from ._abi import NB_PME, NB_PME_DIRECT, SystemData
 
 AMBER_CHARGE = 18.2223
 KCAL = 4.184
@@ -96,12 +96,15 @@ def ewald_alpha(cutoff, tolerance):
 
 def system_from_amber(prm, positions, box, cutoff=1.0, ewald_error_tolerance=0.005, constraints="HBonds",
                       rigid_water=True, hydrogen_mass=None, remove_cm_motion=True, alchemical_atoms=(),
-                      tip3p_for_untyped_water=True):
+                      tip3p_for_untyped_water=True, reciprocal_space=True, dispersion_correction=True):
     """Amber topology -> SystemData, following structure.createSystem's kwargs
     (reference examples/rotmove_cuda.yml:19-27: PME, 10 A cutoff, HBonds,
     rigidWater, removeCMMotion, hydrogenMass 3.024, ewaldErrorTolerance 0.005).
     Constrained bonds and rigid-water angles are left out of the harmonic terms
-    (they contribute zero at the constrained geometry)."""
+    (they contribute zero at the constrained geometry).
+    reciprocal_space=True is nonbondedMethod=PME in full (mesh of OpenMM's Reference platform for the tolerance, self term,
+    excluded-pair corrections, dispersion correction); False keeps the direct-space sum only and says so in the log --
+    forces on the water then differ from the reference's, only the protocol work (lambda-dependent pairs) does not."""
     p = prm["POINTERS"]
     natom, ntypes = int(p[0]), int(p[1])
     charge = prm["CHARGE"] / AMBER_CHARGE
@@ -218,7 +221,17 @@ def system_from_amber(prm, positions, box, cutoff=1.0, ewald_error_tolerance=0.0
     excl = np.array(sorted(excl), dtype=np.int32).reshape(-1, 2)
     exc_pairs = sorted(exc.keys())
 
+    alpha = ewald_alpha(cutoff, ewald_error_tolerance)
+    if reciprocal_space:
+        from .systems import pme_grid_for
+        method, grid = NB_PME, pme_grid_for(box, alpha, cutoff, ewald_error_tolerance)
+    else:
+        import logging
+        logging.getLogger(__name__).warning("system_from_amber: PME lowered to its direct-space part (reciprocal_space=False): no mesh, self or "
+                                            "dispersion terms; energies and environment forces are not those of nonbondedMethod=PME")
+        method, grid = NB_PME_DIRECT, (0, 0, 0)
     return SystemData(
+        pme_grid=grid, pme_order=5, dispersion_correction=bool(dispersion_correction),
         box=np.asarray(box, dtype=np.float64), mass=mass, charge=charge, sigma=sigma, epsilon=eps,
         exclusions=excl,
         exception_atoms=np.array(exc_pairs, dtype=np.int32).reshape(-1, 2),
@@ -228,7 +241,7 @@ def system_from_amber(prm, positions, box, cutoff=1.0, ewald_error_tolerance=0.0
         torsion_atoms=np.array(tors_atoms, dtype=np.int32).reshape(-1, 4), torsion_params=np.array(tors_params, dtype=np.float64).reshape(-1, 3),
         constraint_atoms=np.array(cons_atoms, dtype=np.int32).reshape(-1, 2), constraint_dist=np.array(cons_dist, dtype=np.float64),
         alchemical_atoms=np.array(sorted(alchemical_atoms), dtype=np.int32),
-        nonbonded_method=NB_PME_DIRECT, cutoff=cutoff, ewald_alpha=ewald_alpha(cutoff, ewald_error_tolerance),
+        nonbonded_method=method, cutoff=cutoff, ewald_alpha=alpha,
         remove_cm_motion=remove_cm_motion, positions=np.asarray(positions, dtype=np.float64),
         residue_of_atom=residue_of_atom, names=list(prm.get("ATOM_NAME", [])),
     )

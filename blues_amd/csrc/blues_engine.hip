@@ -29,6 +29,7 @@
 #include "kernels_bonded.h"
 #include "kernels_integrate.h"
 #include "kernels_nb.h"
+#include "kernels_pme.h"
 #include "kernels_batch.h"
 
 static thread_local std::string g_create_error;
@@ -186,10 +187,18 @@ struct BluesEngine {
     DBuf<AlchJRec> d_jrec; DBuf<AlchARec> d_arec;
     DBuf<double> d_mom_part; bool vel_clean = false, pass_valid_for_l = true;  // velocities unchanged since the last force pass (momentum partials valid)
     DBuf<FinRec> d_finrecs; std::vector<int> h_row_of_orig, h_row_start;
+    // reciprocal space (BLUES_NB_PME, kernels_pme.h)
+    template <typename T> struct PmeBufs { DBuf<T> a_re, a_im, b_re, b_im, eterm, tw_cos[3], tw_sin[3], qf_re, qf_im, phi_f; };
+    bool pme = false; int pme_K[3] = {0, 0, 0}, pme_order = 5, disp_corr = 0;
+    std::vector<double> qn; std::vector<int> pme_frozen;   // NonbondedForce charges (alchemical atoms 0); frozen atoms that carry charge
+    DBuf<double> d_qn, d_frec, d_pme_e; DBuf<int> d_pme_frozen; DBuf<unsigned long long> d_pme_acc;
+    PmeBufs<float> pme_f; PmeBufs<double> pme_d;
+    bool pme_static_valid = false;
+    double e_ewald_const = 0.0, e_disp = 0.0;   // self term + neutralising background; dispersion correction (functions of the box)
     // bonded
     DBuf<int> d_row_atom, d_row_start, d_ent_type, d_ent_term, d_ent_role;
     DBuf<int> d_term_atoms[T_NTYPES]; DBuf<double> d_term_params[T_NTYPES];
-    int n_terms[T_NTYPES] = {0, 0, 0, 0, 0}; int n_rows = 0; double restr_k = 0;
+    int n_terms[T_NTYPES] = {0, 0, 0, 0, 0, 0}; int n_rows = 0; double restr_k = 0;
     // pending integrate program
     Program prog; unsigned prog_draw_base = 0; int prog_trace = -1; bool tracing = false;
     // stats
@@ -381,9 +390,14 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
             arow_partner[h->alch_local[a]].push_back(e2); for (int q = 0; q < 3; q++) arow_par[h->alch_local[a]].push_back(p[q]);
         }
     }
+    if (h->pme) for (int e = 0; e < s->n_exclusions; e++) {   // every excluded pair: its reciprocal-space interaction is removed again
+        const int i = s->exclusions[2 * e], j = s->exclusions[2 * e + 1];
+        const double qq = h->qn[i] * h->qn[j];
+        if (qq != 0.0) { ta[T_EWEX].push_back(i); ta[T_EWEX].push_back(j); tp[T_EWEX].push_back(qq); }
+    }
     for (int r = 0; r < s->n_restraints; r++) { ta[T_RESTR].push_back(s->restraint_atoms[r]); for (int q = 0; q < 3; q++) tp[T_RESTR].push_back(s->restraint_x0[3 * r + q]); }
     h->restr_k = s->restraint_k;
-    const int width[T_NTYPES] = {2, 3, 4, 2, 1};
+    const int width[T_NTYPES] = {2, 3, 4, 2, 1, 2};
     std::vector<std::vector<int>> rtype(h->n), rterm(h->n), rrole(h->n);
     for (int ty = 0; ty < T_NTYPES; ty++) {
         h->n_terms[ty] = (int)ta[ty].size() / width[ty];
@@ -879,7 +893,7 @@ static BondedArgs make_bonded_args(BluesEngine* h) {
     B.n_rows = h->n_rows; B.row_atom = h->d_row_atom.p; B.row_start = h->d_row_start.p;
     B.ent_type = h->d_ent_type.p; B.ent_term = h->d_ent_term.p; B.ent_role = h->d_ent_role.p;
     for (int ty = 0; ty < T_NTYPES; ty++) { B.n_terms[ty] = h->n_terms[ty]; B.atoms[ty] = h->d_term_atoms[ty].p; B.params[ty] = h->d_term_params[ty].p; }
-    B.restr_k = h->restr_k;
+    B.restr_k = h->restr_k; B.ewald_alpha = h->alpha;
     for (int k = 0; k < 3; k++) B.x[k] = h->d_x[k].p;
     B.box = make_box(h); B.periodic = h->nb_method == BLUES_NB_PME_DIRECT; B.fent = h->d_fent.p; B.n_entries = h->n_entries; B.n = h->n; B.epart = h->d_epart_b.p;
     B.n_mobile = (int)h->mobile.size(); B.n_noise = h->n_noise; B.mobile_atoms = h->d_mobile_atoms.p; B.noise = h->d_noise.p;
@@ -912,6 +926,7 @@ static FinArgs make_fin_args(BluesEngine* h, const double le[3], int slot_mask =
     F.ftot = h->d_ftot.p; F.alch_self = h->d_alch_self.p; F.acc = h->d_acc.p; F.ctrl = h->ctrl_arg;
     for (int k = 0; k < 3; k++) F.v[k] = h->d_v[k].p;
     F.mass = h->d_mass.p; F.mom_part = h->d_mom_part.p;
+    F.frec = h->pme ? h->d_frec.p : nullptr;
     return F;
 }
 
@@ -981,6 +996,126 @@ static int launch_forces_fused_sub(BluesEngine* h, const double ls[3], const dou
     return 0;
 }
 
+// ------------------------------------------------------------------ reciprocal space (kernels_pme.h)
+// B-spline moduli, eterm(m) = ONE_4PI_EPS0 exp(-pi^2 m^2 / alpha^2) / (pi V m^2 |b_x b_y b_z|^2), the transform's twiddle tables and the
+// box-dependent constants (self term, neutralising background, dispersion correction): same formulas as the oracle.
+template <typename T> static BluesEngine::PmeBufs<T>& pme_bufs(BluesEngine* h) { if constexpr (sizeof(T) == 4) return h->pme_f; else return h->pme_d; }
+
+static void pme_splines_host(double dr, int order, double* w) {
+    w[order - 1] = 0.0; w[1] = dr; w[0] = 1.0 - dr;
+    for (int l = 3; l < order; l++) {
+        const double div = 1.0 / (l - 1.0);
+        w[l - 1] = div * dr * w[l - 2];
+        for (int k = 1; k < l - 1; k++) w[l - k - 1] = div * ((dr + k) * w[l - k - 2] + (l - k - dr) * w[l - k - 1]);
+        w[0] = div * (1.0 - dr) * w[0];
+    }
+    const double div = 1.0 / (order - 1.0);
+    w[order - 1] = div * dr * w[order - 2];
+    for (int k = 1; k < order - 1; k++) w[order - k - 1] = div * ((dr + k) * w[order - k - 2] + (order - k - dr) * w[order - k - 1]);
+    w[0] = div * (1.0 - dr) * w[0];
+}
+
+template <typename T> static int pme_tables(BluesEngine* h) {
+    auto& P = pme_bufs<T>(h);
+    const int K[3] = {h->pme_K[0], h->pme_K[1], h->pme_K[2]};
+    const size_t ng = (size_t)K[0] * K[1] * K[2];
+    std::vector<double> mod[3]; double w[8];
+    pme_splines_host(0.0, h->pme_order, w);
+    try {
+        for (int d = 0; d < 3; d++) {
+            mod[d].resize(K[d]);
+            std::vector<T> tc(K[d]), ts(K[d]);
+            for (int m = 0; m < K[d]; m++) {
+                tc[m] = (T)std::cos(2.0 * M_PI * m / K[d]); ts[m] = (T)std::sin(2.0 * M_PI * m / K[d]);
+                double sc = 0.0, ss = 0.0;
+                for (int k = 0; k < h->pme_order; k++) { const double a = 2.0 * M_PI * m * (k + 1) / K[d]; sc += w[k] * std::cos(a); ss += w[k] * std::sin(a); }
+                mod[d][m] = sc * sc + ss * ss;
+            }
+            for (int m = 0; m < K[d]; m++) if (mod[d][m] < 1e-7) mod[d][m] = 0.5 * (mod[d][(m + K[d] - 1) % K[d]] + mod[d][(m + 1) % K[d]]);
+            P.tw_cos[d].upload(tc); P.tw_sin[d].upload(ts);
+        }
+        const double V = h->box[0] * h->box[1] * h->box[2], al = h->alpha;
+        std::vector<T> et(ng);
+        for (int kx = 0; kx < K[0]; kx++) for (int ky = 0; ky < K[1]; ky++) for (int kz = 0; kz < K[2]; kz++) {
+            const size_t g = ((size_t)kx * K[1] + ky) * K[2] + kz;
+            if (!kx && !ky && !kz) { et[g] = (T)0; continue; }
+            const double mx = (kx < (K[0] + 1) / 2 ? kx : kx - K[0]) / h->box[0], my = (ky < (K[1] + 1) / 2 ? ky : ky - K[1]) / h->box[1], mz = (kz < (K[2] + 1) / 2 ? kz : kz - K[2]) / h->box[2];
+            const double m2 = mx * mx + my * my + mz * mz;
+            et[g] = (T)(ONE_4PI_EPS0 * std::exp(-M_PI * M_PI * m2 / (al * al)) / (M_PI * V * m2 * mod[0][kx] * mod[1][ky] * mod[2][kz]));
+        }
+        P.eterm.upload(et);
+        P.a_re.alloc(ng); P.a_im.alloc(ng); P.b_re.alloc(ng); P.b_im.alloc(ng); P.qf_re.alloc(ng); P.qf_im.alloc(ng); P.phi_f.alloc(ng);
+        h->d_pme_acc.alloc(ng); h->d_pme_e.alloc(4); h->d_frec.alloc((size_t)3 * h->n);
+    } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    // constants of the box: self term, neutralising background, dispersion correction
+    double qsum = 0.0, q2 = 0.0;
+    for (double q : h->qn) { qsum += q; q2 += q * q; }
+    const double V = h->box[0] * h->box[1] * h->box[2];
+    h->e_ewald_const = -ONE_4PI_EPS0 * h->alpha / std::sqrt(M_PI) * q2 - M_PI * ONE_4PI_EPS0 * qsum * qsum / (2.0 * V * h->alpha * h->alpha);
+    h->e_disp = 0.0;
+    if (h->disp_corr) {   // [recalled: OpenMM NonbondedForceImpl::calcDispersionCorrection without switching function]; alchemical atoms enter with epsilon 0
+        std::vector<double> cs, ce; std::vector<long long> cn;
+        for (int i = 0; i < h->n; i++) {
+            const double e = h->alch_local[i] >= 0 ? 0.0 : h->eps[i], sg = h->sigma[i];
+            size_t c = 0; for (; c < cs.size(); c++) if (cs[c] == sg && ce[c] == e) break;
+            if (c == cs.size()) { cs.push_back(sg); ce.push_back(e); cn.push_back(0); }
+            cn[c]++;
+        }
+        double s12 = 0.0, s6 = 0.0;
+        for (size_t a = 0; a < cs.size(); a++) for (size_t b = a; b < cs.size(); b++) {
+            const double cnt = a == b ? 0.5 * cn[a] * (cn[a] + 1.0) : (double)cn[a] * cn[b];
+            const double sg = 0.5 * (cs[a] + cs[b]), e = std::sqrt(ce[a] * ce[b]), s2 = sg * sg, s6_ = s2 * s2 * s2;
+            s12 += cnt * e * s6_ * s6_; s6 += cnt * e * s6_;
+        }
+        const double tot = 0.5 * h->n * (h->n + 1.0), rc = h->cutoff, rc3 = rc * rc * rc, rc9 = rc3 * rc3 * rc3;
+        h->e_disp = 8.0 * h->n * (double)h->n * M_PI * (s12 / tot / (9.0 * rc9) - s6 / tot / (3.0 * rc3)) / V;
+    }
+    h->pme_static_valid = false;
+    return 0;
+}
+
+template <typename T> static PmeArgs<T> make_pme_args(BluesEngine* h, bool is_static) {
+    PmeArgs<T> P; memset(&P, 0, sizeof P);
+    if (!h->pme) return P;
+    auto& b = pme_bufs<T>(h);
+    P.n = h->n; P.order = h->pme_order; for (int d = 0; d < 3; d++) P.K[d] = h->pme_K[d];
+    P.ng = h->pme_K[0] * h->pme_K[1] * h->pme_K[2];
+    P.n_sel = is_static ? (int)h->pme_frozen.size() : (int)h->mobile.size();
+    P.sel = is_static ? h->d_pme_frozen.p : h->d_mobile_atoms.p;
+    for (int k = 0; k < 3; k++) { P.x[k] = h->d_x[k].p; P.tw_cos[k] = b.tw_cos[k].p; P.tw_sin[k] = b.tw_sin[k].p; }
+    P.qn = h->d_qn.p; P.box = make_box(h); P.acc = h->d_pme_acc.p;
+    P.a_re = b.a_re.p; P.a_im = b.a_im.p; P.b_re = b.b_re.p; P.b_im = b.b_im.p; P.eterm = b.eterm.p;
+    P.qf_re = b.qf_re.p; P.qf_im = b.qf_im.p; P.phi_f = b.phi_f.p; P.have_static = !h->pme_frozen.empty();
+    P.frec = h->d_frec.p; P.epart = h->d_pme_e.p; P.want_energy = 0;
+    return P;
+}
+
+// reciprocal-space forces on the mobile atoms (and the mesh energy when asked); the frozen charges' meshes first if they are stale
+template <typename T> static void pme_ensure_static(BluesEngine* h) {
+    if (h->pme_static_valid) return;
+    if (!h->pme_frozen.empty()) { hipLaunchKernelGGL((k_pme<T, true>), dim3(1), dim3(PME_THREADS), 0, h->cur, make_pme_args<T>(h, true)); h->st_launches++; }
+    h->pme_static_valid = true;
+}
+template <typename T> static int launch_pme_t(BluesEngine* h, int want_energy) {
+    if (batch_dry(h)) return 0;
+    if (batch_lead(h)) {
+        // the shared launch reads every member's static meshes: whoever's are stale gets them first (lone launches, same stream)
+        for (BluesEngine* m : h->batch->eng) if (m->pme) pme_ensure_static<T>(m);
+        hipLaunchKernelGGL(k_pme_b<T>, dim3(h->batch->R()), dim3(PME_THREADS), 0, h->cur, batch_reps_nb<T>(h->batch), want_energy);
+    } else {
+        pme_ensure_static<T>(h);
+        PmeArgs<T> P = make_pme_args<T>(h, false); P.want_energy = want_energy;
+        hipLaunchKernelGGL((k_pme<T, false>), dim3(1), dim3(PME_THREADS), 0, h->cur, P);
+    }
+    h->st_launches++;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+static int launch_pme(BluesEngine* h, int want_energy) {
+    if (!h->pme) return 0;
+    return h->precision == 0 ? launch_pme_t<float>(h, want_energy) : launch_pme_t<double>(h, want_energy);
+}
+
 static int ensure_sorted(BluesEngine* h) {
     if (!h->have_positions) E_FAIL(h, "positions have not been set");
     if (!h->sorted_ok) return sort_and_tile(h);
@@ -1005,14 +1140,17 @@ static int force_pass(BluesEngine* h, int base_L) {
     if (h->fuse_forces && h->wpb == 4) {
         rc = h->precision == 0 ? launch_forces_fused<float>(h, ls, le) : launch_forces_fused<double>(h, ls, le);
         if (rc) return 1;
+        if (launch_pme(h, 0)) return 1;
         if (launch_finalize(h, le, fmask)) return 1;
     } else if (h->k1_mode == 1 && h->precision == 0 && h->fuse_big) {
         if (launch_forces_fused_sub(h, ls, le)) return 1;
+        if (launch_pme(h, 0)) return 1;
         if (launch_finalize(h, le, fmask)) return 1;
     } else {
         if (launch_alchemical(h, ls, le, fmask)) return 1;
         rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (rc) return 1;
+        if (launch_pme(h, 0)) return 1;
         if (launch_bonded_and_finalize(h, le, true, fmask)) return 1;
     }
     h->pass_valid = true; h->pass_L = base_L; h->st_passes++; h->vel_clean = true;
@@ -1081,6 +1219,7 @@ static int energy_launch(BluesEngine* h) {
     if (launch_alchemical(h, ls, le, 1)) return 1;
     rc = h->precision == 0 ? launch_nonbonded<float, true>(h) : launch_nonbonded<double, true>(h);
     if (rc) return 1;
+    if (launch_pme(h, 1)) return 1;
     const EnergyShape g = energy_shape(h);
     if (g.nbb > 0) {
         if (batch_lead(h)) hipLaunchKernelGGL(k_bonded_energy_b, dim3(g.nbb, h->batch->R()), dim3(256), 0, h->cur, h->batch->d_core.p);
@@ -1093,12 +1232,13 @@ static int energy_launch(BluesEngine* h) {
 
 // the host-side sums over the partials, in a fixed order (the same whether they were downloaded one engine at a time or
 // gathered for a whole batch)
-static void energy_sum(BluesEngine* h, const double* enb, const double* eb, int jcount_alch, const double* ep, double T[BLUES_N_ENERGY_TERMS]) {
+static void energy_sum(BluesEngine* h, const double* enb, const double* eb, int jcount_alch, const double* ep, double e_mesh, double T[BLUES_N_ENERGY_TERMS]) {
     const EnergyShape g = energy_shape(h);
     for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) T[t] = 0.0;
     double e_nb = 0.0; for (int w = 0; w < g.nw; w++) e_nb += enb[2 * w] + enb[2 * w + 1];
     T[3] = e_nb + h->e_frozen[0] + h->e_frozen[1];
-    for (int b = 0; b < g.nbb; b++) { T[0] += eb[b * T_NTYPES + T_BOND]; T[1] += eb[b * T_NTYPES + T_ANGLE]; T[2] += eb[b * T_NTYPES + T_TORSION]; T[4] += eb[b * T_NTYPES + T_EXC]; T[7] += eb[b * T_NTYPES + T_RESTR]; }
+    for (int b = 0; b < g.nbb; b++) { T[0] += eb[b * T_NTYPES + T_BOND]; T[1] += eb[b * T_NTYPES + T_ANGLE]; T[2] += eb[b * T_NTYPES + T_TORSION]; T[4] += eb[b * T_NTYPES + T_EXC]; T[7] += eb[b * T_NTYPES + T_RESTR]; T[8] += eb[b * T_NTYPES + T_EWEX]; }
+    if (h->pme) { T[8] += e_mesh + h->e_ewald_const; T[9] = h->e_disp; }
     if (!h->alch.empty()) {
         const int nb_env = k2_env_blocks(jcount_alch, h->PA, h->k2_jiter);
         double s[K2_NE] = {0, 0, 0, 0, 0, 0};
@@ -1130,7 +1270,9 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
         if (g.nbb > 0) h->d_epart_b.download(eb);
         if (!h->alch.empty()) { h->d_jcount.download(jc); h->d_e_part.download(ep); }
     } catch (std::string& msg) { E_FAIL(h, "%s", msg.c_str()); }
-    energy_sum(h, enb.data(), eb.data(), h->alch.empty() ? 0 : jc[h->n_lists], ep.data(), T);
+    double e_mesh = 0.0;
+    if (h->pme) HIP_OK(h, hipMemcpy(&e_mesh, h->d_pme_e.p, sizeof e_mesh, hipMemcpyDeviceToHost));
+    energy_sum(h, enb.data(), eb.data(), h->alch.empty() ? 0 : jc[h->n_lists], ep.data(), e_mesh, T);
     return 0;
 }
 
@@ -1403,7 +1545,7 @@ static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const ch
     BC(device) BC(n) BC(precision) BC(nsteps) BC(nprop) BC(n_lambda) BC(split) BC(remove_cm) BC(dt) BC(gamma) BC(kT) BC(tol) BC(prop_min) BC(prop_max)
     BC(n_itiles) BC(n_tiles) BC(jcap) BC(n_islots) BC(pool_cap) BC(PA) BC(k2_nblocks_env) BC(k2_jiter) BC(seg_len) BC(waves_tile) BC(wpb) BC(npart)
     BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k1_iw) BC(k1_mode) BC(acap) BC(S) BC(n_lists) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
-    BC(cutoff) BC(alpha) BC(sc_alpha) BC(annih_elec) BC(annih_ster) BC(nb_method) BC(restr_k) BC(total_mass)
+    BC(cutoff) BC(alpha) BC(sc_alpha) BC(annih_elec) BC(annih_ster) BC(nb_method) BC(pme) BC(pme_K[0]) BC(pme_K[1]) BC(pme_K[2]) BC(pme_order) BC(restr_k) BC(total_mass)
     BC(box[0]) BC(box[1]) BC(box[2])
 #undef BC
     if (a->clusters.size() != b->clusters.size()) { *why = "constraint clusters"; return false; }
@@ -1434,8 +1576,8 @@ static int batch_refresh_args(BluesBatch* B) {
         core[r].al = make_alch_args(h, one, one, 7); core[r].bo = make_bonded_args(h); core[r].fin = make_fin_args(h, one); core[r].in = make_int_args(h);
         core[r].in.work_trace = h->d_trace.p;  // the launch decides whether it is written (IntDyn.tracing)
         core[r].in.n_noise = h->n_noise;
-        if (single) { nf[r].L = make_list_args(h); nf[r].nb = make_nb_args<float>(h); nf[r].c = make_nbconst<float>(h); nf[r].img = h->d_img_f.p; }
-        else { nd[r].L = make_list_args(h); nd[r].nb = make_nb_args<double>(h); nd[r].c = make_nbconst<double>(h); nd[r].img = h->d_img_d.p; }
+        if (single) { nf[r].L = make_list_args(h); nf[r].nb = make_nb_args<float>(h); nf[r].c = make_nbconst<float>(h); nf[r].img = h->d_img_f.p; nf[r].pme = make_pme_args<float>(h, false); }
+        else { nd[r].L = make_list_args(h); nd[r].nb = make_nb_args<double>(h); nd[r].c = make_nbconst<double>(h); nd[r].img = h->d_img_d.p; nd[r].pme = make_pme_args<double>(h, false); }
         B->seen_epoch[r] = h->args_epoch;
     }
     // the records may be in use by launches still in flight
@@ -1487,7 +1629,7 @@ static int batch_prefetch(BluesBatch* B, int what) {
             for (int r = 0; r < R && ok; r++) if (live[r]) ok = energy_launch(B->eng[r]) == 0;
             B->lockstep = false;
             const EnergyShape g = energy_shape(lead);
-            const int n_nb = 2 * g.nw, n_b = g.nbb * T_NTYPES, n_al = lead->alch.empty() ? 0 : (lead->k2_nblocks_env + 1) * K2_NP, stride = n_nb + n_b + n_al + 1;
+            const int n_nb = 2 * g.nw, n_b = g.nbb * T_NTYPES, n_al = lead->alch.empty() ? 0 : (lead->k2_nblocks_env + 1) * K2_NP, stride = n_nb + n_b + n_al + 2;
             std::vector<double> slab; std::vector<int> hints;
             try {
                 if (ok) {
@@ -1504,7 +1646,7 @@ static int batch_prefetch(BluesBatch* B, int what) {
                 BluesEngine* m = B->eng[r];
                 const double* o = slab.data() + (size_t)r * stride;
                 double T[BLUES_N_ENERGY_TERMS], E = 0.0;
-                energy_sum(m, o, o + n_nb, (int)o[n_nb + n_b + n_al], o + n_nb + n_b, T);
+                energy_sum(m, o, o + n_nb, (int)o[n_nb + n_b + n_al], o + n_nb + n_b, o[n_nb + n_b + n_al + 1], T);
                 for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) E += T[t];
                 m->ecache.put(m->cur_ls, m->cur_le, E);
             }
@@ -1641,11 +1783,17 @@ const char* blues_last_error(const BluesEngine* h) { return h ? h->err.c_str() :
 
 static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesIntegratorDesc* it) {
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) if (r != c && s->box[3 * r + c] != 0.0) E_FAIL(h, "only orthorhombic boxes are supported");
-    if (s->nonbonded_method != BLUES_NB_PME_DIRECT) E_FAIL(h, "the GPU engine supports periodic PME-direct systems only");
+    if (s->nonbonded_method != BLUES_NB_PME_DIRECT && s->nonbonded_method != BLUES_NB_PME) E_FAIL(h, "the GPU engine supports periodic systems only (BLUES_NB_PME_DIRECT, BLUES_NB_PME)");
+    if (s->nonbonded_method == BLUES_NB_PME) {
+        h->pme = true; h->pme_order = s->pme_order; h->disp_corr = s->dispersion_correction;
+        for (int d = 0; d < 3; d++) { h->pme_K[d] = s->pme_grid[d]; if (h->pme_K[d] < s->pme_order || h->pme_K[d] > 256) E_FAIL(h, "PME mesh %d along axis %d is outside [order, 256]", h->pme_K[d], d); }
+        if (h->pme_order < 2 || h->pme_order > PME_MAX_ORDER) E_FAIL(h, "PME order %d is outside [2, %d]", h->pme_order, PME_MAX_ORDER);
+    }
     const int n = h->n = s->n_atoms;
     if (n <= 0) E_FAIL(h, "empty system");
     h->box[0] = s->box[0]; h->box[1] = s->box[4]; h->box[2] = s->box[8];
-    h->nb_method = s->nonbonded_method; h->cutoff = s->cutoff; h->alpha = s->ewald_alpha; h->sc_alpha = s->softcore_alpha;
+    h->nb_method = BLUES_NB_PME_DIRECT; h->cutoff = s->cutoff;   // (the direct-space kernels are the same under both methods)
+    h->alpha = s->ewald_alpha; h->sc_alpha = s->softcore_alpha;
     for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * h->cutoff) E_FAIL(h, "box edge %g < 2*cutoff", h->box[k]);
     if (const char* sk = getenv("BLUES_SKIN")) { h->skin = atof(sk); h->skin_from_env = true; }
     for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) h->skin = std::max(0.0, 0.5 * h->box[k] - h->cutoff - 1e-6);
@@ -1701,6 +1849,12 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
         for (size_t m = 0; m < h->mobile.size(); m++) mi[h->mobile[m]] = (int)m;
         try { h->d_mobile_atoms.upload(h->mobile); h->d_mobile_index.upload(mi); h->n_noise = std::max(1, h->n_O + h->n_L);
               h->d_noise.alloc((size_t)h->n_noise * 3 * std::max<size_t>(1, h->mobile.size())); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    }
+    if (h->pme) {
+        h->qn = h->charge; for (int a : h->alch) h->qn[a] = 0.0;
+        for (int i = 0; i < n; i++) if (h->mass[i] == 0.0 && h->qn[i] != 0.0) h->pme_frozen.push_back(i);
+        try { h->d_qn.upload(h->qn); h->d_pme_frozen.upload(h->pme_frozen); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+        if (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h)) return 1;
     }
     if (build_clusters(h, s)) return 1;
     try { if (build_bonded(h, s)) return 1; } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
@@ -1835,7 +1989,7 @@ static int load_positions(BluesEngine* h, const double* const src[3], int stride
     HIP_OK(h, hipMemcpyAsync(out, h->d_xfer_out.p, sizeof out, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear();
-    if (out[0]) h->e_frozen_valid = false;
+    if (out[0]) { h->e_frozen_valid = false; h->pme_static_valid = false; }
     float worst; memcpy(&worst, &out[1], sizeof worst);
     // tiles are formed from the mobile non-alchemical atoms.  A few wandering i-atoms only stretch their tile's bounding
     // box, and the device notices when that starts to cost (resort_hint); the host re-sorts when an i-atom is far out
@@ -1877,7 +2031,7 @@ int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
         HIP_OK(h, hipStreamSynchronize(h->stream));
         h->hx = st;
         if (upload_xyz(h, h->hx.data(), h->d_x)) return 1;
-        h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear(); h->e_frozen_valid = false;
+        h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear(); h->e_frozen_valid = false; h->pme_static_valid = false;
         return sort_and_tile(h);
     }
     // one interleaved transfer; de-interleaving, image refresh and the re-sort statistics happen on the device
@@ -1904,6 +2058,7 @@ int blues_set_box(BluesEngine* h, const double box[9]) {
     h->box[0] = box[0]; h->box[1] = box[4]; h->box[2] = box[8];
     for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) E_FAIL(h, "box edge %g < 2*(cutoff+skin)", h->box[k]);
     h->sorted_ok = false; h->pass_valid = false; h->e_frozen_valid = false; h->ecache.clear();
+    if (h->pme && (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h))) return 1;
     if (h->have_positions) { if (download_xyz(h, h->hx.data(), h->d_x)) return 1; return sort_and_tile(h); }
     return 0;
 }
@@ -1942,6 +2097,7 @@ int blues_get_forces(BluesEngine* h, double* out, int32_t n_atoms) {
     if (launch_alchemical(h, ls, le, 1)) return 1;
     rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
     if (rc) return 1;
+    if (launch_pme(h, 0)) return 1;
     if (launch_bonded_and_finalize(h, le, false)) return 1;
     IntArgs A = make_int_args(h);
     DBuf<double> tmp;

@@ -13,10 +13,12 @@
 // is static and lives in the per-replica records, refreshed only when a replica re-sorts its atoms.
 #pragma once
 #include "kernels_integrate.h"
+#include "kernels_pme.h"
 
 template <typename R> struct RepNb {   // precision-dependent part of a replica's argument record
     int active;   // 0: the member sits this launch out (its blocks return at once)
     ListArgs L; NbArgs<R> nb; NbConst<R> c; const typename Img<R>::Atom* img;
+    PmeArgs<R> pme;   // reciprocal space (n = 0: none)
 };
 struct RepCore {
     int active;
@@ -128,6 +130,15 @@ __global__ void __launch_bounds__(1024) k_nonbonded_atom_b(const RepNb<float>* _
     if (!rp.active) return;
     const NbArgs<float> a = rp.nb; const NbConst<float> c = rp.c;
     nonbonded_atom_body<ENERGY>(a, c, rp.img, bx);
+}
+
+// reciprocal space of every member: one workgroup each (kernels_pme.h)
+template <typename R>
+__global__ void __launch_bounds__(PME_THREADS) k_pme_b(const RepNb<R>* __restrict__ reps, int want_energy) {
+    const RepNb<R>& rp = reps[blockIdx.x];
+    if (!rp.active) return;
+    PmeArgs<R> P = rp.pme; P.want_energy = want_energy;
+    pme_body<R, false>(P);
 }
 
 template <bool FAST, int MASK>
@@ -245,4 +256,5 @@ __global__ void __launch_bounds__(256) k_gather_energy_parts_b(const RepNb<R>* _
     for (int k = threadIdx.x; k < n_b; k += 256) o[n_nb + k] = eb[k];
     for (int k = threadIdx.x; k < n_alch; k += 256) o[n_nb + n_b + k] = ep[k];
     if (threadIdx.x == 0) o[n_nb + n_b + n_alch] = n_alch > 0 ? (double)*reps[r].al.jcount : 0.0;
+    if (threadIdx.x == 1 && stride > n_nb + n_b + n_alch + 1) o[n_nb + n_b + n_alch + 1] = rnb[r].pme.n > 0 ? rnb[r].pme.epart[0] : 0.0;   // mesh energy
 }

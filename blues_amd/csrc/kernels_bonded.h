@@ -10,7 +10,7 @@
 #pragma once
 #include "device_common.h"
 
-enum { T_BOND = 0, T_ANGLE = 1, T_TORSION = 2, T_EXC = 3, T_RESTR = 4, T_NTYPES = 5 };
+enum { T_BOND = 0, T_ANGLE = 1, T_TORSION = 2, T_EXC = 3, T_RESTR = 4, T_EWEX = 5, T_NTYPES = 6 };   // T_EWEX: Ewald correction of an excluded pair (BLUES_NB_PME)
 
 struct BondedArgs {
     int n_rows;
@@ -21,9 +21,10 @@ struct BondedArgs {
     const int* ent_role;
     // all terms (caller indices)
     int n_terms[T_NTYPES];
-    const int* atoms[T_NTYPES];      // 2,3,4,2,1 indices per term
-    const double* params[T_NTYPES];  // 2,2,3,3,3 doubles per term (restraint: x0,y0,z0)
+    const int* atoms[T_NTYPES];      // 2,3,4,2,1,2 indices per term
+    const double* params[T_NTYPES];  // 2,2,3,3,3,1 doubles per term (restraint: x0,y0,z0; Ewald correction: q_i q_j)
     double restr_k;
+    double ewald_alpha;
     const double* x[3];
     Box3 box;
     int periodic;
@@ -115,6 +116,19 @@ __device__ inline double bonded_term(const BondedArgs& B, int type, int idx, int
         if (role >= 0) for (int c = 0; c < 3; c++) F[c] = sgn * (fs + fc) * d[c];
         return e;
     }
+    if (type == T_EWEX) {  // excluded pair under PME: its reciprocal-space interaction is taken out, -ONE_4PI_EPS0 q_i q_j erf(alpha r) / r
+        const int i = B.atoms[T_EWEX][2 * idx], j = B.atoms[T_EWEX][2 * idx + 1];
+        const double pre = ONE_4PI_EPS0 * B.params[T_EWEX][idx], al = B.ewald_alpha;
+        double d[3] = {B.x[0][i] - B.x[0][j], B.x[1][i] - B.x[1][j], B.x[2][i] - B.x[2][j]};
+        mi3(B, d);
+        const double r2 = dot3(d, d), r = sqrt(r2), er = erf(al * r);
+        if (role >= 0) {
+            const double dEdr = -pre * (TWO_OVER_SQRT_PI * al * exp(-al * al * r2) / r - er / r2);
+            const double fs = -dEdr / r, sgn = role == 0 ? 1.0 : -1.0;
+            for (int c = 0; c < 3; c++) F[c] = sgn * fs * d[c];
+        }
+        return -pre * er / r;
+    }
     // T_RESTR
     const int i = B.atoms[T_RESTR][idx];
     double d[3] = {B.x[0][i] - B.params[T_RESTR][3 * idx], B.x[1][i] - B.params[T_RESTR][3 * idx + 1], B.x[2][i] - B.params[T_RESTR][3 * idx + 2]};
@@ -149,7 +163,7 @@ __global__ void __launch_bounds__(128) k_bonded_entries(BondedArgs B) { bonded_e
 // energy of every term (frozen ones included): per-block partial sums per type
 __device__ __forceinline__ void bonded_energy_body(const BondedArgs& B) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
-    double e[T_NTYPES] = {0, 0, 0, 0, 0};
+    double e[T_NTYPES] = {0, 0, 0, 0, 0, 0};
     int base = 0;
     for (int ty = 0; ty < T_NTYPES; ty++) {
         const int idx = gid - base;

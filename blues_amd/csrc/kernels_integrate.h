@@ -242,6 +242,7 @@ struct FinArgs {
     // momentum bookkeeping for CMMotionRemover without a grid-wide reduction inside the step kernel:
     // mom_part[block][0..2] = sum m v, [3..5] = sum of the slot-0 force, over the block's atoms
     const double* v[3]; const double* mass; double* mom_part;
+    const double* frec;   // [3][n] reciprocal-space force (kernels_pme.h), lambda-independent; null without BLUES_NB_PME
 };
 
 // grid: [0, n_itiles) one block per i-tile | [n_itiles, +nb_alch_atoms) alchemical atoms' bonded rows |
@@ -311,6 +312,7 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
                 for (int u = 0; u < 8; u++) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
             }
         }
+        if (wv == 0 && i >= 0 && A.frec) { f[0] += A.frec[i]; f[1] += A.frec[(size_t)A.n + i]; f[2] += A.frec[2 * (size_t)A.n + i]; }
         red[wv][0][lane] = f[0]; red[wv][1][lane] = f[1]; red[wv][2][lane] = f[2];
         __syncthreads();
         if (wv == 0 && i >= 0) {

@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from ._abi import SystemData
+from ._abi import NB_PME, NB_PME_DIRECT, SystemData
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 _ARRAY_FIELDS = ("box", "mass", "charge", "sigma", "epsilon", "exclusions", "exception_atoms", "exception_params",
@@ -21,11 +21,13 @@ _ARRAY_FIELDS = ("box", "mass", "charge", "sigma", "epsilon", "exclusions", "exc
                  "positions", "residue_of_atom")
 _SCALAR_FIELDS = ("restraint_k", "nonbonded_method", "cutoff", "ewald_alpha", "softcore_alpha",
                   "annihilate_electrostatics", "annihilate_sterics", "remove_cm_motion")
+_OPTIONAL_SCALARS = ("pme_order", "dispersion_correction")   # (files written before reciprocal space existed do not have them)
 
 
 def save_system(path, system: SystemData, **extra):
     d = {k: np.asarray(getattr(system, k)) for k in _ARRAY_FIELDS if getattr(system, k) is not None}
-    d.update({k: np.asarray(getattr(system, k)) for k in _SCALAR_FIELDS})
+    d.update({k: np.asarray(getattr(system, k)) for k in _SCALAR_FIELDS + _OPTIONAL_SCALARS})
+    d["pme_grid"] = np.asarray(system.pme_grid, dtype=np.int32)
     d.update({k: np.asarray(v) for k, v in extra.items()})
     np.savez_compressed(path, **d)
 
@@ -36,8 +38,37 @@ def load_system(path):
     for k in _SCALAR_FIELDS:
         v = z[k].item()
         kw[k] = v
+    for k in _OPTIONAL_SCALARS:
+        if k in z.files:
+            kw[k] = z[k].item()
+    if "pme_grid" in z.files:
+        kw["pme_grid"] = tuple(int(v) for v in z["pme_grid"])
     extra = {k: z[k] for k in z.files if k not in kw}
     return SystemData(**kw), extra
+
+
+def ewald_tolerance(alpha, cutoff):
+    """Inverse of alpha = sqrt(-ln(2 tol)) / cutoff (OpenMM NonbondedForceImpl::calcPMEParameters)."""
+    return 0.5 * np.exp(-(alpha * cutoff) ** 2)
+
+
+def pme_grid_for(box, alpha, cutoff, tol=None):
+    """Mesh OpenMM's Reference platform uses for ewaldErrorTolerance tol: ceil(2 alpha L / (3 tol^(1/5))) per edge, at least 6
+    [recalled: OpenMM 7.4.2 NonbondedForceImpl::calcPMEParameters; the GPU platforms round up further to FFT-friendly sizes]."""
+    if tol is None:
+        tol = ewald_tolerance(alpha, cutoff)
+    return tuple(max(6, int(np.ceil(2.0 * alpha * float(L) / (3.0 * tol ** 0.2) - 1e-9))) for L in np.asarray(box, dtype=np.float64).reshape(-1)[:3])
+
+
+def with_reciprocal_space(system: SystemData, dispersion_correction=True):
+    """The same system under nonbondedMethod=PME in full (reference blues/simulation.py:219 with examples/rotmove_cuda.yml:20):
+    direct space as before plus the reciprocal-space mesh, self term, excluded-pair corrections and the dispersion correction."""
+    s = copy.copy(system)
+    s.nonbonded_method = NB_PME
+    s.pme_grid = pme_grid_for(system.box, system.ewald_alpha, system.cutoff)
+    s.pme_order = 5
+    s.dispersion_correction = bool(dispersion_correction)
+    return s
 
 
 def freeze_atoms(system: SystemData, frozen_idx):
@@ -123,6 +154,8 @@ def tile_system(system: SystemData, reps):
         nonbonded_method=system.nonbonded_method, cutoff=system.cutoff, ewald_alpha=system.ewald_alpha,
         softcore_alpha=system.softcore_alpha, annihilate_electrostatics=system.annihilate_electrostatics,
         annihilate_sterics=system.annihilate_sterics, remove_cm_motion=system.remove_cm_motion,
+        pme_order=system.pme_order, dispersion_correction=system.dispersion_correction,
+        pme_grid=pme_grid_for(system.box * np.array(reps, dtype=np.float64), system.ewald_alpha, system.cutoff) if system.nonbonded_method == NB_PME else (0, 0, 0),
         positions=pos,
         residue_of_atom=None if res is None else np.concatenate([res + c * nres for c in range(ncopy)]).astype(np.int32),
         names=None if system.names is None else list(system.names) * ncopy,

@@ -33,11 +33,18 @@
 extern "C" {
 #endif
 
-#define BLUES_ABI_VERSION 1
+#define BLUES_ABI_VERSION 2
 
 /* nonbonded_method */
 #define BLUES_NB_NOCUTOFF 0   /* oracle only: vacuum systems (vacDivaline, two-body checks) */
 #define BLUES_NB_PME_DIRECT 1 /* periodic cutoff, erfc(alpha r)/r direct-space Coulomb + 12-6 LJ */
+#define BLUES_NB_PME 2        /* the same plus what OpenMM's NonbondedForce adds under nonbondedMethod=PME (reference
+                               * blues/simulation.py:219, examples/rotmove_cuda.yml:20): smooth-PME reciprocal space on
+                               * pme_grid (order-pme_order B-splines), the Ewald self term, the erf correction of every
+                               * excluded pair and, with dispersion_correction, the analytic long-range LJ correction.
+                               * Alchemical atoms take part with charge 0 and epsilon 0, as
+                               * alchemical_pme_treatment='direct-space' and disable_alchemical_dispersion_correction=True
+                               * leave them in the NonbondedForce (reference blues/simulation.py:225-236). */
 
 /*
  * Flat description of the alchemical System that
@@ -86,6 +93,10 @@ typedef struct BluesSystemDesc {
     int32_t annihilate_electrostatics; /* 1 */
     int32_t annihilate_sterics;        /* 0 */
     int32_t remove_cm_motion;      /* CMMotionRemover from removeCMMotion: True (examples/rotmove_cuda.yml:24) */
+    /* BLUES_NB_PME only (ignored otherwise) */
+    int32_t pme_grid[3];           /* mesh points along a,b,c: ceil(2 alpha L / (3 tol^(1/5))) for ewaldErrorTolerance tol */
+    int32_t pme_order;             /* B-spline order; OpenMM uses 5 */
+    int32_t dispersion_correction; /* NonbondedForce.getUseDispersionCorrection() (OpenMM's default: on) */
 } BluesSystemDesc;
 
 /*
@@ -139,8 +150,10 @@ int blues_set_velocities_to_temperature(BluesEngine *h, double temperature, uint
 int blues_get_energy(BluesEngine *h, double *potential, double *kinetic);
 /* per-term potential energies at the current state, for parity tests:
  * [0] bonds [1] angles [2] torsions [3] nonbonded env-env [4] exceptions
- * [5] alchemical sterics [6] alchemical electrostatics [7] restraint */
-#define BLUES_N_ENERGY_TERMS 8
+ * [5] alchemical sterics [6] alchemical electrostatics [7] restraint
+ * [8] Ewald reciprocal space (mesh + self term + erf corrections of excluded pairs + neutralising background)
+ * [9] long-range dispersion correction; [8], [9] are 0 unless BLUES_NB_PME */
+#define BLUES_N_ENERGY_TERMS 10
 int blues_get_energy_terms(BluesEngine *h, double terms[BLUES_N_ENERGY_TERMS]);
 
 /* integrator.step(n)  (reference blues/simulation.py:1082) */

@@ -98,7 +98,15 @@ struct Oracle {
     /* cell list scratch */
     int *cell_head, *cell_next;
     int ncell[3];
+    /* reciprocal space (BLUES_NB_PME) */
+    int pme_K[3], pme_order, disp_corr;
+    double *pme_mod[3];          /* B-spline moduli per axis */
+    double *pme_q, *pme_re, *pme_im, *pme_tr, *pme_ti;   /* charge mesh, its transform, scratch */
+    double *pme_cos[3], *pme_sin[3];
 };
+
+static void pme_setup(Oracle *o);
+static void reciprocal_space(Oracle *o, double *F, double *T);
 
 /* ------------------------------------------------------------------ RNG */
 static inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
@@ -253,7 +261,14 @@ Oracle *orc_create(const BluesSystemDesc *s, const BluesIntegratorDesc *it) {
     o->restr_k = s->restraint_k;
     o->nb_method = s->nonbonded_method; o->cutoff = s->cutoff; o->alpha_ewald = s->ewald_alpha; o->sc_alpha = s->softcore_alpha;
     o->annihilate_elec = s->annihilate_electrostatics; o->annihilate_sterics = s->annihilate_sterics; o->remove_cm = s->remove_cm_motion;
-    if (o->nb_method == BLUES_NB_PME_DIRECT)
+    if (o->nb_method == BLUES_NB_PME) {
+        o->pme_order = s->pme_order; o->disp_corr = s->dispersion_correction;
+        for (int d = 0; d < 3; d++) o->pme_K[d] = s->pme_grid[d];
+        if (o->pme_order < 2 || o->pme_order > 8 || o->pme_K[0] < o->pme_order || o->pme_K[1] < o->pme_order || o->pme_K[2] < o->pme_order) {
+            snprintf(g_err, sizeof g_err, "PME needs 2 <= order <= 8 and a mesh of at least `order` points per edge"); orc_destroy(o); return NULL; }
+        pme_setup(o);
+    }
+    if (o->nb_method == BLUES_NB_PME_DIRECT || o->nb_method == BLUES_NB_PME)
         for (int d = 0; d < 3; d++) if (o->box[d] < 2.0 * o->cutoff) { snprintf(g_err, sizeof g_err, "box edge %g < 2*cutoff", o->box[d]); orc_destroy(o); return NULL; }
     if (build_clusters(o)) { orc_destroy(o); return NULL; }
     /* integrator */
@@ -291,6 +306,8 @@ void orc_destroy(Oracle *o) {
     free(o->cluster_start); free(o->cluster_cons); free(o->alch_atoms); free(o->is_alch); free(o->restr_atoms);
     free(o->restr_x0); free(o->tab_ls); free(o->tab_le); free(o->x); free(o->v); free(o->xref); free(o->f);
     free(o->cell_head); free(o->cell_next);
+    for (int d = 0; d < 3; d++) { free(o->pme_mod[d]); free(o->pme_cos[d]); free(o->pme_sin[d]); }
+    free(o->pme_q); free(o->pme_re); free(o->pme_im); free(o->pme_tr); free(o->pme_ti);
     free(o);
 }
 
@@ -360,7 +377,7 @@ static inline void nb_pair(const Oracle *o, int i, int j, double ls, double le, 
     double d[3] = {o->x[3 * i] - o->x[3 * j], o->x[3 * i + 1] - o->x[3 * j + 1], o->x[3 * i + 2] - o->x[3 * j + 2]};
     min_image(o, d);
     double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    int pme = o->nb_method == BLUES_NB_PME_DIRECT;
+    int pme = (o->nb_method == BLUES_NB_PME_DIRECT || o->nb_method == BLUES_NB_PME);
     if (pme && r2 >= o->cutoff * o->cutoff) return;
     if (is_excluded(o, i, j)) return;
     if (o->custom_pair_mode == 1) { /* ethylene_system.xml:52: interaction group set1 x set2 only */
@@ -392,7 +409,7 @@ static inline void nb_pair(const Oracle *o, int i, int j, double ls, double le, 
 
 static void nonbonded(Oracle *o, double ls, double le, double *F, double *T) {
     int n = o->n;
-    int use_cells = o->nb_method == BLUES_NB_PME_DIRECT;
+    int use_cells = (o->nb_method == BLUES_NB_PME_DIRECT || o->nb_method == BLUES_NB_PME);
     int nc[3] = {1, 1, 1};
     if (use_cells) for (int d = 0; d < 3; d++) { nc[d] = (int)floor(o->box[d] / o->cutoff); if (nc[d] < 3) use_cells = 0; }
     if (!use_cells) {
@@ -532,12 +549,220 @@ static void bonded(const Oracle *o, double *F, double *T) {
     }
 }
 
+
+/* ------------------------------------------------------------------ reciprocal space (BLUES_NB_PME)
+ * What OpenMM's NonbondedForce adds under nonbondedMethod=PME on the Reference platform, restated from the published
+ * smooth particle-mesh Ewald algorithm (Essmann et al., J. Chem. Phys. 103, 8577 (1995)) in the form OpenMM 7.4.2's
+ * ReferencePME.cpp uses it [recalled -- OpenMM is not under /root/reference]: order-5 cardinal B-splines, charges spread on
+ * the mesh points (floor(u) + k) mod K, k = 0..order-1, forward transform, multiplication by
+ *     eterm(m) = ONE_4PI_EPS0 exp(-pi^2 m^2 / alpha^2) / (pi V m^2 |b_x(m_x) b_y(m_y) b_z(m_z)|^2),
+ * E = 1/2 sum_m eterm |Q^(m)|^2, backward transform, forces from the spline derivatives; then the Ewald self term
+ * -ONE_4PI_EPS0 alpha/sqrt(pi) sum q_i^2, -ONE_4PI_EPS0 q_i q_j erf(alpha r)/r for every excluded pair, and the neutralising
+ * background -pi ONE_4PI_EPS0 Q^2 / (2 V alpha^2).  The charges are the NonbondedForce's: alchemical atoms enter with 0
+ * (alchemical_pme_treatment='direct-space', reference blues/simulation.py:225-236), and with epsilon 0 in the dispersion
+ * correction (disable_alchemical_dispersion_correction=True).  Transforms are plain separable DFTs (meshes are ~20-40 points
+ * per edge): this is a checker, not a fast code. */
+static void pme_bsplines(double dr, int order, double *w, double *dw) {
+    w[order - 1] = 0.0; w[1] = dr; w[0] = 1.0 - dr;
+    for (int l = 3; l < order; l++) {
+        const double div = 1.0 / (l - 1.0);
+        w[l - 1] = div * dr * w[l - 2];
+        for (int k = 1; k < l - 1; k++) w[l - k - 1] = div * ((dr + k) * w[l - k - 2] + (l - k - dr) * w[l - k - 1]);
+        w[0] = div * (1.0 - dr) * w[0];
+    }
+    if (dw) { dw[0] = -w[0]; for (int k = 1; k < order; k++) dw[k] = w[k - 1] - w[k]; }
+    const double div = 1.0 / (order - 1.0);
+    w[order - 1] = div * dr * w[order - 2];
+    for (int k = 1; k < order - 1; k++) w[order - k - 1] = div * ((dr + k) * w[order - k - 2] + (order - k - dr) * w[order - k - 1]);
+    w[0] = div * (1.0 - dr) * w[0];
+}
+
+static void pme_setup(Oracle *o) {
+    const int order = o->pme_order;
+    double w[8];
+    pme_bsplines(0.0, order, w, NULL);
+    for (int d = 0; d < 3; d++) {
+        const int K = o->pme_K[d];
+        o->pme_mod[d] = malloc(sizeof(double) * K); o->pme_cos[d] = malloc(sizeof(double) * K); o->pme_sin[d] = malloc(sizeof(double) * K);
+        for (int m = 0; m < K; m++) {
+            o->pme_cos[d][m] = cos(2.0 * M_PI * m / K); o->pme_sin[d][m] = sin(2.0 * M_PI * m / K);
+            double sc = 0.0, ss = 0.0;
+            for (int k = 0; k < order; k++) { const double a = 2.0 * M_PI * m * (k + 1) / K; sc += w[k] * cos(a); ss += w[k] * sin(a); }
+            o->pme_mod[d][m] = sc * sc + ss * ss;
+        }
+        for (int m = 0; m < K; m++) if (o->pme_mod[d][m] < 1e-7) o->pme_mod[d][m] = 0.5 * (o->pme_mod[d][(m + K - 1) % K] + o->pme_mod[d][(m + 1) % K]);
+    }
+    const size_t ng = (size_t)o->pme_K[0] * o->pme_K[1] * o->pme_K[2];
+    o->pme_q = malloc(sizeof(double) * ng); o->pme_re = malloc(sizeof(double) * ng); o->pme_im = malloc(sizeof(double) * ng);
+    o->pme_tr = malloc(sizeof(double) * ng); o->pme_ti = malloc(sizeof(double) * ng);
+}
+
+/* separable DFT of (re, im) in place; sign -1 forward, +1 backward (no normalisation) */
+static void pme_dft3(const Oracle *o, double *re, double *im, double *tr, double *ti, int sign) {
+    const int K0 = o->pme_K[0], K1 = o->pme_K[1], K2 = o->pme_K[2];
+    const int dims[3] = {K0, K1, K2};
+    const size_t stride[3] = {(size_t)K1 * K2, (size_t)K2, 1};
+    for (int ax = 2; ax >= 0; ax--) {
+        const int K = dims[ax]; const size_t st = stride[ax];
+        const size_t ng = (size_t)K0 * K1 * K2;
+        for (size_t base = 0; base < ng; base++) {
+            if ((base / st) % K) continue;   /* first element of a line along ax */
+            for (int m = 0; m < K; m++) {
+                double sr = 0.0, si = 0.0;
+                for (int k = 0; k < K; k++) {
+                    const int t = (int)(((long)m * k) % K);
+                    const double c = o->pme_cos[ax][t], s_ = sign * o->pme_sin[ax][t];
+                    const double a = re[base + k * st], b = im[base + k * st];
+                    sr += a * c - b * s_; si += a * s_ + b * c;
+                }
+                tr[base + m * st] = sr; ti[base + m * st] = si;
+            }
+        }
+        memcpy(re, tr, sizeof(double) * ng); memcpy(im, ti, sizeof(double) * ng);
+    }
+}
+
+static double dispersion_correction(const Oracle *o) {
+    /* [recalled: OpenMM NonbondedForceImpl::calcDispersionCorrection, no switching function]: atoms grouped by (sigma, epsilon);
+     * pairs of classes counted n_i (n_i + 1) / 2 and n_i n_j, normalised by N (N + 1) / 2; E = 8 pi N^2 (S12 / (9 rc^9) - S6 / (3 rc^3)) / V */
+    const int n = o->n;
+    double *cs = malloc(sizeof(double) * n), *ce = malloc(sizeof(double) * n); long *cn = calloc(n, sizeof(long));
+    int nc = 0;
+    for (int i = 0; i < n; i++) {
+        const double e = o->is_alch[i] ? 0.0 : o->eps[i], sg = o->sigma[i];
+        int c = -1;
+        for (int q = 0; q < nc; q++) if (cs[q] == sg && ce[q] == e) { c = q; break; }
+        if (c < 0) { c = nc++; cs[c] = sg; ce[c] = e; }
+        cn[c]++;
+    }
+    double s12 = 0.0, s6 = 0.0;
+    for (int a = 0; a < nc; a++) for (int b = a; b < nc; b++) {
+        const double cnt = a == b ? 0.5 * cn[a] * (cn[a] + 1.0) : (double)cn[a] * cn[b];
+        const double sg = 0.5 * (cs[a] + cs[b]), e = sqrt(ce[a] * ce[b]);
+        const double s2 = sg * sg, s6_ = s2 * s2 * s2;
+        s12 += cnt * e * s6_ * s6_; s6 += cnt * e * s6_;
+    }
+    const double tot = 0.5 * n * (n + 1.0);
+    s12 /= tot; s6 /= tot;
+    free(cs); free(ce); free(cn);
+    const double rc = o->cutoff, rc3 = rc * rc * rc, rc9 = rc3 * rc3 * rc3;
+    const double V = o->box[0] * o->box[1] * o->box[2];
+    return 8.0 * n * (double)n * M_PI * (s12 / (9.0 * rc9) - s6 / (3.0 * rc3)) / V;
+}
+
+static void reciprocal_space(Oracle *o, double *F, double *T) {
+    const int n = o->n, order = o->pme_order;
+    const int K0 = o->pme_K[0], K1 = o->pme_K[1], K2 = o->pme_K[2];
+    const size_t ng = (size_t)K0 * K1 * K2;
+    const double V = o->box[0] * o->box[1] * o->box[2], alpha = o->alpha_ewald;
+    memset(o->pme_q, 0, sizeof(double) * ng);
+    int *idx = malloc(sizeof(int) * 3 * n); double *w = malloc(sizeof(double) * 3 * 8 * n), *dw = malloc(sizeof(double) * 3 * 8 * n);
+    double qsum = 0.0, q2sum = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double q = o->is_alch[i] ? 0.0 : o->charge[i];
+        qsum += q; q2sum += q * q;
+        for (int d = 0; d < 3; d++) {
+            double fr = o->x[3 * i + d] / o->box[d]; fr -= floor(fr);
+            double u = fr * o->pme_K[d]; int ti = (int)u; double dr = u - ti;
+            if (ti >= o->pme_K[d]) { ti -= o->pme_K[d]; }
+            idx[3 * i + d] = ti;
+            pme_bsplines(dr, order, w + (3 * i + d) * 8, dw + (3 * i + d) * 8);
+        }
+        if (q == 0.0) continue;
+        for (int a = 0; a < order; a++) for (int b = 0; b < order; b++) for (int c = 0; c < order; c++) {
+            const int ix = (idx[3 * i] + a) % K0, iy = (idx[3 * i + 1] + b) % K1, iz = (idx[3 * i + 2] + c) % K2;
+            o->pme_q[((size_t)ix * K1 + iy) * K2 + iz] += q * w[(3 * i) * 8 + a] * w[(3 * i + 1) * 8 + b] * w[(3 * i + 2) * 8 + c];
+        }
+    }
+    memcpy(o->pme_re, o->pme_q, sizeof(double) * ng); memset(o->pme_im, 0, sizeof(double) * ng);
+    pme_dft3(o, o->pme_re, o->pme_im, o->pme_tr, o->pme_ti, -1);
+    double esum = 0.0;
+    for (int kx = 0; kx < K0; kx++) for (int ky = 0; ky < K1; ky++) for (int kz = 0; kz < K2; kz++) {
+        const size_t g = ((size_t)kx * K1 + ky) * K2 + kz;
+        if (kx == 0 && ky == 0 && kz == 0) { o->pme_re[g] = 0.0; o->pme_im[g] = 0.0; continue; }
+        const double mx = (kx < (K0 + 1) / 2 ? kx : kx - K0) / o->box[0], my = (ky < (K1 + 1) / 2 ? ky : ky - K1) / o->box[1], mz = (kz < (K2 + 1) / 2 ? kz : kz - K2) / o->box[2];
+        const double m2 = mx * mx + my * my + mz * mz;
+        const double eterm = ONE_4PI_EPS0 * exp(-M_PI * M_PI * m2 / (alpha * alpha)) / (M_PI * V * m2 * o->pme_mod[0][kx] * o->pme_mod[1][ky] * o->pme_mod[2][kz]);
+        esum += eterm * (o->pme_re[g] * o->pme_re[g] + o->pme_im[g] * o->pme_im[g]);
+        o->pme_re[g] *= eterm; o->pme_im[g] *= eterm;
+    }
+    double E = 0.5 * esum;
+    if (F) {
+        pme_dft3(o, o->pme_re, o->pme_im, o->pme_tr, o->pme_ti, +1);
+        for (int i = 0; i < n; i++) {
+            const double q = o->is_alch[i] ? 0.0 : o->charge[i];
+            if (q == 0.0) continue;
+            double fx = 0.0, fy = 0.0, fz = 0.0;
+            for (int a = 0; a < order; a++) for (int b = 0; b < order; b++) for (int c = 0; c < order; c++) {
+                const int ix = (idx[3 * i] + a) % K0, iy = (idx[3 * i + 1] + b) % K1, iz = (idx[3 * i + 2] + c) % K2;
+                const double phi = o->pme_re[((size_t)ix * K1 + iy) * K2 + iz];
+                const double wx = w[(3 * i) * 8 + a], wy = w[(3 * i + 1) * 8 + b], wz = w[(3 * i + 2) * 8 + c];
+                fx += dw[(3 * i) * 8 + a] * wy * wz * phi; fy += wx * dw[(3 * i + 1) * 8 + b] * wz * phi; fz += wx * wy * dw[(3 * i + 2) * 8 + c] * phi;
+            }
+            F[3 * i] -= q * fx * K0 / o->box[0]; F[3 * i + 1] -= q * fy * K1 / o->box[1]; F[3 * i + 2] -= q * fz * K2 / o->box[2];
+        }
+    }
+    free(idx); free(w); free(dw);
+    /* self term, neutralising background */
+    E -= ONE_4PI_EPS0 * alpha / sqrt(M_PI) * q2sum;
+    E -= M_PI * ONE_4PI_EPS0 * qsum * qsum / (2.0 * V * alpha * alpha);
+    /* excluded pairs: their reciprocal-space interaction is taken out again */
+    for (int i = 0; i < n; i++) {
+        const double qi = o->is_alch[i] ? 0.0 : o->charge[i];
+        if (qi == 0.0) continue;
+        for (int e = o->excl_start[i]; e < o->excl_start[i + 1]; e++) {
+            const int j = o->excl_list[e];
+            if (j <= i) continue;
+            const double qj = o->is_alch[j] ? 0.0 : o->charge[j];
+            if (qj == 0.0) continue;
+            double d[3] = {o->x[3 * i] - o->x[3 * j], o->x[3 * i + 1] - o->x[3 * j + 1], o->x[3 * i + 2] - o->x[3 * j + 2]};
+            min_image(o, d);
+            const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], r = sqrt(r2), pre = ONE_4PI_EPS0 * qi * qj;
+            const double er = erf(alpha * r);
+            E -= pre * er / r;
+            if (F) {
+                /* -d/dr [ -pre erf(ar)/r ] / r along d */
+                const double dEdr = -pre * (2.0 * alpha / sqrt(M_PI) * exp(-alpha * alpha * r2) / r - er / r2);
+                const double fs = -dEdr / r;
+                for (int k = 0; k < 3; k++) { F[3 * i + k] += fs * d[k]; F[3 * j + k] -= fs * d[k]; }
+            }
+        }
+    }
+    T[8] += E;
+    if (o->disp_corr) T[9] += dispersion_correction(o);
+}
+
+/* exact Ewald reciprocal sum of the same charges (test helper: what the mesh approximates):
+ * (2 pi ONE_4PI_EPS0 / V) sum_{k != 0} exp(-k^2 / 4 alpha^2) / k^2 |S(k)|^2 over k = 2 pi (m_x/L_x, ...) with |m_d| <= mmax */
+double orc_ewald_reciprocal_exact(Oracle *o, int mmax) {
+    const int n = o->n;
+    const double V = o->box[0] * o->box[1] * o->box[2], alpha = o->alpha_ewald;
+    double E = 0.0;
+    for (int mx = -mmax; mx <= mmax; mx++) for (int my = -mmax; my <= mmax; my++) for (int mz = -mmax; mz <= mmax; mz++) {
+        if (!mx && !my && !mz) continue;
+        const double k[3] = {2.0 * M_PI * mx / o->box[0], 2.0 * M_PI * my / o->box[1], 2.0 * M_PI * mz / o->box[2]};
+        const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+        const double g = exp(-k2 / (4.0 * alpha * alpha)) / k2;
+        if (g < 1e-16) continue;
+        double sr = 0.0, si = 0.0;
+        for (int i = 0; i < n; i++) {
+            const double q = o->is_alch[i] ? 0.0 : o->charge[i];
+            if (q == 0.0) continue;
+            const double ph = k[0] * o->x[3 * i] + k[1] * o->x[3 * i + 1] + k[2] * o->x[3 * i + 2];
+            sr += q * cos(ph); si += q * sin(ph);
+        }
+        E += g * (sr * sr + si * si);
+    }
+    return 2.0 * M_PI * ONE_4PI_EPS0 / V * E;
+}
+
 double orc_energy_forces(Oracle *o, double ls, double le, double *forces, double *terms) {
     double T[BLUES_N_ENERGY_TERMS] = {0};
     if (forces) memset(forces, 0, sizeof(double) * 3 * o->n);
     bonded(o, forces, T);
     nonbonded(o, ls, le, forces, T);
     exceptions(o, ls, le, forces, T);
+    if (o->nb_method == BLUES_NB_PME) reciprocal_space(o, forces, T);
     double E = 0.0;
     for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) E += T[t];
     if (terms) memcpy(terms, T, sizeof T);

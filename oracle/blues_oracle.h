@@ -62,6 +62,9 @@ long orc_num_evaluations(Oracle *o);
 void orc_set_custom_pair_mode(Oracle *o, int mode);
 int orc_add_centroid_bond(Oracle *o, int n1, const int *i1, const double *w1, int n2, const int *i2, const double *w2, double k);
 
+/* exact Ewald reciprocal-space energy of the NonbondedForce charges (what the PME mesh approximates), |m| <= mmax per axis */
+double orc_ewald_reciprocal_exact(Oracle *o, int mmax);
+
 /* plain steepest-descent relaxation with constraints (used to prepare fixtures) */
 double orc_minimize(Oracle *o, int max_iter, double step0);
 

@@ -49,6 +49,7 @@ def lib():
         L.orc_set_custom_pair_mode.argtypes = [H, C.c_int]; L.orc_set_custom_pair_mode.restype = None
         L.orc_add_centroid_bond.argtypes = [H, C.c_int, C.POINTER(C.c_int), _dp, C.c_int, C.POINTER(C.c_int), _dp, C.c_double]; L.orc_add_centroid_bond.restype = C.c_int
         L.orc_minimize.argtypes = [H, C.c_int, C.c_double]; L.orc_minimize.restype = C.c_double
+        L.orc_ewald_reciprocal_exact.argtypes = [H, C.c_int]; L.orc_ewald_reciprocal_exact.restype = C.c_double
         L.orc_default_lambda_sterics.argtypes = [C.c_double]; L.orc_default_lambda_sterics.restype = C.c_double
         L.orc_default_lambda_electrostatics.argtypes = [C.c_double]; L.orc_default_lambda_electrostatics.restype = C.c_double
         L.orc_get_prop_lambda.argtypes = [C.c_double, _dp]; L.orc_get_prop_lambda.restype = None
@@ -145,6 +146,9 @@ class Oracle:
         a1 = np.ascontiguousarray(w1, dtype=np.float64); a2 = np.ascontiguousarray(w2, dtype=np.float64)
         if self._L.orc_add_centroid_bond(self._h, len(idx1), i1, _ptr(a1), len(idx2), i2, _ptr(a2), float(k)):
             raise RuntimeError("too many centroid bonds")
+
+    def ewald_reciprocal_exact(self, mmax=12):
+        return self._L.orc_ewald_reciprocal_exact(self._h, int(mmax))
 
     def minimize(self, max_iter=200, step0=0.01):
         return self._L.orc_minimize(self._h, int(max_iter), float(step0))

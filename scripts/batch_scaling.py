@@ -11,9 +11,12 @@ from blues_amd.replicas import replica_seed
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="rotmove")
 ap.add_argument("--nsteps", type=int, default=400)
+ap.add_argument("--pme", action="store_true")
 ap.add_argument("R", nargs="*", type=int, default=[1, 2, 4, 8, 16, 32])
 a = ap.parse_args()
 system, vel = systems.s23k(frozen=False) if a.workload == "water" else systems.s23k(mobile_atoms=275, frozen=True)
+if a.pme:
+    system = systems.with_reciprocal_space(system)
 rng = np.random.RandomState(3)
 for R in a.R:
     engs = []

@@ -34,7 +34,7 @@ def make_tol_box():
     prm = amber.read_prmtop(os.path.join(REF, "TOL-parm.prmtop"))
     pos, _, box = amber.read_inpcrd(os.path.join(REF, "TOL-parm.inpcrd"))
     s = amber.system_from_amber(prm, pos, box, cutoff=1.0, ewald_error_tolerance=0.005, constraints="HBonds",
-                                rigid_water=True, hydrogen_mass=3.024, remove_cm_motion=True,
+                                rigid_water=True, hydrogen_mass=3.024, remove_cm_motion=True, reciprocal_space=False,
                                 alchemical_atoms=range(15))
     print("atoms", s.n_atoms, "box", s.box, "constraints", len(s.constraint_dist), "bonds", len(s.bond_atoms),
           "angles", len(s.angle_atoms), "torsions", len(s.torsion_atoms), "excl", len(s.exclusions), "exc14", len(s.exception_atoms))

@@ -105,6 +105,10 @@ def test_amber_reader_on_reference_fixture(known_answers, tol_box):
     assert np.array_equal(s.exclusions, ref.exclusions) and np.allclose(s.exception_params, ref.exception_params)
     # toluene charges (e), reference TOL-parm.prmtop:64-66 / 18.2223
     assert np.allclose(s.charge[:3], [-0.0538, -0.0773, -0.131], atol=5e-5) and np.allclose(s.charge[15:18], [-0.834, 0.417, 0.417], atol=1e-6)
+    # createSystem(nonbondedMethod=PME) in full by default: the mesh of OpenMM's Reference platform at ewaldErrorTolerance 0.005
+    from blues_amd._abi import NB_PME, NB_PME_DIRECT
+    assert s.nonbonded_method == NB_PME and tuple(s.pme_grid) == (9, 9, 9) and s.pme_order == 5 and s.dispersion_correction
+    assert amber.system_from_amber(prm, pos, box, reciprocal_space=False).nonbonded_method == NB_PME_DIRECT
 
 
 def test_s23k_construction():
