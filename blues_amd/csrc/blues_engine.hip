@@ -1098,14 +1098,37 @@ template <typename T> static void pme_ensure_static(BluesEngine* h) {
 }
 template <typename T> static int launch_pme_t(BluesEngine* h, int want_energy) {
     if (batch_dry(h)) return 0;
+    // mixed precision with a mesh whose half spectrum fits two LDS buffers: the pruned in-LDS pipeline (k_pme_fast); otherwise
+    // (double precision, large meshes) the general one on global memory
+    bool fast = false; size_t lds = 0;
+    if constexpr (sizeof(T) == 4) {
+        fast = (size_t)h->pme_K[0] * h->pme_K[1] * (h->pme_K[2] / 2 + 1) <= PME_LDS_Y && !getenv("BLUES_PME_GENERAL");
+        lds = PME_FAST_LDS(h->pme_K[0], h->pme_K[1], h->pme_K[2]);
+        if (fast) {
+            static thread_local size_t lds_set[2] = {0, 0};
+            const bool lead = batch_lead(h);
+            if (lds > lds_set[lead]) {
+                hipError_t e = lead ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pme_fast_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                    : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pme_fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) E_FAIL(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
+                lds_set[lead] = lds;
+            }
+        }
+    }
     if (batch_lead(h)) {
         // the shared launch reads every member's static meshes: whoever's are stale gets them first (lone launches, same stream)
         for (BluesEngine* m : h->batch->eng) if (m->pme) pme_ensure_static<T>(m);
-        hipLaunchKernelGGL(k_pme_b<T>, dim3(h->batch->R()), dim3(PME_THREADS), 0, h->cur, batch_reps_nb<T>(h->batch), want_energy);
+        if constexpr (sizeof(T) == 4) {
+            if (fast) hipLaunchKernelGGL(k_pme_fast_b, dim3(h->batch->R()), dim3(PME_THREADS), lds, h->cur, h->batch->d_nb_f.p, want_energy);
+            else hipLaunchKernelGGL(k_pme_b<T>, dim3(h->batch->R()), dim3(PME_THREADS), 0, h->cur, batch_reps_nb<T>(h->batch), want_energy);
+        } else hipLaunchKernelGGL(k_pme_b<T>, dim3(h->batch->R()), dim3(PME_THREADS), 0, h->cur, batch_reps_nb<T>(h->batch), want_energy);
     } else {
         pme_ensure_static<T>(h);
         PmeArgs<T> P = make_pme_args<T>(h, false); P.want_energy = want_energy;
-        hipLaunchKernelGGL((k_pme<T, false>), dim3(1), dim3(PME_THREADS), 0, h->cur, P);
+        if constexpr (sizeof(T) == 4) {
+            if (fast) hipLaunchKernelGGL(k_pme_fast, dim3(1), dim3(PME_THREADS), lds, h->cur, P);
+            else hipLaunchKernelGGL((k_pme<T, false>), dim3(1), dim3(PME_THREADS), 0, h->cur, P);
+        } else hipLaunchKernelGGL((k_pme<T, false>), dim3(1), dim3(PME_THREADS), 0, h->cur, P);
     }
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
@@ -1787,7 +1810,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     if (s->nonbonded_method == BLUES_NB_PME) {
         h->pme = true; h->pme_order = s->pme_order; h->disp_corr = s->dispersion_correction;
         for (int d = 0; d < 3; d++) { h->pme_K[d] = s->pme_grid[d]; if (h->pme_K[d] < s->pme_order || h->pme_K[d] > 256) E_FAIL(h, "PME mesh %d along axis %d is outside [order, 256]", h->pme_K[d], d); }
-        if (h->pme_order < 2 || h->pme_order > PME_MAX_ORDER) E_FAIL(h, "PME order %d is outside [2, %d]", h->pme_order, PME_MAX_ORDER);
+        if (h->pme_order != 5) E_FAIL(h, "PME order %d: the engine implements order 5 (OpenMM's PME_ORDER)", h->pme_order);
     }
     const int n = h->n = s->n_atoms;
     if (n <= 0) E_FAIL(h, "empty system");
@@ -2106,6 +2129,9 @@ int blues_get_forces(BluesEngine* h, double* out, int32_t n_atoms) {
     h->st_launches++;
     if (check_flags(h)) return 1;
     HIP_OK(h, hipMemcpy(out, tmp.p, sizeof(double) * 3 * h->n, hipMemcpyDeviceToHost));
+#ifdef BLUES_STAMP
+    if (h->pme) { long long st[32]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nb_stamps), sizeof st); fprintf(stderr, "[stamps] pme_fast (cycles since start: cache+region, spread, to X, forward, eterm, backward, gather):"); for (int i = 10; i < 17; i++) fprintf(stderr, " %lld", st[i] - st[9]); fprintf(stderr, "\n"); }
+#endif
     return 0;
 }
 
@@ -2271,7 +2297,8 @@ int blues_time_nonbonded(BluesEngine* h, int32_t reps, double* usec) {
     HIP_OK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *usec = 1000.0 * ms / std::max(1, reps);
 #ifdef BLUES_STAMP
-    { long long st[32]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nb_stamps), sizeof st); fprintf(stderr, "[stamps] nonbonded_atom (cycles since start):"); for (int i = 17; i < 28; i++) fprintf(stderr, " %lld", st[i] - st[16]); fprintf(stderr, "\n"); }
+    { long long st[40]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nb_stamps), sizeof(long long) * 32); fprintf(stderr, "[stamps] nonbonded_atom (cycles since start):"); for (int i = 17; i < 28; i++) fprintf(stderr, " %lld", st[i] - st[16]); fprintf(stderr, "\n");
+      fprintf(stderr, "[stamps] last kernel that stamped 0..7 (pme_fast: cache+region, spread, to X, fwd, eterm, bwd, gather):"); for (int i = 10; i < 17; i++) fprintf(stderr, " %lld", st[i] - st[9]); fprintf(stderr, "\n"); }
 #endif
     return check_flags(h);
 }

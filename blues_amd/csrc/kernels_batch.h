@@ -138,7 +138,14 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_b(const RepNb<R>* __restric
     const RepNb<R>& rp = reps[blockIdx.x];
     if (!rp.active) return;
     PmeArgs<R> P = rp.pme; P.want_energy = want_energy;
-    pme_body<R, false>(P);
+    pme_body<R, false, 5>(P);
+}
+
+__global__ void __launch_bounds__(PME_THREADS) k_pme_fast_b(const RepNb<float>* __restrict__ reps, int want_energy) {
+    const RepNb<float>& rp = reps[blockIdx.x];
+    if (!rp.active) return;
+    PmeArgs<float> P = rp.pme; P.want_energy = want_energy;
+    pme_fast_body<5>(P);
 }
 
 template <bool FAST, int MASK>
