@@ -27,6 +27,9 @@
 #include "blues_oracle.h"
 
 #include <math.h>
+#ifdef ORC_OPENMP
+#include <omp.h>
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -429,6 +432,37 @@ static void nonbonded(Oracle *o, double ls, double le, double *F, double *T) {
         int c = (ci[0] * nc[1] + ci[1]) * nc[2] + ci[2];
         cell_of[i] = c; o->cell_next[i] = o->cell_head[c]; o->cell_head[c] = i;
     }
+#ifdef ORC_OPENMP
+    /* CPU baseline (ii) of SURVEY.md 8(d): the same pair loop on all cores.  Cells are dealt to the threads statically and the
+     * thread-private force / energy arrays are summed in thread order, so a run is reproducible for a given thread count. */
+    const int nt = omp_get_max_threads();
+    double *Fp = F ? calloc((size_t)nt * 3 * n, sizeof(double)) : NULL;
+    double *Tp = calloc((size_t)nt * BLUES_N_ENERGY_TERMS, sizeof(double));
+#pragma omp parallel
+    {
+        const int th = omp_get_thread_num();
+        double *Ft = F ? Fp + (size_t)th * 3 * n : NULL, *Tt = Tp + (size_t)th * BLUES_N_ENERGY_TERMS;
+#pragma omp for schedule(static)
+        for (int c = 0; c < ncell; c++) {
+            const int cx = c / (nc[1] * nc[2]), cy = (c / nc[2]) % nc[1], cz = c % nc[2];
+            for (int dx = -1; dx <= 1; dx++) for (int dy = -1; dy <= 1; dy++) for (int dz = -1; dz <= 1; dz++) {
+                int ox = (cx + dx + nc[0]) % nc[0], oy = (cy + dy + nc[1]) % nc[1], oz = (cz + dz + nc[2]) % nc[2];
+                int c2 = (ox * nc[1] + oy) * nc[2] + oz;
+                if (c2 < c) continue;
+                for (int i = o->cell_head[c]; i >= 0; i = o->cell_next[i])
+                    for (int j = o->cell_head[c2]; j >= 0; j = o->cell_next[j]) {
+                        if (c2 == c && j <= i) continue;
+                        nb_pair(o, i, j, ls, le, Ft, Tt);
+                    }
+            }
+        }
+    }
+    for (int th = 0; th < nt; th++) {
+        if (F) for (int q = 0; q < 3 * n; q++) F[q] += Fp[(size_t)th * 3 * n + q];
+        for (int q = 0; q < BLUES_N_ENERGY_TERMS; q++) T[q] += Tp[(size_t)th * BLUES_N_ENERGY_TERMS + q];
+    }
+    free(Fp); free(Tp);
+#else
     for (int cx = 0; cx < nc[0]; cx++) for (int cy = 0; cy < nc[1]; cy++) for (int cz = 0; cz < nc[2]; cz++) {
         int c = (cx * nc[1] + cy) * nc[2] + cz;
         for (int dx = -1; dx <= 1; dx++) for (int dy = -1; dy <= 1; dy++) for (int dz = -1; dz <= 1; dz++) {
@@ -442,6 +476,7 @@ static void nonbonded(Oracle *o, double ls, double le, double *F, double *T) {
                 }
         }
     }
+#endif
     free(cell_of);
 }
 

@@ -14,23 +14,36 @@ from blues_amd._abi import (BluesIntegratorDesc, BluesSystemDesc, IntegratorData
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libblues_oracle.so")
+_LIB_PATH_OMP = os.path.join(_HERE, "_build", "libblues_oracle_omp.so")   # pair loop on all cores (cpu_baseline only)
 _dp = C.POINTER(C.c_double)
 _lib = None
+_lib_omp = None
 
 
 def build(force=False):
     src = os.path.join(_HERE, "blues_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    if force or not os.path.exists(_LIB_PATH) or not os.path.exists(_LIB_PATH_OMP) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
-def lib():
-    global _lib
+def lib(openmp=False):
+    global _lib, _lib_omp
+    if openmp:
+        if _lib_omp is None:
+            if not os.path.exists(_LIB_PATH_OMP):
+                build()
+            _lib_omp = _declare(C.CDLL(_LIB_PATH_OMP))
+        return _lib_omp
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        _lib = _declare(C.CDLL(_LIB_PATH))
+    return _lib
+
+
+def _declare(L):
+    if True:   # (argument and result types of every entry point)
         H = C.c_void_p
         L.orc_create.argtypes = [C.POINTER(BluesSystemDesc), C.POINTER(BluesIntegratorDesc)]; L.orc_create.restype = H
         L.orc_destroy.argtypes = [H]; L.orc_destroy.restype = None
@@ -57,8 +70,7 @@ def lib():
         L.orc_philox4x32.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]; L.orc_philox4x32.restype = None
         L.orc_gaussians.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp]; L.orc_gaussians.restype = None
         L.orc_pair_energy.argtypes = [C.c_double] * 5 + [C.c_int] + [C.c_double] * 3 + [_dp]; L.orc_pair_energy.restype = C.c_double
-        _lib = L
-    return _lib
+    return L
 
 
 def _ptr(a):
@@ -68,8 +80,8 @@ def _ptr(a):
 class Oracle:
     """One alchemical NCMC context + integrator on the CPU (fp64)."""
 
-    def __init__(self, system: SystemData, integrator: IntegratorData):
-        self._L = lib()
+    def __init__(self, system: SystemData, integrator: IntegratorData, openmp=False):
+        self._L = lib(openmp)
         sd, self._keep_s = system.to_desc()
         idesc, self._keep_i = integrator.to_desc()
         self._h = self._L.orc_create(C.byref(sd), C.byref(idesc))
