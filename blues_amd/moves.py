@@ -5,12 +5,15 @@ Moves are host-side geometry on a handful of atoms, executed once or thrice per 
 they talk to the engine only through Context.getState / setPositions / setVelocities,
 exactly as in the reference, so third-party Move subclasses work unchanged.
 """
+import logging
 import sys
 import traceback
 
 import numpy
 
 from . import unit
+
+logger = logging.getLogger(__name__)
 
 
 class Move(object):
@@ -165,6 +168,144 @@ class WaterTranslationMove(Move):
         box = numpy.diag(numpy.asarray(st.getPeriodicBoxVectors(asNumpy=True)._value))
         if self._distance(x, self.atom_indices[0], self._centre(x), box) > self.radius and self.go:
             context._integrator.setGlobalVariableByName("protocol_work", 999999)
+        return context
+
+
+class SideChainMove(Move):
+    """Side-chain torsion move chosen the way the reference chooses it (blues/moves.py:418-844), with the bookkeeping the reference
+    delegates to OpenEye re-derived from the bonded graph alone:
+
+      * backbone atoms (getBackboneAtoms, :483-509): the atoms named N, CA, C, O (OEIsBackboneAtom's heavy set), when names are given;
+      * query atoms (getTargetAtoms, :511-558): the non-backbone atoms of the residues in `residue_list`, water left out;
+      * rotatable heavy bonds (findHeavyRotBonds, :560-601): bonds of a query atom whose two ends are heavy and that OEBond::IsRotor()
+        would accept -- here: not in a ring (removing the bond disconnects its ends) and not terminal (each end has another heavy
+        neighbour).  Bond orders are not in an Amber topology, so multiple bonds are recognised only by being terminal or in rings;
+      * rotating atoms (getRotAtoms, :603-669): [axis1, axis2] followed by what the reference's bounded breadth-first walk from the
+        non-backbone axis atoms collects (neighbours, and neighbours of heavy neighbours, never crossing axis2 or the backbone) --
+        restated as written, quirks included (the walk starts from BOTH non-backbone axis atoms);
+      * chooseBondandTheta (:703-729): uniform residue, uniform bond of it, theta uniform in [0, 2 pi);
+      * move (:752-844): Rodrigues rotation (rotation_matrix, :731-750) of the target atoms about axis1 - axis2 through axis2.
+
+    `atom_indices` is the reference's nested dict {residue: {bond: [atoms]}} (its quirk: SimulationFactory receives dict keys,
+    SURVEY.md Appendix E); `alchemical_atoms` gives the flat list a System needs."""
+
+    BACKBONE_NAMES = ("N", "CA", "C", "O")
+
+    def __init__(self, system, residue_list, names=None, verbose=False, write_move=False, random_state=None):
+        self.residue_list = list(residue_list)
+        self.verbose, self.write_move = verbose, write_move
+        self.random_state = random_state if isinstance(random_state, numpy.random.RandomState) else numpy.random.RandomState(random_state)
+        n = system.n_atoms
+        names = names if names is not None else system.names
+        res = numpy.asarray(system.residue_of_atom if system.residue_of_atom is not None else numpy.zeros(n, int))
+        heavy = numpy.asarray(system.mass) > 3.5   # (hydrogen mass repartitioning puts hydrogens at ~3 Da; frozen atoms have mass 0: names, when given, decide)
+        if names is not None:
+            heavy = numpy.array([not str(nm).strip().upper().startswith("H") for nm in names])
+        nbr = [[] for _ in range(n)]
+        pairs = [tuple(b) for b in numpy.asarray(system.bond_atoms).reshape(-1, 2)] + [tuple(c) for c in numpy.asarray(system.constraint_atoms).reshape(-1, 2)]
+        for a, b in pairs:   # (HBonds constraints removed those bonds from the harmonic terms: both lists make up the graph)
+            a, b = int(a), int(b)
+            if b not in nbr[a]:
+                nbr[a].append(b); nbr[b].append(a)
+        self._nbr, self._heavy = nbr, heavy
+        backbone = set(i for i in range(n) if names is not None and str(names[i]).strip() in self.BACKBONE_NAMES)
+        self.backbone_atoms = sorted(backbone)
+        # (a 3-atom residue with one heavy atom is water: the reference skips "HOH" by name)
+        res_sizes = numpy.bincount(res)
+        qry = [i for i in range(n) if i not in backbone and int(res[i]) in self.residue_list and not (res_sizes[res[i]] == 3 and int(heavy[res == res[i]].sum()) == 1)]
+        self.qry_atoms = qry
+        self.rot_bonds = {}
+        for a in qry:
+            for b in nbr[a]:
+                key = (min(a, b), max(a, b))
+                if key in self.rot_bonds or not (heavy[a] and heavy[b]):
+                    continue
+                if self._is_rotor(key[0], key[1]):
+                    self.rot_bonds[key] = int(res[a])
+        self.rot_atoms = self._rot_atoms()
+        self.atom_indices = self.rot_atoms
+        self.last_choice = None
+
+    # ---- graph predicates standing in for OEBond::IsRotor()
+    def _is_rotor(self, a, b):
+        nbr, heavy = self._nbr, self._heavy
+        if not any(heavy[c] for c in nbr[a] if c != b) or not any(heavy[c] for c in nbr[b] if c != a):
+            return False   # terminal
+        seen, stack = {a}, [a]   # in a ring iff b is reachable from a without the bond itself
+        while stack:
+            u = stack.pop()
+            for w in nbr[u]:
+                if (u == a and w == b) or w in seen:
+                    continue
+                if w == b:
+                    return False
+                seen.add(w); stack.append(w)
+        return True
+
+    def _rot_atoms(self):
+        """reference blues/moves.py:603-669, statement for statement on the graph"""
+        out = {}
+        backbone = set(self.backbone_atoms)
+        for (ax1, ax2), resnum in self.rot_bonds.items():
+            idx_list = [ax1, ax2]
+            query = []
+            if ax1 not in backbone:
+                query.append(ax1)
+            if ax2 not in query and ax2 not in backbone:
+                query.append(ax2)
+            k = 0
+            while k < len(query):   # the reference appends to the list it iterates over
+                atom = query[k]; k += 1
+                for cand in self._nbr[atom]:
+                    if cand not in query and cand not in backbone and cand != ax2:
+                        query.append(cand)
+                        if self._heavy[cand]:
+                            for nb in self._nbr[cand]:
+                                if nb not in query and cand not in backbone and cand != ax2:
+                                    query.append(nb)
+            for y in query:
+                if y not in idx_list:
+                    idx_list.append(y)
+            out.setdefault(resnum, {})[(ax1, ax2)] = idx_list
+        return out
+
+    @property
+    def alchemical_atoms(self):
+        return sorted({a for bonds in self.rot_atoms.values() for atoms in bonds.values() for a in atoms})
+
+    def chooseBondandTheta(self):
+        rs = self.random_state
+        residues = list(self.rot_atoms.keys())
+        res_choice = residues[rs.randint(len(residues))]
+        bonds = list(self.rot_atoms[res_choice].keys())
+        bond_choice = bonds[rs.randint(len(bonds))]
+        return rs.uniform(0.0, 2 * numpy.pi), self.rot_atoms[res_choice][bond_choice], res_choice, bond_choice
+
+    @staticmethod
+    def rotation_matrix(axis, theta):
+        """reference blues/moves.py:731-750 (Euler-Rodrigues parameters)"""
+        axis = numpy.asarray(axis, dtype=float)
+        axis = axis / numpy.sqrt(numpy.dot(axis, axis))
+        a = numpy.cos(theta / 2.0)
+        b, c, d = -axis * numpy.sin(theta / 2.0)
+        aa, bb, cc, dd = a * a, b * b, c * c, d * d
+        bc, ad, ac, ab, bd, cd = b * c, a * d, a * c, a * b, b * d, c * d
+        return numpy.array([[aa + bb - cc - dd, 2 * (bc + ad), 2 * (bd - ac)], [2 * (bc - ad), aa + cc - bb - dd, 2 * (cd + ab)],
+                            [2 * (bd + ac), 2 * (cd - ab), aa + dd - bb - cc]])
+
+    def move(self, context, verbose=False):
+        theta, target_atoms, res, bond = self.chooseBondandTheta()
+        self.last_choice = (theta, res, bond)
+        logger.info('Rotating bond: %s in resnum: %s by %.2f radians' % (bond, res, theta))
+        q = context.getState(getPositions=True).getPositions(asNumpy=True)
+        idx = [int(i) for i in target_atoms]
+        x = numpy.array(q[idx]._value, dtype=float)          # only the touched atoms travel (DeviceQuantity)
+        axis1, axis2 = x[0], x[1]
+        rot = self.rotation_matrix(axis1 - axis2, theta)
+        new = (x - axis2) @ rot.T + axis2
+        for k, i in enumerate(idx):
+            q[i] = new[k]
+        context.setPositions(q)
         return context
 
 

@@ -82,3 +82,42 @@ def test_torsion_move_geometry(oracle_backed_context, tol_box):
         assert np.linalg.norm(x1[h] - x1[1]) == pytest.approx(np.linalg.norm(x0[h] - x0[1]), rel=1e-12)   # and the angle to the axis
     assert np.linalg.norm(x1[7] - x1[8]) == pytest.approx(np.linalg.norm(x0[7] - x0[8]), rel=1e-12)
     assert 0.0 <= mv.last_angle < 2 * np.pi and np.abs(x1[7] - x0[7]).max() > 1e-3
+
+
+def test_sidechain_move_from_the_bond_graph(tol_box):
+    """SideChainMove without OpenEye (reference blues/moves.py:418-844): rotatable heavy bonds and rotating atoms from the bonded
+    graph.  On toluene (residue 0) the only rotor candidate ring-methyl bond C1-C7 is terminal on the methyl side for heavy atoms
+    (no heavy neighbour beyond C7), so OEBond::IsRotor() and this predicate agree there is no heavy rotor; a butane-like chain has one."""
+    from blues_amd import moves
+    from blues_amd._abi import SystemData
+    s, _ = tol_box
+    with pytest.raises(Exception):
+        m = moves.SideChainMove(s, [0]); m.chooseBondandTheta()          # no heavy rotor in toluene: nothing to choose from
+    # n-butane C0-C1-C2-C3 with hydrogens; a ring (cyclopropane C10-C11-C12) whose bonds must not be rotors; one side chain on a backbone
+    names = ["C1", "C2", "C3", "C4"] + ["H%d" % k for k in range(10)]
+    bonds = [(0, 1), (1, 2), (2, 3)] + [(0, 4), (0, 5), (0, 6), (1, 7), (1, 8), (2, 9), (2, 10), (3, 11), (3, 12), (3, 13)]
+    n = 14
+    rng = np.random.RandomState(0)
+    x = rng.normal(size=(n, 3)) * 0.1
+    x[:4] = [[0, 0, 0], [0.15, 0, 0], [0.2, 0.14, 0], [0.35, 0.14, 0.02]]
+    sysd = SystemData(box=np.array([3.0, 3.0, 3.0]), mass=np.array([12.0] * 4 + [1.0] * 10), charge=np.zeros(n), sigma=np.full(n, 0.3), epsilon=np.zeros(n),
+                      bond_atoms=np.array(bonds, np.int32), bond_params=np.tile([0.15, 1000.0], (len(bonds), 1)), positions=x,
+                      residue_of_atom=np.zeros(n, np.int32), names=names)
+    m = moves.SideChainMove(sysd, [0], random_state=4)
+    assert list(m.rot_bonds) == [(1, 2)]                                   # C1-C2 and C3-C4 are terminal, C2-C3 is the heavy rotor
+    atoms = m.rot_atoms[0][(1, 2)]
+    assert atoms[:2] == [1, 2] and set(atoms) == set(range(n))            # the reference's walk starts from both axis atoms (no backbone here)
+    R = m.rotation_matrix([0, 0, 1.0], 0.3)
+    assert np.allclose(R @ R.T, np.eye(3)) and np.isclose(np.linalg.det(R), 1.0) and np.allclose(R @ [0, 0, 1.0], [0, 0, 1.0])
+    theta, target, res, bond = m.chooseBondandTheta()
+    assert 0 <= theta < 2 * np.pi and res == 0 and bond == (1, 2) and m.alchemical_atoms == list(range(n))
+    # a protein-like residue: backbone N, CA, C, O + side chain CB-CG-CD: rotors CA-CB and CB-CG; the walk never crosses into the backbone
+    names2 = ["N", "CA", "C", "O", "CB", "CG", "CD", "HB", "HG"]
+    bonds2 = [(0, 1), (1, 2), (2, 3), (1, 4), (4, 5), (5, 6), (4, 7), (5, 8)]
+    s2 = SystemData(box=np.array([3.0, 3.0, 3.0]), mass=np.array([14.0, 12, 12, 16, 12, 12, 12, 1, 1]), charge=np.zeros(9), sigma=np.full(9, 0.3), epsilon=np.zeros(9),
+                    bond_atoms=np.array(bonds2, np.int32), bond_params=np.tile([0.15, 1000.0], (len(bonds2), 1)), positions=rng.normal(size=(9, 3)),
+                    residue_of_atom=np.zeros(9, np.int32), names=names2)
+    m2 = moves.SideChainMove(s2, [0])
+    assert sorted(m2.rot_bonds) == [(1, 4), (4, 5)] and m2.backbone_atoms == [0, 1, 2, 3]
+    assert m2.rot_atoms[0][(1, 4)][:2] == [1, 4] and set(m2.rot_atoms[0][(1, 4)]) == {1, 4, 5, 6, 7, 8}    # CA is the axis, N / C / O stay
+    assert set(m2.rot_atoms[0][(4, 5)]) == {4, 5, 6, 7, 8}
