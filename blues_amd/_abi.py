@@ -106,6 +106,7 @@ class SystemData:
     pme_grid: tuple = (0, 0, 0)          # NB_PME: mesh of the reciprocal sum
     pme_order: int = 5
     dispersion_correction: bool = True   # NB_PME: OpenMM's NonbondedForce default
+    barostat: tuple = None               # (pressure [bar], temperature [K], frequency): MonteCarloBarostat of the MD leg (host-side, blues_amd/barostat.py)
     positions: np.ndarray = None         # (n,3) nm, optional initial coordinates
     residue_of_atom: np.ndarray = None   # optional bookkeeping for host-side selections
     names: list = None

@@ -169,6 +169,13 @@ class Simulation(object):
         self.reporters = []
         self.currentStep = 0
         self.currentIter = 0
+        # MonteCarloBarostat of the System (reference blues/simulation.py:603-626): applied before every `frequency`-th step
+        self.barostat = None
+        if getattr(system, "barostat", None):
+            from .barostat import MonteCarloBarostat
+            p_bar, temp, freq = system.barostat
+            self.barostat = MonteCarloBarostat(p_bar, temp, freq, seed=getattr(integrator, "_seed", 0) + 7919 * (replica + 1))
+            self._barostat_count = 0
 
     def minimizeEnergy(self, tolerance=None, maxIterations=0):
         raise NotImplementedError("energy minimisation is outside the NCMC switching path (tests only in the reference)")
@@ -204,5 +211,15 @@ class Simulation(object):
         end = self.currentStep + int(steps)
         while self.currentStep < end:
             chunk, due = self._plan_chunk(end)
+            if self.barostat is not None:
+                # OpenMM counts steps in updateContextState and makes its attempt when the count reaches `frequency`, before that step
+                if self._barostat_count >= self.barostat.frequency:
+                    self.barostat.attempt(self.context._engine, self.system)
+                    self._barostat_count = 0
+                left = self.barostat.frequency - self._barostat_count
+                if left < chunk:
+                    chunk = left
+                    due = [(r, nxt) for r, nxt in due if nxt[0] == chunk]
+                self._barostat_count += chunk
             self.integrator.step(chunk)
             self._commit_chunk(chunk, due)

@@ -2079,7 +2079,8 @@ int blues_set_box(BluesEngine* h, const double box[9]) {
     if (flush_program(h)) return 1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     h->box[0] = box[0]; h->box[1] = box[4]; h->box[2] = box[8];
-    for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) E_FAIL(h, "box edge %g < 2*(cutoff+skin)", h->box[k]);
+    for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * h->cutoff) E_FAIL(h, "box edge %g < 2*cutoff", h->box[k]);
+    for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) h->skin = std::max(0.0, 0.5 * h->box[k] - h->cutoff - 1e-6);   // (the layout re-derives the skin for the new box)
     h->sorted_ok = false; h->pass_valid = false; h->e_frozen_valid = false; h->ecache.clear();
     if (h->pme && (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h))) return 1;
     if (h->have_positions) { if (download_xyz(h, h->hx.data(), h->d_x)) return 1; return sort_and_tile(h); }

@@ -71,6 +71,13 @@ def with_reciprocal_space(system: SystemData, dispersion_correction=True):
     return s
 
 
+def add_barostat(system: SystemData, temperature, pressure_bar=1.0, frequency=25):
+    """SimulationFactory.addBarostat (reference blues/simulation.py:603-626): MonteCarloBarostat(pressure, temperature, frequency) on the MD system."""
+    s = copy.copy(system)
+    s.barostat = (float(pressure_bar), float(temperature), int(frequency))
+    return s
+
+
 def freeze_atoms(system: SystemData, frozen_idx):
     """freeze_atoms / utils.zero_masses (reference blues/simulation.py:364-392)."""
     s = copy.copy(system)

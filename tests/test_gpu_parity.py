@@ -512,3 +512,38 @@ def test_resort_when_tiles_spread(Engine, monkeypatch):
     assert np.allclose(w1, w0, rtol=1e-9, atol=1e-8)
     assert np.abs(g1.get_positions() - g0.get_positions()).max() < 1e-9
     g0.close(); g1.close()
+
+
+def test_barostat_on_gpu_matches_the_oracle(Engine, oracle_mod, tol_box):
+    """MD leg with a MonteCarloBarostat (reference blues/simulation.py:603-626): the same volume moves (same barostat seed) on the HIP
+    engine and on the oracle -- the two energies of every attempt come from the device after blues_set_box re-tiled the system for the new
+    box, with reciprocal space on (mesh terms and the dispersion correction depend on the volume)."""
+    from blues_amd import barostat
+    import copy as _copy
+    s, v = tol_box
+    md = systems.with_reciprocal_space(s); md = _copy.copy(md); md.alchemical_atoms = np.zeros(0, np.int32)
+    data = integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=9).to_data(precision=1)
+    g, o = Engine(md, data), oracle_mod.Oracle(md, data)
+
+    class OracleSide:   # the barostat needs get_box / set_box / get_positions / set_positions / potential_energy
+        def __init__(self, orc, box): self.o, self.box = orc, np.diag(np.asarray(box, float))
+        def get_box(self): return self.box.copy()
+        def set_box(self, b): self.box = np.diag(np.asarray(b, float).reshape(-1)[:3]) if np.size(b) == 3 else np.asarray(b, float).reshape(3, 3); self.o.set_box(np.diag(self.box))
+        def get_positions(self): return self.o.get_positions()
+        def set_positions(self, x): self.o.set_positions(x)
+        def potential_energy(self): return self.o.energy_forces(1.0, 1.0)[0]
+    os_ = OracleSide(o, md.box)
+    bg, bo = barostat.MonteCarloBarostat(1.0, 300.0, 25, seed=5), barostat.MonteCarloBarostat(1.0, 300.0, 25, seed=5)
+    g.set_velocities(v); o.set_velocities(v)
+    n_acc = 0
+    for k in range(6):
+        ag, ao = bg.attempt(g, md), bo.attempt(os_, md)
+        assert ag == ao
+        assert bg.last["dU"] == pytest.approx(bo.last["dU"], rel=1e-7, abs=1e-6) and bg.last["volume"] == pytest.approx(bo.last["volume"], rel=1e-14)
+        assert np.allclose(np.diag(g.get_box()), np.diag(os_.get_box()), rtol=1e-14)
+        assert g.potential_energy() == pytest.approx(os_.potential_energy(), rel=1e-10)
+        n_acc += ag
+        g.step(5); o.step(5)
+        assert np.abs(g.get_positions() - o.get_positions()).max() < 1e-8
+    assert 0 < n_acc
+    g.close()
