@@ -435,10 +435,10 @@ static void nonbonded(Oracle *o, double ls, double le, double *F, double *T) {
 #ifdef ORC_OPENMP
     /* CPU baseline (ii) of SURVEY.md 8(d): the same pair loop on all cores.  Cells are dealt to the threads statically and the
      * thread-private force / energy arrays are summed in thread order, so a run is reproducible for a given thread count. */
-    const int nt = omp_get_max_threads();
+    const int nt = omp_get_max_threads() < ncell ? omp_get_max_threads() : ncell;   /* (more threads than cells would only add empty force arrays to sum) */
     double *Fp = F ? calloc((size_t)nt * 3 * n, sizeof(double)) : NULL;
     double *Tp = calloc((size_t)nt * BLUES_N_ENERGY_TERMS, sizeof(double));
-#pragma omp parallel
+#pragma omp parallel num_threads(nt)
     {
         const int th = omp_get_thread_num();
         double *Ft = F ? Fp + (size_t)th * 3 * n : NULL, *Tt = Tp + (size_t)th * BLUES_N_ENERGY_TERMS;
@@ -457,10 +457,11 @@ static void nonbonded(Oracle *o, double ls, double le, double *F, double *T) {
             }
         }
     }
-    for (int th = 0; th < nt; th++) {
-        if (F) for (int q = 0; q < 3 * n; q++) F[q] += Fp[(size_t)th * 3 * n + q];
-        for (int q = 0; q < BLUES_N_ENERGY_TERMS; q++) T[q] += Tp[(size_t)th * BLUES_N_ENERGY_TERMS + q];
+    if (F) {
+#pragma omp parallel for schedule(static)
+        for (int q = 0; q < 3 * n; q++) { double a = 0.0; for (int th = 0; th < nt; th++) a += Fp[(size_t)th * 3 * n + q]; F[q] += a; }   /* thread order: reproducible */
     }
+    for (int th = 0; th < nt; th++) for (int q = 0; q < BLUES_N_ENERGY_TERMS; q++) T[q] += Tp[(size_t)th * BLUES_N_ENERGY_TERMS + q];
     free(Fp); free(Tp);
 #else
     for (int cx = 0; cx < nc[0]; cx++) for (int cy = 0; cy < nc[1]; cy++) for (int cz = 0; cz < nc[2]; cz++) {
