@@ -129,6 +129,7 @@ struct BluesEngine {
     int nb_method = 1; double cutoff = 1, alpha = 0, sc_alpha = 0.5;
     int annih_elec = 1, annih_ster = 0, remove_cm = 0, check_env_excl = 0;
     double skin = 0.12; bool skin_from_env = false;
+    double skin_m = 0.12, trig = 0.06;   // margin of MOBILE list candidates, and the displacement that asks for a rebuild (derive_margins)
     // ---- integrator
     double dt = 0, temperature = 0, gamma = 1, kT = 0, tol = 1e-8;
     int nsteps = 0, nprop = 1, n_lambda = 0, precision = 0;
@@ -252,12 +253,27 @@ template <typename R> static const RepNb<R>* batch_reps_nb(const BluesBatch* b) 
 static Box3 make_box(const BluesEngine* h) {
     Box3 b; for (int k = 0; k < 3; k++) { b.L[k] = h->box[k]; b.invL[k] = 1.0 / h->box[k]; } return b;
 }
+// List margins.  A pair's separation changes by at most the sum of its atoms' displacements since the build, and a rebuild
+// is requested as soon as ONE mobile atom has moved `trig`: a frozen candidate therefore needs a margin of trig, a mobile one
+// 2 trig.  Where nearly everything is frozen (freeze_radius, reference blues/simulation.py:394-480) the few mobile
+// candidates get the double margin and trig = skin: the same lists last twice the displacement.  Otherwise every candidate
+// has the margin `skin` and trig = skin / 2, the usual Verlet rule.
+static void derive_margins(BluesEngine* h) {
+    double room = 1e30;
+    for (int k = 0; k < 3; k++) room = std::min(room, 0.5 * h->box[k] - h->cutoff - 1e-6);
+    h->skin = std::min(h->skin, std::max(0.0, room));
+    const bool mostly_frozen = 4 * h->mobile.size() <= (size_t)h->n && !getenv("BLUES_PLAIN_SKIN");
+    h->skin_m = mostly_frozen ? std::min(2.0 * h->skin, std::max(0.0, room)) : h->skin;
+    h->trig = std::min(h->skin, 0.5 * h->skin_m);
+}
+
 template <typename R> static NbConst<R> make_nbconst(const BluesEngine* h) {
     NbConst<R> c;
     const double two = sizeof(R) == 4 ? 4294967296.0 : 18446744073709551616.0;
     for (int k = 0; k < 3; k++) { c.dscale[k] = h->box[k] / two; c.scale[k] = (R)c.dscale[k]; }
     c.rc2 = (R)(h->cutoff * h->cutoff); c.alpha = (R)h->alpha;
     c.rlist2 = (h->cutoff + h->skin) * (h->cutoff + h->skin);
+    c.rlist2_m = (h->cutoff + h->skin_m) * (h->cutoff + h->skin_m);
     return c;
 }
 
@@ -455,8 +471,8 @@ static int sort_and_tile(BluesEngine* h) {
     // throughput-bound (every extra j costs pair evaluations)
     if (!h->skin_from_env) {
         h->skin = h->n_itiles * h->batch_R <= 32 ? 0.3 : 0.12;  // batch_R: a large batch is throughput-bound like a large i-set
-        for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) h->skin = std::max(0.0, 0.5 * h->box[k] - h->cutoff - 1e-6);
     }
+    derive_margins(h);
     // capacities
     const double rl = h->cutoff + h->skin;
     const double vol = h->box[0] * h->box[1] * h->box[2], rho = n / vol;
@@ -570,8 +586,9 @@ static int sort_and_tile(BluesEngine* h) {
     const int nt = std::max(1, h->n_tiles);
     h->pool_cap = nt * MASK_QUOTA;
     h->PA = 1; while (h->PA < (int)h->alch.size()) h->PA <<= 1;
-    h->k2_jiter = h->n_itiles * h->batch_R <= 32 && h->batch_R < 8 ? 1 : 4;
+    h->k2_jiter = h->n_itiles * h->batch_R <= 32 && h->batch_R < 8 ? 1 : 8;   // measured at R = 256 (us per launch): 2: 160, 4: 123, 8: 110, 16: 113
     if (const char* e = getenv("BLUES_K2_JITER")) h->k2_jiter = std::max(1, atoi(e));
+    h->k2_jiter = std::min(h->k2_jiter, h->PA);   // an env block stages (256 / PA) * jiter <= K2_STAGE list entries in LDS
     h->k2_nblocks_env = k2_env_blocks(jcap, h->PA, h->k2_jiter);
     // exclusions in sorted space (self included)
     std::vector<int> ex_start(n + 1, 0), ex_idx;
@@ -661,7 +678,7 @@ static IntArgs make_int_args(BluesEngine* h) {
     A.noise = h->d_noise.p; A.mobile_index = h->d_mobile_index.p; A.n_mobile = (int)h->mobile.size(); A.n_noise = h->noise_valid ? h->n_noise : 0; A.noise_draw_base = h->noise_draw_base;
     A.box = make_box(h); A.periodic = h->nb_method == BLUES_NB_PME_DIRECT; A.cl_periodic = 0;
     A.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; A.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
-    A.half_skin2 = 0.25 * h->skin * h->skin; A.flags = h->d_flags.p; A.batch_req = batch_req_ptr(h);
+    A.half_skin2 = h->trig * h->trig; A.flags = h->d_flags.p; A.batch_req = batch_req_ptr(h);
     A.total_mass = h->total_mass; A.cm_part = h->d_cm_part.p; A.cm_nblocks = h->int_blocks;
     A.mom_part = h->d_mom_part.p; A.n_mom = h->n_islots / 64 + 2;
     A.acc = h->d_acc.p; A.work_trace = (h->tracing || h->ctrl_arg) ? h->d_trace.p : nullptr; A.trace_index = h->prog_trace;
@@ -730,16 +747,20 @@ static ListArgs make_list_args(BluesEngine* h) {
     return a;
 }
 
-template <typename R> static int launch_lists(BluesEngine* h, int force) {
+// phase 0: the whole rebuild; 1: the group lists only (k_build_lists); 2: the atoms' own lists only (k_build_atom_lists)
+template <typename R> static int launch_lists(BluesEngine* h, int force, int phase = 0) {
+    static const bool force_always = getenv("BLUES_FORCE_LISTS") != nullptr;   // development: every launch rebuilds every list
+    if (force_always) force = 1;
     const ListArgs a = make_list_args(h);
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
-    if (batch_lead(h)) {
+    if (phase == 2) { }
+    else if (batch_lead(h)) {
         hipLaunchKernelGGL(k_build_lists_b<R>, dim3((h->n_tiles + 2) * h->batch->R()), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->R(), h->n_tiles + 2, force);
     } else if (!batch_dry(h)) {
         hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 2), dim3(LIST_THREADS), 0, h->cur, a, make_nbconst<R>(h), img, force);
     }
-    if (h->k1_mode == 2 && h->n_itiles > 0) {
+    if (phase != 1 && h->k1_mode == 2 && h->n_itiles > 0) {
         // second kernel of a rebuild (same gate): the atoms' own lists, one block per i-tile; the group's list lives in
         // dynamic LDS there (positions 12 B + index 4 B + exclusion bitmap 8 B per entry)
         const size_t lds = (size_t)h->jcap * 24;
@@ -856,7 +877,7 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
     AlchArgs A = make_alch_args(h, ls, le, slot_mask);
     const bool fast = h->precision == 0;
     if (batch_lead(h)) {
-        const int nb = h->k2_nblocks_env + 1, nrep = h->batch->R();
+        const int nb = std::min(h->k2_nblocks_env, K2_PHYS) + 1, nrep = h->batch->R();   // (a lone chain keeps one block per logical block: shortest chain)
         const AlchDyn D = make_alch_dyn(A);
         const dim3 g(nb * nrep), b(256);
 #define ALCH_B(F, M) hipLaunchKernelGGL((k_alchemical_b<F, M>), g, b, 0, h->cur, h->batch->d_core.p, D, nb, nrep)
@@ -1157,9 +1178,24 @@ static int force_pass(BluesEngine* h, int base_L) {
     if (h->split == "HVRORVH" && h->nprop == 1) fmask = (base_L & 1) ? 5 : 2;
     if (const char* e = getenv("BLUES_SLOT_MASK")) fmask = atoi(e) & 7;
     h->pass_fmask = fmask;
-    int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced) : launch_lists<double>(h, h->lists_forced);
-    h->lists_forced = false;
+    // A large batch in per-atom-list mode forks the alchemical kernel onto a side stream after the group lists (which hold its
+    // j records): the atoms' own lists are built by a few latency-bound blocks that leave most of the chip idle, and the
+    // alchemical kernel fills it.  Joined before finalize.
+    static const bool fork_env = !getenv("BLUES_FORK") || atoi(getenv("BLUES_FORK")) != 0;
+    const bool decomposed = !(h->fuse_forces && h->wpb == 4) && !(h->k1_mode == 1 && h->precision == 0 && h->fuse_big);
+    const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && !h->alch.empty() && h->s1 && !h->ctrl_arg;
+    int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, fork ? 1 : 0) : launch_lists<double>(h, h->lists_forced, fork ? 1 : 0);
     if (rc) return 1;
+    if (fork) {
+        hipStream_t main_stream = h->cur;
+        HIP_OK(h, hipEventRecord(h->evFork, main_stream)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evFork, 0));
+        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask); h->cur = main_stream;
+        if (rc) return 1;
+        HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
+        rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, 2) : launch_lists<double>(h, h->lists_forced, 2);
+        if (rc) return 1;
+    }
+    h->lists_forced = false;
     if (h->fuse_forces && h->wpb == 4) {
         rc = h->precision == 0 ? launch_forces_fused<float>(h, ls, le) : launch_forces_fused<double>(h, ls, le);
         if (rc) return 1;
@@ -1170,10 +1206,11 @@ static int force_pass(BluesEngine* h, int base_L) {
         if (launch_pme(h, 0)) return 1;
         if (launch_finalize(h, le, fmask)) return 1;
     } else {
-        if (launch_alchemical(h, ls, le, fmask)) return 1;
+        if (!fork && launch_alchemical(h, ls, le, fmask)) return 1;
         rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (rc) return 1;
         if (launch_pme(h, 0)) return 1;
+        if (fork) HIP_OK(h, hipStreamWaitEvent(h->cur, h->evJ1, 0));
         if (launch_bonded_and_finalize(h, le, true, fmask)) return 1;
     }
     h->pass_valid = true; h->pass_L = base_L; h->st_passes++; h->vel_clean = true;
@@ -1819,7 +1856,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     h->alpha = s->ewald_alpha; h->sc_alpha = s->softcore_alpha;
     for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * h->cutoff) E_FAIL(h, "box edge %g < 2*cutoff", h->box[k]);
     if (const char* sk = getenv("BLUES_SKIN")) { h->skin = atof(sk); h->skin_from_env = true; }
-    for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) h->skin = std::max(0.0, 0.5 * h->box[k] - h->cutoff - 1e-6);
+    derive_margins(h);   // (again once the mobile set is known: sort_and_tile)
     h->annih_elec = s->annihilate_electrostatics; h->annih_ster = s->annihilate_sterics; h->remove_cm = s->remove_cm_motion;
     h->mass.assign(s->mass, s->mass + n); h->charge.assign(s->charge, s->charge + n); h->sigma.assign(s->sigma, s->sigma + n); h->eps.assign(s->epsilon, s->epsilon + n);
     h->excl.assign(n, {});
@@ -2080,7 +2117,7 @@ int blues_set_box(BluesEngine* h, const double box[9]) {
     HIP_OK(h, hipStreamSynchronize(h->stream));
     h->box[0] = box[0]; h->box[1] = box[4]; h->box[2] = box[8];
     for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * h->cutoff) E_FAIL(h, "box edge %g < 2*cutoff", h->box[k]);
-    for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * (h->cutoff + h->skin)) h->skin = std::max(0.0, 0.5 * h->box[k] - h->cutoff - 1e-6);   // (the layout re-derives the skin for the new box)
+    derive_margins(h);   // (the layout re-derives the skin for the new box)
     h->sorted_ok = false; h->pass_valid = false; h->e_frozen_valid = false; h->ecache.clear();
     if (h->pme && (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h))) return 1;
     if (h->have_positions) { if (download_xyz(h, h->hx.data(), h->d_x)) return 1; return sort_and_tile(h); }

@@ -19,6 +19,7 @@
 #include "device_common.h"
 
 #define K2_NE 6  // energy partials per block: C_scaled, S0, S1, S2, const_lj, const_coul
+#define K2_STAGE 256  // j entries an env block stages in LDS (>= (256 / PA) * jiter)
 #define K2_NP 9  // K2_NE + the block's total slot-0 force on the alchemical atoms (x,y,z), for the momentum bookkeeping
 // env blocks needed for `count` list entries when a block walks `jiter` groups of 256/PA j's (see alchemical_body): 1 for a
 // lone replica (shortest dependent chain per block), 4 in a large batch (reductions amortised, 4x fewer partials)
@@ -65,8 +66,9 @@ __device__ inline bool excluded_sorted(const int* ex_start, const int* ex_idx, i
 // FAST: the mixed-precision mode's math (device_common.h, fast fp64 forms); false = libm forms, the reference-grade path
 // MASK: the force slot mask known at compile time (5 and 2 are what "H V R O R V H" asks for, see force_pass), so that the
 // force arithmetic, accumulators and reductions of the other slots are not even compiled in; -1 = use A.slot_mask
+// Returns false when the (env) block had no list entries left, i.e. every later block is empty too.
 template <bool FAST, int MASK = -1>
-__device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id) {
+__device__ __forceinline__ bool alchemical_body(AlchArgs& A, const int block_id) {
     auto slot_on = [&](int s) -> bool { return MASK >= 0 ? ((MASK >> s) & 1) != 0 : ((A.slot_mask >> s) & 1) != 0; };
     if (A.ctrl) {
         const int L = A.ctrl->L0 + 2 * A.ctrl->kpass;
@@ -78,6 +80,7 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
     const int a = tid & (PA - 1);
     __shared__ double s_self[4][9][64];
     __shared__ double s_e[4][K2_NE];
+    __shared__ double s_exc[9][256];   // self block: exception rows; env blocks: the block's j records and positions (K2_STAGE entries)
     double f[3][3];  // [slot][xyz] force on the alchemical atom from this pair
 #pragma unroll
     for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = 0.0; }
@@ -93,7 +96,7 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
         // in registers across the groups and are reduced once per block.
         const int count = *A.jcount;
         const int jpg = 256 / PA, j0 = block_id * jpg * A.jiter;
-        if (j0 >= count) return;  // nothing to do; finalize sums only the used blocks
+        if (j0 >= count) return false;  // nothing to do; finalize sums only the used blocks
         AlchARec Ar; Ar.ao = 0; Ar.asrt = 0; Ar.has_env_excl = 0; Ar.sig = Ar.eps = Ar.q = 0.0;
         if (a < A.n_alch) Ar = A.arec[a];
         double xa[3] = {0.0, 0.0, 0.0};
@@ -102,8 +105,25 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
 #pragma unroll
         for (int s = 0; s < 3; s++) { fa[s][0] = fa[s][1] = fa[s][2] = 0.0; }
         wave_hit = false;
+        // The block's j records and their positions are staged in LDS by one round of loads (record -> position: two dependent
+        // memory round trips per BLOCK; read per pair they were two per iteration, and with three waves per SIMD the kernel
+        // spent 60 % of its wave-cycles waiting on them).  jpg * jiter <= K2_STAGE (the host clamps jiter to PA).
+        double* const st_x = &s_exc[0][0];                                   // [3][K2_STAGE]
+        double* const st_sig = st_x + 3 * K2_STAGE; double* const st_eps = st_sig + K2_STAGE; double* const st_q = st_eps + K2_STAGE;
+        int* const st_jsrt = reinterpret_cast<int*>(st_q + K2_STAGE); int* const st_jo = st_jsrt + K2_STAGE;
+        {
+            const int nstage = min(jpg * A.jiter, count - j0);
+            if (tid < nstage) {
+                const AlchJRec J = A.jrec[j0 + tid];
+                st_jsrt[tid] = J.jsrt; st_jo[tid] = J.jo; st_sig[tid] = J.sig; st_eps[tid] = J.eps; st_q[tid] = J.q;
+#pragma unroll
+                for (int k = 0; k < 3; k++) st_x[k * K2_STAGE + tid] = A.x[k][J.jo];
+            }
+            __syncthreads();
+        }
         for (int it = 0; it < A.jiter; it++) {
-            const int js = j0 + it * jpg + tid / PA;
+            const int sl = it * jpg + tid / PA;
+            const int js = j0 + sl;
             if (j0 + it * jpg >= count) break;   // block-uniform
             const bool valid = js < count && a < A.n_alch;
             int jsrt = -1;
@@ -112,11 +132,11 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
 #pragma unroll
             for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = 0.0; }
             if (valid) {
-                const AlchJRec J = A.jrec[js];
+                AlchJRec J; J.jsrt = st_jsrt[sl]; J.jo = st_jo[sl]; J.sig = st_sig[sl]; J.eps = st_eps[sl]; J.q = st_q[sl];
                 jsrt = J.jsrt & 0x3fffffff; j_mobile = (J.jsrt >> 30) & 1;
                 const int jo = J.jo;
                 double d[3];
-                for (int k = 0; k < 3; k++) d[k] = min_image_d(xa[k] - A.x[k][jo], A.box.L[k], A.box.invL[k]);
+                for (int k = 0; k < 3; k++) d[k] = min_image_d(xa[k] - st_x[k * K2_STAGE + sl], A.box.L[k], A.box.invL[k]);
                 const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
                 const bool excl = Ar.has_env_excl && excluded_sorted(A.ex_start, A.ex_idx, Ar.asrt, jsrt);
                 if (!excl && r2 < A.rc2) {
@@ -227,7 +247,6 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
         }
         __syncthreads();
         // ---- exceptions that involve alchemical atoms: one thread per (row, entry), rows summed from LDS in order
-        __shared__ double s_exc[9][256];
         const int n_exc_ent = A.exc_start[A.n_alch];
         for (int e0 = 0; e0 < n_exc_ent; e0 += 256) {
             const int q = e0 + tid;
@@ -277,7 +296,7 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
         __syncthreads();
         if (tid < K2_NE) A.e_part[(size_t)block_id * K2_NP + tid] = s_e[0][tid] + s_e[1][tid] + s_e[2][tid] + s_e[3][tid];
         if (wv == 0) for (int k = 0; k < 3; k++) { const double t = wave_sum(lane < A.n_alch ? s_self[0][k][lane] : 0.0); if (lane == 0) A.e_part[(size_t)block_id * K2_NP + K2_NE + k] = t; }
-        return;
+        return true;
     }
 
     // ---- env blocks: force on alchemical atom a = sum over the j's of this block
@@ -313,7 +332,22 @@ __device__ __forceinline__ void alchemical_body(AlchArgs& A, const int block_id)
         const double t = wave_sum(v);
         if (lane == 0) A.e_part[(size_t)block_id * K2_NP + K2_NE + k] = t;
     }
+    return true;
+}
+
+// The grid holds `nphys` env blocks (+ the alchemical x alchemical block, last): physical block p walks the logical blocks
+// p, p + nphys, ... that still have list entries.  The logical block owns the partial slabs, so the sums finalize forms do
+// not depend on nphys.  (Sized for the list's CAPACITY, 4 of 5 blocks of a launch were empty and each still held an
+// occupancy slot for three dependent loads.)
+#define K2_PHYS 24
+template <bool FAST, int MASK = -1>
+__device__ __forceinline__ void alchemical_blocks(AlchArgs& A, const int p, const int nphys) {
+    if (p >= nphys) { alchemical_body<FAST, MASK>(A, A.nblocks_env); return; }
+    for (int lb = p; lb < A.nblocks_env; lb += nphys) {
+        if (!alchemical_body<FAST, MASK>(A, lb)) return;
+        __syncthreads();   // the next logical block reuses the LDS staging and partial arrays
+    }
 }
 
 template <bool FAST>
-__global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) { alchemical_body<FAST>(A, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) { alchemical_blocks<FAST>(A, blockIdx.x, gridDim.x - 1); }

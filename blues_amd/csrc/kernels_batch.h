@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256, 3) k_alchemical_b(const RepCore* __restri
     int rep, bx; batch_decode(nb, nrep, rep, bx);
     if (!reps[rep].active) return;
     AlchArgs A = reps[rep].al; apply_dyn(A, d);
-    alchemical_body<FAST, MASK>(A, bx);
+    alchemical_blocks<FAST, MASK>(A, bx, nb - 1);
 }
 
 __global__ void __launch_bounds__(128) k_bonded_entries_b(const RepCore* __restrict__ reps, BondedDyn d) {

@@ -36,7 +36,8 @@ template <typename R> struct NbConst {
     R scale[3];   // box edge / 2^32 (or 2^64)
     R rc2;        // cutoff^2
     R alpha;      // Ewald alpha
-    double rlist2;  // (cutoff+skin)^2
+    double rlist2;  // (cutoff+skin)^2: list radius for frozen candidates
+    double rlist2_m;  // list radius for mobile candidates (derive_margins in blues_engine.hip)
     double dscale[3];
 };
 
@@ -165,9 +166,9 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     int* stage = a.jstage + ((size_t)t * LIST_WAVES + wv) * share;
     const float cfs[3] = {(float)c.dscale[0], (float)c.dscale[1], (float)c.dscale[2]};
     const float hfl[3] = {(float)hf[0] * 1.00001f + 1e-6f, (float)hf[1] * 1.00001f + 1e-6f, (float)hf[2] * 1.00001f + 1e-6f};
-    const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f;
-    const float rsph = ((float)s_rad * 1.00001f + 1e-6f + sqrtf(rl2));
-    const float rs2 = a.no_sphere ? __builtin_inff() : rsph * rsph * 1.0001f;
+    const float rl2f = (float)c.rlist2 * 1.0001f + 1e-5f, rl2m = (float)c.rlist2_m * 1.0001f + 1e-5f;   // frozen / mobile candidates
+    const float rsphf = ((float)s_rad * 1.00001f + 1e-6f + sqrtf(rl2f)), rsphm = ((float)s_rad * 1.00001f + 1e-6f + sqrtf(rl2m));
+    const float rs2f = a.no_sphere ? __builtin_inff() : rsphf * rsphf * 1.0001f, rs2m = a.no_sphere ? __builtin_inff() : rsphm * rsphm * 1.0001f;
     const int j_end = min(a.n, (wv + 1) * share);
     int wcount = 0;
     for (int base = wv * share; base < j_end; base += 64 * LIST_PREFETCH) {
@@ -190,6 +191,8 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
                 d = fmaxf(d, 0.0f);
                 d2 = fmaf(d, d, d2);
             }
+            const bool mob = (fl[u] & FLAG_MOBILE) != 0;
+            const float rl2 = mob ? rl2m : rl2f, rs2 = mob ? rs2m : rs2f;
             bool pass = j < j_end && d2 < rl2 && o2 < rs2 && !(fl[u] & FLAG_ALCH);
             if (alch_tile && pass) {
                 // the alchemical kernel spends a thread on every (j, alchemical atom) pair of this list, so the list is
@@ -326,7 +329,7 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     unsigned long long* s_bm = reinterpret_cast<unsigned long long*>(s_jm + a.jcap);   // [64][jcap / 64] excluded candidates of each slot
     const int nchmax = a.jcap >> 6;
     const float cfs[3] = {(float)c.dscale[0], (float)c.dscale[1], (float)c.dscale[2]};
-    const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f;
+    const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f, rl2m = (float)c.rlist2_m * 1.0001f + 1e-5f;
     NB_STAMP(t == 0 && tid == 0, 5);
     const int i0 = a.tile_atoms[t * 64];
     const ufix ref[3] = {img[i0].x, img[i0].y, img[i0].z};
@@ -339,14 +342,14 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     for (int k = tid; k < 64 * nchmax; k += LIST_THREADS) s_bm[k] = 0ull;
     __syncthreads();
     NB_STAMP(t == 0 && tid == 0, 6);
-    int ia4[4]; float pi4[4][3], rl4[4];
+    int ia4[4]; float pi4[4][3]; bool ok4[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int slot = wv + LIST_WAVES * u;
         ia4[u] = __builtin_amdgcn_readfirstlane(a.tile_atoms[t * 64 + slot]);
         const int iq = ia4[u] >= 0 ? ia4[u] : 0;
         pi4[u][0] = (float)(sfix)(img[iq].x - ref[0]) * cfs[0]; pi4[u][1] = (float)(sfix)(img[iq].y - ref[1]) * cfs[1]; pi4[u][2] = (float)(sfix)(img[iq].z - ref[2]) * cfs[2];
-        rl4[u] = ia4[u] >= 0 ? rl2 : -1.0f;   // an empty slot passes nobody
+        ok4[u] = ia4[u] >= 0;   // an empty slot passes nobody
         const int e0 = ia4[u] >= 0 ? a.ex_start[iq] : 0, e1 = ia4[u] >= 0 ? a.ex_start[iq + 1] : 0;
         for (int q = lane; q < e1 - e0; q += 64) {
             const int p = a.ex_idx[e0 + q];
@@ -370,8 +373,10 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     for (int ch = 0; ch < nch; ch++) {
         const int k = ch * 64 + lane, kk = min(k, count - 1);
         const float x = sx[kk], y = sy[kk], z = sz[kk];
-        const unsigned short ent = (unsigned short)(k | ((s_jm[kk] & 0x40000000) ? 0x8000 : 0));
+        const bool mob = (s_jm[kk] & 0x40000000) != 0;
+        const unsigned short ent = (unsigned short)(k | (mob ? 0x8000 : 0));
         const float kinf = k < count ? 0.0f : INF;
+        const float lim = mob ? rl2m : rl2;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const unsigned long long bm = s_bm[(wv + LIST_WAVES * u) * nchmax + ch];   // same address in every lane: broadcast
@@ -379,7 +384,7 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
             dx -= boxf[0] * rintf(dx * iboxf[0]); dy -= boxf[1] * rintf(dy * iboxf[1]); dz -= boxf[2] * rintf(dz * iboxf[2]);
             float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + kinf;
             d2 = ((bm >> lane) & 1ull) ? INF : d2;
-            const bool pass = d2 < rl4[u];
+            const bool pass = d2 < lim && ok4[u];
             const unsigned long long bal = __ballot(pass);
             const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
             const int pos = cntv[u] + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
