@@ -129,7 +129,11 @@ class Context(object):
     def setPeriodicBoxVectors(self, a, b, c):
         """reference blues/simulation.py:958"""
         box = np.array([unit.value_in(a, "nanometer"), unit.value_in(b, "nanometer"), unit.value_in(c, "nanometer")], dtype=np.float64)
+        key = box.tobytes()
+        if key == getattr(self._engine, "_box_key", None):
+            return   # the vectors this context was given last (every hand-over of an NVT chain): nothing to do
         self._engine.set_box(box.reshape(3, 3).diagonal().copy() if np.allclose(box, np.diag(np.diag(box))) else box)
+        self._engine._box_key = key
 
     def setVelocitiesToTemperature(self, temperature, randomSeed=None):
         """reference blues/simulation.py:743, 1187"""

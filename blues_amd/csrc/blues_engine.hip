@@ -150,6 +150,7 @@ struct BluesEngine {
     double e_frozen[2] = {0, 0}; bool e_frozen_valid = false;
     ECache ecache;  // total potential energy at the current positions
     double ke_cache = 0; bool ke_cache_valid = false;
+    DevAccum acc_cache; bool acc_cache_valid = false; int64_t acc_cache_stamp = 0;   // accumulators as read back by a batch prefetch; valid until the next launch
     // ---- derived topology
     std::vector<int> mobile;       // caller indices with mass > 0
     std::vector<HostCluster> clusters;
@@ -689,7 +690,7 @@ static IntArgs make_int_args(BluesEngine* h) {
 
 static int flush_program(BluesEngine* h) {
     if (h->prog.n == 0) return 0;
-    h->ecache.clear(); h->ke_cache_valid = false;   // the launch may move atoms
+    h->ecache.clear(); h->ke_cache_valid = false; h->acc_cache_valid = false;   // the launch may move atoms
     IntArgs A = make_int_args(h);
     // the steady-state program of "H V R O R V H" has a straight-line specialisation (same arithmetic)
     static const unsigned char P_CM[9] = {OP_V0, OP_H01, OP_END, OP_CM_PART, OP_H12, OP_V2, OP_R, OP_O, OP_R};
@@ -1213,7 +1214,7 @@ static int force_pass(BluesEngine* h, int base_L) {
         if (fork) HIP_OK(h, hipStreamWaitEvent(h->cur, h->evJ1, 0));
         if (launch_bonded_and_finalize(h, le, true, fmask)) return 1;
     }
-    h->pass_valid = true; h->pass_L = base_L; h->st_passes++; h->vel_clean = true;
+    h->pass_valid = true; h->pass_L = base_L; h->st_passes++; h->vel_clean = true; h->acc_cache_valid = false;
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -1355,6 +1356,7 @@ static int add_work(BluesEngine* h, double delta) {
     HIP_OK(h, hipMemcpy(&a, h->d_acc.p, sizeof a, hipMemcpyDeviceToHost));
     a.protocol_work += delta;
     HIP_OK(h, hipMemcpy(h->d_acc.p, &a, sizeof a, hipMemcpyHostToDevice));
+    h->acc_cache_valid = false;
     return 0;
 }
 
@@ -1514,6 +1516,7 @@ static int step_head(BluesEngine* h) {
         if (flush_program(h)) return 1;
         h->pass_valid = false;
         HIP_OK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(DevAccum), h->stream));
+        h->acc_cache_valid = false;
         h->h_lambda = 0.0; h->h_lambda_step = 0; h->cur_ls = h->tab_ls[0]; h->cur_le = h->tab_le[0];
         h->h_perturbed = h->h_unperturbed = 0.0; h->unpert_valid = false;
     }
@@ -1733,13 +1736,18 @@ static int batch_prefetch(BluesBatch* B, int what) {
             std::vector<double> ke;
             try {
                 if (ok) {
-                    if (B->d_gather.n < (size_t)R) B->d_gather.alloc((size_t)R);
+                    if (B->d_gather.n < (size_t)7 * R) B->d_gather.alloc((size_t)7 * R);
                     hipLaunchKernelGGL(k_kinetic_b, dim3(R), dim3(256), 0, B->stream, B->d_core.p, B->d_gather.p);
                     ok = hipStreamSynchronize(B->stream) == hipSuccess;
-                    if (ok) { ke.resize(R); ok = hipMemcpy(ke.data(), B->d_gather.p, sizeof(double) * R, hipMemcpyDeviceToHost) == hipSuccess; }
+                    if (ok) { ke.resize((size_t)7 * R); ok = hipMemcpy(ke.data(), B->d_gather.p, sizeof(double) * 7 * R, hipMemcpyDeviceToHost) == hipSuccess; }
                 }
             } catch (std::string& e) { B->err = e; ok = false; }
-            if (ok) for (int r = 0; r < R; r++) if (live[r]) { B->eng[r]->ke_cache = ke[r]; B->eng[r]->ke_cache_valid = true; }
+            if (ok) for (int r = 0; r < R; r++) if (live[r]) {
+                BluesEngine* m = B->eng[r];
+                m->ke_cache = ke[r]; m->ke_cache_valid = true;
+                static_assert(sizeof(DevAccum) == 6 * sizeof(double), "k_kinetic_b copies six doubles");
+                memcpy(&m->acc_cache, &ke[(size_t)R + 6 * r], sizeof(DevAccum)); m->acc_cache_valid = true; m->acc_cache_stamp = m->st_launches;
+            }
             B->st_prefetch_ke++;
         }
     }
@@ -1829,8 +1837,19 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
     }
     if (phase(flush_program)) return 1;
     for (int r = 0; r < R; r++) B->eng[r]->tracing = false;
+    // error flags: one gathered read-back tells which members (normally none) need their own check_flags
+    pick_leader();
+    bool gathered = false;
+    std::vector<int> hints;
+    if (B->leader && !batch_refresh_args(B)) {
+        try {
+            if ((int)B->d_hints.n != R) B->d_hints.alloc(R);
+            hipLaunchKernelGGL(k_gather_hints_b, dim3((R + 255) / 256), dim3(256), 0, B->leader->stream, B->d_core.p, R, B->d_hints.p);
+            if (hipStreamSynchronize(B->leader->stream) == hipSuccess) { B->d_hints.download(hints); gathered = (int)hints.size() == R; }
+        } catch (std::string&) { gathered = false; }
+    }
     B->leader = B->eng[0];
-    for (int r = 0; r < R; r++) if (!B->failed[r] && check_flags(B->eng[r])) fail(r);
+    for (int r = 0; r < R; r++) if (!B->failed[r] && (!gathered || (hints[r] & 2)) && check_flags(B->eng[r])) fail(r);
     return 0;
 }
 
@@ -2180,8 +2199,9 @@ int blues_set_velocities_to_temperature(BluesEngine* h, double temperature, uint
     h->st_launches++;
     h->vel_clean = false; h->ke_cache_valid = false;
     if (emit(h, OP_RATTLE)) return 1;
-    if (flush_program(h)) return 1;
-    return check_flags(h);
+    // (no read-back here: a velocity-constraint failure stays flagged on the device and is raised by the next step, which
+    // checks the flags anyway -- a synchronous check per chain was 20 us of host time for each of R chains per iteration)
+    return flush_program(h);
 }
 
 int blues_get_energy(BluesEngine* h, double* potential, double* kinetic) {
@@ -2232,6 +2252,7 @@ int blues_run_switch(BluesEngine* h, int32_t n_steps, double* work_trace) {
 
 static int read_acc(BluesEngine* h, DevAccum* a) {
     if (flush_program(h)) return 1;
+    if (h->acc_cache_valid && h->acc_cache_stamp == h->st_launches) { *a = h->acc_cache; return 0; }   // nothing was launched since a batch prefetch read them
     HIP_OK(h, hipStreamSynchronize(h->stream));
     HIP_OK(h, hipMemcpy(a, h->d_acc.p, sizeof *a, hipMemcpyDeviceToHost));
     return 0;
@@ -2275,6 +2296,7 @@ int blues_set_global(BluesEngine* h, const char* name, double value) {
         DevAccum a; if (read_acc(h, &a)) return 1;
         a.protocol_work = value;
         HIP_OK(h, hipMemcpy(h->d_acc.p, &a, sizeof a, hipMemcpyHostToDevice));
+        h->acc_cache_valid = false;
     }
     else if (k == "step") h->h_step = (int)value;
     else if (k == "lambda") h->h_lambda = value;
@@ -2297,6 +2319,7 @@ int blues_reset(BluesEngine* h) {
     h->h_step = 0; h->h_lambda = 0.0; h->h_first_step = 0; h->h_perturbed = 0.0; h->h_unperturbed = 0.0; h->h_prop = 1; h->h_lambda_step = 0;
     h->unpert_valid = false; h->x_edited = false; h->pass_valid = false;
     HIP_OK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(DevAccum), h->stream));
+    h->acc_cache_valid = false;
     return 0;
 }
 

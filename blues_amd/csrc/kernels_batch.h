@@ -249,6 +249,8 @@ __global__ void __launch_bounds__(256) k_kinetic_b(const RepCore* __restrict__ r
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) ke[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    // ... and the member's accumulators (protocol work): the Metropolis test reads them next, chain by chain
+    if (threadIdx.x < 6) ke[gridDim.x + 6 * blockIdx.x + threadIdx.x] = reinterpret_cast<const double*>(A.acc)[threadIdx.x];
 }
 
 // energy partials of every member into one slab [R][stride]: nonbonded partials | bonded partials | alchemical partials |

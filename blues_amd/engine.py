@@ -78,6 +78,7 @@ class NativeEngine:
 
     def set_box(self, box3):
         # a full 3x3 matrix goes through as it is: the C side rejects non-orthorhombic boxes (include/blues_engine.h)
+        self._box_key = None   # (Context.setPeriodicBoxVectors remembers what it set last; anybody else's box invalidates that)
         b = np.zeros(9)
         if np.size(box3) == 3:
             b[0], b[4], b[8] = np.asarray(box3, dtype=np.float64).reshape(-1)

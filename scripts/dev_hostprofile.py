@@ -18,3 +18,7 @@ bench.one_switch(drv, chains, states, n, 1, clock)
 pr.disable()
 print(clock)
 pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+st = pstats.Stats(pr)
+st.sort_stats("cumtime").print_stats(45)
+st.print_callers("get_global")
+st.print_callers("getState")
