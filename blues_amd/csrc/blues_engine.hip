@@ -1190,7 +1190,7 @@ static int force_pass(BluesEngine* h, int base_L) {
     if (fork) {
         hipStream_t main_stream = h->cur;
         HIP_OK(h, hipEventRecord(h->evFork, main_stream)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evFork, 0));
-        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask); h->cur = main_stream;
+        h->cur = h->s1; rc = launch_bonded(h, true) || launch_alchemical(h, ls, le, fmask); h->cur = main_stream;   // (bonded terms and the next O step's noise need no list either)
         if (rc) return 1;
         HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
         rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, 2) : launch_lists<double>(h, h->lists_forced, 2);
@@ -1211,8 +1211,8 @@ static int force_pass(BluesEngine* h, int base_L) {
         rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (rc) return 1;
         if (launch_pme(h, 0)) return 1;
-        if (fork) HIP_OK(h, hipStreamWaitEvent(h->cur, h->evJ1, 0));
-        if (launch_bonded_and_finalize(h, le, true, fmask)) return 1;
+        if (fork) { HIP_OK(h, hipStreamWaitEvent(h->cur, h->evJ1, 0)); if (launch_finalize(h, le, fmask)) return 1; }
+        else if (launch_bonded_and_finalize(h, le, true, fmask)) return 1;
     }
     h->pass_valid = true; h->pass_L = base_L; h->st_passes++; h->vel_clean = true; h->acc_cache_valid = false;
     HIP_OK(h, hipGetLastError());

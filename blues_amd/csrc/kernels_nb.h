@@ -319,6 +319,9 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     if (!force && a.flags->list_gen == a.flags->req_gen && !(a.batch_req && *a.batch_req)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (t >= a.n_itiles) return;
+    // In a large batch this kernel shares the chip with the alchemical kernel (forked onto a side stream): its few blocks are
+    // the critical path to the nonbonded kernel, so their waves take precedence at the instruction arbiter.
+    __builtin_amdgcn_s_setprio(3);
     const int l = t / a.S;
     const int count = a.jcount[l];
     const int* jl = a.jlist + (size_t)l * a.jcap;
