@@ -1677,7 +1677,9 @@ static int batch_prefetch(BluesBatch* B, int what) {
             need[r] = !m->ecache.find(m->cur_ls, m->cur_le, nullptr);
             n_need += need[r];
         }
-        bool uniform = n_need == n_live && n_need > 1;   // (a partial set would have to mask the others out of the launches)
+        // members that already know their energy simply take part again (same launches, same value): masking them out of the
+        // shared launches would cost more than it saves, and ONE such member used to send all the others to their own evaluations
+        bool uniform = n_need > 1;
         for (int r = 0; r < R && uniform; r++) if (live[r]) {
             const BluesEngine* m = B->eng[r];
             uniform = m->e_frozen_valid && m->cur_ls == lead->cur_ls && m->cur_le == lead->cur_le && m->lists_forced == lead->lists_forced && m->prog.n == 0;
