@@ -436,12 +436,16 @@ static void nonbonded(Oracle *o, double ls, double le, double *F, double *T) {
     /* CPU baseline (ii) of SURVEY.md 8(d): the same pair loop on all cores.  Cells are dealt to the threads statically and the
      * thread-private force / energy arrays are summed in thread order, so a run is reproducible for a given thread count. */
     const int nt = omp_get_max_threads() < ncell ? omp_get_max_threads() : ncell;   /* (more threads than cells would only add empty force arrays to sum) */
-    double *Fp = F ? calloc((size_t)nt * 3 * n, sizeof(double)) : NULL;
+    /* the threads' force arrays live as long as the process and are cleared by their owners inside the parallel region (allocated
+     * and zeroed afresh by one thread for every evaluation, 192 x 23,400 x 3 doubles of page faults cost more than the pair loop) */
+    static double *Fp = NULL; static size_t Fp_cap = 0;
+    if (F && Fp_cap < (size_t)nt * 3 * n) { free(Fp); Fp_cap = (size_t)nt * 3 * n; Fp = malloc(Fp_cap * sizeof(double)); }
     double *Tp = calloc((size_t)nt * BLUES_N_ENERGY_TERMS, sizeof(double));
 #pragma omp parallel num_threads(nt)
     {
         const int th = omp_get_thread_num();
         double *Ft = F ? Fp + (size_t)th * 3 * n : NULL, *Tt = Tp + (size_t)th * BLUES_N_ENERGY_TERMS;
+        if (Ft) memset(Ft, 0, sizeof(double) * 3 * n);
 #pragma omp for schedule(static)
         for (int c = 0; c < ncell; c++) {
             const int cx = c / (nc[1] * nc[2]), cy = (c / nc[2]) % nc[1], cz = c % nc[2];
@@ -462,7 +466,7 @@ static void nonbonded(Oracle *o, double ls, double le, double *F, double *T) {
         for (int q = 0; q < 3 * n; q++) { double a = 0.0; for (int th = 0; th < nt; th++) a += Fp[(size_t)th * 3 * n + q]; F[q] += a; }   /* thread order: reproducible */
     }
     for (int th = 0; th < nt; th++) for (int q = 0; q < BLUES_N_ENERGY_TERMS; q++) T[q] += Tp[(size_t)th * BLUES_N_ENERGY_TERMS + q];
-    free(Fp); free(Tp);
+    free(Tp);
 #else
     for (int cx = 0; cx < nc[0]; cx++) for (int cy = 0; cy < nc[1]; cy++) for (int cz = 0; cz < nc[2]; cz++) {
         int c = (cx * nc[1] + cy) * nc[2] + cz;
