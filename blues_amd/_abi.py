@@ -9,7 +9,8 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+SWITCH_NONE, SWITCH_VV, SWITCH_GHMC = 0, 1, 2
 NB_NOCUTOFF = 0
 NB_PME_DIRECT = 1
 NB_PME = 2
@@ -53,6 +54,7 @@ class BluesIntegratorDesc(C.Structure):
         ("lambda_sterics", _dp), ("lambda_electrostatics", _dp),
         ("constraint_tolerance", C.c_double),
         ("seed", C.c_uint64), ("replica", C.c_int32), ("precision", C.c_int32),
+        ("switching_mode", C.c_int32), ("steps_per_propagation", C.c_int32),
     ]
 
 
@@ -180,9 +182,13 @@ class IntegratorData:
     seed: int = 0
     replica: int = 0
     precision: int = 0                   # 0 mixed, 1 double
+    switching_mode: int = 0              # SWITCH_NONE / SWITCH_VV / SWITCH_GHMC (reference blues/switching.py)
+    steps_per_propagation: int = 1
 
     @property
     def n_lambda_steps(self):
+        if self.switching_mode:
+            return int(self.nsteps_neq)
         return int(self.nsteps_neq) * self.splitting.count("H")
 
     def to_desc(self):
@@ -203,6 +209,7 @@ class IntegratorData:
         d.lambda_sterics = ls.ctypes.data_as(_dp); d.lambda_electrostatics = le.ctypes.data_as(_dp)
         d.constraint_tolerance = float(self.constraint_tolerance)
         d.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF; d.replica = int(self.replica); d.precision = int(self.precision)
+        d.switching_mode = int(self.switching_mode); d.steps_per_propagation = int(self.steps_per_propagation)
         return d, keep
 
 

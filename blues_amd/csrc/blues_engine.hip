@@ -135,6 +135,12 @@ struct BluesEngine {
     int nsteps = 0, nprop = 1, n_lambda = 0, precision = 0;
     double prop_min = 0, prop_max = 0;
     std::string split; int n_R = 0, n_V = 0, n_O = 0, n_H = 0, n_L = 0;
+    // switching integrators of reference blues/switching.py (BLUES_SWITCH_VV / BLUES_SWITCH_GHMC): `split` is synthesised
+    // ("H" + "AV" x psteps, or "HOAVO"), `split_first` is the propagation of the first-step block; the energy bookkeeping
+    // around each velocity-Verlet step (shadow work / Metropolis test) is done on the host with synchronous energies
+    int switch_mode = 0, psteps = 1; std::string split_first;
+    double sw_Epert = 0.0, sw_shadow = 0.0, sw_Einit = 0.0, sw_Efinal = 0.0, sw_bracket_E0 = 0.0; int sw_accept = 0, sw_naccept = 0, sw_ntrials = 0;
+    bool sw_bracket_open = false; struct BluesSnapshot* sw_saved = nullptr;
     std::vector<double> tab_ls, tab_le;
     uint64_t seed = 0; int replica = 0;
     // ---- mirrored control state
@@ -1379,19 +1385,37 @@ static int need_pass(BluesEngine* h, int lo, int hi) {  // need slots covering L
     return force_pass(h, lo);
 }
 
-static int splitting_pass(BluesEngine* h) {
-    if (h->remove_cm && !h->pass_valid && !h->split.empty() && h->split[0] == 'L') {
+static int total_energy(BluesEngine* h, double* E);
+static int kinetic_energy_now(BluesEngine* h, double* ke);
+static int switching_open(BluesEngine* h);
+static int switching_close(BluesEngine* h);
+static int load_positions(BluesEngine* h, const double* const src[3], int stride, int n_edit);
+
+static int run_fragment(BluesEngine* h, const std::string& frag) {
+    if (h->remove_cm && !h->pass_valid && !frag.empty() && frag[0] == 'L') {
         if (need_pass(h, h->h_lambda_step, h->h_lambda_step)) return 1;  // forces do not depend on velocities: evaluate them first
     }
-    if (emit_cm(h)) return 1;
-    for (char c : h->split) {
+    if (h->switch_mode == BLUES_SWITCH_NONE && emit_cm(h)) return 1;
+    for (size_t ci = 0; ci < frag.size(); ci++) {
+        const char c = frag[ci];
         switch (c) {
         case 'V': {
             if (need_pass(h, h->h_lambda_step, h->h_lambda_step)) return 1;
             if (emit(h, OP_V0 + (h->h_lambda_step - h->pass_L))) return 1;
+            if (h->sw_bracket_open && switching_close(h)) return 1;
+        } break;
+        case 'A': {   // first half of a velocity-Verlet step (switching modes only)
+            if (h->switch_mode == BLUES_SWITCH_VV && emit_cm(h)) return 1;   // addUpdateContextState, switching.py:939
+            if (switching_open(h)) return 1;
+            if (need_pass(h, h->h_lambda_step, h->h_lambda_step)) return 1;
+            if (emit(h, OP_A0 + (h->h_lambda_step - h->pass_L))) return 1;
+            h->pass_valid = false;
         } break;
         case 'R': if (emit(h, OP_R)) return 1; h->pass_valid = false; break;
-        case 'O': if (emit(h, OP_O)) return 1; break;
+        case 'O':
+            if (h->switch_mode == BLUES_SWITCH_GHMC && ci + 1 < frag.size() && frag[ci + 1] == 'A' && emit_cm(h)) return 1;   // addUpdateContextState ahead of the first randomisation, switching.py:976
+            if (emit(h, OP_O)) return 1;
+            break;
         case 'L': {
             if (need_pass(h, h->h_lambda_step, h->h_lambda_step)) return 1;
             if (h->h_lambda_step != h->pass_L) { if (flush_program(h)) return 1; if (force_pass(h, h->h_lambda_step)) return 1; }
@@ -1410,6 +1434,71 @@ static int splitting_pass(BluesEngine* h) {
         default: break;
         }
     }
+    return 0;
+}
+
+static int splitting_pass(BluesEngine* h) { return run_fragment(h, h->split); }
+
+// ---- host-side energy bookkeeping of the switching integrators (reference blues/switching.py; dead code there, so this is the
+// plain synchronous form: one total energy and one kinetic energy per velocity-Verlet step)
+static int kinetic_energy_now(BluesEngine* h, double* kinetic) {
+    if (flush_program(h)) return 1;
+    if (h->ke_cache_valid) { *kinetic = h->ke_cache; return 0; }
+    const int nb = (h->n + 255) / 256;
+    hipLaunchKernelGGL(k_kinetic, dim3(nb), dim3(256), 0, h->stream, h->n, h->d_mass.p, h->d_v[0].p, h->d_v[1].p, h->d_v[2].p, h->d_scratch.p);
+    h->st_launches++;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    std::vector<double> part(nb);
+    HIP_OK(h, hipMemcpy(part.data(), h->d_scratch.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
+    double ke = 0.0; for (double p : part) ke += p;
+    *kinetic = ke; h->ke_cache = ke; h->ke_cache_valid = true;
+    return 0;
+}
+
+// before the first half of a velocity-Verlet step: Eold = energy + kinetic (switching.py:941-942), or for GHMC
+// Eold = kinetic + Epert and the saved state (switching.py:986-989)
+static int switching_open(BluesEngine* h) {
+    if (h->switch_mode == BLUES_SWITCH_NONE) return 0;
+    double ke = 0.0;
+    if (h->switch_mode == BLUES_SWITCH_VV) {
+        double E;
+        if (total_energy(h, &E) || kinetic_energy_now(h, &ke)) return 1;
+        h->sw_bracket_E0 = E + ke;
+    } else {
+        if (kinetic_energy_now(h, &ke)) return 1;
+        h->sw_bracket_E0 = ke + h->sw_Epert;
+        if (h->sw_saved) { blues_snapshot_release(h->sw_saved); h->sw_saved = nullptr; }
+        if (blues_snapshot_capture(h, 3, &h->sw_saved)) return 1;
+    }
+    h->sw_bracket_open = true;
+    return 0;
+}
+
+// after the second half: shadow work (switching.py:955-959), or the Metropolis test with momentum flip (switching.py:998-1005)
+static int switching_close(BluesEngine* h) {
+    h->sw_bracket_open = false;
+    double E, ke;
+    if (total_energy(h, &E) || kinetic_energy_now(h, &ke)) return 1;
+    if (h->switch_mode == BLUES_SWITCH_VV) {
+        h->sw_shadow += (E + ke) - h->sw_bracket_E0;
+        h->sw_Epert = E;
+        return 0;
+    }
+    uint32_t r[4];
+    philox4x32((uint32_t)h->sw_ntrials, 0u, (uint32_t)h->replica * 4u + 2u, 0x47484D43u, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), r);
+    const double u = ((double)r[0] + 0.5) * 2.3283064365386963e-10;
+    h->sw_accept = (exp(-((ke + E) - h->sw_bracket_E0) / h->kT) - u >= 0.0) ? 1 : 0;   // Lepton step(x): 1 for x >= 0
+    if (!h->sw_accept) {
+        BluesSnapshot* sn = h->sw_saved;
+        const double* src[3] = {sn->x[0], sn->x[1], sn->x[2]};
+        if (load_positions(h, src, 1, 0)) return 1;
+        h->x_edited = false;   // (not a Move: no external-perturbation work)
+        hipLaunchKernelGGL(k_negated_copy3, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->n, sn->v[0], sn->v[1], sn->v[2], h->d_v[0].p, h->d_v[1].p, h->d_v[2].p);
+        h->st_launches++; h->vel_clean = false; h->ke_cache_valid = false;
+        if (total_energy(h, &E)) return 1;   // the energy of the restored positions at the current parameters
+    }
+    h->sw_Epert = E;   // "Epert = energy" after the step (switching.py:1357; the second randomisation does not move atoms)
+    h->sw_naccept += h->sw_accept; h->sw_ntrials++;
     return 0;
 }
 
@@ -1519,6 +1608,15 @@ static int step_head(BluesEngine* h) {
         h->acc_cache_valid = false;
         h->h_lambda = 0.0; h->h_lambda_step = 0; h->cur_ls = h->tab_ls[0]; h->cur_le = h->tab_le[0];
         h->h_perturbed = h->h_unperturbed = 0.0; h->unpert_valid = false;
+        if (h->switch_mode != BLUES_SWITCH_NONE) {
+            // first-step block of the switching integrators (switching.py:1209-1222 / 1341-1348): work reset, the initial
+            // alchemical state (table entry 0), its energy, then the propagation that precedes the first perturbation
+            h->sw_shadow = 0.0; h->x_edited = false;
+            double E;
+            if (total_energy(h, &E)) return 1;
+            h->sw_Einit = E; h->sw_Epert = E; h->sw_Efinal = 0.0;
+            if (run_fragment(h, h->split_first)) return 1;
+        }
     }
     if (h->h_step < h->nsteps) {
         if (h->h_first_step < 1) { h->h_first_step = 1; }
@@ -1897,7 +1995,18 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     h->dt = it->timestep; h->temperature = it->temperature; h->gamma = it->collision_rate; h->kT = KB_KJ * it->temperature;
     h->tol = it->constraint_tolerance; h->nsteps = it->nsteps_neq; h->nprop = it->nprop; h->n_lambda = it->n_lambda_steps;
     h->prop_min = it->prop_lambda_min; h->prop_max = it->prop_lambda_max; h->seed = it->seed; h->replica = it->replica; h->precision = it->precision;
-    for (const char* p = it->splitting; *p; p++) {
+    h->switch_mode = it->switching_mode; h->psteps = it->steps_per_propagation;
+    if (h->switch_mode != BLUES_SWITCH_NONE) {
+        if (h->switch_mode != BLUES_SWITCH_VV && h->switch_mode != BLUES_SWITCH_GHMC) E_FAIL(h, "unknown switching_mode %d", h->switch_mode);
+        if (h->psteps < 0 || h->nsteps < 1) E_FAIL(h, "switching integrators need nsteps_neq >= 1 and steps_per_propagation >= 0");
+        if (h->switch_mode == BLUES_SWITCH_VV) for (int q = 0; q < h->psteps; q++) h->split_first += "AV";
+        else if (h->psteps > 0) h->split_first = "OAVO";
+        h->split = "H" + h->split_first;
+        // every velocity-Verlet step is a whole timestep: two half kicks, one drift; the two velocity randomisations of a GHMC
+        // step use sqrt(b) = exp(-gamma dt / 2), which is the O substep of half a timestep
+        h->n_V = 2; h->n_R = 1; h->n_O = 2; h->n_H = 1;
+    }
+    for (const char* p = h->switch_mode ? "" : it->splitting; *p; p++) {
         if (*p == ' ') continue;
         if (*p != 'R' && *p != 'V' && *p != 'O' && *p != 'H' && *p != 'L') E_FAIL(h, "unsupported splitting token '%c'", *p);
         h->split.push_back(*p);
@@ -2021,6 +2130,7 @@ int blues_engine_destroy(BluesEngine* h) {
     hipSetDevice(h->device);
     if (h->batch) batch_detach_all(h->batch);  // a batch does not outlive any of its members
     hipStreamSynchronize(h->stream);
+    if (h->sw_saved) { blues_snapshot_release(h->sw_saved); h->sw_saved = nullptr; }
 #ifdef BLUES_STAMP
     { std::vector<long long> st; h->d_stamps.download(st); fprintf(stderr, "[stamps] last integrate launch, cycles per op:"); for (int i = 1; i < 40 && st[i] > 0; i++) fprintf(stderr, " %lld", st[i] - st[i - 1]); fprintf(stderr, "\n"); }
 #endif
@@ -2048,7 +2158,7 @@ static int download_xyz(BluesEngine* h, double* xyz, DBuf<double>* src) {   // d
 }
 
 // Shared tail of setPositions: the new coordinates are already on the device (src, SoA stride 1 or interleaved stride 3).
-static int load_positions(BluesEngine* h, const double* const src[3], int stride, int n_edit = 0) {
+static int load_positions(BluesEngine* h, const double* const src[3], int stride, int n_edit) {
     LoadPosArgs a; memset(&a, 0, sizeof a);
     a.n = h->n; a.stride = stride;
     for (int k = 0; k < 3; k++) { a.src[k] = src[k]; a.x[k] = h->d_x[k].p; a.x_sort[k] = h->d_x_sort[k].p; }
@@ -2087,7 +2197,7 @@ static int load_positions(BluesEngine* h, const double* const src[3], int stride
 // work bookkeeping for instantaneous moves: remember U(x_old, lambda) before overwriting (integrators.py:205)
 static int before_position_edit(BluesEngine* h) {
     if (flush_program(h)) return 1;
-    if (h->have_positions && h->h_first_step >= 1 && h->h_step > 0 && h->h_step < h->nsteps && !h->unpert_valid) {
+    if (h->switch_mode == BLUES_SWITCH_NONE && h->have_positions && h->h_first_step >= 1 && h->h_step > 0 && h->h_step < h->nsteps && !h->unpert_valid) {
         double E;
         if (total_energy(h, &E)) return 1;
         h->h_unperturbed = E; h->unpert_valid = true;
@@ -2118,7 +2228,7 @@ int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
     // one interleaved transfer; de-interleaving, image refresh and the re-sort statistics happen on the device
     HIP_OK(h, hipMemcpyAsync(h->d_stage.p, st.data(), sizeof(double) * 3 * h->n, hipMemcpyHostToDevice, h->stream));
     const double* src[3] = {h->d_stage.p, h->d_stage.p + 1, h->d_stage.p + 2};
-    return load_positions(h, src, 3);
+    return load_positions(h, src, 3, 0);
 }
 
 int blues_set_velocities(BluesEngine* h, const double* xyz, int32_t n_atoms) {
@@ -2270,7 +2380,7 @@ int blues_get_global(BluesEngine* h, const char* name, double* value) {
     else if (k == "n_lambda_steps") *value = h->n_lambda;
     else if (k == "nsteps") *value = h->nsteps;
     else if (k == "protocol_work") { if (read_acc(h, &a)) return 1; *value = a.protocol_work; }
-    else if (k == "shadow_work") *value = 0.0;
+    else if (k == "shadow_work") *value = h->switch_mode != BLUES_SWITCH_NONE ? h->sw_shadow : 0.0;
     else if (k == "perturbed_pe") *value = h->h_perturbed;
     else if (k == "unperturbed_pe") *value = h->h_unperturbed;
     else if (k == "first_step") *value = h->h_first_step;
@@ -2285,6 +2395,17 @@ int blues_get_global(BluesEngine* h, const char* name, double* value) {
     }
     else if (k == "heat") *value = 0.0;
     else if (k == "kT") *value = h->kT;
+    else if (h->switch_mode != BLUES_SWITCH_NONE && (k == "total_work" || k == "Epert" || k == "initial_energy" || k == "final_energy" || k == "accept" || k == "naccept" || k == "ntrials" || k == "psteps")) {
+        // globals of reference blues/switching.py:1062-1080, energies in kJ/mol
+        if (k == "total_work") { if (read_acc(h, &a)) return 1; *value = a.protocol_work + h->sw_shadow; }
+        else if (k == "Epert") *value = h->sw_Epert;
+        else if (k == "initial_energy") *value = h->sw_Einit;
+        else if (k == "final_energy") { if (h->h_step == 0) *value = 0.0; else if (h->psteps > 0) *value = h->sw_Epert; else if (total_energy(h, value)) return 1; }
+        else if (k == "accept") *value = h->sw_accept;
+        else if (k == "naccept") *value = h->sw_naccept;
+        else if (k == "ntrials") *value = h->sw_ntrials;
+        else *value = h->psteps;
+    }
     else if (k == "lambda_sterics") *value = h->cur_ls;
     else if (k == "lambda_electrostatics") *value = h->cur_le;
     else E_FAIL(h, "unknown global variable '%s'", name);
@@ -2308,7 +2429,10 @@ int blues_set_global(BluesEngine* h, const char* name, double value) {
     else if (k == "nprop") h->nprop = (int)value;
     else if (k == "perturbed_pe") h->h_perturbed = value;
     else if (k == "unperturbed_pe") { h->h_unperturbed = value; }
-    else if (k == "shadow_work") { if (value != 0.0) E_FAIL(h, "shadow work is not measured (measure_shadow_work=False)"); }
+    else if (k == "shadow_work") { if (h->switch_mode != BLUES_SWITCH_NONE) h->sw_shadow = value; else if (value != 0.0) E_FAIL(h, "shadow work is not measured (measure_shadow_work=False)"); }
+    else if (h->switch_mode != BLUES_SWITCH_NONE && (k == "total_work" || k == "naccept" || k == "ntrials")) {
+        if (k == "naccept") h->sw_naccept = (int)value; else if (k == "ntrials") h->sw_ntrials = (int)value;   // (total_work is derived)
+    }
     else if (k == "lambda_sterics") { h->cur_ls = value; h->pass_valid = false; }
     else if (k == "lambda_electrostatics") { h->cur_le = value; h->pass_valid = false; }
     else E_FAIL(h, "global variable '%s' cannot be set", name);
@@ -2322,6 +2446,7 @@ int blues_reset(BluesEngine* h) {
     h->unpert_valid = false; h->x_edited = false; h->pass_valid = false;
     HIP_OK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(DevAccum), h->stream));
     h->acc_cache_valid = false;
+    h->sw_shadow = 0.0; h->sw_Einit = 0.0; h->sw_Efinal = 0.0; h->sw_naccept = 0; h->sw_ntrials = 0; h->sw_accept = 0;   // switching.py:1023-1036
     return 0;
 }
 
@@ -2461,7 +2586,7 @@ int blues_set_positions_from_snapshot(BluesEngine* h, const BluesSnapshot* sn) {
         return blues_set_positions(h, tmp.data(), h->n);
     }
     const double* src[3] = {sn->x[0], sn->x[1], sn->x[2]};
-    if (load_positions(h, src, 1)) return 1;
+    if (load_positions(h, src, 1, 0)) return 1;
     // the energy that was known for these positions is known again (OpenMM re-evaluates; same value)
     if (sn->owner == h) h->ecache = sn->ecache;
     return 0;
@@ -2548,6 +2673,7 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
         if (!engines[r]) { g_batch_create_error = "null engine handle"; return 2; }
         if (engines[r]->batch) { g_batch_create_error = "engine already belongs to a batch"; return 2; }
         if (engines[r]->device != engines[0]->device) { g_batch_create_error = "all engines of a batch must live on the same device"; return 2; }
+        if (engines[r]->switch_mode != BLUES_SWITCH_NONE) { g_batch_create_error = "the switching integrators (switching_mode != 0) step one engine at a time: their energy bookkeeping is synchronous"; return 2; }
         for (int q = 0; q < r; q++) if (engines[q] == engines[r]) { g_batch_create_error = "duplicate engine handle"; return 2; }
     }
     BluesBatch* B = new BluesBatch();

@@ -30,6 +30,8 @@ enum {
     OP_RATTLE,                 // velocity constraints only (setVelocitiesToTemperature)
     OP_CM_PART,                // CMMotionRemover from the momentum partials of k_finalize (only inside the specialised step kernels)
     OP_L,                      // OpenMM LangevinIntegrator step (MD leg): v' = a v + (1-a)/g f/m + sqrt(kT(1-a^2)/m) xi; x' = x + dt v'; SHAKE; v = (x'-x)/dt
+    OP_A0, OP_A1, OP_A2,       // first half of a velocity-Verlet step (reference blues/switching.py:944-948): v += hV f/m (slot 0/1/2, NO RATTLE);
+                               // x += hR v ; SHAKE ; v += (x - x1)/hR (no RATTLE: the second half, OP_V*, kicks and then constrains velocities)
 };
 
 #define MAX_OPS 24
@@ -454,6 +456,23 @@ __device__ __forceinline__ void integrate_body(IntArgs& A, const Program& prog) 
                 moved = true;
             }
         } break;
+        case OP_A0: case OP_A1: case OP_A2: {
+            if (active) {
+                double F[4][3], xr[4][3], x1[4][3];
+                load_force(A, C, op - OP_A0, F);
+#pragma unroll
+                for (int a = 0; a < 4; a++) for (int k = 0; k < 3; k++) {
+                    C.v[a][k] += A.hV * F[a][k] * C.w[a];
+                    xr[a][k] = C.x[a][k];
+                    if (a < C.na) C.x[a][k] += A.hR * C.v[a][k];
+                    x1[a][k] = C.x[a][k];
+                }
+                ok &= shake(C, xr, A.tol, A);
+#pragma unroll
+                for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += (C.x[a][k] - x1[a][k]) * A.inv_hR;
+                moved = true;
+            }
+        } break;
         case OP_O: {
             if (active) {
 #pragma unroll
@@ -683,6 +702,13 @@ __global__ void __launch_bounds__(256) k_copy_arrays(Copy6Args a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
     for (int q = 0; q < a.count; q++) a.dst[q][(size_t)i * a.dst_stride] = a.src[q][(size_t)i * a.src_stride];
+}
+
+// v = -v_saved (momentum flip of a rejected GHMC trial, reference blues/switching.py:1002-1005)
+__global__ void __launch_bounds__(256) k_negated_copy3(int n, const double* s0, const double* s1, const double* s2, double* d0, double* d1, double* d2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    d0[i] = -s0[i]; d1[i] = -s1[i]; d2[i] = -s2[i];
 }
 
 // kinetic energy: per-block partials of sum 0.5 m v^2 over mobile atoms

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define BLUES_ABI_VERSION 2
+#define BLUES_ABI_VERSION 3
 
 /* nonbonded_method */
 #define BLUES_NB_NOCUTOFF 0   /* oracle only: vacuum systems (vacDivaline, two-body checks) */
@@ -123,7 +123,23 @@ typedef struct BluesIntegratorDesc {
     uint64_t seed;                 /* Philox key; stream = replica */
     int32_t replica;
     int32_t precision;             /* 0 = mixed (f32 pair math, f64 accumulation), 1 = double */
+    /* ABI 3: the switching integrators of reference blues/switching.py (dead code there: nothing imports the module).
+     * BLUES_SWITCH_NONE: the program above.  Otherwise `splitting`, nprop and the prop window are ignored and one call of
+     * integrator.step(1) runs the program of
+     *   BLUES_SWITCH_VV   NCMCVVAlchemicalIntegrator   (switching.py:1083-1241): first step: constrain, reset, lambda table
+     *                     entry 0, steps_per_propagation velocity-Verlet steps; every step: perturbation (protocol work), the
+     *                     same number of velocity-Verlet steps, each adding its change of energy + kinetic to the shadow work;
+     *   BLUES_SWITCH_GHMC NCMCGHMCAlchemicalIntegrator (switching.py:1244-1360): one GHMC step instead (velocity randomisation
+     *                     with b = exp(-collision_rate * timestep), Metropolised velocity Verlet with momentum flip on rejection,
+     *                     velocity randomisation), steps_per_propagation is not used, as in the reference.
+     * timestep is the velocity-Verlet step; n_lambda_steps = nsteps_neq; the tables hold the functions at t = i / nsteps_neq
+     * for direction 'insert', 1 - i / nsteps_neq for 'delete' (evaluated by the host language).  Work is kept in kJ/mol. */
+    int32_t switching_mode;
+    int32_t steps_per_propagation;
 } BluesIntegratorDesc;
+#define BLUES_SWITCH_NONE 0
+#define BLUES_SWITCH_VV 1
+#define BLUES_SWITCH_GHMC 2
 
 typedef struct BluesEngine BluesEngine;
 

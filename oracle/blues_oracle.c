@@ -51,6 +51,8 @@ typedef struct {
     double perturbed_pe, unperturbed_pe, first_step, nprop, prop, prop_lambda_min, prop_lambda_max;
     double Eold, Enew, heat, debug;
     double lambda_sterics, lambda_electrostatics;
+    /* switching.py integrators (energies in kJ/mol; the Python mirror divides by kT) */
+    double Epert, total_work, initial_energy, final_energy, accept, naccept, ntrials;
 } Globals;
 
 struct Oracle {
@@ -83,6 +85,7 @@ struct Oracle {
     int nsteps, nprop_i, n_lambda_steps;
     char split[MAX_SPLIT];
     int n_split, n_R, n_V, n_O, n_H;
+    int switch_mode, psteps;     /* BLUES_SWITCH_* (reference blues/switching.py), steps_per_propagation */
     double *tab_ls, *tab_le;
     uint64_t seed;
     uint32_t replica, draw;
@@ -279,7 +282,14 @@ Oracle *orc_create(const BluesSystemDesc *s, const BluesIntegratorDesc *it) {
     o->tol = it->constraint_tolerance; o->nsteps = it->nsteps_neq; o->nprop_i = it->nprop; o->n_lambda_steps = it->n_lambda_steps;
     o->seed = it->seed; o->replica = (uint32_t)it->replica; o->draw = 0;
     o->n_split = 0;
-    for (const char *p = it->splitting; *p; p++) {
+    o->switch_mode = it->switching_mode; o->psteps = it->steps_per_propagation;
+    if (o->switch_mode != BLUES_SWITCH_NONE) {
+        if (o->switch_mode != BLUES_SWITCH_VV && o->switch_mode != BLUES_SWITCH_GHMC) { snprintf(g_err, sizeof g_err, "unknown switching_mode %d", o->switch_mode); orc_destroy(o); return NULL; }
+        /* steps_per_propagation == 0: the reference's nsteps = 0 program, an instantaneous toggle without propagation (switching.py:1198-1207) */
+        if (o->psteps < 0 || o->nsteps < 1) { snprintf(g_err, sizeof g_err, "switching integrators need nsteps_neq >= 1 and steps_per_propagation >= 0"); orc_destroy(o); return NULL; }
+        o->n_H = 1;
+    }
+    for (const char *p = o->switch_mode ? "" : it->splitting; *p; p++) {
         if (*p == ' ') continue;
         if (*p != 'R' && *p != 'V' && *p != 'O' && *p != 'H' && *p != 'L') { snprintf(g_err, sizeof g_err, "unsupported splitting token '%c'", *p); orc_destroy(o); return NULL; }
         if (o->n_split >= MAX_SPLIT - 1) { snprintf(g_err, sizeof g_err, "splitting too long"); orc_destroy(o); return NULL; }
@@ -1080,8 +1090,119 @@ static void splitting_pass(Oracle *o) {
     }
 }
 
+/* ------------------------------------------------------------------ reference blues/switching.py (dead code there)
+ * Work is accumulated in kJ/mol here (the reference divides every increment by kT). */
+static double uniform_for_trial(const Oracle *o, uint32_t trial) {
+    uint32_t r[4];
+    orc_philox4x32(trial, 0u, o->replica * 4u + 2u, 0x47484D43u, (uint32_t)o->seed, (uint32_t)(o->seed >> 32), r);
+    return ((double)r[0] + 0.5) * 2.3283064365386963e-10;
+}
+
+/* addVelocityVerletStep, switching.py:934-959, without its energy bookkeeping */
+static void velocity_verlet(Oracle *o) {
+    const int n3 = 3 * o->n;
+    const double dt = o->dt;
+    cached_energy(o);   /* f at the current (x, parameters) */
+    for (int i = 0; i < o->n; i++) if (o->mass[i] != 0.0) for (int k = 0; k < 3; k++) o->v[3 * i + k] += 0.5 * dt * o->f[3 * i + k] / o->mass[i];
+    memcpy(o->xref, o->x, sizeof(double) * n3);
+    for (int i = 0; i < o->n; i++) if (o->mass[i] != 0.0) for (int k = 0; k < 3; k++) o->x[3 * i + k] += dt * o->v[3 * i + k];
+    o->xver++;
+    double *x1 = malloc(sizeof(double) * n3);
+    memcpy(x1, o->x, sizeof(double) * n3);
+    constrain_positions(o);
+    cached_energy(o);   /* f at the new positions */
+    for (int i = 0; i < o->n; i++) if (o->mass[i] != 0.0) for (int k = 0; k < 3; k++)
+        o->v[3 * i + k] += 0.5 * dt * o->f[3 * i + k] / o->mass[i] + (o->x[3 * i + k] - x1[3 * i + k]) / dt;
+    constrain_velocities(o);
+    free(x1);
+}
+
+/* addVelocityVerletStep with the shadow work, switching.py:941-959 */
+static void vv_with_shadow_work(Oracle *o) {
+    if (o->remove_cm) remove_cm_motion(o);   /* addUpdateContextState, switching.py:939 */
+    const double Eold = cached_energy(o) + orc_kinetic_energy(o);
+    velocity_verlet(o);
+    const double Enew = cached_energy(o) + orc_kinetic_energy(o);
+    o->g.shadow_work += Enew - Eold;
+    o->g.Epert = cached_energy(o);
+}
+
+/* velocity randomisation of addGHMCStep: v = sqrt(b) v + sqrt(1-b) sigma xi, b = exp(-gamma dt); constrain (switching.py:980-981, 1008-1009) */
+static void ghmc_randomise(Oracle *o) {
+    const double b = exp(-o->gamma * o->dt), sb = sqrt(b), s1b = sqrt(1.0 - b);
+    for (int i = 0; i < o->n; i++) if (o->mass[i] != 0.0) {
+        double g[3]; orc_gaussians(o->seed, o->replica * 4u, o->draw, (uint32_t)i, g);
+        const double sg = sqrt(o->kT / o->mass[i]);
+        for (int k = 0; k < 3; k++) o->v[3 * i + k] = sb * o->v[3 * i + k] + s1b * sg * g[k];
+    }
+    o->draw++;
+    constrain_velocities(o);
+}
+
+/* addGHMCStep, switching.py:961-1017.  The reference sums the new kinetic energy into a variable `ke` it never declares and then
+ * forms Enew from the OLD `kinetic` (switching.py:997-998) -- OpenMM would refuse that program; the evident intent (Enew = new
+ * kinetic + energy) is what is restated here. */
+static void ghmc_step(Oracle *o) {
+    const int n3 = 3 * o->n;
+    if (o->remove_cm) remove_cm_motion(o);   /* addUpdateContextState, switching.py:976 */
+    ghmc_randomise(o);
+    const double Eold = orc_kinetic_energy(o) + o->g.Epert;
+    double *xold = malloc(sizeof(double) * n3), *vold = malloc(sizeof(double) * n3);
+    memcpy(xold, o->x, sizeof(double) * n3); memcpy(vold, o->v, sizeof(double) * n3);
+    velocity_verlet(o);
+    const double Enew = orc_kinetic_energy(o) + cached_energy(o);
+    const double u = uniform_for_trial(o, (uint32_t)o->g.ntrials);
+    o->g.accept = (exp(-(Enew - Eold) / o->kT) - u >= 0.0) ? 1.0 : 0.0;   /* Lepton step(x) = 1 for x >= 0 */
+    if (o->g.accept != 1.0) {
+        memcpy(o->x, xold, sizeof(double) * n3); o->xver++;
+        for (int q = 0; q < n3; q++) o->v[q] = -vold[q];
+    }
+    free(xold); free(vold);
+    ghmc_randomise(o);
+    o->g.naccept += o->g.accept; o->g.ntrials += 1.0;
+}
+
+/* NCMCVVAlchemicalIntegrator (switching.py:1173-1241) / NCMCGHMCAlchemicalIntegrator (:1318-1360), nsteps > 0: one integrator step */
+static void switching_step(Oracle *o) {
+    Globals *g = &o->g;
+    if (g->step == 0.0) {
+        g->Epert = cached_energy(o);
+        memcpy(o->xref, o->x, sizeof(double) * 3 * o->n);
+        constrain_positions(o);
+        constrain_velocities(o);
+        g->total_work = 0.0; g->protocol_work = 0.0; g->shadow_work = 0.0;   /* addWorkResetStep */
+        g->lambda_step = 0.0; update_alchemical_parameters(o, 0);             /* addAlchemicalResetStep: table entry 0 = the initial state */
+        g->initial_energy = cached_energy(o);
+        g->Epert = g->initial_energy;   /* (the reference takes Epert before the reset, switching.py:1211, and not at all for nsteps = 0: the first GHMC
+                                           test / the toggle's work would then be measured from another state's energy) */
+        if (o->switch_mode == BLUES_SWITCH_VV) for (int p = 0; p < o->psteps; p++) vv_with_shadow_work(o);
+        else if (o->psteps > 0) { ghmc_step(o); g->Epert = cached_energy(o); }   /* (the reference leaves Epert stale here, switching.py:1341-1348: the first
+                                                                 perturbation would book the GHMC move's energy change as protocol work) */
+    }
+    if (g->step < g->nsteps) {
+        /* addAlchemicalPerturbationStep, switching.py:881-907 */
+        g->Eold = g->Epert;
+        g->lambda_step = g->step + 1.0; g->lambda = g->lambda_step / g->nsteps;
+        update_alchemical_parameters(o, (int)g->lambda_step);
+        g->Enew = cached_energy(o);
+        g->protocol_work += g->Enew - g->Eold;
+        if (o->switch_mode == BLUES_SWITCH_VV) for (int p = 0; p < o->psteps; p++) vv_with_shadow_work(o);
+        else if (o->psteps > 0) { ghmc_step(o); g->Epert = cached_energy(o); }
+        g->step += 1.0;
+        g->total_work = g->protocol_work + g->shadow_work;   /* addComputeTotalWorkStep */
+        g->final_energy = cached_energy(o);
+    }
+}
+
 /* reference blues/integrators.py:159-209, SURVEY.md Appendix A */
 int orc_step(Oracle *o, int nsteps) {
+    if (o->switch_mode != BLUES_SWITCH_NONE) {
+        for (int s = 0; s < nsteps; s++) {
+            switching_step(o);
+            for (int i = 0; i < 3 * o->n; i++) if (isnan(o->x[i])) return 1;
+        }
+        return 0;
+    }
     for (int s = 0; s < nsteps; s++) {
         Globals *g = &o->g;
         if (g->step == 0.0) {
@@ -1116,12 +1237,13 @@ void orc_reset(Oracle *o) {
     Globals *g = &o->g;
     g->step = 0; g->lambda = 0; g->protocol_work = 0; g->shadow_work = 0; g->first_step = 0;
     g->perturbed_pe = 0; g->unperturbed_pe = 0; g->prop = 1; g->lambda_step = 0;
+    g->total_work = 0; g->initial_energy = 0; g->final_energy = 0; g->naccept = 0; g->ntrials = 0;   /* switching.py:1023-1036 */
 }
 
 #define GLOBAL_LIST(X) \
     X(lambda) X(step) X(lambda_step) X(n_lambda_steps) X(nsteps) X(protocol_work) X(shadow_work) X(perturbed_pe) \
     X(unperturbed_pe) X(first_step) X(nprop) X(prop) X(prop_lambda_min) X(prop_lambda_max) X(Eold) X(Enew) X(heat) \
-    X(debug) X(lambda_sterics) X(lambda_electrostatics)
+    X(debug) X(lambda_sterics) X(lambda_electrostatics) X(Epert) X(total_work) X(initial_energy) X(final_energy) X(accept) X(naccept) X(ntrials)
 
 int orc_get_global(Oracle *o, const char *name, double *value) {
 #define X(f) if (!strcmp(name, #f)) { *value = o->g.f; return 0; }
