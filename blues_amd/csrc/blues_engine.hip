@@ -156,6 +156,12 @@ struct BluesEngine {
     double e_frozen[2] = {0, 0}; bool e_frozen_valid = false;
     ECache ecache;  // total potential energy at the current positions
     double ke_cache = 0; bool ke_cache_valid = false;
+    // setPositions' 16-byte verdict (frozen atom changed / how far the i-atoms are from their sort positions) is read back lazily:
+    // the copy into pinned memory is queued with the load and looked at by the next evaluation (resolve_xfer)
+    unsigned* h_xfer = nullptr; bool xfer_pending = false; hipStream_t xfer_stream = nullptr;
+    hipEvent_t ev_edit = nullptr;                             // recorded after the last copy OUT of the pinned staging area
+    unsigned char* h_edit = nullptr; size_t h_edit_cap = 0;   // pinned staging of a Move's edited atoms and of read-backs of a few atoms
+    std::vector<int> edit_idx_host;                           // what d_edit_idx holds (a Move asks for the same atoms every time)
     DevAccum acc_cache; bool acc_cache_valid = false; int64_t acc_cache_stamp = 0;   // accumulators as read back by a batch prefetch; valid until the next launch
     // ---- derived topology
     std::vector<int> mobile;       // caller indices with mass > 0
@@ -1167,7 +1173,27 @@ static int launch_pme(BluesEngine* h, int want_energy) {
     return h->precision == 0 ? launch_pme_t<float>(h, want_energy) : launch_pme_t<double>(h, want_energy);
 }
 
+static int download_xyz(BluesEngine* h, double* xyz, DBuf<double>* src);
+static int sort_and_tile(BluesEngine* h);
+static int resolve_xfer(BluesEngine* h) {
+    if (!h->xfer_pending) return 0;
+    h->xfer_pending = false;
+    HIP_OK(h, hipStreamSynchronize(h->xfer_stream));
+    const unsigned* out = h->h_xfer;
+    if (out[0]) { h->e_frozen_valid = false; h->pme_static_valid = false; }
+    float worst; memcpy(&worst, &out[1], sizeof worst);
+    // tiles are formed from the mobile non-alchemical atoms.  A few wandering i-atoms only stretch their tile's bounding
+    // box, and the device notices when that starts to cost (resort_hint); the host re-sorts when an i-atom is far out
+    // or a sizeable part of the system has moved
+    if (h->sorted_ok && (worst > 1.0f || (int)out[2] > h->n / 10)) {
+        if (download_xyz(h, h->hx.data(), h->d_x)) return 1;
+        h->sorted_ok = false;
+    }
+    return 0;
+}
+
 static int ensure_sorted(BluesEngine* h) {
+    if (resolve_xfer(h)) return 1;
     if (!h->have_positions) E_FAIL(h, "positions have not been set");
     if (!h->sorted_ok) return sort_and_tile(h);
     return 0;
@@ -1357,12 +1383,9 @@ static int total_energy(BluesEngine* h, double* E) {
 
 static int add_work(BluesEngine* h, double delta) {
     if (flush_program(h)) return 1;
-    HIP_OK(h, hipStreamSynchronize(h->stream));
-    DevAccum a;
-    HIP_OK(h, hipMemcpy(&a, h->d_acc.p, sizeof a, hipMemcpyDeviceToHost));
-    a.protocol_work += delta;
-    HIP_OK(h, hipMemcpy(h->d_acc.p, &a, sizeof a, hipMemcpyHostToDevice));
-    h->acc_cache_valid = false;
+    hipLaunchKernelGGL(k_add_work, dim3(1), dim3(1), 0, h->stream, h->d_acc.p, delta);   // (in stream order: no read-modify-write through the host)
+    h->st_launches++; h->acc_cache_valid = false;
+    HIP_OK(h, hipGetLastError());
     return 0;
 }
 
@@ -1756,6 +1779,7 @@ static int batch_prefetch(BluesBatch* B, int what) {
     const int R = B->R();
     if (R == 0) return 0;
     std::vector<char> live(R), need(R, 0);
+    for (int r = 0; r < R; r++) if (B->active[r] && !B->failed[r] && resolve_xfer(B->eng[r])) B->failed[r] = 1;
     for (int r = 0; r < R; r++) live[r] = B->active[r] && !B->failed[r] && B->eng[r]->have_positions && B->eng[r]->sorted_ok;
     BluesEngine* lead = nullptr;
     for (int r = 0; r < R; r++) if (live[r]) { lead = B->eng[r]; break; }
@@ -2131,6 +2155,9 @@ int blues_engine_destroy(BluesEngine* h) {
     if (h->batch) batch_detach_all(h->batch);  // a batch does not outlive any of its members
     hipStreamSynchronize(h->stream);
     if (h->sw_saved) { blues_snapshot_release(h->sw_saved); h->sw_saved = nullptr; }
+    if (h->h_xfer) { hipHostFree(h->h_xfer); h->h_xfer = nullptr; }
+    if (h->h_edit) { hipHostFree(h->h_edit); h->h_edit = nullptr; }
+    if (h->ev_edit) { hipEventDestroy(h->ev_edit); h->ev_edit = nullptr; }
 #ifdef BLUES_STAMP
     { std::vector<long long> st; h->d_stamps.download(st); fprintf(stderr, "[stamps] last integrate launch, cycles per op:"); for (int i = 1; i < 40 && st[i] > 0; i++) fprintf(stderr, " %lld", st[i] - st[i - 1]); fprintf(stderr, "\n"); }
 #endif
@@ -2165,7 +2192,9 @@ static int load_positions(BluesEngine* h, const double* const src[3], int stride
     a.mass = h->d_mass.p; a.alch_local = h->d_alch_local.p; a.sorted_of_orig = h->d_sorted_of_orig.p;
     a.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; a.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
     a.box = make_box(h); a.out = h->d_xfer_out.p;
-    HIP_OK(h, hipMemsetAsync(h->d_xfer_out.p, 0, 4 * sizeof(unsigned), h->stream));
+    // (a verdict still pending from an earlier load is kept: the kernels only OR / max / add into it)
+    if (!h->xfer_pending) HIP_OK(h, hipMemsetAsync(h->d_xfer_out.p, 0, 4 * sizeof(unsigned), h->stream));
+    else if (h->xfer_stream != h->stream) HIP_OK(h, hipStreamSynchronize(h->xfer_stream));
     hipLaunchKernelGGL(k_load_positions, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, a);
     h->st_launches++;
     if (n_edit > 0) {   // the edit list is already in d_edit_idx / d_edit_xyz
@@ -2176,20 +2205,10 @@ static int load_positions(BluesEngine* h, const double* const src[3], int stride
         hipLaunchKernelGGL(k_edit_positions, dim3((n_edit + 63) / 64), dim3(64), 0, h->stream, e);
         h->st_launches++;
     }
-    unsigned out[4];
-    HIP_OK(h, hipMemcpyAsync(out, h->d_xfer_out.p, sizeof out, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(h, hipStreamSynchronize(h->stream));
+    if (!h->h_xfer && hipHostMalloc((void**)&h->h_xfer, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) E_FAIL(h, "hipHostMalloc failed");
+    HIP_OK(h, hipMemcpyAsync(h->h_xfer, h->d_xfer_out.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    h->xfer_pending = true; h->xfer_stream = h->stream;
     h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear();
-    if (out[0]) { h->e_frozen_valid = false; h->pme_static_valid = false; }
-    float worst; memcpy(&worst, &out[1], sizeof worst);
-    // tiles are formed from the mobile non-alchemical atoms.  A few wandering i-atoms only stretch their tile's bounding
-    // box, and the device notices when that starts to cost (resort_hint); the host re-sorts when an i-atom is far out
-    // or a sizeable part of the system has moved
-    if (worst > 1.0f || (int)out[2] > h->n / 10) {
-        if (download_xyz(h, h->hx.data(), h->d_x)) return 1;
-        h->sorted_ok = false;
-        return sort_and_tile(h);
-    }
     h->lists_forced = true;
     return 0;
 }
@@ -2589,6 +2608,39 @@ int blues_set_positions_from_snapshot(BluesEngine* h, const BluesSnapshot* sn) {
     if (load_positions(h, src, 1, 0)) return 1;
     // the energy that was known for these positions is known again (OpenMM re-evaluates; same value)
     if (sn->owner == h) h->ecache = sn->ecache;
+    else if (resolve_xfer(h)) return 1;   // another engine's snapshot: its owner may recycle the buffer on its own stream
+    return 0;
+}
+
+// d_edit_idx <- idx (skipped when it already holds this list: a Move names the same atoms every iteration) and, when xyz is
+// given, d_edit_xyz <- xyz, through pinned staging so that neither copy blocks the host.  The pinned area is reused by the next
+// call: a copy still in flight from the previous one is waited for first (same stream, so normally long done).
+static int stage_edit_list(BluesEngine* h, const int32_t* idx, int n_idx, const double* xyz) {
+    try {
+        if ((int)h->d_edit_idx.n < n_idx) { h->d_edit_idx.alloc(n_idx); h->d_edit_xyz.alloc((size_t)3 * n_idx); h->edit_idx_host.clear(); }
+    } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+    const size_t need = (sizeof(int) + 3 * sizeof(double)) * (size_t)n_idx;
+    if (h->h_edit_cap < need) {
+        if (h->h_edit) { hipStreamSynchronize(h->stream); hipHostFree(h->h_edit); h->h_edit = nullptr; h->h_edit_cap = 0; }
+        if (hipHostMalloc((void**)&h->h_edit, need, hipHostMallocDefault) != hipSuccess) E_FAIL(h, "hipHostMalloc failed");
+        h->h_edit_cap = need;
+    } else if (h->ev_edit) HIP_OK(h, hipEventSynchronize(h->ev_edit));
+    double* px = reinterpret_cast<double*>(h->h_edit);
+    int* pi = reinterpret_cast<int*>(h->h_edit + 3 * sizeof(double) * (size_t)n_idx);
+    const bool same = (int)h->edit_idx_host.size() == n_idx && !memcmp(h->edit_idx_host.data(), idx, sizeof(int) * n_idx);
+    if (!same) {
+        memcpy(pi, idx, sizeof(int) * n_idx);
+        HIP_OK(h, hipMemcpyAsync(h->d_edit_idx.p, pi, sizeof(int) * n_idx, hipMemcpyHostToDevice, h->stream));
+        h->edit_idx_host.assign(idx, idx + n_idx);
+    }
+    if (xyz) {
+        memcpy(px, xyz, sizeof(double) * 3 * n_idx);
+        HIP_OK(h, hipMemcpyAsync(h->d_edit_xyz.p, px, sizeof(double) * 3 * n_idx, hipMemcpyHostToDevice, h->stream));
+    }
+    if (!same || xyz) {
+        if (!h->ev_edit) HIP_OK(h, hipEventCreateWithFlags(&h->ev_edit, hipEventDisableTiming));
+        HIP_OK(h, hipEventRecord(h->ev_edit, h->stream));
+    }
     return 0;
 }
 
@@ -2618,13 +2670,11 @@ int blues_set_positions_from_snapshot_edited(BluesEngine* h, const BluesSnapshot
     HIP_OK(h, hipSetDevice(h->device));
     if (before_position_edit(h)) return 1;
     if (sn->owner->stream != h->stream) HIP_OK(h, hipStreamSynchronize(sn->owner->stream));
-    try {
-        if ((int)h->d_edit_idx.n < n_idx) { h->d_edit_idx.alloc(n_idx); h->d_edit_xyz.alloc((size_t)3 * n_idx); }
-    } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
-    HIP_OK(h, hipMemcpyAsync(h->d_edit_idx.p, idx, sizeof(int) * n_idx, hipMemcpyHostToDevice, h->stream));
-    HIP_OK(h, hipMemcpyAsync(h->d_edit_xyz.p, ed.data(), sizeof(double) * 3 * n_idx, hipMemcpyHostToDevice, h->stream));
+    if (stage_edit_list(h, idx, n_idx, ed.data())) return 1;
     const double* src[3] = {sn->x[0], sn->x[1], sn->x[2]};
-    return load_positions(h, src, 1, n_idx);   // (synchronises before `ed` goes out of scope)
+    if (load_positions(h, src, 1, n_idx)) return 1;
+    if (sn->owner != h && resolve_xfer(h)) return 1;
+    return 0;
 }
 
 // positions / velocities of a few atoms of a snapshot (a Move that reads positions[indices] of a device-resident State)
@@ -2635,14 +2685,13 @@ int blues_snapshot_read_atoms(BluesSnapshot* sn, int32_t what, const int32_t* id
     if (n_idx <= 0) return 0;
     for (int e = 0; e < n_idx; e++) if (idx[e] < 0 || idx[e] >= sn->n) E_FAIL(h, "atom %d out of range", idx[e]);
     HIP_OK(h, hipSetDevice(h->device));
-    try {
-        if ((int)h->d_edit_idx.n < n_idx) { h->d_edit_idx.alloc(n_idx); h->d_edit_xyz.alloc((size_t)3 * n_idx); }
-    } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
-    HIP_OK(h, hipMemcpyAsync(h->d_edit_idx.p, idx, sizeof(int) * n_idx, hipMemcpyHostToDevice, h->stream));
+    if (stage_edit_list(h, idx, n_idx, nullptr)) return 1;
     double* const* s = what == 1 ? sn->x : sn->v;
     hipLaunchKernelGGL(k_gather_atoms, dim3((n_idx + 63) / 64), dim3(64), 0, h->stream, n_idx, h->d_edit_idx.p, s[0], s[1], s[2], h->d_edit_xyz.p);
-    HIP_OK(h, hipMemcpyAsync(out, h->d_edit_xyz.p, sizeof(double) * 3 * n_idx, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(h, hipStreamSynchronize(h->stream));
+    double* px = reinterpret_cast<double*>(h->h_edit);
+    HIP_OK(h, hipMemcpyAsync(px, h->d_edit_xyz.p, sizeof(double) * 3 * n_idx, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));   // the one wait of this call
+    memcpy(out, px, sizeof(double) * 3 * n_idx);
     return 0;
 }
 

@@ -704,6 +704,9 @@ __global__ void __launch_bounds__(256) k_copy_arrays(Copy6Args a) {
     for (int q = 0; q < a.count; q++) a.dst[q][(size_t)i * a.dst_stride] = a.src[q][(size_t)i * a.src_stride];
 }
 
+// protocol_work += delta (the work of an instantaneous Move, reference blues/integrators.py:184-191)
+__global__ void k_add_work(DevAccum* acc, double delta) { acc->protocol_work += delta; }
+
 // v = -v_saved (momentum flip of a rejected GHMC trial, reference blues/switching.py:1002-1005)
 __global__ void __launch_bounds__(256) k_negated_copy3(int n, const double* s0, const double* s1, const double* s2, double* d0, double* d1, double* d2) {
     const int i = blockIdx.x * 256 + threadIdx.x;
