@@ -255,7 +255,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--replicas", type=int, default=256, help="independent chains per GPU, advanced as one replica batch")
+    ap.add_argument("--replicas", type=int, default=512, help="independent chains per GPU, advanced as one replica batch (a multiple of 256 fills the "
+                    "256 CUs evenly: the nonbonded launch places one workgroup per chain; 512 amortises the latency-bound kernels of a step "
+                    "over twice the chains: 1.25 us per chain-step against 1.40 at 256)")
     ap.add_argument("--groups", type=int, default=1, help="the rank's chains form this many replica batches, each driven from its own host thread on its "
                     "own stream: one group's host phases and latency-bound kernels overlap the others' compute-bound ones (1 = a single batch)")
     ap.add_argument("--workers", type=int, default=1, help="host threads for the per-chain plugin-boundary work inside a group")

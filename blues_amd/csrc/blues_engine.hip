@@ -1263,6 +1263,12 @@ static int check_flags(BluesEngine* h) {
         h->pass_valid = false; h->lists_forced = true;
     }
     if (f.nan_flag) E_FAIL(h, "Particle coordinate is nan");
+    if (f.list_overflow && getenv("BLUES_DEBUG_LISTS")) {
+        std::vector<int> jc, ac; h->d_jcount.download(jc); if (h->d_acount.p) h->d_acount.download(ac);
+        int mj = 0, ma = 0; for (int c : jc) mj = std::max(mj, c); for (int c : ac) ma = std::max(ma, c);
+        fprintf(stderr, "[overflow] member %d mode %d S %d n_lists %d n_itiles %d jcap %d max jcount %d (lists %zu) acap %d max acount %d skin %.3f skin_m %.3f trig %.3f\n",
+                h->batch_index, h->k1_mode, h->S, h->n_lists, h->n_itiles, h->jcap, mj, jc.size(), h->acap, ma, h->skin, h->skin_m, h->trig);
+    }
     if (f.list_overflow) E_FAIL(h, "neighbour list capacity exceeded (jcap=%d)", h->jcap);
     if (f.constraint_fail) E_FAIL(h, "constraint solver did not converge (the step is unstable)");
     return 0;

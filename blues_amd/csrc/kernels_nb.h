@@ -603,8 +603,11 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<
 // the tile's j-list is staged into LDS ONCE per workgroup ({x,y,z,q} 16 B + {sigma/2, 2 sqrt(eps)} 8 B per atom), and a wave
 // walks the exact neighbour list of ONE i-atom at a time (list built with the tile lists, skin as margin), lane = one
 // neighbour, gathered from LDS by its 15-bit local index: 7 tested pairs in 10 are inside the cutoff, exclusions were
-// removed when the list was built, and the i-atom lives in scalar registers.  Per-lane fp32 partial sums are folded into fp64
-// every 4 iterations; the 64 lanes are then summed in fp64 in a fixed order (bitwise reproducible; no atomics).
+// removed when the list was built, and the i-atom lives in scalar registers.  Per-lane fp32 partial sums (at most NB_ATOM_U
+// pair terms) are folded into fp64 once per atom; the 64 lanes are then summed in fp64 in a fixed order (bitwise reproducible;
+// no atomics).  (Folding every 4 terms, dropping the index select and pairing the chunks were each within noise of 94 us at
+// R = 256: with four waves per SIMD the kernel is bound by VALU issue of the pair body itself, ~62 instructions of which three
+// are transcendental.)
 #define NB_ATOM_U 12   // list entries per lane requested together (768 neighbours per round)
 template <bool ENERGY>
 __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, const NbConst<float>& c, const AtomF* __restrict__ img, const int t) {   // t: list (group of S i-tiles)
@@ -664,7 +667,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         double fx = 0.0, fy = 0.0, fz = 0.0;
         float bx = 0.0f, by = 0.0f, bz = 0.0f;
         auto pair = [&](unsigned e, bool have) {
-            const unsigned idx = have ? (e & 0x7FFFu) : 0u;
+            const unsigned idx = e & 0x7FFFu;   // (entries past the end of the list were requested as 0: a valid slot, masked by `have`)
             const P4 bj = lp[idx];
             const P2 bp = lq[idx];
             const float dx = (float)(int32_t)(ix - bj.x) * c.scale[0];
@@ -680,11 +683,14 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
                 if (in) { const double wgt = (e & 0x8000u) ? 0.5 : 1.0; elj += wgt * (double)e1; ecl += wgt * (double)e2; }
             }
         };
+        // two list chunks per branch region: their LDS reads and transcendentals overlap (a second chunk past the end of the
+        // list is all-masked work, about 5 % of the iterations); the fp32 partials of a lane hold at most NB_ATOM_U pair terms
+        // before they are folded into fp64
 #pragma unroll
-        for (int u = 0; u < NB_ATOM_U; u++) {
+        for (int u = 0; u < NB_ATOM_U; u += 2) {
             if (u * 64 >= cnt) break;   // wave-uniform
             pair(ent[u], u * 64 + lane < cnt);
-            if ((u & 3) == 3) { fx += (double)bx; fy += (double)by; fz += (double)bz; bx = by = bz = 0.0f; }
+            pair(ent[u + 1], (u + 1) * 64 + lane < cnt);
         }
         for (int base = 64 * NB_ATOM_U; base < cnt; base += 64) {   // lists longer than the prefetch window (dense regions)
             const bool have = base + lane < cnt;
