@@ -352,6 +352,10 @@ def main():
     st0 = engs[0].stats(); b0 = [d._ncmc_batch.stats() for d in drivers]
     for ck in clocks:
         ck.update({"sync": 0.0, "switch": 0.0, "decide": 0.0})
+    # the chains' Python objects (contexts, integrators, move engines, state tables: a few thousand per chain) live as long as the
+    # process: park them in the permanent generation, so that the cyclic collector stops walking them during the iterations
+    import gc
+    gc.collect(); gc.freeze()
     barrier()
     t0 = time.perf_counter()
     recs = []
