@@ -616,3 +616,23 @@ def test_batch_rejects_incongruent_members_and_misuse(Engine, tol_box):
     with pytest.raises(EngineError, match="dissolved"):
         B2.step(1)
     B2.close(); a.step(1)
+
+
+def test_restoring_a_state_that_moves_a_frozen_atom(Engine):
+    """setPositions from a device-resident State learns on the device whether a FROZEN atom changed (the frozen-frozen energy is a
+    cached constant).  The verdict is read back lazily, by the next evaluation; two restores in a row must not lose it."""
+    s, v = systems.s23k(mobile_atoms=275, frozen=True)
+    g = Engine(s, _integ(10, 3).to_data(precision=1))
+    e0 = g.potential_energy()
+    snap = g.snapshot(positions=True, velocities=False)
+    frozen = int(np.nonzero(s.mass == 0.0)[0][100])
+    x = s.positions.copy(); x[frozen] += [0.05, -0.03, 0.02]
+    g.set_positions(x)
+    e1 = g.potential_energy()
+    assert abs(e1 - e0) > 1e-3
+    g.set_positions_from_snapshot(snap)     # the frozen atom goes back: the constant cached for x is stale ...
+    g.set_positions_from_snapshot(snap)     # ... and a second restore (which changes nothing) must not hide that
+    assert g.potential_energy() == pytest.approx(e0, rel=1e-13)
+    g.set_positions(x); g.set_positions_from_snapshot(snap); g.step(2)   # stepping resolves the verdict as well
+    g2 = Engine(s, _integ(10, 3).to_data(precision=1)); g2.step(2)
+    assert np.abs(g.get_positions() - g2.get_positions()).max() < 1e-11   # (not bitwise: the layout was derived from other coordinates)
