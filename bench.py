@@ -139,8 +139,8 @@ def cpu_baseline(system, vel, nsteps_sample):
     out = {"value": v1, "unit": "ns/day", "cores": 1, "kind": "port",
            "sample": "%d NCMC steps of the same S23k switch (3 full fp64 energy/force evaluations per step), %.1f s" % (nsteps_sample, dt1)}
     try:
-        ncores = len(os.sched_getaffinity(0))
-        n_omp = max(50, 4 * nsteps_sample)
+        ncores = int(os.environ.get("OMP_NUM_THREADS", 0)) or oracle.usable_cores()   # (affinity mask capped by the cgroup CPU quota)
+        n_omp = max(150, 12 * nsteps_sample)   # about 10-15 s on 16 cores
         vo, dto = timed(True, n_omp)
         out["all_cores"] = {"value": vo, "unit": "ns/day", "cores": ncores, "kind": "port", "sample": "%d steps, %.1f s, OpenMP over the pair loop's cells" % (n_omp, dto)}
     except Exception as e:   # (no OpenMP runtime on the host: the single-thread figure stands alone)

@@ -27,12 +27,33 @@ def build(force=False):
     return _LIB_PATH
 
 
+def usable_cores():
+    """CPU cores this process can actually keep busy: its affinity mask, capped by the cgroup CPU quota (a container that SEES 256
+    cores may be granted 16 cores' worth of time; 192 OpenMP threads then run slower than 16)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, -(-int(txt[0]) // int(txt[1]))))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, -(-q // per)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def lib(openmp=False):
     global _lib, _lib_omp
     if openmp:
         if _lib_omp is None:
             if not os.path.exists(_LIB_PATH_OMP):
                 build()
+            os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))   # read by libgomp when the library is loaded
             _lib_omp = _declare(C.CDLL(_LIB_PATH_OMP))
         return _lib_omp
     if _lib is None:
