@@ -2396,6 +2396,9 @@ static int read_acc(BluesEngine* h, DevAccum* a) {
 }
 
 int blues_get_global(BluesEngine* h, const char* name, double* value) {
+    // the host-side mirrors BLUES asks for most come first and need no device call
+    if (!strcmp(name, "lambda_sterics")) { *value = h->cur_ls; return 0; }
+    if (!strcmp(name, "lambda_electrostatics")) { *value = h->cur_le; return 0; }
     HIP_OK(h, hipSetDevice(h->device));
     std::string k(name);
     DevAccum a;

@@ -111,21 +111,37 @@ class NativeEngine:
         t = np.zeros(_abi.N_ENERGY_TERMS); self._check(self._lib.blues_get_energy_terms(self._h, self._ptr(t))); return t
 
     def step(self, n=1):
+        self.__dict__["_gcache"] = {}
         self._check(self._lib.blues_step(self._h, int(n)))
 
     def run_switch(self, n, trace=False):
+        self.__dict__["_gcache"] = {}
         if trace:
             w = np.zeros(int(n)); self._check(self._lib.blues_run_switch(self._h, int(n), self._ptr(w))); return w
         self._check(self._lib.blues_run_switch(self._h, int(n), None))
         return None
 
+    # The alchemical parameters are host-side mirrors in the engine and change only when the integrator steps or somebody sets
+    # them; BLUES asks for them six times per chain and iteration (getState(getParameters=True), simulation.py:874-881), so the
+    # last values are kept here and dropped by everything that can change them (step / run_switch / set_global / reset, and the
+    # batch's step).
+    _CACHED_GLOBALS = ("lambda_sterics", "lambda_electrostatics")
+
     def get_global(self, name):
-        v = C.c_double(); self._check(self._lib.blues_get_global(self._h, name.encode(), C.byref(v))); return v.value
+        cache = self.__dict__.setdefault("_gcache", {})
+        if name in cache:
+            return cache[name]
+        v = C.c_double(); self._check(self._lib.blues_get_global(self._h, name.encode(), C.byref(v)))
+        if name in self._CACHED_GLOBALS:
+            cache[name] = v.value
+        return v.value
 
     def set_global(self, name, value):
+        self.__dict__["_gcache"] = {}
         self._check(self._lib.blues_set_global(self._h, name.encode(), float(value)))
 
     def reset(self):
+        self.__dict__["_gcache"] = {}
         self._check(self._lib.blues_reset(self._h))
 
     def stats(self):
@@ -219,6 +235,8 @@ class NativeBatch:
             raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
         status = (C.c_int32 * R)()
         w = np.zeros((R, int(n))) if trace else None
+        for e in self.engines:
+            e.__dict__["_gcache"] = {}
         rc = self._lib.blues_batch_step(self._h, int(n), w.ctypes.data_as(_dp) if trace else None, status)
         if rc:
             raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
