@@ -114,6 +114,16 @@ struct Oracle {
 static void pme_setup(Oracle *o);
 static void reciprocal_space(Oracle *o, double *F, double *T);
 
+/* number of threads of the OpenMP pair loop (no-op in the serial build).  The environment variable is read when the OpenMP runtime
+ * initialises, which in a process that imported torch has long happened. */
+void orc_set_threads(int n) {
+#ifdef ORC_OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------ RNG */
 static inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 

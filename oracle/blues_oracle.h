@@ -73,6 +73,7 @@ double orc_default_lambda_sterics(double lambda);
 double orc_default_lambda_electrostatics(double lambda);
 void orc_get_prop_lambda(double prop_lambda, double out[2]);
 void orc_calculate_ncmc_steps(int nstepsNC, int nprop, double prop_lambda, int out[3]);
+void orc_set_threads(int n);   /* threads of the OpenMP pair loop (ORC_OPENMP build; no-op otherwise) */
 void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]);
 void orc_gaussians(uint64_t seed, uint32_t stream, uint32_t draw, uint32_t atom, double out[3]);
 double orc_pair_energy(double r, double qq, double sigma, double epsilon, double alpha_ewald, int alchemical,

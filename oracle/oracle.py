@@ -53,8 +53,9 @@ def lib(openmp=False):
         if _lib_omp is None:
             if not os.path.exists(_LIB_PATH_OMP):
                 build()
-            os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))   # read by libgomp when the library is loaded
             _lib_omp = _declare(C.CDLL(_LIB_PATH_OMP))
+            _lib_omp.orc_set_threads.argtypes = [C.c_int]; _lib_omp.orc_set_threads.restype = None
+            _lib_omp.orc_set_threads(int(os.environ.get("OMP_NUM_THREADS", 0)) or usable_cores())
         return _lib_omp
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
