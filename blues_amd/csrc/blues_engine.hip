@@ -645,7 +645,7 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_ex_start.upload(ex_start); h->d_ex_idx.upload(ex_idx);
         h->d_jrec.alloc((size_t)jcap);
         { std::vector<AlchARec> ar(h->alch.size());
-          for (size_t a2 = 0; a2 < h->alch.size(); a2++) { AlchARec& r = ar[a2]; const int ao = h->alch[a2]; r.ao = ao; r.asrt = h->h_sorted_of_orig[ao]; r.pad = 0; r.sig = h->sigma[ao]; r.eps = h->eps[ao]; r.q = h->charge[ao];
+          for (size_t a2 = 0; a2 < h->alch.size(); a2++) { AlchARec& r = ar[a2]; const int ao = h->alch[a2]; r.ao = ao; r.asrt = h->h_sorted_of_orig[ao]; r.pad = 0; r.sig = h->sigma[ao]; r.eps = std::sqrt(h->eps[ao]); r.q = h->charge[ao];   // (eps: its square root, see AlchARec)
             r.has_env_excl = 0; for (int p2 : h->excl[ao]) if (h->alch_local[p2] < 0) r.has_env_excl = 1; }
           h->d_arec.upload(ar); }
         h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * LIST_WAVES * ((((n + LIST_WAVES - 1) / LIST_WAVES) + 63) & ~63)); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));

@@ -239,7 +239,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
         if (jr) for (int k = tid; k < count; k += LIST_THREADS) {
             const int js = jl[k], jo = img[js].orig;
             JR r; r.jo = jo; r.jsrt = js | ((img[js].flags & FLAG_MOBILE) ? 0x40000000 : 0);   // bit 30: j is mobile (its force is wanted)
-            r.sig = a.p_sigma[jo]; r.eps = a.p_eps[jo]; r.q = a.p_charge[jo];
+            r.sig = a.p_sigma[jo]; r.eps = sqrt(a.p_eps[jo]); r.q = a.p_charge[jo];   // (eps: its square root, see AlchJRec)
             jr[k] = r;
         }
         return;
