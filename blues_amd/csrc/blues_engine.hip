@@ -775,8 +775,9 @@ template <typename R> static int launch_lists(BluesEngine* h, int force, int pha
     }
     if (phase != 1 && h->k1_mode == 2 && h->n_itiles > 0) {
         // second kernel of a rebuild (same gate): the atoms' own lists, one block per i-tile; the group's list lives in
-        // dynamic LDS there (positions 12 B + index 4 B + exclusion bitmap 8 B per entry)
-        const size_t lds = (size_t)h->jcap * 24;
+        // dynamic LDS there (positions 12 B + index 4 B per entry: 100 KB at the largest capacity, which leaves room for a
+        // workgroup of the alchemical kernel on the same CU)
+        const size_t lds = (size_t)h->jcap * 16;
         if (!batch_dry(h)) {
             static thread_local size_t lds_set[2] = {0, 0};
             const bool lead = batch_lead(h);

@@ -329,8 +329,10 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     extern __shared__ __align__(16) unsigned char list_smem[];
     float* sx = reinterpret_cast<float*>(list_smem); float* sy = sx + a.jcap; float* sz = sy + a.jcap;
     int* s_jm = reinterpret_cast<int*>(sz + a.jcap);                              // sorted index | mobile << 30
-    unsigned long long* s_bm = reinterpret_cast<unsigned long long*>(s_jm + a.jcap);   // [64][jcap / 64] excluded candidates of each slot
-    const int nchmax = a.jcap >> 6;
+    // excluded candidates of each i-slot as a short list of local indices (a [slot][chunk] bitmap cost a third of the LDS image and
+    // kept the alchemical kernel's workgroups off every CU this kernel ran on), with the range of chunks they fall into
+    __shared__ unsigned short s_ex[64][EXK_MAX];
+    __shared__ int s_exn[64], s_exlo[64], s_exhi[64];
     const float cfs[3] = {(float)c.dscale[0], (float)c.dscale[1], (float)c.dscale[2]};
     const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f, rl2m = (float)c.rlist2_m * 1.0001f + 1e-5f;
     NB_STAMP(t == 0 && tid == 0, 5);
@@ -342,7 +344,7 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
         s_jm[k] = js | ((fl & FLAG_MOBILE) ? 0x40000000 : 0);
         sx[k] = (float)(sfix)(qx - ref[0]) * cfs[0]; sy[k] = (float)(sfix)(qy - ref[1]) * cfs[1]; sz[k] = (float)(sfix)(qz - ref[2]) * cfs[2];
     }
-    for (int k = tid; k < 64 * nchmax; k += LIST_THREADS) s_bm[k] = 0ull;
+    if (tid < 64) { s_exn[tid] = 0; s_exlo[tid] = 0x7fffffff; s_exhi[tid] = -1; }
     __syncthreads();
     NB_STAMP(t == 0 && tid == 0, 6);
     int ia4[4]; float pi4[4][3]; bool ok4[4];
@@ -358,10 +360,20 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
             const int p = a.ex_idx[e0 + q];
             int lo = 0, hi = count;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if ((s_jm[mid] & 0x3FFFFFFF) < p) lo = mid + 1; else hi = mid; }
-            if (lo < count && (s_jm[lo] & 0x3FFFFFFF) == p) atomicOr(&s_bm[slot * nchmax + (lo >> 6)], 1ull << (lo & 63));
+            if (lo < count && (s_jm[lo] & 0x3FFFFFFF) == p) {
+                const int at = atomicAdd(&s_exn[slot], 1);
+                if (at < EXK_MAX) { s_ex[slot][at] = (unsigned short)lo; atomicMin(&s_exlo[slot], lo >> 6); atomicMax(&s_exhi[slot], lo >> 6); }
+                else a.flags->list_overflow = 1;   // (more excluded partners in range than any supported topology has)
+            }
         }
     }
     __syncthreads();
+    int exn4[4], exlo4[4], exhi4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int slot = wv + LIST_WAVES * u;
+        exn4[u] = __builtin_amdgcn_readfirstlane(min(s_exn[slot], EXK_MAX)); exlo4[u] = __builtin_amdgcn_readfirstlane(s_exlo[slot]); exhi4[u] = __builtin_amdgcn_readfirstlane(s_exhi[slot]);
+    }
     NB_STAMP(t == 0 && tid == 0, 7);
     int cntv[4] = {0, 0, 0, 0};
     unsigned short* out4[4];
@@ -382,11 +394,15 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
         const float lim = mob ? rl2m : rl2;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const unsigned long long bm = s_bm[(wv + LIST_WAVES * u) * nchmax + ch];   // same address in every lane: broadcast
+            bool excluded = false;
+            if (ch >= exlo4[u] && ch <= exhi4[u]) {   // wave-uniform; a handful of chunks per atom
+                const unsigned short* ex = s_ex[wv + LIST_WAVES * u];
+                for (int e = 0; e < exn4[u]; e++) excluded |= (int)ex[e] == k;   // same address in every lane: broadcast
+            }
             float dx = x - pi4[u][0], dy = y - pi4[u][1], dz = z - pi4[u][2];
             dx -= boxf[0] * rintf(dx * iboxf[0]); dy -= boxf[1] * rintf(dy * iboxf[1]); dz -= boxf[2] * rintf(dz * iboxf[2]);
             float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + kinf;
-            d2 = ((bm >> lane) & 1ull) ? INF : d2;
+            d2 = excluded ? INF : d2;
             const bool pass = d2 < lim && ok4[u];
             const unsigned long long bal = __ballot(pass);
             const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
