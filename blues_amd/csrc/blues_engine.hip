@@ -1311,7 +1311,10 @@ static EnergyShape energy_shape(const BluesEngine* h) {
 static int energy_launch(BluesEngine* h) {
     if (flush_program(h)) return 1;
     if (ensure_sorted(h)) return 1;
-    double ls[3] = {h->cur_ls, h->cur_ls, h->cur_ls}, le[3] = {h->cur_le, h->cur_le, h->cur_le};
+    // slot 1 of the alchemical kernel carries lambda_sterics = lambda_electrostatics = 1: the energy at the unmodified potential is
+    // what _computeAlchemicalCorrection and _syncStatesMDtoNCMC ask for next (reference blues/simulation.py:1100-1119),
+    // and only the alchemical terms differ -- it comes out of the same pass (energy_sum) instead of a second full evaluation
+    double ls[3] = {h->cur_ls, 1.0, h->cur_ls}, le[3] = {h->cur_le, 1.0, h->cur_le};
     int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced) : launch_lists<double>(h, h->lists_forced);
     h->lists_forced = false;
     if (rc) return 1;
@@ -1332,7 +1335,8 @@ static int energy_launch(BluesEngine* h) {
 
 // the host-side sums over the partials, in a fixed order (the same whether they were downloaded one engine at a time or
 // gathered for a whole batch)
-static void energy_sum(BluesEngine* h, const double* enb, const double* eb, int jcount_alch, const double* ep, double e_mesh, double T[BLUES_N_ENERGY_TERMS]) {
+// one[2] (optional): the two alchemical terms at lambda_sterics = lambda_electrostatics = 1 (slot 1 of the same pass)
+static void energy_sum(BluesEngine* h, const double* enb, const double* eb, int jcount_alch, const double* ep, double e_mesh, double T[BLUES_N_ENERGY_TERMS], double* one = nullptr) {
     const EnergyShape g = energy_shape(h);
     for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) T[t] = 0.0;
     double e_nb = 0.0; for (int w = 0; w < g.nw; w++) e_nb += enb[2 * w] + enb[2 * w + 1];
@@ -1344,7 +1348,16 @@ static void energy_sum(BluesEngine* h, const double* enb, const double* eb, int 
         double s[K2_NE] = {0, 0, 0, 0, 0, 0};
         for (int b = 0; b <= h->k2_nblocks_env; b++) { if (b >= nb_env && b != h->k2_nblocks_env) continue; for (int q = 0; q < K2_NE; q++) s[q] += ep[(size_t)b * K2_NP + q]; }
         T[5] = s[1] + s[4]; T[6] = h->cur_le * s[0] + s[5];
-    }
+        if (one) { one[0] = s[2] + s[4]; one[1] = 1.0 * s[0] + s[5]; }
+    } else if (one) { one[0] = 0.0; one[1] = 0.0; }
+}
+
+// total at the current parameters and, from the same terms, at lambda = (1, 1): summed in term order, as a direct evaluation at
+// those parameters would (so the cached value is the one that evaluation returns)
+static void energy_totals(BluesEngine* h, const double T[BLUES_N_ENERGY_TERMS], const double one[2], double* E, double* E_one) {
+    *E = 0.0; *E_one = 0.0;
+    for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) { *E += T[t]; *E_one += (t == 5) ? one[0] : (t == 6 ? one[1] : T[t]); }
+    (void)h;
 }
 
 // full potential energy breakdown at the current state and alchemical parameters (on demand; synchronises)
@@ -1372,7 +1385,10 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
     } catch (std::string& msg) { E_FAIL(h, "%s", msg.c_str()); }
     double e_mesh = 0.0;
     if (h->pme) HIP_OK(h, hipMemcpy(&e_mesh, h->d_pme_e.p, sizeof e_mesh, hipMemcpyDeviceToHost));
-    energy_sum(h, enb.data(), eb.data(), h->alch.empty() ? 0 : jc[h->n_lists], ep.data(), e_mesh, T);
+    double one[2], E, E_one;
+    energy_sum(h, enb.data(), eb.data(), h->alch.empty() ? 0 : jc[h->n_lists], ep.data(), e_mesh, T, one);
+    energy_totals(h, T, one, &E, &E_one);
+    h->ecache.put(1.0, 1.0, E_one); h->ecache.put(h->cur_ls, h->cur_le, E);   // (the current parameters last: they win when both are (1, 1))
     return 0;
 }
 
@@ -1839,10 +1855,10 @@ static int batch_prefetch(BluesBatch* B, int what) {
             if (ok) for (int r = 0; r < R; r++) if (live[r] && !(hints[r] & 2)) {   // a member with an error flag keeps no cached value: its own call will report
                 BluesEngine* m = B->eng[r];
                 const double* o = slab.data() + (size_t)r * stride;
-                double T[BLUES_N_ENERGY_TERMS], E = 0.0;
-                energy_sum(m, o, o + n_nb, (int)o[n_nb + n_b + n_al], o + n_nb + n_b, o[n_nb + n_b + n_al + 1], T);
-                for (int t = 0; t < BLUES_N_ENERGY_TERMS; t++) E += T[t];
-                m->ecache.put(m->cur_ls, m->cur_le, E);
+                double T[BLUES_N_ENERGY_TERMS], one[2], E, E_one;
+                energy_sum(m, o, o + n_nb, (int)o[n_nb + n_b + n_al], o + n_nb + n_b, o[n_nb + n_b + n_al + 1], T, one);
+                energy_totals(m, T, one, &E, &E_one);
+                m->ecache.put(1.0, 1.0, E_one); m->ecache.put(m->cur_ls, m->cur_le, E);
             }
             B->st_prefetch_pe++;
         }

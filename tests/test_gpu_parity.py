@@ -547,3 +547,31 @@ def test_barostat_on_gpu_matches_the_oracle(Engine, oracle_mod, tol_box):
         assert np.abs(g.get_positions() - o.get_positions()).max() < 1e-8
     assert 0 < n_acc
     g.close()
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("reciprocal", [False, True])
+def test_unmodified_potential_comes_with_every_energy_evaluation(Engine, oracle_mod, tol_box, precision, reciprocal):
+    """the energies _computeAlchemicalCorrection takes at lambda_sterics = lambda_electrostatics = 1 differ from the
+    energy at the current parameters only in the alchemical terms.  Every energy evaluation carries those terms at (1, 1) in a spare
+    slot of the same pass, so asking for the energy at (1, 1) afterwards costs no evaluation -- and returns, bit for bit, what a
+    direct evaluation at (1, 1) returns."""
+    s, v = tol_box
+    if reciprocal:
+        s = systems.with_reciprocal_space(s)
+    data = _integ().to_data(precision=precision)
+    g = Engine(s, data)
+    g.set_global("lambda_sterics", 0.4); g.set_global("lambda_electrostatics", 0.25)
+    e_mid = g.potential_energy()
+    n0 = g.stats()["own_energy_evaluations"]
+    g.set_global("lambda_sterics", 1.0); g.set_global("lambda_electrostatics", 1.0)
+    e_one = g.potential_energy()
+    assert g.stats()["own_energy_evaluations"] == n0, "the energy at (1, 1) should have come with the previous evaluation"
+    g2 = Engine(s, data)
+    assert g2.potential_energy() == e_one     # fresh engine: parameters default to (1, 1), a direct evaluation
+    o = oracle_mod.Oracle(s, data)
+    assert e_one == pytest.approx(o.energy_forces(1.0, 1.0)[0], rel=1e-10 if precision else 1e-6)
+    assert e_mid == pytest.approx(o.energy_forces(0.4, 0.25)[0], rel=1e-10 if precision else 1e-6) and abs(e_mid - e_one) > 1.0
+    g.step(1)                                  # positions moved: both cached values are gone
+    g.set_global("lambda_sterics", 1.0); g.set_global("lambda_electrostatics", 1.0)
+    assert g.potential_energy() != e_one
