@@ -89,6 +89,28 @@ def read_inpcrd(path):
     return pos, vel, box
 
 
+def read_rst7(path):
+    """Amber ASCII restart (.rst7 / .rst): the inpcrd layout with a velocity block (reference blues/settings.py:60-90 hands such
+    files to ParmEd).  Returns (positions nm, velocities nm/ps or None, box nm or None)."""
+    return read_inpcrd(path)
+
+
+def write_rst7(path, positions_nm, velocities_nm_ps=None, box_nm=None, title="written by blues_amd", time_ps=0.0):
+    """Amber ASCII restart in the fixed 6F12.7 layout (angstrom; velocities in angstrom per 1/20.455 ps)."""
+    x = np.asarray(positions_nm, dtype=np.float64).reshape(-1, 3) * 10.0
+    blocks = [x.reshape(-1)]
+    if velocities_nm_ps is not None:
+        blocks.append(np.asarray(velocities_nm_ps, dtype=np.float64).reshape(-1) * 10.0 / 20.455)
+    with open(path, "w") as fh:
+        fh.write(title[:80] + "\n")
+        fh.write("%5d%15.7e\n" % (len(x), time_ps) if velocities_nm_ps is not None else "%5d\n" % len(x))
+        for b in blocks:
+            for k in range(0, len(b), 6):
+                fh.write("".join("%12.7f" % v for v in b[k:k + 6]) + "\n")
+        if box_nm is not None:
+            fh.write("".join("%12.7f" % v for v in list(np.asarray(box_nm, dtype=np.float64).reshape(-1)[:3] * 10.0) + [90.0, 90.0, 90.0]) + "\n")
+
+
 def ewald_alpha(cutoff, tolerance):
     """OpenMM: alpha = sqrt(-ln(2 tol)) / cutoff (2.145966 for 0.005 at 1 nm)."""
     return float(np.sqrt(-np.log(2.0 * tolerance)) / cutoff)

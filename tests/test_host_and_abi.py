@@ -264,3 +264,21 @@ def test_header_is_plain_c(tmp_path):
     out = subprocess.check_output([str(exe)]).split()
     assert int(out[0]) == ctypes.sizeof(_abi.BluesSystemDesc) and int(out[1]) == ctypes.sizeof(_abi.BluesIntegratorDesc)
     assert int(out[2]) == _abi.BluesSystemDesc.remove_cm_motion.offset and int(out[3]) == _abi.BluesIntegratorDesc.precision.offset
+
+
+def test_amber_restart_round_trip(tmp_path):
+    """Amber ASCII restart files (.rst7: the inpcrd layout plus velocities; reference blues/settings.py:60-90 passes them to ParmEd):
+    what write_rst7 writes, read_rst7 / read_inpcrd read back to the 7 decimals of the format, with and without velocities and box."""
+    from blues_amd import amber
+    rng = np.random.RandomState(4)
+    x = rng.uniform(-1.0, 5.0, (7, 3)); v = rng.normal(0.0, 0.5, (7, 3)); box = np.array([4.3572, 6.5358, 8.7144])
+    p = str(tmp_path / "a.rst7")
+    amber.write_rst7(p, x, v, box)
+    x2, v2, b2 = amber.read_rst7(p)
+    assert np.abs(x2 - x).max() < 6e-9 and np.abs(v2 - v).max() < 2e-7 and np.abs(b2 - box).max() < 6e-9
+    amber.write_rst7(p, x, None, box)
+    x3, v3, b3 = amber.read_inpcrd(p)
+    assert v3 is None and np.abs(x3 - x).max() < 6e-9 and np.abs(b3 - box).max() < 6e-9
+    amber.write_rst7(p, x[:2], None, None)       # two atoms: a single, partly filled coordinate line and nothing else
+    x4, v4, b4 = amber.read_rst7(p)
+    assert x4.shape == (2, 3) and v4 is None and b4 is None
