@@ -182,7 +182,9 @@ int blues_run_switch(BluesEngine *h, int32_t n_steps, double *work_trace /* [n_s
  * (reference blues/simulation.py:935, blues/moves.py:1082, blues/reporters.py:415-418).
  * names: lambda step lambda_step n_lambda_steps nsteps protocol_work shadow_work
  *        perturbed_pe unperturbed_pe first_step nprop prop prop_lambda_min
- *        prop_lambda_max Eold Enew heat kT lambda_sterics lambda_electrostatics */
+ *        prop_lambda_max Eold Enew heat kT lambda_sterics lambda_electrostatics
+ *        and, with a switching_mode: total_work Epert initial_energy final_energy
+ *        accept naccept ntrials psteps (reference blues/switching.py:1062-1080; kJ/mol) */
 int blues_get_global(BluesEngine *h, const char *name, double *value);
 int blues_set_global(BluesEngine *h, const char *name, double value);
 /* AlchemicalExternalLangevinIntegrator.reset (reference blues/integrators.py:240-249) */
@@ -269,7 +271,11 @@ int blues_batch_set_active(BluesBatch *b, const int32_t *mask);
  * blues_set_positions calls that follow for each member (state.getPotentialEnergy
  * at simulation.py:908, the perturbed / unperturbed energies of
  * integrators.py:184-205) then cost no launch.  Purely an accelerator: results
- * are those of the per-member calls. */
+ * are those of the per-member calls.  (Every potential-energy evaluation, batched or
+ * not, also leaves the energy at lambda = (1, 1) in the cache -- only the alchemical terms
+ * differ and the kernel has a spare lambda slot -- so bit 2 normally finds its values there.
+ * With bit 1 the members' accumulators (protocol work) come back in the same read and serve
+ * the blues_get_global("protocol_work") calls that follow, until the member is stepped.) */
 int blues_batch_prefetch_energies(BluesBatch *b, int32_t what);
 /* [0] steps issued in lock step (one launch for all members) [1] steps that
  * fell back to per-member launches [2] members [3] batched energy evaluations */
