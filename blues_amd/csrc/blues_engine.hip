@@ -1223,7 +1223,7 @@ static int force_pass(BluesEngine* h, int base_L) {
     if (fork) {
         hipStream_t main_stream = h->cur;
         HIP_OK(h, hipEventRecord(h->evFork, main_stream)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evFork, 0));
-        h->cur = h->s1; rc = launch_bonded(h, true) || launch_alchemical(h, ls, le, fmask); h->cur = main_stream;   // (bonded terms and the next O step's noise need no list either)
+        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask) || launch_bonded(h, true); h->cur = main_stream;   // (bonded terms and the next O step's noise need no list either; the long kernel first)
         if (rc) return 1;
         HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
         rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, 2) : launch_lists<double>(h, h->lists_forced, 2);
