@@ -93,7 +93,7 @@ class Context(object):
         x = v = snap = None
         pe = ke = None
         if getEnergy:   # before the snapshot, so that the snapshot carries the energy of its positions
-            pe, ke = e.potential_energy(), e.kinetic_energy()
+            pe, ke = e.energies() if hasattr(e, "energies") else (e.potential_energy(), e.kinetic_energy())
         if (getPositions or getVelocities) and hasattr(e, "snapshot"):
             snap = e.snapshot(positions=bool(getPositions), velocities=bool(getVelocities))   # stays in HBM until somebody reads it
         else:

@@ -79,6 +79,7 @@ class NativeEngine:
     def set_box(self, box3):
         # a full 3x3 matrix goes through as it is: the C side rejects non-orthorhombic boxes (include/blues_engine.h)
         self._box_key = None   # (Context.setPeriodicBoxVectors remembers what it set last; anybody else's box invalidates that)
+        self.__dict__["_box_copy"] = None
         b = np.zeros(9)
         if np.size(box3) == 3:
             b[0], b[4], b[8] = np.asarray(box3, dtype=np.float64).reshape(-1)
@@ -96,10 +97,19 @@ class NativeEngine:
         f = np.empty((self.n, 3)); self._check(self._lib.blues_get_forces(self._h, self._ptr(f), self.n)); return f
 
     def get_box(self):
-        b = np.zeros(9); self._check(self._lib.blues_get_box(self._h, self._ptr(b))); return b.reshape(3, 3)
+        # (asked for by every getState; it changes only through set_box, which drops the copy kept here)
+        b = self.__dict__.get("_box_copy")
+        if b is None:
+            b = np.zeros(9); self._check(self._lib.blues_get_box(self._h, self._ptr(b))); b = b.reshape(3, 3)
+            self.__dict__["_box_copy"] = b
+        return b.copy()
 
     def set_velocities_to_temperature(self, T, seed=0):
         self._check(self._lib.blues_set_velocities_to_temperature(self._h, float(T), int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def energies(self):
+        """(potential, kinetic) in one call (state.getPotentialEnergy / getKineticEnergy of one getState)."""
+        e = C.c_double(); k = C.c_double(); self._check(self._lib.blues_get_energy(self._h, C.byref(e), C.byref(k))); return e.value, k.value
 
     def potential_energy(self):
         e = C.c_double(); self._check(self._lib.blues_get_energy(self._h, C.byref(e), None)); return e.value
