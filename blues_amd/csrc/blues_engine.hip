@@ -36,15 +36,18 @@ static thread_local std::string g_create_error;
 
 template <typename T> struct DBuf {
     T* p = nullptr; size_t n = 0;
-    void alloc(size_t count) {   // zero-filled; an existing buffer of the right size is reused (a re-sort keeps every address)
+    void reserve(size_t count) {   // an existing buffer of the right size is reused (a re-sort keeps every address)
         if (!p || count != n) {
             release(); n = count;
             if (hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::string("hipMalloc failed");
         }
+    }
+    void alloc(size_t count) {   // zero-filled
+        reserve(count);
         hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
     }
-    void upload(const std::vector<T>& h) {
-        if (h.size() != n || !p) alloc(h.size());
+    void upload(const std::vector<T>& h) {   // (every element is overwritten: no fill first)
+        if (h.size() != n || !p) reserve(h.size());
         if (!h.empty() && hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw std::string("hipMemcpy H2D failed");
     }
     void download(std::vector<T>& h) const {
