@@ -230,6 +230,7 @@ def declare_engine_prototypes(lib):
         "blues_get_box": ([H, _dp], C.c_int),
         "blues_set_velocities_to_temperature": ([H, C.c_double, C.c_uint64], C.c_int),
         "blues_get_energy": ([H, _dp, _dp], C.c_int),
+        "blues_get_energy_at": ([H, C.c_double, C.c_double, _dp], C.c_int),
         "blues_get_energy_terms": ([H, _dp], C.c_int),
         "blues_step": ([H, C.c_int32], C.c_int),
         "blues_run_switch": ([H, C.c_int32, _dp], C.c_int),
@@ -267,7 +268,7 @@ ENGINE_SYMBOLS = (
     "blues_engine_create", "blues_engine_destroy", "blues_last_error", "blues_abi_version",
     "blues_set_positions", "blues_set_velocities", "blues_set_box", "blues_get_positions",
     "blues_get_velocities", "blues_get_forces", "blues_get_box", "blues_set_velocities_to_temperature",
-    "blues_get_energy", "blues_get_energy_terms", "blues_step", "blues_run_switch", "blues_get_global",
+    "blues_get_energy", "blues_get_energy_at", "blues_get_energy_terms", "blues_step", "blues_run_switch", "blues_get_global",
     "blues_set_global", "blues_reset", "blues_get_stats", "blues_time_nonbonded", "blues_time_list_build",
     "blues_snapshot_capture", "blues_snapshot_release", "blues_snapshot_read", "blues_set_positions_from_snapshot",
     "blues_set_velocities_from_snapshot", "blues_snapshot_read_atoms", "blues_set_positions_from_snapshot_edited",

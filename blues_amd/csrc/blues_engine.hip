@@ -2379,6 +2379,19 @@ int blues_get_energy(BluesEngine* h, double* potential, double* kinetic) {
     return 0;
 }
 
+int blues_get_energy_at(BluesEngine* h, double lambda_sterics, double lambda_electrostatics, double* potential) {
+    if (!potential) E_FAIL(h, "blues_get_energy_at: null result pointer");
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    if (h->ecache.find(lambda_sterics, lambda_electrostatics, potential)) return 0;
+    const double ls = h->cur_ls, le = h->cur_le;
+    h->cur_ls = lambda_sterics; h->cur_le = lambda_electrostatics;
+    const int rc = total_energy(h, potential);
+    h->cur_ls = ls; h->cur_le = le;
+    h->pass_valid = false;   // (the slabs now hold another parameter set)
+    return rc;
+}
+
 int blues_get_energy_terms(BluesEngine* h, double terms[BLUES_N_ENERGY_TERMS]) {
     HIP_OK(h, hipSetDevice(h->device));
     return energy_terms(h, terms);

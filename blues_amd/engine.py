@@ -111,6 +111,10 @@ class NativeEngine:
         """(potential, kinetic) in one call (state.getPotentialEnergy / getKineticEnergy of one getState)."""
         e = C.c_double(); k = C.c_double(); self._check(self._lib.blues_get_energy(self._h, C.byref(e), C.byref(k))); return e.value, k.value
 
+    def potential_energy_at(self, lambda_sterics, lambda_electrostatics):
+        """Potential energy of the current coordinates at other alchemical parameters; the engine's own stay as they are."""
+        e = C.c_double(); self._check(self._lib.blues_get_energy_at(self._h, float(lambda_sterics), float(lambda_electrostatics), C.byref(e))); return e.value
+
     def potential_energy(self):
         e = C.c_double(); self._check(self._lib.blues_get_energy(self._h, C.byref(e), None)); return e.value
 

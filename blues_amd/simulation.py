@@ -91,6 +91,9 @@ class BLUESSimulation(object):
 
     def _energy_at_lambda_one(self):
         ctx = self._ncmc_sim.context
+        eng = getattr(ctx, "_engine", None)
+        if eng is not None and hasattr(eng, "potential_energy_at"):
+            return eng.potential_energy_at(1.0, 1.0)   # one call; the value normally comes with the previous evaluation
         ls, le = ctx.getParameter("lambda_sterics"), ctx.getParameter("lambda_electrostatics")
         ctx.setParameter("lambda_sterics", 1.0); ctx.setParameter("lambda_electrostatics", 1.0)
         e = ctx.getState(getEnergy=True).getPotentialEnergy()._value

@@ -164,6 +164,11 @@ int blues_get_box(BluesEngine *h, double box[9]);
 int blues_set_velocities_to_temperature(BluesEngine *h, double temperature, uint64_t seed);
 /* state.getPotentialEnergy() / getKineticEnergy() (simulation.py:908-909) */
 int blues_get_energy(BluesEngine *h, double *potential, double *kinetic);
+/* The potential energy of the current coordinates with lambda_sterics / lambda_electrostatics set to the given values, the
+ * engine's own parameters left as they are: what the reference obtains from a second Context (`alch`, wrapping the MD system)
+ * that it copies the coordinates into (simulation.py:1107-1110, 791-792).  For (1, 1) the value normally lies in the energy
+ * cache already (every evaluation leaves it there); otherwise one evaluation. */
+int blues_get_energy_at(BluesEngine *h, double lambda_sterics, double lambda_electrostatics, double *potential);
 /* per-term potential energies at the current state, for parity tests:
  * [0] bonds [1] angles [2] torsions [3] nonbonded env-env [4] exceptions
  * [5] alchemical sterics [6] alchemical electrostatics [7] restraint
