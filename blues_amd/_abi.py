@@ -9,13 +9,13 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 SWITCH_NONE, SWITCH_VV, SWITCH_GHMC = 0, 1, 2
 NB_NOCUTOFF = 0
 NB_PME_DIRECT = 1
 NB_PME = 2
 N_ENERGY_TERMS = 10
-N_STATS = 16
+N_STATS = 20
 ENERGY_TERM_NAMES = ("bonds", "angles", "torsions", "nonbonded", "exceptions", "alch_sterics",
                      "alch_electrostatics", "restraint", "reciprocal", "dispersion_correction")
 
@@ -55,6 +55,20 @@ class BluesIntegratorDesc(C.Structure):
         ("constraint_tolerance", C.c_double),
         ("seed", C.c_uint64), ("replica", C.c_int32), ("precision", C.c_int32),
         ("switching_mode", C.c_int32), ("steps_per_propagation", C.c_int32),
+    ]
+
+
+class BluesTuning(C.Structure):
+    """include/blues_engine.h: BluesTuning (launch-policy overrides; the library reads no environment variables)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("plain_skin", C.c_int32),
+        ("skin", C.c_double), ("prune_margin", C.c_double), ("jcap_scale", C.c_double), ("acap_scale", C.c_double),
+        ("k1_mode", C.c_int32), ("list_group", C.c_int32), ("sub_iw", C.c_int32), ("sub_chunks", C.c_int32),
+        ("seg_len", C.c_int32), ("waves_per_block", C.c_int32), ("k2_jiter", C.c_int32),
+        ("fuse_forces", C.c_int32), ("fuse_big", C.c_int32), ("fast_step", C.c_int32), ("slot_mask", C.c_int32),
+        ("fork", C.c_int32), ("use_graph", C.c_int32), ("graph_units", C.c_int32), ("graph_fork", C.c_int32),
+        ("batch_sync_lists", C.c_int32), ("force_lists", C.c_int32), ("no_sphere", C.c_int32),
+        ("pme_general", C.c_int32), ("debug_lists", C.c_int32), ("assume_batch", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -221,6 +235,9 @@ def declare_engine_prototypes(lib):
         "blues_engine_destroy": ([H], C.c_int),
         "blues_last_error": ([H], C.c_char_p),
         "blues_abi_version": ([], C.c_int),
+        "blues_tuning_default": ([C.POINTER(BluesTuning)], None),
+        "blues_set_tuning": ([C.POINTER(BluesTuning)], C.c_int),
+        "blues_get_tuning": ([C.POINTER(BluesTuning)], C.c_int),
         "blues_set_positions": ([H, _dp, C.c_int32], C.c_int),
         "blues_set_velocities": ([H, _dp, C.c_int32], C.c_int),
         "blues_set_box": ([H, _dp], C.c_int),
@@ -256,6 +273,7 @@ def declare_engine_prototypes(lib):
         "blues_batch_prefetch_energies": ([H, C.c_int32], C.c_int),
         "blues_batch_get_stats": ([H, C.POINTER(C.c_int64)], C.c_int),
         "blues_batch_time_nonbonded": ([H, C.c_int32, _dp], C.c_int),
+        "blues_batch_time_nonbonded_modes": ([H, C.c_int32, _dp, _dp], C.c_int),
     }
     for name, (args, res) in protos.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
@@ -266,6 +284,7 @@ def declare_engine_prototypes(lib):
 
 ENGINE_SYMBOLS = (
     "blues_engine_create", "blues_engine_destroy", "blues_last_error", "blues_abi_version",
+    "blues_tuning_default", "blues_set_tuning", "blues_get_tuning",
     "blues_set_positions", "blues_set_velocities", "blues_set_box", "blues_get_positions",
     "blues_get_velocities", "blues_get_forces", "blues_get_box", "blues_set_velocities_to_temperature",
     "blues_get_energy", "blues_get_energy_at", "blues_get_energy_terms", "blues_step", "blues_run_switch", "blues_get_global",
@@ -273,5 +292,5 @@ ENGINE_SYMBOLS = (
     "blues_snapshot_capture", "blues_snapshot_release", "blues_snapshot_read", "blues_set_positions_from_snapshot",
     "blues_set_velocities_from_snapshot", "blues_snapshot_read_atoms", "blues_set_positions_from_snapshot_edited",
     "blues_batch_create", "blues_batch_destroy", "blues_batch_last_error", "blues_batch_size", "blues_batch_step", "blues_batch_set_active", "blues_batch_prefetch_energies",
-    "blues_batch_get_stats", "blues_batch_time_nonbonded",
+    "blues_batch_get_stats", "blues_batch_time_nonbonded", "blues_batch_time_nonbonded_modes",
 )

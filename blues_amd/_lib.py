@@ -25,4 +25,6 @@ def load():
         if lib.blues_abi_version() != _abi.ABI_VERSION:
             raise EngineUnavailable("blues_amd: ABI version mismatch")
         _lib = lib
+        from . import tuning
+        tuning.apply_environment()   # BLUES_TUNING="field=value,..." (the native library itself reads no environment)
     return _lib

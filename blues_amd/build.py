@@ -6,7 +6,24 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BLUES_LIB_PATH") or os.path.join(CSRC, "libblues_hip.so")   # (override: development builds with other compiler flags)
-SOURCES = ["blues_engine.hip", "device_common.h", "kernels_nb.h", "kernels_alch.h", "kernels_bonded.h", "kernels_integrate.h", "kernels_batch.h"]
+# -fno-slp-vectorize: the SLP pass packs pairs of fp32 operations into v_pk_* instructions, which issue at half rate on
+# gfx950 (scripts/valu_issue.hip) and cost extra moves: the pair kernel runs 10 % faster without it (profiles/README.md)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize"]
+
+
+def sources():
+    """Everything the library is compiled from: the one translation unit and every header beside it."""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+
+
+def source_sha():
+    """SHA-256 prefix of the sources AND the compiler flags: evidence collected from one build (PMC counters) is only
+    quoted for the same build."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sources():
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def hipcc_path():
@@ -22,7 +39,7 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(_HERE, "..", "include", "blues_engine.h")]
+    deps = [os.path.join(CSRC, s) for s in sources()] + [os.path.join(_HERE, "..", "include", "blues_engine.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -38,10 +55,7 @@ def build_engine(force=False, verbose=False):
             if not force and not is_stale():
                 return LIB_PATH
             tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-            # -fno-slp-vectorize: the SLP pass packs pairs of fp32 operations into v_pk_* instructions, which issue at half rate on
-            # gfx950 (scripts/valu_issue.hip) and cost extra moves: the pair kernel runs 10 % faster without it (profiles/README.md)
-            cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
-                   "-o", tmp, os.path.join(CSRC, "blues_engine.hip")]
+            cmd = [hipcc_path()] + FLAGS + ["-o", tmp, os.path.join(CSRC, "blues_engine.hip")]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -34,6 +34,10 @@
 
 static thread_local std::string g_create_error;
 
+// Launch-policy overrides (include/blues_engine.h, BluesTuning): process-wide defaults copied into every engine / batch at its
+// creation.  The library reads no environment variables.
+static BluesTuning g_tuning = [] { BluesTuning t; blues_tuning_default(&t); return t; }();
+
 template <typename T> struct DBuf {
     T* p = nullptr; size_t n = 0;
     void reserve(size_t count) {   // an existing buffer of the right size is reused (a re-sort keeps every address)
@@ -131,8 +135,12 @@ struct BluesEngine {
     std::vector<int> alch_local;         // [n] -> local index or -1
     int nb_method = 1; double cutoff = 1, alpha = 0, sc_alpha = 0.5;
     int annih_elec = 1, annih_ster = 0, remove_cm = 0, check_env_excl = 0;
-    double skin = 0.12; bool skin_from_env = false;
+    BluesTuning tune;   // the process-wide tuning at the time this engine was created
+    double skin = 0.12; bool skin_fixed = false;
     double skin_m = 0.12, trig = 0.06;   // margin of MOBILE list candidates, and the displacement that asks for a rebuild (derive_margins)
+    // pruned per-atom lists (nonbonded_atom_body): inner margins for frozen / mobile candidates, displacement that asks for a prune
+    bool prune_on = false; double prune_m = 0.0, prune_m_mobile = 0.0, ptrig = 0.0;
+    EwaldPoly ewpoly;   // degree-9 fit of the smooth part of the Ewald pair force (fit_ewald_poly), mixed precision
     // ---- integrator
     double dt = 0, temperature = 0, gamma = 1, kT = 0, tol = 1e-8;
     int nsteps = 0, nprop = 1, n_lambda = 0, precision = 0;
@@ -181,7 +189,7 @@ struct BluesEngine {
     int hint_count = 0;   // list length that raises resort_hint
     int shape_S = 0, shape_jcap = 0; bool shape_overflow = false, forbid_atom = false; double shape_need = 0.0;
     int S = 1, n_lists = 0;   // S consecutive i-tiles share one j-list (mode 2; 1 otherwise); n_lists = ceil(n_itiles / S)
-    DBuf<unsigned short> d_alist; DBuf<int> d_acount;
+    DBuf<unsigned short> d_alist, d_plist; DBuf<int> d_acount, d_pcount; DBuf<double> d_xprune[3];
     int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
     double total_mass = 0;
@@ -251,6 +259,7 @@ struct BluesBatch {
     // list synchronisation: in a large batch some member needs new lists at almost every step, and the launch lasts as long
     // as one rebuild whoever asks; when they all rebuild together (any request rebuilds all) most steps see no rebuild at all
     DBuf<int> d_req; bool sync_lists = false;
+    BluesTuning tune;   // the process-wide tuning at the time the batch was created
     // Members keep their own streams for everything that is per replica (moves, state exchange, energies) so that host
     // threads serving different chains overlap; stepping runs on the batch's stream.  enter: the batch stream waits for
     // each member's pending work and the members issue into it; leave: the batch stream is drained, members go home.
@@ -274,13 +283,54 @@ static Box3 make_box(const BluesEngine* h) {
 // 2 trig.  Where nearly everything is frozen (freeze_radius, reference blues/simulation.py:394-480) the few mobile
 // candidates get the double margin and trig = skin: the same lists last twice the displacement.  Otherwise every candidate
 // has the margin `skin` and trig = skin / 2, the usual Verlet rule.
+// Pruned lists (prune_on): they keep what lies within cutoff + m of the positions at the last prune, m = prune_m for a frozen
+// candidate, 2 prune_m for a mobile one, and a prune is requested when an atom has moved ptrig = prune_m.  A prune reads the
+// full list, so that list must hold every pair within cutoff + m whenever a prune can happen: its own trigger is the
+// margin minus m.
 static void derive_margins(BluesEngine* h) {
     double room = 1e30;
     for (int k = 0; k < 3; k++) room = std::min(room, 0.5 * h->box[k] - h->cutoff - 1e-6);
     h->skin = std::min(h->skin, std::max(0.0, room));
-    const bool mostly_frozen = 4 * h->mobile.size() <= (size_t)h->n && !getenv("BLUES_PLAIN_SKIN");
+    const bool mostly_frozen = 4 * h->mobile.size() <= (size_t)h->n && !h->tune.plain_skin;
     h->skin_m = mostly_frozen ? std::min(2.0 * h->skin, std::max(0.0, room)) : h->skin;
     h->trig = std::min(h->skin, 0.5 * h->skin_m);
+    // the dual list pays where most candidates are frozen (one displacement per pair); elsewhere the full lists are walked
+    double m = h->tune.prune_margin < 0.0 ? 0.04 : h->tune.prune_margin;
+    h->prune_on = mostly_frozen && m > 0.0 && m < 0.75 * h->skin;
+    h->prune_m = h->prune_m_mobile = h->ptrig = 0.0;
+    if (h->prune_on) {
+        h->prune_m = m; h->prune_m_mobile = 2.0 * m; h->ptrig = m;
+        h->trig = std::min(h->skin - h->prune_m, 0.5 * (h->skin_m - h->prune_m_mobile));
+        if (h->trig <= 0.0) { h->prune_on = false; h->trig = std::min(h->skin, 0.5 * h->skin_m); }
+    }
+}
+
+// Degree-9 Chebyshev fit of T(u) = [erf(x) - 2/sqrt(pi) x exp(-x^2)] / r^3, x = alpha r, u = r^2 on [0, cutoff^2], in the
+// variable w = 2u/cutoff^2 - 1, converted to monomials in w (device_common.h: pair_regular<float>)
+static void fit_ewald_poly(double alpha, double rc, EwaldPoly* P) {
+    const int N = 64, D = EWALD_POLY_DEG;
+    const double two_sqrtpi = 2.0 / std::sqrt(M_PI);
+    double f[N], ck[D + 1];
+    for (int j = 0; j < N; j++) {
+        const double xj = std::cos(M_PI * (j + 0.5) / N), u = 0.5 * (xj + 1.0) * rc * rc, r = std::sqrt(u), x = alpha * r, x2 = x * x;
+        if (x < 0.1) f[j] = alpha * alpha * alpha * two_sqrtpi * (2.0 / 3.0 - 0.4 * x2 + x2 * x2 / 7.0 - x2 * x2 * x2 / 27.0 + x2 * x2 * x2 * x2 / 132.0);
+        else f[j] = (std::erf(x) - two_sqrtpi * x * std::exp(-x2)) / (r * r * r);
+    }
+    for (int k = 0; k <= D; k++) {
+        double sum = 0.0;
+        for (int j = 0; j < N; j++) sum += f[j] * std::cos(M_PI * k * (j + 0.5) / N);
+        ck[k] = (k == 0 ? 1.0 : 2.0) * sum / N;
+    }
+    // Chebyshev -> monomial: T_0 = 1, T_1 = w, T_{k+1} = 2 w T_k - T_{k-1}
+    double mono[D + 1] = {0}, t0[D + 1] = {0}, t1[D + 1] = {0}, t2[D + 1];
+    t0[0] = 1.0; t1[1] = 1.0;
+    for (int q = 0; q <= D; q++) mono[q] += ck[0] * t0[q] + (D >= 1 ? ck[1] * t1[q] : 0.0);
+    for (int k = 2; k <= D; k++) {
+        for (int q = 0; q <= D; q++) t2[q] = (q > 0 ? 2.0 * t1[q - 1] : 0.0) - t0[q];
+        for (int q = 0; q <= D; q++) { mono[q] += ck[k] * t2[q]; t0[q] = t1[q]; t1[q] = t2[q]; }
+    }
+    for (int q = 0; q <= D; q++) P->c[q] = (float)mono[q];
+    P->wa = (float)(2.0 / (rc * rc));
 }
 
 template <typename R> static NbConst<R> make_nbconst(const BluesEngine* h) {
@@ -290,6 +340,8 @@ template <typename R> static NbConst<R> make_nbconst(const BluesEngine* h) {
     c.rc2 = (R)(h->cutoff * h->cutoff); c.alpha = (R)h->alpha;
     c.rlist2 = (h->cutoff + h->skin) * (h->cutoff + h->skin);
     c.rlist2_m = (h->cutoff + h->skin_m) * (h->cutoff + h->skin_m);
+    c.rp2 = (float)((h->cutoff + h->prune_m) * (h->cutoff + h->prune_m)) * 1.00001f; c.rp2_m = (float)((h->cutoff + h->prune_m_mobile) * (h->cutoff + h->prune_m_mobile)) * 1.00001f;
+    c.ew = h->ewpoly;
     return c;
 }
 
@@ -485,8 +537,12 @@ static int sort_and_tile(BluesEngine* h) {
     h->n_islots = std::max(1, h->n_itiles) * 64;
     // Verlet skin: a small i-set is latency-bound (longer j-lists cost nothing, rebuilds do); a large one is
     // throughput-bound (every extra j costs pair evaluations)
-    if (!h->skin_from_env) {
-        h->skin = h->n_itiles * h->batch_R <= 32 ? 0.3 : 0.12;  // batch_R: a large batch is throughput-bound like a large i-set
+    if (!h->skin_fixed) {
+        // batch_R: a large batch is throughput-bound like a large i-set.  With pruned lists the nonbonded kernel no longer pays for
+        // the outer margin, and the rebuild trigger is the margin minus the inner one: the margin grows by it (same rebuild rate)
+        const bool mostly_frozen = 4 * h->mobile.size() <= (size_t)h->n && !h->tune.plain_skin;
+        const double m = h->tune.prune_margin < 0.0 ? 0.04 : h->tune.prune_margin;
+        h->skin = h->n_itiles * h->batch_R <= 32 ? 0.3 : (mostly_frozen ? 0.12 + m : 0.12);
     }
     derive_margins(h);
     // capacities
@@ -494,7 +550,7 @@ static int sort_and_tile(BluesEngine* h) {
     const double vol = h->box[0] * h->box[1] * h->box[2], rho = n / vol;
     const double a = std::cbrt(64.0 / std::max(rho, 1e-9)) * 1.35;  // tile edge incl. slack for diffusion
     double est = rho * (a * a * a + 6 * a * a * rl + 3 * M_PI * a * rl * rl + 4.0 / 3.0 * M_PI * rl * rl * rl) * 1.8;
-    if (const char* e = getenv("BLUES_JCAP_SCALE")) est *= atof(e);   // tests: shrink the capacity to exercise the re-sort path
+    if (h->tune.jcap_scale > 0.0) est *= h->tune.jcap_scale;   // tests: shrink the capacity to exercise the re-sort path
     int jcap = (int)std::min<double>(n, est);
     jcap = std::max(64, ((jcap + 63) / 64) * 64);
     jcap = std::min(jcap, 16384);
@@ -505,28 +561,28 @@ static int sort_and_tile(BluesEngine* h) {
         const double est_count = std::min<double>(jcap, est / 1.8);
         int CH = 64;
         while (CH > 8 && nit * (est_count / CH) < 4096.0) CH >>= 1;
-        if (const char* e = getenv("BLUES_SEG")) CH = std::max(4, std::min(64, atoi(e)));
+        if (h->tune.seg_len > 0) CH = std::max(4, std::min(64, h->tune.seg_len));
         int NW = std::max(1, std::min(jcap / CH, (8192 + nit - 1) / nit));
         int WPB = h->precision == 0 ? 16 : 8;
         while (WPB > 1 && (WPB > NW || nit * NW / WPB < 64)) WPB >>= 1;
-        if (const char* e = getenv("BLUES_WPB")) WPB = std::max(1, std::min(h->precision == 0 ? 16 : 8, atoi(e)));
+        if (h->tune.waves_per_block > 0) WPB = std::max(1, std::min(h->precision == 0 ? 16 : 8, h->tune.waves_per_block));
         // small i-set: every force kernel is latency-bound -> one fused launch.  In a replica batch the launch holds
         // batch_R times the work: from a few replicas on it is throughput that counts, and the separate kernels (each
         // with its own register / LDS budget, sub-tile nonbonded variant) win -- measured 259 vs 197 us at R = 64.
         h->fuse_forces = nit * h->batch_R <= 32;
-        if (const char* e = getenv("BLUES_FUSE")) h->fuse_forces = atoi(e) != 0;
+        if (h->tune.fuse_forces >= 0) h->fuse_forces = h->tune.fuse_forces != 0;
         if (h->fuse_forces) { WPB = 4; NW = std::max(4, NW / 3); }  // ~3 segments per wave: as long as the alchemical role
         NW = std::max(WPB, (NW / WPB) * WPB);
         h->seg_len = CH; h->waves_tile = NW; h->wpb = WPB; h->npart = NW / WPB;
         h->k1_iw = 64;
         if (!h->fuse_forces && h->precision == 0) {
             h->k1_iw = 8;
-            if (const char* e = getenv("BLUES_IW")) h->k1_iw = atoi(e);
+            if (h->tune.sub_iw > 0) h->k1_iw = h->tune.sub_iw;
             if (h->k1_iw != 8 && h->k1_iw != 16 && h->k1_iw != 32) h->k1_iw = 64;
         }
         if (h->k1_iw != 64) {
             int NC = 8;
-            if (const char* e = getenv("BLUES_NC")) NC = std::max(1, atoi(e));
+            if (h->tune.sub_chunks > 0) NC = h->tune.sub_chunks;
             h->waves_tile = NC; h->npart = NC; h->wpb = 4; h->seg_len = 64;
         }
         // throughput regime in mixed precision: per-atom Verlet lists over an LDS-resident image of the j-list
@@ -535,7 +591,7 @@ static int sort_and_tile(BluesEngine* h) {
         h->k1_mode = h->k1_iw != 64 ? 1 : 0;
         h->S = 1; h->acap = 0;
         bool want_atom = h->k1_mode == 1;
-        if (const char* e = getenv("BLUES_K1_MODE")) { if (atoi(e) == 1) want_atom = false; }
+        if (h->tune.k1_mode == 1) want_atom = false;
         if (h->forbid_atom) want_atom = false;
         if (want_atom && h->n_itiles > 0) {
             auto group_est = [&](int S) {   // largest expected list length over the groups of S tiles
@@ -560,7 +616,7 @@ static int sort_and_tile(BluesEngine* h) {
                 return worst;
             };
             double slack = 1.5;    // room for the i-atoms to spread before the next re-sort (a re-sort is asked for at 1.25x)
-            if (const char* e = getenv("BLUES_JCAP_SCALE")) slack *= atof(e);
+            if (h->tune.jcap_scale > 0.0) slack *= h->tune.jcap_scale;
             const int lds_max = 6400;     // list entries whose image (24 B each) fits the 160 KB of LDS beside the kernel's statics
             double best_cost = 1e300; int best_S = 0, best_cap = 0;
             h->shape_overflow = false;
@@ -568,7 +624,7 @@ static int sort_and_tile(BluesEngine* h) {
                 best_S = std::min(h->shape_S, std::max(1, h->n_itiles)); best_cap = h->shape_jcap;
                 h->shape_need = group_est(best_S);
                 if (h->shape_need * 1.1 + 64 > best_cap) h->shape_overflow = true;   // a re-sort (asked for at 90 % of the capacity) that does not make room
-                if (getenv("BLUES_DEBUG_LISTS")) fprintf(stderr, "[shape] member %d: S=%d need %.0f cap %d hint %d overflow %d\n", h->batch_index, best_S, h->shape_need, best_cap, h->hint_count, (int)h->shape_overflow);
+                if (h->tune.debug_lists) fprintf(stderr, "[shape] member %d: S=%d need %.0f cap %d hint %d overflow %d\n", h->batch_index, best_S, h->shape_need, best_cap, h->hint_count, (int)h->shape_overflow);
             } else {
                 for (int S : {1, 2, 3, 4, 5, 6, 8, 12, 16}) {
                     if (S > 1 && S > h->n_itiles) continue;
@@ -583,14 +639,14 @@ static int sort_and_tile(BluesEngine* h) {
                     const double cost = need / (std::min(S, h->n_itiles) * 64.0) * (one_wg ? 1.3 : 1.0);   // staging work per i-atom
                     if (cost < best_cost) { best_cost = cost; best_S = S; best_cap = cap; }
                 }
-                if (const char* e = getenv("BLUES_LIST_GROUP")) { const int S = std::max(1, std::min(16, atoi(e))); best_S = S; best_cap = group_est(S) * 1.3 + 64 > 3328 ? lds_max : 3328; }
+                if (h->tune.list_group > 0) { const int S = std::max(1, std::min(16, h->tune.list_group)); best_S = S; best_cap = group_est(S) * 1.3 + 64 > 3328 ? lds_max : 3328; }
                 if (best_S > 0) h->shape_need = group_est(best_S);
             }
             if (best_S > 0 && best_cap < 32768) {
                 h->k1_mode = 2; h->S = best_S; jcap = std::min(best_cap, ((n + 63) / 64) * 64); h->jcap = jcap;
                 h->waves_tile = 1; h->npart = 1; h->wpb = 4; h->seg_len = 64;
                 double cap = rho * 4.0 / 3.0 * M_PI * rl * rl * rl * 1.7;   // mean neighbour count within cutoff+skin, with slack for dense regions
-                if (const char* e = getenv("BLUES_ACAP_SCALE")) cap *= atof(e);
+                if (h->tune.acap_scale > 0.0) cap *= h->tune.acap_scale;
                 h->acap = std::min(jcap, std::max(64, (((int)cap + 63) / 64) * 64));
             }
         }
@@ -603,7 +659,7 @@ static int sort_and_tile(BluesEngine* h) {
     h->pool_cap = nt * MASK_QUOTA;
     h->PA = 1; while (h->PA < (int)h->alch.size()) h->PA <<= 1;
     h->k2_jiter = h->n_itiles * h->batch_R <= 32 && h->batch_R < 8 ? 1 : 8;   // measured at R = 256 (us per launch): 2: 160, 4: 123, 8: 110, 16: 113
-    if (const char* e = getenv("BLUES_K2_JITER")) h->k2_jiter = std::max(1, atoi(e));
+    if (h->tune.k2_jiter > 0) h->k2_jiter = h->tune.k2_jiter;
     h->k2_jiter = std::min(h->k2_jiter, h->PA);   // an env block stages (256 / PA) * jiter <= K2_STAGE list entries in LDS
     h->k2_nblocks_env = k2_env_blocks(jcap, h->PA, h->k2_jiter);
     // exclusions in sorted space (self included)
@@ -654,7 +710,10 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * LIST_WAVES * ((((n + LIST_WAVES - 1) / LIST_WAVES) + 63) & ~63)); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
         h->d_mask_pool.alloc((size_t)h->pool_cap * 64);
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
-        if (h->k1_mode == 2) { h->d_alist.alloc((size_t)h->n_islots * h->acap); h->d_acount.alloc(h->n_islots); }
+        if (h->k1_mode == 2) {
+            h->d_alist.alloc((size_t)h->n_islots * h->acap); h->d_acount.alloc(h->n_islots);
+            if (h->prune_on) { h->d_plist.alloc((size_t)h->n_islots * h->acap); h->d_pcount.alloc(h->n_islots); }
+        }
         h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1)) + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
         { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi);
           std::vector<FinRec> fr(h->n_islots + 64);
@@ -695,6 +754,9 @@ static IntArgs make_int_args(BluesEngine* h) {
     A.box = make_box(h); A.periodic = h->nb_method == BLUES_NB_PME_DIRECT; A.cl_periodic = 0;
     A.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; A.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
     A.half_skin2 = h->trig * h->trig; A.flags = h->d_flags.p; A.batch_req = batch_req_ptr(h);
+    const bool pruned = h->prune_on && h->k1_mode == 2;
+    for (int k = 0; k < 3; k++) A.xprune[k] = pruned ? h->d_xprune[k].p : nullptr;
+    A.prune_trig2 = h->ptrig * h->ptrig;
     A.total_mass = h->total_mass; A.cm_part = h->d_cm_part.p; A.cm_nblocks = h->int_blocks;
     A.mom_part = h->d_mom_part.p; A.n_mom = h->n_islots / 64 + 2;
     A.acc = h->d_acc.p; A.work_trace = (h->tracing || h->ctrl_arg) ? h->d_trace.p : nullptr; A.trace_index = h->prog_trace;
@@ -759,14 +821,13 @@ static ListArgs make_list_args(BluesEngine* h) {
     a.fJ = h->d_fJ.p; a.n_fJ = 9 * h->n;
     a.alch_jrec = h->alch.empty() ? nullptr : (void*)h->d_jrec.p; a.p_sigma = h->d_sigma.p; a.p_eps = h->d_eps.p; a.p_charge = h->d_charge.p;
     if (h->k1_mode == 2) { a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap; }
-    a.S = h->S; a.n_lists = h->n_lists; a.hint_count = h->hint_count; a.no_sphere = getenv("BLUES_NO_SPHERE") != nullptr;
+    a.S = h->S; a.n_lists = h->n_lists; a.hint_count = h->hint_count; a.no_sphere = h->tune.no_sphere;
     return a;
 }
 
 // phase 0: the whole rebuild; 1: the group lists only (k_build_lists); 2: the atoms' own lists only (k_build_atom_lists)
 template <typename R> static int launch_lists(BluesEngine* h, int force, int phase = 0) {
-    static const bool force_always = getenv("BLUES_FORCE_LISTS") != nullptr;   // development: every launch rebuilds every list
-    if (force_always) force = 1;
+    if (h->tune.force_lists) force = 1;   // development: every launch rebuilds every list
     const ListArgs a = make_list_args(h);
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
@@ -812,7 +873,13 @@ template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
     a.seg_len = h->seg_len; a.waves_tile = h->waves_tile; a.npart = h->npart;
     a.tile_atoms = h->d_tile_atoms.p; a.jlist = h->d_jlist.p; a.jcount = h->d_jcount.p; a.batch_slot = h->d_batch_slot.p; a.mask_pool = h->d_mask_pool.p;
     a.fpart = h->d_fpart.p; a.epart = h->d_epart_nb.p; a.flags = h->d_flags.p; a.batch_req = batch_req_ptr(h);
-    if (h->k1_mode == 2) { a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap; }
+    if (h->k1_mode == 2) {
+        a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap;
+        if (h->prune_on) {
+            a.plist = h->d_plist.p; a.pcount = h->d_pcount.p; a.mobile_atoms = h->d_mobile_atoms.p; a.n_mobile = (int)h->mobile.size();
+            for (int k = 0; k < 3; k++) { a.x[k] = h->d_x[k].p; a.xprune[k] = h->d_xprune[k].p; }
+        }
+    }
     a.S = h->S; a.n_lists = h->n_lists;
     return a;
 }
@@ -965,6 +1032,7 @@ static FinArgs make_fin_args(BluesEngine* h, const double le[3], int slot_mask =
     for (int k = 0; k < 3; k++) F.v[k] = h->d_v[k].p;
     F.mass = h->d_mass.p; F.mom_part = h->d_mom_part.p;
     F.frec = h->pme ? h->d_frec.p : nullptr;
+    F.flags = (h->prune_on && h->k1_mode == 2) ? h->d_flags.p : nullptr;
     return F;
 }
 
@@ -1140,7 +1208,7 @@ template <typename T> static int launch_pme_t(BluesEngine* h, int want_energy) {
     // (double precision, large meshes) the general one on global memory
     bool fast = false; size_t lds = 0;
     if constexpr (sizeof(T) == 4) {
-        fast = (size_t)h->pme_K[0] * h->pme_K[1] * (h->pme_K[2] / 2 + 1) <= PME_LDS_Y && !getenv("BLUES_PME_GENERAL");
+        fast = (size_t)h->pme_K[0] * h->pme_K[1] * (h->pme_K[2] / 2 + 1) <= PME_LDS_Y && !h->tune.pme_general;
         lds = PME_FAST_LDS(h->pme_K[0], h->pme_K[1], h->pme_K[2]);
         if (fast) {
             static thread_local size_t lds_set[2] = {0, 0};
@@ -1213,12 +1281,12 @@ static int force_pass(BluesEngine* h, int base_L) {
     // at an even index (first step, or the step after a Move) only V(slot 1).  Energies are always formed for all three.
     int fmask = 7;
     if (h->split == "HVRORVH" && h->nprop == 1) fmask = (base_L & 1) ? 5 : 2;
-    if (const char* e = getenv("BLUES_SLOT_MASK")) fmask = atoi(e) & 7;
+    if (h->tune.slot_mask >= 0) fmask = h->tune.slot_mask & 7;
     h->pass_fmask = fmask;
     // A large batch in per-atom-list mode forks the alchemical kernel onto a side stream after the group lists (which hold its
     // j records): the atoms' own lists are built by a few latency-bound blocks that leave most of the chip idle, and the
     // alchemical kernel fills it.  Joined before finalize.
-    static const bool fork_env = !getenv("BLUES_FORK") || atoi(getenv("BLUES_FORK")) != 0;
+    const bool fork_env = (h->batch ? h->batch->tune.fork : h->tune.fork) != 0;
     const bool decomposed = !(h->fuse_forces && h->wpb == 4) && !(h->k1_mode == 1 && h->precision == 0 && h->fuse_big);
     const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && !h->alch.empty() && h->s1 && !h->ctrl_arg;
     int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, fork ? 1 : 0) : launch_lists<double>(h, h->lists_forced, fork ? 1 : 0);
@@ -1267,7 +1335,7 @@ static int check_flags(BluesEngine* h) {
         h->pass_valid = false; h->lists_forced = true;
     }
     if (f.nan_flag) E_FAIL(h, "Particle coordinate is nan");
-    if (f.list_overflow && getenv("BLUES_DEBUG_LISTS")) {
+    if (f.list_overflow && h->tune.debug_lists) {
         std::vector<int> jc, ac; h->d_jcount.download(jc); if (h->d_acount.p) h->d_acount.download(ac);
         int mj = 0, ma = 0; for (int c : jc) mj = std::max(mj, c); for (int c : ac) ma = std::max(ma, c);
         fprintf(stderr, "[overflow] member %d mode %d S %d n_lists %d n_itiles %d jcap %d max jcount %d (lists %zu) acap %d max acount %d skin %.3f skin_m %.3f trig %.3f\n",
@@ -1290,7 +1358,7 @@ static int poll_resort(BluesEngine* h) {
     DevFlags f;
     HIP_OK(h, hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost));
     if (!f.resort_hint || f.list_overflow || f.nan_flag || f.constraint_fail) return 0;   // errors are reported by check_flags
-    if (getenv("BLUES_DEBUG_LISTS")) { std::vector<int> jc; h->d_jcount.download(jc); fprintf(stderr, "[resort] member %d step %d jcount[0]=%d hint_count %d jcap %d\n", h->batch_index, h->h_step, jc.empty() ? -1 : jc[0], h->hint_count, h->jcap); }
+    if (h->tune.debug_lists) { std::vector<int> jc; h->d_jcount.download(jc); fprintf(stderr, "[resort] member %d step %d jcount[0]=%d hint_count %d jcap %d\n", h->batch_index, h->h_step, jc.empty() ? -1 : jc[0], h->hint_count, h->jcap); }
     f.resort_hint = 0;
     HIP_OK(h, hipMemcpy(h->d_flags.p, &f, sizeof f, hipMemcpyHostToDevice));
     h->st_resorts++;
@@ -2008,6 +2076,20 @@ extern "C" {
 
 int blues_abi_version(void) { return BLUES_ABI_VERSION; }
 
+void blues_tuning_default(BluesTuning* t) {
+    memset(t, 0, sizeof *t);
+    t->struct_size = (int32_t)sizeof *t;
+    t->prune_margin = -1.0;
+    t->k1_mode = -1; t->fuse_forces = -1; t->fuse_big = -1; t->fast_step = -1; t->slot_mask = -1; t->fork = 1; t->use_graph = -1; t->graph_fork = -1;
+}
+int blues_set_tuning(const BluesTuning* t) {
+    if (!t) { blues_tuning_default(&g_tuning); return 0; }
+    if (t->struct_size != (int32_t)sizeof(BluesTuning)) { g_create_error = "blues_set_tuning: struct_size does not match this library's BluesTuning (call blues_tuning_default first)"; return 1; }
+    g_tuning = *t;
+    return 0;
+}
+int blues_get_tuning(BluesTuning* t) { *t = g_tuning; return 0; }
+
 const char* blues_last_error(const BluesEngine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesIntegratorDesc* it) {
@@ -2024,8 +2106,11 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     h->nb_method = BLUES_NB_PME_DIRECT; h->cutoff = s->cutoff;   // (the direct-space kernels are the same under both methods)
     h->alpha = s->ewald_alpha; h->sc_alpha = s->softcore_alpha;
     for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * h->cutoff) E_FAIL(h, "box edge %g < 2*cutoff", h->box[k]);
-    if (const char* sk = getenv("BLUES_SKIN")) { h->skin = atof(sk); h->skin_from_env = true; }
+    h->tune = g_tuning;
+    if (h->tune.assume_batch > 0) h->batch_R = h->tune.assume_batch;
+    if (h->tune.skin > 0.0) { h->skin = h->tune.skin; h->skin_fixed = true; }
     derive_margins(h);   // (again once the mobile set is known: sort_and_tile)
+    fit_ewald_poly(h->alpha, h->cutoff, &h->ewpoly);
     h->annih_elec = s->annihilate_electrostatics; h->annih_ster = s->annihilate_sterics; h->remove_cm = s->remove_cm_motion;
     h->mass.assign(s->mass, s->mass + n); h->charge.assign(s->charge, s->charge + n); h->sigma.assign(s->sigma, s->sigma + n); h->eps.assign(s->epsilon, s->epsilon + n);
     h->excl.assign(n, {});
@@ -2071,13 +2156,13 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     HIP_OK(h, hipStreamCreate(&h->s1)); HIP_OK(h, hipStreamCreate(&h->s2)); h->cur = h->stream;
     HIP_OK(h, hipEventCreate(&h->ev0)); HIP_OK(h, hipEventCreate(&h->ev1));
     HIP_OK(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ1, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ2, hipEventDisableTiming));
-    if (const char* g = getenv("BLUES_GRAPH")) h->use_graph = atoi(g) != 0;
-    if (const char* g = getenv("BLUES_FAST_STEP")) h->fast_step = atoi(g) != 0;
-    if (const char* g = getenv("BLUES_FUSE_BIG")) h->fuse_big = atoi(g) != 0;
-    if (const char* g = getenv("BLUES_GRAPH_UNITS")) h->graph_units = std::max(1, atoi(g));
-    if (const char* g = getenv("BLUES_GRAPH_FORK")) h->graph_fork = atoi(g) != 0;
+    if (h->tune.use_graph >= 0) h->use_graph = h->tune.use_graph != 0;
+    if (h->tune.fast_step >= 0) h->fast_step = h->tune.fast_step != 0;
+    if (h->tune.fuse_big >= 0) h->fuse_big = h->tune.fuse_big != 0;
+    if (h->tune.graph_units > 0) h->graph_units = h->tune.graph_units;
+    if (h->tune.graph_fork >= 0) h->graph_fork = h->tune.graph_fork != 0;
     try {
-        for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); h->d_x_sort[k].alloc(n); }
+        for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); h->d_x_sort[k].alloc(n); h->d_xprune[k].alloc(n); }
         h->d_stage.alloc((size_t)3 * n); h->d_xfer_out.alloc(4); h->hx.assign((size_t)3 * n, 0.0);
         h->d_mass.upload(h->mass); h->d_charge.upload(h->charge); h->d_sigma.upload(h->sigma); h->d_eps.upload(h->eps);
         h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ctrl.alloc(1); h->d_stamps.alloc(64); h->d_tab_ls.upload(h->tab_ls); h->d_tab_le.upload(h->tab_le); h->d_ftot.alloc((size_t)9 * n); h->d_alch_self.alloc(9 * 64);
@@ -2167,7 +2252,7 @@ static void batch_detach_all(BluesBatch* B) {
     batch_leave(B);
     for (BluesEngine* m : B->eng) if (m) {
         hipStreamSynchronize(m->stream);
-        m->batch = nullptr; m->batch_index = -1; m->batch_R = 1;
+        m->batch = nullptr; m->batch_index = -1; m->batch_R = m->tune.assume_batch > 0 ? m->tune.assume_batch : 1;
         m->shape_S = 0; m->shape_jcap = 0; m->forbid_atom = false;
         relayout(m);
     }
@@ -2515,7 +2600,7 @@ int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
     for (int i = 0; i < BLUES_N_STATS; i++) stats[i] = 0;
     stats[9] = h->st_resorts; stats[11] = h->st_energy_evals;
     if (h->d_jcount.p && h->sorted_ok) { std::vector<int> jc; hipSetDevice(h->device); hipStreamSynchronize(h->stream); try { h->d_jcount.download(jc); for (int c : jc) stats[8] = std::max<int64_t>(stats[8], c); } catch (std::string&) {} }
-    if (getenv("BLUES_DEBUG_LISTS") && h->k1_mode == 2 && h->d_acount.p) {
+    if (h->tune.debug_lists && h->k1_mode == 2 && h->d_acount.p) {
         std::vector<int> ac; h->d_acount.download(ac); std::vector<int> jc2; h->d_jcount.download(jc2);
         fprintf(stderr, "[lists] S=%d n_lists=%d jcap=%d acap=%d jcount:", h->S, h->n_lists, h->jcap, h->acap); for (int c : jc2) fprintf(stderr, " %d", c);
         fprintf(stderr, "\n[lists] acount:"); for (size_t i = 0; i < ac.size(); i++) fprintf(stderr, " %d", ac[i]); fprintf(stderr, "\n");
@@ -2526,7 +2611,12 @@ int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
         try { h->d_acount.download(ac); for (int c : ac) { stats[14] += c; stats[15] += (c + 63) / 64; } } catch (std::string&) {}
     }
     stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
-    if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) { stats[1] = f.list_gen; stats[10] = f.builds; } }
+    if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) { stats[1] = f.list_gen; stats[10] = f.builds; stats[16] = f.prunes; } }
+    stats[19] = h->prune_on && h->k1_mode == 2;
+    if (stats[19] && h->d_pcount.p && h->sorted_ok) {
+        std::vector<int> pc, ta;
+        try { h->d_pcount.download(pc); h->d_tile_atoms.download(ta); for (size_t q = 0; q < pc.size() && q < ta.size(); q++) if (ta[q] >= 0) { stats[17] += pc[q]; stats[18] += (pc[q] + 63) / 64; } } catch (std::string&) {}
+    }
     return 0;
 }
 
@@ -2537,7 +2627,10 @@ int blues_time_nonbonded(BluesEngine* h, int32_t reps, double* usec) {
     int rc = h->precision == 0 ? launch_lists<float>(h, 1) : launch_lists<double>(h, 1);
     if (rc) return 1;
     h->pass_valid = false;
+    // (with pruned lists: the first launch prunes, the acknowledged state is what the timed launches see -- the steady state
+    // between two prunes; blues_batch_time_nonbonded_modes times both kinds of pass)
     for (int w = 0; w < 3; w++) { rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h); if (rc) return 1; }
+    if (h->prune_on && h->k1_mode == 2) hipLaunchKernelGGL(k_prune_set, dim3(1), dim3(64), 0, h->stream, (const RepCore*)nullptr, h->d_flags.p, 1, 0);
     HIP_OK(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; r++) { rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h); if (rc) return 1; }
     HIP_OK(h, hipEventRecord(h->ev1, h->stream));
@@ -2781,7 +2874,8 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
     // off by default: measured on MI355X at R = 256 it does not pay (with 256 x 276 mobile atoms SOME atom crosses skin/2
     // every ~3 steps, and rebuilding all members at once costs about what one rebuild per step did: 669 vs 678 us/step)
     B->sync_lists = false;
-    if (const char* e = getenv("BLUES_BATCH_SYNC_LISTS")) B->sync_lists = atoi(e) != 0;
+    B->tune = g_tuning;
+    B->sync_lists = B->tune.batch_sync_lists != 0;
     try { B->d_req.alloc(1); } catch (std::string& e) { g_batch_create_error = e; batch_detach_all(B); delete B; return 1; }
     B->seen_epoch.assign(count, 0); B->failed.assign(count, 0); B->active.assign(count, 1); B->rec_active.assign(count, 0); B->rec_delta.assign(count, 0); B->leader = engines[0];
     *out = B;
@@ -2838,28 +2932,55 @@ int blues_batch_get_stats(BluesBatch* b, int64_t stats[4]) {
 }
 
 // average duration of one batched nonbonded launch (all replicas), HIP events on the batch's stream
-int blues_batch_time_nonbonded(BluesBatch* b, int32_t reps, double* usec) {
+// usec[0]: a pass over current pruned lists; usec[1]: a pass that re-derives them (walks the full lists); equal where the
+// kernel has no pruned lists.  frac: the share of prune passes among this batch's force passes so far.
+int blues_batch_time_nonbonded_modes(BluesBatch* b, int32_t reps, double usec[2], double* prune_fraction) {
     if (!b || b->eng.empty()) return 2;
     BluesEngine* h = b->eng[0];
     if (hipSetDevice(h->device) != hipSuccess) { b->err = "hipSetDevice failed"; return 1; }
     for (BluesEngine* m : b->eng) { if (flush_program(m) || ensure_sorted(m)) { b->err = m->err; return 1; } m->pass_valid = false; }
+    {   // history of this batch: prune passes / force passes (before the timing launches add to the counters)
+        double np = 0.0, nf = 0.0;
+        for (BluesEngine* m : b->eng) {
+            DevFlags f; hipStreamSynchronize(m->stream);
+            if (hipMemcpy(&f, m->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) np += f.prunes;
+            nf += (double)m->st_passes;
+        }
+        if (prune_fraction) *prune_fraction = (h->prune_on && h->k1_mode == 2) ? (nf > 0.0 ? std::min(1.0, np / nf) : 1.0) : 0.0;
+    }
     b->failed.assign(b->R(), 0); b->active.assign(b->R(), 1);
     if (batch_enter(b)) return 1;
     if (batch_refresh_args(b)) { batch_leave(b); return 1; }
     b->leader = h; b->lockstep = true;
+    const bool dual = h->prune_on && h->k1_mode == 2;
     int rc = h->precision == 0 ? launch_lists<float>(h, 1) : launch_lists<double>(h, 1);
-    for (int w = 0; w < 3 && !rc; w++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
-    if (!rc && hipEventRecord(h->ev0, h->stream) != hipSuccess) rc = 1;
-    for (int r = 0; r < reps && !rc; r++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
-    if (!rc && hipEventRecord(h->ev1, h->stream) != hipSuccess) rc = 1;
+    float ms[2] = {0.f, 0.f};
+    for (int mode = 0; mode < 2 && !rc; mode++) {   // 0: pruned lists current, 1: stale (every launch prunes)
+        for (int w = 0; w < 3 && !rc; w++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
+        if (dual) hipLaunchKernelGGL(k_prune_set, dim3((b->R() + 63) / 64), dim3(64), 0, h->cur, b->d_core.p, (DevFlags*)nullptr, b->R(), mode);
+        if (!rc && hipEventRecord(h->ev0, h->cur) != hipSuccess) rc = 1;
+        for (int r = 0; r < reps && !rc; r++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
+        if (!rc && hipEventRecord(h->ev1, h->cur) != hipSuccess) rc = 1;
+        if (rc || hipEventSynchronize(h->ev1) != hipSuccess) { rc = 1; break; }
+        hipEventElapsedTime(&ms[mode], h->ev0, h->ev1);
+    }
+    if (dual && !rc) hipLaunchKernelGGL(k_prune_set, dim3((b->R() + 63) / 64), dim3(64), 0, h->cur, b->d_core.p, (DevFlags*)nullptr, b->R(), 0);   // the last launch pruned
     b->lockstep = false;
     for (BluesEngine* m : b->eng) m->lists_forced = false;
-    if (rc || hipEventSynchronize(h->ev1) != hipSuccess) { b->err = "timing launch failed: " + h->err; batch_leave(b); return 1; }
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, h->ev0, h->ev1);
-    *usec = 1000.0 * ms / std::max(1, reps);
+    if (rc) { b->err = "timing launch failed: " + h->err; batch_leave(b); return 1; }
+    usec[0] = 1000.0 * ms[0] / std::max(1, reps); usec[1] = 1000.0 * ms[1] / std::max(1, reps);
     batch_leave(b);
     for (BluesEngine* m : b->eng) if (check_flags(m)) { b->err = m->err; return 1; }
+    return 0;
+}
+
+// mean duration of the batched nonbonded launch as this batch has been running it: the two kinds of pass weighted by how
+// often each occurred
+int blues_batch_time_nonbonded(BluesBatch* b, int32_t reps, double* usec) {
+    double u[2], f = 0.0;
+    const int rc = blues_batch_time_nonbonded_modes(b, reps, u, &f);
+    if (rc) return rc;
+    *usec = (1.0 - f) * u[0] + f * u[1];
     return 0;
 }
 

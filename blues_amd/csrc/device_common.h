@@ -97,26 +97,52 @@ __device__ inline float erfc_scaled_f(float x) {  // returns erfc(x)*exp(x^2)
     return p * t;
 }
 
+// The Ewald direct-space pair FORCE without transcendentals (mixed precision).  With x = alpha r,
+//   -dU/dr / r = qq [erfc(x)/r + 2 alpha/sqrt(pi) exp(-x^2)] / r^2 = qq [1/r^3 - T(r^2)],
+//   T(u) = [erf(x) - 2/sqrt(pi) x exp(-x^2)] / r^3 = alpha^3 (2/sqrt(pi)) (2/3 - 2/5 x^2 + 1/7 x^4 - ...),
+// an entire function of u = r^2: a degree-9 Chebyshev fit on [0, cutoff^2] (host: fit_ewald_poly) is good to 3e-7 of T(0),
+// below the fp32 rounding of the 1/r^3 it is subtracted from.  Near the cutoff the two terms agree to two digits, so the
+// screened force of such a pair carries ~1e-5 of ITS OWN size in error -- 1e-7 of the 1/r^3 scale, i.e. nothing on the
+// scale the 1e-5 force tolerance is stated on (the largest force component / the norm of the force vector).  This replaces
+// v_exp, v_rcp and a degree-7 polynomial (22 instructions, two of them quarter-rate) by 10 FMAs.
+#define EWALD_POLY_DEG 9
+struct EwaldPoly { float c[EWALD_POLY_DEG + 1]; float wa; };   // T(u) = sum c[k] w^k, w = wa u - 1
+
+template <typename R> struct NbConst {
+    R scale[3];   // box edge / 2^32 (or 2^64)
+    R rc2;        // cutoff^2
+    R alpha;      // Ewald alpha
+    double rlist2;  // (cutoff+skin)^2: list radius for frozen candidates
+    double rlist2_m;  // list radius for mobile candidates (derive_margins in blues_engine.hip)
+    double dscale[3];
+    float rp2, rp2_m;  // (cutoff + inner margin)^2 of the pruned per-atom lists, frozen / mobile candidates (nonbonded_atom_body)
+    EwaldPoly ew;      // mixed precision only
+};
+
 // Regular (non-alchemical) pair: 12-6 LJ + erfc-screened Coulomb.  r2 < cutoff^2 is the caller's business.
 // q is pre-multiplied by sqrt(ONE_4PI_EPS0); sig = hs_i+hs_j; eps4 = se_i*se_j.
-// Returns fscale = -dU/dr / r ; *e_lj, *e_c energies.
-template <typename R> __device__ inline R pair_regular(R r2, R qq, R sig, R eps4, R alpha, R* e_lj, R* e_c);
+// Returns fscale = -dU/dr / r ; *e_lj, *e_c energies (dead code in the callers that do not use them).
+template <typename R> __device__ inline R pair_regular(R r2, R qq, R sig, R eps4, const NbConst<R>& c, R* e_lj, R* e_c);
 
-template <> __device__ inline float pair_regular<float>(float r2, float qq, float sig, float eps4, float alpha, float* e_lj, float* e_c) {
-    float inv_r = __builtin_amdgcn_rsqf(r2);  // v_rsq_f32; r2 is never subnormal here (fixed-point resolution is 2e-9 nm)
-    float inv_r2 = inv_r * inv_r;
-    float s2 = sig * sig * inv_r2, s6 = s2 * s2 * s2;
-    *e_lj = eps4 * (s6 * s6 - s6);
-    float f = eps4 * (12.0f * s6 * s6 - 6.0f * s6) * inv_r2;
-    float r = r2 * inv_r, ar = alpha * r;
-    float ex = __expf(-ar * ar);
-    float ec = erfc_scaled_f(ar) * ex;
-    *e_c = qq * ec * inv_r;
-    f += qq * (ec * inv_r + (float)TWO_OVER_SQRT_PI * alpha * ex) * inv_r2;
-    return f;
+template <> __device__ __forceinline__ float pair_regular<float>(float r2, float qq, float sig, float eps4, const NbConst<float>& c, float* e_lj, float* e_c) {
+    const float inv_r = __builtin_amdgcn_rsqf(r2);  // v_rsq_f32; r2 is never subnormal here (fixed-point resolution is 2e-9 nm)
+    const float inv_r2 = inv_r * inv_r;
+    const float s2 = sig * sig * inv_r2, s6 = s2 * s2 * s2, t = eps4 * s6;
+    const float flj = t * fmaf(12.0f, s6, -6.0f);
+    const float w = fmaf(r2, c.ew.wa, -1.0f);
+    float T = c.ew.c[EWALD_POLY_DEG];
+#pragma unroll
+    for (int k = EWALD_POLY_DEG - 1; k >= 0; k--) T = fmaf(T, w, c.ew.c[k]);
+    const float g = fmaf(inv_r, inv_r2, -T);
+    // energies (only the energy kernels keep this part alive)
+    *e_lj = t * (s6 - 1.0f);
+    const float ar = c.alpha * (r2 * inv_r);
+    *e_c = qq * erfc_scaled_f(ar) * __expf(-ar * ar) * inv_r;
+    return fmaf(qq, g, flj * inv_r2);
 }
 
-template <> __device__ inline double pair_regular<double>(double r2, double qq, double sig, double eps4, double alpha, double* e_lj, double* e_c) {
+template <> __device__ inline double pair_regular<double>(double r2, double qq, double sig, double eps4, const NbConst<double>& c, double* e_lj, double* e_c) {
+    const double alpha = c.alpha;
     double r = sqrt(r2), inv_r = 1.0 / r, inv_r2 = inv_r * inv_r;
     double s2 = sig * sig * inv_r2, s6 = s2 * s2 * s2;
     *e_lj = eps4 * (s6 * s6 - s6);

@@ -29,16 +29,12 @@ struct DevFlags {  // device-resident control words
     int nan_flag;
     int resort_hint;             // a j-list has grown to within 15 % of its capacity: the tiles have spread, re-sort soon
     int builds;                  // list builds executed (own requests, forced ones and batch-synchronised ones)
-    int pad[1];
-};
-
-template <typename R> struct NbConst {
-    R scale[3];   // box edge / 2^32 (or 2^64)
-    R rc2;        // cutoff^2
-    R alpha;      // Ewald alpha
-    double rlist2;  // (cutoff+skin)^2: list radius for frozen candidates
-    double rlist2_m;  // list radius for mobile candidates (derive_margins in blues_engine.hip)
-    double dscale[3];
+    int prunes;                  // force passes that re-derived the pruned per-atom lists (nonbonded_atom_body)
+    // pruned lists are current iff equal.  Raised (req = done + 1) by the atom-list build and by the integrator when an atom has
+    // moved the inner margin since the last prune; the nonbonded kernel of a FORCE pass prunes, k_finalize of that pass
+    // acknowledges (done = req) -- a later kernel, because every nonbonded workgroup of the chain has to see the request
+    unsigned prune_req, prune_done;
+    int pad[3];
 };
 
 struct ListArgs {
@@ -417,6 +413,7 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
         }
     }
     NB_STAMP(t == 0 && tid == 0, 8);
+    if (t == 0 && tid == 0) a.flags->prune_req = a.flags->prune_done + 1;   // new full lists: the pruned ones are stale
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         if (lane == 0) {
@@ -448,6 +445,9 @@ template <typename R> struct NbArgs {
     int* batch_req;  // see ListArgs; cleared here (every list block of this pass has read it by now)
     const unsigned short* alist; const int* acount; int acap;   // per-atom lists (ListArgs), nonbonded_atom_body only
     int S, n_lists;                                                // tiles per j-list, number of lists (ListArgs)
+    // pruned per-atom lists (null: not in use): the entries of alist within cutoff + inner margin when they were last pruned
+    unsigned short* plist; int* pcount;
+    const double* x[3]; double* xprune[3]; const int* mobile_atoms; int n_mobile;   // where the mobile atoms were at the last prune
 };
 
 // One block = WPB waves working on the SAME i-tile; wave w of the tile walks the j-list segments
@@ -494,7 +494,7 @@ __device__ __forceinline__ void nonbonded_body(const NbArgs<R>& a, const NbConst
             bool in = (r2 < c.rc2) && !((m >> k) & 1ull);
             if (in) {
                 R e1, e2;
-                R fs = pair_regular<R>(r2, ai.q * bj.q, ai.hs + bj.hs, ai.se * bj.se, c.alpha, &e1, &e2);
+                R fs = pair_regular<R>(r2, ai.q * bj.q, ai.hs + bj.hs, ai.se * bj.se, c, &e1, &e2);
                 fx += (double)(fs * dx); fy += (double)(fs * dy); fz += (double)(fs * dz);
                 if (ENERGY) {
                     double wgt = (bj.flags & FLAG_MOBILE) ? 0.5 : 1.0;
@@ -584,7 +584,7 @@ __device__ __forceinline__ void nonbonded_sub_body(const NbArgs<float>& a, const
             if (in) {
                 const P2 bp = mq[k];
                 float e1, e2;
-                float fs = pair_regular<float>(r2, ai.q * bj.q, ai.hs + bp.hs, ai.se * bp.se, c.alpha, &e1, &e2);
+                float fs = pair_regular<float>(r2, ai.q * bj.q, ai.hs + bp.hs, ai.se * bp.se, c, &e1, &e2);
                 bx = fmaf(fs, dx, bx); by = fmaf(fs, dy, by); bz = fmaf(fs, dz, bz);
                 if (ENERGY) {
                     const double wgt = (mf[k] & FLAG_MOBILE) ? 0.5 : 1.0;
@@ -625,6 +625,16 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<
 // R = 256: with four waves per SIMD the kernel is bound by VALU issue of the pair body itself, ~62 instructions of which three
 // are transcendental.)
 #define NB_ATOM_U 12   // list entries per lane requested together (768 neighbours per round)
+// Dual lists.  The atoms' lists (alist) are built with the full Verlet margin and are rebuilt rarely; a third of their entries
+// sit in the margin, and every one of them costs a full pair evaluation of all 64 lanes.  The kernel therefore walks PRUNED
+// lists (plist: the entries within cutoff + a small inner margin) and re-derives them itself, in passing, whenever the
+// integrator reports that an atom has moved the inner margin since the last prune (DevFlags::prune_req): in such a pass the
+// wave walks the full list -- same arithmetic, out-of-range lanes masked as before -- and writes the survivors back in list
+// order (ballot + prefix count).  No extra kernel, no extra staging of the image; a prune pass costs what every pass used to.
+// Validity (derive_margins, blues_engine.hip): a pruned list holds every pair within cutoff + m of the prune positions; the
+// pair can close at most by the displacements of its two atoms since, and a prune is requested as soon as one atom has moved
+// ptrig (m = ptrig for a frozen partner, 2 ptrig for a mobile one).  For the full list to hold every pair within cutoff + m
+// at ANY prune, its own rebuild trigger is the margin minus m.
 template <bool ENERGY>
 __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, const NbConst<float>& c, const AtomF* __restrict__ img, const int t) {   // t: list (group of S i-tiles)
     struct P4 { uint32_t x, y, z; float q; };
@@ -636,6 +646,15 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
     if (t == 0 && tid == 0) { a.flags->list_gen = a.flags->req_gen; if (a.batch_req) *a.batch_req = 0; }  // lists are current for this pass
     if (t >= a.n_lists) return;
+    // (block-uniform; every workgroup of the chain sees the same two words: they change only in other kernels)
+    const bool stale = a.plist == nullptr || a.flags->prune_req != a.flags->prune_done;
+    const bool pruning = !ENERGY && a.plist != nullptr && stale;   // an energy evaluation reads whichever list is valid and writes none
+    const unsigned short* const lists = stale ? a.alist : a.plist;
+    const int* const counts = stale ? a.acount : a.pcount;
+    if (pruning && t == 0) {
+        for (int q = tid; q < a.n_mobile; q += blockDim.x) { const int i = a.mobile_atoms[q]; a.xprune[0][i] = a.x[0][i]; a.xprune[1][i] = a.x[1][i]; a.xprune[2][i] = a.x[2][i]; }
+        if (tid == 0) a.flags->prunes++;
+    }
     const int count = a.jcount[t];
     const int* jlst = a.jlist + (size_t)t * a.jcap;
     const int slot0 = t * a.S * 64, nslot = min(a.S, a.n_itiles - t * a.S) * 64;   // the i-slots this list serves
@@ -648,8 +667,8 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         if (s < nslot) {
             ian = __builtin_amdgcn_readfirstlane(a.tile_atoms[slot0 + s]);
             if (ian >= 0) {
-                cntn = __builtin_amdgcn_readfirstlane(a.acount[slot0 + s]);
-                const unsigned short* lst = a.alist + (size_t)(slot0 + s) * a.acap;
+                cntn = __builtin_amdgcn_readfirstlane(counts[slot0 + s]);
+                const unsigned short* lst = lists + (size_t)(slot0 + s) * a.acap;
 #pragma unroll
                 for (int u = 0; u < NB_ATOM_U; u++) { const int q = u * 64 + lane; entn[u] = q < cntn ? (unsigned)lst[q] : 0u; }
             }
@@ -679,10 +698,12 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         const float iq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].q)));
         const float ihs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].hs)));
         const float ise = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].se)));
-        const unsigned short* lst = a.alist + (size_t)islot * a.acap;
+        const unsigned short* lst = lists + (size_t)islot * a.acap;
+        unsigned short* const pout = pruning ? a.plist + (size_t)islot * a.acap : nullptr;
+        int pcnt = 0;   // survivors written so far (wave-uniform)
         double fx = 0.0, fy = 0.0, fz = 0.0;
         float bx = 0.0f, by = 0.0f, bz = 0.0f;
-        auto pair = [&](unsigned e, bool have) {
+        auto pair = [&](unsigned e, bool have, bool write) {
             const unsigned idx = e & 0x7FFFu;   // (entries past the end of the list were requested as 0: a valid slot, masked by `have`)
             const P4 bj = lp[idx];
             const P2 bp = lq[idx];
@@ -692,26 +713,43 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
             const float r2 = dx * dx + dy * dy + dz * dz;
             const bool in = have && (r2 < c.rc2);
             float e1, e2;
-            float fs = pair_regular<float>(r2, iq * bj.q, ihs + bp.hs, ise * bp.se, c.alpha, &e1, &e2);
-            fs = in ? fs : 0.0f;   // select, not a branch: ~70 % of the lanes are in range, the body would run anyway
+            float fs = pair_regular<float>(r2, iq * bj.q, ihs + bp.hs, ise * bp.se, c, &e1, &e2);
+            fs = in ? fs : 0.0f;   // select, not a branch: most lanes are in range, the body would run anyway
             bx = fmaf(fs, dx, bx); by = fmaf(fs, dy, by); bz = fmaf(fs, dz, bz);
             if (ENERGY) {
                 if (in) { const double wgt = (e & 0x8000u) ? 0.5 : 1.0; elj += wgt * (double)e1; ecl += wgt * (double)e2; }
             }
+            if (write) {   // prune pass: keep what lies within cutoff + inner margin, in list order
+                const bool keep = have && r2 < ((e & 0x8000u) ? c.rp2_m : c.rp2);
+                const unsigned long long bal = __ballot(keep);
+                if (keep) pout[pcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)e;
+                pcnt += __popcll(bal);
+            }
         };
-        // two list chunks per branch region: their LDS reads and transcendentals overlap (a second chunk past the end of the
-        // list is all-masked work, about 5 % of the iterations); the fp32 partials of a lane hold at most NB_ATOM_U pair terms
-        // before they are folded into fp64
+        // the fp32 partials of a lane hold at most NB_ATOM_U pair terms before they are folded into fp64
+        if (!pruning) {
 #pragma unroll
-        for (int u = 0; u < NB_ATOM_U; u += 2) {
-            if (u * 64 >= cnt) break;   // wave-uniform
-            pair(ent[u], u * 64 + lane < cnt);
-            pair(ent[u + 1], (u + 1) * 64 + lane < cnt);
-        }
-        for (int base = 64 * NB_ATOM_U; base < cnt; base += 64) {   // lists longer than the prefetch window (dense regions)
-            const bool have = base + lane < cnt;
-            pair(have ? (unsigned)lst[base + lane] : 0u, have);
-            fx += (double)bx; fy += (double)by; fz += (double)bz; bx = by = bz = 0.0f;
+            for (int u = 0; u < NB_ATOM_U; u++) {
+                if (u * 64 >= cnt) break;   // wave-uniform
+                pair(ent[u], u * 64 + lane < cnt, false);
+            }
+            for (int base = 64 * NB_ATOM_U; base < cnt; base += 64) {   // lists longer than the prefetch window (dense regions)
+                const bool have = base + lane < cnt;
+                pair(have ? (unsigned)lst[base + lane] : 0u, have, false);
+                fx += (double)bx; fy += (double)by; fz += (double)bz; bx = by = bz = 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NB_ATOM_U; u++) {
+                if (u * 64 >= cnt) break;
+                pair(ent[u], u * 64 + lane < cnt, true);
+            }
+            for (int base = 64 * NB_ATOM_U; base < cnt; base += 64) {
+                const bool have = base + lane < cnt;
+                pair(have ? (unsigned)lst[base + lane] : 0u, have, true);
+                fx += (double)bx; fy += (double)by; fz += (double)bz; bx = by = bz = 0.0f;
+            }
+            if (lane == 0) a.pcount[islot] = pcnt;   // (a subset of a list that fits acap)
         }
         NB_STAMP(t == 0 && tid == 0, 20 + min(2 * (s / nw), 6));
         fx += (double)bx; fy += (double)by; fz += (double)bz;
@@ -800,7 +838,7 @@ __global__ void __launch_bounds__(256) k_energy_frozen(int n, NbConst<R> c, cons
                     for (int e = e0; e < e1; e++) ex |= (ex_idx[e] == jj);
                     if (!ex) {
                         R a1, a2;
-                        pair_regular<R>(r2, ai.q * bj.q, ai.hs + bj.hs, ai.se * bj.se, c.alpha, &a1, &a2);
+                        pair_regular<R>(r2, ai.q * bj.q, ai.hs + bj.hs, ai.se * bj.se, c, &a1, &a2);
                         elj += (double)a1; ecl += (double)a2;
                     }
                 }

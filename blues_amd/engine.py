@@ -163,7 +163,8 @@ class NativeEngine:
         return {"force_passes": s[0], "list_generation": s[1], "kernel_launches": s[2], "i_tiles": s[3],
                 "clusters": s[4], "jcap": s[5], "npart": s[6], "seg_len": s[7] // 1000, "wpb": s[7] % 1000,
                 "max_jcount": s[8], "resorts": s[9], "list_builds": s[10], "own_energy_evaluations": s[11],
-                "nonbonded_kernel": s[12], "tiles_per_list": s[13], "atom_list_entries": s[14], "atom_list_iterations": s[15]}
+                "nonbonded_kernel": s[12], "tiles_per_list": s[13], "atom_list_entries": s[14], "atom_list_iterations": s[15],
+                "prune_passes": s[16], "pruned_list_entries": s[17], "pruned_list_iterations": s[18], "pruned_lists": s[19]}
 
     def time_nonbonded(self, reps=20):
         u = C.c_double(); self._check(self._lib.blues_time_nonbonded(self._h, int(reps), C.byref(u))); return u.value
@@ -279,3 +280,10 @@ class NativeBatch:
         if self._lib.blues_batch_time_nonbonded(self._h, int(reps), C.byref(u)):
             raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
         return u.value
+
+    def time_nonbonded_modes(self, reps=20):
+        """(usec over current pruned lists, usec of a pass that re-derives them, share of the latter among the passes so far)"""
+        u = (C.c_double * 2)(); f = C.c_double()
+        if self._lib.blues_batch_time_nonbonded_modes(self._h, int(reps), u, C.byref(f)):
+            raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
+        return u[0], u[1], f.value

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define BLUES_ABI_VERSION 3
+#define BLUES_ABI_VERSION 4
 
 /* nonbonded_method */
 #define BLUES_NB_NOCUTOFF 0   /* oracle only: vacuum systems (vacDivaline, two-body checks) */
@@ -150,6 +150,55 @@ int blues_engine_destroy(BluesEngine *h);
 const char *blues_last_error(const BluesEngine *h);
 int blues_abi_version(void);
 
+/* ---- Launch policy (ABI 4) -------------------------------------------------
+ * OpenMM takes such choices as platform properties (the `properties` dict of
+ * openmm.app.Simulation, reference blues/simulation.py:730-737).  The engine
+ * chooses every one of them itself; this struct exists so that tests and
+ * profiling runs can pin a decomposition without touching the environment:
+ * the library reads NO environment variables.  The process-wide tuning is copied
+ * into every engine and batch when it is created; none of it changes results
+ * beyond floating-point summation order (pruned lists, list margins) or nothing
+ * at all (stream forks, graph replay, capacities).
+ * -1 / 0 = "engine default" unless stated otherwise. */
+typedef struct BluesTuning {
+    int32_t struct_size;       /* sizeof(BluesTuning) of the caller: set by blues_tuning_default */
+    int32_t plain_skin;        /* 1: every list candidate gets the margin `skin`, rebuild at skin/2 (plain Verlet rule) instead of
+                                * the split margins for a mostly frozen system */
+    double skin;               /* nm; outer margin of the neighbour lists; <= 0: by system size */
+    double prune_margin;       /* nm; inner margin of the pruned per-atom lists; < 0: default (0.04 where most atoms are frozen);
+                                * 0: the nonbonded kernel walks the full lists */
+    double jcap_scale;         /* > 0: scales the list capacities (tests shrink them to reach the re-sort path) */
+    double acap_scale;
+    int32_t k1_mode;           /* -1 auto; 1: never the per-atom-list kernel (sub-tile kernel in its place) */
+    int32_t list_group;        /* i-tiles per list of the per-atom-list kernel; 0 auto */
+    int32_t sub_iw;            /* i-atoms per wave of the sub-tile kernel (8, 16, 32); 0 auto */
+    int32_t sub_chunks;        /* its list chunks per i-tile; 0 auto */
+    int32_t seg_len;           /* tile kernel: j-atoms per wave segment; 0 auto */
+    int32_t waves_per_block;   /* tile kernel; 0 auto */
+    int32_t k2_jiter;          /* j groups per environment block of the alchemical kernel; 0 auto */
+    int32_t fuse_forces;       /* -1 auto; 0 / 1: separate force kernels / one launch with block roles */
+    int32_t fuse_big;          /* -1 auto (off) */
+    int32_t fast_step;         /* -1 auto (on): straight-line step kernels */
+    int32_t slot_mask;         /* -1 auto; else the lambda slots whose force a pass produces */
+    int32_t fork;              /* 1 (default): a batch runs the alchemical / bonded kernels on a side stream; 0: every kernel alone */
+    int32_t use_graph;         /* -1 auto (off): hipGraph replay of the steady-state step of a lone engine */
+    int32_t graph_units;       /* 0 auto */
+    int32_t graph_fork;        /* -1 auto (off) */
+    int32_t batch_sync_lists;  /* 1: every member of a batch rebuilds when one asks (drops batch = solo bitwise identity) */
+    int32_t force_lists;       /* 1: rebuild the lists at every launch (development) */
+    int32_t no_sphere;         /* 1: bounding-box list test only (development) */
+    int32_t pme_general;       /* 1: reciprocal space through the global-memory kernel */
+    int32_t debug_lists;       /* 1: print layout shapes, re-sorts and overflow diagnostics to stderr */
+    int32_t assume_batch;      /* > 0: a lone engine lays itself out as a member of a batch of this many would (the decomposition
+                                * depends on how many chains share a launch): what makes "a batch member equals the same
+                                * chain advanced alone, bit for bit" testable */
+    int32_t reserved;
+} BluesTuning;
+void blues_tuning_default(BluesTuning *t);
+/* NULL restores the defaults.  Applies to engines and batches created afterwards. */
+int blues_set_tuning(const BluesTuning *t);
+int blues_get_tuning(BluesTuning *t);
+
 /* context.setPositions / setVelocities / setPeriodicBoxVectors
  * (reference blues/simulation.py:957-962, blues/moves.py:307). */
 int blues_set_positions(BluesEngine *h, const double *xyz_nm, int32_t n_atoms);
@@ -203,8 +252,11 @@ int blues_reset(BluesEngine *h);
  * alone (those served by blues_batch_prefetch_energies are not counted)
  * [12] nonbonded kernel in use: 0 tile kernel, 1 sub-tile kernel, 2 per-atom
  * lists over an LDS image [13] i-tiles per j-list [14] entries of all per-atom
- * lists at the last rebuild [15] 64-entry wave iterations they take */
-#define BLUES_N_STATS 16
+ * lists at the last rebuild [15] 64-entry wave iterations they take
+ * [16] force passes that re-derived the pruned per-atom lists [17] entries of
+ * all pruned lists now [18] 64-entry wave iterations they take [19] 1 if the
+ * nonbonded kernel walks pruned lists */
+#define BLUES_N_STATS 20
 int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
 /* time `reps` launches of the dominant nonbonded kernel alone with HIP events
  * on the engine's own stream; returns mean microseconds per launch. */
@@ -285,7 +337,11 @@ int blues_batch_prefetch_energies(BluesBatch *b, int32_t what);
 /* [0] steps issued in lock step (one launch for all members) [1] steps that
  * fell back to per-member launches [2] members [3] batched energy evaluations */
 int blues_batch_get_stats(BluesBatch *b, int64_t stats[4]);
-/* as blues_time_nonbonded, for one batched launch covering all members */
+/* as blues_time_nonbonded, for one batched launch covering all members.  With pruned per-atom lists the kernel has two
+ * kinds of pass: over current pruned lists (usec[0]) and one that re-derives them from the full lists (usec[1]);
+ * prune_fraction is the share of the second kind among the force passes this batch has run so far, and
+ * blues_batch_time_nonbonded returns the mean weighted with it. */
+int blues_batch_time_nonbonded_modes(BluesBatch *b, int32_t reps, double usec[2], double *prune_fraction);
 int blues_batch_time_nonbonded(BluesBatch *b, int32_t reps, double *usec_per_launch);
 
 #ifdef __cplusplus

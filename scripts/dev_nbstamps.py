@@ -1,7 +1,7 @@
 """Phase stamps (s_memtime, 100 MHz) of the list build and the per-atom-list force kernel on a lone S23k engine in the
 large-batch decomposition (BLUES_FUSE=0).  Uses the -DBLUES_STAMP build blues_amd/csrc/libblues_hip_stamp.so."""
 import os, sys
-os.environ.setdefault("BLUES_FUSE", "0"); os.environ.setdefault("BLUES_SKIN", "0.12"); os.environ.setdefault("BLUES_K2_JITER", "4")
+os.environ.setdefault("BLUES_TUNING", "assume_batch=256")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from blues_amd import build
 build.LIB_PATH = os.path.join(build.CSRC, "libblues_hip_stamp.so")

@@ -1,5 +1,5 @@
 import os, sys
-os.environ.setdefault("BLUES_FUSE", "0"); os.environ.setdefault("BLUES_SKIN", "0.12"); os.environ.setdefault("BLUES_K2_JITER", "4")
+os.environ.setdefault("BLUES_TUNING", "assume_batch=256")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from blues_amd import build
 build.LIB_PATH = os.path.join(build.CSRC, "libblues_hip_stamp.so")

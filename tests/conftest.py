@@ -86,6 +86,16 @@ def oracle_backed_context(monkeypatch):
     return context
 
 
+@pytest.fixture()
+def tune():
+    """tune(field=value, ...) pins launch-policy fields of the engine (blues_amd.tuning, include/blues_engine.h: BluesTuning) for the
+    engines and batches the test creates afterwards; the defaults come back when the test ends."""
+    from blues_amd import tuning
+    saved = tuning.current()
+    yield tuning.set
+    tuning._apply(saved)
+
+
 def gpu_available():
     try:
         import torch

@@ -57,12 +57,11 @@ def _state(g):
 
 
 @pytest.fixture(params=["0", "1"])
-def same_decomposition(request, monkeypatch):
+def same_decomposition(request, tune):
     """A batch picks its launch decomposition for R replicas (fused force launch only while the whole batch is small), which
     changes the order of the partial force sums.  Pinning the choice makes solo and batched runs comparable bit for bit --
     once with the fused launch, once with the separate kernels."""
-    monkeypatch.setenv("BLUES_FUSE", request.param)
-    monkeypatch.setenv("BLUES_K2_JITER", "1" if request.param == "1" else "4")   # j-groups per alchemical block: lone-replica / large-batch value
+    tune(fuse_forces=int(request.param), k2_jiter=1 if request.param == "1" else 4)   # j-groups per alchemical block: lone-replica / large-batch value
     return request.param
 
 
@@ -372,7 +371,7 @@ def test_device_resident_state_round_trip(Engine, tol_box):
     assert sim2.context.getState(getEnergy=True).getPotentialEnergy()._value == pytest.approx(e1, rel=1e-12)
 
 
-def test_batch_synchronised_list_rebuilds(Engine, tol_box, monkeypatch):
+def test_batch_synchronised_list_rebuilds(Engine, tol_box, tune):
     """Large batches rebuild every member's neighbour lists together (any member's request rebuilds all): same physics,
     another summation order.  Forced on here for a small batch: all members then count the same rebuilds, more than a
     lone replica needs, and agree with their solo runs to rounding (fp64 mode)."""
@@ -384,10 +383,10 @@ def test_batch_synchronised_list_rebuilds(Engine, tol_box, monkeypatch):
     vf = v * (sf.mass[:, None] > 0)
     R, n = 3, 60
     vels = _replica_inputs(sf, vf, R)
-    monkeypatch.setenv("BLUES_SKIN", "0.08")          # frequent rebuilds within a short run
+    tune(skin=0.08)          # frequent rebuilds within a short run
     solo = _make(Engine, sf, vels, n, 1)
     ws = [g.run_switch(n, trace=True) for g in solo]
-    monkeypatch.setenv("BLUES_BATCH_SYNC_LISTS", "1")
+    tune(batch_sync_lists=1)
     bat = _make(Engine, sf, vels, n, 1)
     B = NativeBatch(bat)
     _, wb = B.step(n, trace=True)
@@ -436,16 +435,16 @@ def test_batched_energy_prefetch_equals_per_member_evaluation(Engine, tol_box, s
     B.close()
 
 
-def test_full_size_batch_of_eight(Engine, oracle_mod, monkeypatch):
+def test_full_size_batch_of_eight(Engine, oracle_mod, tune):
     """The benchmark system (S23k, 276 mobile atoms) in a batch of 8: the member count is a multiple of 8, so the nonbonded
-    and alchemical launches use the XCD-aware block -> replica map; large-batch decomposition (separate force kernels,
-    four j-groups per alchemical block, short skin).  Every member equals its solo run bit for bit (same decomposition
-    pinned for the lone engines), and one member is checked against the oracle."""
+    and alchemical launches use the XCD-aware block -> replica map, and the engine's own policy puts a batch of 8 such chains
+    into the decomposition bench.py runs at R = 512 (separate force kernels, per-atom lists pruned in passing, side-stream fork).
+    Every member equals its solo run bit for bit (the lone engines lay themselves out as members of a batch of 8 would:
+    BluesTuning.assume_batch, nothing else pinned), and one member is checked against the oracle."""
     from blues_amd.engine import NativeBatch
     s, v = systems.s23k(mobile_atoms=275, frozen=True)
-    for k, val in (("BLUES_FUSE", "0"), ("BLUES_K2_JITER", "4"), ("BLUES_SKIN", "0.12")):
-        monkeypatch.setenv(k, val)
     R, n = 8, 10
+    tune(assume_batch=R)
     rng = np.random.RandomState(5)
     vels = [v * (1.0 + 0.03 * r) for r in range(R)]
     solo = _make(Engine, s, vels, n, 0)
@@ -464,7 +463,7 @@ def test_full_size_batch_of_eight(Engine, oracle_mod, monkeypatch):
     wo = []
     for _ in range(n):
         o.step(1); wo.append(o.get_global("protocol_work"))
-    assert np.allclose(wb[r], wo, rtol=2e-5, atol=2e-5)     # mixed precision: north_star's 1e-5 relative on the work
+    assert np.abs(wb[r] - np.array(wo)).max() <= 1e-5 * max(1.0, np.abs(wo).max())   # mixed precision, 10 free-running steps: north_star's 1e-5 on the work
     assert np.abs(bat[r].get_positions() - o.get_positions()).max() < 1e-6
     B.close()
 
@@ -547,16 +546,15 @@ def test_move_style_edits_of_a_device_resident_state(Engine, tol_box):
     assert np.array_equal(a.context._engine.get_positions(), b.context._engine.get_positions())
 
 
-def test_full_protocol_full_size_batch_properties(Engine, monkeypatch):
+def test_full_protocol_full_size_batch_properties(Engine, tune):
     """BASELINE.json configs[1] at full size in a batch: eight chains of the S23k system through the whole 1000-step protocol
     with the ligand rotated at lambda = 0.5.  Size-independent properties: every chain ends at lambda = 1 with finite work,
     constraints satisfied, no frozen atom moved, the alchemical parameters back at (1, ~1); and -- determinism across the
     batched and the lone code path -- one chain reproduces its 1000-step solo trajectory bit for bit."""
     from blues_amd.engine import NativeBatch
     s, v = systems.s23k(mobile_atoms=275, frozen=True)
-    for k, val in (("BLUES_FUSE", "0"), ("BLUES_K2_JITER", "4"), ("BLUES_SKIN", "0.12")):
-        monkeypatch.setenv(k, val)
     R, n = 8, 1000
+    tune(assume_batch=R)   # (the lone chain below lays itself out as a batch member does; nothing else pinned)
     lig = np.arange(15)
     rot = np.array([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
 

@@ -493,7 +493,7 @@ def test_driver_end_to_end_rotation_and_torsion(Engine, tol_box):
     assert np.abs(xg - xo).max() < 1e-8 and eg == pytest.approx(eo, rel=1e-10)
 
 
-def test_resort_when_tiles_spread(Engine, monkeypatch):
+def test_resort_when_tiles_spread(Engine, tune):
     """Nothing frozen (configs[3]): the tiles formed at set_positions spread as the liquid diffuses and their j-lists grow.
     With the list capacity squeezed, the engine must notice (resort_hint), re-sort on its own and carry on -- with the
     same trajectory as a run whose lists never came near their capacity (fp64 mode: equal to summation-order rounding)."""
@@ -504,7 +504,7 @@ def test_resort_when_tiles_spread(Engine, monkeypatch):
     w0 = g0.run_switch(n, trace=True)
     assert g0.stats()["resorts"] == 0
     cap0 = g0.stats()["jcap"]; top = g0.stats()["max_jcount"]
-    monkeypatch.setenv("BLUES_JCAP_SCALE", "%.3f" % (1.12 * top / cap0))   # capacity ~12 % above the longest list
+    tune(jcap_scale=1.12 * top / cap0)   # capacity ~12 % above the longest list
     g1 = Engine(s, data); g1.set_velocities(v)
     assert g1.stats()["jcap"] < cap0
     w1 = g1.run_switch(n, trace=True)

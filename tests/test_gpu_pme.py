@@ -89,13 +89,12 @@ def test_switch_with_reciprocal_space(Engine, oracle_mod, tol_box, precision, to
     g.close()
 
 
-def test_batch_with_reciprocal_space_is_bitwise_solo(Engine, monkeypatch):
+def test_batch_with_reciprocal_space_is_bitwise_solo(Engine, tune):
     from blues_amd.engine import NativeBatch
     s, v = systems.s23k(mobile_atoms=275, frozen=True)
     r = systems.with_reciprocal_space(s)
-    for k, val in (("BLUES_FUSE", "0"), ("BLUES_K2_JITER", "4"), ("BLUES_SKIN", "0.12")):
-        monkeypatch.setenv(k, val)
     R, n = 4, 12
+    tune(assume_batch=8)   # separate force kernels, per-atom lists: the decomposition of a large batch, for the lone engines too
 
     def make():
         out = []

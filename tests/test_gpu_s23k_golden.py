@@ -77,16 +77,14 @@ def _apply_move(x, s, gold):
 
 @pytest.mark.parametrize("precision", [1, 0])
 @pytest.mark.parametrize("batched", [False, True])
-def test_100_step_switch_with_rotation_golden(Engine, gold, s23k, precision, batched, monkeypatch):
+def test_100_step_switch_with_rotation_golden(Engine, gold, s23k, precision, batched, tune):
     from blues_amd.engine import NativeBatch
     s, v = s23k
     wo = gold["work_trace"]
     scale = np.abs(wo).max()
     assert scale > 1.0
     R = 8 if batched else 1
-    if batched:   # pin the large-batch decomposition bench.py runs with (R = 256 there): separate force kernels, sub-tile nonbonded kernel
-        for k, val in (("BLUES_FUSE", "0"), ("BLUES_K2_JITER", "4"), ("BLUES_SKIN", "0.12")):
-            monkeypatch.setenv(k, val)
+    # (batched: eight congruent chains get the engine's own large-batch policy -- the decomposition bench.py runs; nothing pinned)
 
     def make():
         engs = [Engine(s, _data(gold, precision)) for _ in range(R)]
@@ -122,6 +120,39 @@ def test_100_step_switch_with_rotation_golden(Engine, gold, s23k, precision, bat
         g.close()
     assert err <= (1e-9 if precision == 1 else 1e-5), (err, free_err)
     print("S23k configs[0] switch: precision=%d batched=%s free-running %.2e teacher-forced %.2e (of max|w| = %.3f kJ/mol)" % (precision, batched, free_err, err, scale))
+
+
+def test_bench_configuration_golden(Engine, gold, s23k):
+    """The launch configuration bench.py runs, with NOTHING pinned: 256 congruent S23k chains in one replica batch under the engine's
+    own policy (default BluesTuning: per-atom lists pruned in passing, default margins and alchemical block shape, side-stream fork),
+    mixed precision, BASELINE.json configs[0] -- the 100-step switch with the rigid rotation at step 50 -- teacher-forced every 10
+    steps from the committed oracle states: protocol work within 1e-5 of max|w| for every member, and members that were given
+    identical inputs stay bitwise identical (they share launches but never data).  bench.py's default is 512 chains: the same code
+    path and decomposition (the layout changes at n_itiles * R > 32); 256 halves this test's set-up time."""
+    from blues_amd import tuning
+    from blues_amd.engine import NativeBatch
+    assert tuning.as_dict() == {k: getattr(tuning.defaults(), k) for k in tuning.FIELDS}       # no override is active
+    s, v = s23k
+    R = 256
+    wo = gold["work_trace"]; scale = np.abs(wo).max()
+    engs = [Engine(s, _data(gold, 0)) for _ in range(R)]
+    B = NativeBatch(engs)
+    w = _run_switch_teacher(engs, lambda n: B.step(n, trace=True)[1], s, v, gold)
+    st, bst = engs[0].stats(), B.stats()
+    assert st["nonbonded_kernel"] == 2 and st["pruned_lists"] == 1 and st["prune_passes"] >= 10, st     # the benchmarked kernel, pruning as it goes
+    assert bst["fallback_steps"] <= 2 * (int(gold["nsteps"]) // int(gold["checkpoint_every"])), bst       # only the re-synchronisations are per member
+    errs = [np.abs(w[r] - wo).max() / scale for r in (0, 1, 7, 8, 31, 64, 100, 127, 128, 200, 254, 255)]
+    assert max(errs) <= 1e-5, errs
+    for r in range(1, R):
+        assert np.array_equal(w[r], w[0]), r
+    x0 = engs[0].get_positions()
+    for r in (1, 128, 255):
+        assert np.array_equal(engs[r].get_positions(), x0)
+    B.close()
+    for g in engs:
+        g.close()
+    print("bench configuration (R = %d, default policy) teacher-forced work error %.2e of max|w| = %.3f kJ/mol; %d prune passes, %d rebuilds per chain"
+          % (R, max(errs), scale, st["prune_passes"], st["list_generation"]))
 
 
 def _run_switch_free(engines, stepper, s, v, gold):

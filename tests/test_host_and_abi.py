@@ -30,12 +30,39 @@ def engine_lib():
 
 def test_library_exports_every_declared_symbol(engine_lib):
     header = open(os.path.join(ROOT, "include", "blues_engine.h")).read()
-    declared = set(re.findall(r"^(?:int|const char \*)\s*\*?(blues_[a-z_]+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|const char \*)\s*\*?(blues_[a-z_]+)\(", header, flags=re.M))
     assert declared == set(_abi.ENGINE_SYMBOLS), declared ^ set(_abi.ENGINE_SYMBOLS)
     for name in declared:
         assert hasattr(engine_lib, name), name
     _abi.declare_engine_prototypes(engine_lib)
     assert engine_lib.blues_abi_version() == _abi.ABI_VERSION
+
+
+def test_tuning_struct_mirror_and_no_environment_reads(engine_lib):
+    """BluesTuning: the ctypes mirror has the header's fields in the header's order, the defaults round-trip, and the native
+    sources read no environment variable (the launch policy is an explicit, documented struct)."""
+    header = open(os.path.join(ROOT, "include", "blues_engine.h")).read()
+    body = re.search(r"typedef struct BluesTuning \{(.*?)\} BluesTuning;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(int32_t|double)\s+([a-z_0-9]+);", body)
+    ctype = {"int32_t": ctypes.c_int32, "double": ctypes.c_double}
+    assert [(n, ctype[t]) for t, n in fields] == list(_abi.BluesTuning._fields_)
+    _abi.declare_engine_prototypes(engine_lib)
+    t = _abi.BluesTuning()
+    engine_lib.blues_tuning_default(t)
+    assert t.struct_size == ctypes.sizeof(_abi.BluesTuning) and t.fork == 1 and t.prune_margin < 0 and t.skin == 0.0
+    t.skin = 0.2; t.fork = 0
+    assert engine_lib.blues_set_tuning(t) == 0
+    u = _abi.BluesTuning(); engine_lib.blues_get_tuning(u)
+    assert u.skin == 0.2 and u.fork == 0
+    t.struct_size = 8
+    assert engine_lib.blues_set_tuning(t) != 0          # a caller built against another layout is refused
+    assert engine_lib.blues_set_tuning(None) == 0
+    engine_lib.blues_get_tuning(u)
+    assert u.skin == 0.0 and u.fork == 1
+    for f in os.listdir(build.CSRC):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(build.CSRC, f)).read(), f
 
 
 def test_engine_fails_loudly_without_gpu(tol_box):
