@@ -189,7 +189,8 @@ struct BluesEngine {
     int hint_count = 0;   // list length that raises resort_hint
     int shape_S = 0, shape_jcap = 0; bool shape_overflow = false, forbid_atom = false; double shape_need = 0.0;
     int S = 1, n_lists = 0;   // S consecutive i-tiles share one j-list (mode 2; 1 otherwise); n_lists = ceil(n_itiles / S)
-    DBuf<unsigned short> d_alist, d_plist; DBuf<int> d_acount, d_pcount; DBuf<double> d_xprune[3];
+    DBuf<unsigned short> d_alist, d_plist; DBuf<int> d_acount, d_pcount, d_pneed; DBuf<unsigned> d_xprune[3];   // pruned lists (by i-slot)
+    DBuf<uint4> d_pimg4; DBuf<float2> d_pimg2; DBuf<int> d_mlist, d_mcount; int mcap = 0;   // packed group images (ListArgs)
     int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
     double total_mass = 0;
@@ -283,10 +284,12 @@ static Box3 make_box(const BluesEngine* h) {
 // 2 trig.  Where nearly everything is frozen (freeze_radius, reference blues/simulation.py:394-480) the few mobile
 // candidates get the double margin and trig = skin: the same lists last twice the displacement.  Otherwise every candidate
 // has the margin `skin` and trig = skin / 2, the usual Verlet rule.
-// Pruned lists (prune_on): they keep what lies within cutoff + m of the positions at the last prune, m = prune_m for a frozen
-// candidate, 2 prune_m for a mobile one, and a prune is requested when an atom has moved ptrig = prune_m.  A prune reads the
-// full list, so that list must hold every pair within cutoff + m whenever a prune can happen: its own trigger is the
-// margin minus m.
+// Pruned lists (prune_on; kernels_nb.h: nonbonded_atom_body): an atom's pruned list keeps what lies within cutoff + m of the
+// positions at ITS last prune, and the atom asks for the next one when it has moved ptrig.  Frozen candidate: m = ptrig.  Mobile
+// candidate: it has moved less than ptrig since its own last prune, i.e. less than 2 ptrig since this atom's: m = 3 ptrig.  A
+// prune reads the full list, which must therefore hold every pair within cutoff + m whenever a prune can happen: its trigger
+// is the outer margin minus m (frozen) / half of the mobile margin minus 3 ptrig; the mobile margin grows by ptrig to keep
+// the two equal.
 static void derive_margins(BluesEngine* h) {
     double room = 1e30;
     for (int k = 0; k < 3; k++) room = std::min(room, 0.5 * h->box[k] - h->cutoff - 1e-6);
@@ -295,13 +298,14 @@ static void derive_margins(BluesEngine* h) {
     h->skin_m = mostly_frozen ? std::min(2.0 * h->skin, std::max(0.0, room)) : h->skin;
     h->trig = std::min(h->skin, 0.5 * h->skin_m);
     // the dual list pays where most candidates are frozen (one displacement per pair); elsewhere the full lists are walked
-    double m = h->tune.prune_margin < 0.0 ? 0.04 : h->tune.prune_margin;
+    const double m = h->tune.prune_margin < 0.0 ? 0.04 : h->tune.prune_margin;
     h->prune_on = mostly_frozen && m > 0.0 && m < 0.75 * h->skin;
     h->prune_m = h->prune_m_mobile = h->ptrig = 0.0;
     if (h->prune_on) {
-        h->prune_m = m; h->prune_m_mobile = 2.0 * m; h->ptrig = m;
+        h->prune_m = m; h->prune_m_mobile = 3.0 * m; h->ptrig = m;
+        h->skin_m = std::min(2.0 * h->skin + m, std::max(0.0, room));
         h->trig = std::min(h->skin - h->prune_m, 0.5 * (h->skin_m - h->prune_m_mobile));
-        if (h->trig <= 0.0) { h->prune_on = false; h->trig = std::min(h->skin, 0.5 * h->skin_m); }
+        if (h->trig <= 0.25 * h->skin) { h->prune_on = false; h->prune_m = h->prune_m_mobile = h->ptrig = 0.0; h->skin_m = std::min(2.0 * h->skin, std::max(0.0, room)); h->trig = std::min(h->skin, 0.5 * h->skin_m); }
     }
 }
 
@@ -440,7 +444,7 @@ static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
             ClusterRec& r = h->h_recs[c]; memset(&r, 0, sizeof r);
             r.type = ct[c]; r.nc = cn[c]; r.na = 0;
             for (int a = 0; a < 4; a++) {
-                r.atoms[a] = ca[c * 4 + a]; r.alch[a] = cal[c * 4 + a]; r.mobile[a] = cmo[c * 4 + a]; r.sorted[a] = 0;
+                r.atoms[a] = ca[c * 4 + a]; r.alch[a] = cal[c * 4 + a]; r.mobile[a] = cmo[c * 4 + a]; r.sorted[a] = 0; r.islot[a] = -1;
                 if (r.atoms[a] >= 0) { r.na = a + 1; r.w[a] = 1.0 / h->mass[r.atoms[a]]; }
             }
             for (int q = 0; q < 3; q++) r.dist[q] = cd[c * 3 + q];
@@ -698,7 +702,7 @@ static int sort_and_tile(BluesEngine* h) {
         { std::vector<int> cs(h->clusters.size() * 4, 0);
           for (size_t c = 0; c < h->clusters.size(); c++) for (int a = 0; a < 4; a++) if (h->clusters[c].atoms[a] >= 0) cs[c * 4 + a] = h->h_sorted_of_orig[h->clusters[c].atoms[a]];
           h->d_cl_sorted.upload(cs);
-          for (size_t c = 0; c < h->clusters.size(); c++) for (int a = 0; a < 4; a++) h->h_recs[c].sorted[a] = cs[c * 4 + a];
+          for (size_t c = 0; c < h->clusters.size(); c++) for (int a = 0; a < 4; a++) { h->h_recs[c].sorted[a] = cs[c * 4 + a]; h->h_recs[c].islot[a] = h->clusters[c].atoms[a] >= 0 ? islot[h->clusters[c].atoms[a]] : -1; }
           h->d_recs.upload(h->h_recs); }
         h->d_tile_atoms.upload(tile_atoms); h->d_islot.upload(islot);
         h->d_ex_start.upload(ex_start); h->d_ex_idx.upload(ex_idx);
@@ -712,7 +716,14 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
         if (h->k1_mode == 2) {
             h->d_alist.alloc((size_t)h->n_islots * h->acap); h->d_acount.alloc(h->n_islots);
-            if (h->prune_on) { h->d_plist.alloc((size_t)h->n_islots * h->acap); h->d_pcount.alloc(h->n_islots); }
+            if (h->prune_on) {
+                h->d_plist.alloc((size_t)h->n_islots * h->acap); h->d_pcount.alloc(h->n_islots); h->d_pneed.alloc(h->n_islots);
+                for (int k = 0; k < 3; k++) h->d_xprune[k].alloc(h->n_islots);
+                // packed images where most list entries are frozen atoms (the same condition as the pruned lists)
+                h->mcap = std::min(jcap, (((int)h->mobile.size() + 63) / 64) * 64);
+                h->d_pimg4.alloc((size_t)std::max(1, h->n_lists) * jcap); h->d_pimg2.alloc((size_t)std::max(1, h->n_lists) * jcap);
+                h->d_mlist.alloc((size_t)std::max(1, h->n_lists) * h->mcap * 2); h->d_mcount.alloc(std::max(1, h->n_lists));
+            }
         }
         h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1)) + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
         { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi);
@@ -755,8 +766,9 @@ static IntArgs make_int_args(BluesEngine* h) {
     A.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; A.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
     A.half_skin2 = h->trig * h->trig; A.flags = h->d_flags.p; A.batch_req = batch_req_ptr(h);
     const bool pruned = h->prune_on && h->k1_mode == 2;
-    for (int k = 0; k < 3; k++) A.xprune[k] = pruned ? h->d_xprune[k].p : nullptr;
-    A.prune_trig2 = h->ptrig * h->ptrig;
+    for (int k = 0; k < 3; k++) { A.xprune[k] = pruned ? h->d_xprune[k].p : nullptr; A.fscale[k] = (float)(h->box[k] / 4294967296.0); }
+    A.pneed = pruned ? h->d_pneed.p : nullptr;
+    A.prune_trig2 = (float)(h->ptrig * h->ptrig);
     A.total_mass = h->total_mass; A.cm_part = h->d_cm_part.p; A.cm_nblocks = h->int_blocks;
     A.mom_part = h->d_mom_part.p; A.n_mom = h->n_islots / 64 + 2;
     A.acc = h->d_acc.p; A.work_trace = (h->tracing || h->ctrl_arg) ? h->d_trace.p : nullptr; A.trace_index = h->prog_trace;
@@ -822,6 +834,7 @@ static ListArgs make_list_args(BluesEngine* h) {
     a.alch_jrec = h->alch.empty() ? nullptr : (void*)h->d_jrec.p; a.p_sigma = h->d_sigma.p; a.p_eps = h->d_eps.p; a.p_charge = h->d_charge.p;
     if (h->k1_mode == 2) { a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap; }
     a.S = h->S; a.n_lists = h->n_lists; a.hint_count = h->hint_count; a.no_sphere = h->tune.no_sphere;
+    if (h->k1_mode == 2 && h->prune_on) { a.pneed = h->d_pneed.p; a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap; }
     return a;
 }
 
@@ -876,8 +889,9 @@ template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
     if (h->k1_mode == 2) {
         a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap;
         if (h->prune_on) {
-            a.plist = h->d_plist.p; a.pcount = h->d_pcount.p; a.mobile_atoms = h->d_mobile_atoms.p; a.n_mobile = (int)h->mobile.size();
-            for (int k = 0; k < 3; k++) { a.x[k] = h->d_x[k].p; a.xprune[k] = h->d_xprune[k].p; }
+            a.plist = h->d_plist.p; a.pcount = h->d_pcount.p; a.pneed = h->d_pneed.p;
+            for (int k = 0; k < 3; k++) a.xprune[k] = h->d_xprune[k].p;
+            a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap;
         }
     }
     a.S = h->S; a.n_lists = h->n_lists;
@@ -1032,7 +1046,6 @@ static FinArgs make_fin_args(BluesEngine* h, const double le[3], int slot_mask =
     for (int k = 0; k < 3; k++) F.v[k] = h->d_v[k].p;
     F.mass = h->d_mass.p; F.mom_part = h->d_mom_part.p;
     F.frec = h->pme ? h->d_frec.p : nullptr;
-    F.flags = (h->prune_on && h->k1_mode == 2) ? h->d_flags.p : nullptr;
     return F;
 }
 
@@ -2162,7 +2175,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     if (h->tune.graph_units > 0) h->graph_units = h->tune.graph_units;
     if (h->tune.graph_fork >= 0) h->graph_fork = h->tune.graph_fork != 0;
     try {
-        for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); h->d_x_sort[k].alloc(n); h->d_xprune[k].alloc(n); }
+        for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); h->d_x_sort[k].alloc(n); }
         h->d_stage.alloc((size_t)3 * n); h->d_xfer_out.alloc(4); h->hx.assign((size_t)3 * n, 0.0);
         h->d_mass.upload(h->mass); h->d_charge.upload(h->charge); h->d_sigma.upload(h->sigma); h->d_eps.upload(h->eps);
         h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ctrl.alloc(1); h->d_stamps.alloc(64); h->d_tab_ls.upload(h->tab_ls); h->d_tab_le.upload(h->tab_le); h->d_ftot.alloc((size_t)9 * n); h->d_alch_self.alloc(9 * 64);
@@ -2630,7 +2643,7 @@ int blues_time_nonbonded(BluesEngine* h, int32_t reps, double* usec) {
     // (with pruned lists: the first launch prunes, the acknowledged state is what the timed launches see -- the steady state
     // between two prunes; blues_batch_time_nonbonded_modes times both kinds of pass)
     for (int w = 0; w < 3; w++) { rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h); if (rc) return 1; }
-    if (h->prune_on && h->k1_mode == 2) hipLaunchKernelGGL(k_prune_set, dim3(1), dim3(64), 0, h->stream, (const RepCore*)nullptr, h->d_flags.p, 1, 0);
+    if (h->prune_on && h->k1_mode == 2) hipLaunchKernelGGL(k_prune_set, dim3(1), dim3(256), 0, h->stream, (const RepCore*)nullptr, h->d_pneed.p, h->n_islots, 0);
     HIP_OK(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; r++) { rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h); if (rc) return 1; }
     HIP_OK(h, hipEventRecord(h->ev1, h->stream));
@@ -2946,7 +2959,8 @@ int blues_batch_time_nonbonded_modes(BluesBatch* b, int32_t reps, double usec[2]
             if (hipMemcpy(&f, m->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) np += f.prunes;
             nf += (double)m->st_passes;
         }
-        if (prune_fraction) *prune_fraction = (h->prune_on && h->k1_mode == 2) ? (nf > 0.0 ? std::min(1.0, np / nf) : 1.0) : 0.0;
+        int n_i = 0; for (int i : h->mobile) if (h->alch_local[i] < 0) n_i++;
+        if (prune_fraction) *prune_fraction = (h->prune_on && h->k1_mode == 2) ? (nf > 0.0 && n_i > 0 ? std::min(1.0, np / (nf * n_i)) : 1.0) : 0.0;
     }
     b->failed.assign(b->R(), 0); b->active.assign(b->R(), 1);
     if (batch_enter(b)) return 1;
@@ -2957,14 +2971,14 @@ int blues_batch_time_nonbonded_modes(BluesBatch* b, int32_t reps, double usec[2]
     float ms[2] = {0.f, 0.f};
     for (int mode = 0; mode < 2 && !rc; mode++) {   // 0: pruned lists current, 1: stale (every launch prunes)
         for (int w = 0; w < 3 && !rc; w++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
-        if (dual) hipLaunchKernelGGL(k_prune_set, dim3((b->R() + 63) / 64), dim3(64), 0, h->cur, b->d_core.p, (DevFlags*)nullptr, b->R(), mode);
+        if (dual) hipLaunchKernelGGL(k_prune_set, dim3(1, b->R()), dim3(256), 0, h->cur, b->d_core.p, (int*)nullptr, h->n_islots, mode);
         if (!rc && hipEventRecord(h->ev0, h->cur) != hipSuccess) rc = 1;
         for (int r = 0; r < reps && !rc; r++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (!rc && hipEventRecord(h->ev1, h->cur) != hipSuccess) rc = 1;
         if (rc || hipEventSynchronize(h->ev1) != hipSuccess) { rc = 1; break; }
         hipEventElapsedTime(&ms[mode], h->ev0, h->ev1);
     }
-    if (dual && !rc) hipLaunchKernelGGL(k_prune_set, dim3((b->R() + 63) / 64), dim3(64), 0, h->cur, b->d_core.p, (DevFlags*)nullptr, b->R(), 0);   // the last launch pruned
+    // (the last timed launch pruned every list at these positions: the flags are down, nothing to restore)
     b->lockstep = false;
     for (BluesEngine* m : b->eng) m->lists_forced = false;
     if (rc) { b->err = "timing launch failed: " + h->err; batch_leave(b); return 1; }

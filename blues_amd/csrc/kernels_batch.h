@@ -233,11 +233,9 @@ __global__ void k_gather_hints_b(const RepCore* __restrict__ reps, int R, int* o
 
 // timing harness only (blues_time_nonbonded*): put the pruned lists of every member (or of one lone engine) into the "stale" or
 // the "current" state, so that the launches that follow are all prune passes or all pruned-list passes
-__global__ void k_prune_set(const RepCore* __restrict__ reps, DevFlags* one, int R, int raise) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    DevFlags* f = reps ? reps[r].in.flags : one;
-    f->prune_req = f->prune_done + (raise ? 1u : 0u);
+__global__ void k_prune_set(const RepCore* __restrict__ reps, int* one, int n_islots, int raise) {
+    int* f = reps ? reps[blockIdx.y].in.pneed : one;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_islots; q += gridDim.x * blockDim.x) f[q] = raise;
 }
 
 __global__ void __launch_bounds__(256) k_bonded_energy_b(const RepCore* __restrict__ reps) {

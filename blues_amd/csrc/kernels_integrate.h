@@ -48,6 +48,7 @@ struct ClusterRec {
     int alch[4];     // local alchemical index or -1
     int mobile[4];   // index into the mobile list (noise buffer)
     int sorted[4];   // index into the tile image
+    int islot[4];    // i-slot of the nonbonded kernel (mobile non-alchemical atoms) or -1
     int type, nc, na, pad;
     double dist[3];
     double w[4];     // 1/mass (0 for empty slots)
@@ -73,7 +74,9 @@ struct IntArgs {
     // tile image refresh + list validity
     AtomF* img_f; AtomD* img_d;
     const double* xbuild[3]; double half_skin2;
-    const double* xprune[3]; double prune_trig2;   // positions at the last prune of the per-atom lists, (displacement that asks for the next one)^2; null: no pruned lists
+    // pruned per-atom lists of the nonbonded kernel (kernels_nb.h; null: none): where each i-atom was when its list was last pruned
+    // (fixed point, by i-slot), the flag that asks for the next prune, (displacement that raises it)^2, box edge / 2^32
+    const unsigned* xprune[3]; int* pneed; float prune_trig2; float fscale[3];
     DevFlags* flags; int* batch_req;   // batch_req: see ListArgs (null outside a list-synchronised batch)
     // COM removal
     double total_mass; double* cm_part; int cm_nblocks;
@@ -246,7 +249,6 @@ struct FinArgs {
     // mom_part[block][0..2] = sum m v, [3..5] = sum of the slot-0 force, over the block's atoms
     const double* v[3]; const double* mass; double* mom_part;
     const double* frec;   // [3][n] reciprocal-space force (kernels_pme.h), lambda-independent; null without BLUES_NB_PME
-    DevFlags* flags;      // acknowledges the prune the nonbonded kernel of this pass did (DevFlags::prune_req)
 };
 
 // grid: [0, n_itiles) one block per i-tile | [n_itiles, +nb_alch_atoms) alchemical atoms' bonded rows |
@@ -268,7 +270,6 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
     const int nb_alch_atoms = A.n_alch > 0 ? 1 : 0;
     __shared__ double red[4][3][64];
     int blk = blockIdx.x;
-    if (blk == 0 && tid == 0 && A.flags) A.flags->prune_done = A.flags->prune_req;
     if (blk < n_itiles + nb_alch_atoms) {
         const int isl = blk < n_itiles ? blk * 64 + lane : -1;
         const FinRec rec = A.recs[blk < n_itiles ? isl : A.n_islots + lane];
@@ -405,7 +406,7 @@ __device__ __forceinline__ void integrate_body(IntArgs& A, const Program& prog) 
     const bool active = cl < A.n_clusters;
     ClusterRec R;
     if (active) R = A.recs[cl];
-    else { for (int a = 0; a < 4; a++) { R.atoms[a] = -1; R.alch[a] = -1; R.mobile[a] = 0; R.sorted[a] = 0; R.w[a] = 0.0; } R.type = 0; R.nc = 0; R.na = 0; R.dist[0] = R.dist[1] = R.dist[2] = 0.0; }
+    else { for (int a = 0; a < 4; a++) { R.atoms[a] = -1; R.alch[a] = -1; R.mobile[a] = 0; R.sorted[a] = 0; R.islot[a] = -1; R.w[a] = 0.0; } R.type = 0; R.nc = 0; R.na = 0; R.dist[0] = R.dist[1] = R.dist[2] = 0.0; }
     C.na = R.na; C.nc = R.nc; C.type = R.type;
     bool moved = false, ok = true;
     unsigned draw = A.draw_base;
@@ -583,24 +584,30 @@ _Pragma("unroll") for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 
 #endif
     if (!active) return;
     // ---- write back, refresh the fixed-point image, check list validity
-    bool need_rebuild = false, need_prune = false, bad = false;
+    bool need_rebuild = false, bad = false;
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         if (a < C.na) {
             const int i = C.id[a];
             for (int k = 0; k < 3; k++) { A.v[k][i] = C.v[a][k]; bad |= !(C.x[a][k] == C.x[a][k]) || !(C.v[a][k] == C.v[a][k]); }
             if (moved) {
-                double d2 = 0.0, p2 = 0.0;
-                for (int k = 0; k < 3; k++) { A.x[k][i] = C.x[a][k]; const double d = C.x[a][k] - A.xbuild[k][i]; d2 += d * d; if (A.xprune[0]) { const double e = C.x[a][k] - A.xprune[k][i]; p2 += e * e; } }
-                need_rebuild |= d2 > A.half_skin2; need_prune |= p2 > A.prune_trig2;
+                double d2 = 0.0;
+                for (int k = 0; k < 3; k++) { A.x[k][i] = C.x[a][k]; const double d = C.x[a][k] - A.xbuild[k][i]; d2 += d * d; }
+                need_rebuild |= d2 > A.half_skin2;
                 const int s = R.sorted[a];
-                if (A.img_f) { unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2]; }
+                if (A.img_f) {
+                    unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2];
+                    if (A.pneed && R.islot[a] >= 0) {
+                        float p2 = 0.0f;
+                        for (int k = 0; k < 3; k++) { const float e = (float)(int)(u[k] - A.xprune[k][R.islot[a]]) * A.fscale[k]; p2 += e * e; }
+                        if (p2 > A.prune_trig2) A.pneed[R.islot[a]] = 1;
+                    }
+                }
                 else { unsigned long long u[3]; to_fixed(C.x[a], A.box, u); A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
             }
         }
     }
     if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; if (A.batch_req) *A.batch_req = 1; }
-    if (need_prune) A.flags->prune_req = A.flags->prune_done + 1;
 #ifdef BLUES_STAMP
     if (cl == 0 && A.stamps) A.stamps[2 + prog.n] = clock64();
 #endif
@@ -781,20 +788,21 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
     const bool active = cl < A.n_clusters;
     ClusterRec R;
     if (active) R = A.recs[cl];
-    else { for (int a = 0; a < 4; a++) { R.atoms[a] = -1; R.alch[a] = -1; R.mobile[a] = 0; R.sorted[a] = 0; R.w[a] = 0.0; } R.type = 0; R.nc = 0; R.na = 0; R.dist[0] = R.dist[1] = R.dist[2] = 0.0; }
+    else { for (int a = 0; a < 4; a++) { R.atoms[a] = -1; R.alch[a] = -1; R.mobile[a] = 0; R.sorted[a] = 0; R.islot[a] = -1; R.w[a] = 0.0; } R.type = 0; R.nc = 0; R.na = 0; R.dist[0] = R.dist[1] = R.dist[2] = 0.0; }
     Cluster C;
     C.na = R.na; C.nc = R.nc; C.type = R.type;
     const unsigned nd0 = A.draw_base - A.noise_draw_base;
     const bool pre_noise = nd0 < (unsigned)A.n_noise;
-    double FA[4][3], FB[4][3], G0[4][3], XB[4][3], XP[4][3];
-    const bool pruned = A.xprune[0] != nullptr;   // (uniform)
+    double FA[4][3], FB[4][3], G0[4][3], XB[4][3];
+    unsigned XP[4][3];
+    const bool pruned = A.pneed != nullptr;   // (uniform)
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int i = max(R.atoms[a], 0), al = R.alch[a], alc = max(al, 0);
         C.id[a] = R.atoms[a]; C.al[a] = al; C.w[a] = R.w[a];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; XB[a][k] = A.xbuild[k][i]; XP[a][k] = pruned ? A.xprune[k][i] : 0.0;
+            C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; XB[a][k] = A.xbuild[k][i]; XP[a][k] = pruned ? A.xprune[k][max(R.islot[a], 0)] : 0u;
             const double fa0 = A.ftot[(size_t)((al >= 0 ? 0 : 0) + k) * A.n + i];
             const double fb0 = A.ftot[(size_t)((al >= 0 ? 0 : 6) + k) * A.n + i];
             const double sa = A.alch_self[(0 + k) * 64 + alc], sb = A.alch_self[(6 + k) * 64 + alc];
@@ -838,7 +846,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
         const double dE = A.acc->e_slot[2] - A.acc->e_slot[1];
         A.acc->protocol_work += dE; A.acc->dE_last = dE;
     }
-    bool need_rebuild = false, need_prune = false, bad = false;
+    bool need_rebuild = false, bad = false;
     if (active) {
         // V(slot 2)
 #pragma unroll
@@ -875,21 +883,27 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
 #pragma unroll
         for (int a = 0; a < 4; a++) if (a < C.na) {
             const int i = C.id[a];
-            double d2 = 0.0, p2 = 0.0;
+            double d2 = 0.0;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 A.v[k][i] = C.v[a][k]; A.x[k][i] = C.x[a][k];
                 bad |= !(C.x[a][k] == C.x[a][k]) || !(C.v[a][k] == C.v[a][k]);
                 const double d = C.x[a][k] - XB[a][k]; d2 += d * d;
-                const double e = C.x[a][k] - XP[a][k]; p2 += e * e;
             }
-            need_rebuild |= d2 > A.half_skin2; need_prune |= pruned && p2 > A.prune_trig2;
+            need_rebuild |= d2 > A.half_skin2;
             const int s = R.sorted[a];
-            if (A.img_f) { unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2]; }
+            if (A.img_f) {
+                unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2];
+                if (pruned && R.islot[a] >= 0) {
+                    float p2 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { const float e = (float)(int)(u[k] - XP[a][k]) * A.fscale[k]; p2 += e * e; }
+                    if (p2 > A.prune_trig2) A.pneed[R.islot[a]] = 1;
+                }
+            }
             else { unsigned long long u[3]; to_fixed(C.x[a], A.box, u); A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
         }
         if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; if (A.batch_req) *A.batch_req = 1; }
-        if (need_prune) A.flags->prune_req = A.flags->prune_done + 1;
         if (bad) A.flags->nan_flag = 1;
         if (!ok) A.flags->constraint_fail = 1;
     }
@@ -908,20 +922,21 @@ __device__ __forceinline__ void step_md_body(IntArgs& A) {
     const bool active = cl < A.n_clusters;
     ClusterRec R;
     if (active) R = A.recs[cl];
-    else { for (int a = 0; a < 4; a++) { R.atoms[a] = -1; R.alch[a] = -1; R.mobile[a] = 0; R.sorted[a] = 0; R.w[a] = 0.0; } R.type = 0; R.nc = 0; R.na = 0; R.dist[0] = R.dist[1] = R.dist[2] = 0.0; }
+    else { for (int a = 0; a < 4; a++) { R.atoms[a] = -1; R.alch[a] = -1; R.mobile[a] = 0; R.sorted[a] = 0; R.islot[a] = -1; R.w[a] = 0.0; } R.type = 0; R.nc = 0; R.na = 0; R.dist[0] = R.dist[1] = R.dist[2] = 0.0; }
     Cluster C;
     C.na = R.na; C.nc = R.nc; C.type = R.type;
     const unsigned nd0 = A.draw_base - A.noise_draw_base;
     const bool pre_noise = nd0 < (unsigned)A.n_noise;
-    double F[4][3], G0[4][3], XB[4][3], XP[4][3], x0[4][3];
-    const bool pruned = A.xprune[0] != nullptr;   // (uniform)
+    double F[4][3], G0[4][3], XB[4][3], x0[4][3];
+    unsigned XP[4][3];
+    const bool pruned = A.pneed != nullptr;   // (uniform)
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int i = max(R.atoms[a], 0), al = R.alch[a], alc = max(al, 0);
         C.id[a] = R.atoms[a]; C.al[a] = al; C.w[a] = R.w[a];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; XB[a][k] = A.xbuild[k][i]; XP[a][k] = pruned ? A.xprune[k][i] : 0.0;
+            C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; XB[a][k] = A.xbuild[k][i]; XP[a][k] = pruned ? A.xprune[k][max(R.islot[a], 0)] : 0u;
             F[a][k] = A.ftot[(size_t)k * A.n + i] + (al >= 0 ? A.alch_self[k * 64 + alc] : 0.0);
             G0[a][k] = pre_noise ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : 0.0;
         }
@@ -937,7 +952,7 @@ __device__ __forceinline__ void step_md_body(IntArgs& A) {
         __syncthreads();
     }
     if (!active) return;
-    bool ok = true, need_rebuild = false, need_prune = false, bad = false;
+    bool ok = true, need_rebuild = false, bad = false;
 #pragma unroll
     for (int a = 0; a < 4; a++) {
 #pragma unroll
@@ -960,22 +975,28 @@ __device__ __forceinline__ void step_md_body(IntArgs& A) {
 #pragma unroll
     for (int a = 0; a < 4; a++) if (a < C.na) {
         const int i = C.id[a];
-        double d2 = 0.0, p2 = 0.0;
+        double d2 = 0.0;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             C.v[a][k] = (C.x[a][k] - x0[a][k]) * inv_dt;
             A.v[k][i] = C.v[a][k]; A.x[k][i] = C.x[a][k];
             bad |= !(C.x[a][k] == C.x[a][k]) || !(C.v[a][k] == C.v[a][k]);
             const double d = C.x[a][k] - XB[a][k]; d2 += d * d;
-            const double e = C.x[a][k] - XP[a][k]; p2 += e * e;
         }
-        need_rebuild |= d2 > A.half_skin2; need_prune |= pruned && p2 > A.prune_trig2;
+        need_rebuild |= d2 > A.half_skin2;
         const int s = R.sorted[a];
-        if (A.img_f) { unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2]; }
+        if (A.img_f) {
+            unsigned u[3]; to_fixed32(C.x[a], A.box, u); A.img_f[s].x = u[0]; A.img_f[s].y = u[1]; A.img_f[s].z = u[2];
+            if (pruned && R.islot[a] >= 0) {
+                float p2 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const float e = (float)(int)(u[k] - XP[a][k]) * A.fscale[k]; p2 += e * e; }
+                if (p2 > A.prune_trig2) A.pneed[R.islot[a]] = 1;
+            }
+        }
         else { unsigned long long u[3]; to_fixed(C.x[a], A.box, u); A.img_d[s].x = u[0]; A.img_d[s].y = u[1]; A.img_d[s].z = u[2]; }
     }
     if (need_rebuild) { A.flags->req_gen = A.flags->list_gen + 1; if (A.batch_req) *A.batch_req = 1; }
-    if (need_prune) A.flags->prune_req = A.flags->prune_done + 1;
     if (bad) A.flags->nan_flag = 1;
     if (!ok) A.flags->constraint_fail = 1;
 }

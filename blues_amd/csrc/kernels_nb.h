@@ -29,12 +29,7 @@ struct DevFlags {  // device-resident control words
     int nan_flag;
     int resort_hint;             // a j-list has grown to within 15 % of its capacity: the tiles have spread, re-sort soon
     int builds;                  // list builds executed (own requests, forced ones and batch-synchronised ones)
-    int prunes;                  // force passes that re-derived the pruned per-atom lists (nonbonded_atom_body)
-    // pruned lists are current iff equal.  Raised (req = done + 1) by the atom-list build and by the integrator when an atom has
-    // moved the inner margin since the last prune; the nonbonded kernel of a FORCE pass prunes, k_finalize of that pass
-    // acknowledges (done = req) -- a later kernel, because every nonbonded workgroup of the chain has to see the request
-    unsigned prune_req, prune_done;
-    int pad[3];
+    int prunes;                  // pruned per-atom lists re-derived so far (one count per atom and prune; nonbonded_atom_body)
 };
 
 struct ListArgs {
@@ -64,6 +59,11 @@ struct ListArgs {
     int no_sphere;           // development: bounding-box test only
     int hint_count;          // a list longer than this raises resort_hint (the i-atoms have spread: re-derive the layout)
     int S, n_lists;          // S consecutive i-tiles share one j-list (1 in the bitmask modes); n_lists = ceil(n_itiles / S), the alchemical tile's list comes after them
+    int* pneed;              // [n_islots] pruned-list mode: 1 = this atom's pruned list is stale (set here for every atom of a rebuilt list)
+    // packed image of every group list (null: not kept): the list's atoms as the nonbonded kernel stages them, {x,y,z,q} and
+    // {sigma/2, 2 sqrt(eps)}, written when the list is built -- frozen atoms never change, so the kernel copies it with
+    // coalesced loads and refreshes only the MOBILE entries (mlist: pairs (list position, image index)) from the live image
+    uint4* pimg4; float2* pimg2; int* mlist; int* mcount; int mcap;
 };
 
 // LIST_WAVES waves share one tile's scan of all n atoms; each wave keeps LIST_PREFETCH independent loads in flight.
@@ -242,6 +242,22 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     }
 
     NB_STAMP(t == 0 && tid == 0, 4);
+    if (a.alist && a.pimg4) {
+        if constexpr (sizeof(ufix) == 4) {
+            __shared__ int s_mc;
+            if (tid == 0) s_mc = 0;
+            __syncthreads();
+            uint4* g4 = a.pimg4 + (size_t)t * a.jcap; float2* g2 = a.pimg2 + (size_t)t * a.jcap; int* ml = a.mlist + (size_t)t * a.mcap * 2;
+            for (int k = tid; k < count; k += LIST_THREADS) {
+                const int js = jl[k];
+                const typename Img<R>::Atom A = img[js];
+                g4[k] = make_uint4((unsigned)A.x, (unsigned)A.y, (unsigned)A.z, __float_as_uint((float)A.q)); g2[k] = make_float2((float)A.hs, (float)A.se);
+                if (A.flags & FLAG_MOBILE) { const int q = atomicAdd(&s_mc, 1); if (q < a.mcap) { ml[2 * q] = k; ml[2 * q + 1] = js; } else a.flags->list_overflow = 1; }   // (order is irrelevant: the entries are only refreshed)
+            }
+            __syncthreads();
+            if (tid == 0) a.mcount[t] = min(s_mc, a.mcap);
+        }
+    }
     if (a.alist) return;   // per-atom-list mode: exclusions are dropped when build_atom_lists_body forms the atoms' lists -- no bitmask tiles
     __shared__ int s_jl[LIST_LDS];
 
@@ -413,10 +429,10 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
         }
     }
     NB_STAMP(t == 0 && tid == 0, 8);
-    if (t == 0 && tid == 0) a.flags->prune_req = a.flags->prune_done + 1;   // new full lists: the pruned ones are stale
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         if (lane == 0) {
+            if (a.pneed) a.pneed[t * 64 + wv + LIST_WAVES * u] = 1;   // new full list: the pruned one is stale
             a.acount[t * 64 + wv + LIST_WAVES * u] = min(cntv[u], a.acap);
             if (cntv[u] > a.acap) a.flags->list_overflow = 1;
             else if (cntv[u] > a.acap - a.acap / 8) a.flags->resort_hint = 1;   // (a re-sort re-derives the capacities)
@@ -445,9 +461,10 @@ template <typename R> struct NbArgs {
     int* batch_req;  // see ListArgs; cleared here (every list block of this pass has read it by now)
     const unsigned short* alist; const int* acount; int acap;   // per-atom lists (ListArgs), nonbonded_atom_body only
     int S, n_lists;                                                // tiles per j-list, number of lists (ListArgs)
-    // pruned per-atom lists (null: not in use): the entries of alist within cutoff + inner margin when they were last pruned
-    unsigned short* plist; int* pcount;
-    const double* x[3]; double* xprune[3]; const int* mobile_atoms; int n_mobile;   // where the mobile atoms were at the last prune
+    // pruned per-atom lists (null: not in use): the entries of alist within cutoff + inner margin when the atom's list was last
+    // pruned; pneed[islot] != 0: stale (ListArgs); xprune[k][islot]: where the atom was then (fixed point, as in the image)
+    unsigned short* plist; int* pcount; int* pneed; unsigned* xprune[3];
+    const uint4* pimg4; const float2* pimg2; const int* mlist; const int* mcount; int mcap;   // packed group images (ListArgs)
 };
 
 // One block = WPB waves working on the SAME i-tile; wave w of the tile walks the j-list segments
@@ -627,14 +644,15 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<
 #define NB_ATOM_U 12   // list entries per lane requested together (768 neighbours per round)
 // Dual lists.  The atoms' lists (alist) are built with the full Verlet margin and are rebuilt rarely; a third of their entries
 // sit in the margin, and every one of them costs a full pair evaluation of all 64 lanes.  The kernel therefore walks PRUNED
-// lists (plist: the entries within cutoff + a small inner margin) and re-derives them itself, in passing, whenever the
-// integrator reports that an atom has moved the inner margin since the last prune (DevFlags::prune_req): in such a pass the
-// wave walks the full list -- same arithmetic, out-of-range lanes masked as before -- and writes the survivors back in list
-// order (ballot + prefix count).  No extra kernel, no extra staging of the image; a prune pass costs what every pass used to.
-// Validity (derive_margins, blues_engine.hip): a pruned list holds every pair within cutoff + m of the prune positions; the
-// pair can close at most by the displacements of its two atoms since, and a prune is requested as soon as one atom has moved
-// ptrig (m = ptrig for a frozen partner, 2 ptrig for a mobile one).  For the full list to hold every pair within cutoff + m
-// at ANY prune, its own rebuild trigger is the margin minus m.
+// lists (plist: the entries within cutoff + a small inner margin) and re-derives them itself, in passing and PER ATOM: the
+// integrator raises pneed[islot] when that atom has moved the inner margin since its list was last pruned; for such an atom
+// the wave walks the full list -- same arithmetic, out-of-range lanes masked as before -- and writes the survivors back in
+// list order (ballot + prefix count).  No extra kernel, no extra staging of the image.  A hydrogen asks every ~6 steps, a
+// heavy atom every ~20: about one atom in ten per pass, spread evenly over the waves.
+// Validity (derive_margins, blues_engine.hip): a pruned list holds every pair within cutoff + m of the atom's prune positions.
+// A frozen partner never moves: m = ptrig covers the atom's own displacement.  A mobile partner j has moved less than ptrig
+// since ITS last prune, hence less than 2 ptrig since this atom's: m = 3 ptrig.  For the full list to hold every pair within
+// cutoff + m at any prune, its own rebuild trigger is the outer margin minus m.
 template <bool ENERGY>
 __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, const NbConst<float>& c, const AtomF* __restrict__ img, const int t) {   // t: list (group of S i-tiles)
     struct P4 { uint32_t x, y, z; float q; };
@@ -646,29 +664,22 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
     if (t == 0 && tid == 0) { a.flags->list_gen = a.flags->req_gen; if (a.batch_req) *a.batch_req = 0; }  // lists are current for this pass
     if (t >= a.n_lists) return;
-    // (block-uniform; every workgroup of the chain sees the same two words: they change only in other kernels)
-    const bool stale = a.plist == nullptr || a.flags->prune_req != a.flags->prune_done;
-    const bool pruning = !ENERGY && a.plist != nullptr && stale;   // an energy evaluation reads whichever list is valid and writes none
-    const unsigned short* const lists = stale ? a.alist : a.plist;
-    const int* const counts = stale ? a.acount : a.pcount;
-    if (pruning && t == 0) {
-        for (int q = tid; q < a.n_mobile; q += blockDim.x) { const int i = a.mobile_atoms[q]; a.xprune[0][i] = a.x[0][i]; a.xprune[1][i] = a.x[1][i]; a.xprune[2][i] = a.x[2][i]; }
-        if (tid == 0) a.flags->prunes++;
-    }
+    const bool dual = a.plist != nullptr;
     const int count = a.jcount[t];
     const int* jlst = a.jlist + (size_t)t * a.jcap;
     const int slot0 = t * a.S * 64, nslot = min(a.S, a.n_itiles - t * a.S) * 64;   // the i-slots this list serves
     // An atom's whole list is requested up front (NB_ATOM_U wave-loads of 64 entries, all in flight together) and ONE ATOM
     // AHEAD: the next atom's entries travel while the current atom is computed, the first atom's while the image is staged.
     // (With one load per iteration, or with all waves requesting and waiting in step, the list stream ran at HBM latency.)
-    unsigned entn[NB_ATOM_U]; int cntn = 0, ian = -1;
+    unsigned entn[NB_ATOM_U]; int cntn = 0, ian = -1; bool stalen = true;
     auto request = [&](int s) {
         ian = -1; cntn = 0;
         if (s < nslot) {
             ian = __builtin_amdgcn_readfirstlane(a.tile_atoms[slot0 + s]);
             if (ian >= 0) {
-                cntn = __builtin_amdgcn_readfirstlane(counts[slot0 + s]);
-                const unsigned short* lst = lists + (size_t)(slot0 + s) * a.acap;
+                stalen = !dual || __builtin_amdgcn_readfirstlane(a.pneed[slot0 + s]) != 0;
+                cntn = __builtin_amdgcn_readfirstlane((stalen ? a.acount : a.pcount)[slot0 + s]);
+                const unsigned short* lst = (stalen ? a.alist : a.plist) + (size_t)(slot0 + s) * a.acap;
 #pragma unroll
                 for (int u = 0; u < NB_ATOM_U; u++) { const int q = u * 64 + lane; entn[u] = q < cntn ? (unsigned)lst[q] : 0u; }
             }
@@ -677,10 +688,26 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     NB_STAMP(t == 0 && tid == 0, 16);
     request(wv);
     NB_STAMP(t == 0 && tid == 0, 17);
-    for (int k = tid; k < count; k += blockDim.x) {
-        const AtomF aj = img[jlst[k]];
-        P4 v4; v4.x = aj.x; v4.y = aj.y; v4.z = aj.z; v4.q = aj.q; lp[k] = v4;
-        P2 v2; v2.hs = aj.hs; v2.se = aj.se; lq[k] = v2;
+    if (a.pimg4) {
+        // packed image: a straight copy, every load of a thread in flight before its first LDS store; then the few mobile entries
+        const uint4* g4 = a.pimg4 + (size_t)t * a.jcap; const float2* g2 = a.pimg2 + (size_t)t * a.jcap;
+        constexpr int SU = 7;   // 7 x 1024 threads >= the largest list capacity whose image fits LDS
+        for (int base = 0; base < count; base += SU * 1024) {
+            uint4 r4[SU]; float2 r2[SU];
+#pragma unroll
+            for (int u = 0; u < SU; u++) { const int k = base + u * 1024 + tid; if (k < count) { r4[u] = g4[k]; r2[u] = g2[k]; } }
+#pragma unroll
+            for (int u = 0; u < SU; u++) { const int k = base + u * 1024 + tid; if (k < count) { *reinterpret_cast<uint4*>(&lp[k]) = r4[u]; *reinterpret_cast<float2*>(&lq[k]) = r2[u]; } }
+        }
+        __syncthreads();
+        const int mc = a.mcount[t]; const int* ml = a.mlist + (size_t)t * a.mcap * 2;
+        for (int q = tid; q < mc; q += blockDim.x) { const int k = ml[2 * q], js = ml[2 * q + 1]; lp[k].x = img[js].x; lp[k].y = img[js].y; lp[k].z = img[js].z; }
+    } else {
+        for (int k = tid; k < count; k += blockDim.x) {
+            const AtomF aj = img[jlst[k]];
+            P4 v4; v4.x = aj.x; v4.y = aj.y; v4.z = aj.z; v4.q = aj.q; lp[k] = v4;
+            P2 v2; v2.hs = aj.hs; v2.se = aj.se; lq[k] = v2;
+        }
     }
     NB_STAMP(t == 0 && tid == 0, 18);
     __syncthreads();
@@ -689,6 +716,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     for (int s = wv; s < nslot; s += nw) {
         const int islot = slot0 + s;
         const int ia = ian, cnt = cntn;
+        const bool stale = stalen;
         unsigned ent[NB_ATOM_U];
 #pragma unroll
         for (int u = 0; u < NB_ATOM_U; u++) ent[u] = entn[u];
@@ -698,7 +726,8 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         const float iq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].q)));
         const float ihs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].hs)));
         const float ise = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].se)));
-        const unsigned short* lst = lists + (size_t)islot * a.acap;
+        const bool pruning = !ENERGY && dual && stale;   // an energy evaluation reads whichever list is valid and writes none
+        const unsigned short* lst = (stale ? a.alist : a.plist) + (size_t)islot * a.acap;
         unsigned short* const pout = pruning ? a.plist + (size_t)islot * a.acap : nullptr;
         int pcnt = 0;   // survivors written so far (wave-uniform)
         double fx = 0.0, fy = 0.0, fz = 0.0;
@@ -719,7 +748,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
             if (ENERGY) {
                 if (in) { const double wgt = (e & 0x8000u) ? 0.5 : 1.0; elj += wgt * (double)e1; ecl += wgt * (double)e2; }
             }
-            if (write) {   // prune pass: keep what lies within cutoff + inner margin, in list order
+            if (write) {   // prune: keep what lies within cutoff + inner margin, in list order
                 const bool keep = have && r2 < ((e & 0x8000u) ? c.rp2_m : c.rp2);
                 const unsigned long long bal = __ballot(keep);
                 if (keep) pout[pcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)e;
@@ -749,7 +778,12 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
                 pair(have ? (unsigned)lst[base + lane] : 0u, have, true);
                 fx += (double)bx; fy += (double)by; fz += (double)bz; bx = by = bz = 0.0f;
             }
-            if (lane == 0) a.pcount[islot] = pcnt;   // (a subset of a list that fits acap)
+            if (lane == 0) {
+                a.pcount[islot] = pcnt;   // (a subset of a list that fits acap)
+                a.xprune[0][islot] = ix; a.xprune[1][islot] = iy; a.xprune[2][islot] = iz;
+                a.pneed[islot] = 0;       // (this wave is the only reader of the flag in this launch; the integrator sets it in a later one)
+                atomicAdd(&a.flags->prunes, 1);
+            }
         }
         NB_STAMP(t == 0 && tid == 0, 20 + min(2 * (s / nw), 6));
         fx += (double)bx; fy += (double)by; fz += (double)bz;

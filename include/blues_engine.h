@@ -253,9 +253,9 @@ int blues_reset(BluesEngine *h);
  * [12] nonbonded kernel in use: 0 tile kernel, 1 sub-tile kernel, 2 per-atom
  * lists over an LDS image [13] i-tiles per j-list [14] entries of all per-atom
  * lists at the last rebuild [15] 64-entry wave iterations they take
- * [16] force passes that re-derived the pruned per-atom lists [17] entries of
- * all pruned lists now [18] 64-entry wave iterations they take [19] 1 if the
- * nonbonded kernel walks pruned lists */
+ * [16] pruned per-atom lists re-derived so far (one count per atom and prune)
+ * [17] entries of all pruned lists now [18] 64-entry wave iterations they take
+ * [19] 1 if the nonbonded kernel walks pruned lists */
 #define BLUES_N_STATS 20
 int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
 /* time `reps` launches of the dominant nonbonded kernel alone with HIP events
@@ -337,10 +337,10 @@ int blues_batch_prefetch_energies(BluesBatch *b, int32_t what);
 /* [0] steps issued in lock step (one launch for all members) [1] steps that
  * fell back to per-member launches [2] members [3] batched energy evaluations */
 int blues_batch_get_stats(BluesBatch *b, int64_t stats[4]);
-/* as blues_time_nonbonded, for one batched launch covering all members.  With pruned per-atom lists the kernel has two
- * kinds of pass: over current pruned lists (usec[0]) and one that re-derives them from the full lists (usec[1]);
- * prune_fraction is the share of the second kind among the force passes this batch has run so far, and
- * blues_batch_time_nonbonded returns the mean weighted with it. */
+/* as blues_time_nonbonded, for one batched launch covering all members.  With pruned per-atom lists an atom is served in
+ * one of two ways: from its current pruned list, or from its full list while the pruned one is re-derived.  usec[0] / usec[1]:
+ * the launch with every atom served the first / the second way; prune_fraction: the share of (atom, pass) pairs served the
+ * second way in the force passes this batch has run so far; blues_batch_time_nonbonded returns the mean weighted with it. */
 int blues_batch_time_nonbonded_modes(BluesBatch *b, int32_t reps, double usec[2], double *prune_fraction);
 int blues_batch_time_nonbonded(BluesBatch *b, int32_t reps, double *usec_per_launch);
 

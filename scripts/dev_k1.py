@@ -32,7 +32,7 @@ for spec in a.specs:
     u0, u1, f = B.time_nonbonded_modes(30)
     nat = 261.0
     reb = np.mean([b["list_generation"] - a_["list_generation"] for a_, b in zip(s0, s1)]) / a.nsteps
-    pr = np.mean([b["prune_passes"] - a_["prune_passes"] for a_, b in zip(s0, s1)]) / a.nsteps
+    pr = np.mean([b["atom_prunes"] - a_["atom_prunes"] for a_, b in zip(s0, s1)]) / a.nsteps / nat
     st = s1[0]
     algo = 36.0 * system.n_atoms * a.R
     blend = (1 - pr) * u0 + pr * u1
