@@ -68,7 +68,7 @@ class BluesTuning(C.Structure):
         ("fuse_forces", C.c_int32), ("fuse_big", C.c_int32), ("fast_step", C.c_int32), ("slot_mask", C.c_int32),
         ("fork", C.c_int32), ("use_graph", C.c_int32), ("graph_units", C.c_int32), ("graph_fork", C.c_int32),
         ("batch_sync_lists", C.c_int32), ("force_lists", C.c_int32), ("no_sphere", C.c_int32),
-        ("pme_general", C.c_int32), ("debug_lists", C.c_int32), ("assume_batch", C.c_int32), ("reserved", C.c_int32),
+        ("pme_general", C.c_int32), ("debug_lists", C.c_int32), ("assume_batch", C.c_int32), ("k1_threads", C.c_int32),
     ]
 
 

@@ -651,7 +651,7 @@ static int sort_and_tile(BluesEngine* h) {
                 h->waves_tile = 1; h->npart = 1; h->wpb = 4; h->seg_len = 64;
                 double cap = rho * 4.0 / 3.0 * M_PI * rl * rl * rl * 1.7;   // mean neighbour count within cutoff+skin, with slack for dense regions
                 if (h->tune.acap_scale > 0.0) cap *= h->tune.acap_scale;
-                h->acap = std::min(jcap, std::max(64, (((int)cap + 63) / 64) * 64));
+                h->acap = std::max(64 * NB_ATOM_U, std::min(jcap, std::max(64, (((int)cap + 63) / 64) * 64)));   // (at least the prefetch window of nonbonded_atom_body: its loads stay inside the atom's row)
             }
         }
     }
@@ -911,8 +911,9 @@ template <bool ENERGY> static int launch_nb_atom(BluesEngine* h, const NbArgs<fl
         lds_set[lead][ENERGY] = lds;
     }
     const int nb = std::max(1, h->n_lists);
-    if (lead) hipLaunchKernelGGL((k_nonbonded_atom_b<ENERGY>), dim3(nb * h->batch->R()), dim3(1024), lds, h->cur, h->batch->d_nb_f.p, nb, h->batch->R());
-    else hipLaunchKernelGGL((k_nonbonded_atom<ENERGY>), dim3(nb), dim3(1024), lds, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
+    const int nthr = h->tune.k1_threads > 0 ? std::min(1024, std::max(64, (h->tune.k1_threads / 64) * 64)) : 1024;
+    if (lead) hipLaunchKernelGGL((k_nonbonded_atom_b<ENERGY>), dim3(nb * h->batch->R()), dim3(nthr), lds, h->cur, h->batch->d_nb_f.p, nb, h->batch->R());
+    else hipLaunchKernelGGL((k_nonbonded_atom<ENERGY>), dim3(nb), dim3(nthr), lds, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
     return 0;
 }
 
@@ -2971,14 +2972,14 @@ int blues_batch_time_nonbonded_modes(BluesBatch* b, int32_t reps, double usec[2]
     float ms[2] = {0.f, 0.f};
     for (int mode = 0; mode < 2 && !rc; mode++) {   // 0: pruned lists current, 1: stale (every launch prunes)
         for (int w = 0; w < 3 && !rc; w++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
-        if (dual) hipLaunchKernelGGL(k_prune_set, dim3(1, b->R()), dim3(256), 0, h->cur, b->d_core.p, (int*)nullptr, h->n_islots, mode);
+        if (dual) hipLaunchKernelGGL(k_prune_set, dim3(1, b->R()), dim3(256), 0, h->cur, b->d_core.p, (int*)nullptr, h->n_islots, 2 * mode);   // 2: the kernel leaves the flag up
         if (!rc && hipEventRecord(h->ev0, h->cur) != hipSuccess) rc = 1;
         for (int r = 0; r < reps && !rc; r++) rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (!rc && hipEventRecord(h->ev1, h->cur) != hipSuccess) rc = 1;
         if (rc || hipEventSynchronize(h->ev1) != hipSuccess) { rc = 1; break; }
         hipEventElapsedTime(&ms[mode], h->ev0, h->ev1);
     }
-    // (the last timed launch pruned every list at these positions: the flags are down, nothing to restore)
+    if (dual && !rc) hipLaunchKernelGGL(k_prune_set, dim3(1, b->R()), dim3(256), 0, h->cur, b->d_core.p, (int*)nullptr, h->n_islots, 0);   // (the last launch pruned every list at these positions)
     b->lockstep = false;
     for (BluesEngine* m : b->eng) m->lists_forced = false;
     if (rc) { b->err = "timing launch failed: " + h->err; batch_leave(b); return 1; }

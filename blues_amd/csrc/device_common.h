@@ -264,6 +264,21 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     v += __shfl_xor(v, 32, 64);
     return v;
 }
+// fp32 sum over the 64 lanes entirely on DPP, fixed order: quad xor 1, quad xor 2, row_half_mirror, row_mirror leave the sum of a
+// 16-lane row in each of its lanes; row_bcast15 adds row 0 into row 1 and row 2 into row 3, row_bcast31 adds row 1 into rows 2, 3:
+// lane 63 holds the total (one v_add_f32 with a DPP operand per level; the fp64 version above needs two moves and a 4-cycle add).
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_add_f(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp_f32(float v) {   // result valid in lane 63; readlane'd into every lane
+    v = dpp_add_f<0xB1, 0xF>(v);
+    v = dpp_add_f<0x4E, 0xF>(v);
+    v = dpp_add_f<0x141, 0xF>(v);
+    v = dpp_add_f<0x140, 0xF>(v);
+    v = dpp_add_f<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+    v = dpp_add_f<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ inline double seg_sum(double v, int width) {  // sum over aligned groups of `width` lanes (power of two)
     for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;

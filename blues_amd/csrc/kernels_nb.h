@@ -642,6 +642,8 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<
 // R = 256: with four waves per SIMD the kernel is bound by VALU issue of the pair body itself, ~62 instructions of which three
 // are transcendental.)
 #define NB_ATOM_U 12   // list entries per lane requested together (768 neighbours per round)
+#define NB_ATOM_UA 7   // ... of which this many unconditionally (448 neighbours: the typical pruned list)
+#define NB_ATOM_G 4    // chunks per straight-line group of the pair loop (divides NB_ATOM_U)
 // Dual lists.  The atoms' lists (alist) are built with the full Verlet margin and are rebuilt rarely; a third of their entries
 // sit in the margin, and every one of them costs a full pair evaluation of all 64 lanes.  The kernel therefore walks PRUNED
 // lists (plist: the entries within cutoff + a small inner margin) and re-derives them itself, in passing and PER ATOM: the
@@ -664,24 +666,54 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
     if (t == 0 && tid == 0) { a.flags->list_gen = a.flags->req_gen; if (a.batch_req) *a.batch_req = 0; }  // lists are current for this pass
     if (t >= a.n_lists) return;
+    // Every pointer below arrives inside an argument record read from memory, i.e. as a GENERIC pointer: left like that, each
+    // access is a FLAT instruction (64-bit address pair per lane, and counted on LGKMCNT as well as VMCNT, which would tie the
+    // hand-counted LDS pipeline of the pair loop to the list prefetches).  They all point to global memory: say so.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define G1(T, p) ((__attribute__((address_space(1))) T*)(p))
+#else
+#define G1(T, p) ((T*)(p))   // (the host pass only parses this function)
+#endif
+    const auto g_alist = G1(const unsigned short, a.alist); const auto g_plist = G1(unsigned short, a.plist);
+    const auto g_acount = G1(const int, a.acount); const auto g_pcount = G1(int, a.pcount); const auto g_pneed = G1(int, a.pneed);
+    const auto g_tile_atoms = G1(const int, a.tile_atoms); const auto g_img = G1(const AtomF, img);
+    const auto g_fpart = G1(double, a.fpart); const auto g_flags = G1(DevFlags, a.flags);
+    const auto g_xprune0 = G1(unsigned, a.xprune[0]); const auto g_xprune1 = G1(unsigned, a.xprune[1]); const auto g_xprune2 = G1(unsigned, a.xprune[2]);
     const bool dual = a.plist != nullptr;
+    // (the pruned lists and their counts are addressed as offsets from the full ones: selecting between two POINTERS inside the
+    // lambdas below makes the optimiser keep the whole argument record in scratch memory)
+    const long plist_off = dual ? (long)(a.plist - a.alist) : 0L, pcount_off = dual ? (long)(a.pcount - a.acount) : 0L;   // (separate allocations: can be gigabytes apart)
     const int count = a.jcount[t];
     const int* jlst = a.jlist + (size_t)t * a.jcap;
     const int slot0 = t * a.S * 64, nslot = min(a.S, a.n_itiles - t * a.S) * 64;   // the i-slots this list serves
     // An atom's whole list is requested up front (NB_ATOM_U wave-loads of 64 entries, all in flight together) and ONE ATOM
     // AHEAD: the next atom's entries travel while the current atom is computed, the first atom's while the image is staged.
     // (With one load per iteration, or with all waves requesting and waiting in step, the list stream ran at HBM latency.)
+    // ... and so does the atom's own image record (asked for at the top of the atom's turn it was a memory round trip per atom)
     unsigned entn[NB_ATOM_U]; int cntn = 0, ian = -1; bool stalen = true;
+#pragma unroll
+    for (int u = 0; u < NB_ATOM_U; u++) entn[u] = 0u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); typedef float f32x2 __attribute__((ext_vector_type(2)));   // (plain vector types: loads through an address-space pointer stay loads)
+    unsigned pxn = 0u, pyn = 0u, pzn = 0u; float pqn = 0.0f, phsn = 0.0f, psen = 0.0f;
     auto request = [&](int s) {
         ian = -1; cntn = 0;
         if (s < nslot) {
-            ian = __builtin_amdgcn_readfirstlane(a.tile_atoms[slot0 + s]);
+            ian = __builtin_amdgcn_readfirstlane(g_tile_atoms[slot0 + s]);
             if (ian >= 0) {
-                stalen = !dual || __builtin_amdgcn_readfirstlane(a.pneed[slot0 + s]) != 0;
-                cntn = __builtin_amdgcn_readfirstlane((stalen ? a.acount : a.pcount)[slot0 + s]);
-                const unsigned short* lst = (stalen ? a.alist : a.plist) + (size_t)(slot0 + s) * a.acap;
+                pxn = g_img[ian].x; pyn = g_img[ian].y; pzn = g_img[ian].z; pqn = g_img[ian].q; phsn = g_img[ian].hs; psen = g_img[ian].se;
+                stalen = !dual || __builtin_amdgcn_readfirstlane(g_pneed[slot0 + s]) != 0;
+                cntn = __builtin_amdgcn_readfirstlane(g_acount[(long)(slot0 + s) + (stalen ? 0L : pcount_off)]);
+                const auto lst = g_alist + ((long)(slot0 + s) * a.acap + (stalen ? 0L : plist_off));
+                // the first NB_ATOM_UA chunks unconditionally (a pruned list is about that long), the others only for a longer list (one
+                // wave-uniform branch; a branch per chunk costs a dozen register copies each).  Loads may run past the count inside
+                // the atom's own row (acap >= 64 NB_ATOM_U, host): whatever lies there was a valid entry once, and the lane is
+                // masked when it is used
 #pragma unroll
-                for (int u = 0; u < NB_ATOM_U; u++) { const int q = u * 64 + lane; entn[u] = q < cntn ? (unsigned)lst[q] : 0u; }
+                for (int u = 0; u < NB_ATOM_UA; u++) entn[u] = (unsigned)lst[u * 64 + lane];
+                if (cntn > 64 * NB_ATOM_UA) {
+#pragma unroll
+                    for (int u = NB_ATOM_UA; u < NB_ATOM_U; u++) entn[u] = (unsigned)lst[u * 64 + lane];
+                }
             }
         }
     };
@@ -690,21 +722,22 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     NB_STAMP(t == 0 && tid == 0, 17);
     if (a.pimg4) {
         // packed image: a straight copy, every load of a thread in flight before its first LDS store; then the few mobile entries
-        const uint4* g4 = a.pimg4 + (size_t)t * a.jcap; const float2* g2 = a.pimg2 + (size_t)t * a.jcap;
+        const auto g4 = G1(const u32x4, a.pimg4) + (size_t)t * a.jcap; const auto g2 = G1(const f32x2, a.pimg2) + (size_t)t * a.jcap;
         constexpr int SU = 7;   // 7 x 1024 threads >= the largest list capacity whose image fits LDS
-        for (int base = 0; base < count; base += SU * 1024) {
-            uint4 r4[SU]; float2 r2[SU];
+        const int nthr = blockDim.x;
+        for (int base = 0; base < count; base += SU * nthr) {
+            u32x4 r4[SU]; f32x2 r2[SU];
 #pragma unroll
-            for (int u = 0; u < SU; u++) { const int k = base + u * 1024 + tid; if (k < count) { r4[u] = g4[k]; r2[u] = g2[k]; } }
+            for (int u = 0; u < SU; u++) { const int k = base + u * nthr + tid; if (k < count) { r4[u] = g4[k]; r2[u] = g2[k]; } }
 #pragma unroll
-            for (int u = 0; u < SU; u++) { const int k = base + u * 1024 + tid; if (k < count) { *reinterpret_cast<uint4*>(&lp[k]) = r4[u]; *reinterpret_cast<float2*>(&lq[k]) = r2[u]; } }
+            for (int u = 0; u < SU; u++) { const int k = base + u * nthr + tid; if (k < count) { *reinterpret_cast<u32x4*>(&lp[k]) = r4[u]; *reinterpret_cast<f32x2*>(&lq[k]) = r2[u]; } }
         }
         __syncthreads();
-        const int mc = a.mcount[t]; const int* ml = a.mlist + (size_t)t * a.mcap * 2;
-        for (int q = tid; q < mc; q += blockDim.x) { const int k = ml[2 * q], js = ml[2 * q + 1]; lp[k].x = img[js].x; lp[k].y = img[js].y; lp[k].z = img[js].z; }
+        const int mc = G1(const int, a.mcount)[t]; const auto ml = G1(const int, a.mlist) + (size_t)t * a.mcap * 2;
+        for (int q = tid; q < mc; q += blockDim.x) { const int k = ml[2 * q], js = ml[2 * q + 1]; lp[k].x = g_img[js].x; lp[k].y = g_img[js].y; lp[k].z = g_img[js].z; }
     } else {
         for (int k = tid; k < count; k += blockDim.x) {
-            const AtomF aj = img[jlst[k]];
+            const AtomF aj = g_img[G1(const int, jlst)[k]];
             P4 v4; v4.x = aj.x; v4.y = aj.y; v4.z = aj.z; v4.q = aj.q; lp[k] = v4;
             P2 v2; v2.hs = aj.hs; v2.se = aj.se; lq[k] = v2;
         }
@@ -720,22 +753,25 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         unsigned ent[NB_ATOM_U];
 #pragma unroll
         for (int u = 0; u < NB_ATOM_U; u++) ent[u] = entn[u];
+        const uint32_t ix = __builtin_amdgcn_readfirstlane(pxn), iy = __builtin_amdgcn_readfirstlane(pyn), iz = __builtin_amdgcn_readfirstlane(pzn);
+        const float iq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pqn)));
+        const float ihs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, phsn)));
+        const float ise = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, psen)));
         request(s + nw);
         if (ia < 0) continue;   // wave-uniform; empty slots are never read back (FinRec.atom < 0)
-        const uint32_t ix = __builtin_amdgcn_readfirstlane(img[ia].x), iy = __builtin_amdgcn_readfirstlane(img[ia].y), iz = __builtin_amdgcn_readfirstlane(img[ia].z);
-        const float iq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].q)));
-        const float ihs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].hs)));
-        const float ise = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, img[ia].se)));
         const bool pruning = !ENERGY && dual && stale;   // an energy evaluation reads whichever list is valid and writes none
-        const unsigned short* lst = (stale ? a.alist : a.plist) + (size_t)islot * a.acap;
-        unsigned short* const pout = pruning ? a.plist + (size_t)islot * a.acap : nullptr;
+        const auto lst = g_alist + ((long)islot * a.acap + (stale ? 0L : plist_off));
+        const auto pout = g_plist + (size_t)islot * a.acap;   // (written only when pruning)
         int pcnt = 0;   // survivors written so far (wave-uniform)
         double fx = 0.0, fy = 0.0, fz = 0.0;
         float bx = 0.0f, by = 0.0f, bz = 0.0f;
-        auto pair = [&](unsigned e, bool have, bool write) {
-            const unsigned idx = e & 0x7FFFu;   // (entries past the end of the list were requested as 0: a valid slot, masked by `have`)
-            const P4 bj = lp[idx];
-            const P2 bp = lq[idx];
+        auto fetch = [&](unsigned e, u32x4& q4, f32x2& q2) {
+            const unsigned idx = e & 0x7FFFu;
+            q4 = *reinterpret_cast<const u32x4*>(&lp[idx]); q2 = *reinterpret_cast<const f32x2*>(&lq[idx]);
+        };
+        auto pair = [&](unsigned e, const u32x4& q4, const f32x2& q2, bool have, bool write) {
+            P4 bj; bj.x = q4.x; bj.y = q4.y; bj.z = q4.z; bj.q = __uint_as_float(q4.w);
+            P2 bp; bp.hs = q2.x; bp.se = q2.y;
             const float dx = (float)(int32_t)(ix - bj.x) * c.scale[0];
             const float dy = (float)(int32_t)(iy - bj.y) * c.scale[1];
             const float dz = (float)(int32_t)(iz - bj.z) * c.scale[2];
@@ -755,42 +791,65 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
                 pcnt += __popcll(bal);
             }
         };
-        // the fp32 partials of a lane hold at most NB_ATOM_U pair terms before they are folded into fp64
-        if (!pruning) {
+        // The list is walked in straight-line groups of NB_ATOM_G chunks: all gathers of a group are issued before its first pair
+        // is computed (sched_group_barrier pins that order), so the LDS latency is paid once per group.  With one chunk per
+        // basic block the gather sat right in front of a s_waitcnt lgkmcnt(0), and with four waves per SIMD half of every wave's
+        // cycles went into that wait (gathers issued across a branch are sunk back to their first use by the optimiser).
+        // The fp32 partials of a lane hold at most NB_ATOM_U pair terms before they are folded.
+        const int nch = __builtin_amdgcn_readfirstlane((cnt + 63) >> 6);   // wave-uniform (and known to be: scalar branches below)
+        auto walk = [&](auto write_tag) {
+            constexpr bool W = decltype(write_tag)::value;
 #pragma unroll
-            for (int u = 0; u < NB_ATOM_U; u++) {
-                if (u * 64 >= cnt) break;   // wave-uniform
-                pair(ent[u], u * 64 + lane < cnt, false);
+            for (int u0 = 0; u0 < NB_ATOM_U; u0 += NB_ATOM_G) {
+                if (u0 >= nch) break;   // wave-uniform (scalar branch)
+                if (u0 + NB_ATOM_G <= nch) {
+                    u32x4 q4[NB_ATOM_G]; f32x2 q2[NB_ATOM_G];
+#pragma unroll
+                    for (int g = 0; g < NB_ATOM_G; g++) fetch(ent[u0 + g], q4[g], q2[g]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB_ATOM_G, 0);   // the DS reads first
+#pragma unroll
+                    for (int g = 0; g < NB_ATOM_G; g++) pair(ent[u0 + g], q4[g], q2[g], (u0 + g) * 64 + lane < cnt, W);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < NB_ATOM_G - 1; g++) {
+                        if (u0 + g >= nch) break;
+                        u32x4 q4; f32x2 q2;
+                        fetch(ent[u0 + g], q4, q2);
+                        pair(ent[u0 + g], q4, q2, (u0 + g) * 64 + lane < cnt, W);
+                    }
+                }
             }
             for (int base = 64 * NB_ATOM_U; base < cnt; base += 64) {   // lists longer than the prefetch window (dense regions)
                 const bool have = base + lane < cnt;
-                pair(have ? (unsigned)lst[base + lane] : 0u, have, false);
+                const unsigned e = have ? (unsigned)lst[base + lane] : 0u;
+                u32x4 q4; f32x2 q2;
+                fetch(e, q4, q2);
+                pair(e, q4, q2, have, W);
                 fx += (double)bx; fy += (double)by; fz += (double)bz; bx = by = bz = 0.0f;
             }
-        } else {
-#pragma unroll
-            for (int u = 0; u < NB_ATOM_U; u++) {
-                if (u * 64 >= cnt) break;
-                pair(ent[u], u * 64 + lane < cnt, true);
-            }
-            for (int base = 64 * NB_ATOM_U; base < cnt; base += 64) {
-                const bool have = base + lane < cnt;
-                pair(have ? (unsigned)lst[base + lane] : 0u, have, true);
-                fx += (double)bx; fy += (double)by; fz += (double)bz; bx = by = bz = 0.0f;
-            }
+        };
+        if (!pruning) walk(std::false_type{});
+        else {
+            walk(std::true_type{});
             if (lane == 0) {
-                a.pcount[islot] = pcnt;   // (a subset of a list that fits acap)
-                a.xprune[0][islot] = ix; a.xprune[1][islot] = iy; a.xprune[2][islot] = iz;
-                a.pneed[islot] = 0;       // (this wave is the only reader of the flag in this launch; the integrator sets it in a later one)
-                atomicAdd(&a.flags->prunes, 1);
+                g_pcount[islot] = pcnt;   // (a subset of a list that fits acap)
+                g_xprune0[islot] = ix; g_xprune1[islot] = iy; g_xprune2[islot] = iz;
+                if (g_pneed[islot] == 1) g_pneed[islot] = 0;   // (this wave is the only reader of the flag in this launch; the integrator sets it in a later one; 2 = kept up by the timing harness)
+                __hip_atomic_fetch_add(&g_flags->prunes, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         NB_STAMP(t == 0 && tid == 0, 20 + min(2 * (s / nw), 6));
-        fx += (double)bx; fy += (double)by; fz += (double)bz;
-        fx = wave_sum_dpp(fx); fy = wave_sum_dpp(fy); fz = wave_sum_dpp(fz);
-        if (lane == 0) { a.fpart[islot] = fx; a.fpart[a.n_islots + islot] = fy; a.fpart[2 * a.n_islots + islot] = fz; }
+        // 64 lanes -> one force: fp32 on DPP, fixed order (bitwise reproducible).  A lane's partial is a few pair terms of at
+        // most ~10^3 kJ/mol/nm; six levels of fp32 adds put ~10^-3 kJ/mol/nm on a force of that size, the rounding the
+        // per-lane fp32 accumulation carries anyway (tolerance: 10^-5 of the largest force, ~2 10^-2).  Lists past the
+        // prefetch window were folded into fp64 per chunk above.
+        const float sx = wave_sum_dpp_f32(bx), sy = wave_sum_dpp_f32(by), sz = wave_sum_dpp_f32(bz);
+        if (cnt > 64 * NB_ATOM_U) { fx = wave_sum_dpp(fx); fy = wave_sum_dpp(fy); fz = wave_sum_dpp(fz); }   // (wave-uniform; otherwise they are zero)
+        fx += (double)sx; fy += (double)sy; fz += (double)sz;
+        if (lane == 0) { g_fpart[islot] = fx; g_fpart[a.n_islots + islot] = fy; g_fpart[2 * a.n_islots + islot] = fz; }
         NB_STAMP(t == 0 && tid == 0, 21 + min(2 * (s / nw), 6));
     }
+#undef G1
     if (ENERGY) {
         elj = wave_sum(elj); ecl = wave_sum(ecl);
         if (lane == 0) { s_e[wv][0] = elj; s_e[wv][1] = ecl; }

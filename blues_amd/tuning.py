@@ -13,7 +13,7 @@ import os
 
 from . import _abi, _lib
 
-FIELDS = tuple(name for name, _ in _abi.BluesTuning._fields_ if name not in ("struct_size", "reserved"))
+FIELDS = tuple(name for name, _ in _abi.BluesTuning._fields_ if name != "struct_size")
 
 
 def defaults():

@@ -192,7 +192,7 @@ typedef struct BluesTuning {
     int32_t assume_batch;      /* > 0: a lone engine lays itself out as a member of a batch of this many would (the decomposition
                                 * depends on how many chains share a launch): what makes "a batch member equals the same
                                 * chain advanced alone, bit for bit" testable */
-    int32_t reserved;
+    int32_t k1_threads;        /* threads per workgroup of the per-atom-list kernel (multiple of 64, <= 1024); 0: 1024 */
 } BluesTuning;
 void blues_tuning_default(BluesTuning *t);
 /* NULL restores the defaults.  Applies to engines and batches created afterwards. */
