@@ -834,7 +834,8 @@ static ListArgs make_list_args(BluesEngine* h) {
     a.alch_jrec = h->alch.empty() ? nullptr : (void*)h->d_jrec.p; a.p_sigma = h->d_sigma.p; a.p_eps = h->d_eps.p; a.p_charge = h->d_charge.p;
     if (h->k1_mode == 2) { a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap; }
     a.S = h->S; a.n_lists = h->n_lists; a.hint_count = h->hint_count; a.no_sphere = h->tune.no_sphere;
-    if (h->k1_mode == 2 && h->prune_on) { a.pneed = h->d_pneed.p; a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap; }
+    if (h->k1_mode == 2 && h->prune_on) { a.pneed = h->d_pneed.p; a.plist = h->d_plist.p; a.pcount = h->d_pcount.p; for (int k = 0; k < 3; k++) a.xprune[k] = h->d_xprune[k].p;
+        a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap; }
     return a;
 }
 
@@ -2881,7 +2882,7 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
         BluesEngine* m = engines[r];
         if (flush_program(m) || hipStreamSynchronize(m->stream) != hipSuccess) { g_batch_create_error = "could not drain engine stream: " + m->err; batch_detach_all(B); delete B; return 1; }
         B->eng.push_back(m); m->batch = B; m->batch_index = r;
-        m->batch_R = count;
+        m->batch_R = std::max((int)count, m->tune.assume_batch);   // (assume_batch: a floor, so that small test batches take the large-batch decomposition too)
         m->use_graph = false;  // graph replays carry per-engine frozen arguments
     }
     if (batch_plan_shape(B, true)) { g_batch_create_error = B->err; batch_detach_all(B); delete B; return 1; }

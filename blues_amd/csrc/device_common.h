@@ -239,6 +239,16 @@ __device__ __forceinline__ void softcore_lj3_fast_d(double r2, double sig, doubl
     }
 }
 
+// the same at one lambda (all three slots carry the same lambda_sterics)
+__device__ __forceinline__ void softcore_lj1_fast_d(double r2, double sig, double eps, double ls, double sc_alpha, double* e, double* fs) {
+    if (eps == 0.0 || sig == 0.0) { *e = 0.0; *fs = 0.0; return; }
+    const double inv_s2 = rcp_fast_d(sig * sig), q2 = r2 * inv_s2, q4 = q2 * q2, q6 = q4 * q2;
+    const double g = 24.0 * eps * q4 * inv_s2;
+    const double x = rcp_fast_d(sc_alpha * (1.0 - ls) + q6);
+    *e = ls * 4.0 * eps * x * (x - 1.0);
+    *fs = ls * g * (2.0 * x - 1.0) * x * x;
+}
+
 __device__ inline double min_image_d(double d, double L, double invL) { return d - L * rint(d * invL); }
 
 // wave64 reductions
@@ -280,6 +290,10 @@ __device__ __forceinline__ float wave_sum_dpp_f32(float v) {   // result valid i
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ inline double seg_sum(double v, int width) {  // sum over aligned groups of `width` lanes (power of two)
+    for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ inline float seg_sum(float v, int width) {
     for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }

@@ -83,29 +83,43 @@ __device__ __forceinline__ bool alchemical_body(AlchArgs& A, const int block_id)
     __shared__ double s_self[4][9][64];
     __shared__ double s_e[4][K2_NE];
     __shared__ double s_exc[9][256];   // self block: exception rows; env blocks: the block's j records and positions (K2_STAGE entries)
-    double f[3][3];  // [slot][xyz] force on the alchemical atom from this pair
+    // Force arithmetic of the env blocks: fp32 in the mixed mode (FAST) -- the force scale of a pair is formed in fp64 with its
+    // energy and rounded once; its three components, the sum over the alchemical lanes (force on j) and the running sum over
+    // this thread's j's (force on a) are fp32; block partials are fp64 again.  The ENERGIES -- the protocol work -- stay fp64
+    // throughout.  Half the live registers of the loop were these fp64 force values.
+    using FT = typename std::conditional<FAST, float, double>::type;
+    FT f[3][3];  // [slot][xyz] force on the alchemical atom from this pair
 #pragma unroll
-    for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = 0.0; }
+    for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = (FT)0; }
     double e[K2_NE];
 #pragma unroll
     for (int q = 0; q < K2_NE; q++) e[q] = 0.0;
 
     const bool env_block = block_id < A.nblocks_env;
+    const bool no_elec = A.le[0] == 0.0 && A.le[1] == 0.0 && A.le[2] == 0.0, same_ls = A.ls[0] == A.ls[1] && A.ls[1] == A.ls[2];   // (uniform)
     bool wave_hit = true;
     if (env_block) {
         // An env block covers A.jiter groups of 256/PA consecutive j's; a thread keeps its alchemical atom a and walks one
         // j per group.  The force on j is reduced over the PA lanes per group; the force on a and the energies accumulate
         // in registers across the groups and are reduced once per block.
-        const int count = *A.jcount;
+        // (the record's pointers are generic; they all point to global memory: FLAT accesses cost an address pair per lane)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define G1(T, p) ((__attribute__((address_space(1))) T*)(p))
+#else
+#define G1(T, p) ((T*)(p))
+#endif
+        const auto g_fJ = G1(double, A.fJ); const auto g_jrec = G1(const AlchJRec, A.jrec); const auto g_arec = G1(const AlchARec, A.arec);
+        const auto g_x0 = G1(const double, A.x[0]); const auto g_x1 = G1(const double, A.x[1]); const auto g_x2 = G1(const double, A.x[2]);
+        const int count = *G1(const int, A.jcount);
         const int jpg = 256 / PA, j0 = block_id * jpg * A.jiter;
         if (j0 >= count) return false;  // nothing to do; finalize sums only the used blocks
         AlchARec Ar; Ar.ao = 0; Ar.asrt = 0; Ar.has_env_excl = 0; Ar.sig = Ar.eps = Ar.q = 0.0;
-        if (a < A.n_alch) Ar = A.arec[a];
+        if (a < A.n_alch) { Ar.ao = g_arec[a].ao; Ar.asrt = g_arec[a].asrt; Ar.has_env_excl = g_arec[a].has_env_excl; Ar.sig = g_arec[a].sig; Ar.eps = g_arec[a].eps; Ar.q = g_arec[a].q; }
         double xa[3] = {0.0, 0.0, 0.0};
-        if (a < A.n_alch) for (int k = 0; k < 3; k++) xa[k] = A.x[k][Ar.ao];
-        double fa[3][3];
+        if (a < A.n_alch) { xa[0] = g_x0[Ar.ao]; xa[1] = g_x1[Ar.ao]; xa[2] = g_x2[Ar.ao]; }
+        FT fa[3][3];
 #pragma unroll
-        for (int s = 0; s < 3; s++) { fa[s][0] = fa[s][1] = fa[s][2] = 0.0; }
+        for (int s = 0; s < 3; s++) { fa[s][0] = fa[s][1] = fa[s][2] = (FT)0; }
         wave_hit = false;
         // The block's j records and their positions are staged in LDS by one round of loads (record -> position: two dependent
         // memory round trips per BLOCK; read per pair they were two per iteration, and with three waves per SIMD the kernel
@@ -116,10 +130,9 @@ __device__ __forceinline__ bool alchemical_body(AlchArgs& A, const int block_id)
         {
             const int nstage = min(jpg * A.jiter, count - j0);
             if (tid < nstage) {
-                const AlchJRec J = A.jrec[j0 + tid];
-                st_jsrt[tid] = J.jsrt; st_jo[tid] = J.jo; st_sig[tid] = J.sig; st_eps[tid] = J.eps; st_q[tid] = J.q;
-#pragma unroll
-                for (int k = 0; k < 3; k++) st_x[k * K2_STAGE + tid] = A.x[k][J.jo];
+                const int jo = g_jrec[j0 + tid].jo;
+                st_jsrt[tid] = g_jrec[j0 + tid].jsrt; st_jo[tid] = jo; st_sig[tid] = g_jrec[j0 + tid].sig; st_eps[tid] = g_jrec[j0 + tid].eps; st_q[tid] = g_jrec[j0 + tid].q;
+                st_x[tid] = g_x0[jo]; st_x[K2_STAGE + tid] = g_x1[jo]; st_x[2 * K2_STAGE + tid] = g_x2[jo];
             }
             __syncthreads();
         }
@@ -132,7 +145,7 @@ __device__ __forceinline__ bool alchemical_body(AlchArgs& A, const int block_id)
             bool hit = false;  // this lane holds a pair term
             bool j_mobile = false;
 #pragma unroll
-            for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = 0.0; }
+            for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = (FT)0; }
             if (valid) {
                 AlchJRec J; J.jsrt = st_jsrt[sl]; J.jo = st_jo[sl]; J.sig = st_sig[sl]; J.eps = st_eps[sl]; J.q = st_q[sl];
                 jsrt = J.jsrt & 0x3fffffff; j_mobile = (J.jsrt >> 30) & 1;
@@ -147,15 +160,21 @@ __device__ __forceinline__ bool alchemical_body(AlchArgs& A, const int block_id)
                     double fc;
                     hit = true;
                     if (FAST && A.pme) {
-                        e[0] += coulomb_fast_d(r2, qq, A.alpha, &fc);
+                        // Two things the schedule makes common (reference blues/simulation.py:654-659: sterics move only for
+                        // 0.2 < lambda < 0.8, electrostatics only outside) are checked on the actual slot values, not assumed:
+                        // with lambda_electrostatics = 0 in every slot the Coulomb sum multiplies zeros (energy le * C, force
+                        // le * fc) and is skipped; with one lambda_sterics in all slots the softcore term is evaluated once.
+                        fc = 0.0;
+                        if (!no_elec) e[0] += coulomb_fast_d(r2, qq, A.alpha, &fc);
                         double es[3], fs3[3];
-                        softcore_lj3_fast_d(r2, sig, eps, A.ls, A.sc_alpha, es, fs3);
+                        if (same_ls) { softcore_lj1_fast_d(r2, sig, eps, A.ls[0], A.sc_alpha, &es[0], &fs3[0]); es[1] = es[2] = es[0]; fs3[1] = fs3[2] = fs3[0]; }
+                        else softcore_lj3_fast_d(r2, sig, eps, A.ls, A.sc_alpha, es, fs3);
 #pragma unroll
                         for (int s = 0; s < 3; s++) {
                             e[1 + s] += es[s];
                             if (MASK >= 0 && !((MASK >> s) & 1)) continue;
-                            const double ft = fs3[s] + A.le[s] * fc;
-                            f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                            const FT ft = (FT)(fs3[s] + A.le[s] * fc);
+                            f[s][0] = ft * (FT)d[0]; f[s][1] = ft * (FT)d[1]; f[s][2] = ft * (FT)d[2];
                         }
                     } else {
                         e[0] += coulomb_d(r2, qq, A.alpha, A.pme != 0, &fc);
@@ -164,7 +183,7 @@ __device__ __forceinline__ bool alchemical_body(AlchArgs& A, const int block_id)
                             double fs;
                             e[1 + s] += softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
                             const double ft = fs + A.le[s] * fc;
-                            f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                            f[s][0] = (FT)(ft * d[0]); f[s][1] = (FT)(ft * d[1]); f[s][2] = (FT)(ft * d[2]);
                         }
                     }
                 } else if (excl) {
@@ -183,7 +202,7 @@ __device__ __forceinline__ bool alchemical_body(AlchArgs& A, const int block_id)
                             double fs;
                             e[1 + s] += softcore_lj_d(r2, sig, eps, A.ls[s], A.sc_alpha, &fs);
                             const double ft = fs + A.le[s] * fc;
-                            f[s][0] = ft * d[0]; f[s][1] = ft * d[1]; f[s][2] = ft * d[2];
+                            f[s][0] = (FT)(ft * d[0]); f[s][1] = (FT)(ft * d[1]); f[s][2] = (FT)(ft * d[2]);
                         }
                     }
                 }
@@ -200,14 +219,15 @@ __device__ __forceinline__ bool alchemical_body(AlchArgs& A, const int block_id)
                 if (!slot_on(s)) continue;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const double fj = group_fj ? seg_sum(f[s][k], PA) : 0.0;
-                    if (a == 0 && j_mobile) A.fJ[(size_t)(s * 3 + k) * A.n + jsrt] = -fj;
+                    const FT fj = group_fj ? seg_sum(f[s][k], PA) : (FT)0;
+                    if (a == 0 && j_mobile) g_fJ[(size_t)(s * 3 + k) * A.n + jsrt] = -(double)fj;
                     fa[s][k] += f[s][k];
                 }
             }
         }
 #pragma unroll
         for (int s = 0; s < 3; s++) { f[s][0] = fa[s][0]; f[s][1] = fa[s][1]; f[s][2] = fa[s][2]; }
+#undef G1
     } else {
         // ---- alchemical x alchemical pairs: thread (a2, b) with b fastest
         const int rows_per_iter = 256 / PA;
@@ -307,12 +327,12 @@ __device__ __forceinline__ bool alchemical_body(AlchArgs& A, const int block_id)
         for (int s = 0; s < 3; s++)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                double v = 0.0;
+                FT v = (FT)0;
                 if (slot_on(s)) {   // a slot whose force nobody applies is not reduced (its energy still is)
                     v = f[s][k];
                     for (int off = PA; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
                 }
-                if (lane < PA) s_self[wv][s * 3 + k][lane] = v;
+                if (lane < PA) s_self[wv][s * 3 + k][lane] = (double)v;
             }
 #pragma unroll
         for (int q = 0; q < K2_NE; q++) e[q] = wave_sum(e[q]);

@@ -59,7 +59,9 @@ struct ListArgs {
     int no_sphere;           // development: bounding-box test only
     int hint_count;          // a list longer than this raises resort_hint (the i-atoms have spread: re-derive the layout)
     int S, n_lists;          // S consecutive i-tiles share one j-list (1 in the bitmask modes); n_lists = ceil(n_itiles / S), the alchemical tile's list comes after them
-    int* pneed;              // [n_islots] pruned-list mode: 1 = this atom's pruned list is stale (set here for every atom of a rebuilt list)
+    // pruned-list mode (NbArgs; null: none): the atom-list build writes every atom's pruned list along with the full one -- it
+    // has the distances at hand -- so a rebuild leaves nothing for the nonbonded kernel to re-derive
+    int* pneed; unsigned short* plist; int* pcount; unsigned* xprune[3];
     // packed image of every group list (null: not kept): the list's atoms as the nonbonded kernel stages them, {x,y,z,q} and
     // {sigma/2, 2 sqrt(eps)}, written when the list is built -- frozen atoms never change, so the kernel copies it with
     // coalesced loads and refreshes only the MOBILE entries (mlist: pairs (list position, image index)) from the live image
@@ -387,10 +389,12 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
         exn4[u] = __builtin_amdgcn_readfirstlane(min(s_exn[slot], EXK_MAX)); exlo4[u] = __builtin_amdgcn_readfirstlane(s_exlo[slot]); exhi4[u] = __builtin_amdgcn_readfirstlane(s_exhi[slot]);
     }
     NB_STAMP(t == 0 && tid == 0, 7);
-    int cntv[4] = {0, 0, 0, 0};
-    unsigned short* out4[4];
+    int cntv[4] = {0, 0, 0, 0}, cntp[4] = {0, 0, 0, 0};
+    unsigned short* out4[4]; unsigned short* outp4[4];
+    const bool dual = a.plist != nullptr;
+    const float rp2 = c.rp2 * 1.0001f + 1e-5f, rp2m = c.rp2_m * 1.0001f + 1e-5f;   // (float distances relative to the tile: same safety margin as the full lists)
 #pragma unroll
-    for (int u = 0; u < 4; u++) out4[u] = a.alist + ((size_t)t * 64 + wv + LIST_WAVES * u) * a.acap;
+    for (int u = 0; u < 4; u++) { out4[u] = a.alist + ((size_t)t * 64 + wv + LIST_WAVES * u) * a.acap; outp4[u] = dual ? a.plist + ((size_t)t * 64 + wv + LIST_WAVES * u) * a.acap : nullptr; }
     const float INF = __builtin_inff();
     const int acap1 = a.acap - 1;
     // both positions are relative to the tile's first atom (each one a minimum image OF THAT ATOM): their difference is the
@@ -403,7 +407,7 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
         const bool mob = (s_jm[kk] & 0x40000000) != 0;
         const unsigned short ent = (unsigned short)(k | (mob ? 0x8000 : 0));
         const float kinf = k < count ? 0.0f : INF;
-        const float lim = mob ? rl2m : rl2;
+        const float lim = mob ? rl2m : rl2, plim = mob ? rp2m : rp2;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             bool excluded = false;
@@ -426,13 +430,27 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
             asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c2) : "s"(blo), "s"(bhi), "v"(cntv[u]));
             cntv[u] = c2;
             if (pass) out4[u][min(pos, acap1)] = ent;   // on overflow (flagged below) the surplus lands on the last entry
+            if (dual) {   // (block-uniform) the pruned list: the same entries within cutoff + inner margin, same order
+                const bool keep = pass && d2 < plim;
+                const unsigned long long bk = __ballot(keep);
+                const unsigned klo = (unsigned)bk, khi = (unsigned)(bk >> 32);
+                const int ppos = cntp[u] + (int)__builtin_amdgcn_mbcnt_hi(khi, __builtin_amdgcn_mbcnt_lo(klo, 0u));
+                int c3;
+                asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c3) : "s"(klo), "s"(khi), "v"(cntp[u]));
+                cntp[u] = c3;
+                if (keep) outp4[u][min(ppos, acap1)] = ent;
+            }
         }
     }
     NB_STAMP(t == 0 && tid == 0, 8);
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         if (lane == 0) {
-            if (a.pneed) a.pneed[t * 64 + wv + LIST_WAVES * u] = 1;   // new full list: the pruned one is stale
+            if (dual) {   // the pruned list is current as of these positions
+                const int sl = t * 64 + wv + LIST_WAVES * u, iq = ia4[u] >= 0 ? ia4[u] : 0;
+                a.pcount[sl] = min(cntp[u], a.acap); a.pneed[sl] = 0;
+                a.xprune[0][sl] = (unsigned)img[iq].x; a.xprune[1][sl] = (unsigned)img[iq].y; a.xprune[2][sl] = (unsigned)img[iq].z;
+            }
             a.acount[t * 64 + wv + LIST_WAVES * u] = min(cntv[u], a.acap);
             if (cntv[u] > a.acap) a.flags->list_overflow = 1;
             else if (cntv[u] > a.acap - a.acap / 8) a.flags->resort_hint = 1;   // (a re-sort re-derives the capacities)
@@ -717,6 +735,12 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
             }
         }
     };
+    // Atoms are handed to the waves on demand (an LDS counter): lists differ in length, an atom that re-derives its pruned
+    // list costs half as much again, and a static deal left the workgroup waiting for its unluckiest wave.  An atom's force
+    // is computed by one wave in a fixed order whoever takes it: the assignment does not touch the result.
+    __shared__ int s_next;
+    if (tid == 0) s_next = nw;   // (the first nw atoms are dealt statically; the barrier behind the image staging publishes this)
+    auto grab = [&]() -> int { int v = 0; if (lane == 0) v = atomicAdd(&s_next, 1); return __builtin_amdgcn_readfirstlane(v); };
     NB_STAMP(t == 0 && tid == 0, 16);
     request(wv);
     NB_STAMP(t == 0 && tid == 0, 17);
@@ -746,7 +770,9 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     __syncthreads();
     NB_STAMP(t == 0 && tid == 0, 19);
     double elj = 0.0, ecl = 0.0;
-    for (int s = wv; s < nslot; s += nw) {
+    int s_nxt = wv;
+    while (s_nxt < nslot) {
+        const int s = s_nxt;
         const int islot = slot0 + s;
         const int ia = ian, cnt = cntn;
         const bool stale = stalen;
@@ -757,7 +783,8 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         const float iq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pqn)));
         const float ihs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, phsn)));
         const float ise = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, psen)));
-        request(s + nw);
+        s_nxt = grab();
+        request(s_nxt);
         if (ia < 0) continue;   // wave-uniform; empty slots are never read back (FinRec.atom < 0)
         const bool pruning = !ENERGY && dual && stale;   // an energy evaluation reads whichever list is valid and writes none
         const auto lst = g_alist + ((long)islot * a.acap + (stale ? 0L : plist_off));
