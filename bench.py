@@ -98,22 +98,33 @@ def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
     def sync(r, c):
         c.currentIter = it
         c._syncStatesMDtoNCMC()
+    fast = driver is not None and driver._batchable()   # the plugin boundary for all chains at once (simulation.py)
     t0 = time.perf_counter()
-    each(hand_over)
-    if driver is not None:
-        driver._ncmc_batch.prefetch_energies(at_lambda_one=True)
-    each(sync)
+    if fast:
+        driver._restore_states(states)
+        for c in chains:
+            c.currentIter = it
+        driver._sync_batched()
+    else:
+        each(hand_over)
+        if driver is not None:
+            driver._ncmc_batch.prefetch_energies(at_lambda_one=True)
+        each(sync)
     t1 = time.perf_counter()
     if driver is None:
         chains[0]._stepNCMC(nsteps, nsteps // 2)
     else:
         driver._stepNCMC(nsteps, nsteps // 2)
     t2 = time.perf_counter()
-    each(lambda r, c: c._acceptRejectMove())
+    if fast:
+        driver._decide_batched(300.0)
+    else:
+        each(lambda r, c: c._acceptRejectMove())
     recs = np.array([[c.last["accept"], it, c.last["log_accept"], c.last["protocol_work"], c.last["correction"]] for c in chains], dtype=np.float64)
     if gather:
         recs = gather_decision_block(recs)
-    each(lambda r, c: c._resetSimulations(300.0))
+    if not fast:
+        each(lambda r, c: c._resetSimulations(300.0))
     t3 = time.perf_counter()
     clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2
     return recs

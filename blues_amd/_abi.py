@@ -271,6 +271,12 @@ def declare_engine_prototypes(lib):
         "blues_batch_step": ([H, C.c_int32, _dp, C.POINTER(C.c_int32)], C.c_int),
         "blues_batch_set_active": ([H, C.POINTER(C.c_int32)], C.c_int),
         "blues_batch_prefetch_energies": ([H, C.c_int32], C.c_int),
+        "blues_batch_snapshot_capture": ([H, C.c_int32, C.POINTER(C.c_int32), C.POINTER(H)], C.c_int),
+        "blues_batch_restore": ([H, C.POINTER(H), C.c_int32], C.c_int),
+        "blues_batch_restore_edited": ([H, C.POINTER(H), C.POINTER(C.c_int32), C.c_int32, _dp], C.c_int),
+        "blues_batch_read_atoms": ([H, C.POINTER(H), C.c_int32, C.POINTER(C.c_int32), C.c_int32, _dp], C.c_int),
+        "blues_batch_reset": ([H, C.POINTER(C.c_int32)], C.c_int),
+        "blues_batch_set_velocities_to_temperature": ([H, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)], C.c_int),
         "blues_batch_get_stats": ([H, C.POINTER(C.c_int64)], C.c_int),
         "blues_batch_time_nonbonded": ([H, C.c_int32, _dp], C.c_int),
         "blues_batch_time_nonbonded_modes": ([H, C.c_int32, _dp, _dp], C.c_int),
@@ -292,5 +298,7 @@ ENGINE_SYMBOLS = (
     "blues_snapshot_capture", "blues_snapshot_release", "blues_snapshot_read", "blues_set_positions_from_snapshot",
     "blues_set_velocities_from_snapshot", "blues_snapshot_read_atoms", "blues_set_positions_from_snapshot_edited",
     "blues_batch_create", "blues_batch_destroy", "blues_batch_last_error", "blues_batch_size", "blues_batch_step", "blues_batch_set_active", "blues_batch_prefetch_energies",
+    "blues_batch_snapshot_capture", "blues_batch_restore", "blues_batch_restore_edited", "blues_batch_read_atoms", "blues_batch_reset",
+    "blues_batch_set_velocities_to_temperature",
     "blues_batch_get_stats", "blues_batch_time_nonbonded", "blues_batch_time_nonbonded_modes",
 )

@@ -170,6 +170,7 @@ struct BluesEngine {
     // setPositions' 16-byte verdict (frozen atom changed / how far the i-atoms are from their sort positions) is read back lazily:
     // the copy into pinned memory is queued with the load and looked at by the next evaluation (resolve_xfer)
     unsigned* h_xfer = nullptr; bool xfer_pending = false; hipStream_t xfer_stream = nullptr;
+    const unsigned* xfer_src = nullptr;   // where the pending verdict will be found: h_xfer, or this member's slot of a batch-wide read-back
     hipEvent_t ev_edit = nullptr;                             // recorded after the last copy OUT of the pinned staging area
     unsigned char* h_edit = nullptr; size_t h_edit_cap = 0;   // pinned staging of a Move's edited atoms and of read-backs of a few atoms
     std::vector<int> edit_idx_host;                           // what d_edit_idx holds (a Move asks for the same atoms every time)
@@ -261,6 +262,9 @@ struct BluesBatch {
     // as one rebuild whoever asks; when they all rebuild together (any request rebuilds all) most steps see no rebuild at all
     DBuf<int> d_req; bool sync_lists = false;
     BluesTuning tune;   // the process-wide tuning at the time the batch was created
+    // argument arena of the batched boundary calls (blues_batch_capture ...): pinned host side, device side, one upload per call
+    unsigned char* h_arena = nullptr; size_t arena_cap = 0; DBuf<unsigned char> d_arena;
+    unsigned* h_xfer_all = nullptr; DBuf<unsigned> d_xfer_all;   // [R][4] verdicts of a batched setPositions
     // Members keep their own streams for everything that is per replica (moves, state exchange, energies) so that host
     // threads serving different chains overlap; stepping runs on the batch's stream.  enter: the batch stream waits for
     // each member's pending work and the members issue into it; leave: the batch stream is drained, members go home.
@@ -1266,7 +1270,7 @@ static int resolve_xfer(BluesEngine* h) {
     if (!h->xfer_pending) return 0;
     h->xfer_pending = false;
     HIP_OK(h, hipStreamSynchronize(h->xfer_stream));
-    const unsigned* out = h->h_xfer;
+    const unsigned* out = h->xfer_src ? h->xfer_src : h->h_xfer;
     if (out[0]) { h->e_frozen_valid = false; h->pme_static_valid = false; }
     float worst; memcpy(&worst, &out[1], sizeof worst);
     // tiles are formed from the mobile non-alchemical atoms.  A few wandering i-atoms only stretch their tile's bounding
@@ -2333,7 +2337,7 @@ static int load_positions(BluesEngine* h, const double* const src[3], int stride
     }
     if (!h->h_xfer && hipHostMalloc((void**)&h->h_xfer, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) E_FAIL(h, "hipHostMalloc failed");
     HIP_OK(h, hipMemcpyAsync(h->h_xfer, h->d_xfer_out.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-    h->xfer_pending = true; h->xfer_stream = h->stream;
+    h->xfer_pending = true; h->xfer_stream = h->stream; h->xfer_src = h->h_xfer;
     h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear();
     h->lists_forced = true;
     return 0;
@@ -2900,7 +2904,10 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
 int blues_batch_destroy(BluesBatch* b) {
     if (!b) return 0;
     if (!b->eng.empty()) hipSetDevice(b->eng[0]->device);
+    for (BluesEngine* m : b->eng) if (m && m->xfer_pending && m->xfer_src != m->h_xfer) resolve_xfer(m);   // (a verdict parked in the batch's buffer)
     batch_detach_all(b);
+    if (b->h_arena) { hipHostFree(b->h_arena); b->h_arena = nullptr; }
+    if (b->h_xfer_all) { hipHostFree(b->h_xfer_all); b->h_xfer_all = nullptr; }
     delete b;
     return 0;
 }
@@ -2947,6 +2954,269 @@ int blues_batch_get_stats(BluesBatch* b, int64_t stats[4]) {
 }
 
 // average duration of one batched nonbonded launch (all replicas), HIP events on the batch's stream
+// ---- the plugin boundary for a whole batch.  BLUES takes and hands back whole States of every chain three times per
+// iteration, a Move reads and writes a few atoms of each, and the Metropolis step resets every integrator and redraws every
+// chain's velocities (reference blues/simulation.py:1028-1187).  Chain by chain that is ~60 C-ABI calls and ~25 small launches
+// per chain and iteration; the entry points below do one thing for ALL members with one launch per kernel: the host part of the
+// per-member entry point runs in a loop, the kernel arguments of the members travel as an array.
+static int batch_arena(BluesBatch* B, size_t bytes) {
+    if (B->arena_cap >= bytes) return 0;
+    if (B->h_arena) { hipStreamSynchronize(B->stream); hipHostFree(B->h_arena); B->h_arena = nullptr; B->arena_cap = 0; }
+    const size_t cap = std::max<size_t>(bytes * 2, 1 << 16);
+    if (hipHostMalloc((void**)&B->h_arena, cap, hipHostMallocDefault) != hipSuccess) { B->err = "hipHostMalloc failed"; return 1; }
+    try { B->d_arena.alloc(cap); } catch (std::string& e) { B->err = e; return 1; }
+    B->arena_cap = cap;
+    return 0;
+}
+static int batch_arena_upload(BluesBatch* B, size_t bytes) {
+    if (hipMemcpyAsync(B->d_arena.p, B->h_arena, bytes, hipMemcpyHostToDevice, B->stream) != hipSuccess) { B->err = "argument upload failed"; return 1; }
+    return 0;
+}
+static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+int blues_batch_snapshot_capture(BluesBatch* B, int32_t what, const int32_t* mask, BluesSnapshot** out) {
+    if (!B || !out || !(what & 3)) return 2;
+    const int R = B->R();
+    BluesEngine* h0 = B->eng[0];
+    if (hipSetDevice(h0->device) != hipSuccess) { B->err = "hipSetDevice failed"; return 1; }
+    if (batch_arena(B, sizeof(Copy6Args) * R)) return 1;
+    for (int r = 0; r < R; r++) if ((!mask || mask[r]) && flush_program(B->eng[r])) { B->err = B->eng[r]->err; return 1; }
+    if (batch_enter(B)) return 1;
+    Copy6Args* args = reinterpret_cast<Copy6Args*>(B->h_arena);
+    for (int r = 0; r < R; r++) {
+        BluesEngine* h = B->eng[r];
+        Copy6Args& c = args[r]; memset(&c, 0, sizeof c);
+        out[r] = nullptr;
+        if (mask && !mask[r]) continue;
+        if ((what & 1) && !h->have_positions) { B->err = "positions have not been set"; batch_leave(B); return 1; }
+        BluesSnapshot* sn = nullptr;
+        if (!h->snap_pool.empty()) { sn = h->snap_pool.back(); h->snap_pool.pop_back(); }
+        else {
+            sn = new BluesSnapshot(); sn->owner = h; sn->n = h->n;
+            if (hipMalloc((void**)&sn->block, sizeof(double) * 6 * (size_t)h->n) != hipSuccess) { delete sn; B->err = "hipMalloc failed"; batch_leave(B); return 1; }
+            for (int k = 0; k < 3; k++) { sn->x[k] = sn->block + (size_t)k * h->n; sn->v[k] = sn->block + (size_t)(3 + k) * h->n; }
+        }
+        sn->has_x = what & 1; sn->has_v = (what & 2) != 0;
+        c.n = h->n; c.src_stride = 1; c.dst_stride = 1;
+        if (what & 1) for (int k = 0; k < 3; k++) { c.src[c.count] = h->d_x[k].p; c.dst[c.count++] = sn->x[k]; }
+        if (what & 2) for (int k = 0; k < 3; k++) { c.src[c.count] = h->d_v[k].p; c.dst[c.count++] = sn->v[k]; }
+        sn->ecache = h->ecache; if (!(what & 1)) sn->ecache.clear();
+        h->st_launches++;
+        out[r] = sn;
+    }
+    int rc = batch_arena_upload(B, sizeof(Copy6Args) * R);
+    if (!rc) hipLaunchKernelGGL(k_copy_arrays_b, dim3((h0->n + 255) / 256, R), dim3(256), 0, B->stream, reinterpret_cast<const Copy6Args*>(B->d_arena.p));
+    if (!rc && hipGetLastError() != hipSuccess) { B->err = "launch failed"; rc = 1; }
+    batch_leave(B);
+    return rc;
+}
+
+// positions (what bit 0; `edit_*`: a few atoms of every member overwritten on the way, xyz [R][n_idx][3]) and / or velocities
+// (bit 1) of every member from its snapshot (null: the member sits out).  Returns 3 without doing anything when some member cannot
+// take the device route (never laid out; an edited atom constrained to an unedited one): the caller falls back to member calls.
+static int batch_restore_impl(BluesBatch* B, BluesSnapshot* const* snaps, int what, const int32_t* idx, int n_idx, const double* xyz) {
+    const int R = B->R();
+    BluesEngine* h0 = B->eng[0];
+    if (hipSetDevice(h0->device) != hipSuccess) { B->err = "hipSetDevice failed"; return 1; }
+    const int n = h0->n;
+    std::vector<double> ed;
+    if (what & 1) {
+        for (int r = 0; r < R; r++) if (snaps[r]) {
+            BluesEngine* h = B->eng[r];
+            if (snapshot_usable(h, snaps[r]) || !snaps[r]->has_x) { B->err = h->err.empty() ? "the snapshot holds no positions" : h->err; return 1; }
+            if (!h->sorted_ok || h->n != n) return 3;
+        }
+        if (n_idx > 0) {   // whole constraint clusters only, each stored as one periodic image (blues_set_positions_from_snapshot_edited)
+            std::vector<int> pos_of(n, -1);
+            for (int e = 0; e < n_idx; e++) { if (idx[e] < 0 || idx[e] >= n) { B->err = "edited atom out of range"; return 1; } pos_of[idx[e]] = e; }
+            ed.assign(xyz, xyz + (size_t)3 * n_idx * R);
+            for (int r = 0; r < R; r++) if (snaps[r]) {
+                BluesEngine* h = B->eng[r];
+                double* e0 = ed.data() + (size_t)3 * n_idx * r;
+                for (const HostCluster& c : h->clusters) {
+                    int inside = 0, total = 0;
+                    for (int a = 0; a < 4; a++) if (c.atoms[a] >= 0) { total++; inside += pos_of[c.atoms[a]] >= 0; }
+                    if (inside == 0) continue;
+                    if (inside != total) return 3;
+                    for (int a = 1; a < 4; a++) if (c.atoms[a] >= 0)
+                        for (int k = 0; k < 3; k++) {
+                            const double d = e0[3 * pos_of[c.atoms[a]] + k] - e0[3 * pos_of[c.atoms[0]] + k];
+                            e0[3 * pos_of[c.atoms[a]] + k] -= h->box[k] * std::nearbyint(d / h->box[k]);
+                        }
+                }
+            }
+        }
+    }
+    if (what & 2) for (int r = 0; r < R; r++) if (snaps[r] && (snapshot_usable(B->eng[r], snaps[r]) || !snaps[r]->has_v)) { B->err = "the snapshot holds no velocities"; return 1; }
+    // (before_position_edit may evaluate an energy of its own: before the members move to the batch stream)
+    for (int r = 0; r < R; r++) if (snaps[r]) {
+        BluesEngine* h = B->eng[r];
+        if ((what & 1) ? before_position_edit(h) : flush_program(h)) { B->err = h->err; return 1; }
+        if (snaps[r]->owner->stream != h->stream && !(snaps[r]->owner->batch == B)) hipStreamSynchronize(snaps[r]->owner->stream);   // captured on a stream outside this batch
+    }
+    const size_t off_load = 0, off_edit = align16(off_load + sizeof(LoadPosArgs) * R), off_copy = align16(off_edit + sizeof(EditPosArgs) * R),
+                 off_idx = align16(off_copy + sizeof(Copy6Args) * R), off_xyz = align16(off_idx + sizeof(int) * std::max(1, n_idx)), total = align16(off_xyz + sizeof(double) * 3 * (size_t)std::max(1, n_idx) * R);
+    if (batch_arena(B, total)) return 1;
+    if (!B->h_xfer_all) { if (hipHostMalloc((void**)&B->h_xfer_all, sizeof(unsigned) * 4 * R, hipHostMallocDefault) != hipSuccess) { B->err = "hipHostMalloc failed"; return 1; } try { B->d_xfer_all.alloc((size_t)4 * R); } catch (std::string& e) { B->err = e; return 1; } }
+    if (batch_enter(B)) return 1;
+    LoadPosArgs* la = reinterpret_cast<LoadPosArgs*>(B->h_arena + off_load); EditPosArgs* ea = reinterpret_cast<EditPosArgs*>(B->h_arena + off_edit);
+    Copy6Args* ca = reinterpret_cast<Copy6Args*>(B->h_arena + off_copy);
+    if (n_idx > 0) { memcpy(B->h_arena + off_idx, idx, sizeof(int) * n_idx); memcpy(B->h_arena + off_xyz, ed.data(), sizeof(double) * 3 * (size_t)n_idx * R); }
+    unsigned char* dbase = B->d_arena.p;
+    for (int r = 0; r < R; r++) {
+        BluesEngine* h = B->eng[r];
+        LoadPosArgs& a = la[r]; memset(&a, 0, sizeof a); EditPosArgs& e = ea[r]; memset(&e, 0, sizeof e); Copy6Args& c = ca[r]; memset(&c, 0, sizeof c);
+        if (!snaps[r]) continue;
+        const BluesSnapshot* sn = snaps[r];
+        if (what & 1) {
+            a.n = h->n; a.stride = 1;
+            for (int k = 0; k < 3; k++) { a.src[k] = sn->x[k]; a.x[k] = h->d_x[k].p; a.x_sort[k] = h->d_x_sort[k].p; }
+            a.mass = h->d_mass.p; a.alch_local = h->d_alch_local.p; a.sorted_of_orig = h->d_sorted_of_orig.p;
+            a.img_f = h->precision == 0 ? h->d_img_f.p : nullptr; a.img_d = h->precision == 0 ? nullptr : h->d_img_d.p;
+            a.box = make_box(h); a.out = h->d_xfer_out.p;
+            a.keep_out = h->xfer_pending ? 1 : 0;   // (a verdict still pending from an earlier load is kept: the kernels only OR / max / add into it)
+            if (n_idx > 0) {
+                e.n_edit = n_idx; e.idx = reinterpret_cast<const int*>(dbase + off_idx); e.xyz = reinterpret_cast<const double*>(dbase + off_xyz) + (size_t)3 * n_idx * r;
+                for (int k = 0; k < 3; k++) { e.x[k] = h->d_x[k].p; e.x_sort[k] = h->d_x_sort[k].p; }
+                e.mass = a.mass; e.alch_local = a.alch_local; e.sorted_of_orig = a.sorted_of_orig; e.img_f = a.img_f; e.img_d = a.img_d; e.box = a.box; e.out = a.out;
+            }
+        }
+        if (what & 2) { c.n = h->n; c.count = 3; c.src_stride = 1; c.dst_stride = 1; for (int k = 0; k < 3; k++) { c.src[k] = sn->v[k]; c.dst[k] = h->d_v[k].p; } }
+    }
+    int rc = batch_arena_upload(B, total);
+    const LoadPosArgs* dla = reinterpret_cast<const LoadPosArgs*>(dbase + off_load);
+    if (!rc && (what & 1)) {
+        hipLaunchKernelGGL(k_zero_xfer_b, dim3((R + 255) / 256), dim3(256), 0, B->stream, dla, R);
+        hipLaunchKernelGGL(k_load_positions_b, dim3((n + 255) / 256, R), dim3(256), 0, B->stream, dla);
+        if (n_idx > 0) hipLaunchKernelGGL(k_edit_positions_b, dim3((n_idx + 63) / 64, R), dim3(64), 0, B->stream, reinterpret_cast<const EditPosArgs*>(dbase + off_edit));
+        hipLaunchKernelGGL(k_gather_xfer_b, dim3((R + 255) / 256), dim3(256), 0, B->stream, dla, R, B->d_xfer_all.p);
+        if (hipMemcpyAsync(B->h_xfer_all, B->d_xfer_all.p, sizeof(unsigned) * 4 * R, hipMemcpyDeviceToHost, B->stream) != hipSuccess) rc = 1;
+    }
+    if (!rc && (what & 2)) hipLaunchKernelGGL(k_copy_arrays_b, dim3((n + 255) / 256, R), dim3(256), 0, B->stream, reinterpret_cast<const Copy6Args*>(dbase + off_copy));
+    if (!rc && hipGetLastError() != hipSuccess) { B->err = "launch failed"; rc = 1; }
+    batch_leave(B);   // (drains the batch stream: the verdicts have arrived)
+    if (rc) { if (B->err.empty()) B->err = "batched restore failed"; return 1; }
+    for (int r = 0; r < R; r++) if (snaps[r]) {
+        BluesEngine* h = B->eng[r];
+        if (what & 1) {
+            h->xfer_pending = true; h->xfer_stream = h->stream; h->xfer_src = B->h_xfer_all + 4 * r;
+            h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear(); h->lists_forced = true;
+            h->st_launches += n_idx > 0 ? 2 : 1;
+            if (snaps[r]->owner == h && n_idx == 0) h->ecache = snaps[r]->ecache;   // the energy that was known for these positions is known again
+            if (resolve_xfer(h)) { B->err = h->err; return 1; }   // (already on the host: no wait)
+        }
+        if (what & 2) { h->st_launches++; h->vel_clean = false; h->ke_cache_valid = false; }
+    }
+    return 0;
+}
+int blues_batch_restore(BluesBatch* B, BluesSnapshot* const* snaps, int32_t what) {
+    if (!B || !snaps || !(what & 3)) return 2;
+    return batch_restore_impl(B, snaps, what, nullptr, 0, nullptr);
+}
+int blues_batch_restore_edited(BluesBatch* B, BluesSnapshot* const* snaps, const int32_t* idx, int32_t n_idx, const double* xyz) {
+    if (!B || !snaps || n_idx < 0 || (n_idx > 0 && (!idx || !xyz))) return 2;
+    return batch_restore_impl(B, snaps, 1, idx, n_idx, xyz);
+}
+
+// positions (what = 1) or velocities (2) of the atoms idx of every member -- from its snapshot, or its live state where
+// snaps is NULL -- as out[R][n_idx][3]: one gather, one read-back (positions[atom_indices] of a Move, for all chains)
+int blues_batch_read_atoms(BluesBatch* B, BluesSnapshot* const* snaps, int32_t what, const int32_t* idx, int32_t n_idx, double* out) {
+    if (!B || !idx || !out || n_idx <= 0 || (what != 1 && what != 2)) return 2;
+    const int R = B->R();
+    BluesEngine* h0 = B->eng[0];
+    if (hipSetDevice(h0->device) != hipSuccess) { B->err = "hipSetDevice failed"; return 1; }
+    for (int e = 0; e < n_idx; e++) if (idx[e] < 0 || idx[e] >= h0->n) { B->err = "atom out of range"; return 1; }
+    const size_t off_src = 0, off_idx = align16(sizeof(double*) * 3 * R), off_out = align16(off_idx + sizeof(int) * n_idx), total = off_out + sizeof(double) * 3 * (size_t)n_idx * R;
+    if (batch_arena(B, total)) return 1;
+    for (int r = 0; r < R; r++) if (!snaps && flush_program(B->eng[r])) { B->err = B->eng[r]->err; return 1; }
+    if (batch_enter(B)) return 1;
+    const double** src = reinterpret_cast<const double**>(B->h_arena + off_src);
+    for (int r = 0; r < R; r++) for (int k = 0; k < 3; k++) {
+        const double* p = nullptr;
+        if (snaps) { if (snaps[r] && (what == 1 ? snaps[r]->has_x : snaps[r]->has_v)) p = what == 1 ? snaps[r]->x[k] : snaps[r]->v[k]; }
+        else p = what == 1 ? B->eng[r]->d_x[k].p : B->eng[r]->d_v[k].p;
+        src[3 * r + k] = p;
+    }
+    memcpy(B->h_arena + off_idx, idx, sizeof(int) * n_idx);
+    int rc = batch_arena_upload(B, off_out);
+    if (!rc) {
+        hipLaunchKernelGGL(k_gather_atoms_b, dim3((n_idx + 63) / 64, R), dim3(64), 0, B->stream, n_idx, reinterpret_cast<const int*>(B->d_arena.p + off_idx),
+                           reinterpret_cast<const double* const*>(B->d_arena.p + off_src), reinterpret_cast<double*>(B->d_arena.p + off_out));
+        if (hipMemcpyAsync(B->h_arena + off_out, B->d_arena.p + off_out, sizeof(double) * 3 * (size_t)n_idx * R, hipMemcpyDeviceToHost, B->stream) != hipSuccess) rc = 1;
+    }
+    batch_leave(B);
+    if (rc) { if (B->err.empty()) B->err = "batched gather failed"; return 1; }
+    memcpy(out, B->h_arena + off_out, sizeof(double) * 3 * (size_t)n_idx * R);
+    return 0;
+}
+
+// integrator.reset() of every member (mask NULL: all) -- reference blues/integrators.py:240-249, simulation.py:1184
+int blues_batch_reset(BluesBatch* B, const int32_t* mask) {
+    if (!B) return 2;
+    const int R = B->R();
+    if (hipSetDevice(B->eng[0]->device) != hipSuccess) { B->err = "hipSetDevice failed"; return 1; }
+    if (batch_arena(B, sizeof(DevAccum*) * R)) return 1;
+    for (int r = 0; r < R; r++) if ((!mask || mask[r]) && flush_program(B->eng[r])) { B->err = B->eng[r]->err; return 1; }
+    if (batch_enter(B)) return 1;
+    DevAccum** acc = reinterpret_cast<DevAccum**>(B->h_arena);
+    for (int r = 0; r < R; r++) {
+        BluesEngine* h = B->eng[r];
+        acc[r] = nullptr;
+        if (mask && !mask[r]) continue;
+        acc[r] = h->d_acc.p;
+        h->h_step = 0; h->h_lambda = 0.0; h->h_first_step = 0; h->h_perturbed = 0.0; h->h_unperturbed = 0.0; h->h_prop = 1; h->h_lambda_step = 0;
+        h->unpert_valid = false; h->x_edited = false; h->pass_valid = false; h->acc_cache_valid = false;
+    }
+    int rc = batch_arena_upload(B, sizeof(DevAccum*) * R);
+    if (!rc) hipLaunchKernelGGL(k_zero_acc_b, dim3((R + 255) / 256), dim3(256), 0, B->stream, reinterpret_cast<DevAccum* const*>(B->d_arena.p), R);
+    batch_leave(B);
+    return rc;
+}
+
+// context.setVelocitiesToTemperature(T, seed[r]) of every member (reference blues/simulation.py:1187): one Maxwell-Boltzmann
+// launch, then the velocity constraints of all members in lock step
+int blues_batch_set_velocities_to_temperature(BluesBatch* B, double temperature, const uint64_t* seeds, const int32_t* mask) {
+    if (!B || !seeds) return 2;
+    const int R = B->R();
+    BluesEngine* h0 = B->eng[0];
+    if (hipSetDevice(h0->device) != hipSuccess) { B->err = "hipSetDevice failed"; return 1; }
+    if (batch_arena(B, sizeof(MaxwellArgs) * R)) return 1;
+    for (int r = 0; r < R; r++) if ((!mask || mask[r]) && flush_program(B->eng[r])) { B->err = B->eng[r]->err; return 1; }
+    if (batch_enter(B)) return 1;
+    MaxwellArgs* ma = reinterpret_cast<MaxwellArgs*>(B->h_arena);
+    for (int r = 0; r < R; r++) {
+        BluesEngine* h = B->eng[r];
+        MaxwellArgs& a = ma[r]; memset(&a, 0, sizeof a);
+        if (mask && !mask[r]) continue;
+        a.n = h->n; a.mass = h->d_mass.p; for (int k = 0; k < 3; k++) a.v[k] = h->d_v[k].p;
+        a.kT = KB_KJ * temperature; a.seed = (unsigned long long)seeds[r]; a.stream = (unsigned)h->replica * 4u + 1u;
+        h->st_launches++; h->vel_clean = false; h->ke_cache_valid = false;
+    }
+    int rc = batch_arena_upload(B, sizeof(MaxwellArgs) * R);
+    if (!rc) hipLaunchKernelGGL(k_maxwell_b, dim3((h0->n + 255) / 256, R), dim3(256), 0, B->stream, reinterpret_cast<const MaxwellArgs*>(B->d_arena.p));
+    // the velocity constraints: every member queues OP_RATTLE; congruent members flush in lock step (one launch)
+    std::vector<char> saved_active = B->active;
+    B->failed.assign(R, 0);
+    for (int r = 0; r < R; r++) { B->active[r] = (!mask || mask[r]) ? 1 : 0; if (!B->active[r]) B->failed[r] = 1; }
+    BluesEngine* lead = nullptr;
+    for (int r = 0; r < R && !rc; r++) if (!B->failed[r]) { if (!lead) lead = B->eng[r]; if (ensure_sorted(B->eng[r]) || emit(B->eng[r], OP_RATTLE)) { B->err = B->eng[r]->err; rc = 1; } }
+    if (!rc && lead) {
+        B->leader = lead;
+        bool uniform = true;
+        const BatchSig ls = batch_sig(lead);
+        for (int r = 0; r < R && uniform; r++) if (!B->failed[r]) { const BatchSig g = batch_sig(B->eng[r]); const char* why = ""; uniform = !memcmp(&g, &ls, sizeof g) && batch_congruent(lead, B->eng[r], &why); }
+        if (uniform && batch_refresh_args(B)) rc = 1;
+        if (!rc) {
+            B->lockstep = uniform;
+            for (int r = 0; r < R && !rc; r++) if (!B->failed[r] && flush_program(B->eng[r])) { B->err = B->eng[r]->err; rc = 1; }
+            B->lockstep = false;
+        }
+    }
+    B->active = saved_active; B->leader = B->eng[0];
+    batch_leave(B);
+    return rc;
+}
+
 // usec[0]: a pass over current pruned lists; usec[1]: a pass that re-derives them (walks the full lists); equal where the
 // kernel has no pruned lists.  frac: the share of prune passes among this batch's force passes so far.
 int blues_batch_time_nonbonded_modes(BluesBatch* b, int32_t reps, double usec[2], double* prune_fraction) {

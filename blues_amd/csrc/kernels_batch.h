@@ -238,6 +238,55 @@ __global__ void k_prune_set(const RepCore* __restrict__ reps, int* one, int n_is
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_islots; q += gridDim.x * blockDim.x) f[q] = raise;
 }
 
+// ---- the plugin boundary for a whole batch (blues_batch_capture / _restore / _read_atoms / _restore_edited / _reset /
+// _set_velocities_to_temperature): the per-member kernels of the single-engine entry points, one launch for all members.
+// The per-member arguments are plain structs uploaded as an array; a member that sits the call out has n = 0 / count = 0.
+__global__ void __launch_bounds__(256) k_copy_arrays_b(const Copy6Args* __restrict__ args) {
+    const Copy6Args a = args[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    for (int q = 0; q < a.count; q++) a.dst[q][(size_t)i * a.dst_stride] = a.src[q][(size_t)i * a.src_stride];
+}
+__global__ void k_zero_xfer_b(const LoadPosArgs* __restrict__ args, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R && args[r].n > 0 && !args[r].keep_out) { unsigned* o = args[r].out; o[0] = o[1] = o[2] = o[3] = 0u; }
+}
+__global__ void __launch_bounds__(256) k_load_positions_b(const LoadPosArgs* __restrict__ args) {
+    const LoadPosArgs a = args[blockIdx.y];
+    if (a.n <= 0) return;
+    load_positions_body(a, blockIdx.x);
+}
+__global__ void __launch_bounds__(64) k_edit_positions_b(const EditPosArgs* __restrict__ args) {
+    const EditPosArgs a = args[blockIdx.y];
+    edit_positions_body(a, blockIdx.x);
+}
+// out[r][e][3] <- the atoms idx[e] of member r's arrays src[3r + k]
+__global__ void __launch_bounds__(64) k_gather_atoms_b(int n_idx, const int* __restrict__ idx, const double* const* __restrict__ src, double* out) {
+    const int e = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y;
+    if (e >= n_idx || !src[3 * r]) return;
+    const int i = idx[e];
+    double* o = out + ((size_t)r * n_idx + e) * 3;
+    o[0] = src[3 * r][i]; o[1] = src[3 * r + 1][i]; o[2] = src[3 * r + 2][i];
+}
+__global__ void k_gather_xfer_b(const LoadPosArgs* __restrict__ args, int R, unsigned* out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    for (int q = 0; q < 4; q++) out[4 * r + q] = args[r].n > 0 ? args[r].out[q] : 0u;
+}
+struct MaxwellArgs { int n; const double* mass; double* v[3]; double kT; unsigned long long seed; unsigned stream; };
+__global__ void __launch_bounds__(256) k_maxwell_b(const MaxwellArgs* __restrict__ args) {
+    const MaxwellArgs a = args[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    double g[3] = {0.0, 0.0, 0.0};
+    if (a.mass[i] != 0.0) { gaussians3(a.seed, a.stream, 0u, (unsigned)i, g); const double s = sqrt(a.kT / a.mass[i]); g[0] *= s; g[1] *= s; g[2] *= s; }
+    a.v[0][i] = g[0]; a.v[1][i] = g[1]; a.v[2][i] = g[2];
+}
+__global__ void k_zero_acc_b(DevAccum* const* __restrict__ acc, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R && acc[r]) { DevAccum z; z.protocol_work = z.dE_last = z.heat = 0.0; z.e_slot[0] = z.e_slot[1] = z.e_slot[2] = 0.0; *acc[r] = z; }
+}
+
 __global__ void __launch_bounds__(256) k_bonded_energy_b(const RepCore* __restrict__ reps) {
     if (!reps[blockIdx.y].active) return;
     const BondedArgs B = reps[blockIdx.y].bo;

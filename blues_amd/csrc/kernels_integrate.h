@@ -625,6 +625,7 @@ __global__ void __launch_bounds__(256) k_integrate(IntArgs A) { integrate_body(A
 //   out[2]       number of atoms farther than 0.5 nm from where they were sorted
 struct LoadPosArgs {
     int n, stride;
+    int keep_out;   // batched call: an older verdict is still pending in `out`, do not zero it
     const double* src[3];
     double* x[3];
     const double* x_sort[3];
@@ -632,8 +633,8 @@ struct LoadPosArgs {
     AtomF* img_f; AtomD* img_d; Box3 box;
     unsigned* out;
 };
-__global__ void __launch_bounds__(256) k_load_positions(LoadPosArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void load_positions_body(const LoadPosArgs& a, const int block) {
+    const int i = block * 256 + threadIdx.x;
     unsigned changed = 0, far = 0; float worst = 0.0f;
     if (i < a.n) {
         double p[3], d2 = 0.0;
@@ -665,6 +666,7 @@ __global__ void __launch_bounds__(256) k_load_positions(LoadPosArgs a) {
         if (f) atomicAdd(&a.out[2], f);
     }
 }
+__global__ void __launch_bounds__(256) k_load_positions(LoadPosArgs a) { load_positions_body(a, blockIdx.x); }
 
 // a few atoms of the positions just loaded are overwritten (a Move's edit of a State handed back otherwise unchanged):
 // one thread per edited atom; same statistics as k_load_positions, for the new coordinates
@@ -675,8 +677,8 @@ struct EditPosArgs {
     AtomF* img_f; AtomD* img_d; Box3 box;
     unsigned* out;
 };
-__global__ void __launch_bounds__(64) k_edit_positions(EditPosArgs a) {
-    const int e = blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void edit_positions_body(const EditPosArgs& a, const int block) {
+    const int e = block * 64 + threadIdx.x;
     if (e >= a.n_edit) return;
     const int i = a.idx[e];
     double p[3], d2 = 0.0;
@@ -697,6 +699,7 @@ __global__ void __launch_bounds__(64) k_edit_positions(EditPosArgs a) {
     if (a.img_f) { unsigned u[3]; to_fixed32(p, a.box, u); a.img_f[s].x = u[0]; a.img_f[s].y = u[1]; a.img_f[s].z = u[2]; }
     else { unsigned long long u[3]; to_fixed(p, a.box, u); a.img_d[s].x = u[0]; a.img_d[s].y = u[1]; a.img_d[s].z = u[2]; }
 }
+__global__ void __launch_bounds__(64) k_edit_positions(EditPosArgs a) { edit_positions_body(a, blockIdx.x); }
 
 // gather of a few atoms' coordinates (snapshot or live) into a dense [n][3] buffer
 __global__ void __launch_bounds__(64) k_gather_atoms(int n_idx, const int* idx, const double* s0, const double* s1, const double* s2, double* out) {

@@ -176,11 +176,13 @@ class NativeEngine:
 class DeviceSnapshot:
     """openmm.State's positions / velocities kept on the GPU (include/blues_engine.h "Device-resident State")."""
 
-    def __init__(self, engine, what):
+    def __init__(self, engine, what, handle=None):
+        """handle: a snapshot already captured for this engine (NativeBatch.snapshot_all)."""
         self.engine, self.what = engine, int(what)
-        h = C.c_void_p()
-        engine._check(engine._lib.blues_snapshot_capture(engine._h, self.what, C.byref(h)))
-        self._h = h
+        if handle is None:
+            handle = C.c_void_p()
+            engine._check(engine._lib.blues_snapshot_capture(engine._h, self.what, C.byref(handle)))
+        self._h = handle
         self._host = {}
 
     def read(self, kind):
@@ -269,6 +271,76 @@ class NativeBatch:
         what = (1 if potential else 0) | (2 if kinetic else 0) | (4 if at_lambda_one else 0)
         if self._lib.blues_batch_set_active(self._h, mask) or self._lib.blues_batch_prefetch_energies(self._h, what):
             raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
+
+    # ---- the plugin boundary for all members at once (include/blues_engine.h, "The plugin boundary for a whole batch")
+    def _mask(self, active):
+        R = len(self.engines)
+        return None if active is None else (C.c_int32 * R)(*[1 if active[r] else 0 for r in range(R)])
+
+    def _fail(self):
+        raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
+
+    def snapshot_all(self, positions=True, velocities=True, active=None):
+        """[DeviceSnapshot or None per member]: every member's positions / velocities captured with one launch."""
+        R = len(self.engines)
+        what = (1 if positions else 0) | (2 if velocities else 0)
+        out = (C.c_void_p * R)()
+        if self._lib.blues_batch_snapshot_capture(self._h, what, self._mask(active), out):
+            self._fail()
+        return [DeviceSnapshot(e, what, handle=C.c_void_p(out[r])) if out[r] else None for r, e in enumerate(self.engines)]
+
+    def _handles(self, snaps):
+        R = len(self.engines)
+        return (C.c_void_p * R)(*[(s._h if s is not None else None) for s in snaps])
+
+    def restore_all(self, snaps, positions=True, velocities=True):
+        """setPositions / setVelocities of every member from its snapshot (None: the member sits out).  False: some member cannot
+        take the device route -- nothing was done, use the member calls."""
+        for e, s in zip(self.engines, snaps):
+            if s is not None:
+                e.__dict__["_gcache"] = {}
+        rc = self._lib.blues_batch_restore(self._h, self._handles(snaps), (1 if positions else 0) | (2 if velocities else 0))
+        if rc == 3:
+            return False
+        if rc:
+            self._fail()
+        return True
+
+    def restore_edited_all(self, snaps, indices, xyz):
+        """setPositions of every member from its snapshot with the atoms `indices` overwritten by xyz[r] (nm)."""
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(len(self.engines), len(idx), 3)
+        for e, s in zip(self.engines, snaps):
+            if s is not None:
+                e.__dict__["_gcache"] = {}
+        rc = self._lib.blues_batch_restore_edited(self._h, self._handles(snaps), idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx), xyz.ctypes.data_as(_dp))
+        if rc == 3:
+            return False
+        if rc:
+            self._fail()
+        return True
+
+    def read_atoms_all(self, indices, snaps=None, kind=1):
+        """(R, len(indices), 3): the atoms `indices` of every member's snapshot (or live state): one gather, one read-back."""
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        out = np.zeros((len(self.engines), len(idx), 3))
+        if self._lib.blues_batch_read_atoms(self._h, self._handles(snaps) if snaps is not None else None, int(kind),
+                                            idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx), out.ctypes.data_as(_dp)):
+            self._fail()
+        return out
+
+    def reset_all(self, active=None):
+        for r, e in enumerate(self.engines):
+            if active is None or active[r]:
+                e.__dict__["_gcache"] = {}
+        if self._lib.blues_batch_reset(self._h, self._mask(active)):
+            self._fail()
+
+    def set_velocities_to_temperature_all(self, temperature, seeds, active=None):
+        R = len(self.engines)
+        sd = (C.c_uint64 * R)(*[int(x) & 0xFFFFFFFFFFFFFFFF for x in seeds])
+        if self._lib.blues_batch_set_velocities_to_temperature(self._h, float(temperature), sd, self._mask(active)):
+            self._fail()
 
     def stats(self):
         s = (C.c_int64 * 4)()

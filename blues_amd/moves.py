@@ -72,16 +72,22 @@ class RandomLigandRotationMove(Move):
         coordinates = numpy.asarray(positions, numpy.float32)
         return (coordinates * masses).sum(0) / masses.sum()
 
-    def move(self, context):
-        """reference blues/moves.py:278-310, statement for statement: the State's positions are indexed and assigned through
-        the Quantity (which, on this engine, moves only the ligand's coordinates between device and host)."""
-        positions = context.getState(getPositions=True).getPositions(asNumpy=True)
-        self.positions = positions[self.atom_indices]._value
+    def propose(self, ligand_positions):
+        """The geometry of the move on the ligand's own coordinates ((n_ligand, 3), nm) -> the rotated coordinates: random rotation
+        about the centre of mass (reference blues/moves.py:293-302).  `move` applies it through the Context; a replica batch calls
+        it for every chain between ONE gather and ONE scatter of all chains' ligand atoms (BatchedBLUESSimulation)."""
+        self.positions = ligand_positions
         self.center_of_mass = self.getCenterOfMass(self.positions, self.masses)
         reduced_pos = self.positions - self.center_of_mass
         rand_quat = uniform_quaternion(self.random_state)
         rand_rotation_matrix = rotation_matrix_from_quaternion(rand_quat)
-        rot_move = numpy.dot(reduced_pos, rand_rotation_matrix) + self.center_of_mass
+        return numpy.dot(reduced_pos, rand_rotation_matrix) + self.center_of_mass
+
+    def move(self, context):
+        """reference blues/moves.py:278-310: read the ligand out of the State's positions, rotate, assign, hand the positions back
+        (on this engine the Quantity moves only the ligand's coordinates between device and host)."""
+        positions = context.getState(getPositions=True).getPositions(asNumpy=True)
+        rot_move = self.propose(positions[self.atom_indices]._value)
         for index, atomidx in enumerate(self.atom_indices):
             positions[atomidx] = rot_move[index]
         context.setPositions(positions)

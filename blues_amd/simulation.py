@@ -248,7 +248,7 @@ class BatchedBLUESSimulation(object):
     NCMC engines form one native batch (and the MD engines another), so `step(n)` is one kernel launch sequence for all
     chains.  Hooks, state exchange and the Metropolis test run per chain, in chain order."""
 
-    def __init__(self, chains, workers=1):
+    def __init__(self, chains, workers=1, batched_boundary=True):
         """workers > 1: the per-chain host work (hooks, state exchange through the plugin boundary, Metropolis test) of
         different chains runs on a thread pool -- the C-ABI calls release the GIL and engines are independent objects;
         each chain then draws from its own RandomState (seeded here, in chain order, from numpy's global stream)."""
@@ -256,6 +256,7 @@ class BatchedBLUESSimulation(object):
         self.chains = list(chains)
         if not self.chains:
             raise ValueError("no chains")
+        self.batched_boundary = bool(batched_boundary)   # False: hooks, State hand-overs and the Metropolis step chain by chain, always
         self._pool = None
         if workers and workers > 1 and len(self.chains) > 1:
             from concurrent.futures import ThreadPoolExecutor
@@ -308,7 +309,137 @@ class BatchedBLUESSimulation(object):
                     del left[r]
         return errors
 
+    # ---- the plugin boundary for all chains at once (include/blues_engine.h: blues_batch_snapshot_capture ...).  Chain by chain
+    # the hooks, State hand-overs and the Metropolis step are ~60 C-ABI calls and ~25 small launches per chain and iteration;
+    # where every chain's Move exposes its geometry as `propose(coordinates of its atoms)` and leaves the other hooks alone, the
+    # same sequence of operations is issued once for the whole batch.  Same results, bit for bit, as the chain-by-chain path
+    # (tests/test_gpu_batch.py); chains with other Moves take that path.
+    def _batchable(self):
+        from . import moves
+        if not self.batched_boundary or not hasattr(self._ncmc_batch, "snapshot_all"):
+            return False
+        first = None
+        for c in self.chains:
+            me = c._move_engine
+            if me is None or len(getattr(me, "moves", [])) != 1 or c._alch_sim is not None or c._md_sim is not None:
+                return False
+            m = me.moves[0]
+            if not hasattr(m, "propose") or any(getattr(type(m), hook) is not getattr(moves.Move, hook) for hook in ("beforeMove", "afterMove", "_error")):
+                return False
+            if first is None:
+                first = m
+            elif type(m) is not type(first) or list(m.atom_indices) != list(first.atom_indices):
+                return False
+            if c._ncmc_sim.reporters:
+                return False
+        return True
+
+    def _capture_states(self, active=None):
+        """getStateFromContext (reference blues/simulation.py:883-911) of every chain's NCMC context: one capture for all."""
+        snaps = self._ncmc_batch.snapshot_all(True, True, active=active)
+        out = []
+        for r, c in enumerate(self.chains):
+            if snaps[r] is None:
+                out.append(None)
+                continue
+            ctx = c._ncmc_sim.context
+            e = ctx._engine
+            pe, ke = e.energies()
+            out.append({'positions': unit.DeviceQuantity(snaps[r], 1, "nanometer"), 'velocities': unit.DeviceQuantity(snaps[r], 2, "nanometer/picosecond"),
+                        'potential_energy': unit.Quantity(pe, "kilojoule/mole"), 'kinetic_energy': unit.Quantity(ke, "kilojoule/mole"),
+                        'box_vectors': [unit.Quantity(np.array(row), "nanometer") for row in e.get_box()]})
+        return out
+
+    def _restore_states(self, states, velocities=True):
+        """setContextFromState of every chain whose entry is not None (box vectors of an NVT chain never change: context.py)."""
+        snaps = [None if st is None else st['positions'].on_device() for st in states]
+        if any(st is not None and sn is None for st, sn in zip(states, snaps)) or not self._ncmc_batch.restore_all(snaps, True, velocities):
+            for c, st in zip(self.chains, states):   # somebody read or edited the arrays on the host: the member calls
+                if st is not None:
+                    c._ncmc_sim.context = c.setContextFromState(c._ncmc_sim.context, st, velocities=velocities)
+
+    def _stepNCMC_batched(self, nstepsNC, moveStep):
+        chains, batch = self.chains, self._ncmc_batch
+        R = len(chains)
+        sims = [c._ncmc_sim for c in chains]
+        batch.prefetch_energies()
+        for c, st in zip(chains, self._capture_states()):
+            c._setStateTable('ncmc', 'state0', st)
+            c._ncmc_sim.currentIter = c.currentIter
+            c._move_engine.selectMove()
+        nstepsNC, moveStep = int(nstepsNC), int(moveStep)
+        cuts = sorted(set([0, nstepsNC] + ([moveStep] if 0 <= moveStep < nstepsNC else [])))
+        failed = {}
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            live = [r not in failed for r in range(R)]
+            if a == moveStep and any(live):
+                idx = list(chains[0]._move_engine.selected_move.atom_indices)
+                snaps = batch.snapshot_all(True, False, active=live)                 # context.getState(getPositions=True)
+                xyz = batch.read_atoms_all(idx, snaps=snaps)                         # positions[atom_indices]
+                new = np.array([chains[r]._move_engine.selected_move.propose(xyz[r]) if live[r] else xyz[r] for r in range(R)])
+                if not batch.restore_edited_all(snaps, idx, new):                    # positions[i] = ...; context.setPositions(positions)
+                    for r in range(R):
+                        if live[r]:
+                            q = unit.DeviceQuantity(snaps[r], 1, "nanometer")
+                            for k, i in enumerate(idx):
+                                q[i] = new[r][k]
+                            chains[r]._ncmc_sim.context.setPositions(q)
+                for r in range(R):
+                    if live[r]:
+                        m = chains[r]._move_engine.selected_move
+                        m.positions = new[r]
+                        chains[r]._move_engine.move_name = getattr(chains[r]._move_engine, "move_name", type(m).__name__)
+            if b > a:
+                failed.update(self._advance(batch, sims, {r: b - a for r in range(R) if r not in failed}))
+        for r, e in failed.items():   # reference policy (simulation.py:1088-1094): log, abandon that chain's switch
+            logger.error(e)
+        batch.prefetch_energies(active=[r not in failed for r in range(R)], at_lambda_one=True)
+        for c, st in zip(chains, self._capture_states()):
+            c._setStateTable('ncmc', 'state1', st)
+
+    def _decide_batched(self, temperature):
+        """_acceptRejectMove + _resetSimulations of every chain (reference blues/simulation.py:1121-1187): the tests chain by chain
+        on numbers already on the host, the restores of the rejected chains, the resets and the velocity redraws once each."""
+        chains = self.chains
+        restore = []
+        for c in chains:
+            work_ncmc = c._ncmc_sim.context._integrator.getLogAcceptanceProbability(c._ncmc_sim.context)
+            randnum = math.log(c._rng.random_sample())
+            correction_factor = 0.0
+            if not np.isnan(work_ncmc):
+                correction_factor = c._computeAlchemicalCorrection()
+                work_ncmc = work_ncmc + correction_factor
+            accepted = bool(work_ncmc > randnum)
+            c.last = {'accept': accepted, 'log_accept': float(work_ncmc), 'correction': float(correction_factor), 'randnum': randnum,
+                      'protocol_work': c._ncmc_sim.context._integrator.getGlobalVariableByName('protocol_work')}
+            if accepted:
+                c.accept += 1
+                restore.append(None)
+            else:
+                c.reject += 1
+                restore.append(c.stateTable['ncmc']['state0'])    # no separate MD context: the pre-switch state, in place
+        self._restore_states(restore)
+        seeds, temps = [], []
+        for c in chains:
+            c._ncmc_sim.currentStep = 0
+            c._ncmc_sim.context._integrator._pre_globals = {}       # integrator.reset(): the engine part follows for all chains at once
+            temps.append(unit.value_in(temperature if temperature else c._ncmc_sim.context._integrator.getTemperature(), "kelvin"))
+            seeds.append(c._rng.randint(0, 2 ** 31 - 1))
+        self._ncmc_batch.reset_all()
+        for T in sorted(set(temps)):   # (one launch per distinct temperature: one, in practice)
+            self._ncmc_batch.set_velocities_to_temperature_all(T, seeds, active=[t == T for t in temps])
+
+    def _sync_batched(self):
+        """_syncStatesMDtoNCMC of every chain where there is no separate MD context (reference blues/simulation.py:1028-1037): the
+        MD state is the NCMC context's own, its potential the one at lambda = 1."""
+        self._ncmc_batch.prefetch_energies(at_lambda_one=True)
+        for c, st in zip(self.chains, self._capture_states()):
+            st['potential_energy'] = unit.Quantity(c._energy_at_lambda_one(), "kilojoule/mole")
+            c._setStateTable('md', 'state0', st)
+
     def _stepNCMC(self, nstepsNC, moveStep):
+        if self._batchable():
+            return self._stepNCMC_batched(nstepsNC, moveStep)
         sims = [c._ncmc_sim for c in self.chains]
         plans = {r: c._ncmc_plan(nstepsNC, moveStep) for r, c in enumerate(self.chains)}
         DONE = object()
@@ -355,13 +486,23 @@ class BatchedBLUESSimulation(object):
             def sync(r, c):
                 c.currentIter = N
                 c._syncStatesMDtoNCMC()
-            (self._md_batch or self._ncmc_batch).prefetch_energies(at_lambda_one=self._md_batch is None)
-            self.for_each_chain(sync)
+            if self._batchable():
+                for c in self.chains:
+                    c.currentIter = N
+                self._sync_batched()
+            else:
+                (self._md_batch or self._ncmc_batch).prefetch_energies(at_lambda_one=self._md_batch is None)
+                self.for_each_chain(sync)
             self._stepNCMC(nstepsNC, moveStep)
-            self.for_each_chain(lambda r, c: c._acceptRejectMove(write_move))
-            if on_iteration is not None:
-                on_iteration(N, [c.last for c in self.chains])
-            self.for_each_chain(lambda r, c: c._resetSimulations(temperature))
+            if self._batchable():
+                self._decide_batched(temperature)
+                if on_iteration is not None:
+                    on_iteration(N, [c.last for c in self.chains])
+            else:
+                self.for_each_chain(lambda r, c: c._acceptRejectMove(write_move))
+                if on_iteration is not None:
+                    on_iteration(N, [c.last for c in self.chains])
+                self.for_each_chain(lambda r, c: c._resetSimulations(temperature))
             self._stepMD(nstepsMD)
         for c in self.chains:
             c.acceptRatio = c.accept / float(nIter)

@@ -334,6 +334,28 @@ int blues_batch_set_active(BluesBatch *b, const int32_t *mask);
  * With bit 1 the members' accumulators (protocol work) come back in the same read and serve
  * the blues_get_global("protocol_work") calls that follow, until the member is stepped.) */
 int blues_batch_prefetch_energies(BluesBatch *b, int32_t what);
+/* ---- The plugin boundary for a whole batch ---------------------------------
+ * What BLUES does to each Context around the stepping -- getStateFromContext /
+ * setContextFromState (reference blues/simulation.py:883-963, called at :1035, :1056,
+ * :1096, :1150-1163), positions[atom_indices] / setPositions of a Move (blues/moves.py:
+ * 292-307), integrator.reset() and setVelocitiesToTemperature (simulation.py:1184-1187)
+ * -- for every member of a batch at once: the per-member entry points' host part in a
+ * loop, ONE launch per kernel.  Semantics are those of the member calls named with each
+ * function; out / snaps arrays have one slot per member, mask[r] == 0 / snaps[r] == NULL
+ * leaves member r alone (mask NULL: everyone).
+ * blues_batch_restore* return 3, having done nothing, when some member cannot take the
+ * device route (no layout yet; an edited atom constrained to an unedited one): use the
+ * member calls then. */
+int blues_batch_snapshot_capture(BluesBatch *b, int32_t what, const int32_t *mask, BluesSnapshot **out);        /* blues_snapshot_capture */
+int blues_batch_restore(BluesBatch *b, BluesSnapshot *const *snaps, int32_t what);                              /* blues_set_positions_from_snapshot (bit 0), blues_set_velocities_from_snapshot (bit 1) */
+int blues_batch_restore_edited(BluesBatch *b, BluesSnapshot *const *snaps, const int32_t *idx, int32_t n_idx,
+                               const double *xyz_nm /* [count][n_idx][3] */);                                    /* blues_set_positions_from_snapshot_edited */
+int blues_batch_read_atoms(BluesBatch *b, BluesSnapshot *const *snaps /* NULL: the live state */, int32_t what,
+                           const int32_t *idx, int32_t n_idx, double *out /* [count][n_idx][3] */);              /* blues_snapshot_read_atoms */
+int blues_batch_reset(BluesBatch *b, const int32_t *mask);                                                       /* blues_reset */
+int blues_batch_set_velocities_to_temperature(BluesBatch *b, double temperature, const uint64_t *seeds,
+                                              const int32_t *mask);                                              /* blues_set_velocities_to_temperature */
+
 /* [0] steps issued in lock step (one launch for all members) [1] steps that
  * fell back to per-member launches [2] members [3] batched energy evaluations */
 int blues_batch_get_stats(BluesBatch *b, int64_t stats[4]);

