@@ -2708,6 +2708,7 @@ int blues_snapshot_capture(BluesEngine* h, int32_t what, BluesSnapshot** out) {
     if (what & 2) for (int k = 0; k < 3; k++) { c.src[c.count] = h->d_v[k].p; c.dst[c.count++] = sn->v[k]; }
     hipLaunchKernelGGL(k_copy_arrays, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, c);
     h->st_launches++;
+    if (h->acc_cache_valid && h->acc_cache_stamp + 1 == h->st_launches) h->acc_cache_stamp = h->st_launches;   // (a copy of x, v does not touch the accumulators)
     sn->ecache = h->ecache; if (!(what & 1)) sn->ecache.clear();
     HIP_OK(h, hipGetLastError());
     *out = sn;
@@ -3002,6 +3003,7 @@ int blues_batch_snapshot_capture(BluesBatch* B, int32_t what, const int32_t* mas
         if (what & 2) for (int k = 0; k < 3; k++) { c.src[c.count] = h->d_v[k].p; c.dst[c.count++] = sn->v[k]; }
         sn->ecache = h->ecache; if (!(what & 1)) sn->ecache.clear();
         h->st_launches++;
+        if (h->acc_cache_valid && h->acc_cache_stamp + 1 == h->st_launches) h->acc_cache_stamp = h->st_launches;   // (a copy of x, v does not touch the accumulators)
         out[r] = sn;
     }
     int rc = batch_arena_upload(B, sizeof(Copy6Args) * R);

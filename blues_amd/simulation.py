@@ -373,6 +373,8 @@ class BatchedBLUESSimulation(object):
         for a, b in zip(cuts[:-1], cuts[1:]):
             live = [r not in failed for r in range(R)]
             if a == moveStep and any(live):
+                if a > 0:   # the work of the instantaneous move needs U(x) before the edit (integrators.py:184-205): for all chains at once
+                    batch.prefetch_energies(active=live, kinetic=False)
                 idx = list(chains[0]._move_engine.selected_move.atom_indices)
                 snaps = batch.snapshot_all(True, False, active=live)                 # context.getState(getPositions=True)
                 xyz = batch.read_atoms_all(idx, snaps=snaps)                         # positions[atom_indices]
