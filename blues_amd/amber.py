@@ -90,13 +90,22 @@ def read_inpcrd(path):
 
 
 def read_rst7(path):
-    """Amber ASCII restart (.rst7 / .rst): the inpcrd layout with a velocity block (reference blues/settings.py:60-90 hands such
-    files to ParmEd).  Returns (positions nm, velocities nm/ps or None, box nm or None)."""
+    """Amber restart (.rst7 / .rst) in either form parmed.amber.Rst7 accepts (reference blues/settings.py:76-85): the NetCDF
+    "AMBERRESTART" file the reference's own RestartReporter writes (blues/reporters.py:217-225, netcdf=True), recognised by its
+    magic bytes, or the ASCII inpcrd layout with a velocity block.  Returns (positions nm, velocities nm/ps or None, box nm or None)."""
+    from .formats import AmberNetCDFRestart
+    if AmberNetCDFRestart.is_netcdf(path):
+        pos, vel, box, _ = AmberNetCDFRestart.read(path)
+        return pos, vel, box
     return read_inpcrd(path)
 
 
-def write_rst7(path, positions_nm, velocities_nm_ps=None, box_nm=None, title="written by blues_amd", time_ps=0.0):
-    """Amber ASCII restart in the fixed 6F12.7 layout (angstrom; velocities in angstrom per 1/20.455 ps)."""
+def write_rst7(path, positions_nm, velocities_nm_ps=None, box_nm=None, title="written by blues_amd", time_ps=0.0, netcdf=False):
+    """Amber restart: NetCDF (netcdf=True, the reference's choice) or ASCII in the fixed 6F12.7 layout (angstrom; velocities in
+    angstrom per 1/20.455 ps)."""
+    if netcdf:
+        from .formats import AmberNetCDFRestart
+        return AmberNetCDFRestart.write(path, positions_nm, velocities_nm_ps, box_nm, time_ps=time_ps, title=title)
     x = np.asarray(positions_nm, dtype=np.float64).reshape(-1, 3) * 10.0
     blocks = [x.reshape(-1)]
     if velocities_nm_ps is not None:

@@ -10,13 +10,69 @@ from . import unit
 from .engine import EngineError, NativeEngine
 
 
+class PeriodicWrapper(object):
+    """enforcePeriodicBox=True of Context.getState (reference blues/simulation.py:874-881): positions are reported with the centre of
+    every MOLECULE inside the box, molecules kept whole, as OpenMM does.  Molecules are the connected components of the bond and
+    constraint graph.  The shift of an atom is a lattice vector of its molecule, found from that molecule's atoms alone, so the few
+    atoms a Move reads (positions[atom_indices]) are wrapped without fetching the rest."""
+
+    def __init__(self, system):
+        n = system.n_atoms
+        parent = list(range(n))
+
+        def find(i):
+            while parent[i] != i:
+                parent[i] = parent[parent[i]]
+                i = parent[i]
+            return i
+        for pairs in (getattr(system, "bond_atoms", []), getattr(system, "constraint_atoms", [])):
+            for a, b in np.asarray(pairs, dtype=np.int64).reshape(-1, 2):
+                ra, rb = find(int(a)), find(int(b))
+                if ra != rb:
+                    parent[max(ra, rb)] = min(ra, rb)
+        roots = np.array([find(i) for i in range(n)], dtype=np.int64)
+        _, self.molecule_of = np.unique(roots, return_inverse=True)
+        order = np.argsort(self.molecule_of, kind="stable")
+        self._order = order
+        self._start = np.searchsorted(self.molecule_of[order], np.arange(self.molecule_of.max() + 2))
+        self.box = np.asarray(system.box, dtype=np.float64).reshape(-1)[:3].copy() if np.size(system.box) == 3 else np.diag(np.asarray(system.box, dtype=np.float64).reshape(3, 3)).copy()
+
+    def atoms_of(self, molecule):
+        return self._order[self._start[molecule]:self._start[molecule + 1]]
+
+    def wrap_all(self, x, box=None):
+        box = self.box if box is None else box
+        x = np.asarray(x, dtype=np.float64)
+        counts = np.diff(self._start).astype(np.float64)
+        centre = np.zeros((len(counts), 3))
+        np.add.at(centre, self.molecule_of, x)
+        centre /= counts[:, None]
+        return x - (np.floor(centre / box) * box)[self.molecule_of]
+
+    def shifts_for(self, indices, read_atoms, box=None):
+        """Lattice shifts of the atoms `indices`; read_atoms(idx) -> coordinates of any atoms (used for their molecules' other atoms)."""
+        box = self.box if box is None else box
+        indices = np.asarray(indices, dtype=np.int64)
+        mols = np.unique(self.molecule_of[indices])
+        need = np.concatenate([self.atoms_of(m) for m in mols])
+        xyz = np.asarray(read_atoms(need), dtype=np.float64)
+        shift_of = {}
+        pos = 0
+        for m in mols:
+            k = len(self.atoms_of(m))
+            shift_of[m] = -np.floor(xyz[pos:pos + k].mean(0) / box) * box
+            pos += k
+        return np.array([shift_of[m] for m in self.molecule_of[indices]])
+
+
 class State(object):
     """Result of Context.getState (reference blues/simulation.py:904-910)."""
 
     def __init__(self, positions=None, velocities=None, forces=None, potential=None, kinetic=None, box=None, time=0.0,
-                 parameters=None, snapshot=None):
+                 parameters=None, snapshot=None, wrapper=None):
         self._x, self._v, self._f, self._pe, self._ke, self._box, self._t, self._par = positions, velocities, forces, potential, kinetic, box, time, parameters
         self._snap = snapshot   # positions / velocities still on the device (engine.DeviceSnapshot); downloaded on demand
+        self._wrapper = wrapper  # enforcePeriodicBox: applied to whatever part of the positions reaches the host
 
     @staticmethod
     def _need(v, what):
@@ -27,9 +83,14 @@ class State(object):
     def getPositions(self, asNumpy=False):
         if self._snap is not None and (self._snap.what & 1):
             if asNumpy:
-                return unit.DeviceQuantity(self._snap, 1, "nanometer")
-            return unit.Quantity([tuple(r) for r in self._snap.read(1)], "nanometer")
+                return unit.DeviceQuantity(self._snap, 1, "nanometer", wrapper=self._wrapper)
+            x = self._snap.read(1)
+            if self._wrapper is not None:
+                x = self._wrapper.wrap_all(x)
+            return unit.Quantity([tuple(r) for r in x], "nanometer")
         x = self._need(self._x, "getPositions()")
+        if self._wrapper is not None:
+            x = self._wrapper.wrap_all(x)
         return unit.Quantity(x if asNumpy else [tuple(r) for r in x], "nanometer") if not asNumpy else unit.Quantity(x, "nanometer")
 
     def getVelocities(self, asNumpy=False):
@@ -85,6 +146,14 @@ class Context(object):
         integrator._bind(self._engine)
         self._time = 0.0
         self._platform = Platform()
+        self._wrapper = None   # built on first use (enforcePeriodicBox=True)
+
+    def periodic_wrapper(self):
+        if self._wrapper is None:
+            self._wrapper = PeriodicWrapper(self._system)
+        box = np.asarray(self._engine.get_box(), dtype=np.float64)
+        self._wrapper.box = np.diag(box).copy() if box.shape == (3, 3) else box.reshape(-1)[:3].copy()
+        return self._wrapper
 
     def getState(self, getPositions=False, getVelocities=False, getForces=False, getEnergy=False, getParameters=False,
                  enforcePeriodicBox=False, groups=-1):
@@ -103,7 +172,11 @@ class Context(object):
         par = None
         if getParameters:
             par = {"lambda_sterics": e.get_global("lambda_sterics"), "lambda_electrostatics": e.get_global("lambda_electrostatics")}
-        return State(x, v, f, pe, ke, e.get_box(), self._time, par, snapshot=snap)
+        # (only where the potential itself is periodic: wrapped coordinates handed to a NoCutoff system -- the ethylene fixture of
+        # reference blues/tests/test_ethylene.py -- would change its energies)
+        periodic = getattr(self._system, "nonbonded_method", 1) != 0
+        wrapper = self.periodic_wrapper() if (enforcePeriodicBox and getPositions and periodic and hasattr(self._system, "n_atoms")) else None
+        return State(x, v, f, pe, ke, e.get_box(), self._time, par, snapshot=snap, wrapper=wrapper)
 
     def setPositions(self, positions):
         """reference blues/simulation.py:960, blues/moves.py:307"""
@@ -181,8 +254,53 @@ class Simulation(object):
             self.barostat = MonteCarloBarostat(p_bar, temp, freq, seed=getattr(integrator, "_seed", 0) + 7919 * (replica + 1))
             self._barostat_count = 0
 
-    def minimizeEnergy(self, tolerance=None, maxIterations=0):
-        raise NotImplementedError("energy minimisation is outside the NCMC switching path (tests only in the reference)")
+    def minimizeEnergy(self, tolerance=10.0, maxIterations=0):
+        """app.Simulation.minimizeEnergy (the reference calls it in its test fixtures only, blues/tests/test_simulation.py:139-141).
+        OpenMM runs L-BFGS; here: steepest descent on the engine's forces with an adaptive step -- accepted while the potential
+        energy falls, halved otherwise -- and the constraints re-imposed after every displacement (the procedure of the oracle's
+        orc_minimize).  tolerance: largest force component (kJ/mol/nm) at which to stop; maxIterations 0: up to 500."""
+        e = self.context._engine
+        s = self.system
+        tol = unit.value_in(tolerance, "kilojoule/(nanometer*mole)") if isinstance(tolerance, unit.Quantity) else float(tolerance)
+        mobile = np.asarray(s.mass) > 0
+        ca = np.asarray(getattr(s, "constraint_atoms", []), dtype=np.int64).reshape(-1, 2)
+        cd = np.asarray(getattr(s, "constraint_dist", []), dtype=np.float64).reshape(-1)
+        live = mobile[ca[:, 0]] | mobile[ca[:, 1]] if len(ca) else np.zeros(0, bool)
+        ca, cd = ca[live], cd[live]
+        w = np.where(mobile, 1.0 / np.where(mobile, s.mass, 1.0), 0.0)
+        box = np.diag(np.asarray(e.get_box()).reshape(3, 3))
+
+        def constrain(x, ref):   # SHAKE along the reference bond directions, all constraints per sweep
+            for _ in range(200):
+                d = x[ca[:, 0]] - x[ca[:, 1]]; d -= box * np.round(d / box)
+                diff = (d * d).sum(1) - cd * cd
+                if not len(ca) or np.abs(diff).max() <= 2e-8 * (cd * cd).max():
+                    break
+                r = ref[ca[:, 0]] - ref[ca[:, 1]]; r -= box * np.round(r / box)
+                g = diff / (2.0 * (w[ca[:, 0]] + w[ca[:, 1]]) * (d * r).sum(1))
+                np.add.at(x, ca[:, 0], -(g * w[ca[:, 0]])[:, None] * r)
+                np.add.at(x, ca[:, 1], (g * w[ca[:, 1]])[:, None] * r)
+            return x
+        x = e.get_positions()
+        x = constrain(x.copy(), x)
+        e.set_positions(x)
+        E, f = e.potential_energy(), e.get_forces()
+        step = 0.01
+        for _ in range(int(maxIterations) if maxIterations else 500):
+            fmax = np.abs(f[mobile]).max() if mobile.any() else 0.0
+            if fmax <= tol or step < 1e-7:
+                break
+            xn = x.copy(); xn[mobile] += step * f[mobile] / fmax
+            xn = constrain(xn, x)
+            e.set_positions(xn)
+            En = e.potential_energy()
+            if En < E:
+                x, E, f, step = xn, En, e.get_forces(), step * 1.2
+            else:
+                e.set_positions(x); step *= 0.5
+        v = e.get_velocities()
+        if np.any(v):
+            e.set_velocities(v)   # (unchanged; keeps the engine's velocity bookkeeping in step with the new positions)
 
     def _plan_chunk(self, end):
         """Steps that can be taken before the next reporter is due (at most up to `end`), and the reporters asked."""
@@ -215,12 +333,15 @@ class Simulation(object):
         end = self.currentStep + int(steps)
         while self.currentStep < end:
             chunk, due = self._plan_chunk(end)
-            if self.barostat is not None:
-                # OpenMM counts steps in updateContextState and makes its attempt when the count reaches `frequency`, before that step
-                if self._barostat_count >= self.barostat.frequency:
+            if self.barostat is not None and self.barostat.frequency > 0:   # (frequency 0: OpenMM's "barostat disabled")
+                # OpenMM's updateContextState runs at the top of every step: it increments its counter and makes the attempt when the
+                # counter reaches `frequency` -- i.e. BEFORE the frequency-th step, after frequency - 1 completed ones
+                if self._barostat_count + 1 >= self.barostat.frequency:
                     self.barostat.attempt(self.context._engine, self.system)
-                    self._barostat_count = 0
-                left = self.barostat.frequency - self._barostat_count
+                    self._barostat_count = -1      # (the step that follows is the first of the next period)
+                    left = 1
+                else:
+                    left = self.barostat.frequency - 1 - self._barostat_count
                 if left < chunk:
                     chunk = left
                     due = [(r, nxt) for r, nxt in due if nxt[0] == chunk]

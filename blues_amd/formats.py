@@ -120,3 +120,63 @@ class AmberNetCDFTraj(object):
     def protocolWork(self): return self._var("protocolWork")
     @property
     def alchemicalLambda(self): return self._var("alchemicalLambda")
+
+
+class AmberNetCDFRestart(object):
+    """AMBER NetCDF restart file (Conventions "AMBERRESTART", version 1.0): what the reference writes through
+    parmed.openmm.reporters.RestartReporter(outfname + '.rst7', netcdf=True) (reference blues/reporters.py:217-225) and loads back
+    through parmed.amber.Rst7 (reference blues/settings.py:76-85).  One frame, no `frame` dimension, everything in double:
+    coordinates [atom][spatial] (angstrom), velocities [atom][spatial] (angstrom/picosecond with scale_factor 20.455), time (ps),
+    cell_lengths / cell_angles.  NetCDF-3 with 64-bit offsets through scipy, as the trajectory above."""
+
+    @staticmethod
+    def is_netcdf(path):
+        with open(path, "rb") as fh:
+            return fh.read(3) == b"CDF"
+
+    @staticmethod
+    def write(fname, positions_nm, velocities_nm_ps=None, box_nm=None, time_ps=0.0, title="", angles_deg=(90.0, 90.0, 90.0)):
+        from scipy.io import netcdf_file
+        x = np.asarray(positions_nm, dtype=np.float64).reshape(-1, 3)
+        nc = netcdf_file(fname, "w", version=2, mmap=False)
+        try:
+            nc.Conventions = "AMBERRESTART"; nc.ConventionVersion = "1.0"
+            nc.application = "blues_amd"; nc.program = "blues_amd"; nc.programVersion = "1"
+            nc.title = title or "blues_amd restart"
+            nc.createDimension("spatial", 3); nc.createDimension("atom", len(x))
+            v = nc.createVariable("spatial", "c", ("spatial",)); v[:] = np.array(list("xyz"), dtype="S1")
+            t = nc.createVariable("time", "d", ()); t.units = "picosecond"; t.assignValue(float(time_ps))
+            c = nc.createVariable("coordinates", "d", ("atom", "spatial")); c.units = "angstrom"; c[:] = x * _NM_TO_A
+            if velocities_nm_ps is not None:
+                w = nc.createVariable("velocities", "d", ("atom", "spatial")); w.units = "angstrom/picosecond"; w.scale_factor = AMBER_VELOCITY_SCALE
+                w[:] = np.asarray(velocities_nm_ps, dtype=np.float64).reshape(-1, 3) * (_NM_TO_A / AMBER_VELOCITY_SCALE)
+            if box_nm is not None:
+                nc.createDimension("cell_spatial", 3); nc.createDimension("cell_angular", 3); nc.createDimension("label", 5)
+                v = nc.createVariable("cell_spatial", "c", ("cell_spatial",)); v[:] = np.array(list("abc"), dtype="S1")
+                v = nc.createVariable("cell_angular", "c", ("cell_angular", "label")); v[:] = np.array([list("alpha"), list("beta "), list("gamma")], dtype="S1")
+                l = nc.createVariable("cell_lengths", "d", ("cell_spatial",)); l.units = "angstrom"; l[:] = np.asarray(box_nm, dtype=np.float64).reshape(-1)[:3] * _NM_TO_A
+                g = nc.createVariable("cell_angles", "d", ("cell_angular",)); g.units = "degree"; g[:] = np.asarray(angles_deg, dtype=np.float64)
+        finally:
+            nc.close()
+
+    @staticmethod
+    def read(fname):
+        """-> (positions nm, velocities nm/ps or None, box nm or None, time ps)"""
+        from scipy.io import netcdf_file
+        nc = netcdf_file(fname, "r", mmap=False)
+        try:
+            conv = getattr(nc, "Conventions", b"")
+            conv = conv.decode() if isinstance(conv, bytes) else str(conv)
+            if "AMBERRESTART" not in conv:
+                raise ValueError("%s: NetCDF file with Conventions %r, not an AMBERRESTART file" % (fname, conv))
+            v = nc.variables
+            pos = np.array(v["coordinates"][:], dtype=np.float64) / _NM_TO_A
+            vel = None
+            if "velocities" in v:
+                scale = float(getattr(v["velocities"], "scale_factor", 1.0))
+                vel = np.array(v["velocities"][:], dtype=np.float64) * (scale / _NM_TO_A)
+            box = np.array(v["cell_lengths"][:], dtype=np.float64) / _NM_TO_A if "cell_lengths" in v else None
+            time = float(np.array(v["time"].getValue())) if "time" in v else 0.0
+            return pos, vel, box, time
+        finally:
+            nc.close()

@@ -176,3 +176,25 @@ class BLUESStateDataReporter(_Schedule):
         if self._own and self._out is not None:
             self._out.close()
             self._out = None
+
+
+class RestartReporter(_Schedule):
+    """parmed.openmm.reporters.RestartReporter as the reference configures it (reference blues/reporters.py:217-225:
+    RestartReporter(outfname + '.rst7', netcdf=True, **cfg)): every reportInterval steps the current positions, velocities and
+    box are written as an Amber restart, overwriting the file unless write_multiple (then `<file>.<step>`)."""
+
+    def __init__(self, file, reportInterval=1, write_multiple=False, netcdf=False, write_velocities=True, frame_indices=[]):
+        super(RestartReporter, self).__init__(reportInterval, frame_indices)
+        self.fname, self.write_multiple, self.netcdf, self.write_velocities = file, bool(write_multiple), bool(netcdf), bool(write_velocities)
+
+    def describeNextReport(self, simulation):
+        return (self.steps_to_next(simulation), True, self.write_velocities, False, False)
+
+    def report(self, simulation, state):
+        from .amber import write_rst7
+        from . import unit
+        fname = "%s.%d" % (self.fname, simulation.currentStep) if self.write_multiple else self.fname
+        x = unit.value_in(state.getPositions(asNumpy=True), "nanometer")
+        v = unit.value_in(state.getVelocities(asNumpy=True), "nanometer/picosecond") if self.write_velocities else None
+        box = np.diag(np.asarray(unit.value_in(state.getPeriodicBoxVectors(asNumpy=True), "nanometer")).reshape(3, 3))
+        write_rst7(fname, x, v, box, time_ps=unit.value_in(state.getTime(), "picosecond"), netcdf=self.netcdf)

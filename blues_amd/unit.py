@@ -90,17 +90,20 @@ class DeviceQuantity(Quantity):
     without the full array: the few atoms are fetched, the assignments are remembered and applied on the device when the
     Quantity is handed to setPositions.  Once `_value` has been read the host copy is authoritative."""
 
-    def __init__(self, snapshot, kind, unit):
+    def __init__(self, snapshot, kind, unit, wrapper=None):
         if unit not in _UNITS:
             raise ValueError("unknown unit %r" % unit)
         self.unit = unit
         self._snapshot, self._kind, self._host = snapshot, kind, None
+        self._wrapper = wrapper if kind == 1 else None   # enforcePeriodicBox (context.PeriodicWrapper): applied to what reaches the host
         self._edits = {}   # atom index -> (3,) values in this Quantity's unit, while the array is still on the device
 
     @property
     def _value(self):
         if self._host is None:
             self._host = self._snapshot.read(self._kind).copy()
+            if self._wrapper is not None:
+                self._host = self._wrapper.wrap_all(self._host)
             for i, row in self._edits.items():
                 self._host[i] = row
             self._edits = {}
@@ -142,6 +145,8 @@ class DeviceQuantity(Quantity):
             rows = np.array([self._edits[i] for i in idx], dtype=np.float64).reshape(-1, 3)
         else:
             rows = self._snapshot.read_atoms(self._kind, idx)
+            if self._wrapper is not None:
+                rows = rows + self._wrapper.shifts_for(idx, lambda need: self._snapshot.read_atoms(self._kind, [int(q) for q in need]))
             for j, i in enumerate(idx):
                 if i in self._edits:
                     rows[j] = self._edits[i]

@@ -22,7 +22,8 @@ def test_molecules_and_rigid_scaling(tol_box):
 
 
 def test_volume_moves_through_the_simulation_mirror(oracle_backed_context, tol_box):
-    """Simulation.step makes an attempt before every 25th step; the Metropolis weight is dU + P dV - N kT ln(V'/V); a rejected move
+    """Simulation.step makes an attempt before every frequency-th step (OpenMM's updateContextState counts at the top of each step and
+    acts when the count reaches `frequency`); frequency 0 disables the barostat; the Metropolis weight is dU + P dV - N kT ln(V'/V); a rejected move
     restores box and coordinates exactly; the step size adapts."""
     ctx = oracle_backed_context
     s, v = tol_box
@@ -39,7 +40,7 @@ def test_volume_moves_through_the_simulation_mirror(oracle_backed_context, tol_b
         sim.step(5)
         if sim.barostat.last is not None and sim.barostat.total_attempted > len(seen):
             seen.append(dict(sim.barostat.last))
-    assert sim.barostat.total_attempted == 11           # before steps 6, 11, ..., 56: the first five steps run without an attempt
+    assert sim.barostat.total_attempted == 12           # before steps 5, 10, ..., 60 (after frequency - 1 completed steps, then every frequency)
     assert sim.currentStep == 60
     acc = [r for r in seen if r["accepted"]]
     assert 0 < len(acc) <= len(seen)
@@ -49,6 +50,11 @@ def test_volume_moves_through_the_simulation_mirror(oracle_backed_context, tol_b
         assert r["w"] == pytest.approx(r["dU"] + sim.barostat.pressure * r["dV"] - n * sim.barostat.kT * np.log((r["volume"] if r["accepted"] else r["volume"] + r["dV"]) / (r["volume"] - r["dV"] if r["accepted"] else r["volume"])), rel=1e-9, abs=1e-9)
     vol1 = np.prod(np.diag(eng.get_box()))
     assert vol1 == pytest.approx(seen[-1]["volume"], rel=1e-12) and abs(vol1 / vol0 - 1) < 0.2
+    # frequency 0 = no barostat: stepping neither hangs nor attempts
+    sim.barostat.frequency = 0
+    sim.step(7)
+    assert sim.currentStep == 67 and sim.barostat.total_attempted == 12
+    sim.barostat.frequency = 5
     # a rejected attempt leaves the state bit for bit where it was
     b = sim.barostat
     b.pressure = 1e9          # an absurd pressure rejects every expansion

@@ -94,3 +94,85 @@ def test_state_data_reporter_lines(oracle_backed_context, tol_box):
     assert float(cols[7]) == pytest.approx(2 * sim.context._engine.kinetic_energy() / (ndof * 0.0083144626), rel=1e-9)
     with pytest.raises(ValueError):
         reporters.BLUESStateDataReporter(out, progress=True)
+
+
+def test_netcdf_restart_round_trip_and_layout(tmp_path):
+    """The Amber restart as the reference writes and reads it: parmed's RestartReporter(outfname + '.rst7', netcdf=True)
+    (reference blues/reporters.py:217-225) -> parmed.amber.Rst7 (blues/settings.py:76-85).  Round trip in OpenMM units, the AMBERRESTART
+    layout on disk (NetCDF-3 64-bit offsets, no frame dimension, doubles, velocity scale factor 20.455), the ASCII form still read,
+    and the reporter mirror writing through a State."""
+    from scipy.io import netcdf_file
+    from blues_amd import amber, formats, reporters, unit
+    rng = np.random.RandomState(4)
+    n = 37
+    x, v, box = rng.uniform(-1, 5, (n, 3)), rng.normal(0, 0.5, (n, 3)), np.array([4.3572, 6.5358, 8.7144])
+    p = str(tmp_path / "restart.rst7")
+    amber.write_rst7(p, x, v, box, time_ps=12.5, netcdf=True)
+    with open(p, "rb") as fh:
+        assert fh.read(4) == b"CDF\x02"                      # classic format, 64-bit offsets
+    assert formats.AmberNetCDFRestart.is_netcdf(p)
+    x2, v2, box2 = amber.read_rst7(p)                         # dispatches on the magic bytes
+    assert np.allclose(x2, x, rtol=0, atol=1e-13) and np.allclose(v2, v, rtol=1e-14, atol=1e-14) and np.allclose(box2, box, atol=1e-13)
+    nc = netcdf_file(p, "r", mmap=False)
+    try:
+        assert nc.Conventions == b"AMBERRESTART" and nc.ConventionVersion == b"1.0"
+        assert "frame" not in nc.dimensions and nc.dimensions["atom"] == n and nc.dimensions["spatial"] == 3
+        c, w = nc.variables["coordinates"], nc.variables["velocities"]
+        assert c.dimensions == ("atom", "spatial") and c.typecode() == "d" and c.units == b"angstrom"
+        assert w.units == b"angstrom/picosecond" and w.scale_factor == pytest.approx(20.455)
+        assert np.allclose(np.array(c[:]), x * 10.0) and np.allclose(np.array(w[:]) * 20.455, v * 10.0)      # angstrom; Amber's time unit
+        assert nc.variables["time"].units == b"picosecond" and float(nc.variables["time"].getValue()) == 12.5
+        assert np.allclose(np.array(nc.variables["cell_lengths"][:]), box * 10.0) and np.allclose(np.array(nc.variables["cell_angles"][:]), 90.0)
+        assert bytes(np.array(nc.variables["cell_angular"][:]).tobytes()) == b"alphabeta gamma"
+    finally:
+        nc.close()
+    # a NetCDF file that is not a restart is refused, the ASCII form is still read
+    traj = str(tmp_path / "traj.nc")
+    t = formats.AmberNetCDFTraj.open_new(traj, n, True); t.add_coordinates(x); t.add_cell_lengths_angles(box); t.add_time(0.0); t.close()
+    with pytest.raises(ValueError, match="AMBERRESTART"):
+        formats.AmberNetCDFRestart.read(traj)
+    pa = str(tmp_path / "ascii.rst7")
+    amber.write_rst7(pa, x, v, box)
+    xa, va, ba = amber.read_rst7(pa)
+    assert np.allclose(xa, x, atol=1e-7) and np.allclose(va, v, atol=1e-5) and np.allclose(ba, box, atol=1e-7)
+
+    class _State:
+        def getPositions(self, asNumpy=False): return unit.Quantity(x, "nanometer")
+        def getVelocities(self, asNumpy=False): return unit.Quantity(v, "nanometer/picosecond")
+        def getPeriodicBoxVectors(self, asNumpy=False): return unit.Quantity(np.diag(box), "nanometer")
+        def getTime(self): return unit.Quantity(3.0, "picosecond")
+
+    class _Sim:
+        currentStep = 40
+    rep = reporters.RestartReporter(str(tmp_path / "out.rst7"), reportInterval=20, netcdf=True)
+    assert rep.describeNextReport(_Sim())[:3] == (20, True, True)
+    rep.report(_Sim(), _State())
+    x3, v3, b3 = amber.read_rst7(str(tmp_path / "out.rst7"))
+    assert np.allclose(x3, x, atol=1e-13) and np.allclose(v3, v, atol=1e-13) and np.allclose(b3, box, atol=1e-13)
+
+
+def test_enforce_periodic_box_wraps_whole_molecules(oracle_backed_context, tol_box):
+    """getState(enforcePeriodicBox=True) (reference blues/simulation.py:874-881): every molecule's centre inside the box, molecules whole,
+    lattice translations only; a Move's positions[atom_indices] sees the same wrapped coordinates as the full array."""
+    from blues_amd import integrators, unit
+    from blues_amd.context import PeriodicWrapper
+    s, v = tol_box
+    box = np.asarray(s.box)
+    sim = oracle_backed_context.Simulation(None, s, integrators.generateNCMCIntegrator(nstepsNC=4, dt=0.002, seed=1))
+    x = np.array(s.positions, dtype=float)
+    x[:15] += box * np.array([2, -1, 0])            # the ligand two boxes away; one water one box away
+    x[15:18] -= box * np.array([0, 0, 1])
+    sim.context.setPositions(unit.Quantity(x, "nanometer"))
+    raw = sim.context.getState(getPositions=True).getPositions(asNumpy=True)._value
+    wrapped = sim.context.getState(getPositions=True, enforcePeriodicBox=True).getPositions(asNumpy=True)._value
+    w = PeriodicWrapper(s)
+    assert len(np.unique(w.molecule_of)) == 1 + (s.n_atoms - 15) // 3 and len(set(w.molecule_of[:15])) == 1
+    d = (wrapped - raw) / box
+    assert np.allclose(d, np.round(d), atol=1e-12)                                       # lattice translations only
+    for m in range(w.molecule_of.max() + 1):
+        a = w.atoms_of(m)
+        assert len(np.unique(np.round(d[a]), axis=0)) == 1                               # the same one for a whole molecule
+        c = wrapped[a].mean(0)
+        assert np.all(c >= -1e-12) and np.all(c < box + 1e-12)                           # centre inside the box
+    sh = w.shifts_for(list(range(15)), lambda need: raw[np.asarray(need)])
+    assert np.allclose(raw[:15] + sh, wrapped[:15], atol=1e-12)
