@@ -145,10 +145,10 @@ class AmberNetCDFRestart(object):
             nc.title = title or "blues_amd restart"
             nc.createDimension("spatial", 3); nc.createDimension("atom", len(x))
             v = nc.createVariable("spatial", "c", ("spatial",)); v[:] = np.array(list("xyz"), dtype="S1")
-            t = nc.createVariable("time", "d", ()); t.units = "picosecond"; t.assignValue(float(time_ps))
+            t = nc.createVariable("time", "d", ()); t.units = "picosecond"; t[...] = float(time_ps)   # (a scalar variable; scipy's assignValue indexes it with [:])
             c = nc.createVariable("coordinates", "d", ("atom", "spatial")); c.units = "angstrom"; c[:] = x * _NM_TO_A
             if velocities_nm_ps is not None:
-                w = nc.createVariable("velocities", "d", ("atom", "spatial")); w.units = "angstrom/picosecond"; w.scale_factor = AMBER_VELOCITY_SCALE
+                w = nc.createVariable("velocities", "d", ("atom", "spatial")); w.units = "angstrom/picosecond"; w.scale_factor = np.float64(AMBER_VELOCITY_SCALE)   # (a double, as the restart convention has it)
                 w[:] = np.asarray(velocities_nm_ps, dtype=np.float64).reshape(-1, 3) * (_NM_TO_A / AMBER_VELOCITY_SCALE)
             if box_nm is not None:
                 nc.createDimension("cell_spatial", 3); nc.createDimension("cell_angular", 3); nc.createDimension("label", 5)
