@@ -110,7 +110,8 @@ struct BluesSnapshot {
     int n = 0; bool has_x = false, has_v = false;
     double* x[3] = {nullptr, nullptr, nullptr}; double* v[3] = {nullptr, nullptr, nullptr};
     double* block = nullptr;   // one allocation: x[0..2], v[0..2]
-    ECache ecache;   // potential energies that were known for the captured positions
+    ECache ecache;   // potential energies that were known for the captured positions ...
+    uint64_t box_epoch = 0;   // ... in the box the owner had then (a barostat move or set_box in between makes them stale)
 };
 
 struct BluesEngine {
@@ -119,6 +120,7 @@ struct BluesEngine {
     // replica batching (see BluesBatch below): while the batch is in lock step the leader's launches cover every
     // replica (gridDim.y) and the other members only advance their mirrored control state
     BluesBatch* batch = nullptr; int batch_index = -1; hipStream_t own_stream = nullptr;
+    uint64_t box_epoch = 1;   // bumped by every change of the box: cached energies of a State are only good in the box they were computed in
     int batch_R = 1;  // replicas sharing this engine's launches (shapes the launch decomposition in sort_and_tile)
     uint64_t args_epoch = 1;  // bumped whenever a device buffer referenced by the argument records is (re)allocated
     hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, cur = nullptr;
@@ -151,6 +153,7 @@ struct BluesEngine {
     // around each velocity-Verlet step (shadow work / Metropolis test) is done on the host with synchronous energies
     int switch_mode = 0, psteps = 1; std::string split_first;
     double sw_Epert = 0.0, sw_shadow = 0.0, sw_Einit = 0.0, sw_Efinal = 0.0, sw_bracket_E0 = 0.0; int sw_accept = 0, sw_naccept = 0, sw_ntrials = 0;
+    unsigned sw_draw = 0;   // Metropolis uniforms drawn so far by the GHMC integrator: the Philox counter; reset() does NOT touch it (ntrials is a statistic)
     bool sw_bracket_open = false; struct BluesSnapshot* sw_saved = nullptr;
     std::vector<double> tab_ls, tab_le;
     uint64_t seed = 0; int replica = 0;
@@ -1621,7 +1624,9 @@ static int switching_close(BluesEngine* h) {
         return 0;
     }
     uint32_t r[4];
-    philox4x32((uint32_t)h->sw_ntrials, 0u, (uint32_t)h->replica * 4u + 2u, 0x47484D43u, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), r);
+    // keyed on a counter that only ever grows: keyed on ntrials, which reset() zeroes, every switch would have met the same
+    // sequence of thresholds u_1, u_2, ... (correlated accept/reject decisions across BLUES iterations)
+    philox4x32((uint32_t)h->sw_draw++, 0u, (uint32_t)h->replica * 4u + 2u, 0x47484D43u, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), r);
     const double u = ((double)r[0] + 0.5) * 2.3283064365386963e-10;
     h->sw_accept = (exp(-((ke + E) - h->sw_bracket_E0) / h->kT) - u >= 0.0) ? 1 : 0;   // Lepton step(x): 1 for x >= 0
     if (!h->sw_accept) {
@@ -2395,8 +2400,9 @@ int blues_set_box(BluesEngine* h, const double box[9]) {
     HIP_OK(h, hipSetDevice(h->device));
     if (flush_program(h)) return 1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 3; k++) if (box[4 * k] < 2.0 * h->cutoff) E_FAIL(h, "box edge %g < 2*cutoff", box[4 * k]);   // (before anything is changed: a refused box leaves the engine as it was)
     h->box[0] = box[0]; h->box[1] = box[4]; h->box[2] = box[8];
-    for (int k = 0; k < 3; k++) if (h->box[k] < 2.0 * h->cutoff) E_FAIL(h, "box edge %g < 2*cutoff", h->box[k]);
+    h->box_epoch++;
     derive_margins(h);   // (the layout re-derives the skin for the new box)
     h->sorted_ok = false; h->pass_valid = false; h->e_frozen_valid = false; h->ecache.clear();
     if (h->pme && (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h))) return 1;
@@ -2710,6 +2716,7 @@ int blues_snapshot_capture(BluesEngine* h, int32_t what, BluesSnapshot** out) {
     h->st_launches++;
     if (h->acc_cache_valid && h->acc_cache_stamp + 1 == h->st_launches) h->acc_cache_stamp = h->st_launches;   // (a copy of x, v does not touch the accumulators)
     sn->ecache = h->ecache; if (!(what & 1)) sn->ecache.clear();
+    sn->box_epoch = h->box_epoch;
     HIP_OK(h, hipGetLastError());
     *out = sn;
     return 0;
@@ -2762,7 +2769,7 @@ int blues_set_positions_from_snapshot(BluesEngine* h, const BluesSnapshot* sn) {
     const double* src[3] = {sn->x[0], sn->x[1], sn->x[2]};
     if (load_positions(h, src, 1, 0)) return 1;
     // the energy that was known for these positions is known again (OpenMM re-evaluates; same value)
-    if (sn->owner == h) h->ecache = sn->ecache;
+    if (sn->owner == h) { if (sn->box_epoch == h->box_epoch) h->ecache = sn->ecache; }   // (not across a change of the box)
     else if (resolve_xfer(h)) return 1;   // another engine's snapshot: its owner may recycle the buffer on its own stream
     return 0;
 }
@@ -3002,6 +3009,7 @@ int blues_batch_snapshot_capture(BluesBatch* B, int32_t what, const int32_t* mas
         if (what & 1) for (int k = 0; k < 3; k++) { c.src[c.count] = h->d_x[k].p; c.dst[c.count++] = sn->x[k]; }
         if (what & 2) for (int k = 0; k < 3; k++) { c.src[c.count] = h->d_v[k].p; c.dst[c.count++] = sn->v[k]; }
         sn->ecache = h->ecache; if (!(what & 1)) sn->ecache.clear();
+        sn->box_epoch = h->box_epoch;
         h->st_launches++;
         if (h->acc_cache_valid && h->acc_cache_stamp + 1 == h->st_launches) h->acc_cache_stamp = h->st_launches;   // (a copy of x, v does not touch the accumulators)
         out[r] = sn;
@@ -3104,7 +3112,7 @@ static int batch_restore_impl(BluesBatch* B, BluesSnapshot* const* snaps, int wh
             h->xfer_pending = true; h->xfer_stream = h->stream; h->xfer_src = B->h_xfer_all + 4 * r;
             h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear(); h->lists_forced = true;
             h->st_launches += n_idx > 0 ? 2 : 1;
-            if (snaps[r]->owner == h && n_idx == 0) h->ecache = snaps[r]->ecache;   // the energy that was known for these positions is known again
+            if (snaps[r]->owner == h && n_idx == 0 && snaps[r]->box_epoch == h->box_epoch) h->ecache = snaps[r]->ecache;   // the energy that was known for these positions (in this box) is known again
             if (resolve_xfer(h)) { B->err = h->err; return 1; }   // (already on the host: no wait)
         }
         if (what & 2) { h->st_launches++; h->vel_clean = false; h->ke_cache_valid = false; }

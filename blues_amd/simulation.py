@@ -22,11 +22,20 @@ rtol = 6  # reference blues/simulation.py:26-27
 class SimulationSet(object):
     """The `simulations` object BLUESSimulation expects: attributes md, alch, ncmc
     (reference blues/simulation.py:768-809).  md / alch may be None: the MD leg is then skipped
-    and the alchemical-correction energies are taken from the NCMC engine at lambda=1, which is
-    exactly the MD potential in the direct-space-only model."""
+    and the alchemical-correction energies (reference simulation.py:1100-1119) are taken from the NCMC engine at lambda = 1.
+    In the direct-space model (BLUES_NB_PME_DIRECT) that IS the MD potential.  With reciprocal space (BLUES_NB_PME) it is not: the
+    alchemical System keeps the ligand's charges out of the mesh, the self term and the excluded-pair corrections, and its epsilons
+    out of the dispersion correction (alchemical_pme_treatment='direct-space', disable_alchemical_dispersion_correction=True), so
+    E(lambda = 1) of that System differs from the MD System's energy by the ligand's reciprocal-space and long-range terms and the
+    correction comes out near zero instead of the reference's value: hand in `alch` (and `md`) Simulations built from the
+    NON-alchemical System, as the reference does, or accept the warning below (throughput runs)."""
 
     def __init__(self, ncmc, md=None, alch=None):
         self.ncmc, self.md, self.alch = ncmc, md, alch
+        system = getattr(ncmc, "system", None)
+        if alch is None and getattr(system, "nonbonded_method", None) == 2 and len(getattr(system, "alchemical_atoms", [])):
+            logger.warning("SimulationSet without an `alch` Simulation on a PME System: the alchemical correction will use E(lambda=1) of the "
+                           "alchemical System, which lacks the ligand's reciprocal-space, self, excluded-pair and dispersion terms")
 
 
 class BLUESSimulation(object):

@@ -56,6 +56,7 @@ typedef struct {
 } Globals;
 
 struct Oracle {
+    uint32_t ghmc_draw;   /* Metropolis uniforms drawn so far by the GHMC integrator: the Philox counter (never reset: ntrials is a statistic) */
     int n;
     double box[3];
     double *mass, *charge, *sigma, *eps;
@@ -1186,7 +1187,7 @@ static void ghmc_step(Oracle *o) {
     memcpy(xold, o->x, sizeof(double) * n3); memcpy(vold, o->v, sizeof(double) * n3);
     velocity_verlet(o);
     const double Enew = orc_kinetic_energy(o) + cached_energy(o);
-    const double u = uniform_for_trial(o, (uint32_t)o->g.ntrials);
+    const double u = uniform_for_trial(o, o->ghmc_draw++);   /* (keyed on ntrials, which reset() zeroes, every switch would meet the same thresholds) */
     o->g.accept = (exp(-(Enew - Eold) / o->kT) - u >= 0.0) ? 1.0 : 0.0;   /* Lepton step(x) = 1 for x >= 0 */
     if (o->g.accept != 1.0) {
         memcpy(o->x, xold, sizeof(double) * n3); o->xver++;

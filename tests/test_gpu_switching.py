@@ -68,6 +68,17 @@ def test_ghmc_switching_matches_the_oracle(Engine, oracle_mod, tol_box, precisio
     assert g.get_global("total_work") == pytest.approx(o.get_global("total_work"), rel=tol) and g.get_global("shadow_work") == 0.0
     assert np.abs(g.get_positions() - o.get_positions()).max() < (1e-9 if precision else 5e-5)
     assert np.abs(g.get_velocities() - o.get_velocities()).max() < (1e-8 if precision else 5e-3)
+    if precision == 1:
+        # a second switch after reset(): the Metropolis uniforms carry on in the Philox stream (keyed on a counter reset() does not
+        # touch -- keyed on ntrials every switch would meet the same thresholds); engine and oracle stay in step trial by trial
+        first = (g.get_global("naccept"), g.get_global("ntrials"))
+        g.reset(); o.reset()
+        x0 = o.get_positions(); g.set_positions(x0); o.set_positions(x0)
+        g.step(8); o.step(8)
+        assert g.get_global("ntrials") == o.get_global("ntrials") == first[1]
+        assert g.get_global("naccept") == o.get_global("naccept")
+        assert g.get_global("total_work") == pytest.approx(o.get_global("total_work"), rel=1e-8)
+        assert np.abs(g.get_positions() - o.get_positions()).max() < 1e-8
 
 
 def test_instantaneous_toggle_and_mirror_accessors(Engine, oracle_mod, tol_box):
