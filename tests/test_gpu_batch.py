@@ -706,14 +706,16 @@ def test_configs3_full_size_water_switch_properties():
     class Outside(moves.WaterTranslationMove):
         def _random_sphere_point(self, radius, origin):
             d = super()._random_sphere_point(radius, origin) - origin
-            return origin + d / np.linalg.norm(d) * radius * 1.15
+            return origin + d / np.linalg.norm(d) * radius * 1.5
     chains = []
     for r in range(R):
         integ = integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=0.004, temperature=300.0, seed=9000 + r)
         sim = Simulation(None, system, integ, precision="mixed", replica=r)
         sim.context.setVelocities(unit.Quantity(vel, "nanometer/picosecond"))
         cls = Outside if r == R - 1 else moves.WaterTranslationMove
-        mover = moves.MoveEngine(cls(waters, np.arange(15), system.mass[:15], radius=2.0))
+        # (the chain that must be rejected: a 1 nm sphere and a placement at 1.5 nm -- half a nanometre is more than a water diffuses
+        # back in the 4 ps that remain; with the 2 nm sphere of the example the box's half edge, 2.18 nm, leaves no room outside)
+        mover = moves.MoveEngine(cls(waters, np.arange(15), system.mass[:15], radius=1.0 if cls is Outside else 2.0))
         chains.append(simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": 1}, mover,
                                                  rng=np.random.RandomState(60 + r)))
     np.random.seed(21)

@@ -58,7 +58,7 @@ def test_pruned_lists_hold_every_pair_in_range(Engine, oracle_mod, tune):
     assert np.linalg.norm(fp - fo) <= 1e-5 * np.linalg.norm(fo)
     st = p.stats()
     n_i = int((s.mass > 0).sum()) - len(s.alchemical_atoms)
-    assert st["atom_prunes"] > n_i * (st["list_generation"] + 1), st     # (iii) every rebuild prunes every atom once; the atoms ask for more in between
+    assert st["atom_prunes"] > n_i, st     # (iii) a rebuild writes every atom's pruned list itself; in between the atoms asked for more than one prune each
     assert 0 < st["pruned_list_entries"] < 0.85 * st["atom_list_entries"], st
     assert q.stats()["atom_prunes"] == 0
     p.close(); q.close()
