@@ -159,14 +159,14 @@ def cpu_baseline(system, vel, nsteps_sample):
     return out
 
 
+PMC_FILE = "profiles/r03_pmc_nonbonded.json"
+
+
 def kernel_source_sha():
-    """Identifies the build of the nonbonded kernel the PMC evidence was taken on (profiles/*pmc*.json carry the same hash)."""
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("kernels_nb.h", "device_common.h", "kernels_batch.h"):
-        with open(os.path.join(ROOT, "blues_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    """Identifies the build the PMC evidence was taken on (profiles/*pmc*.json carry the same hash): every source of the library AND
+    the compiler flags (blues_amd/build.py)."""
+    from blues_amd import build
+    return build.source_sha()
 
 
 def pmc_evidence(workload, R):
@@ -174,7 +174,7 @@ def pmc_evidence(workload, R):
     cannot be collected inside this run; they are only reported when they were taken on THIS build of the kernel (source
     hash) and this workload / batch size -- otherwise null, never a stale number."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_nonbonded.json")) as fh:
+        with open(os.path.join(ROOT, PMC_FILE)) as fh:
             table = json.load(fh)
         e = table.get("%s_R%d" % (workload, R))
         if e and e.get("source_sha") == kernel_source_sha():
@@ -281,6 +281,8 @@ def main():
     ap.add_argument("--reciprocal", action="store_true", help="PME in full: reciprocal-space mesh, self, excluded-pair and dispersion terms on top of the direct-space sum "
                     "(the switching path north_star names is the direct-space one; this adds SURVEY.md 8f.2)")
     ap.add_argument("--launch-check", action="store_true", help="CPU-only check of the N-rank launch path (gloo, no engine)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the stand-alone launches of the nonbonded kernel at the end (counter-collection runs: "
+                    "every launch of the kernel in the trace is then one of the stepping loop)")
     args = ap.parse_args()
 
     # ---- N ranks: either a launcher (torch.distributed.run) already started us as one of them, or we start them ourselves
@@ -389,13 +391,23 @@ def main():
     clock = {k: max(ck[k] for ck in clocks) for k in clocks[0]}
     b0 = {k: sum(b[k] for b in b0) / G for k in b0[0]}; b1 = {k: sum(b[k] for b in b1) / G for k in b1[0]}
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tmin = t.clone()
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+    rank_elapsed = {"max": float(t.item()), "min": float(tmin.item()), "this_rank": elapsed}   # (host imbalance between ranks shows here first)
     elapsed = float(t.item())
 
     # the kernel north_star prices against the HBM roofline: the direct-space nonbonded kernel, timed alone with HIP
     # events on the batch's own stream; one launch processes all R chains of this rank
-    k1_us = drivers[0]._ncmc_batch.time_nonbonded(50)
+    # (with pruned per-atom lists an atom is served from its current pruned list or -- a few percent of the atoms of a pass -- from its
+    # full list while the pruned one is re-derived: both kinds of launch are timed, k1_us is their mean weighted with the share of
+    # the second kind in THIS run's force passes; profiles/ holds the rocprofv3 average over the stepping loop beside it)
+    if args.no_kernel_timing:
+        k1_pruned = k1_full = k1_us = float("nan"); prune_share = float("nan")
+    else:
+        k1_pruned, k1_full, prune_share = drivers[0]._ncmc_batch.time_nonbonded_modes(50)
+        k1_us = (1.0 - prune_share) * k1_pruned + prune_share * k1_full
     R_launch = len(groups[0])
     if rank == 0:
         n_atoms = system.n_atoms
@@ -415,14 +427,17 @@ def main():
         roofline = {"bound": "valu" if ev else "valu (counters not taken on this build: see profiles/README.md)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "kernel": "%s (direct-space LJ + erfc Coulomb; one launch = %d chains, timed alone with HIP events)" % ({0: "k_nonbonded_b", 1: "k_nonbonded_sub_b", 2: "k_nonbonded_atom_b"}[est["nonbonded_kernel"]], R_launch),
-                    "usec_per_launch": k1_us, "algorithmic_bytes_per_launch": algo,
+                    "usec_per_launch": k1_us, "usec_per_launch_by_kind": {"pruned_lists": k1_pruned, "re_deriving_every_list": k1_full, "share_of_atoms_re_deriving": prune_share},
+                    "algorithmic_bytes_per_launch": algo,
                     "algorithmic_bytes_definition": "36 B x all %d atoms x %d chains (SURVEY.md 8d: nominal, defined on all atoms)" % (n_atoms, R_launch),
                     "traffic": ev["traffic_bytes_per_launch"] if ev and "traffic_bytes_per_launch" in ev else None,
                     "mobile_only": {"algorithmic_bytes": mob_bytes, "achieved": mob_bytes / secs / 1e9, "frac": mob_bytes / secs / 1e9 / HBM_PEAK_GBS,
                                     "definition": "24 B x %d environment atoms within the cutoff of a mobile atom + 12 B x %d mobile atoms, per chain" % (n_touched, n_i)},
-                    "pairs": {"in_range_per_launch": n_pairs * R_launch, "listed_per_launch": est["atom_list_entries"] * R_launch,
-                              "lane_efficiency": n_pairs / max(1.0, 64.0 * est["atom_list_iterations"]) if est["atom_list_iterations"] else None,
-                              "note": "lane efficiency = pairs inside the cutoff / (wave iterations x 64 lanes) of the per-atom lists (chain 0, at its last rebuild)"}}
+                    "pairs": {"in_range_per_launch": n_pairs * R_launch,
+                              "listed_per_launch": (est["pruned_list_entries"] if est.get("pruned_lists") else est["atom_list_entries"]) * R_launch,
+                              "full_lists_per_launch": est["atom_list_entries"] * R_launch,
+                              "lane_efficiency": n_pairs / max(1.0, 64.0 * (est["pruned_list_iterations"] if est.get("pruned_lists") else est["atom_list_iterations"])),
+                              "note": "lane efficiency = pairs inside the cutoff / (wave iterations x 64 lanes) of the lists the kernel walks (the pruned per-atom lists; chain 0, end of the run)"}}
         if ev:
             c = ev["counters_per_launch"]
             insts = c.get("SQ_INSTS_VALU")
@@ -435,7 +450,7 @@ def main():
                 if c.get("SQ_INSTS_VALU_TRANS_F32"):
                     v["transcendental_insts_per_launch"] = c["SQ_INSTS_VALU_TRANS_F32"]
                 roofline["valu"] = v
-            roofline["pmc_source"] = {"file": "profiles/r02_pmc_nonbonded.json", "source_sha": ev["source_sha"], "kernel": ev["kernel"]}
+            roofline["pmc_source"] = {"file": PMC_FILE, "source_sha": ev["source_sha"], "kernel": ev["kernel"]}
         out = {
             "metric": "NCMC ns/day (23k-atom toluene box, 1000-step switch, RandomLigandRotationMove), aggregate over independent chains",
             "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -449,7 +464,9 @@ def main():
                        "parallelism": "%d replica batch(es) x %d chains per gpu, %d gpu(s)" % (G, R_launch, world)},
             "roofline": roofline,
             "single_replica": single,
+            "rank_elapsed_seconds": rank_elapsed,
             "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup,
+                       "plugin_boundary": "one call per operation for all chains (blues_batch_*)" if drivers[0]._batchable() else "chain by chain",
                        "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,
                        "list_rebuilds_per_switch": (st1["list_generation"] - st0["list_generation"]) / args.steps,
                        "own_energy_evaluations_per_switch": (st1["own_energy_evaluations"] - st0["own_energy_evaluations"]) / args.steps,

@@ -553,7 +553,9 @@ static int sort_and_tile(BluesEngine* h) {
         // the outer margin, and the rebuild trigger is the margin minus the inner one: the margin grows by it (same rebuild rate)
         const bool mostly_frozen = 4 * h->mobile.size() <= (size_t)h->n && !h->tune.plain_skin;
         const double m = h->tune.prune_margin < 0.0 ? 0.04 : h->tune.prune_margin;
-        h->skin = h->n_itiles * h->batch_R <= 32 ? 0.3 : (mostly_frozen ? 0.12 + m : 0.12);
+        // (measured at R = 512, us per step: margin 0.12: 661, 0.14: 587, 0.16: 574, 0.20: 554, 0.24: 550, 0.28: 557 -- the rebuild
+        // kernels cost in proportion to the members that rebuild, the pruned lists make the nonbonded kernel indifferent)
+        h->skin = h->n_itiles * h->batch_R <= 32 ? 0.3 : (mostly_frozen && m > 0.0 ? 0.16 + m : 0.12);
     }
     derive_margins(h);
     // capacities

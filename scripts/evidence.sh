@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/ev_$tag; rm -rf $out; mkdir -p $out
 python3 bench.py "$@" > $out/bench.log 2>&1; tail -1 $out/bench.log > $out/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-single "$@" > $out/stats.log 2>&1; rm -f $out/stats/*/*kernel_trace.csv
-for c in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
+for c in ${PMC_COUNTERS:-}; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-single --nsteps-nc 40 "$@" > $out/pmc_$c.log 2>&1
 done
 python3 - <<PY

@@ -1,14 +1,13 @@
 """Reduces the rocprofv3 --pmc passes of scripts/pmc_nb.sh to one JSON: per-launch means of the batched nonbonded kernel's counters
-(the standalone launches bench.py times at the end: the last 50 dispatches of the kernel), with the gfx950 corrections of
+(the force launches of the stepping loop; bench.py runs with --no-kernel-timing so that the trace holds nothing else), with the gfx950 corrections of
 MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read: doubled; SQ_*_CYCLES / SQ_ACTIVE_* are quad-cycles)."""
 import csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = sys.argv[1]
+sys.path.insert(0, ROOT)
 def source_sha():
-    h = hashlib.sha256()
-    for f in ("kernels_nb.h", "device_common.h", "kernels_batch.h"):
-        h.update(open(os.path.join(ROOT, "blues_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    from blues_amd import build
+    return build.source_sha()   # every source of the library + the compiler flags
 res = {}; kernel = None; durations = {}
 for f in sorted(glob.glob(out + "/g*/*/*counter_collection.csv")):
     per = {}
@@ -19,12 +18,12 @@ for f in sorted(glob.glob(out + "/g*/*/*counter_collection.csv")):
         kernel = n
         per.setdefault(int(r["Dispatch_Id"]), {}).setdefault(r["Counter_Name"], 0.0)
         per[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
-    ids = sorted(per)[-50:]
+    ids = sorted(per)[3:]   # every force launch of the stepping loop but the first few (bench.py --no-kernel-timing: no stand-alone launches in the trace)
     for c in set(k for d in per.values() for k in d):
         vals = [per[i][c] for i in ids if c in per[i]]
         if vals:
             res[c] = sum(vals) / len(vals)
-d = {"_how": "scripts/pmc_nb.sh: rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-single --nsteps-nc 40 " + " ".join(sys.argv[2:]) + "; mean over the last 50 launches of the kernel",
+d = {"_how": "scripts/pmc_nb.sh: rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-single --no-kernel-timing --nsteps-nc 200 " + " ".join(sys.argv[2:]) + "; mean over the force launches of the stepping loop",
      "kernel": kernel, "source_sha": source_sha(), "bench_args": sys.argv[2:], "counters_per_launch": res}
 if "FETCH_SIZE" in res or "WRITE_SIZE" in res:
     # FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3's derived metric
