@@ -257,6 +257,7 @@ def declare_engine_prototypes(lib):
         "blues_get_stats": ([H, C.POINTER(C.c_int64)], C.c_int),
         "blues_time_nonbonded": ([H, C.c_int32, _dp], C.c_int),
         "blues_time_list_build": ([H, C.c_int32, _dp], C.c_int),
+        "blues_audit_lists": ([H, C.POINTER(C.c_int64)], C.c_int),
         "blues_snapshot_capture": ([H, C.c_int32, C.POINTER(H)], C.c_int),
         "blues_snapshot_release": ([H], C.c_int),
         "blues_snapshot_read": ([H, C.c_int32, _dp, C.c_int32], C.c_int),
@@ -294,7 +295,7 @@ ENGINE_SYMBOLS = (
     "blues_set_positions", "blues_set_velocities", "blues_set_box", "blues_get_positions",
     "blues_get_velocities", "blues_get_forces", "blues_get_box", "blues_set_velocities_to_temperature",
     "blues_get_energy", "blues_get_energy_at", "blues_get_energy_terms", "blues_step", "blues_run_switch", "blues_get_global",
-    "blues_set_global", "blues_reset", "blues_get_stats", "blues_time_nonbonded", "blues_time_list_build",
+    "blues_set_global", "blues_reset", "blues_get_stats", "blues_time_nonbonded", "blues_time_list_build", "blues_audit_lists",
     "blues_snapshot_capture", "blues_snapshot_release", "blues_snapshot_read", "blues_set_positions_from_snapshot",
     "blues_set_velocities_from_snapshot", "blues_snapshot_read_atoms", "blues_set_positions_from_snapshot_edited",
     "blues_batch_create", "blues_batch_destroy", "blues_batch_last_error", "blues_batch_size", "blues_batch_step", "blues_batch_set_active", "blues_batch_prefetch_energies",

@@ -141,7 +141,7 @@ struct BluesEngine {
     double skin = 0.12; bool skin_fixed = false;
     double skin_m = 0.12, trig = 0.06;   // margin of MOBILE list candidates, and the displacement that asks for a rebuild (derive_margins)
     // pruned per-atom lists (nonbonded_atom_body): inner margins for frozen / mobile candidates, displacement that asks for a prune
-    bool prune_on = false; double prune_m = 0.0, prune_m_mobile = 0.0, ptrig = 0.0;
+    bool prune_on = false; double prune_m = 0.0, ptrig = 0.0;
     EwaldPoly ewpoly;   // degree-9 fit of the smooth part of the Ewald pair force (fit_ewald_poly), mixed precision
     // ---- integrator
     double dt = 0, temperature = 0, gamma = 1, kT = 0, tol = 1e-8;
@@ -291,12 +291,7 @@ static Box3 make_box(const BluesEngine* h) {
 // 2 trig.  Where nearly everything is frozen (freeze_radius, reference blues/simulation.py:394-480) the few mobile
 // candidates get the double margin and trig = skin: the same lists last twice the displacement.  Otherwise every candidate
 // has the margin `skin` and trig = skin / 2, the usual Verlet rule.
-// Pruned lists (prune_on; kernels_nb.h: nonbonded_atom_body): an atom's pruned list keeps what lies within cutoff + m of the
-// positions at ITS last prune, and the atom asks for the next one when it has moved ptrig.  Frozen candidate: m = ptrig.  Mobile
-// candidate: it has moved less than ptrig since its own last prune, i.e. less than 2 ptrig since this atom's: m = 3 ptrig.  A
-// prune reads the full list, which must therefore hold every pair within cutoff + m whenever a prune can happen: its trigger
-// is the outer margin minus m (frozen) / half of the mobile margin minus 3 ptrig; the mobile margin grows by ptrig to keep
-// the two equal.
+// Pruned lists (prune_on; kernels_nb.h: nonbonded_atom_body): see the rule inside derive_margins.
 static void derive_margins(BluesEngine* h) {
     double room = 1e30;
     for (int k = 0; k < 3; k++) room = std::min(room, 0.5 * h->box[k] - h->cutoff - 1e-6);
@@ -304,15 +299,27 @@ static void derive_margins(BluesEngine* h) {
     const bool mostly_frozen = 4 * h->mobile.size() <= (size_t)h->n && !h->tune.plain_skin;
     h->skin_m = mostly_frozen ? std::min(2.0 * h->skin, std::max(0.0, room)) : h->skin;
     h->trig = std::min(h->skin, 0.5 * h->skin_m);
-    // the dual list pays where most candidates are frozen (one displacement per pair); elsewhere the full lists are walked
+    // the dual list pays where most candidates are frozen (one displacement per pair); elsewhere the full lists are walked.
+    // Full lists are built for the whole chain at once; until the next rebuild every atom stays within `trig` of its build
+    // position.  Frozen candidates within cutoff + skin, mobile candidates within cutoff + skin_m of the atom's build position.
+    // Pruned list of atom i, formed at time t_i from its full list and valid while i stays within m of x_i(t_i) (its own
+    // trigger, ptrig = m):
+    //   frozen candidate j: kept if |x_i(t_i) - x_j| < cutoff + m.  The full list holds all of those while i has moved at most
+    //     skin - m since the build: trig <= skin - m.
+    //   mobile candidate j: kept if |x_i(t_i) - xb_j| < cutoff + trig + m, xb_j = where j was at the BUILD: j is within trig of
+    //     xb_j until the next rebuild and i within m of x_i(t_i) until its next prune, so a pair that is left out stays beyond
+    //     the cutoff.  The full list holds all of those if skin_m >= 2 trig + m.  j's CURRENT position cannot be used: j's own
+    //     prunes reset j's reference, so nothing bounds how far j moves after t_i except the chain-level trigger (round 3: the
+    //     first version kept mobile candidates within cutoff + 3m of their current position, and the list audit --
+    //     blues_audit_lists -- found pairs inside the cutoff missing from the lists in 17 of 150 steps of a hot chain).
     const double m = h->tune.prune_margin < 0.0 ? 0.04 : h->tune.prune_margin;
     h->prune_on = mostly_frozen && m > 0.0 && m < 0.75 * h->skin;
-    h->prune_m = h->prune_m_mobile = h->ptrig = 0.0;
+    h->prune_m = h->ptrig = 0.0;
     if (h->prune_on) {
-        h->prune_m = m; h->prune_m_mobile = 3.0 * m; h->ptrig = m;
-        h->skin_m = std::min(2.0 * h->skin + m, std::max(0.0, room));
-        h->trig = std::min(h->skin - h->prune_m, 0.5 * (h->skin_m - h->prune_m_mobile));
-        if (h->trig <= 0.25 * h->skin) { h->prune_on = false; h->prune_m = h->prune_m_mobile = h->ptrig = 0.0; h->skin_m = std::min(2.0 * h->skin, std::max(0.0, room)); h->trig = std::min(h->skin, 0.5 * h->skin_m); }
+        h->prune_m = m; h->ptrig = m;
+        h->trig = std::min(h->skin - m, 0.5 * (std::max(0.0, room) - m));
+        h->skin_m = 2.0 * h->trig + m;
+        if (h->trig <= 0.25 * h->skin) { h->prune_on = false; h->prune_m = h->ptrig = 0.0; h->trig = std::min(h->skin, 0.5 * h->skin_m); }
     }
 }
 
@@ -351,7 +358,7 @@ template <typename R> static NbConst<R> make_nbconst(const BluesEngine* h) {
     c.rc2 = (R)(h->cutoff * h->cutoff); c.alpha = (R)h->alpha;
     c.rlist2 = (h->cutoff + h->skin) * (h->cutoff + h->skin);
     c.rlist2_m = (h->cutoff + h->skin_m) * (h->cutoff + h->skin_m);
-    c.rp2 = (float)((h->cutoff + h->prune_m) * (h->cutoff + h->prune_m)) * 1.00001f; c.rp2_m = (float)((h->cutoff + h->prune_m_mobile) * (h->cutoff + h->prune_m_mobile)) * 1.00001f;
+    c.rp2 = (float)((h->cutoff + h->prune_m) * (h->cutoff + h->prune_m)) * 1.00001f; c.rp2_m = (float)((h->cutoff + h->trig + h->prune_m) * (h->cutoff + h->trig + h->prune_m)) * 1.00001f;   // (from the candidate's BUILD position: derive_margins)
     c.ew = h->ewpoly;
     return c;
 }
@@ -2669,6 +2676,31 @@ int blues_time_nonbonded(BluesEngine* h, int32_t reps, double* usec) {
     { long long st[40]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nb_stamps), sizeof(long long) * 32); fprintf(stderr, "[stamps] nonbonded_atom (cycles since start):"); for (int i = 17; i < 28; i++) fprintf(stderr, " %lld", st[i] - st[16]); fprintf(stderr, "\n");
       fprintf(stderr, "[stamps] last kernel that stamped 0..7 (pme_fast: cache+region, spread, to X, fwd, eterm, bwd, gather):"); for (int i = 10; i < 17; i++) fprintf(stderr, " %lld", st[i] - st[9]); fprintf(stderr, "\n"); }
 #endif
+    return check_flags(h);
+}
+
+// Audit of the per-atom lists at the current positions (kernels_nb.h: k_audit_atom_lists): out[0] = pairs within the cutoff that
+// the nonbonded kernel is responsible for, out[1] = how many of them are in no list (must be 0).  Lists that are due for a
+// rebuild are rebuilt first, as the next force pass would.
+int blues_audit_lists(BluesEngine* h, int64_t* out) {
+    HIP_OK(h, hipSetDevice(h->device));
+    if (flush_program(h)) return 1;
+    if (ensure_sorted(h)) return 1;
+    if (h->k1_mode != 2 || h->precision != 0) E_FAIL(h, "blues_audit_lists: the engine is not in per-atom-list mode");
+    if (h->jcap > 32768) E_FAIL(h, "blues_audit_lists: list capacity %d is beyond the audit kernel's bitmap", h->jcap);
+    hipStream_t st = h->batch && h->batch->entered ? h->batch->stream : h->stream;
+    hipStream_t keep = h->cur; h->cur = st;
+    BluesBatch* B = h->batch; h->batch = nullptr;   // (the member's own rebuild kernels, whoever leads the batch)
+    int rc = launch_lists<float>(h, h->lists_forced);
+    h->batch = B; h->cur = keep;
+    if (rc) return 1;
+    h->lists_forced = false;
+    DBuf<unsigned long long> d_out; d_out.alloc(2);
+    hipLaunchKernelGGL(k_audit_atom_lists, dim3(h->n_islots), dim3(256), 0, st, make_nb_args<float>(h), make_list_args(h), make_nbconst<float>(h), h->d_img_f.p, d_out.p);
+    HIP_OK(h, hipGetLastError());
+    HIP_OK(h, hipStreamSynchronize(st));
+    std::vector<unsigned long long> v; d_out.download(v); d_out.release();
+    out[0] = (int64_t)v[0]; out[1] = (int64_t)v[1];
     return check_flags(h);
 }
 

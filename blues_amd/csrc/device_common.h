@@ -115,7 +115,7 @@ template <typename R> struct NbConst {
     double rlist2;  // (cutoff+skin)^2: list radius for frozen candidates
     double rlist2_m;  // list radius for mobile candidates (derive_margins in blues_engine.hip)
     double dscale[3];
-    float rp2, rp2_m;  // (cutoff + inner margin)^2 of the pruned per-atom lists, frozen / mobile candidates (nonbonded_atom_body)
+    float rp2, rp2_m;  // (cutoff + inner margin)^2 of the pruned per-atom lists, frozen candidates (current position) / mobile candidates (position at the list build) (nonbonded_atom_body)
     EwaldPoly ew;      // mixed precision only
 };
 

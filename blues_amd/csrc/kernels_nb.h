@@ -812,7 +812,17 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
                 if (in) { const double wgt = (e & 0x8000u) ? 0.5 : 1.0; elj += wgt * (double)e1; ecl += wgt * (double)e2; }
             }
             if (write) {   // prune: keep what lies within cutoff + inner margin, in list order
-                const bool keep = have && r2 < ((e & 0x8000u) ? c.rp2_m : c.rp2);
+                float r2k = r2;
+                if (have && (e & 0x8000u)) {
+                    // a MOBILE candidate is measured from where it was when the chain's lists were built (the packed image keeps
+                    // that position): until the next rebuild it stays within `trig` of there, whatever prunes it goes through
+                    // itself, so cutoff + trig + m from this atom's position now is a bound that holds until this atom's next
+                    // prune (derive_margins).  Its current position says nothing about where it may be by then.
+                    const u32x4 pb = (G1(const u32x4, a.pimg4) + (size_t)t * a.jcap)[e & 0x7FFFu];
+                    const float ex = (float)(int32_t)(ix - pb.x) * c.scale[0], ey = (float)(int32_t)(iy - pb.y) * c.scale[1], ez = (float)(int32_t)(iz - pb.z) * c.scale[2];
+                    r2k = ex * ex + ey * ey + ez * ez;
+                }
+                const bool keep = have && r2k < ((e & 0x8000u) ? c.rp2_m : c.rp2);
                 const unsigned long long bal = __ballot(keep);
                 if (keep) pout[pcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)e;
                 pcnt += __popcll(bal);
@@ -887,6 +897,45 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
             a.epart[2 * t] = s0; a.epart[2 * t + 1] = s1;
         }
     }
+}
+
+// Audit of the per-atom lists (diagnostic; blues_audit_lists).  One block per i-slot: every atom of the SYSTEM within the cutoff
+// of the slot's atom at the current positions -- not alchemical, not an excluded partner -- must be an entry of the list the
+// nonbonded kernel would walk for it now (the pruned list; the full list if the atom is flagged for a prune).  out[0] counts
+// the pairs within the cutoff, out[1] those that are in no list.  This checks the whole chain of margins and triggers
+// (derive_margins) against the one thing they exist for.
+__global__ void __launch_bounds__(256) k_audit_atom_lists(NbArgs<float> a, ListArgs L, NbConst<float> c, const AtomF* __restrict__ img, unsigned long long* out) {
+    __shared__ unsigned s_bits[8192 / 32 * 4];   // one bit per group-list entry (jcap <= 32768)
+    const int sl = blockIdx.x, tid = threadIdx.x;
+    const int ia = a.tile_atoms[sl];
+    if (ia < 0) return;
+    const int l = (sl >> 6) / a.S;
+    const int count = a.jcount[l];
+    const int* jl = a.jlist + (size_t)l * a.jcap;
+    const bool full = a.plist == nullptr || a.pneed[sl] != 0;
+    const unsigned short* lst = (full ? a.alist : a.plist) + (size_t)sl * a.acap;
+    const int cnt = full ? a.acount[sl] : a.pcount[sl];
+    for (int w = tid; w < (a.jcap + 31) / 32; w += 256) s_bits[w] = 0u;
+    __syncthreads();
+    for (int e = tid; e < cnt; e += 256) { const int k = lst[e] & 0x7fff; atomicOr(&s_bits[k >> 5], 1u << (k & 31)); }
+    __syncthreads();
+    const uint32_t xi = img[ia].x, yi = img[ia].y, zi = img[ia].z;
+    const int e0 = L.ex_start[ia], e1 = L.ex_start[ia + 1];
+    unsigned long long found = 0, missing = 0;
+    for (int js = tid; js < L.n; js += 256) {
+        if (js == ia || (img[js].flags & FLAG_ALCH)) continue;
+        const double dx = (double)(int32_t)(img[js].x - xi) * c.dscale[0], dy = (double)(int32_t)(img[js].y - yi) * c.dscale[1], dz = (double)(int32_t)(img[js].z - zi) * c.dscale[2];
+        if (dx * dx + dy * dy + dz * dz >= (double)c.rc2) continue;
+        bool excluded = false;
+        for (int e = e0; e < e1; e++) excluded |= L.ex_idx[e] == js;
+        if (excluded) continue;
+        found++;
+        int lo = 0, hi = count;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (jl[mid] < js) lo = mid + 1; else hi = mid; }
+        if (!(lo < count && jl[lo] == js && ((s_bits[lo >> 5] >> (lo & 31)) & 1u))) missing++;
+    }
+    if (found) atomicAdd(&out[0], found);
+    if (missing) atomicAdd(&out[1], missing);
 }
 
 template <bool ENERGY>

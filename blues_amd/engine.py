@@ -172,6 +172,10 @@ class NativeEngine:
     def time_list_build(self, reps=20):
         u = C.c_double(); self._check(self._lib.blues_time_list_build(self._h, int(reps), C.byref(u))); return u.value
 
+    def audit_lists(self):
+        """(pairs within the cutoff, pairs missing from the lists the nonbonded kernel would walk now) -- include/blues_engine.h: blues_audit_lists."""
+        out = (C.c_int64 * 2)(); self._check(self._lib.blues_audit_lists(self._h, out)); return int(out[0]), int(out[1])
+
 
 class DeviceSnapshot:
     """openmm.State's positions / velocities kept on the GPU (include/blues_engine.h "Device-resident State")."""

@@ -263,6 +263,11 @@ int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
 int blues_time_nonbonded(BluesEngine *h, int32_t reps, double *usec_per_launch);
 /* the same for a forced neighbour-list rebuild */
 int blues_time_list_build(BluesEngine *h, int32_t reps, double *usec_per_launch);
+/* Diagnostic: audits the per-atom neighbour lists at the current positions.  out[0] = pairs within the cutoff the nonbonded
+ * kernel is responsible for (neither alchemical nor excluded), out[1] = how many of them are entries of no list (must be
+ * 0: the list margins and rebuild / prune triggers exist to guarantee it).  Per-atom-list mode only (mixed precision,
+ * mostly frozen system in a large batch); an error elsewhere. */
+int blues_audit_lists(BluesEngine *h, int64_t out[2]);
 
 /* ---- Device-resident State -------------------------------------------------
  * BLUES passes whole openmm.State objects around: getStateFromContext takes

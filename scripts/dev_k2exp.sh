@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for e in 0 1 2 3; do
+for e in ${K2_EXPS:-0 1 2 3}; do
   if [ $e = 0 ]; then L=blues_amd/csrc/libblues_hip.so; else L=scripts/devtests/libk2exp$e.so; fi
   out=gpurun_out/k2x_$e; rm -rf $out; mkdir -p $out
   BLUES_TUNING=fork=0 BLUES_LIB_PATH=$PWD/$L rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 scripts/batch_scaling.py --nsteps 120 512 > $out/log 2>&1

@@ -65,6 +65,26 @@ def test_pruned_lists_hold_every_pair_in_range(Engine, oracle_mod, tune):
     assert checked == 3
 
 
+def test_list_audit_no_pair_in_range_is_ever_missing(Engine, tune):
+    """The engine's own audit (include/blues_engine.h: blues_audit_lists) walks every atom of the system for every atom that has a
+    list and counts the pairs inside the cutoff that are entries of NO list the kernel would walk now.  Hot velocities (1.5 x) and
+    a hot thermostat make the atoms trip their prune and rebuild triggers often; audited at every step over several list lives
+    -- including mobile-mobile pairs, whose two atoms prune at different times."""
+    s, v = systems.s23k(mobile_atoms=275, frozen=True)
+    tune(assume_batch=512)
+    g = Engine(s, integrators.generateNCMCIntegrator(nstepsNC=200, dt=0.004, temperature=450.0, seed=11).to_data(precision=0)); g.set_velocities(1.5 * v)
+    total = 0
+    for step in range(150):
+        g.step(1)
+        found, missing = g.audit_lists()
+        assert missing == 0, (step, found, missing)
+        total += found
+    st = g.stats()
+    assert total > 150 * 50000, total                      # ~ 270 list atoms x a few hundred neighbours each, every step
+    assert st["list_builds"] >= 5 and st["atom_prunes"] > 1000, st      # several list lives, many prunes inside each
+    g.close()
+
+
 def test_prune_requests_are_per_chain_inside_a_batch(Engine, tune):
     """Batch = solo bitwise with pruned lists: an atom's list is pruned on ITS OWN displacement flag, so the members of one launch
     prune different atoms at the same step and still reproduce their lone runs bit for bit."""
