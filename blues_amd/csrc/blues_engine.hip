@@ -264,6 +264,7 @@ struct BluesBatch {
     // list synchronisation: in a large batch some member needs new lists at almost every step, and the launch lasts as long
     // as one rebuild whoever asks; when they all rebuild together (any request rebuilds all) most steps see no rebuild at all
     DBuf<int> d_req; bool sync_lists = false;
+    DBuf<int> d_work;   // [1 + R] members that rebuild their lists in the current force pass (kernels_batch.h: k_gather_stale_b)
     BluesTuning tune;   // the process-wide tuning at the time the batch was created
     // argument arena of the batched boundary calls (blues_batch_capture ...): pinned host side, device side, one upload per call
     unsigned char* h_arena = nullptr; size_t arena_cap = 0; DBuf<unsigned char> d_arena;
@@ -855,6 +856,8 @@ static ListArgs make_list_args(BluesEngine* h) {
     return a;
 }
 
+// workgroups of a batch's rebuild kernels (kernels_batch.h: k_gather_stale_b): two per CU; they deal the work items among themselves
+static const int REBUILD_GRID = 512;
 // phase 0: the whole rebuild; 1: the group lists only (k_build_lists); 2: the atoms' own lists only (k_build_atom_lists)
 template <typename R> static int launch_lists(BluesEngine* h, int force, int phase = 0) {
     if (h->tune.force_lists) force = 1;   // development: every launch rebuilds every list
@@ -863,7 +866,8 @@ template <typename R> static int launch_lists(BluesEngine* h, int force, int pha
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
     if (phase == 2) { }
     else if (batch_lead(h)) {
-        hipLaunchKernelGGL(k_build_lists_b<R>, dim3((h->n_tiles + 2) * h->batch->R()), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->R(), h->n_tiles + 2, force);
+        hipLaunchKernelGGL(k_gather_stale_b<R>, dim3(1), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->R(), force, h->batch->d_work.p);
+        hipLaunchKernelGGL(k_build_lists_b<R>, dim3(std::min((h->n_tiles + 2) * h->batch->R(), REBUILD_GRID)), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->d_work.p, h->n_tiles + 2, force);
     } else if (!batch_dry(h)) {
         hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 2), dim3(LIST_THREADS), 0, h->cur, a, make_nbconst<R>(h), img, force);
     }
@@ -881,8 +885,9 @@ template <typename R> static int launch_lists(BluesEngine* h, int force, int pha
                 if (e != hipSuccess) E_FAIL(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
                 lds_set[lead] = lds;
             }
-            if (lead) hipLaunchKernelGGL(k_build_atom_lists_b<R>, dim3(h->n_itiles * h->batch->R()), dim3(LIST_THREADS), lds, h->cur, batch_reps_nb<R>(h->batch), h->batch->R(), h->n_itiles, force);
-            else hipLaunchKernelGGL(k_build_atom_lists<R>, dim3(h->n_itiles), dim3(LIST_THREADS), lds, h->cur, a, make_nbconst<R>(h), img, force);
+            const int items = h->n_itiles * ATOM_LIST_PARTS;   // (an i-tile's atoms are split over ATOM_LIST_PARTS blocks)
+            if (lead) hipLaunchKernelGGL(k_build_atom_lists_b<R>, dim3(std::min(items * h->batch->R(), REBUILD_GRID)), dim3(LIST_THREADS), lds, h->cur, batch_reps_nb<R>(h->batch), h->batch->d_work.p, items, force);
+            else hipLaunchKernelGGL(k_build_atom_lists<R>, dim3(items), dim3(LIST_THREADS), lds, h->cur, a, make_nbconst<R>(h), img, force);
         }
         h->st_launches++;
     }
@@ -1325,11 +1330,14 @@ static int force_pass(BluesEngine* h, int base_L) {
     if (fork) {
         hipStream_t main_stream = h->cur;
         HIP_OK(h, hipEventRecord(h->evFork, main_stream)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evFork, 0));
+        // The atoms' lists are enqueued BEFORE the alchemical kernel: its few workgroups want ~100 KB of LDS each, and once the
+        // alchemical kernel's 12,800 small ones have filled every CU they wait for two of them to retire from the same CU at
+        // once (round 3 timeline: 245 us beside the alchemical kernel against 107 us alone).
+        rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, 2) : launch_lists<double>(h, h->lists_forced, 2);
+        if (rc) return 1;
         h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask) || launch_bonded(h, true); h->cur = main_stream;   // (bonded terms and the next O step's noise need no list either; the long kernel first)
         if (rc) return 1;
         HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
-        rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, 2) : launch_lists<double>(h, h->lists_forced, 2);
-        if (rc) return 1;
     }
     h->lists_forced = false;
     if (h->fuse_forces && h->wpb == 4) {
@@ -2937,7 +2945,7 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
     B->sync_lists = false;
     B->tune = g_tuning;
     B->sync_lists = B->tune.batch_sync_lists != 0;
-    try { B->d_req.alloc(1); } catch (std::string& e) { g_batch_create_error = e; batch_detach_all(B); delete B; return 1; }
+    try { B->d_req.alloc(1); B->d_work.alloc((size_t)count + 1); } catch (std::string& e) { g_batch_create_error = e; batch_detach_all(B); delete B; return 1; }
     B->seen_epoch.assign(count, 0); B->failed.assign(count, 0); B->active.assign(count, 1); B->rec_active.assign(count, 0); B->rec_delta.assign(count, 0); B->leader = engines[0];
     *out = B;
     return 0;

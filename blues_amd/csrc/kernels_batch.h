@@ -59,50 +59,60 @@ __device__ __forceinline__ void apply_dyn(IntArgs& A, const IntDyn& d, unsigned 
     A.ctrl = nullptr;
 }
 
-// Active-first block map of the rebuild kernels.  In a large batch a few members rebuild their lists in any given round; with
-// (block, replica) grids their blocks land wherever the replica index puts them and pile up on the same CUs (one 1024-thread
-// block with its LDS fits a CU at a time) while most CUs only retire blocks that exit at once -- the launch then lasts two
-// or three block times.  Here the grid is 1-D and block b serves block (b % bpc) of the (b / bpc)-th member THAT REBUILDS:
-// the working blocks come first and spread evenly over the chip.  Returns false for a block with nothing to do.
+// Work list of the rebuild kernels.  In a large batch a few members rebuild their lists in any given round (each chain trips
+// its own displacement trigger).  A grid with one workgroup per (member, tile) then consists almost entirely of workgroups
+// that find nothing to do, each a 1024-thread workgroup that wants ~100 KB of LDS and is alone on its CU while it finds out
+// (R = 512: 5,120 of them, twenty rounds of dispatch for ~200 with work).  Instead one small kernel writes the ordered list of
+// the members that rebuild (work[0] = how many, work[1..] = which) and the rebuild kernels run a SMALL grid whose workgroups
+// deal the (member, tile) items of those members among themselves.
 template <typename R>
-__device__ __forceinline__ bool rebuild_slot(const RepNb<R>* __restrict__ reps, int nrep, int force, int bpc, int& rep, int& bx) {
-    const int b = blockIdx.x, want = b / bpc; bx = b - want * bpc;
-    if (nrep > LIST_THREADS) { rep = want; return want < nrep && reps[want].active; }   // (one thread per member below)
-    __shared__ int s_cnt[LIST_WAVES]; __shared__ int s_pick;
+__global__ void __launch_bounds__(LIST_THREADS) k_gather_stale_b(const RepNb<R>* __restrict__ reps, int nrep, int force, int* __restrict__ work) {
+    __shared__ int s_cnt[LIST_WAVES]; __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    bool act = false;
-    if (tid < nrep && reps[tid].active) {
-        const ListArgs& L = reps[tid].L;
-        act = force || L.flags->list_gen != L.flags->req_gen || (L.batch_req && *L.batch_req);
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < nrep; r0 += LIST_THREADS) {
+        const int r = r0 + tid;
+        bool act = false;
+        if (r < nrep && reps[r].active) {
+            const ListArgs& L = reps[r].L;
+            act = force || L.flags->list_gen != L.flags->req_gen || (L.batch_req && *L.batch_req);
+        }
+        const unsigned long long bal = __ballot(act);
+        if (lane == 0) s_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int rank = s_base + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; w++) rank += s_cnt[w];
+        if (act) work[1 + rank] = r;
+        __syncthreads();
+        if (tid == 0) { int tot = 0; for (int w = 0; w < LIST_WAVES; w++) tot += s_cnt[w]; s_base += tot; }
+        __syncthreads();
     }
-    const unsigned long long bal = __ballot(act);
-    if (lane == 0) s_cnt[wv] = __popcll(bal);
-    if (tid == 0) s_pick = -1;
-    __syncthreads();
-    int rank = __popcll(bal & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wv; w++) rank += s_cnt[w];
-    if (act && rank == want) s_pick = tid;
-    __syncthreads();
-    rep = s_pick;
-    return rep >= 0;
+    if (tid == 0) work[0] = s_base;
 }
 
 template <typename R>
-__global__ void __launch_bounds__(LIST_THREADS) k_build_lists_b(const RepNb<R>* __restrict__ reps, int nrep, int bpc, int force) {
-    int rep, bx;
-    if (!rebuild_slot<R>(reps, nrep, force, bpc, rep, bx)) return;
-    const RepNb<R>& rp = reps[rep];
-    const ListArgs a = rp.L; const NbConst<R> c = rp.c;
-    build_lists_body<R>(a, c, rp.img, force, bx, bpc);
+__global__ void __launch_bounds__(LIST_THREADS) k_build_lists_b(const RepNb<R>* __restrict__ reps, const int* __restrict__ work, int bpc, int force) {
+    const int nact = work[0];
+    for (int i = blockIdx.x; i < nact * bpc; i += gridDim.x) {
+        const int m = i / bpc;
+        const RepNb<R>& rp = reps[work[1 + m]];
+        const ListArgs a = rp.L; const NbConst<R> c = rp.c;
+        build_lists_body<R>(a, c, rp.img, force, i - m * bpc, bpc);
+        __syncthreads();   // (the next item reuses the body's LDS)
+    }
 }
 
 template <typename R>
-__global__ void __launch_bounds__(LIST_THREADS) k_build_atom_lists_b(const RepNb<R>* __restrict__ reps, int nrep, int bpc, int force) {
-    int rep, bx;
-    if (!rebuild_slot<R>(reps, nrep, force, bpc, rep, bx)) return;
-    const RepNb<R>& rp = reps[rep];
-    const ListArgs a = rp.L; const NbConst<R> c = rp.c;
-    build_atom_lists_body<R>(a, c, rp.img, force, bx);
+__global__ void __launch_bounds__(LIST_THREADS) k_build_atom_lists_b(const RepNb<R>* __restrict__ reps, const int* __restrict__ work, int bpc, int force) {
+    const int nact = work[0];
+    for (int i = blockIdx.x; i < nact * bpc; i += gridDim.x) {
+        const int m = i / bpc;
+        const RepNb<R>& rp = reps[work[1 + m]];
+        const ListArgs a = rp.L; const NbConst<R> c = rp.c;
+        build_atom_lists_body<R>(a, c, rp.img, force, i - m * bpc);
+        __syncthreads();
+    }
 }
 
 template <typename R, bool ENERGY, int WPB>

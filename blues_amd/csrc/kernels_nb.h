@@ -75,6 +75,9 @@ struct ListArgs {
 #define LIST_WAVES 16
 #define LIST_PREFETCH 4
 #define LIST_THREADS (LIST_WAVES * 64)
+#define ATOM_LIST_U 2                       // atoms per wave of build_atom_lists_body
+#define ATOM_LIST_PARTS (4 / ATOM_LIST_U)    // its blocks per i-tile (LIST_WAVES * 4 = 64 slots)
+#define ATOM_SLOT(part, wv, u) ((part) * (64 / ATOM_LIST_PARTS) + (wv) + LIST_WAVES * (u))
 #define EXK_MAX 64       // excluded partners of one i-atom that can sit in its tile's list (+ sentinel); per-atom-list mode
 #define LIST_LDS 8192      // j-list entries mirrored in LDS for the exclusion searches (longer lists are searched in HBM)
 
@@ -327,7 +330,10 @@ __global__ void __launch_bounds__(LIST_THREADS) k_build_lists(ListArgs a, NbCons
 // this loop, which kept them in scalar registers, was bound by it.
 // The pair kernel tests r < cutoff itself; what must hold here is "within cutoff+skin now" (float, with margin).
 template <typename R>
-__device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force, const int t) {
+__device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force, const int item) {
+    // one block = one PART of an i-tile: ATOM_LIST_U of its atoms per wave (parts of a tile: 4 / ATOM_LIST_U).  The chunk loop is
+    // VALU-bound inside its CU, so a tile split over two CUs halves the latency every batched round waits for.
+    const int t = item / ATOM_LIST_PARTS, part = item - t * ATOM_LIST_PARTS;
     using sfix = typename Img<R>::sfix;
     using ufix = typename Img<R>::ufix;
     if (!force && a.flags->list_gen == a.flags->req_gen && !(a.batch_req && *a.batch_req)) return;
@@ -352,19 +358,32 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     NB_STAMP(t == 0 && tid == 0, 5);
     const int i0 = a.tile_atoms[t * 64];
     const ufix ref[3] = {img[i0].x, img[i0].y, img[i0].z};
-    for (int k = tid; k < count; k += LIST_THREADS) {
-        const int js = jl[k];
-        const ufix qx = img[js].x, qy = img[js].y, qz = img[js].z; const unsigned fl = img[js].flags;
-        s_jm[k] = js | ((fl & FLAG_MOBILE) ? 0x40000000 : 0);
-        sx[k] = (float)(sfix)(qx - ref[0]) * cfs[0]; sy[k] = (float)(sfix)(qy - ref[1]) * cfs[1]; sz[k] = (float)(sfix)(qz - ref[2]) * cfs[2];
+    __shared__ int s_amax[3];   // largest |coordinate| of a candidate per axis (bits of a non-negative float), for the wrap decision below
+    if (tid < 3) s_amax[tid] = 0;
+    __syncthreads();
+    {
+        float am[3] = {0.0f, 0.0f, 0.0f};
+        for (int k = tid; k < count; k += LIST_THREADS) {
+            const int js = jl[k];
+            const ufix qx = img[js].x, qy = img[js].y, qz = img[js].z; const unsigned fl = img[js].flags;
+            s_jm[k] = js | ((fl & FLAG_MOBILE) ? 0x40000000 : 0);
+            const float x = (float)(sfix)(qx - ref[0]) * cfs[0], y = (float)(sfix)(qy - ref[1]) * cfs[1], z = (float)(sfix)(qz - ref[2]) * cfs[2];
+            sx[k] = x; sy[k] = y; sz[k] = z;
+            am[0] = fmaxf(am[0], fabsf(x)); am[1] = fmaxf(am[1], fabsf(y)); am[2] = fmaxf(am[2], fabsf(z));
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            for (int o = 32; o > 0; o >>= 1) am[d] = fmaxf(am[d], __shfl_xor(am[d], o, 64));
+            if (lane == 0) atomicMax(&s_amax[d], __float_as_int(am[d]));
+        }
     }
     if (tid < 64) { s_exn[tid] = 0; s_exlo[tid] = 0x7fffffff; s_exhi[tid] = -1; }
     __syncthreads();
     NB_STAMP(t == 0 && tid == 0, 6);
-    int ia4[4]; float pi4[4][3]; bool ok4[4];
+    int ia4[ATOM_LIST_U]; float pi4[ATOM_LIST_U][3]; bool ok4[ATOM_LIST_U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int slot = wv + LIST_WAVES * u;
+    for (int u = 0; u < ATOM_LIST_U; u++) {
+        const int slot = ATOM_SLOT(part, wv, u);
         ia4[u] = __builtin_amdgcn_readfirstlane(a.tile_atoms[t * 64 + slot]);
         const int iq = ia4[u] >= 0 ? ia4[u] : 0;
         pi4[u][0] = (float)(sfix)(img[iq].x - ref[0]) * cfs[0]; pi4[u][1] = (float)(sfix)(img[iq].y - ref[1]) * cfs[1]; pi4[u][2] = (float)(sfix)(img[iq].z - ref[2]) * cfs[2];
@@ -382,76 +401,98 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
         }
     }
     __syncthreads();
-    int exn4[4], exlo4[4], exhi4[4];
+    int exn4[ATOM_LIST_U], exlo4[ATOM_LIST_U], exhi4[ATOM_LIST_U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int slot = wv + LIST_WAVES * u;
+    for (int u = 0; u < ATOM_LIST_U; u++) {
+        const int slot = ATOM_SLOT(part, wv, u);
         exn4[u] = __builtin_amdgcn_readfirstlane(min(s_exn[slot], EXK_MAX)); exlo4[u] = __builtin_amdgcn_readfirstlane(s_exlo[slot]); exhi4[u] = __builtin_amdgcn_readfirstlane(s_exhi[slot]);
     }
     NB_STAMP(t == 0 && tid == 0, 7);
-    int cntv[4] = {0, 0, 0, 0}, cntp[4] = {0, 0, 0, 0};
-    unsigned short* out4[4]; unsigned short* outp4[4];
+    int cntv[ATOM_LIST_U], cntp[ATOM_LIST_U];
+#pragma unroll
+    for (int u = 0; u < ATOM_LIST_U; u++) cntv[u] = cntp[u] = 0;
+    unsigned short* out4[ATOM_LIST_U]; unsigned short* outp4[ATOM_LIST_U];
     const bool dual = a.plist != nullptr;
     const float rp2 = c.rp2 * 1.0001f + 1e-5f, rp2m = c.rp2_m * 1.0001f + 1e-5f;   // (float distances relative to the tile: same safety margin as the full lists)
 #pragma unroll
-    for (int u = 0; u < 4; u++) { out4[u] = a.alist + ((size_t)t * 64 + wv + LIST_WAVES * u) * a.acap; outp4[u] = dual ? a.plist + ((size_t)t * 64 + wv + LIST_WAVES * u) * a.acap : nullptr; }
+    for (int u = 0; u < ATOM_LIST_U; u++) { out4[u] = a.alist + ((size_t)t * 64 + ATOM_SLOT(part, wv, u)) * a.acap; outp4[u] = dual ? a.plist + ((size_t)t * 64 + ATOM_SLOT(part, wv, u)) * a.acap : nullptr; }
     const float INF = __builtin_inff();
     const int acap1 = a.acap - 1;
     // both positions are relative to the tile's first atom (each one a minimum image OF THAT ATOM): their difference is the
     // minimum image of the pair only while the list's extent stays below half a box edge, hence the explicit wrap below
     const float boxf[3] = {(float)(c.dscale[0] * 4294967296.0 * (sizeof(ufix) == 8 ? 4294967296.0 : 1.0)), (float)(c.dscale[1] * 4294967296.0 * (sizeof(ufix) == 8 ? 4294967296.0 : 1.0)), (float)(c.dscale[2] * 4294967296.0 * (sizeof(ufix) == 8 ? 4294967296.0 : 1.0))};
     const float iboxf[3] = {1.0f / boxf[0], 1.0f / boxf[1], 1.0f / boxf[2]};
-    for (int ch = 0; ch < nch; ch++) {
-        const int k = ch * 64 + lane, kk = min(k, count - 1);
-        const float x = sx[kk], y = sy[kk], z = sz[kk];
-        const bool mob = (s_jm[kk] & 0x40000000) != 0;
-        const unsigned short ent = (unsigned short)(k | (mob ? 0x8000 : 0));
-        const float kinf = k < count ? 0.0f : INF;
-        const float lim = mob ? rl2m : rl2, plim = mob ? rp2m : rp2;
+    // Both positions of a pair are relative to the tile's first atom.  The periodic wrap of their difference matters only if the
+    // wrapped image can be in range, i.e. if |difference| can reach (box edge - list radius): below that a pair is either the
+    // minimum image already or out of range both ways.  Decided per wave from its atoms' and the candidates' largest
+    // |coordinates| (9 of the ~40 instructions of a test).
+    bool wrap = false;
+    {
+        const float rlmax = sqrtf(fmaxf(rl2, rl2m));
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            bool excluded = false;
-            if (ch >= exlo4[u] && ch <= exhi4[u]) {   // wave-uniform; a handful of chunks per atom
-                const unsigned short* ex = s_ex[wv + LIST_WAVES * u];
-                for (int e = 0; e < exn4[u]; e++) excluded |= (int)ex[e] == k;   // same address in every lane: broadcast
-            }
-            float dx = x - pi4[u][0], dy = y - pi4[u][1], dz = z - pi4[u][2];
-            dx -= boxf[0] * rintf(dx * iboxf[0]); dy -= boxf[1] * rintf(dy * iboxf[1]); dz -= boxf[2] * rintf(dz * iboxf[2]);
-            float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + kinf;
-            d2 = excluded ? INF : d2;
-            const bool pass = d2 < lim && ok4[u];
-            const unsigned long long bal = __ballot(pass);
-            const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
-            const int pos = cntv[u] + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
-            // running count on the vector ALU.  gfx950 needs two wait states between a VALU write of an SGPR / VCC (the
-            // compare behind the ballot) and a VALU read of it as an operand; the compiler inserts them for its own
-            // instructions but not around inline assembly (without the s_nop the counts came out stale)
-            int c2;
-            asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c2) : "s"(blo), "s"(bhi), "v"(cntv[u]));
-            cntv[u] = c2;
-            if (pass) out4[u][min(pos, acap1)] = ent;   // on overflow (flagged below) the surplus lands on the last entry
-            if (dual) {   // (block-uniform) the pruned list: the same entries within cutoff + inner margin, same order
-                const bool keep = pass && d2 < plim;
-                const unsigned long long bk = __ballot(keep);
-                const unsigned klo = (unsigned)bk, khi = (unsigned)(bk >> 32);
-                const int ppos = cntp[u] + (int)__builtin_amdgcn_mbcnt_hi(khi, __builtin_amdgcn_mbcnt_lo(klo, 0u));
-                int c3;
-                asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c3) : "s"(klo), "s"(khi), "v"(cntp[u]));
-                cntp[u] = c3;
-                if (keep) outp4[u][min(ppos, acap1)] = ent;
+        for (int d = 0; d < 3; d++) {
+            float bw = 0.0f;
+#pragma unroll
+            for (int u = 0; u < ATOM_LIST_U; u++) if (ok4[u]) bw = fmaxf(bw, fabsf(pi4[u][d]));
+            wrap |= __int_as_float(s_amax[d]) + bw >= boxf[d] - rlmax;
+        }
+        wrap = __builtin_amdgcn_readfirstlane((int)wrap) != 0;
+    }
+    auto chunk_loop = [&](auto wrap_tag) {
+        constexpr bool WRAP = decltype(wrap_tag)::value;
+        for (int ch = 0; ch < nch; ch++) {
+            const int k = ch * 64 + lane, kk = min(k, count - 1);
+            const float x = sx[kk], y = sy[kk], z = sz[kk];
+            const bool mob = (s_jm[kk] & 0x40000000) != 0;
+            const unsigned short ent = (unsigned short)(k | (mob ? 0x8000 : 0));
+            const float kinf = k < count ? 0.0f : INF;
+            const float lim = mob ? rl2m : rl2, plim = mob ? rp2m : rp2;
+#pragma unroll
+            for (int u = 0; u < ATOM_LIST_U; u++) {
+                bool excluded = false;
+                if (ch >= exlo4[u] && ch <= exhi4[u]) {   // wave-uniform; a handful of chunks per atom
+                    const unsigned short* ex = s_ex[ATOM_SLOT(part, wv, u)];
+                    for (int e = 0; e < exn4[u]; e++) excluded |= (int)ex[e] == k;   // same address in every lane: broadcast
+                }
+                float dx = x - pi4[u][0], dy = y - pi4[u][1], dz = z - pi4[u][2];
+                if (WRAP) { dx -= boxf[0] * rintf(dx * iboxf[0]); dy -= boxf[1] * rintf(dy * iboxf[1]); dz -= boxf[2] * rintf(dz * iboxf[2]); }
+                float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + kinf;
+                d2 = excluded ? INF : d2;
+                const bool pass = d2 < lim && ok4[u];
+                const unsigned long long bal = __ballot(pass);
+                const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
+                const int pos = cntv[u] + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
+                // running count on the vector ALU.  gfx950 needs two wait states between a VALU write of an SGPR / VCC (the
+                // compare behind the ballot) and a VALU read of it as an operand; the compiler inserts them for its own
+                // instructions but not around inline assembly (without the s_nop the counts came out stale)
+                int c2;
+                asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c2) : "s"(blo), "s"(bhi), "v"(cntv[u]));
+                cntv[u] = c2;
+                if (pass) out4[u][min(pos, acap1)] = ent;   // on overflow (flagged below) the surplus lands on the last entry
+                if (dual) {   // (block-uniform) the pruned list: the same entries within cutoff + inner margin, same order
+                    const bool keep = pass && d2 < plim;
+                    const unsigned long long bk = __ballot(keep);
+                    const unsigned klo = (unsigned)bk, khi = (unsigned)(bk >> 32);
+                    const int ppos = cntp[u] + (int)__builtin_amdgcn_mbcnt_hi(khi, __builtin_amdgcn_mbcnt_lo(klo, 0u));
+                    int c3;
+                    asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c3) : "s"(klo), "s"(khi), "v"(cntp[u]));
+                    cntp[u] = c3;
+                    if (keep) outp4[u][min(ppos, acap1)] = ent;
+                }
             }
         }
-    }
+    };
+    if (wrap) chunk_loop(std::true_type{}); else chunk_loop(std::false_type{});
     NB_STAMP(t == 0 && tid == 0, 8);
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < ATOM_LIST_U; u++) {
         if (lane == 0) {
             if (dual) {   // the pruned list is current as of these positions
-                const int sl = t * 64 + wv + LIST_WAVES * u, iq = ia4[u] >= 0 ? ia4[u] : 0;
+                const int sl = t * 64 + ATOM_SLOT(part, wv, u), iq = ia4[u] >= 0 ? ia4[u] : 0;
                 a.pcount[sl] = min(cntp[u], a.acap); a.pneed[sl] = 0;
                 a.xprune[0][sl] = (unsigned)img[iq].x; a.xprune[1][sl] = (unsigned)img[iq].y; a.xprune[2][sl] = (unsigned)img[iq].z;
             }
-            a.acount[t * 64 + wv + LIST_WAVES * u] = min(cntv[u], a.acap);
+            a.acount[t * 64 + ATOM_SLOT(part, wv, u)] = min(cntv[u], a.acap);
             if (cntv[u] > a.acap) a.flags->list_overflow = 1;
             else if (cntv[u] > a.acap - a.acap / 8) a.flags->resort_hint = 1;   // (a re-sort re-derives the capacities)
         }
