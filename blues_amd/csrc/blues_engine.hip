@@ -38,6 +38,9 @@ static thread_local std::string g_create_error;
 // creation.  The library reads no environment variables.
 static BluesTuning g_tuning = [] { BluesTuning t; blues_tuning_default(&t); return t; }();
 
+// workgroups of the kernels of a batch that run from the rebuild's work list (kernels_batch.h: k_gather_stale_b): two per CU
+static const int REBUILD_GRID = 512;
+
 template <typename T> struct DBuf {
     T* p = nullptr; size_t n = 0;
     void reserve(size_t count) {   // an existing buffer of the right size is reused (a re-sort keeps every address)
@@ -124,7 +127,7 @@ struct BluesEngine {
     int batch_R = 1;  // replicas sharing this engine's launches (shapes the launch decomposition in sort_and_tile)
     uint64_t args_epoch = 1;  // bumped whenever a device buffer referenced by the argument records is (re)allocated
     hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, cur = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr, evJ1 = nullptr, evJ2 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr, evJ1 = nullptr, evJ2 = nullptr, evA = nullptr, evB = nullptr;
     hipGraphExec_t gexec = nullptr; int graph_units = 16; bool graph_valid = false, use_graph = false, graph_fork = false;
     DevCtrl* ctrl_arg = nullptr; DevCtrl host_ctrl;
     int64_t st_graph_steps = 0;
@@ -238,7 +241,7 @@ struct BluesEngine {
     ~BluesEngine() {
         for (BluesSnapshot* sn : snap_pool) { if (sn->block) hipFree(sn->block); delete sn; }
         if (gexec) hipGraphExecDestroy(gexec);
-        for (hipEvent_t e : {ev0, ev1, evFork, evJ1, evJ2}) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : {ev0, ev1, evFork, evJ1, evJ2, evA, evB}) if (e) hipEventDestroy(e);
         for (hipStream_t q : {stream, s1, s2}) if (q) hipStreamDestroy(q);
     }
 };
@@ -264,7 +267,7 @@ struct BluesBatch {
     // list synchronisation: in a large batch some member needs new lists at almost every step, and the launch lasts as long
     // as one rebuild whoever asks; when they all rebuild together (any request rebuilds all) most steps see no rebuild at all
     DBuf<int> d_req; bool sync_lists = false;
-    DBuf<int> d_work;   // [1 + R] members that rebuild their lists in the current force pass (kernels_batch.h: k_gather_stale_b)
+    DBuf<int> d_work;   // [1 + 2R] members that rebuild their lists in the current force pass (kernels_batch.h: k_gather_stale_b)
     BluesTuning tune;   // the process-wide tuning at the time the batch was created
     // argument arena of the batched boundary calls (blues_batch_capture ...): pinned host side, device side, one upload per call
     unsigned char* h_arena = nullptr; size_t arena_cap = 0; DBuf<unsigned char> d_arena;
@@ -856,9 +859,8 @@ static ListArgs make_list_args(BluesEngine* h) {
     return a;
 }
 
-// workgroups of a batch's rebuild kernels (kernels_batch.h: k_gather_stale_b): two per CU; they deal the work items among themselves
-static const int REBUILD_GRID = 512;
-// phase 0: the whole rebuild; 1: the group lists only (k_build_lists); 2: the atoms' own lists only (k_build_atom_lists)
+// phase 0: the whole rebuild; 1: the group lists only (k_build_lists); 2: the atoms' own lists only (k_build_atom_lists);
+// a batch's leader also: 3: the work list only (k_gather_stale_b); 4: the group lists without the work list (1 = 3 then 4)
 template <typename R> static int launch_lists(BluesEngine* h, int force, int phase = 0) {
     if (h->tune.force_lists) force = 1;   // development: every launch rebuilds every list
     const ListArgs a = make_list_args(h);
@@ -866,28 +868,17 @@ template <typename R> static int launch_lists(BluesEngine* h, int force, int pha
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
     if (phase == 2) { }
     else if (batch_lead(h)) {
-        hipLaunchKernelGGL(k_gather_stale_b<R>, dim3(1), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->R(), force, h->batch->d_work.p);
-        hipLaunchKernelGGL(k_build_lists_b<R>, dim3(std::min((h->n_tiles + 2) * h->batch->R(), REBUILD_GRID)), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->d_work.p, h->n_tiles + 2, force);
+        if (phase != 4) hipLaunchKernelGGL(k_gather_stale_b<R>, dim3(1), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->R(), force, h->batch->d_work.p);
+        if (phase != 3) hipLaunchKernelGGL(k_build_lists_b<R>, dim3(std::min((h->n_tiles + 2) * h->batch->R(), REBUILD_GRID)), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->d_work.p, h->n_tiles + 2, force);
     } else if (!batch_dry(h)) {
         hipLaunchKernelGGL(k_build_lists<R>, dim3(h->n_tiles + 2), dim3(LIST_THREADS), 0, h->cur, a, make_nbconst<R>(h), img, force);
     }
-    if (phase != 1 && h->k1_mode == 2 && h->n_itiles > 0) {
-        // second kernel of a rebuild (same gate): the atoms' own lists, one block per i-tile; the group's list lives in
-        // dynamic LDS there (positions 12 B + index 4 B per entry: 100 KB at the largest capacity, which leaves room for a
-        // workgroup of the alchemical kernel on the same CU)
-        const size_t lds = (size_t)h->jcap * 16;
+    if (phase != 1 && phase != 3 && phase != 4 && h->k1_mode == 2 && h->n_itiles > 0) {
+        // second kernel of a rebuild (same gate): the atoms' own lists, ATOM_LIST_PARTS blocks per i-tile (kernels_nb.h: build_atom_lists_body)
         if (!batch_dry(h)) {
-            static thread_local size_t lds_set[2] = {0, 0};
-            const bool lead = batch_lead(h);
-            if (lds > lds_set[lead]) {
-                hipError_t e = lead ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_atom_lists_b<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                                    : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_atom_lists<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) E_FAIL(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
-                lds_set[lead] = lds;
-            }
-            const int items = h->n_itiles * ATOM_LIST_PARTS;   // (an i-tile's atoms are split over ATOM_LIST_PARTS blocks)
-            if (lead) hipLaunchKernelGGL(k_build_atom_lists_b<R>, dim3(std::min(items * h->batch->R(), REBUILD_GRID)), dim3(LIST_THREADS), lds, h->cur, batch_reps_nb<R>(h->batch), h->batch->d_work.p, items, force);
-            else hipLaunchKernelGGL(k_build_atom_lists<R>, dim3(items), dim3(LIST_THREADS), lds, h->cur, a, make_nbconst<R>(h), img, force);
+            const int items = h->n_itiles * ATOM_LIST_PARTS;
+            if (batch_lead(h)) hipLaunchKernelGGL(k_build_atom_lists_b<R>, dim3(std::min(items * h->batch->R(), 4 * REBUILD_GRID)), dim3(ATOM_LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->d_work.p, items, force);
+            else hipLaunchKernelGGL(k_build_atom_lists<R>, dim3(items), dim3(ATOM_LIST_THREADS), 0, h->cur, a, make_nbconst<R>(h), img, force);
         }
         h->st_launches++;
     }
@@ -993,15 +984,19 @@ template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
 static AlchArgs make_alch_args(BluesEngine* h, const double ls[3], const double le[3], int slot_mask);
 static AlchDyn make_alch_dyn(const AlchArgs& A) { AlchDyn d; for (int s = 0; s < 3; s++) { d.ls[s] = A.ls[s]; d.le[s] = A.le[s]; } d.slot_mask = A.slot_mask; return d; }
 
-static int launch_alchemical(BluesEngine* h, const double ls[3], const double le[3], int slot_mask) {
+// part (a batch's leader only; kernels_batch.h: k_alchemical_b): 0 every member, 1 those that do not rebuild their lists in this
+// force pass, 2 those that do (both from the work list of the rebuild)
+static int launch_alchemical(BluesEngine* h, const double ls[3], const double le[3], int slot_mask, int part = 0) {
     if (h->alch.empty()) return 0;
     AlchArgs A = make_alch_args(h, ls, le, slot_mask);
     const bool fast = h->precision == 0;
     if (batch_lead(h)) {
         const int nb = std::min(h->k2_nblocks_env, K2_PHYS) + 1, nrep = h->batch->R();   // (a lone chain keeps one block per logical block: shortest chain)
         const AlchDyn D = make_alch_dyn(A);
-        const dim3 g(nb * nrep), b(256);
-#define ALCH_B(F, M) hipLaunchKernelGGL((k_alchemical_b<F, M>), g, b, 0, h->cur, h->batch->d_core.p, D, nb, nrep)
+        const dim3 g(part == 2 ? std::min(nb * nrep, 8 * REBUILD_GRID) : nb * nrep), b(256);
+        const int* work = h->batch->d_work.p;
+#define ALCH_B(F, M) do { if (part == 2) hipLaunchKernelGGL((k_alchemical_stale_b<F, M>), g, b, 0, h->cur, h->batch->d_core.p, D, nb, work); \
+                          else hipLaunchKernelGGL((k_alchemical_b<F, M>), g, b, 0, h->cur, h->batch->d_core.p, D, nb, nrep, part == 1 ? work : (const int*)nullptr); } while (0)
         if (fast) { if (slot_mask == 5) ALCH_B(true, 5); else if (slot_mask == 2) ALCH_B(true, 2); else ALCH_B(true, -1); }
         else { if (slot_mask == 5) ALCH_B(false, 5); else if (slot_mask == 2) ALCH_B(false, 2); else ALCH_B(false, -1); }
 #undef ALCH_B
@@ -1325,19 +1320,41 @@ static int force_pass(BluesEngine* h, int base_L) {
     const bool fork_env = (h->batch ? h->batch->tune.fork : h->tune.fork) != 0;
     const bool decomposed = !(h->fuse_forces && h->wpb == 4) && !(h->k1_mode == 1 && h->precision == 0 && h->fuse_big);
     const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && !h->alch.empty() && h->s1 && !h->ctrl_arg;
-    int rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, fork ? 1 : 0) : launch_lists<double>(h, h->lists_forced, fork ? 1 : 0);
-    if (rc) return 1;
+    // k2_early (off by default): the alchemical kernel of the members that do NOT rebuild needs nothing from the rebuild and can
+    // start as soon as the work list says who they are, with the rebuild kernels on a high-priority stream beside it and the
+    // members that rebuild following their group lists.  Measured at R = 512 (round 3): 545-565 us per step against 545-555
+    // without -- the step is bound by the sum of the kernels' work, not by their order ("what the timeline says").
+    // In the default order the atoms' lists are enqueued BEFORE the alchemical kernel: behind its 12,800 small workgroups the
+    // few workgroups of the rebuild waited for room on full CUs (245 us against 107 us alone).
+    const bool early = fork && h->s2 && !h->lists_forced && !h->tune.force_lists && (h->batch ? h->batch->tune.k2_early : h->tune.k2_early) != 0;
+    int rc = 0;
+    bool wait_lists = false;
     if (fork) {
         hipStream_t main_stream = h->cur;
-        HIP_OK(h, hipEventRecord(h->evFork, main_stream)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evFork, 0));
-        // The atoms' lists are enqueued BEFORE the alchemical kernel: its few workgroups want ~100 KB of LDS each, and once the
-        // alchemical kernel's 12,800 small ones have filled every CU they wait for two of them to retire from the same CU at
-        // once (round 3 timeline: 245 us beside the alchemical kernel against 107 us alone).
-        rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, 2) : launch_lists<double>(h, h->lists_forced, 2);
+        hipStream_t rb = early ? h->s2 : main_stream;   // the rebuild's stream (high priority: see engine creation)
+#define LISTS(ph) (h->precision == 0 ? launch_lists<float>(h, h->lists_forced, ph) : launch_lists<double>(h, h->lists_forced, ph))
+        if (early) { HIP_OK(h, hipEventRecord(h->evFork, main_stream)); HIP_OK(h, hipStreamWaitEvent(rb, h->evFork, 0)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evFork, 0)); }
+        h->cur = rb; rc = LISTS(3); h->cur = main_stream;
         if (rc) return 1;
-        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask) || launch_bonded(h, true); h->cur = main_stream;   // (bonded terms and the next O step's noise need no list either; the long kernel first)
+        if (early) {
+            HIP_OK(h, hipEventRecord(h->evA, rb)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evA, 0));
+            h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, 1); h->cur = main_stream;
+            if (rc) return 1;
+        }
+        h->cur = rb; rc = LISTS(4); h->cur = main_stream;
+        if (rc) return 1;
+        HIP_OK(h, hipEventRecord(h->evJ2, rb)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evJ2, 0));
+        h->cur = rb; rc = LISTS(2); h->cur = main_stream;
+        if (rc) return 1;
+        if (early) { HIP_OK(h, hipEventRecord(h->evB, rb)); wait_lists = true; }
+#undef LISTS
+        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, early ? 2 : 0) || launch_bonded(h, true); h->cur = main_stream;   // (bonded terms and the next O step's noise need no list either)
         if (rc) return 1;
         HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
+        if (wait_lists) HIP_OK(h, hipStreamWaitEvent(main_stream, h->evB, 0));
+    } else {
+        rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, 0) : launch_lists<double>(h, h->lists_forced, 0);
+        if (rc) return 1;
     }
     h->lists_forced = false;
     if (h->fuse_forces && h->wpb == 4) {
@@ -2194,9 +2211,17 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     h->prog.n = 0;
     HIP_OK(h, hipSetDevice(h->device));
     HIP_OK(h, hipStreamCreate(&h->stream));
-    HIP_OK(h, hipStreamCreate(&h->s1)); HIP_OK(h, hipStreamCreate(&h->s2)); h->cur = h->stream;
+    HIP_OK(h, hipStreamCreate(&h->s1));
+    {   // s2 carries a batch's rebuild kernels (force_pass): a few workgroups on the critical path that must find room on CUs the
+        // alchemical kernel has filled -- at equal priority the dispatcher keeps refilling those CUs with that kernel's workgroups
+        int least = 0, greatest = 0;
+        HIP_OK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_OK(h, hipStreamCreateWithPriority(&h->s2, hipStreamDefault, greatest));
+    }
+    h->cur = h->stream;
     HIP_OK(h, hipEventCreate(&h->ev0)); HIP_OK(h, hipEventCreate(&h->ev1));
     HIP_OK(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ1, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ2, hipEventDisableTiming));
+    HIP_OK(h, hipEventCreateWithFlags(&h->evA, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evB, hipEventDisableTiming));
     if (h->tune.use_graph >= 0) h->use_graph = h->tune.use_graph != 0;
     if (h->tune.fast_step >= 0) h->fast_step = h->tune.fast_step != 0;
     if (h->tune.fuse_big >= 0) h->fuse_big = h->tune.fuse_big != 0;
@@ -2945,7 +2970,7 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
     B->sync_lists = false;
     B->tune = g_tuning;
     B->sync_lists = B->tune.batch_sync_lists != 0;
-    try { B->d_req.alloc(1); B->d_work.alloc((size_t)count + 1); } catch (std::string& e) { g_batch_create_error = e; batch_detach_all(B); delete B; return 1; }
+    try { B->d_req.alloc(1); B->d_work.alloc((size_t)2 * count + 1); } catch (std::string& e) { g_batch_create_error = e; batch_detach_all(B); delete B; return 1; }
     B->seen_epoch.assign(count, 0); B->failed.assign(count, 0); B->active.assign(count, 1); B->rec_active.assign(count, 0); B->rec_delta.assign(count, 0); B->leader = engines[0];
     *out = B;
     return 0;

@@ -64,9 +64,10 @@ __device__ __forceinline__ void apply_dyn(IntArgs& A, const IntDyn& d, unsigned 
 // that find nothing to do, each a 1024-thread workgroup that wants ~100 KB of LDS and is alone on its CU while it finds out
 // (R = 512: 5,120 of them, twenty rounds of dispatch for ~200 with work).  Instead one small kernel writes the ordered list of
 // the members that rebuild (work[0] = how many, work[1..] = which) and the rebuild kernels run a SMALL grid whose workgroups
-// deal the (member, tile) items of those members among themselves.
+// deal the (member, tile) items of those members among themselves.  The alchemical kernel uses the same list to run in two
+// parts (k_alchemical_b): the members that do not rebuild need nothing from the rebuild and start beside it.
 template <typename R>
-__global__ void __launch_bounds__(LIST_THREADS) k_gather_stale_b(const RepNb<R>* __restrict__ reps, int nrep, int force, int* __restrict__ work) {
+__global__ void __launch_bounds__(LIST_THREADS) k_gather_stale_b(const RepNb<R>* __restrict__ reps, int nrep, int force, int* __restrict__ work) {   // work[1 + nrep + r] = member r rebuilds (0 / 1)
     __shared__ int s_cnt[LIST_WAVES]; __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_base = 0;
@@ -84,6 +85,7 @@ __global__ void __launch_bounds__(LIST_THREADS) k_gather_stale_b(const RepNb<R>*
         int rank = s_base + __popcll(bal & ((1ull << lane) - 1ull));
         for (int w = 0; w < wv; w++) rank += s_cnt[w];
         if (act) work[1 + rank] = r;
+        if (r < nrep) work[1 + nrep + r] = act ? 1 : 0;
         __syncthreads();
         if (tid == 0) { int tot = 0; for (int w = 0; w < LIST_WAVES; w++) tot += s_cnt[w]; s_base += tot; }
         __syncthreads();
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(LIST_THREADS) k_build_lists_b(const RepNb<R>* 
 }
 
 template <typename R>
-__global__ void __launch_bounds__(LIST_THREADS) k_build_atom_lists_b(const RepNb<R>* __restrict__ reps, const int* __restrict__ work, int bpc, int force) {
+__global__ void __launch_bounds__(ATOM_LIST_THREADS) k_build_atom_lists_b(const RepNb<R>* __restrict__ reps, const int* __restrict__ work, int bpc, int force) {
     const int nact = work[0];
     for (int i = blockIdx.x; i < nact * bpc; i += gridDim.x) {
         const int m = i / bpc;
@@ -158,12 +160,26 @@ __global__ void __launch_bounds__(PME_THREADS) k_pme_fast_b(const RepNb<float>* 
     pme_fast_body<5>(P);
 }
 
+// stale: null = every member; else the work list of the rebuild (k_gather_stale_b): the members that rebuild are left to
+// k_alchemical_stale_b, which follows the rebuild of the group lists (the alchemical tile's records are among them)
 template <bool FAST, int MASK>
-__global__ void __launch_bounds__(256, 3) k_alchemical_b(const RepCore* __restrict__ reps, AlchDyn d, int nb, int nrep) {
+__global__ void __launch_bounds__(256, 3) k_alchemical_b(const RepCore* __restrict__ reps, AlchDyn d, int nb, int nrep, const int* __restrict__ stale) {
     int rep, bx; batch_decode(nb, nrep, rep, bx);
     if (!reps[rep].active) return;
+    if (stale && stale[1 + nrep + rep]) return;
     AlchArgs A = reps[rep].al; apply_dyn(A, d);
     alchemical_blocks<FAST, MASK>(A, bx, nb - 1);
+}
+
+template <bool FAST, int MASK>
+__global__ void __launch_bounds__(256, 3) k_alchemical_stale_b(const RepCore* __restrict__ reps, AlchDyn d, int nb, const int* __restrict__ work) {
+    const int nact = work[0];
+    for (int i = blockIdx.x; i < nact * nb; i += gridDim.x) {
+        const int m = i / nb;
+        AlchArgs A = reps[work[1 + m]].al; apply_dyn(A, d);
+        alchemical_blocks<FAST, MASK>(A, i - m * nb, nb - 1);
+        __syncthreads();   // (the next item reuses the LDS staging)
+    }
 }
 
 __global__ void __launch_bounds__(128) k_bonded_entries_b(const RepCore* __restrict__ reps, BondedDyn d) {

@@ -75,9 +75,12 @@ struct ListArgs {
 #define LIST_WAVES 16
 #define LIST_PREFETCH 4
 #define LIST_THREADS (LIST_WAVES * 64)
-#define ATOM_LIST_U 2                       // atoms per wave of build_atom_lists_body
-#define ATOM_LIST_PARTS (4 / ATOM_LIST_U)    // its blocks per i-tile (LIST_WAVES * 4 = 64 slots)
-#define ATOM_SLOT(part, wv, u) ((part) * (64 / ATOM_LIST_PARTS) + (wv) + LIST_WAVES * (u))
+#define ATOM_LIST_WAVES 4                   // waves per block of build_atom_lists_body: a 256-thread block with < 168 registers per
+#define ATOM_LIST_THREADS (ATOM_LIST_WAVES * 64)   // lane fits exactly where a workgroup of the alchemical kernel retires
+#define ATOM_LIST_U 2                       // atoms per wave
+#define ATOM_LIST_PARTS (64 / (ATOM_LIST_WAVES * ATOM_LIST_U))    // its blocks per i-tile
+#define ATOM_SLOT(part, wv, u) ((part) * (64 / ATOM_LIST_PARTS) + (wv) + ATOM_LIST_WAVES * (u))
+#define ATOM_LIST_MOBW 1024                 // words of its mobile-candidate bitmap (list capacity <= 32768)
 #define EXK_MAX 64       // excluded partners of one i-atom that can sit in its tile's list (+ sentinel); per-atom-list mode
 #define LIST_LDS 8192      // j-list entries mirrored in LDS for the exclusion searches (longer lists are searched in HBM)
 
@@ -320,22 +323,28 @@ __global__ void __launch_bounds__(LIST_THREADS) k_build_lists(ListArgs a, NbCons
     build_lists_body<R>(a, c, img, force, blockIdx.x, gridDim.x);
 }
 
-// ---- per-atom Verlet lists (second kernel of a rebuild, per-atom-list mode): one block per i-TILE; wave wv serves the
-// i-slots wv, wv+16, wv+32, wv+48.  The list of the tile's group is staged in LDS (positions as floats relative to the
-// tile's first atom; sorted index + mobile bit) and walked once per wave, every lane testing one candidate against the wave's
-// four i-atoms (wave-uniform); hits are compacted in list order (ballot + prefix count), so an atom's list is ascending in
-// the local index and consecutive lanes of the force kernel read neighbouring LDS addresses.  Exclusions: each i-atom's
-// excluded partners are looked up in the list once (binary search) and set bits in an LDS bitmap [slot][chunk]; the running
-// counts live in vector registers (v_bcnt / v_mbcnt) -- a CU has ONE scalar ALU for its 16 waves, and the first version of
-// this loop, which kept them in scalar registers, was bound by it.
+// ---- per-atom Verlet lists (second kernel of a rebuild, per-atom-list mode): one block per PART of an i-tile (ATOM_LIST_PARTS
+// parts; wave wv of part p serves ATOM_LIST_U slots, ATOM_SLOT).  Every wave walks the list of the tile's group once, 64
+// candidates at a time, each lane testing one candidate against the wave's atoms (wave-uniform); hits are compacted in list
+// order (ballot + prefix count), so an atom's list is ascending in the local index and consecutive lanes of the force kernel
+// read neighbouring LDS addresses.  The candidates' positions are STREAMED from the packed image the first kernel of the
+// rebuild wrote (fixed point, 16 B per entry, L2-resident: every wave of the block reads the same 1 KB per step; the next
+// chunk is requested before the current one is tested).  The first version staged them in ~100 KB of LDS: such a workgroup
+// is alone on its CU and, worse, finds no CU at all once the alchemical kernel's small workgroups have filled the chip -- the
+// few workgroups of a rebuild then waited out most of that kernel (round 3 timelines: 215-245 us instead of 107).  Registers
+// bind in the same way: the alchemical kernel holds 3 x 168 of a SIMD's 512, so what follows is built to fit the slot ONE of
+// its workgroups leaves (4 waves, one per SIMD, < 168 registers) instead of needing a CU to drain.
+// A difference of fixed-point coordinates IS the minimum image (the box spans 2^32), so there is no reference point and no wrap.
+// Exclusions: each i-atom's excluded partners are looked up in the list once (binary search) and kept as local indices with
+// the range of chunks they fall into; the running counts live in vector registers (v_bcnt / v_mbcnt) -- a CU has ONE scalar
+// ALU for its 16 waves, and the first version of this loop, which kept them in scalar registers, was bound by it.
 // The pair kernel tests r < cutoff itself; what must hold here is "within cutoff+skin now" (float, with margin).
 template <typename R>
 __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force, const int item) {
-    // one block = one PART of an i-tile: ATOM_LIST_U of its atoms per wave (parts of a tile: 4 / ATOM_LIST_U).  The chunk loop is
-    // VALU-bound inside its CU, so a tile split over two CUs halves the latency every batched round waits for.
-    const int t = item / ATOM_LIST_PARTS, part = item - t * ATOM_LIST_PARTS;
-    using sfix = typename Img<R>::sfix;
     using ufix = typename Img<R>::ufix;
+    if constexpr (sizeof(ufix) != 4) return;   // (per-atom lists exist in mixed precision only)
+    else {
+    const int t = item / ATOM_LIST_PARTS, part = item - t * ATOM_LIST_PARTS;
     if (!force && a.flags->list_gen == a.flags->req_gen && !(a.batch_req && *a.batch_req)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (t >= a.n_itiles) return;
@@ -346,54 +355,36 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     const int count = a.jcount[l];
     const int* jl = a.jlist + (size_t)l * a.jcap;
     const int nch = (count + 63) >> 6;
-    extern __shared__ __align__(16) unsigned char list_smem[];
-    float* sx = reinterpret_cast<float*>(list_smem); float* sy = sx + a.jcap; float* sz = sy + a.jcap;
-    int* s_jm = reinterpret_cast<int*>(sz + a.jcap);                              // sorted index | mobile << 30
-    // excluded candidates of each i-slot as a short list of local indices (a [slot][chunk] bitmap cost a third of the LDS image and
-    // kept the alchemical kernel's workgroups off every CU this kernel ran on), with the range of chunks they fall into
+    const bool packed = a.pimg4 != nullptr;   // (block-uniform; without the packed image the candidates are gathered through the list)
+    const uint4* g4 = packed ? a.pimg4 + (size_t)l * a.jcap : nullptr;
     __shared__ unsigned short s_ex[64][EXK_MAX];
     __shared__ int s_exn[64], s_exlo[64], s_exhi[64];
+    __shared__ unsigned s_mob[ATOM_LIST_MOBW];   // packed image: one bit per list entry, set for mobile candidates (from the group's mobile list)
     const float cfs[3] = {(float)c.dscale[0], (float)c.dscale[1], (float)c.dscale[2]};
     const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f, rl2m = (float)c.rlist2_m * 1.0001f + 1e-5f;
     NB_STAMP(t == 0 && tid == 0, 5);
-    const int i0 = a.tile_atoms[t * 64];
-    const ufix ref[3] = {img[i0].x, img[i0].y, img[i0].z};
-    __shared__ int s_amax[3];   // largest |coordinate| of a candidate per axis (bits of a non-negative float), for the wrap decision below
-    if (tid < 3) s_amax[tid] = 0;
-    __syncthreads();
-    {
-        float am[3] = {0.0f, 0.0f, 0.0f};
-        for (int k = tid; k < count; k += LIST_THREADS) {
-            const int js = jl[k];
-            const ufix qx = img[js].x, qy = img[js].y, qz = img[js].z; const unsigned fl = img[js].flags;
-            s_jm[k] = js | ((fl & FLAG_MOBILE) ? 0x40000000 : 0);
-            const float x = (float)(sfix)(qx - ref[0]) * cfs[0], y = (float)(sfix)(qy - ref[1]) * cfs[1], z = (float)(sfix)(qz - ref[2]) * cfs[2];
-            sx[k] = x; sy[k] = y; sz[k] = z;
-            am[0] = fmaxf(am[0], fabsf(x)); am[1] = fmaxf(am[1], fabsf(y)); am[2] = fmaxf(am[2], fabsf(z));
-        }
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            for (int o = 32; o > 0; o >>= 1) am[d] = fmaxf(am[d], __shfl_xor(am[d], o, 64));
-            if (lane == 0) atomicMax(&s_amax[d], __float_as_int(am[d]));
-        }
-    }
     if (tid < 64) { s_exn[tid] = 0; s_exlo[tid] = 0x7fffffff; s_exhi[tid] = -1; }
+    for (int w = tid; w < ATOM_LIST_MOBW; w += ATOM_LIST_THREADS) s_mob[w] = 0u;
     __syncthreads();
+    if (packed) {
+        const int* ml = a.mlist + (size_t)l * a.mcap * 2; const int mc = a.mcount[l];
+        for (int q = tid; q < mc; q += ATOM_LIST_THREADS) { const int k = ml[2 * q]; atomicOr(&s_mob[k >> 5], 1u << (k & 31)); }
+    }
     NB_STAMP(t == 0 && tid == 0, 6);
-    int ia4[ATOM_LIST_U]; float pi4[ATOM_LIST_U][3]; bool ok4[ATOM_LIST_U];
+    int ia4[ATOM_LIST_U]; uint32_t xi4[ATOM_LIST_U][3]; bool ok4[ATOM_LIST_U];
 #pragma unroll
     for (int u = 0; u < ATOM_LIST_U; u++) {
         const int slot = ATOM_SLOT(part, wv, u);
         ia4[u] = __builtin_amdgcn_readfirstlane(a.tile_atoms[t * 64 + slot]);
         const int iq = ia4[u] >= 0 ? ia4[u] : 0;
-        pi4[u][0] = (float)(sfix)(img[iq].x - ref[0]) * cfs[0]; pi4[u][1] = (float)(sfix)(img[iq].y - ref[1]) * cfs[1]; pi4[u][2] = (float)(sfix)(img[iq].z - ref[2]) * cfs[2];
+        xi4[u][0] = __builtin_amdgcn_readfirstlane((uint32_t)img[iq].x); xi4[u][1] = __builtin_amdgcn_readfirstlane((uint32_t)img[iq].y); xi4[u][2] = __builtin_amdgcn_readfirstlane((uint32_t)img[iq].z);
         ok4[u] = ia4[u] >= 0;   // an empty slot passes nobody
         const int e0 = ia4[u] >= 0 ? a.ex_start[iq] : 0, e1 = ia4[u] >= 0 ? a.ex_start[iq + 1] : 0;
         for (int q = lane; q < e1 - e0; q += 64) {
             const int p = a.ex_idx[e0 + q];
             int lo = 0, hi = count;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((s_jm[mid] & 0x3FFFFFFF) < p) lo = mid + 1; else hi = mid; }
-            if (lo < count && (s_jm[lo] & 0x3FFFFFFF) == p) {
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (jl[mid] < p) lo = mid + 1; else hi = mid; }
+            if (lo < count && jl[lo] == p) {
                 const int at = atomicAdd(&s_exn[slot], 1);
                 if (at < EXK_MAX) { s_ex[slot][at] = (unsigned short)lo; atomicMin(&s_exlo[slot], lo >> 6); atomicMax(&s_exhi[slot], lo >> 6); }
                 else a.flags->list_overflow = 1;   // (more excluded partners in range than any supported topology has)
@@ -413,76 +404,64 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     for (int u = 0; u < ATOM_LIST_U; u++) cntv[u] = cntp[u] = 0;
     unsigned short* out4[ATOM_LIST_U]; unsigned short* outp4[ATOM_LIST_U];
     const bool dual = a.plist != nullptr;
-    const float rp2 = c.rp2 * 1.0001f + 1e-5f, rp2m = c.rp2_m * 1.0001f + 1e-5f;   // (float distances relative to the tile: same safety margin as the full lists)
+    const float rp2 = c.rp2 * 1.0001f + 1e-5f, rp2m = c.rp2_m * 1.0001f + 1e-5f;   // (same safety margin as the full lists)
 #pragma unroll
     for (int u = 0; u < ATOM_LIST_U; u++) { out4[u] = a.alist + ((size_t)t * 64 + ATOM_SLOT(part, wv, u)) * a.acap; outp4[u] = dual ? a.plist + ((size_t)t * 64 + ATOM_SLOT(part, wv, u)) * a.acap : nullptr; }
     const float INF = __builtin_inff();
     const int acap1 = a.acap - 1;
-    // both positions are relative to the tile's first atom (each one a minimum image OF THAT ATOM): their difference is the
-    // minimum image of the pair only while the list's extent stays below half a box edge, hence the explicit wrap below
-    const float boxf[3] = {(float)(c.dscale[0] * 4294967296.0 * (sizeof(ufix) == 8 ? 4294967296.0 : 1.0)), (float)(c.dscale[1] * 4294967296.0 * (sizeof(ufix) == 8 ? 4294967296.0 : 1.0)), (float)(c.dscale[2] * 4294967296.0 * (sizeof(ufix) == 8 ? 4294967296.0 : 1.0))};
-    const float iboxf[3] = {1.0f / boxf[0], 1.0f / boxf[1], 1.0f / boxf[2]};
-    // Both positions of a pair are relative to the tile's first atom.  The periodic wrap of their difference matters only if the
-    // wrapped image can be in range, i.e. if |difference| can reach (box edge - list radius): below that a pair is either the
-    // minimum image already or out of range both ways.  Decided per wave from its atoms' and the candidates' largest
-    // |coordinates| (9 of the ~40 instructions of a test).
-    bool wrap = false;
-    {
-        const float rlmax = sqrtf(fmaxf(rl2, rl2m));
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            float bw = 0.0f;
-#pragma unroll
-            for (int u = 0; u < ATOM_LIST_U; u++) if (ok4[u]) bw = fmaxf(bw, fabsf(pi4[u][d]));
-            wrap |= __int_as_float(s_amax[d]) + bw >= boxf[d] - rlmax;
-        }
-        wrap = __builtin_amdgcn_readfirstlane((int)wrap) != 0;
-    }
-    auto chunk_loop = [&](auto wrap_tag) {
-        constexpr bool WRAP = decltype(wrap_tag)::value;
-        for (int ch = 0; ch < nch; ch++) {
-            const int k = ch * 64 + lane, kk = min(k, count - 1);
-            const float x = sx[kk], y = sy[kk], z = sz[kk];
-            const bool mob = (s_jm[kk] & 0x40000000) != 0;
-            const unsigned short ent = (unsigned short)(k | (mob ? 0x8000 : 0));
-            const float kinf = k < count ? 0.0f : INF;
-            const float lim = mob ? rl2m : rl2, plim = mob ? rp2m : rp2;
-#pragma unroll
-            for (int u = 0; u < ATOM_LIST_U; u++) {
-                bool excluded = false;
-                if (ch >= exlo4[u] && ch <= exhi4[u]) {   // wave-uniform; a handful of chunks per atom
-                    const unsigned short* ex = s_ex[ATOM_SLOT(part, wv, u)];
-                    for (int e = 0; e < exn4[u]; e++) excluded |= (int)ex[e] == k;   // same address in every lane: broadcast
-                }
-                float dx = x - pi4[u][0], dy = y - pi4[u][1], dz = z - pi4[u][2];
-                if (WRAP) { dx -= boxf[0] * rintf(dx * iboxf[0]); dy -= boxf[1] * rintf(dy * iboxf[1]); dz -= boxf[2] * rintf(dz * iboxf[2]); }
-                float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + kinf;
-                d2 = excluded ? INF : d2;
-                const bool pass = d2 < lim && ok4[u];
-                const unsigned long long bal = __ballot(pass);
-                const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
-                const int pos = cntv[u] + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
-                // running count on the vector ALU.  gfx950 needs two wait states between a VALU write of an SGPR / VCC (the
-                // compare behind the ballot) and a VALU read of it as an operand; the compiler inserts them for its own
-                // instructions but not around inline assembly (without the s_nop the counts came out stale)
-                int c2;
-                asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c2) : "s"(blo), "s"(bhi), "v"(cntv[u]));
-                cntv[u] = c2;
-                if (pass) out4[u][min(pos, acap1)] = ent;   // on overflow (flagged below) the surplus lands on the last entry
-                if (dual) {   // (block-uniform) the pruned list: the same entries within cutoff + inner margin, same order
-                    const bool keep = pass && d2 < plim;
-                    const unsigned long long bk = __ballot(keep);
-                    const unsigned klo = (unsigned)bk, khi = (unsigned)(bk >> 32);
-                    const int ppos = cntp[u] + (int)__builtin_amdgcn_mbcnt_hi(khi, __builtin_amdgcn_mbcnt_lo(klo, 0u));
-                    int c3;
-                    asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c3) : "s"(klo), "s"(khi), "v"(cntp[u]));
-                    cntp[u] = c3;
-                    if (keep) outp4[u][min(ppos, acap1)] = ent;
-                }
-            }
+    auto fetch = [&](int ch, uint32_t& qx, uint32_t& qy, uint32_t& qz, bool& mob) {
+        const int kk = min(ch * 64 + lane, count - 1);
+        if (packed) {
+            const uint4 v = g4[kk];
+            qx = v.x; qy = v.y; qz = v.z; mob = ((s_mob[(ch * 64 + lane) >> 5] >> (lane & 31)) & 1u) != 0;
+        } else {
+            const int js = jl[kk];
+            qx = (uint32_t)img[js].x; qy = (uint32_t)img[js].y; qz = (uint32_t)img[js].z; mob = (img[js].flags & FLAG_MOBILE) != 0;
         }
     };
-    if (wrap) chunk_loop(std::true_type{}); else chunk_loop(std::false_type{});
+    uint32_t qx = 0, qy = 0, qz = 0; bool mob = false;
+    if (nch > 0) fetch(0, qx, qy, qz, mob);
+    for (int ch = 0; ch < nch; ch++) {
+        uint32_t nx = 0, ny = 0, nz = 0; bool nmob = false;
+        if (ch + 1 < nch) fetch(ch + 1, nx, ny, nz, nmob);   // (in flight while this chunk is tested)
+        const int k = ch * 64 + lane;
+        const unsigned short ent = (unsigned short)(k | (mob ? 0x8000 : 0));
+        const float kinf = k < count ? 0.0f : INF;
+        const float lim = mob ? rl2m : rl2, plim = mob ? rp2m : rp2;
+#pragma unroll
+        for (int u = 0; u < ATOM_LIST_U; u++) {
+            bool excluded = false;
+            if (ch >= exlo4[u] && ch <= exhi4[u]) {   // wave-uniform; a handful of chunks per atom
+                const unsigned short* ex = s_ex[ATOM_SLOT(part, wv, u)];
+                for (int e = 0; e < exn4[u]; e++) excluded |= (int)ex[e] == k;   // same address in every lane: broadcast
+            }
+            const float dx = (float)(int32_t)(qx - xi4[u][0]) * cfs[0], dy = (float)(int32_t)(qy - xi4[u][1]) * cfs[1], dz = (float)(int32_t)(qz - xi4[u][2]) * cfs[2];
+            float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + kinf;
+            d2 = excluded ? INF : d2;
+            const bool pass = d2 < lim && ok4[u];
+            const unsigned long long bal = __ballot(pass);
+            const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
+            const int pos = cntv[u] + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
+            // running count on the vector ALU.  gfx950 needs two wait states between a VALU write of an SGPR / VCC (the
+            // compare behind the ballot) and a VALU read of it as an operand; the compiler inserts them for its own
+            // instructions but not around inline assembly (without the s_nop the counts came out stale)
+            int c2;
+            asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c2) : "s"(blo), "s"(bhi), "v"(cntv[u]));
+            cntv[u] = c2;
+            if (pass) out4[u][min(pos, acap1)] = ent;   // on overflow (flagged below) the surplus lands on the last entry
+            if (dual) {   // (block-uniform) the pruned list: the same entries within cutoff + inner margin, same order
+                const bool keep = pass && d2 < plim;
+                const unsigned long long bk = __ballot(keep);
+                const unsigned klo = (unsigned)bk, khi = (unsigned)(bk >> 32);
+                const int ppos = cntp[u] + (int)__builtin_amdgcn_mbcnt_hi(khi, __builtin_amdgcn_mbcnt_lo(klo, 0u));
+                int c3;
+                asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c3) : "s"(klo), "s"(khi), "v"(cntp[u]));
+                cntp[u] = c3;
+                if (keep) outp4[u][min(ppos, acap1)] = ent;
+            }
+        }
+        qx = nx; qy = ny; qz = nz; mob = nmob;
+    }
     NB_STAMP(t == 0 && tid == 0, 8);
 #pragma unroll
     for (int u = 0; u < ATOM_LIST_U; u++) {
@@ -497,10 +476,11 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
             else if (cntv[u] > a.acap - a.acap / 8) a.flags->resort_hint = 1;   // (a re-sort re-derives the capacities)
         }
     }
+    }
 }
 
 template <typename R>
-__global__ void __launch_bounds__(LIST_THREADS) k_build_atom_lists(ListArgs a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, int force) {
+__global__ void __launch_bounds__(ATOM_LIST_THREADS) k_build_atom_lists(ListArgs a, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, int force) {
     build_atom_lists_body<R>(a, c, img, force, blockIdx.x);
 }
 

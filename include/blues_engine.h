@@ -193,6 +193,8 @@ typedef struct BluesTuning {
                                 * depends on how many chains share a launch): what makes "a batch member equals the same
                                 * chain advanced alone, bit for bit" testable */
     int32_t k1_threads;        /* threads per workgroup of the per-atom-list kernel (multiple of 64, <= 1024); 0: 1024 */
+    int32_t k2_early;          /* 1: with `fork`, the alchemical kernel of the members of a batch that do not rebuild their lists
+                                * in a force pass starts beside the rebuild of the others; 0 (default): after the group lists */
 } BluesTuning;
 void blues_tuning_default(BluesTuning *t);
 /* NULL restores the defaults.  Applies to engines and batches created afterwards. */
