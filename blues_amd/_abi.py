@@ -69,7 +69,7 @@ class BluesTuning(C.Structure):
         ("fork", C.c_int32), ("use_graph", C.c_int32), ("graph_units", C.c_int32), ("graph_fork", C.c_int32),
         ("batch_sync_lists", C.c_int32), ("force_lists", C.c_int32), ("no_sphere", C.c_int32),
         ("pme_general", C.c_int32), ("debug_lists", C.c_int32), ("assume_batch", C.c_int32), ("k1_threads", C.c_int32),
-        ("k2_early", C.c_int32),
+        ("k2_dense", C.c_int32), ("k2_early", C.c_int32),
     ]
 
 

@@ -185,6 +185,7 @@ struct BluesEngine {
     std::vector<int> mobile;       // caller indices with mass > 0
     std::vector<HostCluster> clusters;
     int n_itiles = 0, n_tiles = 0, jcap = 0, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0, k2_jiter = 1;
+    bool k2_dense = false;   // the alchemical kernel's env pairs in their dense form (kernels_alch.h: alchemical_dense_body)
     int seg_len = 64, waves_tile = 4, wpb = 4, npart = 1;  // K1 decomposition
     bool fuse_forces = false, fast_step = true, fuse_big = false;  // fuse_big: measured slower (the alchemical role's 140 VGPRs and 36 KB LDS cap the occupancy of the nonbonded role)
     int k1_iw = 64;  // i-atoms per wave in the nonbonded kernel: 64 = classic tile kernel, 8/16 = sub-tile throughput kernel
@@ -685,6 +686,22 @@ static int sort_and_tile(BluesEngine* h) {
     h->k2_jiter = h->n_itiles * h->batch_R <= 32 && h->batch_R < 8 ? 1 : 8;   // measured at R = 256 (us per launch): 2: 160, 4: 123, 8: 110, 16: 113
     if (h->tune.k2_jiter > 0) h->k2_jiter = h->tune.k2_jiter;
     h->k2_jiter = std::min(h->k2_jiter, h->PA);   // an env block stages (256 / PA) * jiter <= K2_STAGE list entries in LDS
+    {   // dense form: large batches in mixed precision whose alchemical group is free (no excluded environment partner) and small
+        double half_min = 1e30; for (int k = 0; k < 3; k++) half_min = std::min(half_min, 0.5 * h->box[k]);
+        int mobile_env = 0; for (int o : h->mobile) mobile_env += h->alch_local[o] < 0;
+        // (its marking pass measures every list entry from the first alchemical atom and subtracts the other atoms' offsets: a pair
+        // within the cutoff comes out as its minimum image as long as half a box edge exceeds cutoff + the group's extent; the
+        // pair pass takes the minimum image itself)
+        double ext = 0.0;
+        for (size_t a = 1; a < h->alch.size(); a++) {
+            double r2 = 0.0;
+            for (int k = 0; k < 3; k++) { double d = h->hx[3 * h->alch[a] + k] - h->hx[3 * h->alch[0] + k]; d -= h->box[k] * std::rint(d / h->box[k]); r2 += d * d; }
+            ext = std::max(ext, std::sqrt(r2));
+        }
+        h->k2_dense = h->precision == 0 && h->k1_mode == 2 && !h->fuse_forces && h->batch_R >= 8 && !h->check_env_excl && !h->alch.empty() && h->alch.size() <= 16 &&
+                      mobile_env <= K2D_MOB && half_min > h->cutoff + ext + 0.3 && h->tune.k2_dense != 0;
+        if (h->k2_dense) h->k2_jiter = 1 << 20;   // one logical env block: k2_env_blocks() = 1 wherever the partial slabs are summed
+    }
     h->k2_nblocks_env = k2_env_blocks(jcap, h->PA, h->k2_jiter);
     // exclusions in sorted space (self included)
     std::vector<int> ex_start(n + 1, 0), ex_idx;
@@ -990,6 +1007,38 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
     if (h->alch.empty()) return 0;
     AlchArgs A = make_alch_args(h, ls, le, slot_mask);
     const bool fast = h->precision == 0;
+    if (h->k2_dense) {
+        // dense env pairs: one workgroup per chain; the alchemical x alchemical block is the other kernel's (a grid of self blocks only)
+        if (batch_dry(h)) { h->st_launches++; return 0; }
+        static thread_local bool opened[2] = {false, false};
+        const bool lead = batch_lead(h);
+        const size_t lds = sizeof(K2DLds);
+        if (!opened[lead]) {
+            hipError_t e = hipSuccess;
+#define OPEN(M) do { if (e == hipSuccess) e = lead ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_alchemical_dense_b<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) \
+                                                    : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_alchemical_dense<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } while (0)
+            OPEN(5); OPEN(2); OPEN(-1);
+#undef OPEN
+            if (e != hipSuccess) E_FAIL(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
+            opened[lead] = true;
+        }
+        if (lead) {
+            const int nrep = h->batch->R();
+            const AlchDyn D = make_alch_dyn(A);
+#define DENSE_B(M) do { hipLaunchKernelGGL((k_alchemical_dense_b<M>), dim3(nrep), dim3(K2D_THREADS), lds, h->cur, h->batch->d_core.p, D); \
+                        hipLaunchKernelGGL((k_alchemical_b<true, M>), dim3(nrep), dim3(256), 0, h->cur, h->batch->d_core.p, D, 1, nrep, (const int*)nullptr); } while (0)
+            if (slot_mask == 5) DENSE_B(5); else if (slot_mask == 2) DENSE_B(2); else DENSE_B(-1);
+#undef DENSE_B
+        } else {
+            if (slot_mask == 5) hipLaunchKernelGGL(k_alchemical_dense<5>, dim3(1), dim3(K2D_THREADS), lds, h->cur, A);
+            else if (slot_mask == 2) hipLaunchKernelGGL(k_alchemical_dense<2>, dim3(1), dim3(K2D_THREADS), lds, h->cur, A);
+            else hipLaunchKernelGGL(k_alchemical_dense<-1>, dim3(1), dim3(K2D_THREADS), lds, h->cur, A);
+            hipLaunchKernelGGL(k_alchemical<true>, dim3(1), dim3(256), 0, h->cur, A);
+        }
+        h->st_launches++;
+        HIP_OK(h, hipGetLastError());
+        return 0;
+    }
     if (batch_lead(h)) {
         const int nb = std::min(h->k2_nblocks_env, K2_PHYS) + 1, nrep = h->batch->R();   // (a lone chain keeps one block per logical block: shortest chain)
         const AlchDyn D = make_alch_dyn(A);
@@ -1013,6 +1062,7 @@ static AlchArgs make_alch_args(BluesEngine* h, const double ls[3], const double 
     AlchArgs A; memset(&A, 0, sizeof A);
     A.jrec = h->d_jrec.p; A.arec = h->d_arec.p;
     A.n = h->n; A.n_alch = (int)h->alch.size(); A.PA = h->PA; A.jcap = h->jcap; A.nblocks_env = h->k2_nblocks_env; A.jiter = h->k2_jiter;
+    A.flags_overflow = h->d_flags.p ? &h->d_flags.p->list_overflow : nullptr;
     A.alch_orig = h->d_alch_orig.p; A.jlist = h->d_jlist.p + (size_t)h->n_lists * h->jcap; A.jcount = h->d_jcount.p + h->n_lists;
     A.orig_of_sorted = h->d_orig_of_sorted.p; A.sorted_of_orig = h->d_sorted_of_orig.p;
     for (int k = 0; k < 3; k++) A.x[k] = h->d_x[k].p;
@@ -1326,7 +1376,7 @@ static int force_pass(BluesEngine* h, int base_L) {
     // without -- the step is bound by the sum of the kernels' work, not by their order ("what the timeline says").
     // In the default order the atoms' lists are enqueued BEFORE the alchemical kernel: behind its 12,800 small workgroups the
     // few workgroups of the rebuild waited for room on full CUs (245 us against 107 us alone).
-    const bool early = fork && h->s2 && !h->lists_forced && !h->tune.force_lists && (h->batch ? h->batch->tune.k2_early : h->tune.k2_early) != 0;
+    const bool early = fork && h->s2 && !h->k2_dense && !h->lists_forced && !h->tune.force_lists && (h->batch ? h->batch->tune.k2_early : h->tune.k2_early) != 0;
     int rc = 0;
     bool wait_lists = false;
     if (fork) {
@@ -2138,7 +2188,7 @@ void blues_tuning_default(BluesTuning* t) {
     memset(t, 0, sizeof *t);
     t->struct_size = (int32_t)sizeof *t;
     t->prune_margin = -1.0;
-    t->k1_mode = -1; t->fuse_forces = -1; t->fuse_big = -1; t->fast_step = -1; t->slot_mask = -1; t->fork = 1; t->use_graph = -1; t->graph_fork = -1;
+    t->k1_mode = -1; t->fuse_forces = -1; t->fuse_big = -1; t->fast_step = -1; t->slot_mask = -1; t->fork = 1; t->k2_dense = -1; t->use_graph = -1; t->graph_fork = -1;
 }
 int blues_set_tuning(const BluesTuning* t) {
     if (!t) { blues_tuning_default(&g_tuning); return 0; }

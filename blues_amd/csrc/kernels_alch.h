@@ -57,6 +57,7 @@ struct AlchArgs {
     double* self_part;  // [nblocks][3 slots][3][PA]
     double* e_part;     // [nblocks][K2_NP]
     const DevCtrl* ctrl; // non-null in graph replays: lambda slots come from the device tables
+    int* flags_overflow; // -> DevFlags::list_overflow (the dense form: more mobile list entries than it has accumulators for)
 };
 
 __device__ inline bool excluded_sorted(const int* ex_start, const int* ex_idx, int a_sorted, int j_sorted) {
@@ -370,6 +371,247 @@ __device__ __forceinline__ void alchemical_blocks(AlchArgs& A, const int p, cons
         __syncthreads();   // the next logical block reuses the LDS staging and partial arrays
     }
 }
+
+// ---- dense form of the env pairs (large batches, mixed precision): ONE workgroup per chain.
+// The lane = (alchemical atom, list entry) layout above spends a lane on every combination and finds a pair inside the cutoff
+// in one of six; a wave runs the ~350 fp64 instructions of a pair whenever one of its 64 lanes does (45 % of the time at R =
+// 512), and 12,800 workgroups each pay the same prologue of dependent loads (round 3 floor experiments: 60 us of the 161 us
+// were prologue + epilogue, 80 us pair arithmetic at 35 % lane use).  Here the chain's list is staged once (fp64 positions in
+// LDS), a cheap fp32 sweep lists the pairs within the cutoff IN ORDER (a wave per alchemical atom, list index ascending), and
+// the fp64 pair arithmetic runs over those lists with every lane busy.  Forces are accumulated as 64-bit fixed point in LDS (integer addition is associative: any order gives the same
+// bits, so a chain's result does not depend on what shares the launch); energies stay fp64 per thread and are reduced in a
+// fixed order.  Output: the same partial slabs as alchemical_body, as logical block 0 (the host sets jiter so that
+// k2_env_blocks() = 1); the alchemical x alchemical block is still alchemical_body's.
+// Preconditions (host: k2_dense): no alchemical atom has an excluded environment partner; <= 16 alchemical atoms; at most
+// K2D_MOB mobile atoms; every box edge > 2 (cutoff + outer margin + 2 x extent of the alchemical group).
+#ifndef K2D_EXP
+#define K2D_EXP 0
+#endif
+#define K2D_THREADS 512
+#define K2D_WAVES (K2D_THREADS / 64)
+#define K2D_JC 2560        // list entries staged at a time (an alchemical tile's list is ~2,400 entries; longer lists take more rounds)
+#define K2D_AG 8           // alchemical atoms per marking pass (the pair list holds K2D_AG * K2D_JC entries)
+#define K2D_MOB 320        // mobile entries per round that have a force accumulator
+#define K2D_FIX 1048576.0  // 2^20: the accumulators resolve 1e-6 kJ/mol/nm and hold +-8.8e12
+struct K2DLds {
+    double x[3][K2D_JC];
+    unsigned short pairs[K2D_AG][K2D_JC];   // one segment per alchemical atom of the pass, list index ascending
+    unsigned short mslot[K2D_JC];
+    unsigned long long fj[9][K2D_MOB];
+    unsigned long long fa[9][16];
+    double xa[3][16], asig[16], aeps[16], aq[16];
+    float aoff[3][16];
+    int mcnt[K2D_JC / 64];
+    int pcnt[K2D_AG];
+    double e[K2D_WAVES][K2_NE];
+};
+
+template <int MASK>
+__device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
+    auto slot_on = [&](int s) -> bool { return MASK >= 0 ? ((MASK >> s) & 1) != 0 : ((A.slot_mask >> s) & 1) != 0; };
+    if (A.ctrl) {
+        const int L = A.ctrl->L0 + 2 * A.ctrl->kpass;
+#pragma unroll
+        for (int s = 0; s < 3; s++) { const int Ls = min(L + s, A.ctrl->n_lambda); A.ls[s] = A.ctrl->tab_ls[Ls]; A.le[s] = A.ctrl->tab_le[Ls]; }
+    }
+    extern __shared__ __align__(16) unsigned char k2d_smem[];
+    K2DLds& S = *reinterpret_cast<K2DLds*>(k2d_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int count = *A.jcount;
+    if (count <= 0) return;   // (finalize reads no env slab then)
+    const bool no_elec = A.le[0] == 0.0 && A.le[1] == 0.0 && A.le[2] == 0.0, same_ls = A.ls[0] == A.ls[1] && A.ls[1] == A.ls[2];   // (uniform)
+    double e[K2_NE];
+#pragma unroll
+    for (int q = 0; q < K2_NE; q++) e[q] = 0.0;
+    for (int w = tid; w < 9 * 16; w += K2D_THREADS) S.fa[w / 16][w % 16] = 0ull;
+    if (tid < 16) {
+        const bool on = tid < A.n_alch;
+        const int ao = on ? A.arec[tid].ao : 0;
+        S.xa[0][tid] = on ? A.x[0][ao] : 0.0; S.xa[1][tid] = on ? A.x[1][ao] : 0.0; S.xa[2][tid] = on ? A.x[2][ao] : 0.0;
+        S.asig[tid] = on ? A.arec[tid].sig : 0.0; S.aeps[tid] = on ? A.arec[tid].eps : 0.0; S.aq[tid] = on ? A.arec[tid].q : 0.0;
+    }
+    __syncthreads();
+    if (tid < 16) {   // the alchemical atoms relative to the first of them (fp32: the marking pass)
+#pragma unroll
+        for (int k = 0; k < 3; k++) S.aoff[k][tid] = (float)min_image_d(S.xa[k][tid] - S.xa[k][0], A.box.L[k], A.box.invL[k]);
+    }
+    const float rc2m = (float)A.rc2 * 1.0001f + 1e-5f;   // the marking pass keeps a margin; the pair pass tests r < cutoff itself, in fp64
+    constexpr int NIT = K2D_JC / K2D_THREADS;
+    for (int j0 = 0; j0 < count; j0 += K2D_JC) {
+        const int nst = min(K2D_JC, count - j0), nchunk = (nst + 63) >> 6;
+        // ---- stage the round: positions (record -> position: the two dependent loads, all entries of a level in flight together),
+        // mobile entries numbered in list order
+        for (int w = tid; w < 9 * K2D_MOB; w += K2D_THREADS) S.fj[w / K2D_MOB][w % K2D_MOB] = 0ull;
+        int jo[NIT], js[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int kk = min(it * K2D_THREADS + tid, nst - 1);
+            jo[it] = A.jrec[j0 + kk].jo; js[it] = A.jrec[j0 + kk].jsrt;
+        }
+        double px[NIT][3];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) { px[it][0] = A.x[0][jo[it]]; px[it][1] = A.x[1][jo[it]]; px[it][2] = A.x[2][jo[it]]; }
+        bool mob[NIT]; int mrank[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int k = it * K2D_THREADS + tid, ch = k >> 6;
+            S.x[0][k] = px[it][0]; S.x[1][k] = px[it][1]; S.x[2][k] = px[it][2];   // (entries past the end repeat the last one)
+            mob[it] = k < nst && ((js[it] >> 30) & 1);
+            const unsigned long long b = __ballot(mob[it]);
+            mrank[it] = __popcll(b & ((1ull << lane) - 1ull));
+            if (lane == 0) S.mcnt[ch] = __popcll(b);
+        }
+        __syncthreads();
+        {
+            // exclusive scan of the chunks' mobile counts: every wave forms it for itself (lane = chunk; K2D_JC / 64 <= 64)
+            int c = lane < K2D_JC / 64 ? S.mcnt[lane] : 0, inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            const int exc = inc - c;
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int k = it * K2D_THREADS + tid, ch = k >> 6;
+                const int ms = __shfl(exc, ch, 64) + mrank[it];
+                S.mslot[k] = (mob[it] && ms < K2D_MOB) ? (unsigned short)ms : (unsigned short)0xffff;
+            }
+        }
+        for (int a0 = 0; a0 < A.n_alch; a0 += K2D_AG) {
+            const int na = min(K2D_AG, A.n_alch - a0);
+            __syncthreads();
+            // ---- mark and list in one sweep: wave al owns alchemical atom a0 + al and walks the round's chunks in order (fp32
+            // distances relative to the first alchemical atom; a running offset keeps its segment of the pair list ascending)
+            if (wv < na) {
+                const float ox = S.aoff[0][a0 + wv], oy = S.aoff[1][a0 + wv], oz = S.aoff[2][a0 + wv];
+                int pos = 0;
+                for (int ch = 0; ch < nchunk; ch++) {
+                    const int k = ch * 64 + lane;
+                    const float dx = (float)min_image_d(S.x[0][k] - S.xa[0][0], A.box.L[0], A.box.invL[0]) - ox;
+                    const float dy = (float)min_image_d(S.x[1][k] - S.xa[1][0], A.box.L[1], A.box.invL[1]) - oy;
+                    const float dz = (float)min_image_d(S.x[2][k] - S.xa[2][0], A.box.L[2], A.box.invL[2]) - oz;
+                    const bool hit = k < nst && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < rc2m;
+                    const unsigned long long b = __ballot(hit);
+                    if (hit) S.pairs[wv][pos + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)k;
+                    pos += __popcll(b);
+                }
+                if (lane == 0) S.pcnt[wv] = pos;
+            }
+            __syncthreads();
+            // ---- the pairs, every lane busy: work items = (alchemical atom of the pass, 64 consecutive pairs of its segment)
+            int item_al[K2D_AG + 1];   // first item of each segment (uniform)
+            item_al[0] = 0;
+#pragma unroll
+            for (int al = 0; al < K2D_AG; al++) item_al[al + 1] = item_al[al] + (al < na ? (S.pcnt[al] + 63) >> 6 : 0);
+#if K2D_EXP == 3
+            const int nitems = 0;
+#else
+            const int nitems = item_al[K2D_AG];
+#endif
+            // the first item's record (the next one's is requested before the current pair is computed: a global gather per pair)
+            auto locate = [&](int item, int& al, int& p) {
+                al = 0;
+#pragma unroll
+                for (int q = 1; q < K2D_AG; q++) if (item >= item_al[q]) al = q;
+                p = (item - item_al[al]) * 64 + lane;
+            };
+            double njsig = 0.0, njeps = 0.0, njq = 0.0; int nk = 0, nal = 0; bool nvalid = false;
+            auto request = [&](int item) {
+                nvalid = false; nk = 0; nal = 0;
+                if (item < nitems) {
+                    int p; locate(item, nal, p);
+                    nvalid = p < S.pcnt[nal];
+                    nk = nvalid ? (int)S.pairs[nal][p] : 0;
+                    const AlchJRec* jr = A.jrec + j0 + nk;
+                    njsig = jr->sig; njeps = jr->eps; njq = jr->q;
+                }
+            };
+            request(wv);
+            for (int item = wv; item < nitems; item += K2D_WAVES) {
+                const double jsig = njsig, jeps = njeps, jq = njq; const int k = nk, al = nal; const bool valid = nvalid;
+                request(item + K2D_WAVES);
+                const int a = a0 + al;   // (uniform: an item lies inside one segment)
+                double d[3];
+#pragma unroll
+                for (int c3 = 0; c3 < 3; c3++) d[c3] = min_image_d(S.xa[c3][a] - S.x[c3][k], A.box.L[c3], A.box.invL[c3]);
+                const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+#if K2D_EXP == 1
+                const bool hit = false;
+#else
+                const bool hit = valid && r2 < A.rc2;
+#endif
+                float f[3][3];
+#pragma unroll
+                for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = 0.0f; }
+                if (hit) {
+                    const double sig = 0.5 * (S.asig[a] + jsig), eps = S.aeps[a] * jeps, qq = S.aq[a] * jq;   // (eps: both are square roots)
+                    double fc = 0.0;
+                    if (!no_elec) e[0] += coulomb_fast_d(r2, qq, A.alpha, &fc);
+                    double es[3], fs3[3];
+                    if (same_ls) { softcore_lj1_fast_d(r2, sig, eps, A.ls[0], A.sc_alpha, &es[0], &fs3[0]); es[1] = es[2] = es[0]; fs3[1] = fs3[2] = fs3[0]; }
+                    else softcore_lj3_fast_d(r2, sig, eps, A.ls, A.sc_alpha, es, fs3);
+#pragma unroll
+                    for (int s = 0; s < 3; s++) {
+                        e[1 + s] += es[s];
+                        if (!slot_on(s)) continue;
+                        const float ft = (float)(fs3[s] + A.le[s] * fc);
+                        f[s][0] = ft * (float)d[0]; f[s][1] = ft * (float)d[1]; f[s][2] = ft * (float)d[2];
+                    }
+                }
+                // force on the item's alchemical atom: one wave sum per component
+#pragma unroll
+                for (int s = 0; s < 3; s++) {
+                    if (!slot_on(s)) continue;
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; c3++) {
+                        const float v = wave_sum_dpp_f32(f[s][c3]);
+                        if (lane == 0) atomicAdd(&S.fa[s * 3 + c3][a], (unsigned long long)__double2ll_rn((double)v * K2D_FIX));
+                    }
+                }
+                // force on a mobile environment atom: minus the pair force
+                const unsigned ms = hit ? (unsigned)S.mslot[k] : 0xffffu;
+                if (ms != 0xffffu) {
+#pragma unroll
+                    for (int s = 0; s < 3; s++) {
+                        if (!slot_on(s)) continue;
+#pragma unroll
+                        for (int c3 = 0; c3 < 3; c3++) atomicAdd(&S.fj[s * 3 + c3][ms], (unsigned long long)__double2ll_rn(-(double)f[s][c3] * K2D_FIX));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the round's mobile entries: force by sorted index (every one of them is written: zero if it had no pair)
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int k = it * K2D_THREADS + tid;
+            if (k < nst && mob[it]) {
+                const unsigned ms = S.mslot[k];
+                if (ms == 0xffffu) { if (A.flags_overflow) A.flags_overflow[0] = 1; continue; }
+                const int jsrt = js[it] & 0x3fffffff;
+#pragma unroll
+                for (int s = 0; s < 3; s++) {
+                    if (!slot_on(s)) continue;
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; c3++) A.fJ[(size_t)(s * 3 + c3) * A.n + jsrt] = (double)(long long)S.fj[s * 3 + c3][ms] * (1.0 / K2D_FIX);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- partial slabs of logical block 0
+    if (tid < A.PA) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) A.self_part[(size_t)q * A.PA + tid] = (tid < A.n_alch && slot_on(q / 3)) ? (double)(long long)S.fa[q][tid] * (1.0 / K2D_FIX) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < K2_NE; q++) e[q] = wave_sum(e[q]);
+    if (lane == 0) for (int q = 0; q < K2_NE; q++) S.e[wv][q] = e[q];
+    __syncthreads();
+    if (tid < K2_NE) { double t = 0.0; for (int w = 0; w < K2D_WAVES; w++) t += S.e[w][tid]; A.e_part[tid] = t; }
+    if (tid < 3) { double t = 0.0; for (int a = 0; a < A.n_alch; a++) t += (double)(long long)S.fa[tid][a] * (1.0 / K2D_FIX); A.e_part[K2_NE + tid] = slot_on(0) ? t : 0.0; }
+}
+
+template <int MASK>
+__global__ void __launch_bounds__(K2D_THREADS) k_alchemical_dense(AlchArgs A) { alchemical_dense_body<MASK>(A); }
 
 template <bool FAST>
 __global__ void __launch_bounds__(256) k_alchemical(AlchArgs A) { alchemical_blocks<FAST>(A, blockIdx.x, gridDim.x - 1); }

@@ -193,6 +193,8 @@ typedef struct BluesTuning {
                                 * depends on how many chains share a launch): what makes "a batch member equals the same
                                 * chain advanced alone, bit for bit" testable */
     int32_t k1_threads;        /* threads per workgroup of the per-atom-list kernel (multiple of 64, <= 1024); 0: 1024 */
+    int32_t k2_dense;          /* -1 auto (on where it applies: large batch, mixed precision, free alchemical group of <= 16 atoms);
+                                * 0: the alchemical kernel keeps its (atom, list entry) lane layout */
     int32_t k2_early;          /* 1: with `fork`, the alchemical kernel of the members of a batch that do not rebuild their lists
                                 * in a force pass starts beside the rebuild of the others; 0 (default): after the group lists */
 } BluesTuning;
