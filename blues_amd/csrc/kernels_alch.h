@@ -384,9 +384,6 @@ __device__ __forceinline__ void alchemical_blocks(AlchArgs& A, const int p, cons
 // k2_env_blocks() = 1); the alchemical x alchemical block is still alchemical_body's.
 // Preconditions (host: k2_dense): no alchemical atom has an excluded environment partner; <= 16 alchemical atoms; at most
 // K2D_MOB mobile atoms; every box edge > 2 (cutoff + outer margin + 2 x extent of the alchemical group).
-#ifndef K2D_EXP
-#define K2D_EXP 0
-#endif
 #define K2D_THREADS 512
 #define K2D_WAVES (K2D_THREADS / 64)
 #define K2D_JC 2560        // list entries staged at a time (an alchemical tile's list is ~2,400 entries; longer lists take more rounds)
@@ -501,11 +498,7 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
             item_al[0] = 0;
 #pragma unroll
             for (int al = 0; al < K2D_AG; al++) item_al[al + 1] = item_al[al] + (al < na ? (S.pcnt[al] + 63) >> 6 : 0);
-#if K2D_EXP == 3
-            const int nitems = 0;
-#else
             const int nitems = item_al[K2D_AG];
-#endif
             // the first item's record (the next one's is requested before the current pair is computed: a global gather per pair)
             auto locate = [&](int item, int& al, int& p) {
                 al = 0;
@@ -533,11 +526,7 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
 #pragma unroll
                 for (int c3 = 0; c3 < 3; c3++) d[c3] = min_image_d(S.xa[c3][a] - S.x[c3][k], A.box.L[c3], A.box.invL[c3]);
                 const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-#if K2D_EXP == 1
-                const bool hit = false;
-#else
                 const bool hit = valid && r2 < A.rc2;
-#endif
                 float f[3][3];
 #pragma unroll
                 for (int s = 0; s < 3; s++) { f[s][0] = f[s][1] = f[s][2] = 0.0f; }
