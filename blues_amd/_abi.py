@@ -15,7 +15,7 @@ NB_NOCUTOFF = 0
 NB_PME_DIRECT = 1
 NB_PME = 2
 N_ENERGY_TERMS = 10
-N_STATS = 20
+N_STATS = 21
 ENERGY_TERM_NAMES = ("bonds", "angles", "torsions", "nonbonded", "exceptions", "alch_sterics",
                      "alch_electrostatics", "restraint", "reciprocal", "dispersion_correction")
 

@@ -2742,6 +2742,7 @@ int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
     stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
     if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) { stats[1] = f.list_gen; stats[10] = f.builds; stats[16] = f.prunes; } }
     stats[19] = h->prune_on && h->k1_mode == 2;
+    stats[20] = h->k2_dense ? 1 : 0;
     if (stats[19] && h->d_pcount.p && h->sorted_ok) {
         std::vector<int> pc, ta;
         try { h->d_pcount.download(pc); h->d_tile_atoms.download(ta); for (size_t q = 0; q < pc.size() && q < ta.size(); q++) if (ta[q] >= 0) { stats[17] += pc[q]; stats[18] += (pc[q] + 63) / 64; } } catch (std::string&) {}

@@ -259,8 +259,9 @@ int blues_reset(BluesEngine *h);
  * lists at the last rebuild [15] 64-entry wave iterations they take
  * [16] pruned per-atom lists re-derived so far (one count per atom and prune)
  * [17] entries of all pruned lists now [18] 64-entry wave iterations they take
- * [19] 1 if the nonbonded kernel walks pruned lists */
-#define BLUES_N_STATS 20
+ * [19] 1 if the nonbonded kernel walks pruned lists [20] alchemical kernel in
+ * use for the env pairs: 0 lane = (atom, list entry), 1 dense pair lists */
+#define BLUES_N_STATS 21
 int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
 /* time `reps` launches of the dominant nonbonded kernel alone with HIP events
  * on the engine's own stream; returns mean microseconds per launch. */

@@ -34,3 +34,23 @@ def test_launcher_started_ranks_are_respected_and_mismatch_is_refused():
     # --gpus disagrees with the launcher's world size: refuse instead of mislabelling n_gpus
     r = _run(["--gpus", "4", "--launch-check"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "refusing" in r.stderr
+
+
+def test_eight_ranks_under_the_driver_launcher():
+    """The round-end scaling run: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8`.  Eight ranks
+    rendezvous on 127.0.0.1, every rank contributes its block of accept records to the all-gather in rank order, the timing
+    reduction takes the slowest rank, rank 0 alone prints."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-check"], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["records"] == 16 and out["max_rank_time"] == 8.0
+    assert out["work"] == [10.0 + q // 2 for q in range(16)]       # two records per rank, in rank order

@@ -749,3 +749,31 @@ def test_configs3_full_size_water_switch_properties():
     bst = B._ncmc_batch.stats()
     assert bst["lockstep_steps"] > 0.9 * nsteps, bst                         # the members did share their launches
     B.close()
+
+
+def test_dense_alchemical_kernel_equals_the_lane_layout(Engine, tune):
+    """Large batches evaluate the alchemical x environment pairs from compacted pair lists with fixed-point force accumulators
+    (kernels_alch.h: alchemical_dense_body) instead of one lane per (alchemical atom, list entry).  Same pairs, same fp64 pair
+    arithmetic: energies, forces and a free-running work trace agree to summation-order rounding (forces carry 2^-20 kJ/mol/nm of
+    fixed-point rounding per accumulator), and the dense form is what the bench decomposition runs."""
+    from blues_amd import integrators, systems
+    s, v = systems.s23k(mobile_atoms=275, frozen=True)
+    integ = lambda: integrators.generateNCMCIntegrator(nstepsNC=60, dt=0.004, temperature=300.0, seed=21).to_data(precision=0)
+    tune(assume_batch=512)
+    d = Engine(s, integ()); d.set_velocities(v)
+    tune(assume_batch=512, k2_dense=0)
+    l = Engine(s, integ()); l.set_velocities(v)
+    assert d.stats()["alchemical_kernel"] == 1 and l.stats()["alchemical_kernel"] == 0
+    mob = np.nonzero(s.mass > 0)[0]
+    for lam in ((1.0, 1.0), (0.5, 0.0), (0.3, 0.0), (1.0, 0.4)):
+        for g in (d, l):
+            g.set_global("lambda_sterics", lam[0]); g.set_global("lambda_electrostatics", lam[1])
+        ed, el = d.potential_energy(), l.potential_energy()
+        assert abs(ed - el) <= 1e-9 * abs(el), (lam, ed, el)
+        fd, fl = d.get_forces()[mob], l.get_forces()[mob]
+        assert np.abs(fd - fl).max() <= 1e-8 * np.abs(fl).max() + 2e-5, (lam, np.abs(fd - fl).max())
+    for g in (d, l):
+        g.set_global("lambda_sterics", 1.0); g.set_global("lambda_electrostatics", 1.0)
+    wd, wl = d.run_switch(60, trace=True), l.run_switch(60, trace=True)
+    assert np.abs(wd - wl).max() <= 1e-6 * max(1.0, np.abs(wl).max()), np.abs(wd - wl).max()
+    d.close(); l.close()
