@@ -1369,7 +1369,10 @@ static int force_pass(BluesEngine* h, int base_L) {
     // alchemical kernel fills it.  Joined before finalize.
     const bool fork_env = (h->batch ? h->batch->tune.fork : h->tune.fork) != 0;
     const bool decomposed = !(h->fuse_forces && h->wpb == 4) && !(h->k1_mode == 1 && h->precision == 0 && h->fuse_big);
-    const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && !h->alch.empty() && h->s1 && !h->ctrl_arg;
+    // (not with the dense alchemical kernel: one 512-thread workgroup with ~137 KB of LDS per chain cannot share a CU with the
+    // nonbonded kernel's, and beside the rebuild's small workgroups it runs at half speed -- round 3 timelines: 516 us per step with
+    // every kernel alone against 540 with the dense kernel on the side stream)
+    const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && !h->k2_dense && !h->alch.empty() && h->s1 && !h->ctrl_arg;
     // k2_early (off by default): the alchemical kernel of the members that do NOT rebuild needs nothing from the rebuild and can
     // start as soon as the work list says who they are, with the rebuild kernels on a high-priority stream beside it and the
     // members that rebuild following their group lists.  Measured at R = 512 (round 3): 545-565 us per step against 545-555
@@ -1398,21 +1401,9 @@ static int force_pass(BluesEngine* h, int base_L) {
         if (rc) return 1;
         if (early) { HIP_OK(h, hipEventRecord(h->evB, rb)); wait_lists = true; }
 #undef LISTS
-        if (h->k2_dense) {
-            // Dense alchemical kernel: one 512-thread workgroup with ~137 KB of LDS per chain.  It cannot share a CU with the
-            // nonbonded kernel's workgroups (LDS), and run side by side the two only slow each other (round 3 profile: 253 +
-            // 195 us against 153 + 87 alone) -- but it leaves exactly the room the small workgroups of the atoms' lists need
-            // (13 KB of LDS, 77 registers).  So it runs beside THEM and is joined before the nonbonded kernel.
-            h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, 0); h->cur = main_stream;
-            if (rc) return 1;
-            HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
-            if (launch_bonded(h, true)) return 1;   // (a small grid: beside the tail of the side stream)
-            HIP_OK(h, hipStreamWaitEvent(main_stream, h->evJ1, 0));
-        } else {
-            h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, early ? 2 : 0) || launch_bonded(h, true); h->cur = main_stream;   // (bonded terms and the next O step's noise need no list either)
-            if (rc) return 1;
-            HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
-        }
+        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, early ? 2 : 0) || launch_bonded(h, true); h->cur = main_stream;   // (bonded terms and the next O step's noise need no list either)
+        if (rc) return 1;
+        HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
         if (wait_lists) HIP_OK(h, hipStreamWaitEvent(main_stream, h->evB, 0));
     } else {
         rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, 0) : launch_lists<double>(h, h->lists_forced, 0);
@@ -1433,7 +1424,7 @@ static int force_pass(BluesEngine* h, int base_L) {
         rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (rc) return 1;
         if (launch_pme(h, 0)) return 1;
-        if (fork) { if (!h->k2_dense) HIP_OK(h, hipStreamWaitEvent(h->cur, h->evJ1, 0)); if (launch_finalize(h, le, fmask)) return 1; }
+        if (fork) { HIP_OK(h, hipStreamWaitEvent(h->cur, h->evJ1, 0)); if (launch_finalize(h, le, fmask)) return 1; }
         else if (launch_bonded_and_finalize(h, le, true, fmask)) return 1;
     }
     h->pass_valid = true; h->pass_L = base_L; h->st_passes++; h->vel_clean = true; h->acc_cache_valid = false;

@@ -480,16 +480,24 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
             if (wv < na) {
                 const float ox = S.aoff[0][a0 + wv], oy = S.aoff[1][a0 + wv], oz = S.aoff[2][a0 + wv];
                 int pos = 0;
-                for (int ch = 0; ch < nchunk; ch++) {
+                auto test = [&](int ch) -> bool {
                     const int k = ch * 64 + lane;
                     const float dx = (float)min_image_d(S.x[0][k] - S.xa[0][0], A.box.L[0], A.box.invL[0]) - ox;
                     const float dy = (float)min_image_d(S.x[1][k] - S.xa[1][0], A.box.L[1], A.box.invL[1]) - oy;
                     const float dz = (float)min_image_d(S.x[2][k] - S.xa[2][0], A.box.L[2], A.box.invL[2]) - oz;
-                    const bool hit = k < nst && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < rc2m;
+                    return k < nst && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < rc2m;
+                };
+                auto emit = [&](int ch, bool hit) {
                     const unsigned long long b = __ballot(hit);
-                    if (hit) S.pairs[wv][pos + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)k;
+                    if (hit) S.pairs[wv][pos + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)(ch * 64 + lane);
                     pos += __popcll(b);
+                };
+                int ch = 0;
+                for (; ch + 1 < nchunk; ch += 2) {   // two chunks per trip: their LDS reads and fp64 arithmetic are independent
+                    const bool h0 = test(ch), h1 = test(ch + 1);
+                    emit(ch, h0); emit(ch + 1, h1);
                 }
+                if (ch < nchunk) emit(ch, test(ch));
                 if (lane == 0) S.pcnt[wv] = pos;
             }
             __syncthreads();
