@@ -110,6 +110,9 @@ def test_prune_requests_are_per_chain_inside_a_batch(Engine, tune):
         assert np.array_equal(wb[r], ws[r]), r
         assert np.array_equal(solo[r].get_positions(), bat[r].get_positions())
         assert solo[r].stats()["atom_prunes"] == prunes[r]
+    for r in (0, R - 1):                         # the audit of a batch member's lists, mid-life
+        found, missing = bat[r].audit_lists()
+        assert found > 50000 and missing == 0, (r, found, missing)
     B.close()
     for g in solo + bat:
         g.close()
