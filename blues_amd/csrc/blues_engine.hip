@@ -756,11 +756,12 @@ static int sort_and_tile(BluesEngine* h) {
             if (h->prune_on) {
                 h->d_plist.alloc((size_t)h->n_islots * h->acap); h->d_pcount.alloc(h->n_islots); h->d_pneed.alloc(h->n_islots);
                 for (int k = 0; k < 3; k++) h->d_xprune[k].alloc(h->n_islots);
-                // packed images where most list entries are frozen atoms (the same condition as the pruned lists)
-                h->mcap = std::min(jcap, (((int)h->mobile.size() + 63) / 64) * 64);
-                h->d_pimg4.alloc((size_t)std::max(1, h->n_lists) * jcap); h->d_pimg2.alloc((size_t)std::max(1, h->n_lists) * jcap);
-                h->d_mlist.alloc((size_t)std::max(1, h->n_lists) * h->mcap * 2); h->d_mcount.alloc(std::max(1, h->n_lists));
             }
+            // packed group images: what the builder of the atoms' lists streams its candidates from (always), and what the nonbonded
+            // kernel stages its LDS image from where most list entries are frozen atoms (the same condition as the pruned lists)
+            h->mcap = std::min(jcap, (((int)h->mobile.size() + 63) / 64) * 64);
+            h->d_pimg4.alloc((size_t)std::max(1, h->n_lists) * jcap); h->d_pimg2.alloc((size_t)std::max(1, h->n_lists) * jcap);
+            h->d_mlist.alloc((size_t)std::max(1, h->n_lists) * h->mcap * 2); h->d_mcount.alloc(std::max(1, h->n_lists));
         }
         h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1)) + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
         { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi);
@@ -871,8 +872,8 @@ static ListArgs make_list_args(BluesEngine* h) {
     a.alch_jrec = h->alch.empty() ? nullptr : (void*)h->d_jrec.p; a.p_sigma = h->d_sigma.p; a.p_eps = h->d_eps.p; a.p_charge = h->d_charge.p;
     if (h->k1_mode == 2) { a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap; }
     a.S = h->S; a.n_lists = h->n_lists; a.hint_count = h->hint_count; a.no_sphere = h->tune.no_sphere;
-    if (h->k1_mode == 2 && h->prune_on) { a.pneed = h->d_pneed.p; a.plist = h->d_plist.p; a.pcount = h->d_pcount.p; for (int k = 0; k < 3; k++) a.xprune[k] = h->d_xprune[k].p;
-        a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap; }
+    if (h->k1_mode == 2 && h->prune_on) { a.pneed = h->d_pneed.p; a.plist = h->d_plist.p; a.pcount = h->d_pcount.p; for (int k = 0; k < 3; k++) a.xprune[k] = h->d_xprune[k].p; }
+    if (h->k1_mode == 2) { a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap; }
     return a;
 }
 

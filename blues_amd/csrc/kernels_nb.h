@@ -364,10 +364,12 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f, rl2m = (float)c.rlist2_m * 1.0001f + 1e-5f;
     NB_STAMP(t == 0 && tid == 0, 5);
     if (tid < 64) { s_exn[tid] = 0; s_exlo[tid] = 0x7fffffff; s_exhi[tid] = -1; }
-    for (int w = tid; w < ATOM_LIST_MOBW; w += ATOM_LIST_THREADS) s_mob[w] = 0u;
+    const int mc = packed ? a.mcount[l] : 0;
+    const bool all_mobile = packed && mc >= count;   // (block-uniform) nothing frozen in this list: no bitmap to gather
+    for (int w = tid; w < ATOM_LIST_MOBW; w += ATOM_LIST_THREADS) s_mob[w] = all_mobile ? 0xffffffffu : 0u;
     __syncthreads();
-    if (packed) {
-        const int* ml = a.mlist + (size_t)l * a.mcap * 2; const int mc = a.mcount[l];
+    if (packed && !all_mobile) {
+        const int* ml = a.mlist + (size_t)l * a.mcap * 2;
         for (int q = tid; q < mc; q += ATOM_LIST_THREADS) { const int k = ml[2 * q]; atomicOr(&s_mob[k >> 5], 1u << (k & 31)); }
     }
     NB_STAMP(t == 0 && tid == 0, 6);
