@@ -123,7 +123,9 @@ def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
     recs = np.array([[c.last["accept"], it, c.last["log_accept"], c.last["protocol_work"], c.last["correction"]] for c in chains], dtype=np.float64)
     if gather:
         recs = gather_decision_block(recs)
-    if not fast:
+    if fast:
+        driver._reset_batched(300.0)
+    else:
         each(lambda r, c: c._resetSimulations(300.0))
     t3 = time.perf_counter()
     clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2
@@ -365,6 +367,11 @@ def main():
     st0 = engs[0].stats(); b0 = [d._ncmc_batch.stats() for d in drivers]
     for ck in clocks:
         ck.update({"sync": 0.0, "switch": 0.0, "decide": 0.0})
+    # the nonbonded kernel is timed WHERE IT RUNS: every 4th force launch of the timed switches is bracketed by two HIP events on
+    # the batch's stream (blues_batch_kernel_timing); that mean is roofline.usec_per_launch, what rocprofv3 averages for the same loop
+    timing_batch = None if args.no_kernel_timing or not hasattr(drivers[0]._ncmc_batch, "kernel_timing") else drivers[0]._ncmc_batch
+    if timing_batch is not None:
+        timing_batch.kernel_timing(4)
     # the chains' Python objects (contexts, integrators, move engines, state tables: a few thousand per chain) live as long as the
     # process: park them in the permanent generation, so that the cyclic collector stops walking them during the iterations
     import gc
@@ -403,18 +410,23 @@ def main():
     # (with pruned per-atom lists an atom is served from its current pruned list or -- a few percent of the atoms of a pass -- from its
     # full list while the pruned one is re-derived: both kinds of launch are timed, k1_us is their mean weighted with the share of
     # the second kind in THIS run's force passes; profiles/ holds the rocprofv3 average over the stepping loop beside it)
-    if args.no_kernel_timing:
-        k1_pruned = k1_full = k1_us = float("nan"); prune_share = float("nan")
-    else:
+    k1_pruned = k1_full = k1_us = prune_share = k1_alone = None; k1_loop = None
+    if timing_batch is not None:
+        k1_loop = timing_batch.kernel_timing_result(); timing_batch.kernel_timing(0)
+        if k1_loop["launches"] > 0:
+            k1_us = k1_loop["usec"]
+        # extras: the kernel alone (back-to-back launches, nothing else on the device), over current pruned lists and with every
+        # atom re-deriving its list, and their mean weighted with the share of re-deriving atoms of this run
         k1_pruned, k1_full, prune_share = drivers[0]._ncmc_batch.time_nonbonded_modes(50)
-        k1_us = (1.0 - prune_share) * k1_pruned + prune_share * k1_full
+        k1_alone = (1.0 - prune_share) * k1_pruned + prune_share * k1_full
+        if k1_us is None:      # (a layout whose force kernel is not the per-atom-list one has no in-loop hook: the stand-alone figure, said so below)
+            k1_us = k1_alone
     R_launch = len(groups[0])
     if rank == 0:
         n_atoms = system.n_atoms
         ms_per_step = 1e3 * elapsed / args.steps
         ns_day = world * R * args.steps * nsteps * DT_PS * 1e-3 / (elapsed / 86400.0)
         algo = ALGO_BYTES_PER_ATOM * n_atoms * R_launch
-        achieved = algo / (k1_us * 1e-6) / 1e9
         last = np.asarray(recs[-1])
         # ---- roofline block of the dominant kernel.  north_star prices it against HBM with 36 B per atom per force evaluation
         # over ALL atoms; the kernel computes forces for the mobile atoms only, so the byte count of what such a pass has to touch
@@ -423,34 +435,41 @@ def main():
         mob_bytes = (24.0 * n_touched + 12.0 * n_i) * R_launch
         ev = pmc_evidence(args.workload, R_launch)
         est = engs[0].stats()
-        secs = k1_us * 1e-6
-        roofline = {"bound": "valu" if ev else "valu (counters not taken on this build: see profiles/README.md)",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "kernel": "%s (direct-space LJ + erfc Coulomb; one launch = %d chains, timed alone with HIP events)" % ({0: "k_nonbonded_b", 1: "k_nonbonded_sub_b", 2: "k_nonbonded_atom_b"}[est["nonbonded_kernel"]], R_launch),
-                    "usec_per_launch": k1_us, "usec_per_launch_by_kind": {"pruned_lists": k1_pruned, "re_deriving_every_list": k1_full, "share_of_atoms_re_deriving": prune_share},
-                    "algorithmic_bytes_per_launch": algo,
-                    "algorithmic_bytes_definition": "36 B x all %d atoms x %d chains (SURVEY.md 8d: nominal, defined on all atoms)" % (n_atoms, R_launch),
-                    "traffic": ev["traffic_bytes_per_launch"] if ev and "traffic_bytes_per_launch" in ev else None,
-                    "mobile_only": {"algorithmic_bytes": mob_bytes, "achieved": mob_bytes / secs / 1e9, "frac": mob_bytes / secs / 1e9 / HBM_PEAK_GBS,
-                                    "definition": "24 B x %d environment atoms within the cutoff of a mobile atom + 12 B x %d mobile atoms, per chain" % (n_touched, n_i)},
-                    "pairs": {"in_range_per_launch": n_pairs * R_launch,
-                              "listed_per_launch": (est["pruned_list_entries"] if est.get("pruned_lists") else est["atom_list_entries"]) * R_launch,
-                              "full_lists_per_launch": est["atom_list_entries"] * R_launch,
-                              "lane_efficiency": n_pairs / max(1.0, 64.0 * (est["pruned_list_iterations"] if est.get("pruned_lists") else est["atom_list_iterations"])),
-                              "note": "lane efficiency = pairs inside the cutoff / (wave iterations x 64 lanes) of the lists the kernel walks (the pruned per-atom lists; chain 0, end of the run)"}}
-        if ev:
-            c = ev["counters_per_launch"]
-            insts = c.get("SQ_INSTS_VALU")
-            if insts:
-                peak = 1024 * 2.4e9 / 2.0    # SIMDs x clock / 2 cycles per wave64 instruction (scripts/valu_issue.hip: 1.03 T/s reached with plain v_fma_f32)
-                v = {"insts_per_launch": insts, "issue_rate": insts / secs, "peak": peak, "frac": insts / secs / peak, "unit": "wave-instructions/s"}
-                if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
-                    # quad-cycles x 4, summed over the 1024 SIMDs, against the busy cycles of the launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
-                    v["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
-                if c.get("SQ_INSTS_VALU_TRANS_F32"):
-                    v["transcendental_insts_per_launch"] = c["SQ_INSTS_VALU_TRANS_F32"]
-                roofline["valu"] = v
-            roofline["pmc_source"] = {"file": PMC_FILE, "source_sha": ev["source_sha"], "kernel": ev["kernel"]}
+        roofline = None
+        if k1_us is not None:
+          achieved = algo / (k1_us * 1e-6) / 1e9
+          secs = k1_us * 1e-6
+          in_loop = k1_loop is not None and k1_loop["launches"] > 0
+          roofline = {"bound": "valu" if ev else "valu (counters not taken on this build: see profiles/README.md)",
+                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                      "kernel": "%s (direct-space LJ + erfc Coulomb; one launch = %d chains; %s)" % ({0: "k_nonbonded_b", 1: "k_nonbonded_sub_b", 2: "k_nonbonded_atom_b"}[est["nonbonded_kernel"]], R_launch,
+                                 "HIP events around every 4th force launch of the timed switches, on the stream the kernel runs on" if in_loop else "timed alone with HIP events"),
+                      "usec_per_launch": k1_us, "timed": "in the stepping loop" if in_loop else "alone",
+                      "launches_timed": k1_loop["launches"] if in_loop else 50, "usec_longest_launch": k1_loop["usec_max"] if in_loop else None,
+                      "usec_per_launch_alone": {"pruned_lists": k1_pruned, "re_deriving_every_list": k1_full, "share_of_atoms_re_deriving": prune_share, "weighted": k1_alone},
+                      "algorithmic_bytes_per_launch": algo,
+                      "algorithmic_bytes_definition": "36 B x all %d atoms x %d chains (SURVEY.md 8d: nominal, defined on all atoms)" % (n_atoms, R_launch),
+                      "traffic": ev["traffic_bytes_per_launch"] if ev and "traffic_bytes_per_launch" in ev else None,
+                      "mobile_only": {"algorithmic_bytes": mob_bytes, "achieved": mob_bytes / secs / 1e9, "frac": mob_bytes / secs / 1e9 / HBM_PEAK_GBS,
+                                      "definition": "24 B x %d environment atoms within the cutoff of a mobile atom + 12 B x %d mobile atoms, per chain" % (n_touched, n_i)},
+                      "pairs": {"in_range_per_launch": n_pairs * R_launch,
+                                "listed_per_launch": (est["pruned_list_entries"] if est.get("pruned_lists") else est["atom_list_entries"]) * R_launch,
+                                "full_lists_per_launch": est["atom_list_entries"] * R_launch,
+                                "lane_efficiency": n_pairs / max(1.0, 64.0 * (est["pruned_list_iterations"] if est.get("pruned_lists") else est["atom_list_iterations"])),
+                                "note": "lane efficiency = pairs inside the cutoff / (wave iterations x 64 lanes) of the lists the kernel walks (the pruned per-atom lists; chain 0, end of the run)"}}
+          if ev:
+              c = ev["counters_per_launch"]
+              insts = c.get("SQ_INSTS_VALU")
+              if insts:
+                  peak = 1024 * 2.4e9 / 2.0    # SIMDs x clock / 2 cycles per wave64 instruction (scripts/valu_issue.hip: 1.03 T/s reached with plain v_fma_f32)
+                  v = {"insts_per_launch": insts, "issue_rate": insts / secs, "peak": peak, "frac": insts / secs / peak, "unit": "wave-instructions/s"}
+                  if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+                      # quad-cycles x 4, summed over the 1024 SIMDs, against the busy cycles of the launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+                      v["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+                  if c.get("SQ_INSTS_VALU_TRANS_F32"):
+                      v["transcendental_insts_per_launch"] = c["SQ_INSTS_VALU_TRANS_F32"]
+                  roofline["valu"] = v
+              roofline["pmc_source"] = {"file": PMC_FILE, "source_sha": ev["source_sha"], "kernel": ev["kernel"]}
         out = {
             "metric": "NCMC ns/day (23k-atom toluene box, 1000-step switch, RandomLigandRotationMove), aggregate over independent chains",
             "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

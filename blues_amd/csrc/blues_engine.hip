@@ -279,8 +279,31 @@ struct BluesBatch {
     hipStream_t stream = nullptr; bool entered = false;
     DBuf<double> d_gather; int64_t st_prefetch_pe = 0, st_prefetch_ke = 0;
     int64_t st_lockstep_steps = 0, st_fallback_steps = 0, st_replans = 0;
+    // in-situ timing of the nonbonded force kernel (blues_batch_kernel_timing): every `k1t_every`-th lock-step force launch of the
+    // stepping loop is bracketed by two events on the stream it runs on; finished pairs are harvested lazily (no synchronisation)
+    struct EvPair { hipEvent_t a = nullptr, b = nullptr; bool busy = false; };
+    std::vector<EvPair> k1t_pairs; int k1t_every = 0; int64_t k1t_seen = 0, k1t_n = 0; double k1t_sum_us = 0.0, k1t_max_us = 0.0;
     int R() const { return (int)eng.size(); }
 };
+static void k1t_harvest(BluesBatch* B, bool wait) {
+    for (auto& p : B->k1t_pairs) if (p.busy) {
+        if (wait) hipEventSynchronize(p.b);
+        if (hipEventQuery(p.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { B->k1t_sum_us += 1000.0 * ms; B->k1t_max_us = std::max(B->k1t_max_us, 1000.0 * (double)ms); B->k1t_n++; }
+        p.busy = false;
+    }
+    (void)hipGetLastError();   // (hipErrorNotReady of a query is not an error of ours)
+}
+// a free event pair for the launch that is about to be issued, or null (not sampled / all pairs still in flight)
+static BluesBatch::EvPair* k1t_begin(BluesBatch* B, hipStream_t st) {
+    if (!B || B->k1t_every <= 0) return nullptr;
+    if ((B->k1t_seen++ % B->k1t_every) != 0) return nullptr;
+    k1t_harvest(B, false);
+    for (auto& p : B->k1t_pairs) if (!p.busy) { if (hipEventRecord(p.a, st) != hipSuccess) return nullptr; return &p; }
+    return nullptr;
+}
+static void k1t_end(BluesBatch::EvPair* p, hipStream_t st) { if (p && hipEventRecord(p->b, st) == hipSuccess) p->busy = true; }
 static int batch_enter(BluesBatch* B);
 static void batch_leave(BluesBatch* B);
 static inline bool batch_dry(const BluesEngine* h) { return h->batch && h->batch->lockstep && h->batch->leader != h; }
@@ -354,6 +377,18 @@ static void fit_ewald_poly(double alpha, double rc, EwaldPoly* P) {
     }
     for (int q = 0; q <= D; q++) P->c[q] = (float)mono[q];
     P->wa = (float)(2.0 / (rc * rc));
+    // what the kernels will evaluate (fp32 Horner) against T itself on a dense grid of r: the fit is only kept where it is
+    // good enough in absolute terms (device_common.h: EWALD_POLY_MAX_RESIDUAL); tighter Ewald tolerances take the erfc/exp form
+    double worst = 0.0;
+    for (int j = 0; j < 2000; j++) {
+        const double r = rc * (0.05 + 0.95 * (j + 0.5) / 2000.0), x = alpha * r;
+        const float w = fmaf((float)(r * r), P->wa, -1.0f);
+        float T = P->c[D];
+        for (int k = D - 1; k >= 0; k--) T = fmaf(T, w, P->c[k]);
+        worst = std::max(worst, std::fabs((double)T - (std::erf(x) - two_sqrtpi * x * std::exp(-x * x)) / (r * r * r)));
+    }
+    P->residual = worst;
+    P->exact = worst > EWALD_POLY_MAX_RESIDUAL ? 1 : 0;
 }
 
 template <typename R> static NbConst<R> make_nbconst(const BluesEngine* h) {
@@ -619,8 +654,9 @@ static int sort_and_tile(BluesEngine* h) {
         if (h->tune.k1_mode == 1) want_atom = false;
         if (h->forbid_atom) want_atom = false;
         if (want_atom && h->n_itiles > 0) {
+            double est_rad = 0.0;   // radius of the widest group of the last estimate
             auto group_est = [&](int S) {   // largest expected list length over the groups of S tiles
-                double worst = 0.0;
+                double worst = 0.0; est_rad = 0.0;
                 for (int g0 = 0; g0 < h->n_itiles; g0 += S) {
                     double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
                     std::vector<std::array<double, 3>> pts;
@@ -635,6 +671,7 @@ static int sort_and_tile(BluesEngine* h) {
                     double r2 = 0.0;
                     for (auto& d : pts) { double q2 = 0.0; for (int k = 0; k < 3; k++) { const double e = d[k] - 0.5 * (lo[k] + hi[k]); q2 += e * e; } r2 = std::max(r2, q2); }
                     const double rs = std::sqrt(r2) + rl;
+                    est_rad = std::max(est_rad, std::sqrt(r2));
                     const double box_v = (hi[0] - lo[0] + 2 * rl) * (hi[1] - lo[1] + 2 * rl) * (hi[2] - lo[2] + 2 * rl);
                     worst = std::max(worst, rho * std::min(4.0 / 3.0 * M_PI * rs * rs * rs, box_v));
                 }
@@ -667,7 +704,13 @@ static int sort_and_tile(BluesEngine* h) {
                 if (h->tune.list_group > 0) { const int S = std::max(1, std::min(16, h->tune.list_group)); best_S = S; best_cap = group_est(S) * 1.3 + 64 > 3328 ? lds_max : 3328; }
                 if (best_S > 0) h->shape_need = group_est(best_S);
             }
-            if (best_S > 0 && best_cap < 32768) {
+            // the lists are padded with a ghost record placed 0.5 nm outside the group's bounding sphere along the longest box edge
+            // (kernels_nb.h: build_lists_body): that edge must exceed the group's diameter + 1 nm, with room for the group to spread
+            if (best_S > 0) {
+                const double longest = std::max(h->box[0], std::max(h->box[1], h->box[2]));
+                if (2.0 * est_rad + 1.0 + 0.6 >= longest) best_S = 0;   // (est_rad: of group_est(best_S), the call just above)
+            }
+            if (best_S > 0 && best_cap <= NB_JCAP_MAX) {
                 h->k1_mode = 2; h->S = best_S; jcap = std::min(best_cap, ((n + 63) / 64) * 64); h->jcap = jcap;
                 h->waves_tile = 1; h->npart = 1; h->wpb = 4; h->seg_len = 64;
                 double cap = rho * 4.0 / 3.0 * M_PI * rl * rl * rl * 1.7;   // mean neighbour count within cutoff+skin, with slack for dense regions
@@ -922,16 +965,18 @@ template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
         if (h->prune_on) {
             a.plist = h->d_plist.p; a.pcount = h->d_pcount.p; a.pneed = h->d_pneed.p;
             for (int k = 0; k < 3; k++) a.xprune[k] = h->d_xprune[k].p;
-            a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap;
         }
+        a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap;   // (the kernel always stages the packed image: it holds the ghost record the lists are padded with)
     }
     a.S = h->S; a.n_lists = h->n_lists;
     return a;
 }
 
-// per-atom-list kernel: one 1024-thread workgroup per i-tile, the tile's j-image in dynamic LDS (24 B per list entry)
+// per-atom-list kernel: one 1024-thread workgroup per group of i-tiles, the group's j-image in dynamic LDS: the 8-byte records at
+// the bottom (room for the largest capacity), the 16-byte records behind them at a compile-time offset (kernels_nb.h: NB_LQ_BYTES)
 template <bool ENERGY> static int launch_nb_atom(BluesEngine* h, const NbArgs<float>& a) {
-    const size_t lds = (size_t)h->jcap * 24;
+    if (h->jcap > NB_JCAP_MAX) E_FAIL(h, "internal: list capacity %d beyond the per-atom-list kernel's LDS layout", h->jcap);
+    const size_t lds = (size_t)NB_LQ_BYTES + (size_t)h->jcap * 16 + NB_LDS_TAIL;
     static thread_local size_t lds_set[2][2] = {{0, 0}, {0, 0}};   // [batched][ENERGY]: largest dynamic-LDS size the kernel was opened for
     const bool lead = batch_lead(h);
     if (batch_dry(h)) return 0;
@@ -943,8 +988,11 @@ template <bool ENERGY> static int launch_nb_atom(BluesEngine* h, const NbArgs<fl
     }
     const int nb = std::max(1, h->n_lists);
     const int nthr = h->tune.k1_threads > 0 ? std::min(1024, std::max(64, (h->tune.k1_threads / 64) * 64)) : 1024;
-    if (lead) hipLaunchKernelGGL((k_nonbonded_atom_b<ENERGY>), dim3(nb * h->batch->R()), dim3(nthr), lds, h->cur, h->batch->d_nb_f.p, nb, h->batch->R());
-    else hipLaunchKernelGGL((k_nonbonded_atom<ENERGY>), dim3(nb), dim3(nthr), lds, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
+    if (lead) {
+        BluesBatch::EvPair* tp = ENERGY ? nullptr : k1t_begin(h->batch, h->cur);
+        hipLaunchKernelGGL((k_nonbonded_atom_b<ENERGY>), dim3(nb * h->batch->R()), dim3(nthr), lds, h->cur, h->batch->d_nb_f.p, nb, h->batch->R());
+        k1t_end(tp, h->cur);
+    } else hipLaunchKernelGGL((k_nonbonded_atom<ENERGY>), dim3(nb), dim3(nthr), lds, h->cur, a, make_nbconst<float>(h), h->d_img_f.p);
     return 0;
 }
 
@@ -2780,7 +2828,7 @@ int blues_audit_lists(BluesEngine* h, int64_t* out) {
     if (flush_program(h)) return 1;
     if (ensure_sorted(h)) return 1;
     if (h->k1_mode != 2 || h->precision != 0) E_FAIL(h, "blues_audit_lists: the engine is not in per-atom-list mode");
-    if (h->jcap > 32768) E_FAIL(h, "blues_audit_lists: list capacity %d is beyond the audit kernel's bitmap", h->jcap);
+    if (h->jcap > 8192) E_FAIL(h, "blues_audit_lists: list capacity %d is beyond the audit kernel's bitmap", h->jcap);
     hipStream_t st = h->batch && h->batch->entered ? h->batch->stream : h->stream;
     hipStream_t keep = h->cur; h->cur = st;
     BluesBatch* B = h->batch; h->batch = nullptr;   // (the member's own rebuild kernels, whoever leads the batch)
@@ -3037,6 +3085,7 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
 }
 
 int blues_batch_destroy(BluesBatch* b) {
+    if (b) { k1t_harvest(b, true); for (auto& p : b->k1t_pairs) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); } b->k1t_pairs.clear(); }
     if (!b) return 0;
     if (!b->eng.empty()) hipSetDevice(b->eng[0]->device);
     for (BluesEngine* m : b->eng) if (m && m->xfer_pending && m->xfer_src != m->h_xfer) resolve_xfer(m);   // (a verdict parked in the batch's buffer)
@@ -3108,6 +3157,10 @@ static int batch_arena_upload(BluesBatch* B, size_t bytes) {
     return 0;
 }
 static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+// members of a batch need not have the same atom count (non-congruent members step one by one): a launch that covers all of
+// them is sized by the largest, and an index must be valid in the smallest
+static int batch_max_n(const BluesBatch* B) { int m = 0; for (const BluesEngine* h : B->eng) m = std::max(m, h->n); return m; }
+static int batch_min_n(const BluesBatch* B) { int m = B->eng[0]->n; for (const BluesEngine* h : B->eng) m = std::min(m, h->n); return m; }
 
 int blues_batch_snapshot_capture(BluesBatch* B, int32_t what, const int32_t* mask, BluesSnapshot** out) {
     if (!B || !out || !(what & 3)) return 2;
@@ -3123,12 +3176,14 @@ int blues_batch_snapshot_capture(BluesBatch* B, int32_t what, const int32_t* mas
         Copy6Args& c = args[r]; memset(&c, 0, sizeof c);
         out[r] = nullptr;
         if (mask && !mask[r]) continue;
-        if ((what & 1) && !h->have_positions) { B->err = "positions have not been set"; batch_leave(B); return 1; }
+        // (a failure half way through: the snapshots already taken for earlier members go back to their owners' pools)
+        auto undo = [&]() { for (int q = 0; q < r; q++) if (out[q]) { out[q]->owner->snap_pool.push_back(out[q]); out[q] = nullptr; } };
+        if ((what & 1) && !h->have_positions) { undo(); B->err = "positions have not been set"; batch_leave(B); return 1; }
         BluesSnapshot* sn = nullptr;
         if (!h->snap_pool.empty()) { sn = h->snap_pool.back(); h->snap_pool.pop_back(); }
         else {
             sn = new BluesSnapshot(); sn->owner = h; sn->n = h->n;
-            if (hipMalloc((void**)&sn->block, sizeof(double) * 6 * (size_t)h->n) != hipSuccess) { delete sn; B->err = "hipMalloc failed"; batch_leave(B); return 1; }
+            if (hipMalloc((void**)&sn->block, sizeof(double) * 6 * (size_t)h->n) != hipSuccess) { delete sn; undo(); B->err = "hipMalloc failed"; batch_leave(B); return 1; }
             for (int k = 0; k < 3; k++) { sn->x[k] = sn->block + (size_t)k * h->n; sn->v[k] = sn->block + (size_t)(3 + k) * h->n; }
         }
         sn->has_x = what & 1; sn->has_v = (what & 2) != 0;
@@ -3142,7 +3197,7 @@ int blues_batch_snapshot_capture(BluesBatch* B, int32_t what, const int32_t* mas
         out[r] = sn;
     }
     int rc = batch_arena_upload(B, sizeof(Copy6Args) * R);
-    if (!rc) hipLaunchKernelGGL(k_copy_arrays_b, dim3((h0->n + 255) / 256, R), dim3(256), 0, B->stream, reinterpret_cast<const Copy6Args*>(B->d_arena.p));
+    if (!rc) hipLaunchKernelGGL(k_copy_arrays_b, dim3((batch_max_n(B) + 255) / 256, R), dim3(256), 0, B->stream, reinterpret_cast<const Copy6Args*>(B->d_arena.p));
     if (!rc && hipGetLastError() != hipSuccess) { B->err = "launch failed"; rc = 1; }
     batch_leave(B);
     return rc;
@@ -3262,7 +3317,7 @@ int blues_batch_read_atoms(BluesBatch* B, BluesSnapshot* const* snaps, int32_t w
     const int R = B->R();
     BluesEngine* h0 = B->eng[0];
     if (hipSetDevice(h0->device) != hipSuccess) { B->err = "hipSetDevice failed"; return 1; }
-    for (int e = 0; e < n_idx; e++) if (idx[e] < 0 || idx[e] >= h0->n) { B->err = "atom out of range"; return 1; }
+    { const int nmin = batch_min_n(B); for (int e = 0; e < n_idx; e++) if (idx[e] < 0 || idx[e] >= nmin) { B->err = "atom out of range"; return 1; } }
     const size_t off_src = 0, off_idx = align16(sizeof(double*) * 3 * R), off_out = align16(off_idx + sizeof(int) * n_idx), total = off_out + sizeof(double) * 3 * (size_t)n_idx * R;
     if (batch_arena(B, total)) return 1;
     for (int r = 0; r < R; r++) if (!snaps && flush_program(B->eng[r])) { B->err = B->eng[r]->err; return 1; }
@@ -3330,7 +3385,7 @@ int blues_batch_set_velocities_to_temperature(BluesBatch* B, double temperature,
         h->st_launches++; h->vel_clean = false; h->ke_cache_valid = false;
     }
     int rc = batch_arena_upload(B, sizeof(MaxwellArgs) * R);
-    if (!rc) hipLaunchKernelGGL(k_maxwell_b, dim3((h0->n + 255) / 256, R), dim3(256), 0, B->stream, reinterpret_cast<const MaxwellArgs*>(B->d_arena.p));
+    if (!rc) hipLaunchKernelGGL(k_maxwell_b, dim3((batch_max_n(B) + 255) / 256, R), dim3(256), 0, B->stream, reinterpret_cast<const MaxwellArgs*>(B->d_arena.p));
     // the velocity constraints: every member queues OP_RATTLE; congruent members flush in lock step (one launch)
     std::vector<char> saved_active = B->active;
     B->failed.assign(R, 0);
@@ -3352,6 +3407,28 @@ int blues_batch_set_velocities_to_temperature(BluesBatch* B, double temperature,
     B->active = saved_active; B->leader = B->eng[0];
     batch_leave(B);
     return rc;
+}
+
+// In-situ timing of the nonbonded force kernel: `every` > 0 brackets every `every`-th lock-step force launch of the stepping
+// loop with two HIP events on the stream it is launched on (0: off; statistics are reset either way).
+int blues_batch_kernel_timing(BluesBatch* b, int32_t every) {
+    if (!b || every < 0) return 2;
+    if (hipSetDevice(b->eng[0]->device) != hipSuccess) { b->err = "hipSetDevice failed"; return 1; }
+    k1t_harvest(b, true);
+    b->k1t_every = every; b->k1t_seen = 0; b->k1t_n = 0; b->k1t_sum_us = 0.0; b->k1t_max_us = 0.0;
+    if (every > 0 && b->k1t_pairs.empty()) {
+        b->k1t_pairs.resize(32);
+        for (auto& p : b->k1t_pairs) if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) { b->err = "hipEventCreate failed"; return 1; }
+    }
+    return 0;
+}
+// out[0] = mean duration (us) of the sampled launches, out[1] = how many were sampled, out[2] = the longest of them
+int blues_batch_get_kernel_timing(BluesBatch* b, double out[3]) {
+    if (!b || !out) return 2;
+    if (hipSetDevice(b->eng[0]->device) != hipSuccess) { b->err = "hipSetDevice failed"; return 1; }
+    k1t_harvest(b, true);
+    out[0] = b->k1t_n ? b->k1t_sum_us / (double)b->k1t_n : 0.0; out[1] = (double)b->k1t_n; out[2] = b->k1t_max_us;
+    return 0;
 }
 
 // usec[0]: a pass over current pruned lists; usec[1]: a pass that re-derives them (walks the full lists); equal where the

@@ -13,6 +13,7 @@
 #define ONE_4PI_EPS0 138.935456
 #define KB_KJ 0.0083144626
 #define TWO_OVER_SQRT_PI 1.1283791670955126
+#define TWO_OVER_SQRT_PI_F 1.1283791671f
 #define WAVE 64
 #define FLAG_ALCH 1u
 #define FLAG_MOBILE 2u
@@ -106,7 +107,12 @@ __device__ inline float erfc_scaled_f(float x) {  // returns erfc(x)*exp(x^2)
 // scale the 1e-5 force tolerance is stated on (the largest force component / the norm of the force vector).  This replaces
 // v_exp, v_rcp and a degree-7 polynomial (22 instructions, two of them quarter-rate) by 10 FMAs.
 #define EWALD_POLY_DEG 9
-struct EwaldPoly { float c[EWALD_POLY_DEG + 1]; float wa; };   // T(u) = sum c[k] w^k, w = wa u - 1
+// The fit is only as good as T is smooth on [0, cutoff^2]: at alpha rc = 2.15 (ewald tolerance 5e-3) the fp32 Horner form is
+// within 1.2e-6 nm^-3 of T everywhere, at 2.63 (5e-4) within 1.6e-5, at 3.29 (1e-5) within 6e-4 -- more than the screened force
+// of a pair near the cutoff.  The host measures the residual of what it fitted (fit_ewald_poly) and sets `exact` when it
+// exceeds EWALD_POLY_MAX_RESIDUAL: the kernels then evaluate the erfc/exp form instead (22 instructions more per pair).
+#define EWALD_POLY_MAX_RESIDUAL 5e-6   // nm^-3, absolute: times k_e q_i q_j r <~ 50 kJ/mol/nm^-2 this stays below 1e-5 of a typical largest force
+struct EwaldPoly { float c[EWALD_POLY_DEG + 1]; float wa; int exact; float residual; };   // T(u) = sum c[k] w^k, w = wa u - 1; exact != 0: do not use the fit
 
 template <typename R> struct NbConst {
     R scale[3];   // box edge / 2^32 (or 2^64)
@@ -124,21 +130,31 @@ template <typename R> struct NbConst {
 // Returns fscale = -dU/dr / r ; *e_lj, *e_c energies (dead code in the callers that do not use them).
 template <typename R> __device__ inline R pair_regular(R r2, R qq, R sig, R eps4, const NbConst<R>& c, R* e_lj, R* e_c);
 
-template <> __device__ __forceinline__ float pair_regular<float>(float r2, float qq, float sig, float eps4, const NbConst<float>& c, float* e_lj, float* e_c) {
+// EXACT = false: the polynomial form above; true: erfc(x) exp(x^2) by its rational fit and v_exp (what round 2 ran everywhere).
+template <bool EXACT> __device__ __forceinline__ float pair_regular_f(float r2, float qq, float sig, float eps4, const NbConst<float>& c, float* e_lj, float* e_c) {
     const float inv_r = __builtin_amdgcn_rsqf(r2);  // v_rsq_f32; r2 is never subnormal here (fixed-point resolution is 2e-9 nm)
     const float inv_r2 = inv_r * inv_r;
     const float s2 = sig * sig * inv_r2, s6 = s2 * s2 * s2, t = eps4 * s6;
     const float flj = t * fmaf(12.0f, s6, -6.0f);
-    const float w = fmaf(r2, c.ew.wa, -1.0f);
-    float T = c.ew.c[EWALD_POLY_DEG];
-#pragma unroll
-    for (int k = EWALD_POLY_DEG - 1; k >= 0; k--) T = fmaf(T, w, c.ew.c[k]);
-    const float g = fmaf(inv_r, inv_r2, -T);
     // energies (only the energy kernels keep this part alive)
     *e_lj = t * (s6 - 1.0f);
     const float ar = c.alpha * (r2 * inv_r);
-    *e_c = qq * erfc_scaled_f(ar) * __expf(-ar * ar) * inv_r;
+    const float ex = __expf(-ar * ar), ec = erfc_scaled_f(ar) * ex;
+    *e_c = qq * ec * inv_r;
+    float g;
+    if (EXACT) g = fmaf(TWO_OVER_SQRT_PI_F * c.alpha, ex, ec * inv_r) * inv_r2;
+    else {
+        const float w = fmaf(r2, c.ew.wa, -1.0f);
+        float T = c.ew.c[EWALD_POLY_DEG];
+#pragma unroll
+        for (int k = EWALD_POLY_DEG - 1; k >= 0; k--) T = fmaf(T, w, c.ew.c[k]);
+        g = fmaf(inv_r, inv_r2, -T);
+    }
     return fmaf(qq, g, flj * inv_r2);
+}
+// (the kernels off the benchmark path decide per pair: a wave-uniform branch on a kernel argument)
+template <> __device__ __forceinline__ float pair_regular<float>(float r2, float qq, float sig, float eps4, const NbConst<float>& c, float* e_lj, float* e_c) {
+    return c.ew.exact ? pair_regular_f<true>(r2, qq, sig, eps4, c, e_lj, e_c) : pair_regular_f<false>(r2, qq, sig, eps4, c, e_lj, e_c);
 }
 
 template <> __device__ inline double pair_regular<double>(double r2, double qq, double sig, double eps4, const NbConst<double>& c, double* e_lj, double* e_c) {

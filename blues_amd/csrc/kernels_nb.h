@@ -65,6 +65,8 @@ struct ListArgs {
     // packed image of every group list (null: not kept): the list's atoms as the nonbonded kernel stages them, {x,y,z,q} and
     // {sigma/2, 2 sqrt(eps)}, written when the list is built -- frozen atoms never change, so the kernel copies it with
     // coalesced loads and refreshes only the MOBILE entries (mlist: pairs (list position, image index)) from the live image
+    // Round 4: the stored sigma/2 carries "mobile" in its sign, and entry jcount of a list's image is a GHOST record (no charge,
+    // no epsilon, 0.3 ... a few nm from every i-atom of the group) that pads the atoms' lists to whole chunks (nonbonded_atom_body)
     uint4* pimg4; float2* pimg2; int* mlist; int* mcount; int mcap;
 };
 
@@ -80,9 +82,15 @@ struct ListArgs {
 #define ATOM_LIST_U 2                       // atoms per wave
 #define ATOM_LIST_PARTS (64 / (ATOM_LIST_WAVES * ATOM_LIST_U))    // its blocks per i-tile
 #define ATOM_SLOT(part, wv, u) ((part) * (64 / ATOM_LIST_PARTS) + (wv) + ATOM_LIST_WAVES * (u))
-#define ATOM_LIST_MOBW 1024                 // words of its mobile-candidate bitmap (list capacity <= 32768)
+#define ATOM_LIST_MOBW 256                  // words of its mobile-candidate bitmap (list capacity <= 8192)
 #define EXK_MAX 64       // excluded partners of one i-atom that can sit in its tile's list (+ sentinel); per-atom-list mode
 #define LIST_LDS 8192      // j-list entries mirrored in LDS for the exclusion searches (longer lists are searched in HBM)
+// per-atom-list mode (nonbonded_atom_body): layout of the dynamic LDS and of a list entry
+#define NB_LQ_BYTES 51200   // room for 6400 {sigma/2, 2 sqrt(eps)} records at the bottom of the dynamic LDS; the {x,y,z,q} records follow
+#define NB_JCAP_MAX 6400
+#define NB_LDS_TAIL 512      // behind the images: the workgroup's atom counter and the energy kernel's per-wave sums
+#define NB_ENT(k) ((unsigned short)((k) << 3))   // list entry of LDS index k
+#define NB_IDX(e) ((int)(e) >> 3)
 
 template <typename R>
 __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force, const int t, const int nblocks) {
@@ -230,7 +238,8 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
     __syncthreads();
     int count = s_total;
     if (t == 0 && tid == 0) a.flags->builds++;
-    if (count > a.jcap) { if (tid == 0) a.flags->list_overflow = 1; count = a.jcap; }
+    const int cap_eff = (!alch_tile && a.alist && a.pimg4) ? a.jcap - 1 : a.jcap;   // (per-atom-list mode: the image keeps one entry for the ghost)
+    if (count > cap_eff) { if (tid == 0) a.flags->list_overflow = 1; count = cap_eff; }
     else if (count > a.hint_count && tid == 0) a.flags->resort_hint = 1;
     if (tid == 0) a.jcount[t] = count;
     const int nb = (count + 63) >> 6;
@@ -259,8 +268,24 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
             for (int k = tid; k < count; k += LIST_THREADS) {
                 const int js = jl[k];
                 const typename Img<R>::Atom A = img[js];
-                g4[k] = make_uint4((unsigned)A.x, (unsigned)A.y, (unsigned)A.z, __float_as_uint((float)A.q)); g2[k] = make_float2((float)A.hs, (float)A.se);
-                if (A.flags & FLAG_MOBILE) { const int q = atomicAdd(&s_mc, 1); if (q < a.mcap) { ml[2 * q] = k; ml[2 * q + 1] = js; } else a.flags->list_overflow = 1; }   // (order is irrelevant: the entries are only refreshed)
+                const bool mob = (A.flags & FLAG_MOBILE) != 0;
+                g4[k] = make_uint4((unsigned)A.x, (unsigned)A.y, (unsigned)A.z, __float_as_uint((float)A.q));
+                g2[k] = make_float2(mob ? -(float)A.hs : (float)A.hs, (float)A.se);   // (sign bit = mobile; sigma = 0 gives -0.0f, read with |.| and an integer test)
+                if (mob) { const int q = atomicAdd(&s_mc, 1); if (q < a.mcap) { ml[2 * q] = k; ml[2 * q + 1] = js; } else a.flags->list_overflow = 1; }   // (order is irrelevant: the entries are only refreshed)
+            }
+            if (tid == 0) {
+                // the ghost: no charge, no epsilon -- its pair force is exactly zero at ANY finite distance -- and placed where the
+                // arithmetic stays finite: 0.5 nm outside the group's bounding sphere along the longest box edge, i.e. >= 0.3 nm from
+                // every i-atom until the next rebuild (which comes before one has moved 0.2 nm) and a few nm at most.  Needs that edge
+                // to exceed the group's diameter + 1 nm, or the point wraps back into the group (host: sort_and_tile only chooses
+                // this kernel where it holds with room to spare; a group that has spread that far asks for a new layout)
+                const double e0 = c.dscale[0], e1 = c.dscale[1], e2 = c.dscale[2];   // (box edge / 2^32; no runtime index into the argument record)
+                const int kl = e0 >= e1 ? (e0 >= e2 ? 0 : 2) : (e1 >= e2 ? 1 : 2);
+                const double el = kl == 0 ? e0 : (kl == 1 ? e1 : e2);
+                if (2.0 * s_rad + 1.0 >= el * 4294967296.0) a.flags->resort_hint = 1;
+                const unsigned off = (unsigned)(long long)((s_rad + 0.5) / el);
+                const unsigned gp[3] = {(unsigned)cf[0] + (kl == 0 ? off : 0u), (unsigned)cf[1] + (kl == 1 ? off : 0u), (unsigned)cf[2] + (kl == 2 ? off : 0u)};
+                g4[count] = make_uint4(gp[0], gp[1], gp[2], 0u); g2[count] = make_float2(0.0f, 0.0f);
             }
             __syncthreads();
             if (tid == 0) a.mcount[t] = min(s_mc, a.mcap);
@@ -427,7 +452,7 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
         uint32_t nx = 0, ny = 0, nz = 0; bool nmob = false;
         if (ch + 1 < nch) fetch(ch + 1, nx, ny, nz, nmob);   // (in flight while this chunk is tested)
         const int k = ch * 64 + lane;
-        const unsigned short ent = (unsigned short)(k | (mob ? 0x8000 : 0));
+        const unsigned short ent = NB_ENT(k);   // (the LDS index times 8: nonbonded_atom_body; "mobile" travels as the sign of the image's sigma/2)
         const float kinf = k < count ? 0.0f : INF;
         const float lim = mob ? rl2m : rl2, plim = mob ? rp2m : rp2;
 #pragma unroll
@@ -467,6 +492,9 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     NB_STAMP(t == 0 && tid == 0, 8);
 #pragma unroll
     for (int u = 0; u < ATOM_LIST_U; u++) {
+        // whole chunks of 64: the force kernel has no "lane holds an entry" mask, the tail of a list points at the group's ghost record
+        { const int c0 = min(cntv[u], a.acap), padto = min((c0 + 63) & ~63, a.acap); if (c0 + lane < padto) out4[u][c0 + lane] = NB_ENT(count); }
+        if (dual) { const int c0 = min(cntp[u], a.acap), padto = min((c0 + 63) & ~63, a.acap); if (c0 + lane < padto) outp4[u][c0 + lane] = NB_ENT(count); }
         if (lane == 0) {
             if (dual) {   // the pruned list is current as of these positions
                 const int sl = t * 64 + ATOM_SLOT(part, wv, u), iq = ia4[u] >= 0 ? ia4[u] : 0;
@@ -685,70 +713,89 @@ __global__ void __launch_bounds__(256) k_nonbonded_sub(NbArgs<float> a, NbConst<
 #define NB_ATOM_U 12   // list entries per lane requested together (768 neighbours per round)
 #define NB_ATOM_UA 7   // ... of which this many unconditionally (448 neighbours: the typical pruned list)
 #define NB_ATOM_G 4    // chunks per straight-line group of the pair loop (divides NB_ATOM_U)
+// Round 4: what a gfx950 SIMD charges for an instruction (scripts/valu_mix.hip, profiles/r04/valu_mix.txt; cycles per wave64
+// instruction at four waves per SIMD): v_fma/v_mul/v_add/v_sub_f32, v_add/v_sub_u32, v_and, v_mov with VECTOR-register operands,
+// literals or inline constants 2.5-2.8; the same instructions with ANY scalar-register operand 4.2-4.4; v_cvt_f32_i32, every
+// shift (v_lshlrev, v_lshl_add, v_bfe), v_max_f32, v_cmp, v_cndmask (e64), DPP adds 4.2-4.4; v_rsq_f32 8.3.  The round-3 pair
+// body was 50 instructions of which 23 were of the second kind (the i-atom and every constant lived in scalar registers, the
+// fixed-point minimum image cost three conversions, the LDS addresses two shift-adds, the masks two compares and a select):
+// ~180 cycles per 64 pairs.  This one is 43 instructions, all but the v_rsq and three conversions of the first kind: ~125 cycles.
+//   * the i-atom and every constant (box scale, Ewald polynomial, cutoff) sit in VECTOR registers (laundered through an empty
+//     asm so that the compiler does not move them back to scalar registers).  The coordinates stay fixed point: three
+//     v_cvt_f32_i32 at the slower rate are what the exact minimum image costs.  (fp32 coordinates relative to the group's
+//     centre would be three v_sub_f32 and nothing else, but a group of 5 tiles plus its list margin is wider than half the
+//     short edge of the benchmark box: one stored image per list entry is then not every pair's minimum image, and the
+//     fixed-point difference, which wraps by itself, is);
+//   * a list entry is the j-atom's LDS index times 8 (u16; capacity <= 8191): the byte offset of its {sigma/2, 2 sqrt(eps)}
+//     record as it stands and, doubled with one v_add_u32, of its {x, y, z, q} record -- the two arrays start at compile-time
+//     offsets of the dynamic LDS (NB_LQ_BYTES), which go into the instructions' offset fields;
+//   * "j is mobile" (energy weight 1/2, build-position rule of the prune) is the SIGN of the stored sigma/2, read with |.|;
+//   * r < cutoff is a factor clamp((rc^2 - r^2) 2^30) in {0, 1} from one v_fma with the clamp modifier instead of compare +
+//     select, and there is no "lane holds an entry" mask at all: every list is padded to whole chunks of 64 with the index
+//     of a GHOST record (no charge, no epsilon: zero force at any finite distance; the builder keeps it 0.3 nm or more from
+//     every i-atom, behind the last real entry of the group's image).
 // Dual lists.  The atoms' lists (alist) are built with the full Verlet margin and are rebuilt rarely; a third of their entries
 // sit in the margin, and every one of them costs a full pair evaluation of all 64 lanes.  The kernel therefore walks PRUNED
 // lists (plist: the entries within cutoff + a small inner margin) and re-derives them itself, in passing and PER ATOM: the
 // integrator raises pneed[islot] when that atom has moved the inner margin since its list was last pruned; for such an atom
-// the wave walks the full list -- same arithmetic, out-of-range lanes masked as before -- and writes the survivors back in
-// list order (ballot + prefix count).  No extra kernel, no extra staging of the image.  A hydrogen asks every ~6 steps, a
-// heavy atom every ~20: about one atom in ten per pass, spread evenly over the waves.
-// Validity (derive_margins, blues_engine.hip): a pruned list holds every pair within cutoff + m of the atom's prune positions.
-// A frozen partner never moves: m = ptrig covers the atom's own displacement.  A mobile partner j has moved less than ptrig
-// since ITS last prune, hence less than 2 ptrig since this atom's: m = 3 ptrig.  For the full list to hold every pair within
-// cutoff + m at any prune, its own rebuild trigger is the outer margin minus m.
+// the wave walks the full list -- same arithmetic -- and writes the survivors back in list order (ballot + prefix count).
+// No extra kernel, no extra staging of the image.  A hydrogen asks every ~6 steps, a heavy atom every ~20.
+// Validity (derive_margins, blues_engine.hip): a pruned list holds every FROZEN candidate within cutoff + m of the atom's
+// position at its prune (the atom asks again once it has moved m) and every MOBILE candidate whose position at the chain's list
+// BUILD (the packed image keeps it) is within cutoff + trig + m of that position: until the next rebuild the candidate stays
+// within `trig` of its build position whatever prunes it goes through itself.  (Round 3's first rule measured mobile
+// candidates from their current position and lost pairs at the cutoff: blues_audit_lists.)
 template <bool ENERGY>
 __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, const NbConst<float>& c, const AtomF* __restrict__ img, const int t) {   // t: list (group of S i-tiles)
-    struct P4 { uint32_t x, y, z; float q; };
-    struct P2 { float hs, se; };
-    extern __shared__ __align__(16) unsigned char nb_smem[];
-    P4* lp = reinterpret_cast<P4*>(nb_smem);
-    P2* lq = reinterpret_cast<P2*>(nb_smem + (size_t)a.jcap * sizeof(P4));
-    __shared__ double s_e[16][2];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); typedef float f32x4 __attribute__((ext_vector_type(4))); typedef float f32x2 __attribute__((ext_vector_type(2)));   // (plain vector types: loads through an address-space pointer stay loads)
+    extern __shared__ __align__(16) unsigned char nb_smem[];   // (the kernel has NO static LDS: the dynamic area then starts at address 0 and a list entry IS an LDS address)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
     if (t == 0 && tid == 0) { a.flags->list_gen = a.flags->req_gen; if (a.batch_req) *a.batch_req = 0; }  // lists are current for this pass
     if (t >= a.n_lists) return;
     // Every pointer below arrives inside an argument record read from memory, i.e. as a GENERIC pointer: left like that, each
     // access is a FLAT instruction (64-bit address pair per lane, and counted on LGKMCNT as well as VMCNT, which would tie the
-    // hand-counted LDS pipeline of the pair loop to the list prefetches).  They all point to global memory: say so.
+    // LDS pipeline of the pair loop to the list prefetches).  They all point to global memory: say so.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define G1(T, p) ((__attribute__((address_space(1))) T*)(p))
+#define L3(T, p) ((__attribute__((address_space(3))) T*)(p))
 #else
 #define G1(T, p) ((T*)(p))   // (the host pass only parses this function)
+#define L3(T, p) ((T*)(p))
 #endif
+    const auto lds = L3(unsigned char, nb_smem);
+    if (tid == 0 && (unsigned)(size_t)lds != 0u) a.flags->nan_flag = 1;   // (folds away at compile time as long as nobody gives this kernel a __shared__ variable)
     const auto g_alist = G1(const unsigned short, a.alist); const auto g_plist = G1(unsigned short, a.plist);
     const auto g_acount = G1(const int, a.acount); const auto g_pcount = G1(int, a.pcount); const auto g_pneed = G1(int, a.pneed);
     const auto g_tile_atoms = G1(const int, a.tile_atoms); const auto g_img = G1(const AtomF, img);
     const auto g_fpart = G1(double, a.fpart); const auto g_flags = G1(DevFlags, a.flags);
     const auto g_xprune0 = G1(unsigned, a.xprune[0]); const auto g_xprune1 = G1(unsigned, a.xprune[1]); const auto g_xprune2 = G1(unsigned, a.xprune[2]);
+    const auto g4 = G1(const u32x4, a.pimg4) + (size_t)t * a.jcap; const auto g2 = G1(const f32x2, a.pimg2) + (size_t)t * a.jcap;
     const bool dual = a.plist != nullptr;
     // (the pruned lists and their counts are addressed as offsets from the full ones: selecting between two POINTERS inside the
     // lambdas below makes the optimiser keep the whole argument record in scratch memory)
     const long plist_off = dual ? (long)(a.plist - a.alist) : 0L, pcount_off = dual ? (long)(a.pcount - a.acount) : 0L;   // (separate allocations: can be gigabytes apart)
     const int count = a.jcount[t];
-    const int* jlst = a.jlist + (size_t)t * a.jcap;
+    const unsigned ghost = (unsigned)NB_ENT(count);
     const int slot0 = t * a.S * 64, nslot = min(a.S, a.n_itiles - t * a.S) * 64;   // the i-slots this list serves
     // An atom's whole list is requested up front (NB_ATOM_U wave-loads of 64 entries, all in flight together) and ONE ATOM
     // AHEAD: the next atom's entries travel while the current atom is computed, the first atom's while the image is staged.
-    // (With one load per iteration, or with all waves requesting and waiting in step, the list stream ran at HBM latency.)
-    // ... and so does the atom's own image record (asked for at the top of the atom's turn it was a memory round trip per atom)
+    // ... and so does the atom's own image record
     unsigned entn[NB_ATOM_U]; int cntn = 0, ian = -1; bool stalen = true;
 #pragma unroll
     for (int u = 0; u < NB_ATOM_U; u++) entn[u] = 0u;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); typedef float f32x2 __attribute__((ext_vector_type(2)));   // (plain vector types: loads through an address-space pointer stay loads)
-    unsigned pxn = 0u, pyn = 0u, pzn = 0u; float pqn = 0.0f, phsn = 0.0f, psen = 0.0f;
+    float pqn = 0.0f, phsn = 0.0f, psen = 0.0f; unsigned fxn = 0u, fyn = 0u, fzn = 0u;
     auto request = [&](int s) {
         ian = -1; cntn = 0;
         if (s < nslot) {
             ian = __builtin_amdgcn_readfirstlane(g_tile_atoms[slot0 + s]);
             if (ian >= 0) {
-                pxn = g_img[ian].x; pyn = g_img[ian].y; pzn = g_img[ian].z; pqn = g_img[ian].q; phsn = g_img[ian].hs; psen = g_img[ian].se;
+                fxn = g_img[ian].x; fyn = g_img[ian].y; fzn = g_img[ian].z; pqn = g_img[ian].q; phsn = g_img[ian].hs; psen = g_img[ian].se;
                 stalen = !dual || __builtin_amdgcn_readfirstlane(g_pneed[slot0 + s]) != 0;
                 cntn = __builtin_amdgcn_readfirstlane(g_acount[(long)(slot0 + s) + (stalen ? 0L : pcount_off)]);
                 const auto lst = g_alist + ((long)(slot0 + s) * a.acap + (stalen ? 0L : plist_off));
                 // the first NB_ATOM_UA chunks unconditionally (a pruned list is about that long), the others only for a longer list (one
                 // wave-uniform branch; a branch per chunk costs a dozen register copies each).  Loads may run past the count inside
-                // the atom's own row (acap >= 64 NB_ATOM_U, host): whatever lies there was a valid entry once, and the lane is
-                // masked when it is used
+                // the atom's own row (acap >= 64 NB_ATOM_U, host): chunks past the padded count are never walked
 #pragma unroll
                 for (int u = 0; u < NB_ATOM_UA; u++) entn[u] = (unsigned)lst[u * 64 + lane];
                 if (cntn > 64 * NB_ATOM_UA) {
@@ -761,37 +808,46 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     // Atoms are handed to the waves on demand (an LDS counter): lists differ in length, an atom that re-derives its pruned
     // list costs half as much again, and a static deal left the workgroup waiting for its unluckiest wave.  An atom's force
     // is computed by one wave in a fixed order whoever takes it: the assignment does not touch the result.
-    __shared__ int s_next;
-    if (tid == 0) s_next = nw;   // (the first nw atoms are dealt statically; the barrier behind the image staging publishes this)
-    auto grab = [&]() -> int { int v = 0; if (lane == 0) v = atomicAdd(&s_next, 1); return __builtin_amdgcn_readfirstlane(v); };
+    const auto s_next = L3(int, lds + NB_LQ_BYTES + 16 * a.jcap);        // (behind the images; the host adds NB_LDS_TAIL bytes)
+    const auto s_e = L3(double, lds + NB_LQ_BYTES + 16 * a.jcap + 16);   // [16][2], energy kernel only
+    if (tid == 0) *s_next = nw;   // (the first nw atoms are dealt statically; the barrier behind the image staging publishes this)
+    auto grab = [&]() -> int { int v = 0; if (lane == 0) v = __hip_atomic_fetch_add(s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return __builtin_amdgcn_readfirstlane(v); };
     NB_STAMP(t == 0 && tid == 0, 16);
     request(wv);
     NB_STAMP(t == 0 && tid == 0, 17);
-    if (a.pimg4) {
-        // packed image: a straight copy, every load of a thread in flight before its first LDS store; then the few mobile entries
-        const auto g4 = G1(const u32x4, a.pimg4) + (size_t)t * a.jcap; const auto g2 = G1(const f32x2, a.pimg2) + (size_t)t * a.jcap;
+    {
+        // the packed image (frozen entries as the builder left them, the ghost behind them): a straight copy, every load of a
+        // thread in flight before its first LDS store; then the few mobile entries from the live image
         constexpr int SU = 7;   // 7 x 1024 threads >= the largest list capacity whose image fits LDS
         const int nthr = blockDim.x;
-        for (int base = 0; base < count; base += SU * nthr) {
+        for (int base = 0; base <= count; base += SU * nthr) {
             u32x4 r4[SU]; f32x2 r2[SU];
 #pragma unroll
-            for (int u = 0; u < SU; u++) { const int k = base + u * nthr + tid; if (k < count) { r4[u] = g4[k]; r2[u] = g2[k]; } }
+            for (int u = 0; u < SU; u++) { const int k = base + u * nthr + tid; if (k <= count) { r4[u] = g4[k]; r2[u] = g2[k]; } }
 #pragma unroll
-            for (int u = 0; u < SU; u++) { const int k = base + u * nthr + tid; if (k < count) { *reinterpret_cast<u32x4*>(&lp[k]) = r4[u]; *reinterpret_cast<f32x2*>(&lq[k]) = r2[u]; } }
+            for (int u = 0; u < SU; u++) { const int k = base + u * nthr + tid; if (k <= count) { *L3(u32x4, lds + NB_LQ_BYTES + 16 * k) = r4[u]; *L3(f32x2, lds + 8 * k) = r2[u]; } }
         }
         __syncthreads();
         const int mc = G1(const int, a.mcount)[t]; const auto ml = G1(const int, a.mlist) + (size_t)t * a.mcap * 2;
-        for (int q = tid; q < mc; q += blockDim.x) { const int k = ml[2 * q], js = ml[2 * q + 1]; lp[k].x = g_img[js].x; lp[k].y = g_img[js].y; lp[k].z = g_img[js].z; }
-    } else {
-        for (int k = tid; k < count; k += blockDim.x) {
-            const AtomF aj = g_img[G1(const int, jlst)[k]];
-            P4 v4; v4.x = aj.x; v4.y = aj.y; v4.z = aj.z; v4.q = aj.q; lp[k] = v4;
-            P2 v2; v2.hs = aj.hs; v2.se = aj.se; lq[k] = v2;
+        for (int q = tid; q < mc; q += blockDim.x) {
+            const int k = ml[2 * q], js = ml[2 * q + 1];
+            const auto pj = L3(unsigned, lds + NB_LQ_BYTES + 16 * k);
+            pj[0] = g_img[js].x; pj[1] = g_img[js].y; pj[2] = g_img[js].z;
         }
     }
     NB_STAMP(t == 0 && tid == 0, 18);
     __syncthreads();
     NB_STAMP(t == 0 && tid == 0, 19);
+    // constants of the pair body, in vector registers (see the header)
+#define NB_VREG(x) asm volatile("" : "+v"(x))
+    float kw[EWALD_POLY_DEG + 1];
+#pragma unroll
+    for (int k = 0; k <= EWALD_POLY_DEG; k++) { kw[k] = c.ew.c[k]; NB_VREG(kw[k]); }
+    float k_wa = c.ew.wa, k_nbig = -1073741824.0f, k_bigrc2 = c.rc2 * 1073741824.0f, k_sx = c.scale[0], k_sy = c.scale[1], k_sz = c.scale[2];
+    NB_VREG(k_wa); NB_VREG(k_nbig); NB_VREG(k_bigrc2); NB_VREG(k_sx); NB_VREG(k_sy); NB_VREG(k_sz);
+    float k_rp2 = c.rp2, k_rp2m = c.rp2_m;   // (a select between two fields of the argument record becomes an indexed load from a scratch copy of it)
+    NB_VREG(k_rp2); NB_VREG(k_rp2m);
+    const bool exact = c.ew.exact != 0;   // (kernel argument: wave-uniform)
     double elj = 0.0, ecl = 0.0;
     int s_nxt = wv;
     while (s_nxt < nslot) {
@@ -802,10 +858,8 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         unsigned ent[NB_ATOM_U];
 #pragma unroll
         for (int u = 0; u < NB_ATOM_U; u++) ent[u] = entn[u];
-        const uint32_t ix = __builtin_amdgcn_readfirstlane(pxn), iy = __builtin_amdgcn_readfirstlane(pyn), iz = __builtin_amdgcn_readfirstlane(pzn);
-        const float iq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pqn)));
-        const float ihs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, phsn)));
-        const float ise = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, psen)));
+        unsigned ix = fxn, iy = fyn, iz = fzn; float iq = pqn, ihs = phsn, ise = psen;
+        NB_VREG(ix); NB_VREG(iy); NB_VREG(iz); NB_VREG(iq); NB_VREG(ihs); NB_VREG(ise);
         s_nxt = grab();
         request(s_nxt);
         if (ia < 0) continue;   // wave-uniform; empty slots are never read back (FinRec.atom < 0)
@@ -816,49 +870,65 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         double fx = 0.0, fy = 0.0, fz = 0.0;
         float bx = 0.0f, by = 0.0f, bz = 0.0f;
         auto fetch = [&](unsigned e, u32x4& q4, f32x2& q2) {
-            const unsigned idx = e & 0x7FFFu;
-            q4 = *reinterpret_cast<const u32x4*>(&lp[idx]); q2 = *reinterpret_cast<const f32x2*>(&lq[idx]);
+            unsigned e2;   // (the compiler turns e + e into a shift, which issues at half the rate of the add)
+            asm("v_add_u32 %0, %1, %1" : "=v"(e2) : "v"(e));
+            q4 = *L3(const u32x4, (size_t)(e2 + NB_LQ_BYTES)); q2 = *L3(const f32x2, (size_t)e);   // (LDS addresses as numbers: the dynamic area starts at 0, checked below)
         };
-        auto pair = [&](unsigned e, const u32x4& q4, const f32x2& q2, bool have, bool write) {
-            P4 bj; bj.x = q4.x; bj.y = q4.y; bj.z = q4.z; bj.q = __uint_as_float(q4.w);
-            P2 bp; bp.hs = q2.x; bp.se = q2.y;
-            const float dx = (float)(int32_t)(ix - bj.x) * c.scale[0];
-            const float dy = (float)(int32_t)(iy - bj.y) * c.scale[1];
-            const float dz = (float)(int32_t)(iz - bj.z) * c.scale[2];
-            const float r2 = dx * dx + dy * dy + dz * dz;
-            const bool in = have && (r2 < c.rc2);
-            float e1, e2;
-            float fs = pair_regular<float>(r2, iq * bj.q, ihs + bp.hs, ise * bp.se, c, &e1, &e2);
-            fs = in ? fs : 0.0f;   // select, not a branch: most lanes are in range, the body would run anyway
-            bx = fmaf(fs, dx, bx); by = fmaf(fs, dy, by); bz = fmaf(fs, dz, bz);
-            if (ENERGY) {
-                if (in) { const double wgt = (e & 0x8000u) ? 0.5 : 1.0; elj += wgt * (double)e1; ecl += wgt * (double)e2; }
+        auto pair = [&](unsigned e, const u32x4& q4, const f32x2& q2, auto write_tag, auto exact_tag) {
+            constexpr bool W = decltype(write_tag)::value, X = decltype(exact_tag)::value;
+            const float dx = (float)(int32_t)(ix - q4.x) * k_sx, dy = (float)(int32_t)(iy - q4.y) * k_sy, dz = (float)(int32_t)(iz - q4.z) * k_sz;
+            const float jq = __uint_as_float(q4.w);
+            const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            if (!ENERGY) {
+                const float inv_r = __builtin_amdgcn_rsqf(r2), inv_r2 = inv_r * inv_r;
+                const float sig = ihs + __builtin_fabsf(q2.x);
+                const float s2 = sig * sig * inv_r2, s6 = s2 * s2 * s2, tt = (ise * q2.y) * s6;
+                const float flj = tt * fmaf(12.0f, s6, -6.0f);
+                float g;
+                if (X) {
+                    const float ar = c.alpha * (r2 * inv_r), ex = __expf(-ar * ar);
+                    g = fmaf(TWO_OVER_SQRT_PI_F * c.alpha, ex, erfc_scaled_f(ar) * ex * inv_r) * inv_r2;
+                } else {
+                    const float w = fmaf(r2, k_wa, -1.0f);
+                    float T = kw[EWALD_POLY_DEG];
+#pragma unroll
+                    for (int k = EWALD_POLY_DEG - 1; k >= 0; k--) T = fmaf(T, w, kw[k]);
+                    g = fmaf(inv_r, inv_r2, -T);
+                }
+                float fs = fmaf(iq * jq, g, flj * inv_r2);
+                float m;   // 1 inside the cutoff, 0 outside (the ghost and the margin entries): (rc^2 - r^2) 2^30 clamped to [0, 1]
+                asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(r2), "v"(k_nbig), "v"(k_bigrc2));
+                fs *= m;
+                bx = fmaf(fs, dx, bx); by = fmaf(fs, dy, by); bz = fmaf(fs, dz, bz);
+            } else if (r2 < c.rc2) {
+                float e1, e2;
+                pair_regular<float>(r2, iq * jq, ihs + __builtin_fabsf(q2.x), ise * q2.y, c, &e1, &e2);
+                const double wgt = __builtin_bit_cast(int, q2.x) < 0 ? 0.5 : 1.0;   // a mobile j meets this pair again from its own list
+                elj += wgt * (double)e1; ecl += wgt * (double)e2;
             }
-            if (write) {   // prune: keep what lies within cutoff + inner margin, in list order
-                float r2k = r2;
-                if (have && (e & 0x8000u)) {
+            if (W) {   // prune: keep what lies within cutoff + inner margin, in list order
+                const bool mob = __builtin_bit_cast(int, q2.x) < 0;
+                bool keep = r2 < k_rp2;   // frozen candidate: within cutoff + inner margin of where this atom is now
+                if (mob) {
                     // a MOBILE candidate is measured from where it was when the chain's lists were built (the packed image keeps
                     // that position): until the next rebuild it stays within `trig` of there, whatever prunes it goes through
                     // itself, so cutoff + trig + m from this atom's position now is a bound that holds until this atom's next
                     // prune (derive_margins).  Its current position says nothing about where it may be by then.
-                    const u32x4 pb = (G1(const u32x4, a.pimg4) + (size_t)t * a.jcap)[e & 0x7FFFu];
+                    const u32x4 pb = g4[NB_IDX(e)];
                     const float ex = (float)(int32_t)(ix - pb.x) * c.scale[0], ey = (float)(int32_t)(iy - pb.y) * c.scale[1], ez = (float)(int32_t)(iz - pb.z) * c.scale[2];
-                    r2k = ex * ex + ey * ey + ez * ez;
+                    keep = ex * ex + ey * ey + ez * ez < k_rp2m;
                 }
-                const bool keep = have && r2k < ((e & 0x8000u) ? c.rp2_m : c.rp2);
+                keep = keep && e != ghost;   // (the ghost pads lists: it is never an entry in its own right)
                 const unsigned long long bal = __ballot(keep);
                 if (keep) pout[pcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)e;
                 pcnt += __popcll(bal);
             }
         };
         // The list is walked in straight-line groups of NB_ATOM_G chunks: all gathers of a group are issued before its first pair
-        // is computed (sched_group_barrier pins that order), so the LDS latency is paid once per group.  With one chunk per
-        // basic block the gather sat right in front of a s_waitcnt lgkmcnt(0), and with four waves per SIMD half of every wave's
-        // cycles went into that wait (gathers issued across a branch are sunk back to their first use by the optimiser).
+        // is computed (sched_group_barrier pins that order), so the LDS latency is paid once per group.
         // The fp32 partials of a lane hold at most NB_ATOM_U pair terms before they are folded.
         const int nch = __builtin_amdgcn_readfirstlane((cnt + 63) >> 6);   // wave-uniform (and known to be: scalar branches below)
-        auto walk = [&](auto write_tag) {
-            constexpr bool W = decltype(write_tag)::value;
+        auto walk = [&](auto write_tag, auto exact_tag) {
 #pragma unroll
             for (int u0 = 0; u0 < NB_ATOM_U; u0 += NB_ATOM_G) {
                 if (u0 >= nch) break;   // wave-uniform (scalar branch)
@@ -868,29 +938,30 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
                     for (int g = 0; g < NB_ATOM_G; g++) fetch(ent[u0 + g], q4[g], q2[g]);
                     __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB_ATOM_G, 0);   // the DS reads first
 #pragma unroll
-                    for (int g = 0; g < NB_ATOM_G; g++) pair(ent[u0 + g], q4[g], q2[g], (u0 + g) * 64 + lane < cnt, W);
+                    for (int g = 0; g < NB_ATOM_G; g++) pair(ent[u0 + g], q4[g], q2[g], write_tag, exact_tag);
                 } else {
 #pragma unroll
                     for (int g = 0; g < NB_ATOM_G - 1; g++) {
                         if (u0 + g >= nch) break;
                         u32x4 q4; f32x2 q2;
                         fetch(ent[u0 + g], q4, q2);
-                        pair(ent[u0 + g], q4, q2, (u0 + g) * 64 + lane < cnt, W);
+                        pair(ent[u0 + g], q4, q2, write_tag, exact_tag);
                     }
                 }
             }
-            for (int base = 64 * NB_ATOM_U; base < cnt; base += 64) {   // lists longer than the prefetch window (dense regions)
-                const bool have = base + lane < cnt;
-                const unsigned e = have ? (unsigned)lst[base + lane] : 0u;
+            for (int base = 64 * NB_ATOM_U; base < cnt; base += 64) {   // lists longer than the prefetch window (dense regions); padded like the others
+                const unsigned e = (unsigned)lst[base + lane];
                 u32x4 q4; f32x2 q2;
                 fetch(e, q4, q2);
-                pair(e, q4, q2, have, W);
+                pair(e, q4, q2, write_tag, exact_tag);
                 fx += (double)bx; fy += (double)by; fz += (double)bz; bx = by = bz = 0.0f;
             }
         };
-        if (!pruning) walk(std::false_type{});
+        if (!pruning) { if (exact) walk(std::false_type{}, std::true_type{}); else walk(std::false_type{}, std::false_type{}); }
         else {
-            walk(std::true_type{});
+            if (exact) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{});
+            const int padto = min((pcnt + 63) & ~63, a.acap);
+            if (pcnt + lane < padto) pout[pcnt + lane] = (unsigned short)ghost;   // whole chunks: the walk has no "lane holds an entry" mask
             if (lane == 0) {
                 g_pcount[islot] = pcnt;   // (a subset of a list that fits acap)
                 g_xprune0[islot] = ix; g_xprune1[islot] = iy; g_xprune2[islot] = iz;
@@ -903,23 +974,27 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         // most ~10^3 kJ/mol/nm; six levels of fp32 adds put ~10^-3 kJ/mol/nm on a force of that size, the rounding the
         // per-lane fp32 accumulation carries anyway (tolerance: 10^-5 of the largest force, ~2 10^-2).  Lists past the
         // prefetch window were folded into fp64 per chunk above.
-        const float sx = wave_sum_dpp_f32(bx), sy = wave_sum_dpp_f32(by), sz = wave_sum_dpp_f32(bz);
-        if (cnt > 64 * NB_ATOM_U) { fx = wave_sum_dpp(fx); fy = wave_sum_dpp(fy); fz = wave_sum_dpp(fz); }   // (wave-uniform; otherwise they are zero)
-        fx += (double)sx; fy += (double)sy; fz += (double)sz;
-        if (lane == 0) { g_fpart[islot] = fx; g_fpart[a.n_islots + islot] = fy; g_fpart[2 * a.n_islots + islot] = fz; }
+        if (!ENERGY) {
+            const float sx = wave_sum_dpp_f32(bx), sy = wave_sum_dpp_f32(by), sz = wave_sum_dpp_f32(bz);
+            if (cnt > 64 * NB_ATOM_U) { fx = wave_sum_dpp(fx); fy = wave_sum_dpp(fy); fz = wave_sum_dpp(fz); }   // (wave-uniform; otherwise they are zero)
+            fx += (double)sx; fy += (double)sy; fz += (double)sz;
+            if (lane == 0) { g_fpart[islot] = fx; g_fpart[a.n_islots + islot] = fy; g_fpart[2 * a.n_islots + islot] = fz; }
+        }
         NB_STAMP(t == 0 && tid == 0, 21 + min(2 * (s / nw), 6));
     }
 #undef G1
+#undef NB_VREG
     if (ENERGY) {
         elj = wave_sum(elj); ecl = wave_sum(ecl);
-        if (lane == 0) { s_e[wv][0] = elj; s_e[wv][1] = ecl; }
+        if (lane == 0) { s_e[2 * wv] = elj; s_e[2 * wv + 1] = ecl; }
         __syncthreads();
         if (tid == 0) {
             double s0 = 0.0, s1 = 0.0;
-            for (int w = 0; w < nw; w++) { s0 += s_e[w][0]; s1 += s_e[w][1]; }
+            for (int w = 0; w < nw; w++) { s0 += s_e[2 * w]; s1 += s_e[2 * w + 1]; }
             a.epart[2 * t] = s0; a.epart[2 * t + 1] = s1;
         }
     }
+#undef L3
 }
 
 // Audit of the per-atom lists (diagnostic; blues_audit_lists).  One block per i-slot: every atom of the SYSTEM within the cutoff
@@ -928,7 +1003,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
 // the pairs within the cutoff, out[1] those that are in no list.  This checks the whole chain of margins and triggers
 // (derive_margins) against the one thing they exist for.
 __global__ void __launch_bounds__(256) k_audit_atom_lists(NbArgs<float> a, ListArgs L, NbConst<float> c, const AtomF* __restrict__ img, unsigned long long* out) {
-    __shared__ unsigned s_bits[8192 / 32 * 4];   // one bit per group-list entry (jcap <= 32768)
+    __shared__ unsigned s_bits[8192 / 32];   // one bit per group-list entry (jcap <= 8191)
     const int sl = blockIdx.x, tid = threadIdx.x;
     const int ia = a.tile_atoms[sl];
     if (ia < 0) return;
@@ -940,7 +1015,7 @@ __global__ void __launch_bounds__(256) k_audit_atom_lists(NbArgs<float> a, ListA
     const int cnt = full ? a.acount[sl] : a.pcount[sl];
     for (int w = tid; w < (a.jcap + 31) / 32; w += 256) s_bits[w] = 0u;
     __syncthreads();
-    for (int e = tid; e < cnt; e += 256) { const int k = lst[e] & 0x7fff; atomicOr(&s_bits[k >> 5], 1u << (k & 31)); }
+    for (int e = tid; e < cnt; e += 256) { const int k = NB_IDX(lst[e]); if (k < count) atomicOr(&s_bits[k >> 5], 1u << (k & 31)); }
     __syncthreads();
     const uint32_t xi = img[ia].x, yi = img[ia].y, zi = img[ia].z;
     const int e0 = L.ex_start[ia], e1 = L.ex_start[ia + 1];

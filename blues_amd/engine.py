@@ -357,6 +357,18 @@ class NativeBatch:
             raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
         return u.value
 
+    def kernel_timing(self, every):
+        """Bracket every `every`-th force launch of the nonbonded kernel in the stepping loop with HIP events (0: off); resets the statistics."""
+        if self._lib.blues_batch_kernel_timing(self._h, int(every)):
+            raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
+
+    def kernel_timing_result(self):
+        """{"usec": mean duration of the sampled in-loop launches, "launches": how many, "usec_max": the longest}"""
+        o = (C.c_double * 3)()
+        if self._lib.blues_batch_get_kernel_timing(self._h, o):
+            raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
+        return {"usec": o[0], "launches": int(o[1]), "usec_max": o[2]}
+
     def time_nonbonded_modes(self, reps=20):
         """(usec over current pruned lists, usec of a pass that re-derives them, share of the latter among the passes so far)"""
         u = (C.c_double * 2)(); f = C.c_double()

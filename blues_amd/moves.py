@@ -77,21 +77,20 @@ class RandomLigandRotationMove(Move):
         about the centre of mass (reference blues/moves.py:293-302).  `move` applies it through the Context; a replica batch calls
         it for every chain between ONE gather and ONE scatter of all chains' ligand atoms (BatchedBLUESSimulation)."""
         self.positions = ligand_positions
-        self.center_of_mass = self.getCenterOfMass(self.positions, self.masses)
-        reduced_pos = self.positions - self.center_of_mass
-        rand_quat = uniform_quaternion(self.random_state)
-        rand_rotation_matrix = rotation_matrix_from_quaternion(rand_quat)
-        return numpy.dot(reduced_pos, rand_rotation_matrix) + self.center_of_mass
+        pivot = self.center_of_mass = self.getCenterOfMass(ligand_positions, self.masses)
+        rotation = rotation_matrix_from_quaternion(uniform_quaternion(self.random_state))
+        # row vectors times the matrix (x' = x R, not R x): the convention the reference applies its matrix in
+        return pivot + (ligand_positions - pivot) @ rotation
 
     def move(self, context):
         """reference blues/moves.py:278-310: read the ligand out of the State's positions, rotate, assign, hand the positions back
         (on this engine the Quantity moves only the ligand's coordinates between device and host)."""
-        positions = context.getState(getPositions=True).getPositions(asNumpy=True)
-        rot_move = self.propose(positions[self.atom_indices]._value)
-        for index, atomidx in enumerate(self.atom_indices):
-            positions[atomidx] = rot_move[index]
-        context.setPositions(positions)
-        self.positions = positions[self.atom_indices]._value
+        everything = context.getState(getPositions=True).getPositions(asNumpy=True)
+        rotated = self.propose(everything[self.atom_indices]._value)
+        for atom, xyz in zip(self.atom_indices, rotated):
+            everything[atom] = xyz
+        context.setPositions(everything)
+        self.positions = everything[self.atom_indices]._value
         return context
 
 

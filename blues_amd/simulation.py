@@ -38,76 +38,124 @@ class SimulationSet(object):
                            "alchemical System, which lacks the ligand's reciprocal-space, self, excluded-pair and dispersion terms")
 
 
+# ---- the pieces of one BLUES iteration as plain functions over a chain's three Simulations.  BLUESSimulation (one chain) and
+# BatchedBLUESSimulation (R chains sharing launches) are both thin drivers over these: the reference's method names are the
+# public surface (blues/simulation.py:812-1257 is the contract), the formulation is this repo's.
+_STATE_FIELDS = (('positions', 'getPositions', {'asNumpy': True}), ('velocities', 'getVelocities', {'asNumpy': True}),
+                 ('potential_energy', 'getPotentialEnergy', {}), ('kinetic_energy', 'getKineticEnergy', {}),
+                 ('box_vectors', 'getPeriodicBoxVectors', {}))
+_STATE_ORDER = ('box_vectors', 'positions', 'velocities')      # the order the reference writes a State back in (simulation.py:938-963)
+_CONTEXT_SETTERS = {'box_vectors': lambda ctx, v: ctx.setPeriodicBoxVectors(*v), 'positions': lambda ctx, v: ctx.setPositions(v),
+                    'velocities': lambda ctx, v: ctx.setVelocities(v)}
+INTEGRATOR_KEYS = ('lambda', 'shadow_work', 'protocol_work', 'Eold', 'Enew')
+
+
+def read_state(context, state_keys):
+    """A State of `context` as the dict BLUES keeps in its state table (reference blues/simulation.py:883-911)."""
+    state = context.getState(**state_keys)
+    return {name: getattr(state, getter)(**kw) for name, getter, kw in _STATE_FIELDS}
+
+
+def write_state(context, table_entry, parts=_STATE_ORDER):
+    """The named parts of a state-table entry back into `context` (reference blues/simulation.py:938-963)."""
+    for part in _STATE_ORDER:
+        if part in parts:
+            _CONTEXT_SETTERS[part](context, table_entry[part])
+    return context
+
+
+def metropolis(chain):
+    """The NCMC acceptance test of one chain (reference blues/simulation.py:1121-1140): log-acceptance of the protocol work plus
+    the alchemical correction against the log of a uniform draw.  Returns the decision record; changes nothing."""
+    integrator = chain._ncmc_sim.context._integrator
+    log_p = integrator.getLogAcceptanceProbability(chain._ncmc_sim.context)
+    log_u = math.log(chain._rng.random_sample())
+    correction = 0.0
+    if not np.isnan(log_p):       # a NaN work rejects without asking for energies (the reference's guard)
+        correction = chain._computeAlchemicalCorrection()
+        logger.debug('NCMCLogAcceptanceProbability = %.6f + Alchemical Correction = %.6f' % (log_p, correction))
+        log_p = log_p + correction
+    return {'accept': bool(log_p > log_u), 'log_accept': float(log_p), 'correction': float(correction), 'randnum': log_u,
+            'protocol_work': integrator.getGlobalVariableByName('protocol_work')}
+
+
+def record_decision(chain, decision):
+    """Acceptance counters and log line of one decision; returns which state-table entry has to be written where:
+    (simulation, entry, parts) or None."""
+    chain.last = decision
+    verdict = 'ACCEPTED' if decision['accept'] else 'REJECTED'
+    logger.info('NCMC MOVE %s: work_ncmc %s %s randnum %s' % (verdict, decision['log_accept'], '>' if decision['accept'] else '<', decision['randnum']))
+    if decision['accept']:
+        chain.accept += 1
+        # the switched configuration becomes the MD state; the MD velocities are redrawn in _resetSimulations anyway
+        return (chain._md_sim, chain.stateTable['ncmc']['state1'], ('box_vectors', 'positions')) if chain._md_sim is not None else None
+    chain.reject += 1
+    if chain._md_sim is not None:
+        return None      # the MD context was never touched: nothing to undo (checked in _acceptRejectMove, as the reference does)
+    return (chain._ncmc_sim, chain.stateTable['ncmc']['state0'], _STATE_ORDER)   # one context for both legs: undo the switch in place
+
+
 class BLUESSimulation(object):
+    """One BLUES chain: `run` = nIter x (sync MD -> NCMC, NCMC switch with the Move's hooks, Metropolis test, reset, MD leg)."""
+
     def __init__(self, simulations, config=None, move_engine=None, rng=None):
         # the reference draws from numpy's global stream (simulation.py:1133); a private RandomState can be handed in
         # where several chains are driven from worker threads (BatchedBLUESSimulation)
-        self._rng = rng if rng is not None else np.random
+        self._rng = np.random if rng is None else rng
         self._move_engine = move_engine if move_engine is not None else getattr(simulations, "_move_engine", None)
-        self._md_sim = simulations.md
-        self._alch_sim = simulations.alch
-        self._ncmc_sim = simulations.ncmc
+        self._md_sim, self._alch_sim, self._ncmc_sim = simulations.md, simulations.alch, simulations.ncmc
         self._config = config or {}
-        self.accept = 0
-        self.reject = 0
-        self.acceptRatio = 0
-        self.currentIter = 0
-        self.stateTable = {'md': {'state0': {}, 'state1': {}}, 'ncmc': {'state0': {}, 'state1': {}}}
-        self._integrator_keys_ = ['lambda', 'shadow_work', 'protocol_work', 'Eold', 'Enew']
-        self._state_keys = {'getPositions': True, 'getVelocities': True, 'getForces': False, 'getEnergy': True,
-                            'getParameters': True, 'enforcePeriodicBox': True}
+        self.accept = self.reject = self.acceptRatio = self.currentIter = 0
+        self.stateTable = {leg: {'state0': {}, 'state1': {}} for leg in ('md', 'ncmc')}
+        self._integrator_keys_ = list(INTEGRATOR_KEYS)
+        self._state_keys = dict(getPositions=True, getVelocities=True, getForces=False, getEnergy=True, getParameters=True, enforcePeriodicBox=True)
         self.last = {}
 
-    # ---- reference blues/simulation.py:883-963
+    # ---- the reference's class-level helpers (blues/simulation.py:883-963), kept as names
     @classmethod
     def getStateFromContext(cls, context, state_keys):
-        stateinfo = {}
-        state = context.getState(**state_keys)
-        stateinfo['positions'] = state.getPositions(asNumpy=True)
-        stateinfo['velocities'] = state.getVelocities(asNumpy=True)
-        stateinfo['potential_energy'] = state.getPotentialEnergy()
-        stateinfo['kinetic_energy'] = state.getKineticEnergy()
-        stateinfo['box_vectors'] = state.getPeriodicBoxVectors()
-        return stateinfo
+        return read_state(context, state_keys)
 
     @classmethod
-    def getIntegratorInfo(cls, ncmc_integrator, integrator_keys=('lambda', 'shadow_work', 'protocol_work', 'Eold', 'Enew')):
+    def getIntegratorInfo(cls, ncmc_integrator, integrator_keys=INTEGRATOR_KEYS):
         return {key: ncmc_integrator.getGlobalVariableByName(key) for key in integrator_keys}
 
     @classmethod
     def setContextFromState(cls, context, state, box=True, positions=True, velocities=True):
-        if box:
-            context.setPeriodicBoxVectors(*state['box_vectors'])
-        if positions:
-            context.setPositions(state['positions'])
-        if velocities:
-            context.setVelocities(state['velocities'])
-        return context
+        wanted = [p for p, on in zip(_STATE_ORDER, (box, positions, velocities)) if on]
+        return write_state(context, state, wanted)
 
     def _setStateTable(self, simkey, stateidx, stateinfo):
         self.stateTable[simkey][stateidx] = stateinfo
 
-    # ---- reference blues/simulation.py:1028-1037
-    def _syncStatesMDtoNCMC(self):
-        src = self._md_sim if self._md_sim is not None else self._ncmc_sim
-        md_state0 = self.getStateFromContext(src.context, self._state_keys)
-        if self._md_sim is None:
-            # no MD context: the MD potential at x0 is the NCMC potential at lambda = 1
-            md_state0['potential_energy'] = unit.Quantity(self._energy_at_lambda_one(), "kilojoule/mole")
-        self._setStateTable('md', 'state0', md_state0)
-        if self._md_sim is not None:
-            self._ncmc_sim.context = self.setContextFromState(self._ncmc_sim.context, md_state0)
+    def _lambda_one_energy(self):
+        """U(x; lambda = 1) of the NCMC context as a Quantity: the MD potential where no MD / alchemical context was handed in."""
+        return unit.Quantity(self._energy_at_lambda_one(), "kilojoule/mole")
 
     def _energy_at_lambda_one(self):
         ctx = self._ncmc_sim.context
         eng = getattr(ctx, "_engine", None)
         if eng is not None and hasattr(eng, "potential_energy_at"):
             return eng.potential_energy_at(1.0, 1.0)   # one call; the value normally comes with the previous evaluation
-        ls, le = ctx.getParameter("lambda_sterics"), ctx.getParameter("lambda_electrostatics")
-        ctx.setParameter("lambda_sterics", 1.0); ctx.setParameter("lambda_electrostatics", 1.0)
+        saved = {p: ctx.getParameter(p) for p in ("lambda_sterics", "lambda_electrostatics")}
+        for p in saved:
+            ctx.setParameter(p, 1.0)
         e = ctx.getState(getEnergy=True).getPotentialEnergy()._value
-        ctx.setParameter("lambda_sterics", ls); ctx.setParameter("lambda_electrostatics", le)
+        for p, v in saved.items():
+            ctx.setParameter(p, v)
         return e
+
+    # ---- reference blues/simulation.py:1028-1037
+    def _syncStatesMDtoNCMC(self):
+        if self._md_sim is None:
+            # one context serves both legs: its own state is the MD state, the MD potential its energy at lambda = 1
+            entry = read_state(self._ncmc_sim.context, self._state_keys)
+            entry['potential_energy'] = self._lambda_one_energy()
+            self._setStateTable('md', 'state0', entry)
+            return
+        entry = read_state(self._md_sim.context, self._state_keys)
+        self._setStateTable('md', 'state0', entry)
+        self._ncmc_sim.context = write_state(self._ncmc_sim.context, entry)
 
     # ---- reference blues/simulation.py:1039-1098
     def _ncmc_plan(self, nstepsNC, moveStep, move_engine=None):
@@ -160,64 +208,41 @@ class BLUESSimulation(object):
         except StopIteration:
             pass
 
-    # ---- reference blues/simulation.py:1100-1119
+    # ---- reference blues/simulation.py:1100-1119: -[ (U_ncmc - U_md)(x0) + (U_alch - U_ncmc)(x1) ] / kT
     def _computeAlchemicalCorrection(self):
-        md_state0_PE = self.stateTable['md']['state0']['potential_energy']
-        ncmc_state0_PE = self.stateTable['ncmc']['state0']['potential_energy']
-        ncmc_state1 = self.stateTable['ncmc']['state1']
-        ncmc_state1_PE = ncmc_state1['potential_energy']
-        if self._alch_sim is not None:
-            self._alch_sim.context = self.setContextFromState(self._alch_sim.context, ncmc_state1, velocities=False)
-            alch_PE = self._alch_sim.context.getState(getEnergy=True).getPotentialEnergy()
+        table = self.stateTable
+        at_x0 = table['ncmc']['state0']['potential_energy'] - table['md']['state0']['potential_energy']
+        end = table['ncmc']['state1']
+        if self._alch_sim is None:
+            unmodified_at_x1 = self._lambda_one_energy()
         else:
-            alch_PE = unit.Quantity(self._energy_at_lambda_one(), "kilojoule/mole")
-        kT = self._ncmc_sim.context._integrator.kT
-        correction_factor = (ncmc_state0_PE - md_state0_PE + alch_PE - ncmc_state1_PE) * (-1.0 / kT)
-        return correction_factor
+            self._alch_sim.context = write_state(self._alch_sim.context, end, ('box_vectors', 'positions'))
+            unmodified_at_x1 = self._alch_sim.context.getState(getEnergy=True).getPotentialEnergy()
+        return (at_x0 + unmodified_at_x1 - end['potential_energy']) * (-1.0 / self._ncmc_sim.context._integrator.kT)
 
     # ---- reference blues/simulation.py:1121-1166
     def _acceptRejectMove(self, write_move=False):
-        work_ncmc = self._ncmc_sim.context._integrator.getLogAcceptanceProbability(self._ncmc_sim.context)
-        randnum = math.log(self._rng.random_sample())
-        correction_factor = 0.0
-        if not np.isnan(work_ncmc):
-            correction_factor = self._computeAlchemicalCorrection()
-            logger.debug('NCMCLogAcceptanceProbability = %.6f + Alchemical Correction = %.6f' % (work_ncmc, correction_factor))
-            work_ncmc = work_ncmc + correction_factor
-        accepted = bool(work_ncmc > randnum)
-        self.last = {'accept': accepted, 'log_accept': float(work_ncmc), 'correction': float(correction_factor), 'randnum': randnum,
-                     'protocol_work': self._ncmc_sim.context._integrator.getGlobalVariableByName('protocol_work')}
-        if accepted:
-            self.accept += 1
-            logger.info('NCMC MOVE ACCEPTED: work_ncmc {} > randnum {}'.format(work_ncmc, randnum))
-            if self._md_sim is not None:
-                ncmc_state1 = self.stateTable['ncmc']['state1']
-                self._md_sim.context = self.setContextFromState(self._md_sim.context, ncmc_state1, velocities=False)
-        else:
-            self.reject += 1
-            logger.info('NCMC MOVE REJECTED: work_ncmc {} < {}'.format(work_ncmc, randnum))
-            if self._md_sim is not None:
-                md_state0 = self.stateTable['md']['state0']
-                md_PE = self._md_sim.context.getState(getEnergy=True).getPotentialEnergy()
-                if not math.isclose(md_state0['potential_energy']._value, md_PE._value, rel_tol=float('1e-%s' % rtol)):
-                    logger.error('Last MD potential energy %s != Current MD potential energy %s. Potential energy should match the prior state.'
-                                 % (md_state0['potential_energy'], md_PE))
-                    sys.exit(1)
-            else:
-                # no separate MD context: restore the pre-switch state in place
-                st0 = self.stateTable['ncmc']['state0']
-                self._ncmc_sim.context = self.setContextFromState(self._ncmc_sim.context, st0)
+        todo = record_decision(self, metropolis(self))
+        if todo is not None:
+            sim, entry, parts = todo
+            sim.context = write_state(sim.context, entry, parts)
+        elif self._md_sim is not None:
+            # rejected with a separate MD context: it must still be where the iteration started (the reference's sanity check)
+            before = self.stateTable['md']['state0']['potential_energy']
+            now = self._md_sim.context.getState(getEnergy=True).getPotentialEnergy()
+            if not math.isclose(before._value, now._value, rel_tol=10.0 ** -rtol):
+                logger.error('Last MD potential energy %s != Current MD potential energy %s. Potential energy should match the prior state.' % (before, now))
+                sys.exit(1)
 
-    # ---- reference blues/simulation.py:1168-1187
+    # ---- reference blues/simulation.py:1168-1187 (the `temperature` quirk kept: run() passes its own default of 300)
     def _resetSimulations(self, temperature=None):
-        if not temperature:
-            temperature = self._ncmc_sim.context._integrator.getTemperature()
+        integrator = self._ncmc_sim.context._integrator
         self._ncmc_sim.currentStep = 0
-        self._ncmc_sim.context._integrator.reset()
-        target = self._md_sim if self._md_sim is not None else self._ncmc_sim
-        target.context.setVelocitiesToTemperature(temperature, self._rng.randint(0, 2 ** 31 - 1))
+        integrator.reset()
+        leg = self._ncmc_sim if self._md_sim is None else self._md_sim
+        leg.context.setVelocitiesToTemperature(temperature or integrator.getTemperature(), self._rng.randint(0, 2 ** 31 - 1))
 
-    # ---- reference blues/simulation.py:1189-1213
+    # ---- reference blues/simulation.py:1189-1213: an MD failure ends the run
     def _stepMD(self, nstepsMD):
         if self._md_sim is None or not nstepsMD:
             return
@@ -231,14 +256,12 @@ class BLUESSimulation(object):
 
     # ---- reference blues/simulation.py:1215-1257
     def run(self, nIter=0, nstepsNC=0, moveStep=0, nstepsMD=0, temperature=300, write_move=False, **config):
-        if not nIter: nIter = self._config['nIter']
-        if not nstepsNC: nstepsNC = self._config['nstepsNC']
-        if not nstepsMD: nstepsMD = self._config.get('nstepsMD', 0)
-        if not moveStep: moveStep = self._config['moveStep']
+        cfg = self._config
+        nIter, nstepsNC, moveStep = int(nIter or cfg['nIter']), nstepsNC or cfg['nstepsNC'], moveStep or cfg['moveStep']
+        nstepsMD = nstepsMD or cfg.get('nstepsMD', 0)
         logger.info('Running %i BLUES iterations...' % (nIter))
-        for N in range(int(nIter)):
-            self.currentIter = N
-            logger.info('BLUES Iteration: %s' % N)
+        for self.currentIter in range(nIter):
+            logger.info('BLUES Iteration: %s' % self.currentIter)
             self._syncStatesMDtoNCMC()
             self._stepNCMC(nstepsNC, moveStep)
             self._acceptRejectMove(write_move)
@@ -335,11 +358,20 @@ class BatchedBLUESSimulation(object):
             m = me.moves[0]
             if not hasattr(m, "propose") or any(getattr(type(m), hook) is not getattr(moves.Move, hook) for hook in ("beforeMove", "afterMove", "_error")):
                 return False
+            # the batched path calls propose() in place of move(): only valid where move() is the one written around that propose()
+            # (a subclass that overrides move() alone would have its override bypassed)
+            owner = lambda name: next(k for k in type(m).__mro__ if name in vars(k))
+            if owner("move") is not owner("propose"):
+                return False
             if first is None:
-                first = m
+                first, first_sim = m, c._ncmc_sim
             elif type(m) is not type(first) or list(m.atom_indices) != list(first.atom_indices):
                 return False
-            if c._ncmc_sim.reporters:
+            # one launch per operation is sized and laid out for ONE system: same atoms, same box, no barostat moving it
+            sysm, sys0 = getattr(c._ncmc_sim, "system", None), getattr(first_sim, "system", None)
+            if sysm is not sys0 and (getattr(sysm, "n_atoms", None) != getattr(sys0, "n_atoms", None) or not np.array_equal(getattr(sysm, "box", None), getattr(sys0, "box", None))):
+                return False
+            if c._ncmc_sim.reporters or getattr(c._ncmc_sim, "barostat", None) is not None:
                 return False
         return True
 
@@ -354,7 +386,10 @@ class BatchedBLUESSimulation(object):
             ctx = c._ncmc_sim.context
             e = ctx._engine
             pe, ke = e.energies()
-            out.append({'positions': unit.DeviceQuantity(snaps[r], 1, "nanometer"), 'velocities': unit.DeviceQuantity(snaps[r], 2, "nanometer/picosecond"),
+            # (enforcePeriodicBox=True of the chain-by-chain path: what reaches the host is wrapped molecule by molecule, context.getState)
+            periodic = getattr(ctx._system, "nonbonded_method", 1) != 0 and hasattr(ctx._system, "n_atoms") and hasattr(ctx, "periodic_wrapper")
+            out.append({'positions': unit.DeviceQuantity(snaps[r], 1, "nanometer", wrapper=ctx.periodic_wrapper() if periodic else None),
+                        'velocities': unit.DeviceQuantity(snaps[r], 2, "nanometer/picosecond"),
                         'potential_energy': unit.Quantity(pe, "kilojoule/mole"), 'kinetic_energy': unit.Quantity(ke, "kilojoule/mole"),
                         'box_vectors': [unit.Quantity(np.array(row), "nanometer") for row in e.get_box()]})
         return out
@@ -409,27 +444,18 @@ class BatchedBLUESSimulation(object):
             c._setStateTable('ncmc', 'state1', st)
 
     def _decide_batched(self, temperature):
-        """_acceptRejectMove + _resetSimulations of every chain (reference blues/simulation.py:1121-1187): the tests chain by chain
-        on numbers already on the host, the restores of the rejected chains, the resets and the velocity redraws once each."""
+        """_acceptRejectMove of every chain (reference blues/simulation.py:1121-1166): the tests chain by chain on numbers already
+        on the host, then the restores of the rejected chains in one call."""
         chains = self.chains
         restore = []
         for c in chains:
-            work_ncmc = c._ncmc_sim.context._integrator.getLogAcceptanceProbability(c._ncmc_sim.context)
-            randnum = math.log(c._rng.random_sample())
-            correction_factor = 0.0
-            if not np.isnan(work_ncmc):
-                correction_factor = c._computeAlchemicalCorrection()
-                work_ncmc = work_ncmc + correction_factor
-            accepted = bool(work_ncmc > randnum)
-            c.last = {'accept': accepted, 'log_accept': float(work_ncmc), 'correction': float(correction_factor), 'randnum': randnum,
-                      'protocol_work': c._ncmc_sim.context._integrator.getGlobalVariableByName('protocol_work')}
-            if accepted:
-                c.accept += 1
-                restore.append(None)
-            else:
-                c.reject += 1
-                restore.append(c.stateTable['ncmc']['state0'])    # no separate MD context: the pre-switch state, in place
+            todo = record_decision(c, metropolis(c))
+            restore.append(None if todo is None else todo[1])    # (no separate MD context here: a rejection restores the pre-switch state in place)
         self._restore_states(restore)
+
+    def _reset_batched(self, temperature):
+        """_resetSimulations of every chain (reference blues/simulation.py:1168-1187): one reset, one velocity redraw."""
+        chains = self.chains
         seeds, temps = [], []
         for c in chains:
             c._ncmc_sim.currentStep = 0
@@ -445,7 +471,7 @@ class BatchedBLUESSimulation(object):
         MD state is the NCMC context's own, its potential the one at lambda = 1."""
         self._ncmc_batch.prefetch_energies(at_lambda_one=True)
         for c, st in zip(self.chains, self._capture_states()):
-            st['potential_energy'] = unit.Quantity(c._energy_at_lambda_one(), "kilojoule/mole")
+            st['potential_energy'] = c._lambda_one_energy()
             c._setStateTable('md', 'state0', st)
 
     def _stepNCMC(self, nstepsNC, moveStep):
@@ -488,6 +514,8 @@ class BatchedBLUESSimulation(object):
             sys.exit(1)
 
     def run(self, nIter=0, nstepsNC=0, moveStep=0, nstepsMD=0, temperature=300, write_move=False, on_iteration=None, **config):
+        """`write_move` is accepted for signature parity and unused, as in the reference (blues/simulation.py:1121: the argument of
+        _acceptRejectMove is never read there either)."""
         cfg = self.chains[0]._config
         if not nIter: nIter = cfg['nIter']
         if not nstepsNC: nstepsNC = cfg['nstepsNC']
@@ -507,8 +535,9 @@ class BatchedBLUESSimulation(object):
             self._stepNCMC(nstepsNC, moveStep)
             if self._batchable():
                 self._decide_batched(temperature)
-                if on_iteration is not None:
+                if on_iteration is not None:     # (between the decision and the reset, as on the chain-by-chain path below)
                     on_iteration(N, [c.last for c in self.chains])
+                self._reset_batched(temperature)
             else:
                 self.for_each_chain(lambda r, c: c._acceptRejectMove(write_move))
                 if on_iteration is not None:

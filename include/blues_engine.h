@@ -375,6 +375,12 @@ int blues_batch_get_stats(BluesBatch *b, int64_t stats[4]);
  * second way in the force passes this batch has run so far; blues_batch_time_nonbonded returns the mean weighted with it. */
 int blues_batch_time_nonbonded_modes(BluesBatch *b, int32_t reps, double usec[2], double *prune_fraction);
 int blues_batch_time_nonbonded(BluesBatch *b, int32_t reps, double *usec_per_launch);
+/* The same kernel timed WHERE IT RUNS: `every` > 0 brackets every `every`-th lock-step force launch of blues_batch_step with two
+ * HIP events on the batch's stream (0 switches it off; either call resets the statistics).  blues_batch_get_kernel_timing drains
+ * the pending events: out[0] = mean duration in us, out[1] = launches sampled, out[2] = the longest one.  This is the figure
+ * bench.py reports as roofline.usec_per_launch (the reference has no counterpart: OpenMM times nothing per kernel). */
+int blues_batch_kernel_timing(BluesBatch *b, int32_t every);
+int blues_batch_get_kernel_timing(BluesBatch *b, double out[3]);
 
 #ifdef __cplusplus
 }
