@@ -283,6 +283,10 @@ def main():
     ap.add_argument("--reciprocal", action="store_true", help="PME in full: reciprocal-space mesh, self, excluded-pair and dispersion terms on top of the direct-space sum "
                     "(the switching path north_star names is the direct-space one; this adds SURVEY.md 8f.2)")
     ap.add_argument("--launch-check", action="store_true", help="CPU-only check of the N-rank launch path (gloo, no engine)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend of the N-rank run: nccl (= RCCL over xGMI, the default) "
+                    "or gloo (the accept records travel through host memory: what a one-GPU box can run)")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (with --backend gloo: the whole N-rank path with real engines on a one-GPU box; "
+                    "a correctness run -- the ranks share the device, `value` says nothing about scaling)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the stand-alone launches of the nonbonded kernel at the end (counter-collection runs: "
                     "every launch of the kernel in the trace is then one of the stepping loop)")
     args = ap.parse_args()
@@ -304,10 +308,18 @@ def main():
     build.build_engine()
     import torch
     from blues_amd import simulation
-    from blues_amd.replicas import env_rank, init_process_group
+    from blues_amd.replicas import env_rank, init_process_group, replica_seed
     rank, local_rank, world = env_rank()
+    if args.same_device and args.backend == "nccl" and world > 1:
+        sys.stderr.write("bench.py: --same-device needs --backend gloo (RCCL wants one device per rank)\n")
+        sys.exit(2)
+    device_index = 0 if args.same_device else local_rank
     if world > 1:
-        init_process_group("nccl")
+        if args.backend == "nccl":
+            init_process_group("nccl")
+        else:
+            torch.cuda.set_device(device_index)
+            init_process_group("gloo")
     import torch.distributed as dist
 
     def barrier():
@@ -315,7 +327,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device_index)
+    local_rank = device_index      # (what the chains are built on)
     nsteps, R = args.nsteps_nc, max(1, args.replicas)
     t_setup = time.perf_counter()
     system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R, reciprocal=args.reciprocal)
@@ -397,7 +410,7 @@ def main():
     st1 = engs[0].stats(); b1 = [d._ncmc_batch.stats() for d in drivers]
     clock = {k: max(ck[k] for ck in clocks) for k in clocks[0]}
     b0 = {k: sum(b[k] for b in b0) / G for k in b0[0]}; b1 = {k: sum(b[k] for b in b1) / G for k in b1[0]}
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if (world == 1 or args.backend == "nccl") else "cpu")
     tmin = t.clone()
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -484,6 +497,8 @@ def main():
             "roofline": roofline,
             "single_replica": single,
             "rank_elapsed_seconds": rank_elapsed,
+            "process_group": {"backend": (args.backend if world > 1 else None), "same_device": bool(args.same_device),
+                              "replica_seeds_first_chain_of_each_rank": [int(replica_seed(1234, r * R)) for r in range(world)]},
             "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup,
                        "plugin_boundary": "one call per operation for all chains (blues_batch_*)" if drivers[0]._batchable() else "chain by chain",
                        "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,

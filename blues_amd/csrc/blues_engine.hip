@@ -199,6 +199,7 @@ struct BluesEngine {
     int S = 1, n_lists = 0;   // S consecutive i-tiles share one j-list (mode 2; 1 otherwise); n_lists = ceil(n_itiles / S)
     DBuf<unsigned short> d_alist, d_plist; DBuf<int> d_acount, d_pcount, d_pneed; DBuf<unsigned> d_xprune[3];   // pruned lists (by i-slot)
     DBuf<uint4> d_pimg4; DBuf<float2> d_pimg2; DBuf<int> d_mlist, d_mcount; int mcap = 0;   // packed group images (ListArgs)
+    DBuf<unsigned short> d_aself;
     int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
     double total_mass = 0;
@@ -795,7 +796,7 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_mask_pool.alloc((size_t)h->pool_cap * 64);
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
         if (h->k1_mode == 2) {
-            h->d_alist.alloc((size_t)h->n_islots * h->acap); h->d_acount.alloc(h->n_islots);
+            h->d_alist.alloc((size_t)h->n_islots * h->acap); h->d_acount.alloc(h->n_islots); h->d_aself.alloc(h->n_islots);
             if (h->prune_on) {
                 h->d_plist.alloc((size_t)h->n_islots * h->acap); h->d_pcount.alloc(h->n_islots); h->d_pneed.alloc(h->n_islots);
                 for (int k = 0; k < 3; k++) h->d_xprune[k].alloc(h->n_islots);
@@ -916,7 +917,7 @@ static ListArgs make_list_args(BluesEngine* h) {
     if (h->k1_mode == 2) { a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap; }
     a.S = h->S; a.n_lists = h->n_lists; a.hint_count = h->hint_count; a.no_sphere = h->tune.no_sphere;
     if (h->k1_mode == 2 && h->prune_on) { a.pneed = h->d_pneed.p; a.plist = h->d_plist.p; a.pcount = h->d_pcount.p; for (int k = 0; k < 3; k++) a.xprune[k] = h->d_xprune[k].p; }
-    if (h->k1_mode == 2) { a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap; }
+    if (h->k1_mode == 2) { a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap; a.aself = h->d_aself.p; }
     return a;
 }
 
@@ -966,7 +967,7 @@ template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
             a.plist = h->d_plist.p; a.pcount = h->d_pcount.p; a.pneed = h->d_pneed.p;
             for (int k = 0; k < 3; k++) a.xprune[k] = h->d_xprune[k].p;
         }
-        a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap;   // (the kernel always stages the packed image: it holds the ghost record the lists are padded with)
+        a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap; a.aself = h->d_aself.p;   // (the kernel always stages the packed image: it holds the ghost record the lists are padded with)
     }
     a.S = h->S; a.n_lists = h->n_lists;
     return a;
@@ -976,7 +977,7 @@ template <typename R> static NbArgs<R> make_nb_args(BluesEngine* h) {
 // the bottom (room for the largest capacity), the 16-byte records behind them at a compile-time offset (kernels_nb.h: NB_LQ_BYTES)
 template <bool ENERGY> static int launch_nb_atom(BluesEngine* h, const NbArgs<float>& a) {
     if (h->jcap > NB_JCAP_MAX) E_FAIL(h, "internal: list capacity %d beyond the per-atom-list kernel's LDS layout", h->jcap);
-    const size_t lds = (size_t)NB_LQ_BYTES + (size_t)h->jcap * 16 + NB_LDS_TAIL;
+    const size_t lds = (size_t)NB_LQ_BYTES + (size_t)h->jcap * 16 + NB_LDS_TAIL + (size_t)8 * 64 * std::min(h->S, std::max(1, h->n_itiles));
     static thread_local size_t lds_set[2][2] = {{0, 0}, {0, 0}};   // [batched][ENERGY]: largest dynamic-LDS size the kernel was opened for
     const bool lead = batch_lead(h);
     if (batch_dry(h)) return 0;

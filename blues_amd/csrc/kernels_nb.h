@@ -68,6 +68,7 @@ struct ListArgs {
     // Round 4: the stored sigma/2 carries "mobile" in its sign, and entry jcount of a list's image is a GHOST record (no charge,
     // no epsilon, 0.3 ... a few nm from every i-atom of the group) that pads the atoms' lists to whole chunks (nonbonded_atom_body)
     uint4* pimg4; float2* pimg2; int* mlist; int* mcount; int mcap;
+    unsigned short* aself;   // [n_islots] every i-atom's own entry in its group's list (NB_ENT form; 0xffff: not there), written with the atoms' lists
 };
 
 // LIST_WAVES waves share one tile's scan of all n atoms; each wave keeps LIST_PREFETCH independent loads in flight.
@@ -88,7 +89,7 @@ struct ListArgs {
 // per-atom-list mode (nonbonded_atom_body): layout of the dynamic LDS and of a list entry
 #define NB_LQ_BYTES 51200   // room for 6400 {sigma/2, 2 sqrt(eps)} records at the bottom of the dynamic LDS; the {x,y,z,q} records follow
 #define NB_JCAP_MAX 6400
-#define NB_LDS_TAIL 512      // behind the images: the workgroup's atom counter and the energy kernel's per-wave sums
+#define NB_LDS_TAIL 512      // behind the images: the workgroup's atom counter and the energy kernel's per-wave sums; then 8 bytes per i-slot of the group
 #define NB_ENT(k) ((unsigned short)((k) << 3))   // list entry of LDS index k
 #define NB_IDX(e) ((int)(e) >> 3)
 
@@ -411,6 +412,7 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
             const int p = a.ex_idx[e0 + q];
             int lo = 0, hi = count;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (jl[mid] < p) lo = mid + 1; else hi = mid; }
+            if (p == ia4[u]) a.aself[t * 64 + slot] = (lo < count && jl[lo] == p) ? NB_ENT(lo) : (unsigned short)0xffffu;   // (the exclusion row holds the atom itself: its own place in the list)
             if (lo < count && jl[lo] == p) {
                 const int at = atomicAdd(&s_exn[slot], 1);
                 if (at < EXK_MAX) { s_ex[slot][at] = (unsigned short)lo; atomicMin(&s_exlo[slot], lo >> 6); atomicMax(&s_exhi[slot], lo >> 6); }
@@ -534,6 +536,7 @@ template <typename R> struct NbArgs {
     // pruned; pneed[islot] != 0: stale (ListArgs); xprune[k][islot]: where the atom was then (fixed point, as in the image)
     unsigned short* plist; int* pcount; int* pneed; unsigned* xprune[3];
     const uint4* pimg4; const float2* pimg2; const int* mlist; const int* mcount; int mcap;   // packed group images (ListArgs)
+    const unsigned short* aself;   // (ListArgs)
 };
 
 // One block = WPB waves working on the SAME i-tile; wave w of the tile walks the j-list segments
@@ -780,18 +783,23 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     // An atom's whole list is requested up front (NB_ATOM_U wave-loads of 64 entries, all in flight together) and ONE ATOM
     // AHEAD: the next atom's entries travel while the current atom is computed, the first atom's while the image is staged.
     // ... and so does the atom's own image record
-    unsigned entn[NB_ATOM_U]; int cntn = 0, ian = -1; bool stalen = true;
+    unsigned entn[NB_ATOM_U]; int cntn = -1; bool stalen = true;
 #pragma unroll
     for (int u = 0; u < NB_ATOM_U; u++) entn[u] = 0u;
-    float pqn = 0.0f, phsn = 0.0f, psen = 0.0f; unsigned fxn = 0u, fyn = 0u, fzn = 0u;
+    // What a wave needs to know about an i-slot -- how long its list is, whether it is due for a prune, where the atom itself sits
+    // in the LDS image (a mobile atom is an entry of its own group's list: its record there is the atom's own data) -- is put
+    // into LDS ONCE per workgroup while the image is staged: one record of 8 bytes per slot.  Round 3 read it from global memory
+    // at the top of every atom's turn: three dependent round trips (tile_atoms -> pneed / image -> count) in front of the list
+    // requests, the whole turn of a wave long, and the kernel's duration did not depend on the pair arithmetic at all (an empty
+    // pair body took 104 us against 130; lists a quarter as long took the same 130: profiles/r04/README.md).
+    const auto s_slot = L3(int, lds + NB_LQ_BYTES + 16 * a.jcap + NB_LDS_TAIL);   // [nslot][2]: {count or -1, self entry | pneed << 16}
+    int selfn = 0;
     auto request = [&](int s) {
-        ian = -1; cntn = 0;
+        cntn = -1;
         if (s < nslot) {
-            ian = __builtin_amdgcn_readfirstlane(g_tile_atoms[slot0 + s]);
-            if (ian >= 0) {
-                fxn = g_img[ian].x; fyn = g_img[ian].y; fzn = g_img[ian].z; pqn = g_img[ian].q; phsn = g_img[ian].hs; psen = g_img[ian].se;
-                stalen = !dual || __builtin_amdgcn_readfirstlane(g_pneed[slot0 + s]) != 0;
-                cntn = __builtin_amdgcn_readfirstlane(g_acount[(long)(slot0 + s) + (stalen ? 0L : pcount_off)]);
+            const int r0 = __builtin_amdgcn_readfirstlane(s_slot[2 * s]), r1 = __builtin_amdgcn_readfirstlane(s_slot[2 * s + 1]);
+            cntn = r0; selfn = r1 & 0xffff; stalen = (r1 >> 16) != 0;
+            if (cntn >= 0) {
                 const auto lst = g_alist + ((long)(slot0 + s) * a.acap + (stalen ? 0L : plist_off));
                 // the first NB_ATOM_UA chunks unconditionally (a pruned list is about that long), the others only for a longer list (one
                 // wave-uniform branch; a branch per chunk costs a dozen register copies each).  Loads may run past the count inside
@@ -813,7 +821,18 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     if (tid == 0) *s_next = nw;   // (the first nw atoms are dealt statically; the barrier behind the image staging publishes this)
     auto grab = [&]() -> int { int v = 0; if (lane == 0) v = __hip_atomic_fetch_add(s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return __builtin_amdgcn_readfirstlane(v); };
     NB_STAMP(t == 0 && tid == 0, 16);
-    request(wv);
+    for (int sl = tid; sl < nslot; sl += blockDim.x) {   // the slot records (one pass: nslot <= 1024)
+        const int ia = g_tile_atoms[slot0 + sl];
+        int r0 = -1, r1 = 0;
+        if (ia >= 0) {
+            const int need = dual ? g_pneed[slot0 + sl] : 1;   // (no pruned lists: every atom walks its full list)
+            r0 = g_acount[(long)(slot0 + sl) + (need ? 0L : pcount_off)];
+            const unsigned self = G1(const unsigned short, a.aself)[slot0 + sl];
+            if (self == 0xffffu) g_flags->list_overflow = 1;   // (the atom is not in its own group's list: only if that list overflowed)
+            r1 = (int)(self | ((unsigned)need << 16));
+        }
+        s_slot[2 * sl] = r0; s_slot[2 * sl + 1] = r1;
+    }
     NB_STAMP(t == 0 && tid == 0, 17);
     {
         // the packed image (frozen entries as the builder left them, the ghost behind them): a straight copy, every load of a
@@ -828,6 +847,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
             for (int u = 0; u < SU; u++) { const int k = base + u * nthr + tid; if (k <= count) { *L3(u32x4, lds + NB_LQ_BYTES + 16 * k) = r4[u]; *L3(f32x2, lds + 8 * k) = r2[u]; } }
         }
         __syncthreads();
+        request(wv);   // (the first atom's list travels while the mobile entries are refreshed)
         const int mc = G1(const int, a.mcount)[t]; const auto ml = G1(const int, a.mlist) + (size_t)t * a.mcap * 2;
         for (int q = tid; q < mc; q += blockDim.x) {
             const int k = ml[2 * q], js = ml[2 * q + 1];
@@ -853,16 +873,18 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     while (s_nxt < nslot) {
         const int s = s_nxt;
         const int islot = slot0 + s;
-        const int ia = ian, cnt = cntn;
+        const int cnt = cntn, self = selfn;
         const bool stale = stalen;
         unsigned ent[NB_ATOM_U];
 #pragma unroll
         for (int u = 0; u < NB_ATOM_U; u++) ent[u] = entn[u];
-        unsigned ix = fxn, iy = fyn, iz = fzn; float iq = pqn, ihs = phsn, ise = psen;
-        NB_VREG(ix); NB_VREG(iy); NB_VREG(iz); NB_VREG(iq); NB_VREG(ihs); NB_VREG(ise);
         s_nxt = grab();
         request(s_nxt);
-        if (ia < 0) continue;   // wave-uniform; empty slots are never read back (FinRec.atom < 0)
+        if (cnt < 0) continue;   // wave-uniform; empty slots are never read back (FinRec.atom < 0)
+        // the atom itself: its record in the LDS image (same address in every lane: one broadcast read, no scalar round trip)
+        const u32x4 me4 = *L3(const u32x4, (size_t)(2u * (unsigned)self + NB_LQ_BYTES)); const f32x2 me2 = *L3(const f32x2, (size_t)(unsigned)self);
+        unsigned ix = me4.x, iy = me4.y, iz = me4.z; float iq = __uint_as_float(me4.w), ihs = __builtin_fabsf(me2.x), ise = me2.y;
+        NB_VREG(ix); NB_VREG(iy); NB_VREG(iz); NB_VREG(iq); NB_VREG(ihs); NB_VREG(ise);
         const bool pruning = !ENERGY && dual && stale;   // an energy evaluation reads whichever list is valid and writes none
         const auto lst = g_alist + ((long)islot * a.acap + (stale ? 0L : plist_off));
         const auto pout = g_plist + (size_t)islot * a.acap;   // (written only when pruning)
@@ -872,12 +894,24 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         auto fetch = [&](unsigned e, u32x4& q4, f32x2& q2) {
             unsigned e2;   // (the compiler turns e + e into a shift, which issues at half the rate of the add)
             asm("v_add_u32 %0, %1, %1" : "=v"(e2) : "v"(e));
+#if defined(K1X_NOGATHER)  // (floor experiment: conflict-free, consecutive addresses)
+            e2 = (unsigned)lane * 16u + (e2 & 0x3c00u); const unsigned e1 = (unsigned)lane * 8u + (e & 0x1e00u);
+            q4 = *L3(const u32x4, (size_t)(e2 + NB_LQ_BYTES)); q2 = *L3(const f32x2, (size_t)e1);
+#else
             q4 = *L3(const u32x4, (size_t)(e2 + NB_LQ_BYTES)); q2 = *L3(const f32x2, (size_t)e);   // (LDS addresses as numbers: the dynamic area starts at 0, checked below)
+#endif
         };
         auto pair = [&](unsigned e, const u32x4& q4, const f32x2& q2, auto write_tag, auto exact_tag) {
             constexpr bool W = decltype(write_tag)::value, X = decltype(exact_tag)::value;
+#if defined(K1X_NOCVT)     // (floor experiment: wrong numbers, no conversions)
+            const float dx = __uint_as_float(ix - q4.x) * k_sx, dy = __uint_as_float(iy - q4.y) * k_sy, dz = __uint_as_float(iz - q4.z) * k_sz;
+#else
             const float dx = (float)(int32_t)(ix - q4.x) * k_sx, dy = (float)(int32_t)(iy - q4.y) * k_sy, dz = (float)(int32_t)(iz - q4.z) * k_sz;
+#endif
             const float jq = __uint_as_float(q4.w);
+#if defined(K1X_EMPTY)     // (floor experiment: gathers and accumulation only)
+            if (!ENERGY && !W) { bx = fmaf(jq, dx, bx); by = fmaf(q2.x, dy, by); bz = fmaf(q2.y, dz, bz); return; }
+#endif
             const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
             if (!ENERGY) {
                 const float inv_r = __builtin_amdgcn_rsqf(r2), inv_r2 = inv_r * inv_r;
@@ -891,8 +925,12 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
                 } else {
                     const float w = fmaf(r2, k_wa, -1.0f);
                     float T = kw[EWALD_POLY_DEG];
+#if defined(K1X_NOPOLY)    // (floor experiment)
+                    T = fmaf(T, w, kw[0]);
+#else
 #pragma unroll
                     for (int k = EWALD_POLY_DEG - 1; k >= 0; k--) T = fmaf(T, w, kw[k]);
+#endif
                     g = fmaf(inv_r, inv_r2, -T);
                 }
                 float fs = fmaf(iq * jq, g, flj * inv_r2);
@@ -965,7 +1003,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
             if (lane == 0) {
                 g_pcount[islot] = pcnt;   // (a subset of a list that fits acap)
                 g_xprune0[islot] = ix; g_xprune1[islot] = iy; g_xprune2[islot] = iz;
-                if (g_pneed[islot] == 1) g_pneed[islot] = 0;   // (this wave is the only reader of the flag in this launch; the integrator sets it in a later one; 2 = kept up by the timing harness)
+                if (dual && !(s_slot[2 * s + 1] >> 17)) g_pneed[islot] = 0;   // (the flag was 1: taken down -- this wave is its only reader in this launch, the integrator raises it in a later one; 2 = kept up by the timing harness)
                 __hip_atomic_fetch_add(&g_flags->prunes, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }

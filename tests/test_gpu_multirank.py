@@ -61,3 +61,24 @@ def test_bench_gpus_2_reports_two_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["accept_records_last"]["chains"] == 16 and np.isfinite(out["value"])
+
+
+def test_two_ranks_with_real_engines_on_one_gpu():
+    """The whole N-rank path short of RCCL itself, on the one-GPU box: bench.py starts two ranks, BOTH on device 0, each with its own
+    replica batch of 8 real engines; the accept records travel over gloo.  16 records in rank order, distinct Philox keys per
+    rank, both ranks' clocks in the line (the path shards by replica only, one exchange per iteration)."""
+    if _n_gpus() < 1:
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "1", "--warmup", "0",
+                        "--replicas", "8", "--nsteps-nc", "20", "--no-cpu", "--no-single"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["accept_records_last"]["chains"] == 16 and np.isfinite(out["value"])
+    pg = out["process_group"]
+    assert pg["backend"] == "gloo" and pg["same_device"] is True
+    assert len(set(pg["replica_seeds_first_chain_of_each_rank"])) == 2
+    el = out["rank_elapsed_seconds"]
+    assert 0.0 < el["min"] <= el["max"] and el["max"] < 600.0
+    # every chain of both ranks stepped the whole (short) protocol in lock step with its batch
+    assert out["engine"]["lockstep_steps_per_switch"] >= 20 and out["engine"]["fallback_steps_per_switch"] == 0

@@ -114,6 +114,11 @@ def test_100_step_switch_with_rotation_golden(Engine, gold, s23k, precision, bat
     engs, B, stepper = make()
     w = _run_switch_teacher(engs, stepper, s, v, gold)
     err = max(np.abs(wr - wo).max() for wr in w) / scale
+    if B is not None and precision == 0:
+        # a batch of 8 in mixed precision is checked against the golden vectors THROUGH the dense alchemical kernel and the per-atom-list
+        # nonbonded kernel -- what bench.py runs -- not through the forms a lone chain uses
+        st = engs[0].stats()
+        assert st["alchemical_kernel"] == 1 and st["nonbonded_kernel"] == 2, st
     if B is not None:
         B.close()
     for g in engs:
@@ -140,6 +145,7 @@ def test_bench_configuration_golden(Engine, gold, s23k):
     w = _run_switch_teacher(engs, lambda n: B.step(n, trace=True)[1], s, v, gold)
     st, bst = engs[0].stats(), B.stats()
     assert st["nonbonded_kernel"] == 2 and st["pruned_lists"] == 1 and st["atom_prunes"] >= 100, st     # the benchmarked kernel, pruning as it goes
+    assert st["alchemical_kernel"] == 1, st    # ... and the DENSE alchemical kernel (what large batches run): a flipped default would move this test to the other form
     assert bst["fallback_steps"] <= 2 * (int(gold["nsteps"]) // int(gold["checkpoint_every"])), bst       # only the re-synchronisations are per member
     errs = [np.abs(w[r] - wo).max() / scale for r in (0, 1, 7, 8, 31, 64, 100, 127, 128, 200, 254, 255)]
     assert max(errs) <= 1e-5, errs

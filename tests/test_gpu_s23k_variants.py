@@ -1,0 +1,158 @@
+"""GPU suite: the two S23k system VARIANTS bench.py runs beside the headline configuration, at full size, against committed oracle
+vectors (tests/golden/s23k_variant_vectors.npz; generator: tests/golden/make_s23k_variant_vectors.py):
+
+  water     -- BASELINE.json configs[3]: nothing frozen (23,400 mobile atoms, 366 i-tiles), 40 position restraints, the first water
+               alchemical (reference examples/example_water.py, blues/moves.py:846-1083);
+  sidechain -- configs[4]: a PARTIALLY alchemical solute (atoms 0, 7, 8, 9 of the first toluene): alchemical-environment exclusions
+               and 1-4 exceptions active, which puts the alchemical kernel into its lane layout inside a batch
+               (reference blues/moves.py:752-844).
+
+Bar (north_star): energies, forces, protocol work within 1e-5 relative of the fp64 CPU restatement; double precision to 1e-9/1e-10.
+The 40-step work trace is compared teacher-forced at the move step (step 20), lone and in replica batches.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from blues_amd import integrators, systems
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s23k_variant_vectors.npz")
+WATER_SHIFT = np.array([0.21, -0.17, 0.12])
+SIDECHAIN_THETA = 1.1
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from blues_amd import build
+    build.build_engine()
+    from blues_amd.engine import NativeEngine
+    return NativeEngine
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(GOLD))
+
+
+def _variant(name):
+    """The constructions of bench.py's build_chains / the generator, with the move of the vectors and its inverse."""
+    if name == "water":
+        base, vel = systems.s23k(frozen=False, restrained=40)
+        s = copy.copy(base)
+        s.alchemical_atoms = np.array([15, 16, 17], np.int32)
+
+        def move(x, sign=1.0):
+            xn = x.copy(); xn[[15, 16, 17]] += sign * WATER_SHIFT
+            return xn
+        return s, vel, move
+    base, vel = systems.s23k(mobile_atoms=275, frozen=True)
+    s = copy.copy(base)
+    s.alchemical_atoms = np.array([0, 7, 8, 9], np.int32)
+
+    def move(x, sign=1.0):   # Rodrigues rotation about the 1 -> 0 bond (neither end moves: the inverse is the rotation by -theta)
+        th = sign * SIDECHAIN_THETA
+        a, b = x[1], x[0]
+        k = (b - a) / np.linalg.norm(b - a)
+        xn = x.copy()
+        for i in (7, 8, 9):
+            p = x[i] - b
+            xn[i] = b + p * np.cos(th) + np.cross(k, p) * np.sin(th) + k * np.dot(k, p) * (1.0 - np.cos(th))
+        return xn
+    return s, vel, move
+
+
+def _data(gold, name, precision, replica=0):
+    return integrators.generateNCMCIntegrator(nstepsNC=int(gold["nsteps"]), dt=float(gold["dt"]), temperature=float(gold["temperature"]),
+                                              seed=int(gold[name + "_seed"])).to_data(precision=precision, replica=replica)
+
+
+@pytest.mark.parametrize("name", ["water", "sidechain"])
+@pytest.mark.parametrize("precision,tol", [(1, 1e-10), (0, 1e-5)])
+def test_variant_energies_and_forces_golden(Engine, gold, name, precision, tol):
+    s, v, _ = _variant(name)
+    assert np.array_equal(gold[name + "_alchemical_atoms"], np.asarray(s.alchemical_atoms))
+    assert np.array_equal(gold[name + "_mobile_atoms"], np.nonzero(s.mass > 0)[0])
+    sel = gold[name + "_force_atoms"]
+    g = Engine(s, _data(gold, name, precision))
+    for k, (ls, le) in enumerate(gold["lambdas"]):
+        g.set_global("lambda_sterics", ls); g.set_global("lambda_electrostatics", le)
+        t = g.energy_terms()
+        eo, to = gold[name + "_energy_total"][k], gold[name + "_energy_terms"][k]
+        assert abs(t.sum() - eo) <= tol * abs(eo), (name, k, t.sum(), eo)
+        for q in range(min(len(t), len(to))):
+            assert abs(t[q] - to[q]) <= tol * max(1.0, abs(to[q]), 1e-3 * abs(eo)), (name, k, q, t[q], to[q])
+        f = g.get_forces()[sel]
+        fo = gold[name + "_forces"][k]
+        assert np.abs(f - fo).max() <= tol * np.abs(fo).max(), (name, k, np.abs(f - fo).max() / np.abs(fo).max())
+        assert np.linalg.norm(f - fo) <= tol * np.linalg.norm(fo)
+    g.close()
+
+
+def _teacher_forced(engines, stepper, s, v, move, gold, name):
+    """Steps 1-20 from the fixture state; at step 20 every engine is put on the oracle's state (x before the move, v), the move is
+    applied, and steps 21-40 follow.  The re-synchronisation is an instantaneous edit the integrator books like a move
+    (perturbed_pe - unperturbed_pe, reference blues/integrators.py:184-191): it is taken out again, the Move's own work -- the
+    part the oracle booked as well -- stays (as tests/test_gpu_s23k_golden.py does every 10 steps)."""
+    n, ms = int(gold["nsteps"]), int(gold["move_step"])
+    mob = gold[name + "_mobile_atoms"]
+    wo = gold[name + "_work_trace"]
+    for g in engines:
+        g.set_velocities(v)
+    a = stepper(ms)
+    out = []
+    move_work = []
+    for g in engines:
+        x = g.get_positions(); vv = g.get_velocities()
+        x_post = x.copy(); x_post[mob] = gold[name + "_x_after_move"]
+        x_pre = move(x_post, -1.0)
+        vv[mob] = gold[name + "_v_at_move"]
+        g.set_positions(x_pre); g.set_velocities(vv)
+        e0 = g.potential_energy()
+        g.set_positions(x_post)
+        move_work.append(g.potential_energy() - e0)
+    b = stepper(n - ms)
+    for r, g in enumerate(engines):
+        ta, tb = np.asarray(a[r], dtype=np.float64), np.asarray(b[r], dtype=np.float64)
+        d = np.diff(np.concatenate([[ta[-1]], tb]))
+        booked = g.get_global("perturbed_pe") - g.get_global("unperturbed_pe")
+        d[0] -= booked - move_work[r]
+        out.append(np.concatenate([ta, float(gold[name + "_work_before_move_step"]) + np.cumsum(d)]))
+    assert abs(float(gold[name + "_work_before_move_step"]) - wo[ms - 1]) < 1e-12
+    return out
+
+
+@pytest.mark.parametrize("name,R", [("water", 1), ("water", 8), ("sidechain", 1), ("sidechain", 8), ("sidechain", 64)])
+@pytest.mark.parametrize("precision", [1, 0])
+def test_variant_switch_golden(Engine, gold, name, R, precision):
+    from blues_amd.engine import NativeBatch
+    if precision == 1 and R > 8:
+        pytest.skip("the large batch is the mixed-precision decomposition")
+    s, v, move = _variant(name)
+    wo = gold[name + "_work_trace"]
+    scale = np.abs(wo).max()
+    assert scale > 1.0
+    engs = [Engine(s, _data(gold, name, precision)) for _ in range(R)]
+    B = NativeBatch(engs) if R > 1 else None
+    stepper = (lambda n: B.step(n, trace=True)[1]) if B is not None else (lambda n: [engs[0].run_switch(n, trace=True)])
+    w = _teacher_forced(engs, stepper, s, v, move, gold, name)
+    err = max(np.abs(wr - wo).max() for wr in w) / scale
+    for wr in w[1:]:
+        assert np.array_equal(wr, w[0])                 # identical chains of a batch stay bitwise identical
+    st = engs[0].stats()
+    if B is not None:
+        assert B.stats()["fallback_steps"] <= 4, B.stats()         # the re-synchronisation and the Move are per member; the steps are shared
+        if precision == 0 and name == "sidechain" and R >= 8:
+            assert st["alchemical_kernel"] == 0, st                 # alchemical-environment exclusions: the lane layout, inside a batch
+        if precision == 0 and R >= 8:
+            assert st["nonbonded_kernel"] == 2, st                  # per-atom lists (water: full lists, nothing frozen; sidechain: pruned)
+        B.close()
+    mob = gold[name + "_mobile_atoms"]
+    pos_err = np.abs(engs[0].get_positions()[mob] - gold[name + "_x_end"]).max()
+    for g in engs:
+        g.close()
+    assert err <= (1e-9 if precision == 1 else 1e-5), (name, R, precision, err)
+    assert pos_err <= (1e-8 if precision == 1 else 1e-4), pos_err
+    print("S23k %s variant: precision=%d R=%d teacher-forced work error %.2e of max|w| = %.3f kJ/mol, end positions within %.1e nm" % (name, precision, R, err, scale, pos_err))
