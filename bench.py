@@ -73,18 +73,18 @@ def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False):
     return system, vel, chains
 
 
-def md_states(chains, x0, v0):
+def md_states(chains, x0, v0, batch=None):
     """What the MD leg hands over at the start of every iteration (reference simulation.py:1028-1037: getStateFromContext
     on the MD context, setContextFromState on the NCMC one).  There is no MD leg in this benchmark, so the hand-over State
     is taken once per chain from the initial coordinates; like any State of this engine it lives in HBM, i.e. the inputs
     of the timed region are resident on the device."""
     from blues_amd import unit
-    out = []
     for c in chains:
         ctx = c._ncmc_sim.context
         ctx.setPositions(unit.Quantity(x0, "nanometer")); ctx.setVelocities(unit.Quantity(v0, "nanometer/picosecond"))
-        out.append(c.getStateFromContext(ctx, c._state_keys))
-    return out
+    if batch is not None:      # the energies every chain's State is about to ask for: one evaluation for the whole batch (set-up time only)
+        batch.prefetch_energies()
+    return [c.getStateFromContext(c._ncmc_sim.context, c._state_keys) for c in chains]
 
 
 def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
@@ -331,29 +331,38 @@ def main():
     local_rank = device_index      # (what the chains are built on)
     nsteps, R = args.nsteps_nc, max(1, args.replicas)
     t_setup = time.perf_counter()
-    system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R, reciprocal=args.reciprocal)
+    from blues_amd import tuning
+    G0 = max(1, min(args.groups, R))
+    # the chains are laid out from the start as members of the batch they are about to join (BluesTuning.assume_batch: the layout a
+    # batch of that size gives its members anyway), so that forming the batch re-lays nobody out: set-up time, nothing else
+    with tuning.override(assume_batch=(R + G0 - 1) // G0):
+        system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R, reciprocal=args.reciprocal)
     x0 = system.positions.copy()
     v0 = vel.copy()
 
-    # ---- configs[1] to the letter: ONE chain on the GPU (before the batch exists, so it runs with a lone engine's layout)
+    # ---- configs[1] to the letter: ONE chain on the GPU, a lone engine with a lone engine's layout (its own construction, default tuning)
     single = None
+    t_single = time.perf_counter()
     if rank == 0 and not args.no_single:
         clock = {"sync": 0.0, "switch": 0.0, "decide": 0.0}
-        st1 = md_states(chains[:1], x0, v0)
-        one_switch(None, chains[:1], st1, nsteps, 0, clock)
+        _, _, lone = build_chains(rank, local_rank, nsteps, args.workload, 1, reciprocal=args.reciprocal)
+        st1 = md_states(lone, x0, v0)
+        one_switch(None, lone, st1, nsteps, 0, clock)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(2):
-            one_switch(None, chains[:1], st1, nsteps, k, clock)
+            one_switch(None, lone, st1, nsteps, k, clock)
         torch.cuda.synchronize()
         dt1 = (time.perf_counter() - t0) / 2
-        e1 = chains[0]._ncmc_sim.context._engine
+        e1 = lone[0]._ncmc_sim.context._engine
         k1_single = e1.time_nonbonded(50)
         a1 = ALGO_BYTES_PER_ATOM * system.n_atoms / (k1_single * 1e-6) / 1e9
         single = {"value": nsteps * DT_PS * 1e-3 / (dt1 / 86400.0), "unit": "ns/day", "ms_per_switch": 1e3 * dt1,
                   "roofline": {"bound": "latency", "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
                                "traffic": None, "usec_per_launch": k1_single,
                                "note": "one chain keeps a few of the 256 CUs busy: every kernel of its step is latency-bound (DESIGN.md section 4)"}}
+        e1.close()
+    t_single = time.perf_counter() - t_single      # (a measurement, not set-up: taken out of setup_seconds below)
 
     G = max(1, min(args.groups, R))
     bounds = [(g * R) // G for g in range(G + 1)]
@@ -362,8 +371,8 @@ def main():
     if G > 1:   # chains driven from different threads draw from their own streams (reproducible whatever the interleaving)
         for c in chains:
             c._rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1))
-    gstates = [md_states(grp, x0, v0) for grp in groups]
-    t_setup = time.perf_counter() - t_setup
+    gstates = [md_states(grp, x0, v0, batch=drv._ncmc_batch) for grp, drv in zip(groups, drivers)]
+    t_setup = time.perf_counter() - t_setup - t_single
     clocks = [{"sync": 0.0, "switch": 0.0, "decide": 0.0} for _ in range(G)]
 
     def switch_group(g, it):

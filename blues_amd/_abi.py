@@ -9,7 +9,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 SWITCH_NONE, SWITCH_VV, SWITCH_GHMC = 0, 1, 2
 NB_NOCUTOFF = 0
 NB_PME_DIRECT = 1
@@ -69,7 +69,7 @@ class BluesTuning(C.Structure):
         ("fork", C.c_int32), ("use_graph", C.c_int32), ("graph_units", C.c_int32), ("graph_fork", C.c_int32),
         ("batch_sync_lists", C.c_int32), ("force_lists", C.c_int32), ("no_sphere", C.c_int32),
         ("pme_general", C.c_int32), ("debug_lists", C.c_int32), ("assume_batch", C.c_int32), ("k1_threads", C.c_int32),
-        ("k2_dense", C.c_int32), ("k2_early", C.c_int32),
+        ("k2_dense", C.c_int32), ("k2_early", C.c_int32), ("fuse_finalize", C.c_int32),
     ]
 
 
@@ -282,6 +282,7 @@ def declare_engine_prototypes(lib):
         "blues_batch_get_stats": ([H, C.POINTER(C.c_int64)], C.c_int),
         "blues_batch_time_nonbonded": ([H, C.c_int32, _dp], C.c_int),
         "blues_batch_time_nonbonded_modes": ([H, C.c_int32, _dp, _dp], C.c_int),
+        "blues_debug_setup_seconds": ([_dp], C.c_int),
         "blues_batch_kernel_timing": ([H, C.c_int32], C.c_int),
         "blues_batch_get_kernel_timing": ([H, _dp], C.c_int),
     }
@@ -305,5 +306,5 @@ ENGINE_SYMBOLS = (
     "blues_batch_snapshot_capture", "blues_batch_restore", "blues_batch_restore_edited", "blues_batch_read_atoms", "blues_batch_reset",
     "blues_batch_set_velocities_to_temperature",
     "blues_batch_get_stats", "blues_batch_time_nonbonded", "blues_batch_time_nonbonded_modes",
-    "blues_batch_kernel_timing", "blues_batch_get_kernel_timing",
+    "blues_batch_kernel_timing", "blues_batch_get_kernel_timing", "blues_debug_setup_seconds",
 )

@@ -27,12 +27,18 @@
 #include "device_common.h"
 #include "kernels_alch.h"
 #include "kernels_bonded.h"
+#include <chrono>
+#include <mutex>
 #include "kernels_integrate.h"
 #include "kernels_nb.h"
 #include "kernels_pme.h"
 #include "kernels_batch.h"
 
 static thread_local std::string g_create_error;
+// set-up cost accounting (diagnostic, blues_debug_setup_seconds): [0] blues_engine_create, [1] sort_and_tile, [2] its device uploads,
+// [3] device allocations (hipMalloc), [4] zero-fills, [5] host-to-device copies of DBuf::upload, [6] number of allocations, [7] streams and events
+static double g_setup_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+struct SetupTimer { double* acc; std::chrono::steady_clock::time_point t0; explicit SetupTimer(int k) : acc(&g_setup_sec[k]), t0(std::chrono::steady_clock::now()) {} ~SetupTimer() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } };
 
 // Launch-policy overrides (include/blues_engine.h, BluesTuning): process-wide defaults copied into every engine / batch at its
 // creation.  The library reads no environment variables.
@@ -46,15 +52,18 @@ template <typename T> struct DBuf {
     void reserve(size_t count) {   // an existing buffer of the right size is reused (a re-sort keeps every address)
         if (!p || count != n) {
             release(); n = count;
+            SetupTimer tm(3); g_setup_sec[6] += 1.0;
             if (hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::string("hipMalloc failed");
         }
     }
     void alloc(size_t count) {   // zero-filled
         reserve(count);
+        SetupTimer tm(4);
         hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
     }
     void upload(const std::vector<T>& h) {   // (every element is overwritten: no fill first)
         if (h.size() != n || !p) reserve(h.size());
+        SetupTimer tm(5);
         if (!h.empty() && hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw std::string("hipMemcpy H2D failed");
     }
     void download(std::vector<T>& h) const {
@@ -126,7 +135,7 @@ struct BluesEngine {
     uint64_t box_epoch = 1;   // bumped by every change of the box: cached energies of a State are only good in the box they were computed in
     int batch_R = 1;  // replicas sharing this engine's launches (shapes the launch decomposition in sort_and_tile)
     uint64_t args_epoch = 1;  // bumped whenever a device buffer referenced by the argument records is (re)allocated
-    hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, cur = nullptr;
+    hipStream_t stream = nullptr, s1 = nullptr, s2 = nullptr, cur = nullptr; bool stream_pooled = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr, evJ1 = nullptr, evJ2 = nullptr, evA = nullptr, evB = nullptr;
     hipGraphExec_t gexec = nullptr; int graph_units = 16; bool graph_valid = false, use_graph = false, graph_fork = false;
     DevCtrl* ctrl_arg = nullptr; DevCtrl host_ctrl;
@@ -166,6 +175,9 @@ struct BluesEngine {
     double cur_ls = 1.0, cur_le = 1.0, h_lambda = 0.0;
     double h_perturbed = 0, h_unperturbed = 0; bool unpert_valid = false, x_edited = false;
     bool pass_valid = false; int pass_L = 0, pass_fmask = 7;
+    // the sums of the last force pass are still to be formed (launch_finalize_deferred): by the step kernel itself if the next
+    // program is the steady-state one, by k_finalize otherwise
+    bool fin_pending = false; double fin_le[3] = {0, 0, 0}; int fin_mask = 7;
     bool have_positions = false, sorted_ok = false, lists_forced = true;
     std::vector<double> hx;        // host copy of the positions the tiles were last laid out from (caller order, [n][3])
     std::vector<double> h_stage;   // staging for host transfers
@@ -196,10 +208,11 @@ struct BluesEngine {
     // everybody when some member's list outgrows it (shape_overflow)
     int hint_count = 0;   // list length that raises resort_hint
     int shape_S = 0, shape_jcap = 0; bool shape_overflow = false, forbid_atom = false; double shape_need = 0.0;
+    int layout_R = 0;   // the batch size (batch_R) the current layout was derived for (sort_and_tile)
     int S = 1, n_lists = 0;   // S consecutive i-tiles share one j-list (mode 2; 1 otherwise); n_lists = ceil(n_itiles / S)
     DBuf<unsigned short> d_alist, d_plist; DBuf<int> d_acount, d_pcount, d_pneed; DBuf<unsigned> d_xprune[3];   // pruned lists (by i-slot)
     DBuf<uint4> d_pimg4; DBuf<float2> d_pimg2; DBuf<int> d_mlist, d_mcount; int mcap = 0;   // packed group images (ListArgs)
-    DBuf<unsigned short> d_aself;
+    DBuf<unsigned short> d_aself; DBuf<uint4> d_pimgb; DBuf<int> d_sx_row;
     int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
     double total_mass = 0;
@@ -244,7 +257,8 @@ struct BluesEngine {
         for (BluesSnapshot* sn : snap_pool) { if (sn->block) hipFree(sn->block); delete sn; }
         if (gexec) hipGraphExecDestroy(gexec);
         for (hipEvent_t e : {ev0, ev1, evFork, evJ1, evJ2, evA, evB}) if (e) hipEventDestroy(e);
-        for (hipStream_t q : {stream, s1, s2}) if (q) hipStreamDestroy(q);
+        if (stream && !stream_pooled) hipStreamDestroy(stream);
+        for (hipStream_t q : {s1, s2}) if (q) hipStreamDestroy(q);
     }
 };
 
@@ -573,6 +587,7 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
 
 // ------------------------------------------------------------------ spatial sort + tile image (host, at set_positions)
 static int sort_and_tile(BluesEngine* h) {
+    SetupTimer tm_all(1);
     const int n = h->n;
     std::vector<std::pair<uint32_t, int>> keys(n);
     for (int i = 0; i < n; i++) {
@@ -654,6 +669,7 @@ static int sort_and_tile(BluesEngine* h) {
         bool want_atom = h->k1_mode == 1;
         if (h->tune.k1_mode == 1) want_atom = false;
         if (h->forbid_atom) want_atom = false;
+        for (int o : h->mobile) if ((int)h->excl[o].size() + 1 > SX_MAX) want_atom = false;   // (the builder of the atoms' lists keeps an atom's excluded partners in one fixed row: kernels_nb.h SX_ROW)
         if (want_atom && h->n_itiles > 0) {
             double est_rad = 0.0;   // radius of the widest group of the last estimate
             auto group_est = [&](int S) {   // largest expected list length over the groups of S tiles
@@ -758,6 +774,7 @@ static int sort_and_tile(BluesEngine* h) {
         ex_start[s + 1] = (int)ex_idx.size();
     }
     // image
+    SetupTimer tm_up(2);   // (from here on: the image and the uploads)
     const double sq = std::sqrt(ONE_4PI_EPS0);
     std::vector<AtomF> imf; std::vector<AtomD> imd;
     if (h->precision == 0) imf.resize(n); else imd.resize(n);
@@ -783,7 +800,12 @@ static int sort_and_tile(BluesEngine* h) {
         { std::vector<int> cs(h->clusters.size() * 4, 0);
           for (size_t c = 0; c < h->clusters.size(); c++) for (int a = 0; a < 4; a++) if (h->clusters[c].atoms[a] >= 0) cs[c * 4 + a] = h->h_sorted_of_orig[h->clusters[c].atoms[a]];
           h->d_cl_sorted.upload(cs);
-          for (size_t c = 0; c < h->clusters.size(); c++) for (int a = 0; a < 4; a++) { h->h_recs[c].sorted[a] = cs[c * 4 + a]; h->h_recs[c].islot[a] = h->clusters[c].atoms[a] >= 0 ? islot[h->clusters[c].atoms[a]] : -1; }
+          for (size_t c = 0; c < h->clusters.size(); c++) for (int a = 0; a < 4; a++) {
+              const int at = h->clusters[c].atoms[a];
+              h->h_recs[c].sorted[a] = cs[c * 4 + a]; h->h_recs[c].islot[a] = at >= 0 ? islot[at] : -1;
+              const int row = at >= 0 && !h->h_row_of_orig.empty() ? h->h_row_of_orig[at] : -1;
+              h->h_recs[c].e0[a] = row >= 0 ? h->h_row_start[row] : 0; h->h_recs[c].e1[a] = row >= 0 ? h->h_row_start[row + 1] : 0;
+          }
           h->d_recs.upload(h->h_recs); }
         h->d_tile_atoms.upload(tile_atoms); h->d_islot.upload(islot);
         h->d_ex_start.upload(ex_start); h->d_ex_idx.upload(ex_idx);
@@ -797,6 +819,20 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
         if (h->k1_mode == 2) {
             h->d_alist.alloc((size_t)h->n_islots * h->acap); h->d_acount.alloc(h->n_islots); h->d_aself.alloc(h->n_islots);
+            {   // static exclusion rows per i-slot (kernels_nb.h: SX_ROW): the atom's sorted index, then its excluded partners'
+                std::vector<int> rows((size_t)h->n_islots * SX_ROW, -1);
+                for (int q = 0; q < h->n_islots; q++) {
+                    int* r = rows.data() + (size_t)q * SX_ROW;
+                    const int sidx = tile_atoms[q];
+                    r[28] = 0; r[29] = 0x7fffffff; r[30] = -1;
+                    if (sidx < 0) continue;
+                    int nrow = 0; r[nrow++] = sidx;
+                    for (int e = ex_start[sidx]; e < ex_start[sidx + 1]; e++) if (ex_idx[e] != sidx && nrow < SX_MAX) r[nrow++] = ex_idx[e];
+                    r[28] = nrow;
+                    for (int e = 0; e < nrow; e++) { r[29] = std::min(r[29], r[e]); r[30] = std::max(r[30], r[e]); }
+                }
+                h->d_sx_row.upload(rows);
+            }
             if (h->prune_on) {
                 h->d_plist.alloc((size_t)h->n_islots * h->acap); h->d_pcount.alloc(h->n_islots); h->d_pneed.alloc(h->n_islots);
                 for (int k = 0; k < 3; k++) h->d_xprune[k].alloc(h->n_islots);
@@ -804,7 +840,7 @@ static int sort_and_tile(BluesEngine* h) {
             // packed group images: what the builder of the atoms' lists streams its candidates from (always), and what the nonbonded
             // kernel stages its LDS image from where most list entries are frozen atoms (the same condition as the pruned lists)
             h->mcap = std::min(jcap, (((int)h->mobile.size() + 63) / 64) * 64);
-            h->d_pimg4.alloc((size_t)std::max(1, h->n_lists) * jcap); h->d_pimg2.alloc((size_t)std::max(1, h->n_lists) * jcap);
+            h->d_pimg4.alloc((size_t)std::max(1, h->n_lists) * jcap); h->d_pimg2.alloc((size_t)std::max(1, h->n_lists) * jcap); h->d_pimgb.alloc((size_t)std::max(1, h->n_lists) * jcap);
             h->d_mlist.alloc((size_t)std::max(1, h->n_lists) * h->mcap * 2); h->d_mcount.alloc(std::max(1, h->n_lists));
         }
         h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1)) + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
@@ -824,6 +860,7 @@ static int sort_and_tile(BluesEngine* h) {
     for (int k = 0; k < 3; k++)   // the master positions on the device are the ones just sorted (every caller uploads / downloads first)
         if (hipMemcpy(h->d_x_sort[k].p, h->d_x[k].p, sizeof(double) * n, hipMemcpyDeviceToDevice) != hipSuccess) E_FAIL(h, "hipMemcpy D2D failed");
     h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->graph_valid = false;
+    h->layout_R = h->batch_R;
     h->args_epoch++;
     return 0;
 }
@@ -838,6 +875,11 @@ static IntArgs make_int_args(BluesEngine* h) {
     A.ftot = h->d_ftot.p; A.alch_self = h->d_alch_self.p;
     A.fJ = h->d_fJ.p; A.sorted_of_orig = h->d_sorted_of_orig.p; A.n_alch = (int)h->alch.size();
     A.alch_local_of_orig = h->d_alch_local.p;
+    A.fpart = h->d_fpart.p; A.fent = h->d_fent.p; A.frec = h->pme ? h->d_frec.p : nullptr; A.self_part = h->d_self_part.p; A.e_part = h->d_e_part.p;
+    A.jcount_alch = h->d_jcount.p + h->n_lists; A.n_islots = h->n_islots; A.npart = h->npart; A.n_entries = h->n_entries; A.PA = h->PA;
+    A.k2_nblocks_env = h->k2_nblocks_env; A.k2_jiter = h->k2_jiter;
+    for (int s3 = 0; s3 < 3; s3++) A.fin_le[s3] = h->fin_le[s3];
+    A.fin_mask = h->fin_mask;
     A.hV = h->dt / std::max(1, h->n_V); A.hR = h->dt / std::max(1, h->n_R); A.inv_hR = 1.0 / A.hR;
     const double hO = h->dt / std::max(1, h->n_O);
     A.aO = std::exp(-h->gamma * hO); A.bO = std::sqrt(1.0 - std::exp(-2.0 * h->gamma * hO));
@@ -859,6 +901,7 @@ static IntArgs make_int_args(BluesEngine* h) {
     return A;
 }
 
+static int resolve_finalize(BluesEngine* h);
 static int flush_program(BluesEngine* h) {
     if (h->prog.n == 0) return 0;
     h->ecache.clear(); h->ke_cache_valid = false; h->acc_cache_valid = false;   // the launch may move atoms
@@ -872,13 +915,21 @@ static int flush_program(BluesEngine* h) {
     for (int q = 0; q < h->prog.n; q++) has_part |= h->prog.ops[q] == OP_CM_PART;
     const dim3 grid(h->int_blocks, batch_lead(h) ? h->batch->R() : 1), block(h->int_threads);
     IntDyn D; D.draw_base = A.draw_base; D.noise_draw_base = A.noise_draw_base; D.n_noise = A.n_noise; D.trace_index = A.trace_index; D.tracing = A.work_trace != nullptr; D.prog = A.prog;
+    for (int s3 = 0; s3 < 3; s3++) D.fin_le[s3] = h->fin_le[s3];
+    D.fin_mask = h->fin_mask;
     const RepCore* reps = h->batch ? h->batch->d_core.p : nullptr;
     const bool lead = batch_lead(h), dry = batch_dry(h);
-    if (h->fast_step && h->prog.n == 9 && !memcmp(h->prog.ops, P_CM, 9)) {
-        if (lead) hipLaunchKernelGGL(k_step_default_b<true>, grid, block, 0, h->cur, reps, D);
+    const bool is_cm = h->fast_step && h->prog.n == 9 && !memcmp(h->prog.ops, P_CM, 9), is_nc = h->fast_step && h->prog.n == 8 && !memcmp(h->prog.ops, P_NC, 8);
+    const bool fused = h->fin_pending && (is_cm || is_nc);   // the pending sums of the last pass: formed by this launch itself ...
+    if (h->fin_pending && !fused) { if (resolve_finalize(h)) return 1; }   // ... or by k_finalize first (any other program)
+    h->fin_pending = false;
+    if (is_cm) {
+        if (fused) { if (lead) hipLaunchKernelGGL((k_step_default_b<true, true>), grid, block, 0, h->cur, reps, D); else if (!dry) hipLaunchKernelGGL((k_step_default<true, true>), grid, block, 0, h->cur, A); }
+        else if (lead) hipLaunchKernelGGL(k_step_default_b<true>, grid, block, 0, h->cur, reps, D);
         else if (!dry) hipLaunchKernelGGL(k_step_default<true>, grid, block, 0, h->cur, A);
-    } else if (h->fast_step && h->prog.n == 8 && !memcmp(h->prog.ops, P_NC, 8)) {
-        if (lead) hipLaunchKernelGGL(k_step_default_b<false>, grid, block, 0, h->cur, reps, D);
+    } else if (is_nc) {
+        if (fused) { if (lead) hipLaunchKernelGGL((k_step_default_b<false, true>), grid, block, 0, h->cur, reps, D); else if (!dry) hipLaunchKernelGGL((k_step_default<false, true>), grid, block, 0, h->cur, A); }
+        else if (lead) hipLaunchKernelGGL(k_step_default_b<false>, grid, block, 0, h->cur, reps, D);
         else if (!dry) hipLaunchKernelGGL(k_step_default<false>, grid, block, 0, h->cur, A);
     } else if (h->fast_step && h->prog.n == 2 && !memcmp(h->prog.ops, P_MD_CM, 2)) {
         if (lead) hipLaunchKernelGGL(k_step_md_b<true>, grid, block, 0, h->cur, reps, D);
@@ -917,7 +968,7 @@ static ListArgs make_list_args(BluesEngine* h) {
     if (h->k1_mode == 2) { a.alist = h->d_alist.p; a.acount = h->d_acount.p; a.acap = h->acap; }
     a.S = h->S; a.n_lists = h->n_lists; a.hint_count = h->hint_count; a.no_sphere = h->tune.no_sphere;
     if (h->k1_mode == 2 && h->prune_on) { a.pneed = h->d_pneed.p; a.plist = h->d_plist.p; a.pcount = h->d_pcount.p; for (int k = 0; k < 3; k++) a.xprune[k] = h->d_xprune[k].p; }
-    if (h->k1_mode == 2) { a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap; a.aself = h->d_aself.p; }
+    if (h->k1_mode == 2) { a.pimg4 = h->d_pimg4.p; a.pimg2 = h->d_pimg2.p; a.mlist = h->d_mlist.p; a.mcount = h->d_mcount.p; a.mcap = h->mcap; a.aself = h->d_aself.p; a.pimgb = h->d_pimgb.p; a.sx_row = h->d_sx_row.p; }
     return a;
 }
 
@@ -1182,6 +1233,22 @@ static int launch_finalize(BluesEngine* h, const double le[3], int slot_mask = 7
     return 0;
 }
 
+// Round 4: the force pass of a step does not launch k_finalize where the step kernel can form the sums itself
+// (kernels_integrate.h: step_default_body<CM, true>): one block holds every cluster of the chain, both kicks of the steady-state
+// program are served by this pass (slots 0 and 2).  What else needs the summed forces resolves the pending sums first.
+static bool fin_fusable(const BluesEngine* h) { return h->fast_step && h->int_blocks == 1 && h->int_threads == 256 && h->tune.fuse_finalize != 0 && !h->ctrl_arg; }
+static int launch_finalize_deferred(BluesEngine* h, const double le[3], int slot_mask) {
+    if (!fin_fusable(h) || (slot_mask & 5) != 5) { h->fin_pending = false; return launch_finalize(h, le, slot_mask); }
+    h->fin_pending = true; h->fin_mask = slot_mask;
+    for (int s = 0; s < 3; s++) h->fin_le[s] = le[s];
+    return 0;
+}
+static int resolve_finalize(BluesEngine* h) {
+    if (!h->fin_pending) return 0;
+    h->fin_pending = false;
+    return launch_finalize(h, h->fin_le, h->fin_mask);
+}
+
 static int launch_bonded_and_finalize(BluesEngine* h, const double le[3], bool with_noise, int slot_mask = 7) {
     if (launch_bonded(h, with_noise)) return 1;
     return launch_finalize(h, le, slot_mask);
@@ -1402,6 +1469,27 @@ static int ensure_sorted(BluesEngine* h) {
     return 0;
 }
 
+// side streams and their fork / join events (a batch's leader with the lane-layout alchemical kernel, graph capture); timing events
+static int ensure_side(BluesEngine* h) {
+    if (h->s1) return 0;
+    HIP_OK(h, hipStreamCreate(&h->s1));
+    {   // s2 carries a batch's rebuild kernels (force_pass): a few workgroups on the critical path that must find room on CUs the
+        // alchemical kernel has filled -- at equal priority the dispatcher keeps refilling those CUs with that kernel's workgroups
+        int least = 0, greatest = 0;
+        HIP_OK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_OK(h, hipStreamCreateWithPriority(&h->s2, hipStreamDefault, greatest));
+    }
+    if (!h->evFork) HIP_OK(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
+    HIP_OK(h, hipEventCreateWithFlags(&h->evJ1, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ2, hipEventDisableTiming));
+    HIP_OK(h, hipEventCreateWithFlags(&h->evA, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evB, hipEventDisableTiming));
+    return 0;
+}
+static int ensure_timing(BluesEngine* h) {
+    if (h->ev0) return 0;
+    HIP_OK(h, hipEventCreate(&h->ev0)); HIP_OK(h, hipEventCreate(&h->ev1));
+    return 0;
+}
+
 // one force pass at the current positions: lists (if stale) -> alchemical -> nonbonded -> bonded
 static int force_pass(BluesEngine* h, int base_L) {
     if (ensure_sorted(h)) return 1;
@@ -1422,7 +1510,8 @@ static int force_pass(BluesEngine* h, int base_L) {
     // (not with the dense alchemical kernel: one 512-thread workgroup with ~137 KB of LDS per chain cannot share a CU with the
     // nonbonded kernel's, and beside the rebuild's small workgroups it runs at half speed -- round 3 timelines: 516 us per step with
     // every kernel alone against 540 with the dense kernel on the side stream)
-    const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && !h->k2_dense && !h->alch.empty() && h->s1 && !h->ctrl_arg;
+    const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && !h->k2_dense && !h->alch.empty() && !h->ctrl_arg;
+    if (fork && ensure_side(h)) return 1;
     // k2_early (off by default): the alchemical kernel of the members that do NOT rebuild needs nothing from the rebuild and can
     // start as soon as the work list says who they are, with the rebuild kernels on a high-priority stream beside it and the
     // members that rebuild following their group lists.  Measured at R = 512 (round 3): 545-565 us per step against 545-555
@@ -1474,8 +1563,8 @@ static int force_pass(BluesEngine* h, int base_L) {
         rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (rc) return 1;
         if (launch_pme(h, 0)) return 1;
-        if (fork) { HIP_OK(h, hipStreamWaitEvent(h->cur, h->evJ1, 0)); if (launch_finalize(h, le, fmask)) return 1; }
-        else if (launch_bonded_and_finalize(h, le, true, fmask)) return 1;
+        if (fork) { HIP_OK(h, hipStreamWaitEvent(h->cur, h->evJ1, 0)); if (launch_finalize_deferred(h, le, fmask)) return 1; }
+        else { if (launch_bonded(h, true)) return 1; if (launch_finalize_deferred(h, le, fmask)) return 1; }
     }
     h->pass_valid = true; h->pass_L = base_L; h->st_passes++; h->vel_clean = true; h->acc_cache_valid = false;
     HIP_OK(h, hipGetLastError());
@@ -1540,6 +1629,7 @@ static EnergyShape energy_shape(const BluesEngine* h) {
 // leader's launches cover every member that takes part)
 static int energy_launch(BluesEngine* h) {
     if (flush_program(h)) return 1;
+    h->fin_pending = false;   // (the slabs of the last pass are about to be overwritten: nothing left to sum)
     if (ensure_sorted(h)) return 1;
     // slot 1 of the alchemical kernel carries lambda_sterics = lambda_electrostatics = 1: the energy at the unmodified potential is
     // what _computeAlchemicalCorrection and _syncStatesMDtoNCMC ask for next (reference blues/simulation.py:1100-1119),
@@ -1818,6 +1908,7 @@ static int capture_graph(BluesEngine* h) {
         }
         rc |= h->precision == 0 ? launch_lists<float>(h, 0) : launch_lists<double>(h, 0);
         if (h->graph_fork) {
+            rc |= ensure_side(h);
             rc |= hipEventRecord(h->evFork, h->stream) != hipSuccess;
             rc |= hipStreamWaitEvent(h->s1, h->evFork, 0) != hipSuccess;
             rc |= hipStreamWaitEvent(h->s2, h->evFork, 0) != hipSuccess;
@@ -1956,6 +2047,7 @@ static int batch_enter(BluesBatch* B) {
         // and an event record + wait per member was 3-5 ms of every batched boundary call at R = 512)
         if (hipStreamQuery(m->stream) != hipSuccess) {
             (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+            if (!m->evFork && hipEventCreateWithFlags(&m->evFork, hipEventDisableTiming) != hipSuccess) { B->err = "hipEventCreate failed"; return 1; }   // (created on first use: blues_engine_create)
             if (hipEventRecord(m->evFork, m->stream) != hipSuccess || hipStreamWaitEvent(B->stream, m->evFork, 0) != hipSuccess) { B->err = "could not order the batch stream after a member's stream"; return 1; }
         }
         m->own_stream = m->stream; m->stream = B->stream; m->cur = B->stream;
@@ -2246,7 +2338,7 @@ void blues_tuning_default(BluesTuning* t) {
     memset(t, 0, sizeof *t);
     t->struct_size = (int32_t)sizeof *t;
     t->prune_margin = -1.0;
-    t->k1_mode = -1; t->fuse_forces = -1; t->fuse_big = -1; t->fast_step = -1; t->slot_mask = -1; t->fork = 1; t->k2_dense = -1; t->use_graph = -1; t->graph_fork = -1;
+    t->k1_mode = -1; t->fuse_forces = -1; t->fuse_big = -1; t->fast_step = -1; t->slot_mask = -1; t->fork = 1; t->k2_dense = -1; t->use_graph = -1; t->graph_fork = -1; t->fuse_finalize = 1;
 }
 int blues_set_tuning(const BluesTuning* t) {
     if (!t) { blues_tuning_default(&g_tuning); return 0; }
@@ -2318,18 +2410,18 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     h->tab_le.assign(it->lambda_electrostatics, it->lambda_electrostatics + h->n_lambda + 1);
     h->prog.n = 0;
     HIP_OK(h, hipSetDevice(h->device));
-    HIP_OK(h, hipStreamCreate(&h->stream));
-    HIP_OK(h, hipStreamCreate(&h->s1));
-    {   // s2 carries a batch's rebuild kernels (force_pass): a few workgroups on the critical path that must find room on CUs the
-        // alchemical kernel has filled -- at equal priority the dispatcher keeps refilling those CUs with that kernel's workgroups
-        int least = 0, greatest = 0;
-        HIP_OK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_OK(h, hipStreamCreateWithPriority(&h->s2, hipStreamDefault, greatest));
+    { SetupTimer tm_streams(7);
+      // An engine's own stream comes from a small per-device pool (a stream costs ~6 ms to create; 512 engines of a rank do not need
+      // 512 of them: their per-engine calls are short and, inside a batch, run on the batch's stream anyway).  Side streams, fork /
+      // join events and timing events are created when first used (ensure_side / ensure_timing).
+      static std::mutex pool_mu; static std::map<int, std::vector<hipStream_t>> pool; static std::map<int, size_t> next;
+      std::lock_guard<std::mutex> lk(pool_mu);
+      std::vector<hipStream_t>& v = pool[h->device];
+      if (v.size() < 8) { hipStream_t q = nullptr; HIP_OK(h, hipStreamCreate(&q)); v.push_back(q); h->stream = q; }
+      else h->stream = v[next[h->device]++ % v.size()];
+      h->stream_pooled = true;
     }
     h->cur = h->stream;
-    HIP_OK(h, hipEventCreate(&h->ev0)); HIP_OK(h, hipEventCreate(&h->ev1));
-    HIP_OK(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ1, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evJ2, hipEventDisableTiming));
-    HIP_OK(h, hipEventCreateWithFlags(&h->evA, hipEventDisableTiming)); HIP_OK(h, hipEventCreateWithFlags(&h->evB, hipEventDisableTiming));
     if (h->tune.use_graph >= 0) h->use_graph = h->tune.use_graph != 0;
     if (h->tune.fast_step >= 0) h->fast_step = h->tune.fast_step != 0;
     if (h->tune.fuse_big >= 0) h->fuse_big = h->tune.fuse_big != 0;
@@ -2360,7 +2452,10 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     return 0;
 }
 
+int blues_debug_setup_seconds(double* out8) { if (!out8) return 2; for (int k = 0; k < 8; k++) out8[k] = g_setup_sec[k]; return 0; }
+
 int blues_engine_create(const BluesSystemDesc* s, const BluesIntegratorDesc* it, int device, BluesEngine** out) {
+    SetupTimer tm_create(0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available: the blues_amd engine has no CPU fallback"; return 2; }
     if (device < 0 || device >= ndev) { g_create_error = "invalid device ordinal"; return 2; }
@@ -2391,7 +2486,13 @@ static int relayout(BluesEngine* h) {
 static int batch_plan_shape(BluesBatch* B, bool fresh) {
     if (B->eng.empty()) return 0;
     auto fail = [&](BluesEngine* m) { B->err = "re-layout for the batch failed: " + m->err; return 1; };
-    if (fresh) for (BluesEngine* m : B->eng) { m->shape_S = 0; m->shape_jcap = 0; m->forbid_atom = false; if (relayout(m)) return fail(m); }
+    if (fresh) for (BluesEngine* m : B->eng) {
+        // (a member that was already laid out on its own for a batch of this size -- BluesTuning.assume_batch -- keeps its layout:
+        // re-deriving it would give the same one, 10 ms of host work per member)
+        const bool same = m->sorted_ok && m->layout_R == m->batch_R && m->shape_S == 0 && !m->forbid_atom;
+        m->shape_S = 0; m->shape_jcap = 0; m->forbid_atom = false;
+        if (!same && relayout(m)) return fail(m);
+    }
     BluesEngine* lead = B->eng[0];
     if (lead->k1_mode != 2) {   // the other modes size everything from the density: congruent by construction
         for (BluesEngine* m : B->eng) if (m->k1_mode == 2) { m->forbid_atom = true; if (relayout(m)) return fail(m); }
@@ -2408,7 +2509,12 @@ static int batch_plan_shape(BluesBatch* B, bool fresh) {
         }
         const int cap = need * 1.3 + 64 <= 3328 ? 3328 : (need * 1.3 + 64 <= lds_max ? lds_max : lds_max + 64);   // the two capacities of sort_and_tile
         if (cap <= lds_max) {
-            for (BluesEngine* m : B->eng) if (m->shape_S != S || m->shape_jcap != cap || m->jcap != cap || m->shape_overflow) { m->shape_S = S; m->shape_jcap = cap; if (relayout(m)) return fail(m); }
+            for (BluesEngine* m : B->eng) {
+                // (a member whose own layout already has the batch's shape only takes note of it: a re-layout under shape (S, cap) gives what it has)
+                const bool has_it = m->k1_mode == 2 && m->S == S && m->jcap == cap && !m->shape_overflow && m->shape_need * 1.1 + 64 <= cap;
+                m->shape_S = S; m->shape_jcap = cap;
+                if (!has_it && relayout(m)) return fail(m);
+            }
             return 0;
         }
         int next = 0;
@@ -2584,6 +2690,7 @@ int blues_get_forces(BluesEngine* h, double* out, int32_t n_atoms) {
     if (n_atoms != h->n) E_FAIL(h, "expected %d atoms, got %d", h->n, n_atoms);
     HIP_OK(h, hipSetDevice(h->device));
     if (flush_program(h)) return 1;
+    h->fin_pending = false;   // (this call runs a pass and the sums of its own)
     // forces at the current alchemical parameters: evaluate a pass whose slot 0 carries them
     if (ensure_sorted(h)) return 1;
     double ls[3] = {h->cur_ls, h->cur_ls, h->cur_ls}, le[3] = {h->cur_le, h->cur_le, h->cur_le};
@@ -2807,6 +2914,7 @@ int blues_time_nonbonded(BluesEngine* h, int32_t reps, double* usec) {
     // between two prunes; blues_batch_time_nonbonded_modes times both kinds of pass)
     for (int w = 0; w < 3; w++) { rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h); if (rc) return 1; }
     if (h->prune_on && h->k1_mode == 2) hipLaunchKernelGGL(k_prune_set, dim3(1), dim3(256), 0, h->stream, (const RepCore*)nullptr, h->d_pneed.p, h->n_islots, 0);
+    if (ensure_timing(h)) return 1;
     HIP_OK(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; r++) { rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h); if (rc) return 1; }
     HIP_OK(h, hipEventRecord(h->ev1, h->stream));
@@ -2855,6 +2963,7 @@ int blues_time_list_build(BluesEngine* h, int32_t reps, double* usec) {
     int rc = 0;
     for (int w = 0; w < 2 && !rc; w++) rc = h->precision == 0 ? launch_lists<float>(h, 1) : launch_lists<double>(h, 1);
     if (rc) return 1;
+    if (ensure_timing(h)) return 1;
     HIP_OK(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps && !rc; r++) rc = h->precision == 0 ? launch_lists<float>(h, 1) : launch_lists<double>(h, 1);
     if (rc) return 1;
@@ -2865,7 +2974,9 @@ int blues_time_list_build(BluesEngine* h, int32_t reps, double* usec) {
     *usec = 1000.0 * ms / std::max(1, reps);
     h->pass_valid = false; h->lists_forced = false;
 #ifdef BLUES_STAMP
-    { long long st[32]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nb_stamps), sizeof st); fprintf(stderr, "[stamps] list build (cycles since start):"); for (int i = 1; i < 9; i++) fprintf(stderr, " %lld", st[i] - st[0]); fprintf(stderr, "\n"); }
+    { long long st[32]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nb_stamps), sizeof st);
+      fprintf(stderr, "[stamps] group lists, block 0 (cycles since its start; box+sphere, scan, barrier, concatenated+counts, image packed):"); for (int i = 1; i < 5; i++) fprintf(stderr, " %lld", st[i] - st[0]); fprintf(stderr, " %lld\n", st[9] - st[0]);
+      fprintf(stderr, "[stamps] atoms' lists, block 0 (cycles since its start; bitmap, exclusions found, walk, counts written):"); for (int i = 6; i < 9; i++) fprintf(stderr, " %lld", st[i] - st[5]); fprintf(stderr, " %lld | between the two kernels' starts %lld\n", st[10] - st[5], st[5] - st[0]); }
 #endif
     return check_flags(h);
 }
@@ -3454,6 +3565,7 @@ int blues_batch_time_nonbonded_modes(BluesBatch* b, int32_t reps, double usec[2]
     if (batch_refresh_args(b)) { batch_leave(b); return 1; }
     b->leader = h; b->lockstep = true;
     const bool dual = h->prune_on && h->k1_mode == 2;
+    if (ensure_timing(h)) { b->err = h->err; batch_leave(b); return 1; }
     int rc = h->precision == 0 ? launch_lists<float>(h, 1) : launch_lists<double>(h, 1);
     float ms[2] = {0.f, 0.f};
     for (int mode = 0; mode < 2 && !rc; mode++) {   // 0: pruned lists current, 1: stale (every launch prunes)

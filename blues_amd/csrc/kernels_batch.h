@@ -40,7 +40,7 @@ __device__ __forceinline__ void batch_decode(int nb, int R, int& rep, int& bx) {
 struct AlchDyn { double ls[3], le[3]; int slot_mask; };
 struct BondedDyn { unsigned draw_base; int n_entry_blocks; };
 struct FinDyn { double le[3]; int slot_mask; };
-struct IntDyn { unsigned draw_base, noise_draw_base; int n_noise, trace_index, tracing; Program prog; };
+struct IntDyn { unsigned draw_base, noise_draw_base; int n_noise, trace_index, tracing; Program prog; double fin_le[3]; int fin_mask; };   // fin_*: the pass whose forces a fused step kernel forms itself
 
 __device__ __forceinline__ void apply_dyn(AlchArgs& A, const AlchDyn& d) {
 #pragma unroll
@@ -57,6 +57,7 @@ __device__ __forceinline__ void apply_dyn(IntArgs& A, const IntDyn& d, unsigned 
     A.draw_base = d.draw_base + delta; A.noise_draw_base = d.noise_draw_base + delta; A.n_noise = d.n_noise; A.trace_index = d.trace_index;
     if (!d.tracing) A.work_trace = nullptr;
     A.ctrl = nullptr;
+    A.fin_le[0] = d.fin_le[0]; A.fin_le[1] = d.fin_le[1]; A.fin_le[2] = d.fin_le[2]; A.fin_mask = d.fin_mask;
 }
 
 // Work list of the rebuild kernels.  In a large batch a few members rebuild their lists in any given round (each chain trips
@@ -240,11 +241,11 @@ __global__ void __launch_bounds__(256) k_integrate_b(const RepCore* __restrict__
     integrate_body(A, d.prog);
 }
 
-template <bool CM>
+template <bool CM, bool FUSED = false>
 __global__ void __launch_bounds__(256) k_step_default_b(const RepCore* __restrict__ reps, IntDyn d) {
     if (!reps[blockIdx.y].active) return;
     IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d, reps[blockIdx.y].draw_delta);
-    step_default_body<CM>(A);
+    step_default_body<CM, FUSED>(A);
 }
 
 template <bool CM>

@@ -49,6 +49,7 @@ struct ClusterRec {
     int mobile[4];   // index into the mobile list (noise buffer)
     int sorted[4];   // index into the tile image
     int islot[4];    // i-slot of the nonbonded kernel (mobile non-alchemical atoms) or -1
+    int e0[4], e1[4];  // the atom's bonded entries [e0, e1) (BondedArgs::fent): what the step kernel sums when it forms the forces itself
     int type, nc, na, pad;
     double dist[3];
     double w[4];     // 1/mass (0 for empty slots)
@@ -65,6 +66,10 @@ struct IntArgs {
     const double* alch_self;  // [9][64] force on the alchemical atoms per slot (k_finalize)
     const double* fJ; const int* sorted_of_orig; int n_alch;
     const int* alch_local_of_orig;
+    // ... or, when the step kernel forms them itself from the force kernels' slabs (step_default_body<CM, true>: no k_finalize launch):
+    const double* fpart; const double* fent; const double* frec; const double* self_part; const double* e_part; const int* jcount_alch;
+    int n_islots, npart, n_entries, PA, k2_nblocks_env, k2_jiter;
+    double fin_le[3]; int fin_mask;   // lambda_electrostatics of the pass's three slots, slots whose force is applied (FinArgs::le, slot_mask)
     // constants
     double hV, hR, inv_hR, aO, bO, kT, tol;
     double dtL, aL, fsL, nsL;  // OP_L coefficients
@@ -232,6 +237,55 @@ __device__ __forceinline__ void load_force(const IntArgs& A, const Cluster& C, i
 // per-slot record of k_finalize: one 16-byte load replaces the chain islot -> atom -> row -> row_start
 struct FinRec { int atom, sorted, e0, e1; };  // caller index (-1: empty), image index, bonded entry range
 
+// ---- the sums of a force pass, as device functions shared by k_finalize and by the step kernel that forms the forces itself
+// (step_default_body<CM, true>): ONE order of summation, so that a chain gets the same bits whichever kernel does it.
+// lambda-independent force on an atom: nonbonded slabs (i-slot isl, or -1), then its bonded entries in order, then reciprocal space
+__device__ __forceinline__ void fin_atom_base(const double* __restrict__ fpart, int n_islots, int npart, const double* __restrict__ fent, int n_entries,
+                                              const double* __restrict__ frec, int n, int isl, int i, int e0, int e1, double f[3]) {
+    f[0] = f[1] = f[2] = 0.0;
+    if (isl >= 0) for (int p = 0; p < npart; p++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) f[k] += fpart[((size_t)p * 3 + k) * n_islots + isl];
+    for (int e = e0; e < e1; e += 8) {   // 8 entries x 3 components requested together, added in entry order (a loop of dependent load -> add took one round trip per entry)
+        double t[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) t[u][k] = e + u < e1 ? fent[(size_t)k * n_entries + e + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (e + u < e1) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
+    }
+    if (frec) { f[0] += frec[i]; f[1] += frec[(size_t)n + i]; f[2] += frec[2 * (size_t)n + i]; }
+}
+// slab q = slot * 3 + component of the alchemical atoms' pair force: a block of 256 threads, thread = (alchemical atom a, block
+// group g), fixed order; the value for thread tid < n_alch (0 elsewhere).  Two block barriers.
+__device__ __forceinline__ double fin_alch_self(const double* __restrict__ self_part, int PA, int nb_env, int k2_nblocks_env, int q, bool on, int n_alch, double* s_red) {
+    const int tid = threadIdx.x, NG = 256 / PA, a = tid & (PA - 1), g = tid / PA;
+    double s = 0.0;
+    if (on) {
+        for (int b = g; b < nb_env; b += NG) s += self_part[((size_t)b * 9 + q) * PA + a];
+        if (g == 0) s += self_part[((size_t)k2_nblocks_env * 9 + q) * PA + a];
+    }
+    __syncthreads();   // (s_red may still be read from the previous slab)
+    s_red[tid] = s;
+    __syncthreads();
+    double t = 0.0;
+    if (on && tid < n_alch) for (int u = 0; u < NG; u++) t += s_red[u * PA + tid];   // fixed order
+    return t;
+}
+// the K2_NP sums over the alchemical kernel's blocks (energies per kind, slot-0 force on the alchemical atoms) -> s_e[K2_NP]; 256 threads, one barrier at the end
+__device__ __forceinline__ void fin_energy_sums(const double* __restrict__ e_part, int nb_env, int k2_nblocks_env, double* s_e) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int q = wv; q < K2_NP; q += 4) {
+        double s = 0.0;
+        for (int b = lane; b < nb_env; b += 64) s += e_part[(size_t)b * K2_NP + q];
+        if (lane == 0) s += e_part[(size_t)k2_nblocks_env * K2_NP + q];
+        s = wave_sum(s);
+        if (lane == 0) s_e[q] = s;
+    }
+    __syncthreads();
+}
+
 struct FinArgs {
     int n, n_islots, npart, n_alch, PA, k2_nblocks_env, k2_jiter, n_entries;
     const FinRec* recs;         // [n_islots + 64]: i-slots, then the alchemical atoms
@@ -257,7 +311,7 @@ struct FinArgs {
 // fixed order (deterministic, and no chain of dependent global loads).
 // LEAN: same sums in the same order without the deep load batching -- for replica batches, where thousands of these blocks
 // are resident and occupancy (registers) counts for more than the latency of one block's load chain
-template <bool LEAN>
+template <bool LEAN>   // (LEAN: kept as a name of the batched instantiation; the sums are the same shared functions either way)
 __device__ __forceinline__ void finalize_body(FinArgs& A) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (A.ctrl) {
@@ -268,117 +322,55 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
     }
     const int n_itiles = A.n_islots / 64;
     const int nb_alch_atoms = A.n_alch > 0 ? 1 : 0;
-    __shared__ double red[4][3][64];
     int blk = blockIdx.x;
     if (blk < n_itiles + nb_alch_atoms) {
+        if (wv != 0) return;   // one thread per atom: the order of fin_atom_base (the step kernel forms the same sums the same way)
         const int isl = blk < n_itiles ? blk * 64 + lane : -1;
         const FinRec rec = A.recs[blk < n_itiles ? isl : A.n_islots + lane];
         const int i = rec.atom;
         double f[3] = {0.0, 0.0, 0.0};
-        double fj[3][3];  // alchemical force on this (environment) atom per slot: requested now, used after the reduction
+        double fj[3][3];  // alchemical force on this (environment) atom per slot
 #pragma unroll
         for (int sl = 0; sl < 3; sl++)
 #pragma unroll
-            for (int k = 0; k < 3; k++) fj[sl][k] = (wv == 0 && i >= 0 && isl >= 0 && A.n_alch > 0 && ((A.slot_mask >> sl) & 1)) ? A.fJ[(size_t)(sl * 3 + k) * A.n + rec.sorted] : 0.0;
+            for (int k = 0; k < 3; k++) fj[sl][k] = (i >= 0 && isl >= 0 && A.n_alch > 0 && ((A.slot_mask >> sl) & 1)) ? A.fJ[(size_t)(sl * 3 + k) * A.n + rec.sorted] : 0.0;
         if (i >= 0) {
-            if (isl >= 0) {
-                int p = wv;
-                if (!LEAN) for (; p + 28 < A.npart; p += 32) {  // 8 partials x 3 components in flight
-                    double t[8][3];
-#pragma unroll
-                    for (int u = 0; u < 8; u++)
-#pragma unroll
-                        for (int k = 0; k < 3; k++) t[u][k] = A.fpart[((size_t)(p + 4 * u) * 3 + k) * A.n_islots + isl];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
-                }
-                if (!LEAN) for (; p + 12 < A.npart; p += 16) {  // 4 partials x 3 components in flight
-                    double t[4][3];
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-#pragma unroll
-                        for (int k = 0; k < 3; k++) t[u][k] = A.fpart[((size_t)(p + 4 * u) * 3 + k) * A.n_islots + isl];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
-                }
-                for (; p < A.npart; p += 4)
-                    for (int k = 0; k < 3; k++) f[k] += A.fpart[((size_t)p * 3 + k) * A.n_islots + isl];
-            }
-            if (LEAN) {
-                for (int e = rec.e0 + wv; e < rec.e1; e += 4)
-                    for (int k = 0; k < 3; k++) f[k] += A.fent[(size_t)k * A.n_entries + e];
-            } else
-            for (int e = rec.e0 + wv; e < rec.e1; e += 32) {  // up to 8 bonded entries x 3 components in flight
-                double t[8][3];
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-#pragma unroll
-                    for (int k = 0; k < 3; k++) t[u][k] = (e + 4 * u < rec.e1) ? A.fent[(size_t)k * A.n_entries + e + 4 * u] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 8; u++) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
-            }
-        }
-        if (wv == 0 && i >= 0 && A.frec) { f[0] += A.frec[i]; f[1] += A.frec[(size_t)A.n + i]; f[2] += A.frec[2 * (size_t)A.n + i]; }
-        red[wv][0][lane] = f[0]; red[wv][1][lane] = f[1]; red[wv][2][lane] = f[2];
-        __syncthreads();
-        if (wv == 0 && i >= 0) {
+            fin_atom_base(A.fpart, A.n_islots, A.npart, A.fent, A.n_entries, A.frec, A.n, isl, i, rec.e0, rec.e1, f);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const double f = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
                 if (isl >= 0 && A.n_alch > 0) {
 #pragma unroll
-                    for (int sl = 0; sl < 3; sl++) if ((A.slot_mask >> sl) & 1) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f + fj[sl][k];
+                    for (int sl = 0; sl < 3; sl++) if ((A.slot_mask >> sl) & 1) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f[k] + fj[sl][k];
                 } else if (isl >= 0) {
 #pragma unroll
-                    for (int sl = 0; sl < 3; sl++) if ((A.slot_mask >> sl) & 1) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f;
-                } else A.ftot[(size_t)k * A.n + i] = f;  // alchemical atom: bonded part; integrator adds alch_self[slot]
+                    for (int sl = 0; sl < 3; sl++) if ((A.slot_mask >> sl) & 1) A.ftot[(size_t)(sl * 3 + k) * A.n + i] = f[k];
+                } else A.ftot[(size_t)k * A.n + i] = f[k];  // alchemical atom: bonded part; integrator adds alch_self[slot]
             }
         }
-        if (wv == 0) {
-            double pm[6];
-            const double m = i >= 0 ? A.mass[i] : 0.0;
+        double pm[6];
+        const double m = i >= 0 ? A.mass[i] : 0.0;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                pm[k] = i >= 0 ? m * A.v[k][i] : 0.0;
-                pm[3 + k] = i >= 0 ? red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane] + ((isl >= 0 && A.n_alch > 0) ? fj[0][k] : 0.0) : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 6; q++) { pm[q] = wave_sum(pm[q]); if (lane == 0) A.mom_part[(size_t)blk * 6 + q] = pm[q]; }
+        for (int k = 0; k < 3; k++) {
+            pm[k] = i >= 0 ? m * A.v[k][i] : 0.0;
+            pm[3 + k] = i >= 0 ? f[k] + ((isl >= 0 && A.n_alch > 0) ? fj[0][k] : 0.0) : 0.0;
         }
+#pragma unroll
+        for (int q = 0; q < 6; q++) { pm[q] = wave_sum(pm[q]); if (lane == 0) A.mom_part[(size_t)blk * 6 + q] = pm[q]; }
         return;
     }
     if (A.n_alch == 0) return;
     blk -= n_itiles + nb_alch_atoms;
     const int cnt = *A.jcount_alch;
     const int nb_env = k2_env_blocks(cnt, A.PA, A.k2_jiter);
-    if (blk < 9) {  // slab q = slot*3 + component: thread = (alchemical atom a, block group g); contiguous PA-wide rows
-        const int q = blk, PA = A.PA, NG = 256 / PA;
-        const int a = tid & (PA - 1), g = tid / PA;
+    if (blk < 9) {  // slab q = slot*3 + component
         __shared__ double s_red[256];
-        double s = 0.0;
-        const bool on = (A.slot_mask >> (q / 3)) & 1;
-        if (on) {
-            for (int b = g; b < nb_env; b += NG) s += A.self_part[((size_t)b * 9 + q) * PA + a];
-            if (g == 0) s += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * PA + a];
-        }
-        s_red[tid] = s;
-        __syncthreads();
-        if (on && tid < A.n_alch) {
-            double t = 0.0;
-            for (int u = 0; u < NG; u++) t += s_red[u * PA + tid];   // fixed order
-            A.alch_self[q * 64 + tid] = t;
-        }
+        const bool on = (A.slot_mask >> (blk / 3)) & 1;
+        const double t = fin_alch_self(A.self_part, A.PA, nb_env, A.k2_nblocks_env, blk, on, A.n_alch, s_red);
+        if (on && tid < A.n_alch) A.alch_self[blk * 64 + tid] = t;
         return;
     }
     __shared__ double s_e[K2_NP];
-    for (int q = wv; q < K2_NP; q += 4) {
-        double s = 0.0;
-        for (int b = lane; b < nb_env; b += 64) s += A.e_part[(size_t)b * K2_NP + q];
-        if (lane == 0) s += A.e_part[(size_t)A.k2_nblocks_env * K2_NP + q];
-        s = wave_sum(s);
-        if (lane == 0) s_e[q] = s;
-    }
-    __syncthreads();
+    fin_energy_sums(A.e_part, nb_env, A.k2_nblocks_env, s_e);
     // (constant indices only: a runtime index into A -- even a select between its fields -- keeps the whole argument
     // struct in scratch memory and turns every A.field access of the kernel into a scratch load)
     if (tid == 0) A.acc->e_slot[0] = A.le[0] * s_e[0] + s_e[1];
@@ -777,7 +769,11 @@ __global__ void __launch_bounds__(256) k_forces_fused(NbArgs<R> a, NbConst<R> c,
 // Same device functions and arithmetic as the interpreter above (bitwise identical results), but with no op
 // dispatch the compiler sees one basic-block chain: every gather is issued at the top and waited for once, which is
 // what this latency-bound kernel needs (the interpreter spent >65 % of its wave cycles in s_waitcnt).
-template <bool CM>
+// FUSED (round 4): the kernel forms the pass's forces itself from the force kernels' slabs -- what k_finalize would have left in
+// ftot / alch_self / acc->e_slot / mom_part, by the same shared functions in the same order -- so a steady-state step has one
+// launch fewer and no round trip of the summed forces through memory.  One block of 256 threads holds every cluster of the chain
+// (host: int_blocks == 1, int_threads == 256), so the total momentum for CMMotionRemover is a block reduction.
+template <bool CM, bool FUSED = false>
 __device__ __forceinline__ void step_default_body(IntArgs& A) {
     const int tid = threadIdx.x;
     const int cl = blockIdx.x * blockDim.x + tid;
@@ -799,19 +795,72 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
     double FA[4][3], FB[4][3], G0[4][3], XB[4][3];
     unsigned XP[4][3];
     const bool pruned = A.pneed != nullptr;   // (uniform)
+    __shared__ double s_fin[FUSED ? 6 : 1][FUSED ? 256 : 1];   // FUSED: reduction scratch of the alchemical slabs (slots 0 and 2: the two kicks of this program)
+    __shared__ double s_aself[FUSED ? 6 : 1][64];    // ... the alchemical atoms' pair force, slots 0 and 2
+    __shared__ double s_esum[FUSED ? K2_NP : 1];     // ... the alchemical kernel's energy sums
+    if (FUSED && A.n_alch > 0) {   // (uniform) what the last 10 blocks of k_finalize do, the same sums in the same order (fin_alch_self, fin_energy_sums),
+        // with every slab's loads in flight together and ONE barrier for all of them
+        const int nb_env = k2_env_blocks(*A.jcount_alch, A.PA, A.k2_jiter);
+        const int PA = A.PA, NG = 256 / PA, aa = tid & (PA - 1), gg = tid / PA;
+        double sv[6];
+#pragma unroll
+        for (int q6 = 0; q6 < 6; q6++) {
+            const int q = q6 < 3 ? q6 : q6 + 3;
+            double sq = 0.0;
+            for (int b = gg; b < nb_env; b += NG) sq += A.self_part[((size_t)b * 9 + q) * PA + aa];
+            if (gg == 0) sq += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * PA + aa];
+            sv[q6] = sq;
+        }
+#pragma unroll
+        for (int q6 = 0; q6 < 6; q6++) s_fin[q6][tid] = sv[q6];
+        fin_energy_sums(A.e_part, nb_env, A.k2_nblocks_env, s_esum);   // (ends with a barrier: s_fin is published too)
+        if (tid < 64) {
+#pragma unroll
+            for (int q6 = 0; q6 < 6; q6++) {
+                double t = 0.0;
+                if (tid < A.n_alch) for (int u = 0; u < NG; u++) t += s_fin[q6][u * PA + tid];   // fixed order
+                s_aself[q6][tid] = t;
+            }
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int i = max(R.atoms[a], 0), al = R.alch[a], alc = max(al, 0);
         C.id[a] = R.atoms[a]; C.al[a] = al; C.w[a] = R.w[a];
+        double fb[3] = {0.0, 0.0, 0.0};
+        if (FUSED && R.atoms[a] >= 0) fin_atom_base(A.fpart, A.n_islots, A.npart, A.fent, A.n_entries, A.frec, A.n, R.islot[a], i, R.e0[a], R.e1[a], fb);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; XB[a][k] = A.xbuild[k][i]; XP[a][k] = pruned ? A.xprune[k][max(R.islot[a], 0)] : 0u;
-            const double fa0 = A.ftot[(size_t)((al >= 0 ? 0 : 0) + k) * A.n + i];
-            const double fb0 = A.ftot[(size_t)((al >= 0 ? 0 : 6) + k) * A.n + i];
-            const double sa = A.alch_self[(0 + k) * 64 + alc], sb = A.alch_self[(6 + k) * 64 + alc];
-            FA[a][k] = fa0 + (al >= 0 ? sa : 0.0);
-            FB[a][k] = fb0 + (al >= 0 ? sb : 0.0);
+            if (FUSED) {
+                const bool env = R.islot[a] >= 0 && A.n_alch > 0 && R.atoms[a] >= 0;
+                const double ja = env ? A.fJ[(size_t)(0 + k) * A.n + R.sorted[a]] : 0.0, jb = env ? A.fJ[(size_t)(6 + k) * A.n + R.sorted[a]] : 0.0;
+                FA[a][k] = fb[k] + (al >= 0 ? s_aself[k][alc] : ja);
+                FB[a][k] = fb[k] + (al >= 0 ? s_aself[3 + k][alc] : jb);
+            } else {
+                const double fa0 = A.ftot[(size_t)((al >= 0 ? 0 : 0) + k) * A.n + i];
+                const double fb0 = A.ftot[(size_t)((al >= 0 ? 0 : 6) + k) * A.n + i];
+                const double sa = A.alch_self[(0 + k) * 64 + alc], sb = A.alch_self[(6 + k) * 64 + alc];
+                FA[a][k] = fa0 + (al >= 0 ? sa : 0.0);
+                FB[a][k] = fb0 + (al >= 0 ? sb : 0.0);
+            }
             G0[a][k] = pre_noise ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : 0.0;
+        }
+    }
+    double e_sl[3] = {0.0, 0.0, 0.0};
+    if (FUSED) {
+        if (A.n_alch > 0) { e_sl[0] = A.fin_le[0] * s_esum[0] + s_esum[1]; e_sl[1] = A.fin_le[1] * s_esum[0] + s_esum[2]; e_sl[2] = A.fin_le[2] * s_esum[0] + s_esum[3]; }
+        else if (blockIdx.x == 0 && tid == 0) { e_sl[0] = A.acc->e_slot[0]; e_sl[1] = A.acc->e_slot[1]; e_sl[2] = A.acc->e_slot[2]; }   // (no alchemical atoms: nobody updates them)
+        if (blockIdx.x == 0 && tid == 0 && A.n_alch > 0) { A.acc->e_slot[0] = e_sl[0]; A.acc->e_slot[1] = e_sl[1]; A.acc->e_slot[2] = e_sl[2]; }
+    }
+    double p_pre[3] = {0.0, 0.0, 0.0};   // FUSED + CM: this thread's share of sum m v + hV sum F(slot 0), before anything is kicked
+    if (FUSED && CM && active) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) if (a < R.na) {
+            const double m = A.mass[max(R.atoms[a], 0)];
+#pragma unroll
+            for (int k = 0; k < 3; k++) p_pre[k] += m * C.v[a][k] + A.hV * FA[a][k];
         }
     }
 #pragma unroll
@@ -826,15 +875,17 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
         rattle(C, A.tol, A);
     }
     if (blockIdx.x == 0 && tid == 0) {
-        const double dE = A.acc->e_slot[1] - A.acc->e_slot[0];
+        const double dE = FUSED ? e_sl[1] - e_sl[0] : A.acc->e_slot[1] - A.acc->e_slot[0];
         A.acc->protocol_work += dE; A.acc->dE_last = dE;
         if (A.work_trace) A.work_trace[A.trace_index] = A.acc->protocol_work;
     }
     if (CM) {
         // total momentum after the finishing kick = sum m v (before this launch) + hV * sum F(slot 0): both sums were left
         // behind per block by k_finalize, so no grid-wide reduction of the kicked velocities is needed here
+        // (FUSED: the one block of the chain holds every atom; the sums are formed here, in thread order)
         double p[3] = {0.0, 0.0, 0.0};
-        for (int q = tid; q < A.n_mom; q += blockDim.x)
+        if (FUSED) { p[0] = p_pre[0]; p[1] = p_pre[1]; p[2] = p_pre[2]; }
+        else for (int q = tid; q < A.n_mom; q += blockDim.x)
             for (int k = 0; k < 3; k++) p[k] += A.mom_part[(size_t)q * 6 + k] + A.hV * A.mom_part[(size_t)q * 6 + 3 + k];
         for (int k = 0; k < 3; k++) { p[k] = wave_sum(p[k]); if ((tid & 63) == 0) s_red[tid >> 6][k] = p[k]; }
         __syncthreads();
@@ -846,7 +897,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
-        const double dE = A.acc->e_slot[2] - A.acc->e_slot[1];
+        const double dE = FUSED ? e_sl[2] - e_sl[1] : A.acc->e_slot[2] - A.acc->e_slot[1];
         A.acc->protocol_work += dE; A.acc->dE_last = dE;
     }
     bool need_rebuild = false, bad = false;
@@ -912,8 +963,8 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
     }
 }
 
-template <bool CM>
-__global__ void __launch_bounds__(256) k_step_default(IntArgs A) { step_default_body<CM>(A); }
+template <bool CM, bool FUSED = false>
+__global__ void __launch_bounds__(256) k_step_default(IntArgs A) { step_default_body<CM, FUSED>(A); }
 
 // ---- straight-line specialisation of one MD-leg step: [CM] L   (OpenMM LangevinIntegrator)
 template <bool CM>

@@ -69,6 +69,8 @@ struct ListArgs {
     // no epsilon, 0.3 ... a few nm from every i-atom of the group) that pads the atoms' lists to whole chunks (nonbonded_atom_body)
     uint4* pimg4; float2* pimg2; int* mlist; int* mcount; int mcap;
     unsigned short* aself;   // [n_islots] every i-atom's own entry in its group's list (NB_ENT form; 0xffff: not there), written with the atoms' lists
+    uint4* pimgb;            // [n_lists][jcap] what the builder of the atoms' lists streams: {x, y, z, sorted atom index | mobile << 31}
+    const int* sx_row;       // [n_islots][SX_ROW] static per i-slot: the atom's sorted index, its excluded partners, count / min / max (build_atom_lists_body)
 };
 
 // LIST_WAVES waves share one tile's scan of all n atoms; each wave keeps LIST_PREFETCH independent loads in flight.
@@ -80,11 +82,9 @@ struct ListArgs {
 #define LIST_THREADS (LIST_WAVES * 64)
 #define ATOM_LIST_WAVES 4                   // waves per block of build_atom_lists_body: a 256-thread block with < 168 registers per
 #define ATOM_LIST_THREADS (ATOM_LIST_WAVES * 64)   // lane fits exactly where a workgroup of the alchemical kernel retires
-#define ATOM_LIST_U 2                       // atoms per wave
+#define ATOM_LIST_U 2                       // atoms per wave (one atom per wave and twice the workgroups: 60 us against 57 at R = 512)
 #define ATOM_LIST_PARTS (64 / (ATOM_LIST_WAVES * ATOM_LIST_U))    // its blocks per i-tile
 #define ATOM_SLOT(part, wv, u) ((part) * (64 / ATOM_LIST_PARTS) + (wv) + ATOM_LIST_WAVES * (u))
-#define ATOM_LIST_MOBW 256                  // words of its mobile-candidate bitmap (list capacity <= 8192)
-#define EXK_MAX 64       // excluded partners of one i-atom that can sit in its tile's list (+ sentinel); per-atom-list mode
 #define LIST_LDS 8192      // j-list entries mirrored in LDS for the exclusion searches (longer lists are searched in HBM)
 // per-atom-list mode (nonbonded_atom_body): layout of the dynamic LDS and of a list entry
 #define NB_LQ_BYTES 51200   // room for 6400 {sigma/2, 2 sqrt(eps)} records at the bottom of the dynamic LDS; the {x,y,z,q} records follow
@@ -271,6 +271,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
                 const typename Img<R>::Atom A = img[js];
                 const bool mob = (A.flags & FLAG_MOBILE) != 0;
                 g4[k] = make_uint4((unsigned)A.x, (unsigned)A.y, (unsigned)A.z, __float_as_uint((float)A.q));
+                a.pimgb[(size_t)t * a.jcap + k] = make_uint4((unsigned)A.x, (unsigned)A.y, (unsigned)A.z, (unsigned)js | (mob ? 0x80000000u : 0u));
                 g2[k] = make_float2(mob ? -(float)A.hs : (float)A.hs, (float)A.se);   // (sign bit = mobile; sigma = 0 gives -0.0f, read with |.| and an integer test)
                 if (mob) { const int q = atomicAdd(&s_mc, 1); if (q < a.mcap) { ml[2 * q] = k; ml[2 * q + 1] = js; } else a.flags->list_overflow = 1; }   // (order is irrelevant: the entries are only refreshed)
             }
@@ -289,6 +290,7 @@ __device__ __forceinline__ void build_lists_body(const ListArgs& a, const NbCons
                 g4[count] = make_uint4(gp[0], gp[1], gp[2], 0u); g2[count] = make_float2(0.0f, 0.0f);
             }
             __syncthreads();
+            NB_STAMP(t == 0 && tid == 0, 9);
             if (tid == 0) a.mcount[t] = min(s_mc, a.mcap);
         }
     }
@@ -352,19 +354,22 @@ __global__ void __launch_bounds__(LIST_THREADS) k_build_lists(ListArgs a, NbCons
 // ---- per-atom Verlet lists (second kernel of a rebuild, per-atom-list mode): one block per PART of an i-tile (ATOM_LIST_PARTS
 // parts; wave wv of part p serves ATOM_LIST_U slots, ATOM_SLOT).  Every wave walks the list of the tile's group once, 64
 // candidates at a time, each lane testing one candidate against the wave's atoms (wave-uniform); hits are compacted in list
-// order (ballot + prefix count), so an atom's list is ascending in the local index and consecutive lanes of the force kernel
-// read neighbouring LDS addresses.  The candidates' positions are STREAMED from the packed image the first kernel of the
-// rebuild wrote (fixed point, 16 B per entry, L2-resident: every wave of the block reads the same 1 KB per step; the next
-// chunk is requested before the current one is tested).  The first version staged them in ~100 KB of LDS: such a workgroup
-// is alone on its CU and, worse, finds no CU at all once the alchemical kernel's small workgroups have filled the chip -- the
-// few workgroups of a rebuild then waited out most of that kernel (round 3 timelines: 215-245 us instead of 107).  Registers
-// bind in the same way: the alchemical kernel holds 3 x 168 of a SIMD's 512, so what follows is built to fit the slot ONE of
-// its workgroups leaves (4 waves, one per SIMD, < 168 registers) instead of needing a CU to drain.
+// order (ballot + prefix count), so an atom's list is ascending in the local index.
+// Round 4: the walk reads ONE 16-byte record per candidate, {x, y, z, sorted atom index | mobile << 31} (pimgb, written by the
+// first kernel of the rebuild beside the force kernel's image), ATOM_LIST_PF chunks ahead; the atom's excluded partners come
+// as a STATIC row of sorted indices per i-slot (sx_row: the atom itself first, then its partners; laid out by the host at every
+// sort) and are matched against the candidates' indices in the chunks whose index range reaches the row's -- no search, no
+// bitmap, no LDS.  (Round 3 found every partner's place in the list by a binary search over global memory before the walk --
+// a dozen DEPENDENT round trips per atom, two atoms one after the other -- after three more round trips for tile_atoms ->
+// image / exclusion row start -> row: 30 of the kernel's 77 us were that prologue, and the walk waited for a load issued one
+// chunk earlier at every step.)  The atom's own place in the list falls out of the walk (the candidate whose index is the
+// atom's): the force kernel reads the atom's data from its image there.
 // A difference of fixed-point coordinates IS the minimum image (the box spans 2^32), so there is no reference point and no wrap.
-// Exclusions: each i-atom's excluded partners are looked up in the list once (binary search) and kept as local indices with
-// the range of chunks they fall into; the running counts live in vector registers (v_bcnt / v_mbcnt) -- a CU has ONE scalar
-// ALU for its 16 waves, and the first version of this loop, which kept them in scalar registers, was bound by it.
+// The running counts live in vector registers (v_bcnt / v_mbcnt) -- a CU has ONE scalar ALU for its 16 waves.
 // The pair kernel tests r < cutoff itself; what must hold here is "within cutoff+skin now" (float, with margin).
+#define ATOM_LIST_PF 8      // chunks of 64 candidates in flight per wave (a load from the image the previous kernel wrote takes ~2,000 cycles, a chunk's tests ~300)
+#define SX_ROW 32           // ints per i-slot in sx_row: [0] the atom's sorted index (-1: empty slot), [1 .. n-1] its excluded partners, [28] n, [29] min, [30] max of the row
+#define SX_MAX 28
 template <typename R>
 __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int force, const int item) {
     using ufix = typename Img<R>::ufix;
@@ -374,122 +379,102 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
     if (!force && a.flags->list_gen == a.flags->req_gen && !(a.batch_req && *a.batch_req)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (t >= a.n_itiles) return;
-    // In a large batch this kernel shares the chip with the alchemical kernel (forked onto a side stream): its few blocks are
-    // the critical path to the nonbonded kernel, so their waves take precedence at the instruction arbiter.
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);   // (a rebuild's few blocks are the critical path to the nonbonded kernel)
     const int l = t / a.S;
-    const int count = a.jcount[l];
-    const int* jl = a.jlist + (size_t)l * a.jcap;
-    const int nch = (count + 63) >> 6;
-    const bool packed = a.pimg4 != nullptr;   // (block-uniform; without the packed image the candidates are gathered through the list)
-    const uint4* g4 = packed ? a.pimg4 + (size_t)l * a.jcap : nullptr;
-    __shared__ unsigned short s_ex[64][EXK_MAX];
-    __shared__ int s_exn[64], s_exlo[64], s_exhi[64];
-    __shared__ unsigned s_mob[ATOM_LIST_MOBW];   // packed image: one bit per list entry, set for mobile candidates (from the group's mobile list)
-    const float cfs[3] = {(float)c.dscale[0], (float)c.dscale[1], (float)c.dscale[2]};
-    const float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f, rl2m = (float)c.rlist2_m * 1.0001f + 1e-5f;
+    const uint4* gb = a.pimgb + (size_t)l * a.jcap;
     NB_STAMP(t == 0 && tid == 0, 5);
-    if (tid < 64) { s_exn[tid] = 0; s_exlo[tid] = 0x7fffffff; s_exhi[tid] = -1; }
-    const int mc = packed ? a.mcount[l] : 0;
-    const bool all_mobile = packed && mc >= count;   // (block-uniform) nothing frozen in this list: no bitmap to gather
-    for (int w = tid; w < ATOM_LIST_MOBW; w += ATOM_LIST_THREADS) s_mob[w] = all_mobile ? 0xffffffffu : 0u;
-    __syncthreads();
-    if (packed && !all_mobile) {
-        const int* ml = a.mlist + (size_t)l * a.mcap * 2;
-        for (int q = tid; q < mc; q += ATOM_LIST_THREADS) { const int k = ml[2 * q]; atomicOr(&s_mob[k >> 5], 1u << (k & 31)); }
-    }
-    NB_STAMP(t == 0 && tid == 0, 6);
-    int ia4[ATOM_LIST_U]; uint32_t xi4[ATOM_LIST_U][3]; bool ok4[ATOM_LIST_U];
+    // ---- first hop: the list's length, the wave's rows; second hop: the atoms' positions
+    const int count = __builtin_amdgcn_readfirstlane(a.jcount[l]);
+    int rowv[ATOM_LIST_U];
+#pragma unroll
+    for (int u = 0; u < ATOM_LIST_U; u++) rowv[u] = lane < SX_ROW ? a.sx_row[(size_t)(t * 64 + ATOM_SLOT(part, wv, u)) * SX_ROW + lane] : -1;
+    const int nch = (count + 63) >> 6;
+    auto fetch = [&](int ch) { return gb[min(ch * 64 + lane, max(count - 1, 0))]; };   // (past the end: the last entry again; masked by k < count)
+    uint4 pf[ATOM_LIST_PF];
+#pragma unroll
+    for (int d = 0; d < ATOM_LIST_PF; d++) pf[d] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int d = 0; d < ATOM_LIST_PF; d++) if (d < nch) pf[d] = fetch(d);
+    int ia4[ATOM_LIST_U], nrow4[ATOM_LIST_U], rmin4[ATOM_LIST_U], rmax4[ATOM_LIST_U]; uint32_t xi4[ATOM_LIST_U][3];
 #pragma unroll
     for (int u = 0; u < ATOM_LIST_U; u++) {
-        const int slot = ATOM_SLOT(part, wv, u);
-        ia4[u] = __builtin_amdgcn_readfirstlane(a.tile_atoms[t * 64 + slot]);
+        ia4[u] = __builtin_amdgcn_readlane(rowv[u], 0); nrow4[u] = __builtin_amdgcn_readlane(rowv[u], 28);
+        rmin4[u] = __builtin_amdgcn_readlane(rowv[u], 29); rmax4[u] = __builtin_amdgcn_readlane(rowv[u], 30);
+    }
+#pragma unroll
+    for (int u = 0; u < ATOM_LIST_U; u++) {
         const int iq = ia4[u] >= 0 ? ia4[u] : 0;
-        xi4[u][0] = __builtin_amdgcn_readfirstlane((uint32_t)img[iq].x); xi4[u][1] = __builtin_amdgcn_readfirstlane((uint32_t)img[iq].y); xi4[u][2] = __builtin_amdgcn_readfirstlane((uint32_t)img[iq].z);
-        ok4[u] = ia4[u] >= 0;   // an empty slot passes nobody
-        const int e0 = ia4[u] >= 0 ? a.ex_start[iq] : 0, e1 = ia4[u] >= 0 ? a.ex_start[iq + 1] : 0;
-        for (int q = lane; q < e1 - e0; q += 64) {
-            const int p = a.ex_idx[e0 + q];
-            int lo = 0, hi = count;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (jl[mid] < p) lo = mid + 1; else hi = mid; }
-            if (p == ia4[u]) a.aself[t * 64 + slot] = (lo < count && jl[lo] == p) ? NB_ENT(lo) : (unsigned short)0xffffu;   // (the exclusion row holds the atom itself: its own place in the list)
-            if (lo < count && jl[lo] == p) {
-                const int at = atomicAdd(&s_exn[slot], 1);
-                if (at < EXK_MAX) { s_ex[slot][at] = (unsigned short)lo; atomicMin(&s_exlo[slot], lo >> 6); atomicMax(&s_exhi[slot], lo >> 6); }
-                else a.flags->list_overflow = 1;   // (more excluded partners in range than any supported topology has)
-            }
-        }
+        xi4[u][0] = (uint32_t)img[iq].x; xi4[u][1] = (uint32_t)img[iq].y; xi4[u][2] = (uint32_t)img[iq].z;   // (same address in every lane: stays in vector registers)
     }
-    __syncthreads();
-    int exn4[ATOM_LIST_U], exlo4[ATOM_LIST_U], exhi4[ATOM_LIST_U];
+#pragma unroll
+    for (int u = 0; u < ATOM_LIST_U; u++) if (lane == 0 && ia4[u] >= 0) a.aself[t * 64 + ATOM_SLOT(part, wv, u)] = (unsigned short)0xffffu;   // (until the walk meets the atom: same wave, program order)
+    NB_STAMP(t == 0 && tid == 0, 6);
+    float cfx = (float)c.dscale[0], cfy = (float)c.dscale[1], cfz = (float)c.dscale[2];
+    float rl2 = (float)c.rlist2 * 1.0001f + 1e-5f, rl2m = (float)c.rlist2_m * 1.0001f + 1e-5f;
+    const bool dual = a.plist != nullptr;
+    float rp2 = c.rp2 * 1.0001f + 1e-5f, rp2m = c.rp2_m * 1.0001f + 1e-5f;   // (same safety margin as the full lists)
+    asm volatile("" : "+v"(cfx), "+v"(cfy), "+v"(cfz), "+v"(rl2), "+v"(rl2m), "+v"(rp2), "+v"(rp2m));   // (vector-register operands: kernels_nb.h, "Round 4")
+    int cntv[ATOM_LIST_U], cntp[ATOM_LIST_U];
+    unsigned short* out4[ATOM_LIST_U]; unsigned short* outp4[ATOM_LIST_U];
 #pragma unroll
     for (int u = 0; u < ATOM_LIST_U; u++) {
-        const int slot = ATOM_SLOT(part, wv, u);
-        exn4[u] = __builtin_amdgcn_readfirstlane(min(s_exn[slot], EXK_MAX)); exlo4[u] = __builtin_amdgcn_readfirstlane(s_exlo[slot]); exhi4[u] = __builtin_amdgcn_readfirstlane(s_exhi[slot]);
+        cntv[u] = cntp[u] = 0;
+        out4[u] = a.alist + ((size_t)t * 64 + ATOM_SLOT(part, wv, u)) * a.acap; outp4[u] = dual ? a.plist + ((size_t)t * 64 + ATOM_SLOT(part, wv, u)) * a.acap : nullptr;
     }
-    NB_STAMP(t == 0 && tid == 0, 7);
-    int cntv[ATOM_LIST_U], cntp[ATOM_LIST_U];
-#pragma unroll
-    for (int u = 0; u < ATOM_LIST_U; u++) cntv[u] = cntp[u] = 0;
-    unsigned short* out4[ATOM_LIST_U]; unsigned short* outp4[ATOM_LIST_U];
-    const bool dual = a.plist != nullptr;
-    const float rp2 = c.rp2 * 1.0001f + 1e-5f, rp2m = c.rp2_m * 1.0001f + 1e-5f;   // (same safety margin as the full lists)
-#pragma unroll
-    for (int u = 0; u < ATOM_LIST_U; u++) { out4[u] = a.alist + ((size_t)t * 64 + ATOM_SLOT(part, wv, u)) * a.acap; outp4[u] = dual ? a.plist + ((size_t)t * 64 + ATOM_SLOT(part, wv, u)) * a.acap : nullptr; }
     const float INF = __builtin_inff();
     const int acap1 = a.acap - 1;
-    auto fetch = [&](int ch, uint32_t& qx, uint32_t& qy, uint32_t& qz, bool& mob) {
-        const int kk = min(ch * 64 + lane, count - 1);
-        if (packed) {
-            const uint4 v = g4[kk];
-            qx = v.x; qy = v.y; qz = v.z; mob = ((s_mob[(ch * 64 + lane) >> 5] >> (lane & 31)) & 1u) != 0;
-        } else {
-            const int js = jl[kk];
-            qx = (uint32_t)img[js].x; qy = (uint32_t)img[js].y; qz = (uint32_t)img[js].z; mob = (img[js].flags & FLAG_MOBILE) != 0;
-        }
-    };
-    uint32_t qx = 0, qy = 0, qz = 0; bool mob = false;
-    if (nch > 0) fetch(0, qx, qy, qz, mob);
-    for (int ch = 0; ch < nch; ch++) {
-        uint32_t nx = 0, ny = 0, nz = 0; bool nmob = false;
-        if (ch + 1 < nch) fetch(ch + 1, nx, ny, nz, nmob);   // (in flight while this chunk is tested)
-        const int k = ch * 64 + lane;
-        const unsigned short ent = NB_ENT(k);   // (the LDS index times 8: nonbonded_atom_body; "mobile" travels as the sign of the image's sigma/2)
-        const float kinf = k < count ? 0.0f : INF;
-        const float lim = mob ? rl2m : rl2, plim = mob ? rp2m : rp2;
+    NB_STAMP(t == 0 && tid == 0, 7);
+    for (int ch0 = 0; ch0 < nch; ch0 += ATOM_LIST_PF) {
 #pragma unroll
-        for (int u = 0; u < ATOM_LIST_U; u++) {
-            bool excluded = false;
-            if (ch >= exlo4[u] && ch <= exhi4[u]) {   // wave-uniform; a handful of chunks per atom
-                const unsigned short* ex = s_ex[ATOM_SLOT(part, wv, u)];
-                for (int e = 0; e < exn4[u]; e++) excluded |= (int)ex[e] == k;   // same address in every lane: broadcast
-            }
-            const float dx = (float)(int32_t)(qx - xi4[u][0]) * cfs[0], dy = (float)(int32_t)(qy - xi4[u][1]) * cfs[1], dz = (float)(int32_t)(qz - xi4[u][2]) * cfs[2];
-            float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + kinf;
-            d2 = excluded ? INF : d2;
-            const bool pass = d2 < lim && ok4[u];
-            const unsigned long long bal = __ballot(pass);
-            const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
-            const int pos = cntv[u] + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
-            // running count on the vector ALU.  gfx950 needs two wait states between a VALU write of an SGPR / VCC (the
-            // compare behind the ballot) and a VALU read of it as an operand; the compiler inserts them for its own
-            // instructions but not around inline assembly (without the s_nop the counts came out stale)
-            int c2;
-            asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c2) : "s"(blo), "s"(bhi), "v"(cntv[u]));
-            cntv[u] = c2;
-            if (pass) out4[u][min(pos, acap1)] = ent;   // on overflow (flagged below) the surplus lands on the last entry
-            if (dual) {   // (block-uniform) the pruned list: the same entries within cutoff + inner margin, same order
-                const bool keep = pass && d2 < plim;
-                const unsigned long long bk = __ballot(keep);
-                const unsigned klo = (unsigned)bk, khi = (unsigned)(bk >> 32);
-                const int ppos = cntp[u] + (int)__builtin_amdgcn_mbcnt_hi(khi, __builtin_amdgcn_mbcnt_lo(klo, 0u));
-                int c3;
-                asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c3) : "s"(klo), "s"(khi), "v"(cntp[u]));
-                cntp[u] = c3;
-                if (keep) outp4[u][min(ppos, acap1)] = ent;
+        for (int d = 0; d < ATOM_LIST_PF; d++) {
+            const int ch = ch0 + d;
+            if (ch >= nch) break;   // wave-uniform
+            const uint4 cur = pf[d];
+            if (ch + ATOM_LIST_PF < nch) pf[d] = fetch(ch + ATOM_LIST_PF);   // (in flight while the next chunks are tested)
+            const int k = ch * 64 + lane;
+            const bool mob = (int)cur.w < 0;
+            const int js = (int)(cur.w & 0x7fffffffu);
+            const unsigned short ent = NB_ENT(k);   // (the LDS index times 8: nonbonded_atom_body; "mobile" travels as the sign of the image's sigma/2)
+            const float kinf = k < count ? 0.0f : INF;
+            const float lim = mob ? rl2m : rl2, plim = mob ? rp2m : rp2;
+            const int jfirst = __builtin_amdgcn_readfirstlane(js), jlast = __builtin_amdgcn_readlane(js, 63);   // (the list is ascending)
+#pragma unroll
+            for (int u = 0; u < ATOM_LIST_U; u++) {
+                bool excluded = false;
+                if (jlast >= rmin4[u] && jfirst <= rmax4[u]) {   // wave-uniform; a handful of chunks per atom
+                    for (int e = 0; e < nrow4[u]; e++) excluded |= js == __builtin_amdgcn_readlane(rowv[u], e);
+                    if (js == ia4[u] && k < count) a.aself[t * 64 + ATOM_SLOT(part, wv, u)] = ent;   // (the atom itself: its own place in the list)
+                }
+                const float dx = (float)(int32_t)(cur.x - xi4[u][0]) * cfx, dy = (float)(int32_t)(cur.y - xi4[u][1]) * cfy, dz = (float)(int32_t)(cur.z - xi4[u][2]) * cfz;
+                float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + kinf;
+                d2 = excluded ? INF : d2;
+                const bool pass = d2 < lim && ia4[u] >= 0;   // (an empty slot passes nobody)
+                const unsigned long long bal = __ballot(pass);
+                const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
+                const int pos = cntv[u] + (int)__builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0u));
+                // running count on the vector ALU.  gfx950 needs two wait states between a VALU write of an SGPR / VCC (the
+                // compare behind the ballot) and a VALU read of it as an operand; the compiler inserts them for its own
+                // instructions but not around inline assembly (without the s_nop the counts came out stale)
+                int c2;
+                asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c2) : "s"(blo), "s"(bhi), "v"(cntv[u]));
+                cntv[u] = c2;
+                if (pass) out4[u][min(pos, acap1)] = ent;   // on overflow (flagged below) the surplus lands on the last entry
+                if (dual) {   // (block-uniform) the pruned list: the same entries within cutoff + inner margin, same order
+#if defined(NB_PRUNE_MOBILE_BY_BUILD_POSITION)
+                    const bool keep = pass && d2 < plim;
+#else
+                    const bool keep = pass && (mob || d2 < plim);   // (mobile candidates of the full list always stay: nonbonded_atom_body)
+#endif
+                    const unsigned long long bk = __ballot(keep);
+                    const unsigned klo = (unsigned)bk, khi = (unsigned)(bk >> 32);
+                    const int ppos = cntp[u] + (int)__builtin_amdgcn_mbcnt_hi(khi, __builtin_amdgcn_mbcnt_lo(klo, 0u));
+                    int c3;
+                    asm("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %3\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(c3) : "s"(klo), "s"(khi), "v"(cntp[u]));
+                    cntp[u] = c3;
+                    if (keep) outp4[u][min(ppos, acap1)] = ent;
+                }
             }
         }
-        qx = nx; qy = ny; qz = nz; mob = nmob;
     }
     NB_STAMP(t == 0 && tid == 0, 8);
 #pragma unroll
@@ -499,11 +484,12 @@ __device__ __forceinline__ void build_atom_lists_body(const ListArgs& a, const N
         if (dual) { const int c0 = min(cntp[u], a.acap), padto = min((c0 + 63) & ~63, a.acap); if (c0 + lane < padto) outp4[u][c0 + lane] = NB_ENT(count); }
         if (lane == 0) {
             if (dual) {   // the pruned list is current as of these positions
-                const int sl = t * 64 + ATOM_SLOT(part, wv, u), iq = ia4[u] >= 0 ? ia4[u] : 0;
+                const int sl = t * 64 + ATOM_SLOT(part, wv, u);
                 a.pcount[sl] = min(cntp[u], a.acap); a.pneed[sl] = 0;
-                a.xprune[0][sl] = (unsigned)img[iq].x; a.xprune[1][sl] = (unsigned)img[iq].y; a.xprune[2][sl] = (unsigned)img[iq].z;
+                a.xprune[0][sl] = xi4[u][0]; a.xprune[1][sl] = xi4[u][1]; a.xprune[2][sl] = xi4[u][2];
             }
             a.acount[t * 64 + ATOM_SLOT(part, wv, u)] = min(cntv[u], a.acap);
+            NB_STAMP(t == 0 && tid == 0, 10);
             if (cntv[u] > a.acap) a.flags->list_overflow = 1;
             else if (cntv[u] > a.acap - a.acap / 8) a.flags->resort_hint = 1;   // (a re-sort re-derives the capacities)
         }
@@ -804,12 +790,17 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
                 // the first NB_ATOM_UA chunks unconditionally (a pruned list is about that long), the others only for a longer list (one
                 // wave-uniform branch; a branch per chunk costs a dozen register copies each).  Loads may run past the count inside
                 // the atom's own row (acap >= 64 NB_ATOM_U, host): chunks past the padded count are never walked
+#if defined(K1X_NOLIST)    // (floor experiment: no list traffic, made-up entries)
+#pragma unroll
+                for (int u = 0; u < NB_ATOM_U; u++) entn[u] = (unsigned)NB_ENT((lane * 7 + u * 64 + s) % max(count, 1));
+#else
 #pragma unroll
                 for (int u = 0; u < NB_ATOM_UA; u++) entn[u] = (unsigned)lst[u * 64 + lane];
                 if (cntn > 64 * NB_ATOM_UA) {
 #pragma unroll
                     for (int u = NB_ATOM_UA; u < NB_ATOM_U; u++) entn[u] = (unsigned)lst[u * 64 + lane];
                 }
+#endif
             }
         }
     };
@@ -946,16 +937,21 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
             }
             if (W) {   // prune: keep what lies within cutoff + inner margin, in list order
                 const bool mob = __builtin_bit_cast(int, q2.x) < 0;
-                bool keep = r2 < k_rp2;   // frozen candidate: within cutoff + inner margin of where this atom is now
+                // a frozen candidate stays if it is within cutoff + inner margin of where this atom is now; a MOBILE candidate of
+                // the full list always stays (NB_KEEP_MOBILE): measuring it from its position at the list build -- the only bound
+                // that holds until this atom's next prune (derive_margins) -- needs that position, a dependent global load per
+                // chunk in the middle of the walk, and an atom that prunes then takes five normal turns; the mobile region is
+                // compact, the rule dropped one mobile candidate in twelve
+#if defined(NB_PRUNE_MOBILE_BY_BUILD_POSITION)
+                bool keep = r2 < k_rp2;
                 if (mob) {
-                    // a MOBILE candidate is measured from where it was when the chain's lists were built (the packed image keeps
-                    // that position): until the next rebuild it stays within `trig` of there, whatever prunes it goes through
-                    // itself, so cutoff + trig + m from this atom's position now is a bound that holds until this atom's next
-                    // prune (derive_margins).  Its current position says nothing about where it may be by then.
                     const u32x4 pb = g4[NB_IDX(e)];
                     const float ex = (float)(int32_t)(ix - pb.x) * c.scale[0], ey = (float)(int32_t)(iy - pb.y) * c.scale[1], ez = (float)(int32_t)(iz - pb.z) * c.scale[2];
                     keep = ex * ex + ey * ey + ez * ez < k_rp2m;
                 }
+#else
+                bool keep = mob || r2 < k_rp2;
+#endif
                 keep = keep && e != ghost;   // (the ghost pads lists: it is never an entry in its own right)
                 const unsigned long long bal = __ballot(keep);
                 if (keep) pout[pcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)e;
@@ -1013,7 +1009,11 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         // per-lane fp32 accumulation carries anyway (tolerance: 10^-5 of the largest force, ~2 10^-2).  Lists past the
         // prefetch window were folded into fp64 per chunk above.
         if (!ENERGY) {
+#if defined(K1X_NOREDUCE)  // (floor experiment: no wave sums)
+            const float sx = bx, sy = by, sz = bz;
+#else
             const float sx = wave_sum_dpp_f32(bx), sy = wave_sum_dpp_f32(by), sz = wave_sum_dpp_f32(bz);
+#endif
             if (cnt > 64 * NB_ATOM_U) { fx = wave_sum_dpp(fx); fy = wave_sum_dpp(fy); fz = wave_sum_dpp(fz); }   // (wave-uniform; otherwise they are zero)
             fx += (double)sx; fy += (double)sy; fz += (double)sz;
             if (lane == 0) { g_fpart[islot] = fx; g_fpart[a.n_islots + islot] = fy; g_fpart[2 * a.n_islots + islot] = fz; }

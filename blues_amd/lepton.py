@@ -59,11 +59,17 @@ def compile_expression(expr):
     return f
 
 
+_TABLES = {}   # (expression, n) -> tuple of values: R chains of one protocol share the table (50 ms of tree walking each otherwise)
+
+
 def tabulate(expr, n_lambda_steps):
     """[f(i / n_lambda_steps) for i in 0..n_lambda_steps]; lambda is formed exactly as the H step
     forms it, (lambda_step+1)/n_lambda_steps (reference blues/integrators.py:222)."""
-    f = compile_expression(expr)
     n = int(n_lambda_steps)
-    if n <= 0:
-        return [f(**{"lambda": 0.0})]
-    return [f(**{"lambda": i / n}) for i in range(n + 1)]
+    key = (str(expr), n)
+    if key not in _TABLES:
+        f = compile_expression(expr)
+        _TABLES[key] = (f(**{"lambda": 0.0}),) if n <= 0 else tuple(f(**{"lambda": i / n}) for i in range(n + 1))
+        if len(_TABLES) > 64:      # (bounded: protocols are few)
+            _TABLES.pop(next(iter(_TABLES)))
+    return list(_TABLES[key])

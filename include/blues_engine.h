@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define BLUES_ABI_VERSION 4
+#define BLUES_ABI_VERSION 5
 
 /* nonbonded_method */
 #define BLUES_NB_NOCUTOFF 0   /* oracle only: vacuum systems (vacDivaline, two-body checks) */
@@ -197,6 +197,8 @@ typedef struct BluesTuning {
                                 * 0: the alchemical kernel keeps its (atom, list entry) lane layout */
     int32_t k2_early;          /* 1: with `fork`, the alchemical kernel of the members of a batch that do not rebuild their lists
                                 * in a force pass starts beside the rebuild of the others; 0 (default): after the group lists */
+    int32_t fuse_finalize;     /* 1 (default): where one workgroup holds every constraint cluster of a chain, the steady-state step kernel
+                                * forms the summed forces of the pass itself (no k_finalize launch); 0: always the separate kernel */
 } BluesTuning;
 void blues_tuning_default(BluesTuning *t);
 /* NULL restores the defaults.  Applies to engines and batches created afterwards. */
@@ -379,6 +381,9 @@ int blues_batch_time_nonbonded(BluesBatch *b, int32_t reps, double *usec_per_lau
  * HIP events on the batch's stream (0 switches it off; either call resets the statistics).  blues_batch_get_kernel_timing drains
  * the pending events: out[0] = mean duration in us, out[1] = launches sampled, out[2] = the longest one.  This is the figure
  * bench.py reports as roofline.usec_per_launch (the reference has no counterpart: OpenMM times nothing per kernel). */
+/* Diagnostic: where the set-up time of this process went so far (seconds): [0] blues_engine_create, [1] laying out tiles and lists
+ * (sort_and_tile), [2] of which image + uploads, [3] device allocations, [4] zero-fills, [5] host-to-device copies, [6] allocations made, [7] stream and event creation. */
+int blues_debug_setup_seconds(double *out8);
 int blues_batch_kernel_timing(BluesBatch *b, int32_t every);
 int blues_batch_get_kernel_timing(BluesBatch *b, double out[3]);
 

@@ -707,6 +707,12 @@ def test_configs3_full_size_water_switch_properties():
         def _random_sphere_point(self, radius, origin):
             d = super()._random_sphere_point(radius, origin) - origin
             return origin + d / np.linalg.norm(d) * radius * 1.5
+
+        def afterMove(self, context):
+            # (a decoupled water flies ~1 nm in the 4 ps that remain: whether it is back inside a 1 nm sphere at the end is a coin the
+            # rounding of the force sums flips; the check this chain exists for is made against a sphere it cannot be in)
+            self.radius = 0.05
+            return super().afterMove(context)
     chains = []
     for r in range(R):
         integ = integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=0.004, temperature=300.0, seed=9000 + r)

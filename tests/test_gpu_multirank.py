@@ -57,7 +57,7 @@ def test_bench_gpus_2_reports_two_ranks():
         pytest.skip("needs two GPUs")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--replicas", "8",
-                        "--nsteps-nc", "20", "--no-cpu", "--no-single"], env=env, capture_output=True, text=True, timeout=1500)
+                        "--nsteps-nc", "200", "--no-cpu", "--no-single"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["accept_records_last"]["chains"] == 16 and np.isfinite(out["value"])
@@ -71,7 +71,7 @@ def test_two_ranks_with_real_engines_on_one_gpu():
         pytest.skip("needs a GPU")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "1", "--warmup", "0",
-                        "--replicas", "8", "--nsteps-nc", "20", "--no-cpu", "--no-single"], env=env, capture_output=True, text=True, timeout=1500)
+                        "--replicas", "8", "--nsteps-nc", "200", "--no-cpu", "--no-single"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["accept_records_last"]["chains"] == 16 and np.isfinite(out["value"])
@@ -81,4 +81,4 @@ def test_two_ranks_with_real_engines_on_one_gpu():
     el = out["rank_elapsed_seconds"]
     assert 0.0 < el["min"] <= el["max"] and el["max"] < 600.0
     # every chain of both ranks stepped the whole (short) protocol in lock step with its batch
-    assert out["engine"]["lockstep_steps_per_switch"] >= 20 and out["engine"]["fallback_steps_per_switch"] == 0
+    assert out["engine"]["lockstep_steps_per_switch"] >= 200 and out["engine"]["fallback_steps_per_switch"] == 0
