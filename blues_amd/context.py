@@ -317,10 +317,26 @@ class Simulation(object):
             ahead = [i - self.currentStep for i in (getattr(r, "frame_indices", None) or []) if i > self.currentStep]
             if ahead and min(ahead) < chunk:
                 chunk = min(ahead)
+        if self.barostat is not None and self.barostat.frequency > 0 and chunk > 0:   # (frequency 0: OpenMM's "barostat disabled")
+            # OpenMM's updateContextState runs at the top of every step: it increments its counter and makes the attempt when the
+            # counter reaches `frequency` -- i.e. BEFORE the frequency-th step, after frequency - 1 completed ones.  The attempt is
+            # made here, by whoever plans the next chunk: Simulation.step for a lone chain, BatchedBLUESSimulation._advance for the
+            # chains of a replica batch (each member has its own box: the batch's records carry it per member)
+            if self._barostat_count + 1 >= self.barostat.frequency:
+                self.barostat.attempt(self.context._engine, self.system)
+                self._barostat_count = -1      # (the step that follows is the first of the next period)
+                left = 1
+            else:
+                left = self.barostat.frequency - 1 - self._barostat_count
+            if left < chunk:
+                chunk = left
+                due = [(r, nxt) for r, nxt in due if nxt[0] == chunk]
         return chunk, due
 
     def _commit_chunk(self, chunk, due):
         self.currentStep += chunk
+        if self.barostat is not None and self.barostat.frequency > 0:
+            self._barostat_count += chunk
         self.context._time += chunk * self.integrator._timestep
         for r, nxt in due:
             if nxt[0] == chunk:
@@ -332,19 +348,6 @@ class Simulation(object):
         """app.Simulation.step (reference blues/simulation.py:1082): advance, honouring reporter intervals."""
         end = self.currentStep + int(steps)
         while self.currentStep < end:
-            chunk, due = self._plan_chunk(end)
-            if self.barostat is not None and self.barostat.frequency > 0:   # (frequency 0: OpenMM's "barostat disabled")
-                # OpenMM's updateContextState runs at the top of every step: it increments its counter and makes the attempt when the
-                # counter reaches `frequency` -- i.e. BEFORE the frequency-th step, after frequency - 1 completed ones
-                if self._barostat_count + 1 >= self.barostat.frequency:
-                    self.barostat.attempt(self.context._engine, self.system)
-                    self._barostat_count = -1      # (the step that follows is the first of the next period)
-                    left = 1
-                else:
-                    left = self.barostat.frequency - 1 - self._barostat_count
-                if left < chunk:
-                    chunk = left
-                    due = [(r, nxt) for r, nxt in due if nxt[0] == chunk]
-                self._barostat_count += chunk
+            chunk, due = self._plan_chunk(end)     # (makes the barostat's attempt when one is due)
             self.integrator.step(chunk)
             self._commit_chunk(chunk, due)

@@ -1236,7 +1236,9 @@ static int launch_finalize(BluesEngine* h, const double le[3], int slot_mask = 7
 // Round 4: the force pass of a step does not launch k_finalize where the step kernel can form the sums itself
 // (kernels_integrate.h: step_default_body<CM, true>): one block holds every cluster of the chain, both kicks of the steady-state
 // program are served by this pass (slots 0 and 2).  What else needs the summed forces resolves the pending sums first.
-static bool fin_fusable(const BluesEngine* h) { return h->fast_step && h->int_blocks == 1 && h->int_threads == 256 && h->tune.fuse_finalize != 0 && !h->ctrl_arg; }
+// (npart == 1: the per-atom-list kernel's single slab; a lone chain's tile kernel leaves dozens of partial slabs, and four atoms per
+// thread summing them one after the other took longer than k_finalize's thread per atom: 77 against 52 us per step)
+static bool fin_fusable(const BluesEngine* h) { return h->fast_step && h->int_blocks == 1 && h->int_threads == 256 && h->npart == 1 && h->tune.fuse_finalize != 0 && !h->ctrl_arg; }
 static int launch_finalize_deferred(BluesEngine* h, const double le[3], int slot_mask) {
     if (!fin_fusable(h) || (slot_mask & 5) != 5) { h->fin_pending = false; return launch_finalize(h, le, slot_mask); }
     h->fin_pending = true; h->fin_mask = slot_mask;
@@ -1553,13 +1555,13 @@ static int force_pass(BluesEngine* h, int base_L) {
         rc = h->precision == 0 ? launch_forces_fused<float>(h, ls, le) : launch_forces_fused<double>(h, ls, le);
         if (rc) return 1;
         if (launch_pme(h, 0)) return 1;
-        if (launch_finalize(h, le, fmask)) return 1;
+        if (launch_finalize_deferred(h, le, fmask)) return 1;
     } else if (h->k1_mode == 1 && h->precision == 0 && h->fuse_big) {
         if (launch_forces_fused_sub(h, ls, le)) return 1;
         if (launch_pme(h, 0)) return 1;
         if (launch_finalize(h, le, fmask)) return 1;
     } else {
-        if (!fork && launch_alchemical(h, ls, le, fmask)) return 1;
+        if (!fork && launch_alchemical(h, ls, le, fmask)) return 1;   // (the alchemical x alchemical block stays a launch of its own: in the bonded entries' grid it took 49 us against 18 + 13)
         rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (rc) return 1;
         if (launch_pme(h, 0)) return 1;
@@ -2082,7 +2084,7 @@ static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const ch
     BC(n_itiles) BC(n_tiles) BC(jcap) BC(n_islots) BC(pool_cap) BC(PA) BC(k2_nblocks_env) BC(k2_jiter) BC(seg_len) BC(waves_tile) BC(wpb) BC(npart)
     BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k1_iw) BC(k1_mode) BC(acap) BC(S) BC(n_lists) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
     BC(cutoff) BC(alpha) BC(sc_alpha) BC(annih_elec) BC(annih_ster) BC(nb_method) BC(pme) BC(pme_K[0]) BC(pme_K[1]) BC(pme_K[2]) BC(pme_order) BC(restr_k) BC(total_mass)
-    BC(box[0]) BC(box[1]) BC(box[2])
+    // (not the box: a MonteCarloBarostat leaves every member in its own; margins, fixed-point scales and PME tables are per member in the records)
 #undef BC
     if (a->clusters.size() != b->clusters.size()) { *why = "constraint clusters"; return false; }
     if (a->mobile != b->mobile) { *why = "mobile atoms"; return false; }

@@ -243,9 +243,15 @@ struct FinRec { int atom, sorted, e0, e1; };  // caller index (-1: empty), image
 __device__ __forceinline__ void fin_atom_base(const double* __restrict__ fpart, int n_islots, int npart, const double* __restrict__ fent, int n_entries,
                                               const double* __restrict__ frec, int n, int isl, int i, int e0, int e1, double f[3]) {
     f[0] = f[1] = f[2] = 0.0;
-    if (isl >= 0) for (int p = 0; p < npart; p++)
+    if (isl >= 0) for (int p = 0; p < npart; p += 8) {   // (a lone chain's tile kernel leaves dozens of partial slabs: 8 x 3 loads in flight, added in slab order)
+        double t[8][3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) f[k] += fpart[((size_t)p * 3 + k) * n_islots + isl];
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) t[u][k] = p + u < npart ? fpart[((size_t)(p + u) * 3 + k) * n_islots + isl] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (p + u < npart) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
+    }
     for (int e = e0; e < e1; e += 8) {   // 8 entries x 3 components requested together, added in entry order (a loop of dependent load -> add took one round trip per entry)
         double t[8][3];
 #pragma unroll
@@ -798,6 +804,30 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
     __shared__ double s_fin[FUSED ? 6 : 1][FUSED ? 256 : 1];   // FUSED: reduction scratch of the alchemical slabs (slots 0 and 2: the two kicks of this program)
     __shared__ double s_aself[FUSED ? 6 : 1][64];    // ... the alchemical atoms' pair force, slots 0 and 2
     __shared__ double s_esum[FUSED ? K2_NP : 1];     // ... the alchemical kernel's energy sums
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int i = max(R.atoms[a], 0), al = R.alch[a], alc = max(al, 0);
+        C.id[a] = R.atoms[a]; C.al[a] = al; C.w[a] = R.w[a];
+        double fb[3] = {0.0, 0.0, 0.0};
+        if (FUSED && R.atoms[a] >= 0) fin_atom_base(A.fpart, A.n_islots, A.npart, A.fent, A.n_entries, A.frec, A.n, R.islot[a], i, R.e0[a], R.e1[a], fb);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; XB[a][k] = A.xbuild[k][i]; XP[a][k] = pruned ? A.xprune[k][max(R.islot[a], 0)] : 0u;
+            if (FUSED) {
+                const bool env = R.islot[a] >= 0 && A.n_alch > 0 && R.atoms[a] >= 0;
+                const double ja = env ? A.fJ[(size_t)(0 + k) * A.n + R.sorted[a]] : 0.0, jb = env ? A.fJ[(size_t)(6 + k) * A.n + R.sorted[a]] : 0.0;
+                FA[a][k] = fb[k] + ja; FB[a][k] = fb[k] + jb;   // (an alchemical atom: its pair force is added below, once the block has summed it)
+            } else {
+                const double fa0 = A.ftot[(size_t)((al >= 0 ? 0 : 0) + k) * A.n + i];
+                const double fb0 = A.ftot[(size_t)((al >= 0 ? 0 : 6) + k) * A.n + i];
+                const double sa = A.alch_self[(0 + k) * 64 + alc], sb = A.alch_self[(6 + k) * 64 + alc];
+                FA[a][k] = fa0 + (al >= 0 ? sa : 0.0);
+                FB[a][k] = fb0 + (al >= 0 ? sb : 0.0);
+            }
+            G0[a][k] = pre_noise ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : 0.0;
+        }
+    }
+    // (placed behind the gathers above: their loads are in flight while the block sums the alchemical slabs)
     if (FUSED && A.n_alch > 0) {   // (uniform) what the last 10 blocks of k_finalize do, the same sums in the same order (fin_alch_self, fin_energy_sums),
         // with every slab's loads in flight together and ONE barrier for all of them
         const int nb_env = k2_env_blocks(*A.jcount_alch, A.PA, A.k2_jiter);
@@ -824,28 +854,11 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
         }
         __syncthreads();
     }
+    if (FUSED && A.n_alch > 0) {
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const int i = max(R.atoms[a], 0), al = R.alch[a], alc = max(al, 0);
-        C.id[a] = R.atoms[a]; C.al[a] = al; C.w[a] = R.w[a];
-        double fb[3] = {0.0, 0.0, 0.0};
-        if (FUSED && R.atoms[a] >= 0) fin_atom_base(A.fpart, A.n_islots, A.npart, A.fent, A.n_entries, A.frec, A.n, R.islot[a], i, R.e0[a], R.e1[a], fb);
+        for (int a = 0; a < 4; a++) if (R.alch[a] >= 0) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; XB[a][k] = A.xbuild[k][i]; XP[a][k] = pruned ? A.xprune[k][max(R.islot[a], 0)] : 0u;
-            if (FUSED) {
-                const bool env = R.islot[a] >= 0 && A.n_alch > 0 && R.atoms[a] >= 0;
-                const double ja = env ? A.fJ[(size_t)(0 + k) * A.n + R.sorted[a]] : 0.0, jb = env ? A.fJ[(size_t)(6 + k) * A.n + R.sorted[a]] : 0.0;
-                FA[a][k] = fb[k] + (al >= 0 ? s_aself[k][alc] : ja);
-                FB[a][k] = fb[k] + (al >= 0 ? s_aself[3 + k][alc] : jb);
-            } else {
-                const double fa0 = A.ftot[(size_t)((al >= 0 ? 0 : 0) + k) * A.n + i];
-                const double fb0 = A.ftot[(size_t)((al >= 0 ? 0 : 6) + k) * A.n + i];
-                const double sa = A.alch_self[(0 + k) * 64 + alc], sb = A.alch_self[(6 + k) * 64 + alc];
-                FA[a][k] = fa0 + (al >= 0 ? sa : 0.0);
-                FB[a][k] = fb0 + (al >= 0 ? sb : 0.0);
-            }
-            G0[a][k] = pre_noise ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : 0.0;
+            for (int k = 0; k < 3; k++) { FA[a][k] += s_aself[k][R.alch[a]]; FB[a][k] += s_aself[3 + k][R.alch[a]]; }
         }
     }
     double e_sl[3] = {0.0, 0.0, 0.0};

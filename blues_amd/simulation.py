@@ -298,9 +298,8 @@ class BatchedBLUESSimulation(object):
                     c._rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1))
         self._ncmc_batch = NativeBatch([c._ncmc_sim.context._engine for c in self.chains])
         self._md_batch = None
-        if any(getattr(c._md_sim, "barostat", None) is not None for c in self.chains if c._md_sim is not None):
-            # every chain would end up in its own box, and the members of a replica batch share launches shaped by ONE box
-            raise NotImplementedError("MonteCarloBarostat on the MD leg is supported for chains driven one at a time (BLUESSimulation), not in a replica batch")
+        # (a MonteCarloBarostat on the MD leg -- reference blues/simulation.py:603-626 -- leaves every chain in its own box: the batch's
+        # argument records carry the box per member, and the attempts are made member by member where the chunks are planned)
         if all(c._md_sim is not None for c in self.chains):
             self._md_batch = NativeBatch([c._md_sim.context._engine for c in self.chains])
         elif any(c._md_sim is not None for c in self.chains):

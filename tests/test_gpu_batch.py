@@ -505,6 +505,47 @@ def test_batched_full_iterations_with_md_leg(Engine, tol_box, same_decomposition
     B.close()
 
 
+def test_batched_md_leg_with_barostat_equals_per_chain(Engine, tol_box, tune):
+    """MonteCarloBarostat on the MD leg INSIDE a replica batch (reference blues/simulation.py:603-626: the tutorial's flagship iteration is
+    NPT): every chain makes its own volume moves (own random stream, own step size), so the members of the batch end up in
+    different boxes -- the batch's argument records carry box, margins and fixed-point scales per member -- and each equals the
+    same chain stepped on its own, bit for bit."""
+    from blues_amd.context import Simulation
+    from blues_amd.engine import NativeBatch
+    s, v = tol_box
+    md_sys = systems.add_barostat(copy.copy(s), 300.0, pressure_bar=1.0, frequency=5)
+    md_sys.alchemical_atoms = np.zeros(0, np.int32)
+    R, nmd = 8, 42
+    tune(assume_batch=R)
+
+    def sims():
+        out = []
+        for r in range(R):
+            sim = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=400 + r), precision="double", replica=r)
+            sim.context.setVelocities(unit.Quantity(v * (1.0 + 0.02 * r), "nanometer/picosecond"))
+            assert sim.barostat is not None
+            out.append(sim)
+        return out
+    alone = sims()
+    for sim in alone:
+        sim.step(nmd)
+    together = sims()
+    batch = NativeBatch([sim.context._engine for sim in together])
+    errors = simulation.BatchedBLUESSimulation._advance(batch, together, {r: nmd for r in range(R)})
+    assert not errors, errors
+    boxes = []
+    for a, b in zip(alone, together):
+        assert b.currentStep == nmd and b.barostat.total_attempted == a.barostat.total_attempted == nmd // 5
+        assert b.barostat.total_accepted == a.barostat.total_accepted
+        assert np.array_equal(a.context._engine.get_box(), b.context._engine.get_box())
+        assert np.array_equal(a.context._engine.get_positions(), b.context._engine.get_positions())
+        assert np.array_equal(a.context._engine.get_velocities(), b.context._engine.get_velocities())
+        boxes.append(np.asarray(b.context._engine.get_box())[0, 0])
+    assert sum(sim.barostat.total_accepted for sim in together) > 0 and len(set(boxes)) > 1     # volume moves were accepted: the members' boxes differ
+    assert batch.stats()["lockstep_steps"] >= nmd - 2 * (nmd // 5) - 2, batch.stats()            # ... and they still share their launches
+    batch.close()
+
+
 def test_move_style_edits_of_a_device_resident_state(Engine, tol_box):
     """What a Move does (reference blues/moves.py:292-307): read positions[indices], assign positions[i] = xyz, hand the
     Quantity to setPositions.  On this engine only the touched atoms travel; the result equals the plain host route, also
