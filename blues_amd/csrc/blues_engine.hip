@@ -924,11 +924,11 @@ static int flush_program(BluesEngine* h) {
     if (h->fin_pending && !fused) { if (resolve_finalize(h)) return 1; }   // ... or by k_finalize first (any other program)
     h->fin_pending = false;
     if (is_cm) {
-        if (fused) { if (lead) hipLaunchKernelGGL((k_step_default_b<true, true>), grid, block, 0, h->cur, reps, D); else if (!dry) hipLaunchKernelGGL((k_step_default<true, true>), grid, block, 0, h->cur, A); }
+        if (fused) { if (lead) { if (h->batch->R() >= 64) hipLaunchKernelGGL((k_step_default_late_b<true>), grid, block, 0, h->cur, reps, D); else hipLaunchKernelGGL((k_step_default_b<true, true>), grid, block, 0, h->cur, reps, D); } else if (!dry) hipLaunchKernelGGL((k_step_default<true, true>), grid, block, 0, h->cur, A); }
         else if (lead) hipLaunchKernelGGL(k_step_default_b<true>, grid, block, 0, h->cur, reps, D);
         else if (!dry) hipLaunchKernelGGL(k_step_default<true>, grid, block, 0, h->cur, A);
     } else if (is_nc) {
-        if (fused) { if (lead) hipLaunchKernelGGL((k_step_default_b<false, true>), grid, block, 0, h->cur, reps, D); else if (!dry) hipLaunchKernelGGL((k_step_default<false, true>), grid, block, 0, h->cur, A); }
+        if (fused) { if (lead) { if (h->batch->R() >= 64) hipLaunchKernelGGL((k_step_default_late_b<false>), grid, block, 0, h->cur, reps, D); else hipLaunchKernelGGL((k_step_default_b<false, true>), grid, block, 0, h->cur, reps, D); } else if (!dry) hipLaunchKernelGGL((k_step_default<false, true>), grid, block, 0, h->cur, A); }
         else if (lead) hipLaunchKernelGGL(k_step_default_b<false>, grid, block, 0, h->cur, reps, D);
         else if (!dry) hipLaunchKernelGGL(k_step_default<false>, grid, block, 0, h->cur, A);
     } else if (h->fast_step && h->prog.n == 2 && !memcmp(h->prog.ops, P_MD_CM, 2)) {

@@ -525,11 +525,33 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
                     njsig = jr->sig; njeps = jr->eps; njq = jr->q;
                 }
             };
-            request(wv);
-            for (int item = wv; item < nitems; item += K2D_WAVES) {
+            // a wave takes a CONTIGUOUS range of items: nearly all of them belong to one or two alchemical atoms, whose force is summed
+            // per lane across the items and over the wave once per atom (round 3 reduced nine values over the wave after EVERY item:
+            // a quarter of the loop's instructions).  The sums land in fixed-point accumulators: any order gives the same bits.
+            const int per_wave = (nitems + K2D_WAVES - 1) / K2D_WAVES, item_lo = wv * per_wave, item_hi = min(nitems, item_lo + per_wave);
+            float facc[3][3];
+#pragma unroll
+            for (int s = 0; s < 3; s++) { facc[s][0] = facc[s][1] = facc[s][2] = 0.0f; }
+            int acc_a = -1;
+            auto flush = [&]() {
+                if (acc_a < 0) return;
+#pragma unroll
+                for (int s = 0; s < 3; s++) {
+                    if (!slot_on(s)) continue;
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; c3++) {
+                        const float v = wave_sum_dpp_f32(facc[s][c3]);
+                        if (lane == 0) atomicAdd(&S.fa[s * 3 + c3][acc_a], (unsigned long long)__double2ll_rn((double)v * K2D_FIX));
+                        facc[s][c3] = 0.0f;
+                    }
+                }
+            };
+            request(item_lo);
+            for (int item = item_lo; item < item_hi; item++) {
                 const double jsig = njsig, jeps = njeps, jq = njq; const int k = nk, al = nal; const bool valid = nvalid;
-                request(item + K2D_WAVES);
+                request(item + 1 < item_hi ? item + 1 : nitems);
                 const int a = a0 + al;   // (uniform: an item lies inside one segment)
+                if (a != acc_a) { flush(); acc_a = a; }
                 double d[3];
 #pragma unroll
                 for (int c3 = 0; c3 < 3; c3++) d[c3] = min_image_d(S.xa[c3][a] - S.x[c3][k], A.box.L[c3], A.box.invL[c3]);
@@ -553,15 +575,12 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
                         f[s][0] = ft * (float)d[0]; f[s][1] = ft * (float)d[1]; f[s][2] = ft * (float)d[2];
                     }
                 }
-                // force on the item's alchemical atom: one wave sum per component
+                // force on the item's alchemical atom: into the lane's running sums (flushed when the atom changes)
 #pragma unroll
                 for (int s = 0; s < 3; s++) {
                     if (!slot_on(s)) continue;
 #pragma unroll
-                    for (int c3 = 0; c3 < 3; c3++) {
-                        const float v = wave_sum_dpp_f32(f[s][c3]);
-                        if (lane == 0) atomicAdd(&S.fa[s * 3 + c3][a], (unsigned long long)__double2ll_rn((double)v * K2D_FIX));
-                    }
+                    for (int c3 = 0; c3 < 3; c3++) facc[s][c3] += f[s][c3];
                 }
                 // force on a mobile environment atom: minus the pair force
                 const unsigned ms = hit ? (unsigned)S.mslot[k] : 0xffffu;
@@ -574,6 +593,7 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
                     }
                 }
             }
+            flush();
         }
         __syncthreads();
         // ---- the round's mobile entries: force by sorted index (every one of them is written: zero if it had no pair)

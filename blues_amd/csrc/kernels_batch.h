@@ -247,6 +247,13 @@ __global__ void __launch_bounds__(256) k_step_default_b(const RepCore* __restric
     IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d, reps[blockIdx.y].draw_delta);
     step_default_body<CM, FUSED>(A);
 }
+// two waves per SIMD (<= 256 registers): the late-load form of the body (kernels_integrate.h); same arithmetic, same bits
+template <bool CM>
+__global__ void __launch_bounds__(256, 2) k_step_default_late_b(const RepCore* __restrict__ reps, IntDyn d) {
+    if (!reps[blockIdx.y].active) return;
+    IntArgs A = reps[blockIdx.y].in; apply_dyn(A, d, reps[blockIdx.y].draw_delta);
+    step_default_body<CM, true, true>(A);
+}
 
 template <bool CM>
 __global__ void __launch_bounds__(256) k_step_md_b(const RepCore* __restrict__ reps, IntDyn d) {

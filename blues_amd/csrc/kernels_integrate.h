@@ -779,7 +779,10 @@ __global__ void __launch_bounds__(256) k_forces_fused(NbArgs<R> a, NbConst<R> c,
 // ftot / alch_self / acc->e_slot / mom_part, by the same shared functions in the same order -- so a steady-state step has one
 // launch fewer and no round trip of the summed forces through memory.  One block of 256 threads holds every cluster of the chain
 // (host: int_blocks == 1, int_threads == 256), so the total momentum for CMMotionRemover is a block reduction.
-template <bool CM, bool FUSED = false>
+// LATE (with FUSED in a batch): the noise of the O substep and the reference positions of the list checks are loaded where they are
+// used instead of at the top -- 60 registers less across the constraint solves, which lets two waves share a SIMD (256 registers:
+// kernels_batch.h) where the kernel otherwise runs one wave per SIMD in two rounds.
+template <bool CM, bool FUSED = false, bool LATE = false>
 __device__ __forceinline__ void step_default_body(IntArgs& A) {
     const int tid = threadIdx.x;
     const int cl = blockIdx.x * blockDim.x + tid;
@@ -812,7 +815,8 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
         if (FUSED && R.atoms[a] >= 0) fin_atom_base(A.fpart, A.n_islots, A.npart, A.fent, A.n_entries, A.frec, A.n, R.islot[a], i, R.e0[a], R.e1[a], fb);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i]; XB[a][k] = A.xbuild[k][i]; XP[a][k] = pruned ? A.xprune[k][max(R.islot[a], 0)] : 0u;
+            C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i];
+            if (!LATE) { XB[a][k] = A.xbuild[k][i]; XP[a][k] = pruned ? A.xprune[k][max(R.islot[a], 0)] : 0u; }
             if (FUSED) {
                 const bool env = R.islot[a] >= 0 && A.n_alch > 0 && R.atoms[a] >= 0;
                 const double ja = env ? A.fJ[(size_t)(0 + k) * A.n + R.sorted[a]] : 0.0, jb = env ? A.fJ[(size_t)(6 + k) * A.n + R.sorted[a]] : 0.0;
@@ -824,7 +828,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
                 FA[a][k] = fa0 + (al >= 0 ? sa : 0.0);
                 FB[a][k] = fb0 + (al >= 0 ? sb : 0.0);
             }
-            G0[a][k] = pre_noise ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : 0.0;
+            if (!LATE) G0[a][k] = pre_noise ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : 0.0;
         }
     }
     // (placed behind the gathers above: their loads are in flight while the block sums the alchemical slabs)
@@ -937,7 +941,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
 #pragma unroll
                 for (int a = 0; a < 4; a++) if (a < C.na) {
                     double g[3];
-                    if (pre_noise) { for (int k = 0; k < 3; k++) g[k] = G0[a][k]; }
+                    if (pre_noise) { for (int k = 0; k < 3; k++) g[k] = LATE ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : G0[a][k]; }
                     else gaussians3(A.seed, A.stream, A.draw_base, (unsigned)C.id[a], g);
                     const double s = sqrt(A.kT * C.w[a]);
 #pragma unroll
@@ -955,7 +959,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
             for (int k = 0; k < 3; k++) {
                 A.v[k][i] = C.v[a][k]; A.x[k][i] = C.x[a][k];
                 bad |= !(C.x[a][k] == C.x[a][k]) || !(C.v[a][k] == C.v[a][k]);
-                const double d = C.x[a][k] - XB[a][k]; d2 += d * d;
+                const double d = C.x[a][k] - (LATE ? A.xbuild[k][i] : XB[a][k]); d2 += d * d;
             }
             need_rebuild |= d2 > A.half_skin2;
             const int s = R.sorted[a];
@@ -964,7 +968,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
                 if (pruned && R.islot[a] >= 0) {
                     float p2 = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { const float e = (float)(int)(u[k] - XP[a][k]) * A.fscale[k]; p2 += e * e; }
+                    for (int k = 0; k < 3; k++) { const float e = (float)(int)(u[k] - (LATE ? A.xprune[k][R.islot[a]] : XP[a][k])) * A.fscale[k]; p2 += e * e; }
                     if (p2 > A.prune_trig2) A.pneed[R.islot[a]] = 1;
                 }
             }
