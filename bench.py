@@ -339,6 +339,7 @@ def main():
         system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R, reciprocal=args.reciprocal)
     x0 = system.positions.copy()
     v0 = vel.copy()
+    setup_parts = {"chains": time.perf_counter() - t_setup}
 
     # ---- configs[1] to the letter: ONE chain on the GPU, a lone engine with a lone engine's layout (its own construction, default tuning)
     single = None
@@ -367,11 +368,14 @@ def main():
     G = max(1, min(args.groups, R))
     bounds = [(g * R) // G for g in range(G + 1)]
     groups = [chains[bounds[g]:bounds[g + 1]] for g in range(G)]
+    t_part = time.perf_counter()
     drivers = [simulation.BatchedBLUESSimulation(grp, workers=args.workers) for grp in groups]
+    setup_parts["batches"] = time.perf_counter() - t_part; t_part = time.perf_counter()
     if G > 1:   # chains driven from different threads draw from their own streams (reproducible whatever the interleaving)
         for c in chains:
             c._rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1))
     gstates = [md_states(grp, x0, v0, batch=drv._ncmc_batch) for grp, drv in zip(groups, drivers)]
+    setup_parts["hand_over_states"] = time.perf_counter() - t_part
     t_setup = time.perf_counter() - t_setup - t_single
     clocks = [{"sync": 0.0, "switch": 0.0, "decide": 0.0} for _ in range(G)]
 
@@ -508,7 +512,7 @@ def main():
             "rank_elapsed_seconds": rank_elapsed,
             "process_group": {"backend": (args.backend if world > 1 else None), "same_device": bool(args.same_device),
                               "replica_seeds_first_chain_of_each_rank": [int(replica_seed(1234, r * R)) for r in range(world)]},
-            "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup,
+            "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup, "setup_seconds_by_part": setup_parts,
                        "plugin_boundary": "one call per operation for all chains (blues_batch_*)" if drivers[0]._batchable() else "chain by chain",
                        "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,
                        "list_rebuilds_per_switch": (st1["list_generation"] - st0["list_generation"]) / args.steps,

@@ -17,6 +17,13 @@ class PeriodicWrapper(object):
     atoms a Move reads (positions[atom_indices]) are wrapped without fetching the rest."""
 
     def __init__(self, system):
+        # the molecule table depends on the bond / constraint graph alone: R contexts built from one System object share it
+        # (26 ms of union-find per context otherwise -- a third of a rank's set-up time at 512 chains)
+        cached = getattr(system, "_periodic_molecules", None)
+        if cached is not None and cached[0] == system.n_atoms:
+            _, self.molecule_of, self._order, self._start = cached
+            self.box = np.asarray(system.box, dtype=np.float64).reshape(-1)[:3].copy() if np.size(system.box) == 3 else np.diag(np.asarray(system.box, dtype=np.float64).reshape(3, 3)).copy()
+            return
         n = system.n_atoms
         parent = list(range(n))
 
@@ -35,6 +42,10 @@ class PeriodicWrapper(object):
         order = np.argsort(self.molecule_of, kind="stable")
         self._order = order
         self._start = np.searchsorted(self.molecule_of[order], np.arange(self.molecule_of.max() + 2))
+        try:
+            system._periodic_molecules = (n, self.molecule_of, self._order, self._start)
+        except Exception:
+            pass   # (a System that takes no attributes: every context computes its own)
         self.box = np.asarray(system.box, dtype=np.float64).reshape(-1)[:3].copy() if np.size(system.box) == 3 else np.diag(np.asarray(system.box, dtype=np.float64).reshape(3, 3)).copy()
 
     def atoms_of(self, molecule):
