@@ -9,7 +9,8 @@ the volume and is retuned every 10 attempts to keep the acceptance between 25 % 
 
 Host-proposed, device-evaluated: the two potential energies come from the engine (blues_get_energy after blues_set_box /
 blues_set_positions re-tile the system for the new box); everything else is a handful of host operations every 25 steps.
-Lone engines only: the members of a replica batch must share one box (include/blues_engine.h, "Replica batches").
+Lone chains and the members of a replica batch alike (round 4): the attempt is made where the next chunk of steps is planned
+(context.Simulation._plan_chunk), every member of a batch keeps its own box in the batch's argument records.
 """
 import numpy as np
 

@@ -1561,7 +1561,10 @@ static int force_pass(BluesEngine* h, int base_L) {
         if (launch_pme(h, 0)) return 1;
         if (launch_finalize(h, le, fmask)) return 1;
     } else {
-        if (!fork && launch_alchemical(h, ls, le, fmask)) return 1;   // (the alchemical x alchemical block stays a launch of its own: in the bonded entries' grid it took 49 us against 18 + 13)
+        // (the alchemical x alchemical block stays a launch of its own on the main stream: in the bonded entries' grid it took 49 us against
+        // 18 + 13; on a side stream beside the list rebuild, with the bonded entries, the step stayed at 419 us -- the two small kernels
+        // overlapped, the group-list builder they ran beside went from 47 to 62 us)
+        if (!fork && launch_alchemical(h, ls, le, fmask)) return 1;
         rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (rc) return 1;
         if (launch_pme(h, 0)) return 1;

@@ -241,8 +241,8 @@ struct FinRec { int atom, sorted, e0, e1; };  // caller index (-1: empty), image
 // (step_default_body<CM, true>): ONE order of summation, so that a chain gets the same bits whichever kernel does it.
 // lambda-independent force on an atom: nonbonded slabs (i-slot isl, or -1), then its bonded entries in order, then reciprocal space
 __device__ __forceinline__ void fin_atom_base(const double* __restrict__ fpart, int n_islots, int npart, const double* __restrict__ fent, int n_entries,
-                                              const double* __restrict__ frec, int n, int isl, int i, int e0, int e1, double f[3]) {
-    f[0] = f[1] = f[2] = 0.0;
+                                              const double* __restrict__ frec, int n, int isl, int i, int e0, int e1, double f[3], const double* start = nullptr) {
+    f[0] = start ? start[0] : 0.0; f[1] = start ? start[1] : 0.0; f[2] = start ? start[2] : 0.0;   // (start: slab sums formed elsewhere, k_finalize with npart > 1)
     if (isl >= 0) for (int p = 0; p < npart; p += 8) {   // (a lone chain's tile kernel leaves dozens of partial slabs: 8 x 3 loads in flight, added in slab order)
         double t[8][3];
 #pragma unroll
@@ -330,10 +330,31 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
     const int nb_alch_atoms = A.n_alch > 0 ? 1 : 0;
     int blk = blockIdx.x;
     if (blk < n_itiles + nb_alch_atoms) {
-        if (wv != 0) return;   // one thread per atom: the order of fin_atom_base (the step kernel forms the same sums the same way)
         const int isl = blk < n_itiles ? blk * 64 + lane : -1;
         const FinRec rec = A.recs[blk < n_itiles ? isl : A.n_islots + lane];
         const int i = rec.atom;
+        // A lone chain's tile kernel leaves npart > 1 partial slabs: their sum is split over the block's four waves (8 loads in flight
+        // each) and combined in LDS in a fixed order, then handed to fin_atom_base as its starting value.  With ONE slab -- the only case
+        // in which the step kernel forms these sums itself -- wave 0 does everything, in fin_atom_base's order: the same bits either way.
+        double pre[3] = {0.0, 0.0, 0.0};
+        if (A.npart > 1) {   // (uniform)
+            __shared__ double red[4][3][64];
+            double t3[3] = {0.0, 0.0, 0.0};
+            if (i >= 0 && isl >= 0) for (int p0 = wv; p0 < A.npart; p0 += 32) {
+                double t[8][3];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) t[u][k] = p0 + 4 * u < A.npart ? A.fpart[((size_t)(p0 + 4 * u) * 3 + k) * A.n_islots + isl] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (p0 + 4 * u < A.npart) { t3[0] += t[u][0]; t3[1] += t[u][1]; t3[2] += t[u][2]; }
+            }
+            red[wv][0][lane] = t3[0]; red[wv][1][lane] = t3[1]; red[wv][2][lane] = t3[2];
+            __syncthreads();
+            if (wv != 0) return;
+#pragma unroll
+            for (int k = 0; k < 3; k++) pre[k] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+        } else if (wv != 0) return;   // one thread per atom
         double f[3] = {0.0, 0.0, 0.0};
         double fj[3][3];  // alchemical force on this (environment) atom per slot
 #pragma unroll
@@ -341,7 +362,7 @@ __device__ __forceinline__ void finalize_body(FinArgs& A) {
 #pragma unroll
             for (int k = 0; k < 3; k++) fj[sl][k] = (i >= 0 && isl >= 0 && A.n_alch > 0 && ((A.slot_mask >> sl) & 1)) ? A.fJ[(size_t)(sl * 3 + k) * A.n + rec.sorted] : 0.0;
         if (i >= 0) {
-            fin_atom_base(A.fpart, A.n_islots, A.npart, A.fent, A.n_entries, A.frec, A.n, isl, i, rec.e0, rec.e1, f);
+            fin_atom_base(A.fpart, A.n_islots, A.npart > 1 ? 0 : A.npart, A.fent, A.n_entries, A.frec, A.n, isl, i, rec.e0, rec.e1, f, pre);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 if (isl >= 0 && A.n_alch > 0) {

@@ -306,7 +306,7 @@ int blues_set_positions_from_snapshot_edited(BluesEngine *h, const BluesSnapshot
  * BLUES chains are independent (reference examples run one
  * BLUESSimulation per process), and one replica of the 23k-atom system keeps
  * only a few percent of an MI355X busy.  A batch makes `count` congruent
- * engines on ONE device (same topology and protocol; own coordinates,
+ * engines on ONE device (same topology and protocol; own coordinates, box,
  * velocities and Philox stream) share every launch of integrator.step(n):
  * gridDim.y = count.  Each engine keeps its full C-ABI above (moves and
  * state queries stay per replica, as in the reference where they go through
