@@ -818,6 +818,9 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
     ClusterRec R;
     if (active) R = A.recs[cl];
     else { for (int a = 0; a < 4; a++) { R.atoms[a] = -1; R.alch[a] = -1; R.mobile[a] = 0; R.sorted[a] = 0; R.islot[a] = -1; R.w[a] = 0.0; } R.type = 0; R.nc = 0; R.na = 0; R.dist[0] = R.dist[1] = R.dist[2] = 0.0; }
+#if defined(STEPX_DENSE)   // (floor experiment: every gather and scatter of the kernel at consecutive addresses -- wrong numbers, only the time matters)
+    for (int a = 0; a < 4; a++) if (R.atoms[a] >= 0) { R.atoms[a] = cl * 4 + a; R.sorted[a] = cl * 4 + a; }
+#endif
     Cluster C;
     C.na = R.na; C.nc = R.nc; C.type = R.type;
     const unsigned nd0 = A.draw_base - A.noise_draw_base;

@@ -27,6 +27,33 @@ def _integ(n, seed=7):
     return integrators.generateNCMCIntegrator(nstepsNC=n, dt=0.004, temperature=300.0, seed=seed)
 
 
+@pytest.mark.parametrize("tolerance", [5e-4, 1e-5])
+def test_tighter_ewald_tolerances_keep_the_force_contract(Engine, oracle_mod, tune, tolerance):
+    """The mixed-precision pair force replaces erfc/exp by a degree-9 polynomial in r^2 only where the fit is good enough: at the
+    default ewald tolerance (alpha r_c = 2.15) its residual is 1.2e-6 nm^-3; at 5e-4 (2.63) it is 1.6e-5, at 1e-5 (3.29) 6e-4 -- more
+    than the screened force of a pair near the cutoff.  The engine measures the residual of what it fitted and falls back to the
+    erfc/exp form: forces of the benchmarked kernel (per-atom lists, a batch member's layout) stay within 1e-5 of the
+    oracle at both tolerances (reference blues/simulation.py:219: ewaldErrorTolerance is a user input of the System)."""
+    import copy
+    base, v = systems.s23k(mobile_atoms=275, frozen=True)
+    s = copy.copy(base)
+    s.ewald_alpha = float(np.sqrt(-np.log(2.0 * tolerance)) / s.cutoff)
+    tune(assume_batch=512)
+    g = Engine(s, _integ(20).to_data(precision=0)); g.set_velocities(v)
+    assert g.stats()["nonbonded_kernel"] == 2
+    mob = np.nonzero(s.mass > 0)[0]
+    o = oracle_mod.Oracle(s, _integ(20).to_data(precision=0))
+    for ls, le in ((1.0, 1.0), (0.4, 0.2)):
+        g.set_global("lambda_sterics", ls); g.set_global("lambda_electrostatics", le)
+        eo, fo, _ = o.energy_forces(ls, le)
+        f = g.get_forces()[mob]
+        assert np.abs(f - fo[mob]).max() <= 1e-5 * np.abs(fo[mob]).max(), (tolerance, np.abs(f - fo[mob]).max() / np.abs(fo[mob]).max())
+        assert abs(g.potential_energy() - eo) <= 1e-5 * abs(eo)
+    g.step(20)                     # ... and the stepping path (the prune variant of the same pair body) runs
+    assert np.isfinite(g.get_global("protocol_work"))
+    g.close()
+
+
 def test_pruned_lists_hold_every_pair_in_range(Engine, oracle_mod, tune):
     s, v = systems.s23k(mobile_atoms=275, frozen=True)
     n = 120
