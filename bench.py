@@ -203,6 +203,15 @@ def in_range_counts(system):
     return len(i_atoms), len(touched), pairs
 
 
+def memory_use():
+    """Peak resident host memory of this rank and the device memory in use on its GPU (GiB), for sizing chains per GPU."""
+    import resource
+    import torch
+    free, total = torch.cuda.mem_get_info()
+    return {"host_peak_rss_gib": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0,
+            "device_in_use_gib": (total - free) / 2.0 ** 30, "device_total_gib": total / 2.0 ** 30}
+
+
 def _free_port():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
@@ -268,9 +277,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--replicas", type=int, default=512, help="independent chains per GPU, advanced as one replica batch (a multiple of 256 fills the "
-                    "256 CUs evenly: the nonbonded launch places one workgroup per chain; 512 amortises the latency-bound kernels of a step "
-                    "over twice the chains: 1.25 us per chain-step against 1.40 at 256)")
+    ap.add_argument("--replicas", type=int, default=2048, help="independent chains per GPU, advanced as one replica batch (a multiple of 256 fills the "
+                    "256 CUs evenly: the nonbonded launch places one workgroup per chain).  2048 chains are 48 GB of the 288 GB of HBM and "
+                    "14 s of set-up; per chain-step 0.80 us against 0.84 at 1024 and 0.92 at 512 (profiles/README.md, round 4)")
     ap.add_argument("--groups", type=int, default=1, help="the rank's chains form this many replica batches, each driven from its own host thread on its "
                     "own stream: one group's host phases and latency-bound kernels overlap the others' compute-bound ones (1 = a single batch)")
     ap.add_argument("--workers", type=int, default=1, help="host threads for the per-chain plugin-boundary work inside a group")
@@ -512,6 +521,7 @@ def main():
             "rank_elapsed_seconds": rank_elapsed,
             "process_group": {"backend": (args.backend if world > 1 else None), "same_device": bool(args.same_device),
                               "replica_seeds_first_chain_of_each_rank": [int(replica_seed(1234, r * R)) for r in range(world)]},
+            "memory": memory_use(),
             "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup, "setup_seconds_by_part": setup_parts,
                        "plugin_boundary": "one call per operation for all chains (blues_batch_*)" if drivers[0]._batchable() else "chain by chain",
                        "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,

@@ -1238,7 +1238,7 @@ static int launch_finalize(BluesEngine* h, const double le[3], int slot_mask = 7
 // program are served by this pass (slots 0 and 2).  What else needs the summed forces resolves the pending sums first.
 // (npart == 1: the per-atom-list kernel's single slab; a lone chain's tile kernel leaves dozens of partial slabs, and four atoms per
 // thread summing them one after the other took longer than k_finalize's thread per atom: 77 against 52 us per step)
-static bool fin_fusable(const BluesEngine* h) { return h->fast_step && h->int_blocks == 1 && h->int_threads == 256 && h->npart == 1 && h->tune.fuse_finalize != 0 && !h->ctrl_arg; }
+static bool fin_fusable(const BluesEngine* h) { return h->fast_step && h->int_blocks == 1 && h->int_threads == 256 && h->npart == 1 && h->n_entries <= STEP_FENT_LDS && h->tune.fuse_finalize != 0 && !h->ctrl_arg; }   // (one slab, the bonded entries fit the step kernel's LDS: step_default_body<CM, true>)
 static int launch_finalize_deferred(BluesEngine* h, const double le[3], int slot_mask) {
     if (!fin_fusable(h) || (slot_mask & 5) != 5) { h->fin_pending = false; return launch_finalize(h, le, slot_mask); }
     h->fin_pending = true; h->fin_mask = slot_mask;
@@ -1507,12 +1507,13 @@ static int force_pass(BluesEngine* h, int base_L) {
     // A large batch in per-atom-list mode forks the alchemical kernel onto a side stream after the group lists (which hold its
     // j records): the atoms' own lists are built by a few latency-bound blocks that leave most of the chip idle, and the
     // alchemical kernel fills it.  Joined before finalize.
-    const bool fork_env = (h->batch ? h->batch->tune.fork : h->tune.fork) != 0;
+    const int fork_mode = h->batch ? h->batch->tune.fork : h->tune.fork;   // 2: also with the dense alchemical kernel, joined BEFORE the nonbonded kernel
+    const bool fork_env = fork_mode != 0;
     const bool decomposed = !(h->fuse_forces && h->wpb == 4) && !(h->k1_mode == 1 && h->precision == 0 && h->fuse_big);
     // (not with the dense alchemical kernel: one 512-thread workgroup with ~137 KB of LDS per chain cannot share a CU with the
     // nonbonded kernel's, and beside the rebuild's small workgroups it runs at half speed -- round 3 timelines: 516 us per step with
     // every kernel alone against 540 with the dense kernel on the side stream)
-    const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && !h->k2_dense && !h->alch.empty() && !h->ctrl_arg;
+    const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && (!h->k2_dense || fork_mode == 2) && !h->alch.empty() && !h->ctrl_arg;
     if (fork && ensure_side(h)) return 1;
     // k2_early (off by default): the alchemical kernel of the members that do NOT rebuild needs nothing from the rebuild and can
     // start as soon as the work list says who they are, with the rebuild kernels on a high-priority stream beside it and the
@@ -1565,6 +1566,7 @@ static int force_pass(BluesEngine* h, int base_L) {
         // 18 + 13; on a side stream beside the list rebuild, with the bonded entries, the step stayed at 419 us -- the two small kernels
         // overlapped, the group-list builder they ran beside went from 47 to 62 us)
         if (!fork && launch_alchemical(h, ls, le, fmask)) return 1;
+        if (fork && fork_mode == 2) HIP_OK(h, hipStreamWaitEvent(h->cur, h->evJ1, 0));   // (the nonbonded kernel has the device to itself)
         rc = h->precision == 0 ? launch_nonbonded<float, false>(h) : launch_nonbonded<double, false>(h);
         if (rc) return 1;
         if (launch_pme(h, 0)) return 1;
@@ -2555,7 +2557,9 @@ int blues_engine_destroy(BluesEngine* h) {
     if (h->h_edit) { hipHostFree(h->h_edit); h->h_edit = nullptr; }
     if (h->ev_edit) { hipEventDestroy(h->ev_edit); h->ev_edit = nullptr; }
 #ifdef BLUES_STAMP
-    { std::vector<long long> st; h->d_stamps.download(st); fprintf(stderr, "[stamps] last integrate launch, cycles per op:"); for (int i = 1; i < 40 && st[i] > 0; i++) fprintf(stderr, " %lld", st[i] - st[i - 1]); fprintf(stderr, "\n"); }
+    { std::vector<long long> st; h->d_stamps.download(st); static int printed = 0;
+      if (printed++ < 2) { fprintf(stderr, "[stamps] last integrate launch, cycles per op:"); for (int i = 1; i < 40 && st[i] > 0; i++) fprintf(stderr, " %lld", st[i] - st[i - 1]); fprintf(stderr, "\n");
+        fprintf(stderr, "[stamps] last step_default launch, thread 0 (10 ns ticks since entry: gathers issued, alchemical sums, V+rattle, CM, V+rattle, R+shake+rattle, O+rattle, R+shake+rattle, written):"); for (int i = 1; i < 10; i++) fprintf(stderr, " %lld", st[40 + i] - st[40]); fprintf(stderr, " | top: records asked for, entries staged, atom 0, 1, 2, 3 begun:"); for (int i = 10; i < 16; i++) fprintf(stderr, " %lld", st[40 + i] - st[40]); fprintf(stderr, "\n"); } }
 #endif
     delete h;
     return 0;

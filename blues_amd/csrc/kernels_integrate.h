@@ -803,9 +803,16 @@ __global__ void __launch_bounds__(256) k_forces_fused(NbArgs<R> a, NbConst<R> c,
 // LATE (with FUSED in a batch): the noise of the O substep and the reference positions of the list checks are loaded where they are
 // used instead of at the top -- 60 registers less across the constraint solves, which lets two waves share a SIMD (256 registers:
 // kernels_batch.h) where the kernel otherwise runs one wave per SIMD in two rounds.
+#ifdef BLUES_STAMP
+#define STEP_STAMP(i) do { if (threadIdx.x == 0 && A.stamps) A.stamps[40 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STEP_STAMP(i) do { } while (0)
+#endif
+#define STEP_FENT_LDS 512   // bonded entries of a chain the fused step kernel keeps in LDS (a chain with more is not fused: blues_engine.hip, fin_fusable)
 template <bool CM, bool FUSED = false, bool LATE = false>
 __device__ __forceinline__ void step_default_body(IntArgs& A) {
     const int tid = threadIdx.x;
+    STEP_STAMP(0);
     const int cl = blockIdx.x * blockDim.x + tid;
     if (A.ctrl) {
         const int u = A.ctrl->kint;
@@ -831,20 +838,32 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
     __shared__ double s_fin[FUSED ? 6 : 1][FUSED ? 256 : 1];   // FUSED: reduction scratch of the alchemical slabs (slots 0 and 2: the two kicks of this program)
     __shared__ double s_aself[FUSED ? 6 : 1][64];    // ... the alchemical atoms' pair force, slots 0 and 2
     __shared__ double s_esum[FUSED ? K2_NP : 1];     // ... the alchemical kernel's energy sums
+    // FUSED (host: fin_fusable -- ONE nonbonded slab, at most STEP_FENT_LDS bonded entries): the bonded entries of the chain are
+    // staged by the whole block in one round trip (the few threads that hold the solute's clusters add a few dozen entries per
+    // atom: from memory that was sixteen dependent round trips on the critical path of wave 0 while every other thread had none),
+    // and every load of the top of the kernel is REQUESTED before any is waited for -- in a batch a round trip to memory takes
+    // ~7,000 cycles (512 workgroups gather at once).  Same values added in the same order as k_finalize (fin_atom_base).
+    __shared__ double s_fent[FUSED ? 3 * STEP_FENT_LDS : 1];
+    const int jc_alch = (FUSED && A.n_alch > 0) ? *A.jcount_alch : 0;   // (asked for here: on its way while the entries are staged)
+    STEP_STAMP(10);
+    if (FUSED) {
+        for (int e = tid; e < 3 * A.n_entries; e += 256) s_fent[e] = A.fent[e];
+        __syncthreads();
+    }
+    STEP_STAMP(11);
+    double FP[FUSED ? 4 : 1][3];
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int i = max(R.atoms[a], 0), al = R.alch[a], alc = max(al, 0);
         C.id[a] = R.atoms[a]; C.al[a] = al; C.w[a] = R.w[a];
-        double fb[3] = {0.0, 0.0, 0.0};
-        if (FUSED && R.atoms[a] >= 0) fin_atom_base(A.fpart, A.n_islots, A.npart, A.fent, A.n_entries, A.frec, A.n, R.islot[a], i, R.e0[a], R.e1[a], fb);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             C.x[a][k] = A.x[k][i]; C.v[a][k] = A.v[k][i];
             if (!LATE) { XB[a][k] = A.xbuild[k][i]; XP[a][k] = pruned ? A.xprune[k][max(R.islot[a], 0)] : 0u; }
             if (FUSED) {
                 const bool env = R.islot[a] >= 0 && A.n_alch > 0 && R.atoms[a] >= 0;
-                const double ja = env ? A.fJ[(size_t)(0 + k) * A.n + R.sorted[a]] : 0.0, jb = env ? A.fJ[(size_t)(6 + k) * A.n + R.sorted[a]] : 0.0;
-                FA[a][k] = fb[k] + ja; FB[a][k] = fb[k] + jb;   // (an alchemical atom: its pair force is added below, once the block has summed it)
+                FA[a][k] = env ? A.fJ[(size_t)(0 + k) * A.n + R.sorted[a]] : 0.0; FB[a][k] = env ? A.fJ[(size_t)(6 + k) * A.n + R.sorted[a]] : 0.0;   // (the lambda-independent part is added below)
+                FP[a][k] = (R.atoms[a] >= 0 && R.islot[a] >= 0) ? A.fpart[(size_t)k * A.n_islots + R.islot[a]] : 0.0;
             } else {
                 const double fa0 = A.ftot[(size_t)((al >= 0 ? 0 : 0) + k) * A.n + i];
                 const double fb0 = A.ftot[(size_t)((al >= 0 ? 0 : 6) + k) * A.n + i];
@@ -855,18 +874,26 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
             if (!LATE) G0[a][k] = pre_noise ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : 0.0;
         }
     }
+    STEP_STAMP(1);
     // (placed behind the gathers above: their loads are in flight while the block sums the alchemical slabs)
     if (FUSED && A.n_alch > 0) {   // (uniform) what the last 10 blocks of k_finalize do, the same sums in the same order (fin_alch_self, fin_energy_sums),
         // with every slab's loads in flight together and ONE barrier for all of them
-        const int nb_env = k2_env_blocks(*A.jcount_alch, A.PA, A.k2_jiter);
+        const int nb_env = k2_env_blocks(jc_alch, A.PA, A.k2_jiter);
         const int PA = A.PA, NG = 256 / PA, aa = tid & (PA - 1), gg = tid / PA;
-        double sv[6];
+        double sv[6], s0[6], sx[6];
+#pragma unroll
+        for (int q6 = 0; q6 < 6; q6++) {   // (the thread's first slab and the alchemical x alchemical slab of all six sums requested together)
+            const int q = q6 < 3 ? q6 : q6 + 3;
+            s0[q6] = gg < nb_env ? A.self_part[((size_t)gg * 9 + q) * PA + aa] : 0.0;
+            sx[q6] = gg == 0 ? A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * PA + aa] : 0.0;
+        }
 #pragma unroll
         for (int q6 = 0; q6 < 6; q6++) {
             const int q = q6 < 3 ? q6 : q6 + 3;
             double sq = 0.0;
-            for (int b = gg; b < nb_env; b += NG) sq += A.self_part[((size_t)b * 9 + q) * PA + aa];
-            if (gg == 0) sq += A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * PA + aa];
+            if (gg < nb_env) sq += s0[q6];
+            for (int b = gg + NG; b < nb_env; b += NG) sq += A.self_part[((size_t)b * 9 + q) * PA + aa];   // (the dense kernel leaves one slab)
+            if (gg == 0) sq += sx[q6];
             sv[q6] = sq;
         }
 #pragma unroll
@@ -882,6 +909,20 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
         }
         __syncthreads();
     }
+    if (FUSED) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            // fin_atom_base's sum: 0 + the slab, the atom's bonded entries in order, reciprocal space
+            double fb[3] = {0.0, 0.0, 0.0};
+            if (R.atoms[a] >= 0) {
+                if (R.islot[a] >= 0) { fb[0] += FP[a][0]; fb[1] += FP[a][1]; fb[2] += FP[a][2]; }
+                for (int e = R.e0[a]; e < R.e1[a]; e++) { fb[0] += s_fent[e]; fb[1] += s_fent[A.n_entries + e]; fb[2] += s_fent[2 * A.n_entries + e]; }
+                if (A.frec) { const int i = R.atoms[a]; fb[0] += A.frec[i]; fb[1] += A.frec[(size_t)A.n + i]; fb[2] += A.frec[2 * (size_t)A.n + i]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { FA[a][k] = fb[k] + FA[a][k]; FB[a][k] = fb[k] + FB[a][k]; }
+        }
+    }
     if (FUSED && A.n_alch > 0) {
 #pragma unroll
         for (int a = 0; a < 4; a++) if (R.alch[a] >= 0) {
@@ -889,6 +930,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
             for (int k = 0; k < 3; k++) { FA[a][k] += s_aself[k][R.alch[a]]; FB[a][k] += s_aself[3 + k][R.alch[a]]; }
         }
     }
+    STEP_STAMP(2);
     double e_sl[3] = {0.0, 0.0, 0.0};
     if (FUSED) {
         if (A.n_alch > 0) { e_sl[0] = A.fin_le[0] * s_esum[0] + s_esum[1]; e_sl[1] = A.fin_le[1] * s_esum[0] + s_esum[2]; e_sl[2] = A.fin_le[2] * s_esum[0] + s_esum[3]; }
@@ -915,6 +957,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
             for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * FA[a][k] * C.w[a];
         rattle(C, A.tol, A);
     }
+    STEP_STAMP(3);
     if (blockIdx.x == 0 && tid == 0) {
         const double dE = FUSED ? e_sl[1] - e_sl[0] : A.acc->e_slot[1] - A.acc->e_slot[0];
         A.acc->protocol_work += dE; A.acc->dE_last = dE;
@@ -937,6 +980,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
             for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] -= s_cm[k];
         }
     }
+    STEP_STAMP(4);
     if (blockIdx.x == 0 && tid == 0) {
         const double dE = FUSED ? e_sl[2] - e_sl[1] : A.acc->e_slot[2] - A.acc->e_slot[1];
         A.acc->protocol_work += dE; A.acc->dE_last = dE;
@@ -949,6 +993,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
 #pragma unroll
             for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * FB[a][k] * C.w[a];
         rattle(C, A.tol, A);
+        STEP_STAMP(5);
         for (int half = 0; half < 2; half++) {
             // R
             double xr[4][3], x1[4][3];
@@ -960,21 +1005,40 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
 #pragma unroll
             for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += (C.x[a][k] - x1[a][k]) * A.inv_hR;
             rattle(C, A.tol, A);
+            STEP_STAMP(6 + 2 * half);
             if (half == 0) {
                 // O
+                double GL[LATE ? 4 : 1][3];
+                if (LATE && pre_noise) {   // (all twelve requested before the first is used)
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) GL[a][k] = a < C.na ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : 0.0;
+                }
 #pragma unroll
                 for (int a = 0; a < 4; a++) if (a < C.na) {
                     double g[3];
-                    if (pre_noise) { for (int k = 0; k < 3; k++) g[k] = LATE ? A.noise[(size_t)(nd0 * 3 + k) * A.n_mobile + R.mobile[a]] : G0[a][k]; }
+                    if (pre_noise) { for (int k = 0; k < 3; k++) g[k] = LATE ? GL[a][k] : G0[a][k]; }
                     else gaussians3(A.seed, A.stream, A.draw_base, (unsigned)C.id[a], g);
                     const double s = sqrt(A.kT * C.w[a]);
 #pragma unroll
                     for (int k = 0; k < 3; k++) C.v[a][k] = A.aO * C.v[a][k] + A.bO * s * g[k];
                 }
                 rattle(C, A.tol, A);
+                STEP_STAMP(7);
             }
         }
         // write back, refresh the image, list validity
+        double XL[LATE ? 4 : 1][3]; unsigned PL[LATE ? 4 : 1][3];
+        if (LATE) {   // (the reference positions of both list checks, requested together)
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    XL[a][k] = a < C.na ? A.xbuild[k][max(C.id[a], 0)] : 0.0;
+                    PL[a][k] = (pruned && a < C.na && R.islot[a] >= 0) ? A.xprune[k][R.islot[a]] : 0u;
+                }
+        }
 #pragma unroll
         for (int a = 0; a < 4; a++) if (a < C.na) {
             const int i = C.id[a];
@@ -983,7 +1047,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
             for (int k = 0; k < 3; k++) {
                 A.v[k][i] = C.v[a][k]; A.x[k][i] = C.x[a][k];
                 bad |= !(C.x[a][k] == C.x[a][k]) || !(C.v[a][k] == C.v[a][k]);
-                const double d = C.x[a][k] - (LATE ? A.xbuild[k][i] : XB[a][k]); d2 += d * d;
+                const double d = C.x[a][k] - (LATE ? XL[a][k] : XB[a][k]); d2 += d * d;
             }
             need_rebuild |= d2 > A.half_skin2;
             const int s = R.sorted[a];
@@ -992,7 +1056,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
                 if (pruned && R.islot[a] >= 0) {
                     float p2 = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { const float e = (float)(int)(u[k] - (LATE ? A.xprune[k][R.islot[a]] : XP[a][k])) * A.fscale[k]; p2 += e * e; }
+                    for (int k = 0; k < 3; k++) { const float e = (float)(int)(u[k] - (LATE ? PL[a][k] : XP[a][k])) * A.fscale[k]; p2 += e * e; }
                     if (p2 > A.prune_trig2) A.pneed[R.islot[a]] = 1;
                 }
             }
@@ -1002,6 +1066,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
         if (bad) A.flags->nan_flag = 1;
         if (!ok) A.flags->constraint_fail = 1;
     }
+    STEP_STAMP(9);
 }
 
 template <bool CM, bool FUSED = false>
