@@ -2559,6 +2559,7 @@ int blues_engine_destroy(BluesEngine* h) {
 #ifdef BLUES_STAMP
     { std::vector<long long> st; h->d_stamps.download(st); static int printed = 0;
       if (printed++ < 2) { fprintf(stderr, "[stamps] last integrate launch, cycles per op:"); for (int i = 1; i < 40 && st[i] > 0; i++) fprintf(stderr, " %lld", st[i] - st[i - 1]); fprintf(stderr, "\n");
+        { long long gs[64]; hipMemcpyFromSymbol(gs, HIP_SYMBOL(g_nb_stamps), sizeof gs); fprintf(stderr, "[stamps] dense alchemical kernel, block 0 thread 0 (cycles since entry: staged; pass 1: begun, marked, pairs done; pass 2: begun, marked, pairs done; all passes, end):"); for (int i = 33; i < 42; i++) fprintf(stderr, " %lld", gs[i] - gs[32]); fprintf(stderr, "\n"); }
         fprintf(stderr, "[stamps] last step_default launch, thread 0 (10 ns ticks since entry: gathers issued, alchemical sums, V+rattle, CM, V+rattle, R+shake+rattle, O+rattle, R+shake+rattle, written):"); for (int i = 1; i < 10; i++) fprintf(stderr, " %lld", st[40 + i] - st[40]); fprintf(stderr, " | top: records asked for, entries staged, atom 0, 1, 2, 3 begun:"); for (int i = 10; i < 16; i++) fprintf(stderr, " %lld", st[40 + i] - st[40]); fprintf(stderr, "\n"); } }
 #endif
     delete h;

@@ -313,3 +313,11 @@ __device__ inline float seg_sum(float v, int width) {
     for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// ---- phase stamps of development builds (-DBLUES_STAMP): the clock of thread 0 of block 0 at phase boundaries, printed by the host
+#ifdef BLUES_STAMP
+__device__ long long g_nb_stamps[64];   // dev builds: s_memtime of thread 0 of block 0 at phase boundaries ([0..15] list build, [16..31] force kernel, [32..47] dense alchemical kernel)
+#define NB_STAMP(cond, i) do { if (cond) g_nb_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NB_STAMP(cond, i) do { } while (0)
+#endif

@@ -388,10 +388,11 @@ __device__ __forceinline__ void alchemical_blocks(AlchArgs& A, const int p, cons
 #define K2D_WAVES (K2D_THREADS / 64)
 #define K2D_JC 2560        // list entries staged at a time (an alchemical tile's list is ~2,400 entries; longer lists take more rounds)
 #define K2D_AG 8           // alchemical atoms per marking pass (the pair list holds K2D_AG * K2D_JC entries)
-#define K2D_MOB 320        // mobile entries per round that have a force accumulator
+#define K2D_MOB 288        // mobile entries per round that have a force accumulator (with the fp32 offsets of the marking pass the record fills the 160 KB of LDS)
 #define K2D_FIX 1048576.0  // 2^20: the accumulators resolve 1e-6 kJ/mol/nm and hold +-8.8e12
 struct K2DLds {
     double x[3][K2D_JC];
+    float rel[3][K2D_JC];   // the entry relative to the first alchemical atom (minimum image, fp32): what the marking pass measures from
     unsigned short pairs[K2D_AG][K2D_JC];   // one segment per alchemical atom of the pass, list index ascending
     unsigned short mslot[K2D_JC];
     unsigned long long fj[9][K2D_MOB];
@@ -402,6 +403,8 @@ struct K2DLds {
     int pcnt[K2D_AG];
     double e[K2D_WAVES][K2_NE];
 };
+
+static_assert(sizeof(K2DLds) <= 160 * 1024, "the dense alchemical kernel's record must fit the LDS of a CU");
 
 template <int MASK>
 __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
@@ -414,6 +417,7 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
     extern __shared__ __align__(16) unsigned char k2d_smem[];
     K2DLds& S = *reinterpret_cast<K2DLds*>(k2d_smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    NB_STAMP(blockIdx.x == 0 && threadIdx.x == 0, 32);
     const int count = *A.jcount;
     if (count <= 0) return;   // (finalize reads no env slab then)
     const bool no_elec = A.le[0] == 0.0 && A.le[1] == 0.0 && A.le[2] == 0.0, same_ls = A.ls[0] == A.ls[1] && A.ls[1] == A.ls[2];   // (uniform)
@@ -453,6 +457,10 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
         for (int it = 0; it < NIT; it++) {
             const int k = it * K2D_THREADS + tid, ch = k >> 6;
             S.x[0][k] = px[it][0]; S.x[1][k] = px[it][1]; S.x[2][k] = px[it][2];   // (entries past the end repeat the last one)
+            // (formed once per entry: the marking pass below ran these three fp64 minimum images for every (alchemical atom, entry)
+            // combination -- 15 x the work, and two fifths of the kernel's instructions)
+#pragma unroll
+            for (int c3 = 0; c3 < 3; c3++) S.rel[c3][k] = (float)min_image_d(px[it][c3] - S.xa[c3][0], A.box.L[c3], A.box.invL[c3]);
             mob[it] = k < nst && ((js[it] >> 30) & 1);
             const unsigned long long b = __ballot(mob[it]);
             mrank[it] = __popcll(b & ((1ull << lane) - 1ull));
@@ -472,9 +480,11 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
                 S.mslot[k] = (mob[it] && ms < K2D_MOB) ? (unsigned short)ms : (unsigned short)0xffff;
             }
         }
+        NB_STAMP(blockIdx.x == 0 && threadIdx.x == 0, 33);
         for (int a0 = 0; a0 < A.n_alch; a0 += K2D_AG) {
             const int na = min(K2D_AG, A.n_alch - a0);
             __syncthreads();
+            NB_STAMP(blockIdx.x == 0 && threadIdx.x == 0, 34 + 3 * (a0 / K2D_AG));
             // ---- mark and list in one sweep: wave al owns alchemical atom a0 + al and walks the round's chunks in order (fp32
             // distances relative to the first alchemical atom; a running offset keeps its segment of the pair list ascending)
             if (wv < na) {
@@ -482,9 +492,7 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
                 int pos = 0;
                 auto test = [&](int ch) -> bool {
                     const int k = ch * 64 + lane;
-                    const float dx = (float)min_image_d(S.x[0][k] - S.xa[0][0], A.box.L[0], A.box.invL[0]) - ox;
-                    const float dy = (float)min_image_d(S.x[1][k] - S.xa[1][0], A.box.L[1], A.box.invL[1]) - oy;
-                    const float dz = (float)min_image_d(S.x[2][k] - S.xa[2][0], A.box.L[2], A.box.invL[2]) - oz;
+                    const float dx = S.rel[0][k] - ox, dy = S.rel[1][k] - oy, dz = S.rel[2][k] - oz;
                     return k < nst && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < rc2m;
                 };
                 auto emit = [&](int ch, bool hit) {
@@ -501,6 +509,7 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
                 if (lane == 0) S.pcnt[wv] = pos;
             }
             __syncthreads();
+            NB_STAMP(blockIdx.x == 0 && threadIdx.x == 0, 35 + 3 * (a0 / K2D_AG));
             // ---- the pairs, every lane busy: work items = (alchemical atom of the pass, 64 consecutive pairs of its segment)
             int item_al[K2D_AG + 1];   // first item of each segment (uniform)
             item_al[0] = 0;
@@ -594,8 +603,10 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
                 }
             }
             flush();
+            NB_STAMP(blockIdx.x == 0 && threadIdx.x == 0, 36 + 3 * (a0 / K2D_AG));
         }
         __syncthreads();
+        NB_STAMP(blockIdx.x == 0 && threadIdx.x == 0, 40);
         // ---- the round's mobile entries: force by sorted index (every one of them is written: zero if it had no pair)
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
@@ -625,6 +636,7 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
     __syncthreads();
     if (tid < K2_NE) { double t = 0.0; for (int w = 0; w < K2D_WAVES; w++) t += S.e[w][tid]; A.e_part[tid] = t; }
     if (tid < 3) { double t = 0.0; for (int a = 0; a < A.n_alch; a++) t += (double)(long long)S.fa[tid][a] * (1.0 / K2D_FIX); A.e_part[K2_NE + tid] = slot_on(0) ? t : 0.0; }
+    NB_STAMP(blockIdx.x == 0 && threadIdx.x == 0, 41);
 }
 
 template <int MASK>

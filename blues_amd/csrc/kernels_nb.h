@@ -15,12 +15,6 @@
 #pragma once
 #include "device_common.h"
 
-#ifdef BLUES_STAMP
-__device__ long long g_nb_stamps[32];   // dev builds: s_memtime of thread 0 of block 0 at phase boundaries ([0..15] list build, [16..31] force kernel)
-#define NB_STAMP(cond, i) do { if (cond) g_nb_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define NB_STAMP(cond, i) do { } while (0)
-#endif
 
 struct DevFlags {  // device-resident control words
     unsigned list_gen, req_gen;  // neighbour lists are current iff equal
