@@ -277,9 +277,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--replicas", type=int, default=2048, help="independent chains per GPU, advanced as one replica batch (a multiple of 256 fills the "
-                    "256 CUs evenly: the nonbonded launch places one workgroup per chain).  2048 chains are 48 GB of the 288 GB of HBM and "
-                    "14 s of set-up; per chain-step 0.80 us against 0.84 at 1024 and 0.92 at 512 (profiles/README.md, round 4)")
+    ap.add_argument("--replicas", type=int, default=1024, help="independent chains per GPU, advanced as one replica batch (a multiple of 256 fills the "
+                    "256 CUs evenly: the nonbonded launch places one workgroup per chain).  1024 chains are 25 GB of the 288 GB of HBM and "
+                    "7 s of set-up; per chain-step through the driver 0.88 us against 0.95 at 512 and 0.88 at 2048 (DESIGN.md section 4d)")
     ap.add_argument("--groups", type=int, default=1, help="the rank's chains form this many replica batches, each driven from its own host thread on its "
                     "own stream: one group's host phases and latency-bound kernels overlap the others' compute-bound ones (1 = a single batch)")
     ap.add_argument("--workers", type=int, default=1, help="host threads for the per-chain plugin-boundary work inside a group")
@@ -498,9 +498,8 @@ def main():
               if insts:
                   peak = 1024 * 2.4e9 / 2.0    # SIMDs x clock / 2 cycles per wave64 instruction (scripts/valu_issue.hip: 1.03 T/s reached with plain v_fma_f32)
                   v = {"insts_per_launch": insts, "issue_rate": insts / secs, "peak": peak, "frac": insts / secs / peak, "unit": "wave-instructions/s"}
-                  if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
-                      # quad-cycles x 4, summed over the 1024 SIMDs, against the busy cycles of the launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
-                      v["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+                  # (SQ_ACTIVE_INST_VALU is NOT reported as busy time: on gfx950 it counts one quad-cycle per VALU instruction -- it equals
+                  # SQ_INSTS_VALU to 2 % in every kernel measured)
                   if c.get("SQ_INSTS_VALU_TRANS_F32"):
                       v["transcendental_insts_per_launch"] = c["SQ_INSTS_VALU_TRANS_F32"]
                   roofline["valu"] = v

@@ -8,7 +8,7 @@ f = glob.glob("$out/t/*/*kernel_trace.csv")[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))) for r in csv.DictReader(open(f))]
 rows.sort()
 # steps are delimited by k_step_default_b
-idx = [i for i, r in enumerate(rows) if "k_step_default_b" in r[2]]
+idx = [i for i, r in enumerate(rows) if "k_step_default" in r[2]]
 first = int("${4:-60}")
 a, b = idx[first], idx[first + 3]
 t0 = rows[a][1]

@@ -1,4 +1,4 @@
-"""CPU suite: the committed bench line of the round (profiles/r04/bench_R512*.json, written by `python bench.py` on an MI355X) carries
+"""CPU suite: the committed bench line of the round (profiles/r04/bench_R1024*.json, written by `python bench.py` on an MI355X) carries
 what the measurement contract asks for, its roofline block can be recomputed from the committed counters, and the launch duration it
 prices agrees with the committed rocprofv3 kernel statistics of the same workload."""
 import csv
@@ -13,13 +13,13 @@ R04 = os.path.join(ROOT, "profiles", "r04")
 
 @pytest.fixture(scope="module")
 def line():
-    return json.load(open(os.path.join(R04, "bench_R512.json")))
+    return json.load(open(os.path.join(R04, "bench_R1024.json")))
 
 
 @pytest.fixture(scope="module")
 def line_counters():
     """The same command once the PMC counters of the build were on disk (roofline.valu / traffic filled in; no CPU baseline)."""
-    return json.load(open(os.path.join(R04, "bench_R512_with_counters.json")))
+    return json.load(open(os.path.join(R04, "bench_R1024_with_counters.json")))
 
 
 def test_contract_keys(line):
@@ -47,7 +47,7 @@ def test_the_launch_is_timed_where_it_runs_and_agrees_with_rocprof(request, whic
     R = d["config"]["replicas_per_gpu"]
     assert r["algorithmic_bytes_per_launch"] == 36.0 * 23400 * R
     # rocprofv3 --kernel-trace --stats of the same workload: the average duration of the kernel over ALL its launches of the run
-    rows = list(csv.DictReader(open(os.path.join(R04, "kernel_stats_R512.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(R04, "kernel_stats_R1024.csv"))))
     k1 = [x for x in rows if x["Name"].startswith("void k_nonbonded_atom_b<false>")]
     assert len(k1) == 1 and int(k1[0]["Calls"]) >= 2000
     csv_us = float(k1[0]["AverageNs"]) / 1e3
@@ -80,9 +80,25 @@ def test_roofline_is_recomputable_from_the_committed_counters(line_counters):
 
 
 def test_the_round_is_faster_than_the_last(line):
+    """Like for like: 512 chains in one batch, this round and the last; and the default line (1024 chains) against it."""
     last = json.load(open(os.path.join(ROOT, "profiles", "r03", "bench_R512.json")))
-    assert line["config"]["replicas_per_gpu"] == last["config"]["replicas_per_gpu"] == 512
-    assert line["value"] > 1.12 * last["value"]
+    same = json.load(open(os.path.join(R04, "bench_R512.json")))
+    assert same["config"]["replicas_per_gpu"] == last["config"]["replicas_per_gpu"] == 512
+    assert same["value"] > 1.15 * last["value"]
     # (round 3 priced a stand-alone blend of 141.1 us; its kernel took 154.6 us in the stepping loop)
-    assert line["roofline"]["usec_per_launch"] < 0.85 * last["roofline"]["usec_per_launch"]
-    assert line["engine"]["setup_seconds"] < 0.5 * last["engine"]["setup_seconds"]
+    assert same["roofline"]["usec_per_launch"] < 0.85 * last["roofline"]["usec_per_launch"]
+    assert same["engine"]["setup_seconds"] < 0.2 * last["engine"]["setup_seconds"]
+    assert line["config"]["replicas_per_gpu"] == 1024 and line["value"] > 1.25 * last["value"]
+    assert line["engine"]["setup_seconds"] < 0.5 * last["engine"]["setup_seconds"]     # (twice the chains)
+    assert line["memory"]["device_in_use_gib"] < 0.1 * line["memory"]["device_total_gib"]
+
+
+def test_four_batches_on_four_streams_are_faster_and_say_what_that_does_to_the_kernel_timing():
+    """bench.py --groups 4: more ns/day, and a per-launch duration of the nonbonded kernel that includes its co-runners -- why the
+    default stays one batch."""
+    g4 = json.load(open(os.path.join(R04, "bench_R2048_G4.json")))
+    g1 = json.load(open(os.path.join(R04, "bench_R2048.json")))
+    assert g4["config"]["batches_per_gpu"] == 4 and g1["config"]["batches_per_gpu"] == 1
+    assert g4["value"] > 1.1 * g1["value"]
+    assert g4["roofline"]["usec_per_launch"] > 2.0 * g4["roofline"]["usec_per_launch_alone"]["weighted"]
+    assert g1["roofline"]["frac"] >= 0.40
