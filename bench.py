@@ -281,7 +281,10 @@ def main():
                     "256 CUs evenly: the nonbonded launch places one workgroup per chain).  1024 chains are 25 GB of the 288 GB of HBM and "
                     "7 s of set-up; per chain-step through the driver 0.88 us against 0.95 at 512 and 0.88 at 2048 (DESIGN.md section 4d)")
     ap.add_argument("--groups", type=int, default=1, help="the rank's chains form this many replica batches, each driven from its own host thread on its "
-                    "own stream: one group's host phases and latency-bound kernels overlap the others' compute-bound ones (1 = a single batch)")
+                    "own stream.  The batches take TURNS on the device for their stepping calls (one batch's kernels have the GPU to themselves: "
+                    "kernel durations mean what they say) while the other batches' threads do their per-chain host work (1 = a single batch)")
+    ap.add_argument("--concurrent", action="store_true", help="with --groups: no turns, the batches' kernels share the device (more ns/day; a kernel's "
+                    "duration then includes its co-runners: DESIGN.md section 4d)")
     ap.add_argument("--workers", type=int, default=1, help="host threads for the per-chain plugin-boundary work inside a group")
     ap.add_argument("--nsteps-nc", type=int, default=NSTEPS_NC)
     ap.add_argument("--workload", default="rotmove", choices=["rotmove", "water", "sidechain"],
@@ -378,7 +381,9 @@ def main():
     bounds = [(g * R) // G for g in range(G + 1)]
     groups = [chains[bounds[g]:bounds[g + 1]] for g in range(G)]
     t_part = time.perf_counter()
-    drivers = [simulation.BatchedBLUESSimulation(grp, workers=args.workers) for grp in groups]
+    import threading
+    turn = threading.Lock() if (G > 1 and not args.concurrent) else None
+    drivers = [simulation.BatchedBLUESSimulation(grp, workers=args.workers, device_turn=turn) for grp in groups]
     setup_parts["batches"] = time.perf_counter() - t_part; t_part = time.perf_counter()
     if G > 1:   # chains driven from different threads draw from their own streams (reproducible whatever the interleaving)
         for c in chains:
@@ -417,8 +422,17 @@ def main():
     if G == 1:
         for k in range(args.steps):
             recs.append(switch_all(k))
+    elif turn is not None:
+        # the batches take turns on the device: every thread runs its batch through all the iterations on its own (a batch steps
+        # while the others' threads are in their host phases; nobody waits at an iteration boundary), and the rank's all-gathers
+        # of the accept records -- bookkeeping, one per iteration -- follow in iteration order
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=G) as pool:
+            parts = list(pool.map(lambda g: [switch_group(g, k) for k in range(args.steps)], range(G)))
+        for k in range(args.steps):
+            recs.append(gather_decision_block(np.concatenate([parts[g][k] for g in range(G)])))
     else:
-        # the groups run one iteration side by side on their own threads and streams: while they step, one group's
+        # --concurrent: the groups run one iteration side by side on their own threads and streams: while they step, one group's
         # latency-bound kernels (list rebuilds, integrator) overlap another's compute-bound ones.  They are joined every
         # iteration (letting them drift apart was measured slower: a group's small per-chain operations then queue behind
         # the other groups' long launches), then the rank performs its one all-gather.
@@ -514,7 +528,8 @@ def main():
             "config": {"workload": "S23k %s: %d atoms, %d mobile, %d alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in %d replica batch(es)"
                        % (args.workload, n_atoms, int((system.mass > 0).sum()), len(system.alchemical_atoms), nsteps, R, G),
                        "replicas_per_gpu": R, "batches_per_gpu": G, "host_workers": args.workers,
-                       "parallelism": "%d replica batch(es) x %d chains per gpu, %d gpu(s)" % (G, R_launch, world)},
+                       "parallelism": "%d replica batch(es) x %d chains per gpu%s, %d gpu(s)" % (G, R_launch, "" if G == 1 else (" taking turns on the device" if turn is not None else " sharing the device"), world),
+                       "batches_take_turns": turn is not None},
             "roofline": roofline,
             "single_replica": single,
             "rank_elapsed_seconds": rank_elapsed,

@@ -231,6 +231,10 @@ class NativeBatch:
         if rc:
             raise EngineError(self._lib.blues_batch_last_error(None).decode())
         self._h = h
+        # several batches on one GPU, each driven from its own host thread (simulation.BatchedBLUESSimulation(device_turn=...)): the
+        # batches take TURNS on the device for their stepping calls -- one batch's kernels have the GPU to themselves while the
+        # other batches' threads do their per-chain host work (hooks, state tables, Metropolis tests)
+        self.device_turn = None
 
     def __len__(self):
         return len(self.engines)
@@ -258,7 +262,11 @@ class NativeBatch:
         w = np.zeros((R, int(n))) if trace else None
         for e in self.engines:
             e.__dict__["_gcache"] = {}
-        rc = self._lib.blues_batch_step(self._h, int(n), w.ctypes.data_as(_dp) if trace else None, status)
+        if self.device_turn is not None:
+            with self.device_turn:      # (the call blocks until the steps are done and releases the GIL meanwhile)
+                rc = self._lib.blues_batch_step(self._h, int(n), w.ctypes.data_as(_dp) if trace else None, status)
+        else:
+            rc = self._lib.blues_batch_step(self._h, int(n), w.ctypes.data_as(_dp) if trace else None, status)
         if rc:
             raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
         errors = [EngineError(self._lib.blues_last_error(e._h).decode()) if status[r] else None for r, e in enumerate(self.engines)]

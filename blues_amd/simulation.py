@@ -280,10 +280,14 @@ class BatchedBLUESSimulation(object):
     NCMC engines form one native batch (and the MD engines another), so `step(n)` is one kernel launch sequence for all
     chains.  Hooks, state exchange and the Metropolis test run per chain, in chain order."""
 
-    def __init__(self, chains, workers=1, batched_boundary=True):
+    def __init__(self, chains, workers=1, batched_boundary=True, device_turn=None):
         """workers > 1: the per-chain host work (hooks, state exchange through the plugin boundary, Metropolis test) of
         different chains runs on a thread pool -- the C-ABI calls release the GIL and engines are independent objects;
-        each chain then draws from its own RandomState (seeded here, in chain order, from numpy's global stream)."""
+        each chain then draws from its own RandomState (seeded here, in chain order, from numpy's global stream).
+
+        device_turn: a threading.Lock shared by several BatchedBLUESSimulation objects on ONE GPU, each driven from its own
+        host thread.  Their stepping calls then take turns on the device (one batch's kernels have the GPU to themselves),
+        and the per-chain host work of one batch -- a tenth of an iteration's wall time -- runs while another batch steps."""
         from .engine import NativeBatch
         self.chains = list(chains)
         if not self.chains:
@@ -297,11 +301,13 @@ class BatchedBLUESSimulation(object):
                 if c._rng is np.random:
                     c._rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1))
         self._ncmc_batch = NativeBatch([c._ncmc_sim.context._engine for c in self.chains])
+        self._ncmc_batch.device_turn = device_turn
         self._md_batch = None
         # (a MonteCarloBarostat on the MD leg -- reference blues/simulation.py:603-626 -- leaves every chain in its own box: the batch's
         # argument records carry the box per member, and the attempts are made member by member where the chunks are planned)
         if all(c._md_sim is not None for c in self.chains):
             self._md_batch = NativeBatch([c._md_sim.context._engine for c in self.chains])
+            self._md_batch.device_turn = device_turn
         elif any(c._md_sim is not None for c in self.chains):
             raise ValueError("either every chain has an MD simulation or none has")
 

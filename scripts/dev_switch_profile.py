@@ -27,4 +27,4 @@ pr = cProfile.Profile(); pr.enable()
 bench.one_switch(drv, chains, st, 1000, 2, clock, gather=False)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+pstats.Stats(pr).sort_stats("tottime").print_stats(28); pstats.Stats(pr).sort_stats("cumulative").print_stats(45)

@@ -32,4 +32,4 @@ run sidechain_R64 --workload sidechain --replicas 64 --nsteps-nc 5000 --steps 2 
 run reciprocal_R512 --reciprocal --replicas 512 --steps 2 --warmup 1 --no-cpu --no-single
 run bench_R512 --replicas 512 --no-cpu --no-single
 run bench_R2048 --replicas 2048 --steps 2 --no-cpu --no-single
-run bench_R2048_G4 --replicas 2048 --groups 4 --steps 2 --no-cpu --no-single     # four replica batches of 512 on four streams (the nonbonded kernel's duration then includes its co-runners)
+run bench_R2048_G4 --replicas 2048 --groups 4 --concurrent --steps 2 --no-cpu --no-single     # four replica batches of 512 on four streams (the nonbonded kernel's duration then includes its co-runners)

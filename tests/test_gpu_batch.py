@@ -724,6 +724,62 @@ def test_batched_plugin_boundary_equals_chain_by_chain(Engine, tol_box, tune):
     assert st1["fallback_steps"] <= st0["fallback_steps"]
 
 
+def test_two_batches_taking_turns_on_the_device_equal_the_batches_run_one_after_the_other(Engine, tol_box, tune):
+    """Several BatchedBLUESSimulation objects on one GPU, each driven from its own host thread, sharing a `device_turn` lock
+    (bench.py --groups): the stepping calls take turns on the device, the host phases overlap them.  Chains are independent and
+    every chain draws from its own streams, so the interleaving changes nothing: same accept records and final states, bit for
+    bit, as the two batches run one after the other on the main thread."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    lig = np.arange(15)
+    R, nsteps, nIter = 4, 10, 3
+    vels = _replica_inputs(s, v, 2 * R)
+    tune(assume_batch=R)
+
+    def chains(g):
+        out = []
+        for r in range(g * R, (g + 1) * R):
+            integ = _integ(nsteps, seed=900 + r, dt=0.002)
+            sim = Simulation(None, s, integ, precision="mixed", replica=r)
+            sim.context.setVelocities(unit.Quantity(vels[r], "nanometer/picosecond"))
+            mover = moves.MoveEngine(moves.RandomLigandRotationMove(lig, s.mass[lig], random_state=190 + r))
+            out.append(simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": nIter}, mover,
+                                                  rng=np.random.RandomState(5000 + r)))
+        return out
+
+    def run(threaded):
+        turn = threading.Lock() if threaded else None
+        drivers = [simulation.BatchedBLUESSimulation(chains(g), device_turn=turn) for g in range(2)]
+        assert all(d._batchable() for d in drivers)
+        assert all(d._ncmc_batch.device_turn is turn for d in drivers)
+        records = [[], []]
+
+        def go(g):
+            drivers[g].run(nIter=nIter, on_iteration=lambda N, last: records[g].append([dict(l) for l in last]))
+        if threaded:
+            with ThreadPoolExecutor(max_workers=2) as pool:
+                list(pool.map(go, range(2)))
+        else:
+            go(0); go(1)
+        out = (records, [[c._ncmc_sim.context._engine.get_positions() for c in d.chains] for d in drivers], [[c.accept for c in d.chains] for d in drivers])
+        for d in drivers:
+            d.close()
+        return out
+
+    rec0, x0, acc0 = run(False)
+    rec1, x1, acc1 = run(True)
+    assert acc0 == acc1
+    for g in range(2):
+        for N in range(nIter):
+            for r in range(R):
+                for key in ("accept", "log_accept", "correction", "randnum", "protocol_work"):
+                    assert rec0[g][N][r][key] == rec1[g][N][r][key], (g, N, r, key)
+        for r in range(R):
+            assert np.array_equal(x0[g][r], x1[g][r]), (g, r)
+
+
 def test_configs3_full_size_water_switch_properties():
     """BASELINE.json configs[3] at FULL size under pytest: WaterTranslationMove on the 23,400-atom box with NOTHING frozen
     ("backbone" restraints on 40 atoms, the first water alchemical; reference examples/example_water.py, blues/moves.py:846-1083),
