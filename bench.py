@@ -114,7 +114,7 @@ def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
     if driver is None:
         chains[0]._stepNCMC(nsteps, nsteps // 2)
     else:
-        driver._stepNCMC(nsteps, nsteps // 2)
+        driver._stepNCMC(nsteps, nsteps // 2, batchable=fast)
     t2 = time.perf_counter()
     if fast:
         driver._decide_batched(300.0)

@@ -162,9 +162,24 @@ class Context(object):
     def periodic_wrapper(self):
         if self._wrapper is None:
             self._wrapper = PeriodicWrapper(self._system)
-        box = np.asarray(self._engine.get_box(), dtype=np.float64)
-        self._wrapper.box = np.diag(box).copy() if box.shape == (3, 3) else box.reshape(-1)[:3].copy()
+        # (asked for by every state capture of every chain: the box is re-read only when the engine's copy of it was replaced --
+        # NativeEngine.set_box drops that copy)
+        ref = self._engine.__dict__.get("_box_copy")
+        if ref is None or ref is not self.__dict__.get("_wrapper_box_ref"):
+            box = np.asarray(self._engine.get_box(), dtype=np.float64)
+            self._wrapper.box = np.diag(box).copy() if box.shape == (3, 3) else box.reshape(-1)[:3].copy()
+            self._wrapper_box_ref = self._engine.__dict__.get("_box_copy")
         return self._wrapper
+
+    def box_vector_quantities(self):
+        """The three box vectors as Quantities (a State's 'box_vectors'); the same objects until the box changes (read-only by convention)."""
+        ref = self._engine.__dict__.get("_box_copy")
+        hit = self.__dict__.get("_box_q")
+        if hit is None or ref is None or hit[0] is not ref:
+            rows = self._engine.get_box()
+            hit = (self._engine.__dict__.get("_box_copy"), [unit.Quantity(np.array(row), "nanometer") for row in rows])
+            self._box_q = hit
+        return hit[1]
 
     def getState(self, getPositions=False, getVelocities=False, getForces=False, getEnergy=False, getParameters=False,
                  enforcePeriodicBox=False, groups=-1):

@@ -396,7 +396,7 @@ class BatchedBLUESSimulation(object):
             out.append({'positions': unit.DeviceQuantity(snaps[r], 1, "nanometer", wrapper=ctx.periodic_wrapper() if periodic else None),
                         'velocities': unit.DeviceQuantity(snaps[r], 2, "nanometer/picosecond"),
                         'potential_energy': unit.Quantity(pe, "kilojoule/mole"), 'kinetic_energy': unit.Quantity(ke, "kilojoule/mole"),
-                        'box_vectors': [unit.Quantity(np.array(row), "nanometer") for row in e.get_box()]})
+                        'box_vectors': list(ctx.box_vector_quantities()) if hasattr(ctx, "box_vector_quantities") else [unit.Quantity(np.array(row), "nanometer") for row in e.get_box()]})
         return out
 
     def _restore_states(self, states, velocities=True):
@@ -479,8 +479,9 @@ class BatchedBLUESSimulation(object):
             st['potential_energy'] = c._lambda_one_energy()
             c._setStateTable('md', 'state0', st)
 
-    def _stepNCMC(self, nstepsNC, moveStep):
-        if self._batchable():
+    def _stepNCMC(self, nstepsNC, moveStep, batchable=None):
+        """batchable: what _batchable() returned a moment ago, where the caller has just asked (it walks every chain)."""
+        if self._batchable() if batchable is None else batchable:
             return self._stepNCMC_batched(nstepsNC, moveStep)
         sims = [c._ncmc_sim for c in self.chains]
         plans = {r: c._ncmc_plan(nstepsNC, moveStep) for r, c in enumerate(self.chains)}
@@ -530,15 +531,16 @@ class BatchedBLUESSimulation(object):
             def sync(r, c):
                 c.currentIter = N
                 c._syncStatesMDtoNCMC()
-            if self._batchable():
+            fast = self._batchable()      # (once per iteration: the hooks of an iteration do not change what the chains are)
+            if fast:
                 for c in self.chains:
                     c.currentIter = N
                 self._sync_batched()
             else:
                 (self._md_batch or self._ncmc_batch).prefetch_energies(at_lambda_one=self._md_batch is None)
                 self.for_each_chain(sync)
-            self._stepNCMC(nstepsNC, moveStep)
-            if self._batchable():
+            self._stepNCMC(nstepsNC, moveStep, batchable=fast)
+            if fast:
                 self._decide_batched(temperature)
                 if on_iteration is not None:     # (between the decision and the reset, as on the chain-by-chain path below)
                     on_iteration(N, [c.last for c in self.chains])
