@@ -880,3 +880,30 @@ def test_dense_alchemical_kernel_equals_the_lane_layout(Engine, tune):
     wd, wl = d.run_switch(60, trace=True), l.run_switch(60, trace=True)
     assert np.abs(wd - wl).max() <= 5e-5 * np.abs(wl).max(), np.abs(wd - wl).max()   # free-running 0.24 ps of a chaotic liquid: 1e-9 force differences grow (measured 5e-6)
     d.close(); l.close()
+
+
+def test_the_order_of_a_pass_kernels_changes_no_bit(Engine, tune):
+    """BluesTuning.fork = 0 / 2 only decide which stream the alchemical and bonded kernels of a batched force pass run on and where
+    they are joined (fork = 2: beside the builder of the atoms' lists, joined before the nonbonded kernel).  Every sum of a pass is
+    formed in a fixed order, so a batch of the bench decomposition ends on the same bits either way."""
+    from blues_amd import integrators, systems
+    from blues_amd.engine import NativeBatch
+    s, v = systems.s23k(mobile_atoms=275, frozen=True)
+    out = {}
+    for fork in (0, 2):
+        tune(fork=fork)
+        engs = [Engine(s, integrators.generateNCMCIntegrator(nstepsNC=60, dt=0.004, temperature=300.0, seed=33).to_data(precision=0, replica=r)) for r in range(8)]
+        for g in engs:
+            g.set_velocities(v)
+        B = NativeBatch(engs)
+        _, w = B.step(60, trace=True)
+        st = engs[0].stats()
+        assert st["alchemical_kernel"] == 1 and st["nonbonded_kernel"] == 2, st          # the bench decomposition: dense kernel, per-atom lists
+        assert B.stats()["fallback_steps"] == 0
+        out[fork] = (np.asarray(w), [g.get_positions() for g in engs])
+        B.close()
+        for g in engs:
+            g.close()
+    assert np.array_equal(out[0][0], out[2][0])
+    for a, b in zip(out[0][1], out[2][1]):
+        assert np.array_equal(a, b)
