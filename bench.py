@@ -277,12 +277,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--replicas", type=int, default=1024, help="independent chains per GPU, advanced as one replica batch (a multiple of 256 fills the "
-                    "256 CUs evenly: the nonbonded launch places one workgroup per chain).  1024 chains are 25 GB of the 288 GB of HBM and "
-                    "7 s of set-up; per chain-step through the driver 0.88 us against 0.95 at 512 and 0.88 at 2048 (DESIGN.md section 4d)")
-    ap.add_argument("--groups", type=int, default=1, help="the rank's chains form this many replica batches, each driven from its own host thread on its "
+    ap.add_argument("--replicas", type=int, default=2048, help="independent chains per GPU (a multiple of 256 per batch fills the 256 CUs evenly: the "
+                    "nonbonded launch places one workgroup per chain).  The default, 2048 chains as two batches of 1024, is 48 GB of the 288 GB of "
+                    "HBM and 14 s of set-up; one batch of 1024 advances a chain-step in 0.88 us through the driver, 0.95 at 512 (DESIGN.md section 4d)")
+    ap.add_argument("--groups", type=int, default=2, help="the rank's chains form this many replica batches, each driven from its own host thread on its "
                     "own stream.  The batches take TURNS on the device for their stepping calls (one batch's kernels have the GPU to themselves: "
-                    "kernel durations mean what they say) while the other batches' threads do their per-chain host work (1 = a single batch)")
+                    "kernel durations mean what they say) while the other batches' threads do their per-chain host work -- a tenth of an iteration's "
+                    "wall time with one batch (1 = a single batch)")
     ap.add_argument("--concurrent", action="store_true", help="with --groups: no turns, the batches' kernels share the device (more ns/day; a kernel's "
                     "duration then includes its co-runners: DESIGN.md section 4d)")
     ap.add_argument("--workers", type=int, default=1, help="host threads for the per-chain plugin-boundary work inside a group")

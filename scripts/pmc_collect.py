@@ -31,7 +31,9 @@ if "FETCH_SIZE" in res or "WRITE_SIZE" in res:
     d["traffic_note"] = "1024 x (2 x FETCH_SIZE + WRITE_SIZE): FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads (an upper bound for the gathered part)"
 args = sys.argv[2:]
 wl = args[args.index("--workload") + 1] if "--workload" in args else "rotmove"
-R = int(args[args.index("--replicas") + 1]) if "--replicas" in args else 1024   # (bench.py's default)
+R = int(args[args.index("--replicas") + 1]) if "--replicas" in args else 2048   # (bench.py's defaults: 2048 chains ...
+G = int(args[args.index("--groups") + 1]) if "--groups" in args else 2            # ... in two batches: 1024 chains per launch)
+R = R // max(1, min(G, R))
 table = {"%s_R%d" % (wl, R): d}
 json.dump(table, open(out + "/pmc_nonbonded.json", "w"), indent=1)
 print(json.dumps(table, indent=1))

@@ -1,4 +1,5 @@
-"""CPU suite: the committed bench line of the round (profiles/r04/bench_R1024*.json, written by `python bench.py` on an MI355X) carries
+"""CPU suite: the committed bench line of the round (profiles/r04/bench_R2048_G2*.json, written by `python bench.py` on an MI355X:
+2048 chains per GPU as two replica batches of 1024 that take turns on the device) carries
 what the measurement contract asks for, its roofline block can be recomputed from the committed counters, and the launch duration it
 prices agrees with the committed rocprofv3 kernel statistics of the same workload."""
 import csv
@@ -13,13 +14,13 @@ R04 = os.path.join(ROOT, "profiles", "r04")
 
 @pytest.fixture(scope="module")
 def line():
-    return json.load(open(os.path.join(R04, "bench_R1024.json")))
+    return json.load(open(os.path.join(R04, "bench_R2048_G2.json")))
 
 
 @pytest.fixture(scope="module")
 def line_counters():
     """The same command once the PMC counters of the build were on disk (roofline.valu / traffic filled in; no CPU baseline)."""
-    return json.load(open(os.path.join(R04, "bench_R1024_with_counters.json")))
+    return json.load(open(os.path.join(R04, "bench_R2048_G2_with_counters.json")))
 
 
 def test_contract_keys(line):
@@ -44,12 +45,13 @@ def test_the_launch_is_timed_where_it_runs_and_agrees_with_rocprof(request, whic
     r = d["roofline"]
     assert r["timed"] == "in the stepping loop" and r["launches_timed"] >= 500
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["usec_per_launch"] * 1e-6) / 1e9, rel=1e-9)
-    R = d["config"]["replicas_per_gpu"]
+    R = d["config"]["replicas_per_gpu"] // d["config"]["batches_per_gpu"]      # chains per launch
+    assert R == 1024 and d["config"]["batches_take_turns"] is True
     assert r["algorithmic_bytes_per_launch"] == 36.0 * 23400 * R
     # rocprofv3 --kernel-trace --stats of the same workload: the average duration of the kernel over ALL its launches of the run
-    rows = list(csv.DictReader(open(os.path.join(R04, "kernel_stats_R1024.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(R04, "kernel_stats_R2048_G2.csv"))))
     k1 = [x for x in rows if x["Name"].startswith("void k_nonbonded_atom_b<false>")]
-    assert len(k1) == 1 and int(k1[0]["Calls"]) >= 2000
+    assert len(k1) == 1 and int(k1[0]["Calls"]) >= 4000      # (both batches' launches)
     csv_us = float(k1[0]["AverageNs"]) / 1e3
     assert abs(r["usec_per_launch"] - csv_us) <= 0.03 * csv_us, (r["usec_per_launch"], csv_us)
     assert r["frac"] >= 0.40          # north_star's bar, on the in-situ measure
@@ -60,7 +62,7 @@ def test_the_launch_is_timed_where_it_runs_and_agrees_with_rocprof(request, whic
 
 def test_roofline_is_recomputable_from_the_committed_counters(line_counters):
     r = line_counters["roofline"]
-    R = line_counters["config"]["replicas_per_gpu"]
+    R = line_counters["config"]["replicas_per_gpu"] // line_counters["config"]["batches_per_gpu"]
     pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_nonbonded.json")))["rotmove_R%d" % R]
     assert r["pmc_source"]["source_sha"] == pmc["source_sha"]
     c = pmc["counters_per_launch"]
@@ -80,7 +82,7 @@ def test_roofline_is_recomputable_from_the_committed_counters(line_counters):
 
 
 def test_the_round_is_faster_than_the_last(line):
-    """Like for like: 512 chains in one batch, this round and the last; and the default line (1024 chains) against it."""
+    """Like for like: 512 chains in one batch, this round and the last; and the default line (2 x 1024 chains) against it."""
     last = json.load(open(os.path.join(ROOT, "profiles", "r03", "bench_R512.json")))
     same = json.load(open(os.path.join(R04, "bench_R512.json")))
     assert same["config"]["replicas_per_gpu"] == last["config"]["replicas_per_gpu"] == 512
@@ -88,9 +90,20 @@ def test_the_round_is_faster_than_the_last(line):
     # (round 3 priced a stand-alone blend of 141.1 us; its kernel took 154.6 us in the stepping loop)
     assert same["roofline"]["usec_per_launch"] < 0.85 * last["roofline"]["usec_per_launch"]
     assert same["engine"]["setup_seconds"] < 0.2 * last["engine"]["setup_seconds"]
-    assert line["config"]["replicas_per_gpu"] == 1024 and line["value"] > 1.25 * last["value"]
-    assert line["engine"]["setup_seconds"] < 0.5 * last["engine"]["setup_seconds"]     # (twice the chains)
-    assert line["memory"]["device_in_use_gib"] < 0.1 * line["memory"]["device_total_gib"]
+    assert line["config"]["replicas_per_gpu"] == 2048 and line["config"]["batches_per_gpu"] == 2 and line["value"] > 1.4 * last["value"]
+    assert line["engine"]["setup_seconds"] < 0.55 * last["engine"]["setup_seconds"]     # (four times the chains)
+    assert line["memory"]["device_in_use_gib"] < 0.2 * line["memory"]["device_total_gib"]
+
+
+def test_two_batches_taking_turns_hide_the_host_work_and_leave_the_kernel_timing_alone():
+    """The default since the second half of round 4: the driver's command (--steps 20 --warmup 5) on 2 x 1024 chains against one
+    batch of 1024 under the same command -- more ns/day, the nonbonded kernel's in-loop duration within 3 %."""
+    two = json.load(open(os.path.join(R04, "bench_R2048_G2_steps20.json")))
+    one = json.load(open(os.path.join(R04, "bench_R1024.json")))
+    assert two["steps"] == one["steps"] == 20 and one["config"]["batches_per_gpu"] == 1
+    assert two["value"] > 1.08 * one["value"]
+    assert abs(two["roofline"]["usec_per_launch"] - one["roofline"]["usec_per_launch"]) <= 0.03 * one["roofline"]["usec_per_launch"]
+    assert two["roofline"]["frac"] >= 0.40 and two["roofline"]["launches_timed"] >= 5000
 
 
 def test_four_batches_on_four_streams_are_faster_and_say_what_that_does_to_the_kernel_timing():
