@@ -174,6 +174,7 @@ struct BluesEngine {
     unsigned h_draw = 0;
     double cur_ls = 1.0, cur_le = 1.0, h_lambda = 0.0;
     double h_perturbed = 0, h_unperturbed = 0; bool unpert_valid = false, x_edited = false;
+    double work_pending = 0.0; bool work_pending_set = false;   // a work increment the batch is about to book for this member (add_work)
     bool pass_valid = false; int pass_L = 0, pass_fmask = 7;
     // the sums of the last force pass are still to be formed (launch_finalize_deferred): by the step kernel itself if the next
     // program is the steady-state one, by k_finalize otherwise
@@ -297,6 +298,8 @@ struct BluesBatch {
     // in-situ timing of the nonbonded force kernel (blues_batch_kernel_timing): every `k1t_every`-th lock-step force launch of the
     // stepping loop is bracketed by two events on the stream it runs on; finished pairs are harvested lazily (no synchronisation)
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; bool busy = false; };
+    std::vector<const BluesEngine*> congr_lead; std::vector<uint64_t> congr_le, congr_me;   // congruence already established (batch_do_steps)
+    bool defer_work = false; std::vector<DevAccum*> h_wacc; std::vector<double> h_wdelta; DBuf<DevAccum*> d_wacc; DBuf<double> d_wdelta;   // add_work of all members in one launch
     std::vector<EvPair> k1t_pairs; int k1t_every = 0; int64_t k1t_seen = 0, k1t_n = 0; double k1t_sum_us = 0.0, k1t_max_us = 0.0;
     int R() const { return (int)eng.size(); }
 };
@@ -1733,6 +1736,10 @@ static int total_energy(BluesEngine* h, double* E) {
 
 static int add_work(BluesEngine* h, double delta) {
     if (flush_program(h)) return 1;
+    if (h->batch && h->batch->defer_work) {   // (a batch books the work of all its edited members with one launch: batch_do_steps)
+        h->work_pending += delta; h->work_pending_set = true; h->acc_cache_valid = false;
+        return 0;
+    }
     hipLaunchKernelGGL(k_add_work, dim3(1), dim3(1), 0, h->stream, h->d_acc.p, delta);   // (in stream order: no read-modify-write through the host)
     h->st_launches++; h->acc_cache_valid = false;
     HIP_OK(h, hipGetLastError());
@@ -2099,6 +2106,19 @@ static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const ch
     return true;
 }
 
+// (what batch_congruent compares is fixed at construction or changes with a re-layout, which bumps args_epoch: a member that was
+// found congruent with this leader at these epochs is not compared again -- the comparison walks the lambda tables: 3 ms for 1024
+// members at the head of every stepping call, energy prefetch and velocity redraw)
+static bool batch_congruent_cached(BluesBatch* B, int r, const BluesEngine* lead, const char** why) {
+    const int R = B->R();
+    if ((int)B->congr_lead.size() != R) { B->congr_lead.assign(R, nullptr); B->congr_le.assign(R, 0); B->congr_me.assign(R, 0); }
+    const BluesEngine* m = B->eng[r];
+    if (B->congr_lead[r] == lead && B->congr_le[r] == lead->args_epoch && B->congr_me[r] == m->args_epoch) return true;
+    if (!batch_congruent(lead, m, why)) return false;
+    B->congr_lead[r] = lead; B->congr_le[r] = lead->args_epoch; B->congr_me[r] = m->args_epoch;
+    return true;
+}
+
 static int batch_refresh_args(BluesBatch* B) {
     bool dirty = false;
     BluesEngine* lead = B->leader ? B->leader : B->eng[0];
@@ -2165,7 +2185,7 @@ static int batch_prefetch(BluesBatch* B, int what) {
             const BluesEngine* m = B->eng[r];
             uniform = m->e_frozen_valid && m->cur_ls == lead->cur_ls && m->cur_le == lead->cur_le && m->lists_forced == lead->lists_forced && m->prog.n == 0;
             const char* why = "";
-            uniform = uniform && batch_congruent(lead, m, &why);
+            uniform = uniform && batch_congruent_cached(B, r, lead, &why);
         }
         if (uniform) {
             if (batch_enter(B)) return 1;
@@ -2253,7 +2273,7 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
     if (!B->leader) return 0;
     for (int r = 0; r < R; r++) if (!B->failed[r]) {
         const char* why = "";
-        if (!batch_congruent(B->leader, B->eng[r], &why)) { B->err = std::string("replicas of a batch must be congruent; they differ in ") + why; return 1; }
+        if (!batch_congruent_cached(B, r, B->leader, &why)) { B->err = std::string("replicas of a batch must be congruent; they differ in ") + why; return 1; }
     }
     if (batch_refresh_args(B)) return 1;
     // phase(f): run f on every live member, in lock step when their signatures agree
@@ -2314,8 +2334,25 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
             int edited = 0;
             for (int r = 0; r < R; r++) if (!B->failed[r]) { const BluesEngine* m = B->eng[r]; edited += m->h_step > 0 && m->h_step < m->nsteps && m->h_first_step >= 1 && m->x_edited && m->unpert_valid; }
             if (edited > 1 && batch_prefetch(B, 1)) return 1;
+            B->defer_work = edited > 1;
         }
         for (int r = 0; r < R; r++) if (!B->failed[r] && step_head(B->eng[r])) fail(r);
+        if (B->defer_work) {
+            // the members' work increments in one launch (member by member it was a 1-thread launch each: 11 ms of host time for
+            // 1024 chains at the head of the step after a Move, with the device idle)
+            B->defer_work = false;
+            B->h_wacc.assign(R, nullptr); B->h_wdelta.assign(R, 0.0);
+            int any = 0;
+            for (int r = 0; r < R; r++) { BluesEngine* m = B->eng[r]; if (m->work_pending_set) { B->h_wacc[r] = m->d_acc.p; B->h_wdelta[r] = m->work_pending; any++; m->work_pending = 0.0; m->work_pending_set = false; } }
+            if (any) {
+                try { if ((int)B->d_wacc.n != R) { B->d_wacc.reserve(R); B->d_wdelta.reserve(R); } } catch (std::string& e) { B->err = e; return 1; }
+                hipStream_t st = B->stream;
+                if (hipMemcpyAsync(B->d_wacc.p, B->h_wacc.data(), sizeof(DevAccum*) * R, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipMemcpyAsync(B->d_wdelta.p, B->h_wdelta.data(), sizeof(double) * R, hipMemcpyHostToDevice, st) != hipSuccess) { B->err = "upload of the work increments failed"; return 1; }
+                hipLaunchKernelGGL(k_add_work_b, dim3((R + 255) / 256), dim3(256), 0, st, reinterpret_cast<DevAccum* const*>(B->d_wacc.p), B->d_wdelta.p, R);
+                if (hipGetLastError() != hipSuccess) { B->err = "k_add_work_b launch failed"; return 1; }
+            }
+        }
         if (phase(step_body)) return 1;
     }
     if (phase(flush_program)) return 1;
@@ -3518,7 +3555,7 @@ int blues_batch_set_velocities_to_temperature(BluesBatch* B, double temperature,
         B->leader = lead;
         bool uniform = true;
         const BatchSig ls = batch_sig(lead);
-        for (int r = 0; r < R && uniform; r++) if (!B->failed[r]) { const BatchSig g = batch_sig(B->eng[r]); const char* why = ""; uniform = !memcmp(&g, &ls, sizeof g) && batch_congruent(lead, B->eng[r], &why); }
+        for (int r = 0; r < R && uniform; r++) if (!B->failed[r]) { const BatchSig g = batch_sig(B->eng[r]); const char* why = ""; uniform = !memcmp(&g, &ls, sizeof g) && batch_congruent_cached(B, r, lead, &why); }
         if (uniform && batch_refresh_args(B)) rc = 1;
         if (!rc) {
             B->lockstep = uniform;

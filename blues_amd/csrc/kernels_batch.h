@@ -325,6 +325,12 @@ __global__ void __launch_bounds__(256) k_maxwell_b(const MaxwellArgs* __restrict
     if (a.mass[i] != 0.0) { gaussians3(a.seed, a.stream, 0u, (unsigned)i, g); const double s = sqrt(a.kT / a.mass[i]); g[0] *= s; g[1] *= s; g[2] *= s; }
     a.v[0][i] = g[0]; a.v[1][i] = g[1]; a.v[2][i] = g[2];
 }
+// protocol_work += delta of every member that has one (the work of an instantaneous Move, booked at the head of the next step:
+// reference blues/integrators.py:184-191) -- one launch instead of one per member
+__global__ void k_add_work_b(DevAccum* const* __restrict__ acc, const double* __restrict__ delta, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R && acc[r]) acc[r]->protocol_work += delta[r];
+}
 __global__ void k_zero_acc_b(DevAccum* const* __restrict__ acc, int R) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < R && acc[r]) { DevAccum z; z.protocol_work = z.dE_last = z.heat = 0.0; z.e_slot[0] = z.e_slot[1] = z.e_slot[2] = 0.0; *acc[r] = z; }
