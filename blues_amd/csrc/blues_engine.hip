@@ -1129,8 +1129,9 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
         if (lead) {
             const int nrep = h->batch->R();
             const AlchDyn D = make_alch_dyn(A);
-#define DENSE_B(M) do { hipLaunchKernelGGL((k_alchemical_dense_b<M>), dim3(nrep), dim3(K2D_THREADS), lds, h->cur, h->batch->d_core.p, D); \
-                        hipLaunchKernelGGL((k_alchemical_b<true, M>), dim3(nrep), dim3(256), 0, h->cur, h->batch->d_core.p, D, 1, nrep, (const int*)nullptr); } while (0)
+            // (part 3: the alchemical x alchemical block only; part 4: the dense kernel only -- force_pass, fork mode 3)
+#define DENSE_B(M) do { if (part != 3) hipLaunchKernelGGL((k_alchemical_dense_b<M>), dim3(nrep), dim3(K2D_THREADS), lds, h->cur, h->batch->d_core.p, D); \
+                        if (part != 4) hipLaunchKernelGGL((k_alchemical_b<true, M>), dim3(nrep), dim3(256), 0, h->cur, h->batch->d_core.p, D, 1, nrep, (const int*)nullptr); } while (0)
             if (slot_mask == 5) DENSE_B(5); else if (slot_mask == 2) DENSE_B(2); else DENSE_B(-1);
 #undef DENSE_B
         } else {
@@ -1513,10 +1514,16 @@ static int force_pass(BluesEngine* h, int base_L) {
     const int fork_mode = h->batch ? h->batch->tune.fork : h->tune.fork;   // 2: also with the dense alchemical kernel, joined BEFORE the nonbonded kernel
     const bool fork_env = fork_mode != 0;
     const bool decomposed = !(h->fuse_forces && h->wpb == 4) && !(h->k1_mode == 1 && h->precision == 0 && h->fuse_big);
-    // (not with the dense alchemical kernel: one 512-thread workgroup with ~137 KB of LDS per chain cannot share a CU with the
-    // nonbonded kernel's, and beside the rebuild's small workgroups it runs at half speed -- round 3 timelines: 516 us per step with
-    // every kernel alone against 540 with the dense kernel on the side stream)
-    const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && (!h->k2_dense || fork_mode == 2) && !h->alch.empty() && !h->ctrl_arg;
+    // (round 3 kept the dense alchemical kernel off the side stream: a 512-thread workgroup with ~137 KB of LDS per chain cannot share a
+    // CU with the nonbonded kernel's, and beside the rebuild's small workgroups it ran at half speed: 516 us per step with every kernel
+    // alone against 540)
+    const bool fork = fork_env && decomposed && batch_lead(h) && h->k1_mode == 2 && !h->alch.empty() && !h->ctrl_arg;
+    // with the dense alchemical kernel only the two SMALL kernels of a pass go to the side stream (alchemical x alchemical block,
+    // bonded entries + the next step's noise: 54 us per 1024 chains, 168 / 70 registers, 37 KB / no LDS) -- they run beside the
+    // builder of the atoms' lists (85 us, no LDS, 94 registers) and are done before it: 756 -> 716 us per step of 1024 chains.
+    // The dense kernel itself beside that builder (fork = 2) gains nothing; beside the GROUP-list builder the small kernels cost
+    // it what they saved (round 4, first half).
+    const bool small_side = fork && h->k2_dense && fork_mode != 2;
     if (fork && ensure_side(h)) return 1;
     // k2_early (off by default): the alchemical kernel of the members that do NOT rebuild needs nothing from the rebuild and can
     // start as soon as the work list says who they are, with the rebuild kernels on a high-priority stream beside it and the
@@ -1546,9 +1553,10 @@ static int force_pass(BluesEngine* h, int base_L) {
         if (rc) return 1;
         if (early) { HIP_OK(h, hipEventRecord(h->evB, rb)); wait_lists = true; }
 #undef LISTS
-        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, early ? 2 : 0) || launch_bonded(h, true); h->cur = main_stream;   // (bonded terms and the next O step's noise need no list either)
+        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, small_side ? 3 : (early ? 2 : 0)) || launch_bonded(h, true); h->cur = main_stream;   // (bonded terms and the next O step's noise need no list either)
         if (rc) return 1;
         HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
+        if (small_side && launch_alchemical(h, ls, le, fmask, 4)) return 1;   // (the dense kernel follows the atoms' lists on the main stream)
         if (wait_lists) HIP_OK(h, hipStreamWaitEvent(main_stream, h->evB, 0));
     } else {
         rc = h->precision == 0 ? launch_lists<float>(h, h->lists_forced, 0) : launch_lists<double>(h, h->lists_forced, 0);

@@ -180,8 +180,9 @@ typedef struct BluesTuning {
     int32_t fuse_big;          /* -1 auto (off) */
     int32_t fast_step;         /* -1 auto (on): straight-line step kernels */
     int32_t slot_mask;         /* -1 auto; else the lambda slots whose force a pass produces */
-    int32_t fork;              /* 1 (default): a batch runs the alchemical / bonded kernels on a side stream (not the dense alchemical kernel);
-                                * 0: every kernel alone; 2: the dense kernel too, joined before the nonbonded kernel (measured: no gain) */
+    int32_t fork;              /* 1 (default): a batch runs the alchemical / bonded kernels on a side stream beside the builder of the atoms'
+                                * lists -- of a pass with the dense alchemical kernel only the two small ones (alchemical x alchemical block,
+                                * bonded entries); 0: every kernel alone; 2: the dense kernel too, joined before the nonbonded kernel (no gain) */
     int32_t use_graph;         /* -1 auto (off): hipGraph replay of the steady-state step of a lone engine */
     int32_t graph_units;       /* 0 auto */
     int32_t graph_fork;        /* -1 auto (off) */
