@@ -16,6 +16,7 @@ except Exception as e:
     print("== $name failed:", e); print(open("$out/$name.log").read()[-1500:])
 PY
 }
+if [ -z "$OTHERS_ONLY" ]; then   # (OTHERS_ONLY=1: only the other configurations below; the default line and what has to agree with it come from evidence_r04_default.sh)
 run bench_R2048_G2
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-single > $out/stats.log 2>&1
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats_R2048_G2.csv 2>/dev/null; rm -rf $out/stats
@@ -26,11 +27,12 @@ for r in list(csv.DictReader(open("$out/kernel_stats_R2048_G2.csv")))[:14]:
 PY
 bash scripts/pmc_nb.sh r04 > $out/pmc.log 2>&1; cp gpurun_out/pmc_r04/pmc_nonbonded.json $out/pmc_nonbonded.json 2>/dev/null; cp $out/pmc_nonbonded.json profiles/r04_pmc_nonbonded.json 2>/dev/null; tail -3 $out/pmc.log | head -2
 run bench_R2048_G2_with_counters --no-cpu --no-single        # (the same line once the counters of this build are on disk: roofline.valu / traffic filled in)
+fi
 run water_R1 --workload water --replicas 1 --steps 2 --warmup 1 --no-cpu --no-single
 run water_R16 --workload water --replicas 16 --groups 1 --steps 2 --warmup 1 --no-cpu --no-single
 run sidechain_R64 --workload sidechain --replicas 64 --groups 1 --nsteps-nc 5000 --steps 2 --warmup 1 --no-cpu --no-single
 run reciprocal_R512 --reciprocal --replicas 512 --groups 1 --steps 2 --warmup 1 --no-cpu --no-single
 run bench_R512 --replicas 512 --groups 1 --no-cpu --no-single
-run bench_R1024 --replicas 1024 --groups 1 --no-cpu --no-single
+run bench_R1024_steps3 --replicas 1024 --groups 1 --no-cpu --no-single
 run bench_R2048 --replicas 2048 --groups 1 --steps 2 --no-cpu --no-single
 run bench_R2048_G4 --replicas 2048 --groups 4 --concurrent --steps 2 --no-cpu --no-single     # four replica batches of 512 on four streams (the nonbonded kernel's duration then includes its co-runners)
