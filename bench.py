@@ -33,8 +33,11 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_ATOM = 36.0     # x,y,z + q,sigma,eps read, fx,fy,fz written, per force evaluation
 
 
-def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False):
-    """R independent BLUES chains on this rank's GPU: own integrator (Philox key), context, move engine, state table."""
+def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False, md_steps=0, with_alch=True):
+    """R independent BLUES chains on this rank's GPU: own integrator (Philox key), context, move engine, state table.
+    md_steps > 0: every chain gets the reference's full triple (blues/simulation.py:768-809): the NCMC Simulation on the alchemical
+    (frozen) System, an MD Simulation (openmm.LangevinIntegrator, reference simulation.py:647) and an `alch` Simulation, both on
+    the UNFROZEN, non-alchemical System."""
     from blues_amd import integrators, moves, simulation, systems
     from blues_amd.context import Simulation
     from blues_amd.replicas import replica_seed
@@ -63,13 +66,25 @@ def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False):
         make_move = lambda gid: moves.RandomLigandRotationMove(lig, system.mass[lig], random_state=1000 + gid)
     if reciprocal:   # nonbondedMethod=PME in full: mesh + self + excluded-pair + dispersion terms
         system = systems.with_reciprocal_space(system)
+    md_system = None
+    if md_steps > 0:
+        md_system = systems.s23k(frozen=False, restrained=40 if workload == "water" else 0)[0]
+        md_system = copy.copy(md_system)
+        md_system.alchemical_atoms = np.zeros(0, np.int32)
+        if reciprocal:
+            md_system = systems.with_reciprocal_space(md_system)
     chains = []
     for c in range(R):
         gid = rank * R + c   # global chain index
         integ = integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=DT_PS, temperature=300.0, seed=replica_seed(1234, gid))
         sim = Simulation(None, system, integ, device=local_rank, precision="mixed", replica=gid)
         mover = moves.MoveEngine(make_move(gid))
-        chains.append(simulation.BLUESSimulation(simulation.SimulationSet(sim), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": 1}, mover))
+        md = alch = None
+        if md_system is not None:
+            md = Simulation(None, md_system, integrators.LangevinIntegrator(300.0, 1.0, DT_PS, seed=replica_seed(4321, gid)), device=local_rank, precision="mixed", replica=gid)
+            if with_alch:
+                alch = Simulation(None, md_system, integrators.LangevinIntegrator(300.0, 1.0, DT_PS, seed=replica_seed(8765, gid)), device=local_rank, precision="mixed", replica=gid)
+        chains.append(simulation.BLUESSimulation(simulation.SimulationSet(sim, md=md, alch=alch), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": 1, "nstepsMD": md_steps}, mover))
     return system, vel, chains
 
 
@@ -129,6 +144,38 @@ def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
         each(lambda r, c: c._resetSimulations(300.0))
     t3 = time.perf_counter()
     clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2
+    return recs
+
+
+def one_iteration(driver, chains, nsteps, md_steps, it, clock):
+    """One FULL BLUES iteration of every chain, as BLUESSimulation.run does it (reference blues/simulation.py:1215-1257):
+    _syncStatesMDtoNCMC -> _stepNCMC -> _acceptRejectMove -> (gather) -> _resetSimulations -> _stepMD on the unfrozen MD System."""
+    from blues_amd.replicas import gather_decision_block
+    fast = driver._batchable()
+    t0 = time.perf_counter()
+    for c in chains:
+        c.currentIter = it
+    if fast:
+        driver._sync_batched()
+    else:
+        (driver._md_batch or driver._ncmc_batch).prefetch_energies(at_lambda_one=driver._md_batch is None)
+        driver.for_each_chain(lambda r, c: c._syncStatesMDtoNCMC())
+    t1 = time.perf_counter()
+    driver._stepNCMC(nsteps, nsteps // 2, batchable=fast)
+    t2 = time.perf_counter()
+    if fast:
+        driver._decide_batched(300.0)
+    else:
+        driver.for_each_chain(lambda r, c: c._acceptRejectMove())
+    recs = gather_decision_block(np.array([[c.last["accept"], it, c.last["log_accept"], c.last["protocol_work"], c.last["correction"]] for c in chains], dtype=np.float64))
+    if fast:
+        driver._reset_batched(300.0)
+    else:
+        driver.for_each_chain(lambda r, c: c._resetSimulations(300.0))
+    t3 = time.perf_counter()
+    driver._stepMD(md_steps)
+    t4 = time.perf_counter()
+    clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2; clock["md"] = clock.get("md", 0.0) + t4 - t3
     return recs
 
 
@@ -290,6 +337,10 @@ def main():
     ap.add_argument("--nsteps-nc", type=int, default=NSTEPS_NC)
     ap.add_argument("--workload", default="rotmove", choices=["rotmove", "water", "sidechain"],
                     help="rotmove = the benchmark (configs[1]); water / sidechain = full-size runs of configs[3] / configs[4]")
+    ap.add_argument("--md-steps", type=int, default=0, help="> 0: time the reference's FULL iteration (blues/simulation.py:1215-1257): every chain carries the md / alch / ncmc "
+                    "triple, and each timed step is sync -> NCMC switch -> Metropolis -> reset -> this many MD steps on the unfrozen System.  `value` stays the "
+                    "NCMC leg's ns/day (its share of the wall time); `full_iteration` has both legs.  Use --replicas 16..256 --groups 1 (an all-mobile engine is ~60 MB)")
+    ap.add_argument("--no-alch", action="store_true", help="with --md-steps: no `alch` Simulation (the correction's energies then come from the NCMC engine at lambda = 1)")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-chain measurement")
@@ -349,7 +400,7 @@ def main():
     # the chains are laid out from the start as members of the batch they are about to join (BluesTuning.assume_batch: the layout a
     # batch of that size gives its members anyway), so that forming the batch re-lays nobody out: set-up time, nothing else
     with tuning.override(assume_batch=(R + G0 - 1) // G0):
-        system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R, reciprocal=args.reciprocal)
+        system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R, reciprocal=args.reciprocal, md_steps=args.md_steps, with_alch=not args.no_alch)
     x0 = system.positions.copy()
     v0 = vel.copy()
     setup_parts = {"chains": time.perf_counter() - t_setup}
@@ -357,7 +408,7 @@ def main():
     # ---- configs[1] to the letter: ONE chain on the GPU, a lone engine with a lone engine's layout (its own construction, default tuning)
     single = None
     t_single = time.perf_counter()
-    if rank == 0 and not args.no_single:
+    if rank == 0 and not args.no_single and not args.md_steps:
         clock = {"sync": 0.0, "switch": 0.0, "decide": 0.0}
         _, _, lone = build_chains(rank, local_rank, nsteps, args.workload, 1, reciprocal=args.reciprocal)
         st1 = md_states(lone, x0, v0)
@@ -389,17 +440,32 @@ def main():
     if G > 1:   # chains driven from different threads draw from their own streams (reproducible whatever the interleaving)
         for c in chains:
             c._rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1))
-    gstates = [md_states(grp, x0, v0, batch=drv._ncmc_batch) for grp, drv in zip(groups, drivers)]
+    full = args.md_steps > 0
+    if full:
+        # the full iteration: the chains' MD contexts own the state (reference simulation.py:1028-1037 copies it to the NCMC context at
+        # the head of every iteration); a short MD leg per chain before the timed iterations gives every chain its own state
+        if G != 1:
+            sys.stderr.write("bench.py: --md-steps runs one replica batch per rank (--groups 1)\n"); sys.exit(2)
+        from blues_amd import unit
+        for c in chains:
+            c._md_sim.context.setPositions(unit.Quantity(x0, "nanometer")); c._md_sim.context.setVelocities(unit.Quantity(v0, "nanometer/picosecond"))
+        gstates = [None]
+    else:
+        gstates = [md_states(grp, x0, v0, batch=drv._ncmc_batch) for grp, drv in zip(groups, drivers)]
     setup_parts["hand_over_states"] = time.perf_counter() - t_part
     t_setup = time.perf_counter() - t_setup - t_single
     clocks = [{"sync": 0.0, "switch": 0.0, "decide": 0.0} for _ in range(G)]
 
     def switch_group(g, it):
+        if full:
+            return one_iteration(drivers[g], groups[g], nsteps, args.md_steps, it, clocks[g])
         return one_switch(drivers[g], groups[g], gstates[g], nsteps, it, clocks[g], gather=False)
 
     from blues_amd.replicas import gather_decision_block
 
     def switch_all(it):
+        if full:
+            return switch_group(0, it)
         return gather_decision_block(np.concatenate([switch_group(g, it) for g in range(G)]))
 
     for w in range(args.warmup):
@@ -407,7 +473,7 @@ def main():
     engs = [c._ncmc_sim.context._engine for c in chains]
     st0 = engs[0].stats(); b0 = [d._ncmc_batch.stats() for d in drivers]
     for ck in clocks:
-        ck.update({"sync": 0.0, "switch": 0.0, "decide": 0.0})
+        ck.update({"sync": 0.0, "switch": 0.0, "decide": 0.0, "md": 0.0})
     # the nonbonded kernel is timed WHERE IT RUNS: every 4th force launch of the timed switches is bracketed by two HIP events on
     # the batch's stream (blues_batch_kernel_timing); that mean is roofline.usec_per_launch, what rocprofv3 averages for the same loop
     timing_batch = None if args.no_kernel_timing or not hasattr(drivers[0]._ncmc_batch, "kernel_timing") else drivers[0]._ncmc_batch
@@ -476,6 +542,23 @@ def main():
         n_atoms = system.n_atoms
         ms_per_step = 1e3 * elapsed / args.steps
         ns_day = world * R * args.steps * nsteps * DT_PS * 1e-3 / (elapsed / 86400.0)
+        full_iteration = None
+        if full:
+            # `value` keeps BASELINE.json's definition (the switching leg: state sync + _stepNCMC + Metropolis + reset, MD leg excluded,
+            # SURVEY.md 8d) -- here from the legs' clocks of the full iterations; both legs together are in full_iteration
+            t_ncmc = (clock["sync"] + clock["switch"] + clock["decide"]) / args.steps
+            t_md = clock["md"] / args.steps
+            mde = chains[0]._md_sim.context._engine.stats()
+            full_iteration = {"ns_day_both_legs": world * R * args.steps * (nsteps + args.md_steps) * DT_PS * 1e-3 / (elapsed / 86400.0),
+                              "ns_day_md_leg": world * R * args.md_steps * DT_PS * 1e-3 / (t_md / 86400.0) if t_md > 0 else None,
+                              "ms_sync": 1e3 * clock["sync"] / args.steps, "ms_ncmc": 1e3 * clock["switch"] / args.steps, "ms_boundary": 1e3 * clock["decide"] / args.steps,
+                              "ms_md": 1e3 * t_md, "md_steps": args.md_steps, "ncmc_share_of_wall": t_ncmc / (t_ncmc + t_md),
+                              "us_per_chain_step_md": 1e6 * t_md / (R * args.md_steps), "us_per_chain_step_ncmc": 1e6 * clock["switch"] / args.steps / (R * nsteps),
+                              "md_engine": {"nonbonded_kernel": mde["nonbonded_kernel"], "list_builds": mde["list_builds"], "chain_prunes": mde["atom_prunes"], "force_passes": mde["force_passes"]},
+                              "triple": "md + alch + ncmc Simulations per chain" if chains[0]._alch_sim is not None else "md + ncmc Simulations per chain",
+                              "reference": "blues/simulation.py:1215-1257 (run), 1189-1213 (_stepMD), 768-809 (the triple)"}
+            ns_day = world * R * nsteps * DT_PS * 1e-3 / (t_ncmc / 86400.0)
+            ms_per_step = 1e3 * elapsed / args.steps
         algo = ALGO_BYTES_PER_ATOM * n_atoms * R_launch
         last = np.asarray(recs[-1])
         # ---- roofline block of the dominant kernel.  north_star prices it against HBM with 36 B per atom per force evaluation
@@ -492,7 +575,7 @@ def main():
           in_loop = k1_loop is not None and k1_loop["launches"] > 0
           roofline = {"bound": "valu" if ev else "valu (counters not taken on this build: see profiles/README.md)",
                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                      "kernel": "%s (direct-space LJ + erfc Coulomb; one launch = %d chains; %s)" % ({0: "k_nonbonded_b", 1: "k_nonbonded_sub_b", 2: "k_nonbonded_atom_b"}[est["nonbonded_kernel"]], R_launch,
+                      "kernel": "%s (direct-space LJ + erfc Coulomb; one launch = %d chains; %s)" % ({0: "k_nonbonded_b", 1: "k_nonbonded_sub_b", 2: "k_nonbonded_atom_b", 3: "k_nonbonded_frag_b"}[est["nonbonded_kernel"]], R_launch,
                                  "HIP events around every 4th force launch of the timed switches, on the stream the kernel runs on" if in_loop else "timed alone with HIP events"),
                       "usec_per_launch": k1_us, "timed": "in the stepping loop" if in_loop else "alone",
                       "launches_timed": k1_loop["launches"] if in_loop else 50, "usec_longest_launch": k1_loop["usec_max"] if in_loop else None,
@@ -524,7 +607,8 @@ def main():
             "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 pair math / f64 accumulation, f64 alchemical+integrator", "data": "synthetic",
-            "data_note": "every chain starts every switch from the same coordinates and velocities (its Philox stream differs): rebuild statistics are those of the first 4 ps from one geometry",
+            "data_note": ("every chain carries its own state from its own MD legs (the warm-up iterations included one)" if full else
+                          "every chain starts every switch from the same coordinates and velocities (its Philox stream differs): rebuild statistics are those of the first 4 ps from one geometry"),
             "nonbonded_method": "PME direct space only" if system.nonbonded_method == 1 else "PME direct + reciprocal space (mesh %dx%dx%d, order %d), dispersion correction %s" % (tuple(system.pme_grid) + (system.pme_order, "on" if system.dispersion_correction else "off")),
             "config": {"workload": "S23k %s: %d atoms, %d mobile, %d alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in %d replica batch(es)"
                        % (args.workload, n_atoms, int((system.mass > 0).sum()), len(system.alchemical_atoms), nsteps, R, G),
@@ -532,6 +616,7 @@ def main():
                        "parallelism": "%d replica batch(es) x %d chains per gpu%s, %d gpu(s)" % (G, R_launch, "" if G == 1 else (" taking turns on the device" if turn is not None else " sharing the device"), world),
                        "batches_take_turns": turn is not None},
             "roofline": roofline,
+            "full_iteration": full_iteration,
             "single_replica": single,
             "rank_elapsed_seconds": rank_elapsed,
             "process_group": {"backend": (args.backend if world > 1 else None), "same_device": bool(args.same_device),

@@ -202,7 +202,13 @@ struct BluesEngine {
     int seg_len = 64, waves_tile = 4, wpb = 4, npart = 1;  // K1 decomposition
     bool fuse_forces = false, fast_step = true, fuse_big = false;  // fuse_big: measured slower (the alchemical role's 140 VGPRs and 36 KB LDS cap the occupancy of the nonbonded role)
     int k1_iw = 64;  // i-atoms per wave in the nonbonded kernel: 64 = classic tile kernel, 8/16 = sub-tile throughput kernel
-    int k1_mode = 0;  // 0: tile kernel (lane = i-atom), 1: sub-tile kernel, 2: per-atom Verlet lists + LDS tile image (nonbonded_atom_body)
+    int k1_mode = 0;  // 0: tile kernel (lane = i-atom), 1: sub-tile kernel, 2: per-atom Verlet lists + LDS tile image (nonbonded_atom_body), 3: fragment lists (kernels_frag.h)
+    // fragment lists (every environment atom mobile): the static cut of the environment into fragments of <= 3 atoms
+    // (build_fragments), the layout of the current sort, the lists
+    std::vector<std::array<int, 3>> frag_atoms; std::vector<int> frag_cnt, frag_of_atom, frag_pos_of_atom; bool frag_ok = false;
+    std::vector<int> sp_start_h; std::vector<int2> sp_ent_h;
+    int frag_F = 0, frag_NI = 0, frag_nblk = 0, frag_ocap = 0, frag_icap = 0, frag_fpw = 1, frag_nwg = 0; double frag_m = 0.0; DBuf<int> d_ifrag;
+    DBuf<FragRec> d_fimg; DBuf<float2> d_ljtab; int frag_ntypes = 0; DBuf<int> d_sp_start, d_ocount, d_icount; DBuf<int2> d_sp_ent; DBuf<FragBox> d_fbb; DBuf<unsigned> d_olist, d_ilist, d_xprune_s;
     int acap = 0;     // capacity of one atom's list (mode 2)
     // layout shape of the per-atom-list mode.  A lone engine derives (S, jcap) from its own geometry at every re-sort; members
     // of a batch must stay congruent, so the batch fixes the shape for all of them (shape_S > 0) and re-plans it for
@@ -285,6 +291,8 @@ struct BluesBatch {
     // as one rebuild whoever asks; when they all rebuild together (any request rebuilds all) most steps see no rebuild at all
     DBuf<int> d_req; bool sync_lists = false;
     DBuf<int> d_work;   // [1 + 2R] members that rebuild their lists in the current force pass (kernels_batch.h: k_gather_stale_b)
+    bool replanning = false;   // inside batch_plan_shape on behalf of a member (ensure_sorted)
+    DBuf<int> d_work_frag;   // [1 + R] fragment lists: members that rebuild or prune in the current pass (k_gather_frag_b)
     BluesTuning tune;   // the process-wide tuning at the time the batch was created
     // argument arena of the batched boundary calls (blues_batch_capture ...): pinned host side, device side, one upload per call
     unsigned char* h_arena = nullptr; size_t arena_cap = 0; DBuf<unsigned char> d_arena;
@@ -419,6 +427,72 @@ template <typename R> static NbConst<R> make_nbconst(const BluesEngine* h) {
     c.rp2 = (float)((h->cutoff + h->prune_m) * (h->cutoff + h->prune_m)) * 1.00001f; c.rp2_m = (float)((h->cutoff + h->trig + h->prune_m) * (h->cutoff + h->trig + h->prune_m)) * 1.00001f;   // (from the candidate's BUILD position: derive_margins)
     c.ew = h->ewpoly;
     return c;
+}
+
+// ------------------------------------------------------------------ fragments (kernels_frag.h), once per engine
+// The environment (every atom that is not alchemical) cut into fragments of up to three atoms: a molecule's atoms in
+// breadth-first order over its bonds and constraints, three at a time -- a rigid water is one fragment, consecutive atoms of a
+// solute are a bond or two apart.  With them the static table of fragment pairs that hold an excluded atom pair (and of every
+// fragment with itself): the 9-bit masks the list builder copies into such entries.
+static void build_fragments(BluesEngine* h, const BluesSystemDesc* s) {
+    const int n = h->n;
+    std::vector<std::vector<int>> adj(n);
+    auto link = [&](int a, int b) { if (a >= 0 && b >= 0 && a < n && b < n && a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
+    for (int e = 0; e < s->n_bonds; e++) link(s->bond_atoms[2 * e], s->bond_atoms[2 * e + 1]);
+    for (int e = 0; e < s->n_constraints; e++) link(s->constraint_atoms[2 * e], s->constraint_atoms[2 * e + 1]);
+    h->frag_atoms.clear(); h->frag_cnt.clear();
+    h->frag_of_atom.assign(n, -1); h->frag_pos_of_atom.assign(n, 0);
+    std::vector<char> seen(n, 0);
+    std::vector<int> order;
+    for (int i = 0; i < n; i++) {
+        if (seen[i] || h->alch_local[i] >= 0) continue;
+        order.clear(); order.push_back(i); seen[i] = 1;
+        for (size_t q = 0; q < order.size(); q++) {
+            std::vector<int>& nb = adj[order[q]];
+            std::sort(nb.begin(), nb.end());
+            for (int b : nb) if (!seen[b] && h->alch_local[b] < 0) { seen[b] = 1; order.push_back(b); }
+        }
+        for (size_t q = 0; q < order.size(); q += 3) {
+            std::array<int, 3> fr = {-1, -1, -1};
+            int c = 0;
+            for (; c < 3 && q + c < order.size(); c++) { fr[c] = order[q + c]; h->frag_of_atom[order[q + c]] = (int)h->frag_atoms.size(); h->frag_pos_of_atom[order[q + c]] = c; }
+            h->frag_atoms.push_back(fr); h->frag_cnt.push_back(c);
+        }
+    }
+    const int F = (int)h->frag_atoms.size();
+    auto colmask = [](int cnt) { return cnt >= 3 ? 0x1ffu : (cnt == 2 ? 0x0DBu : 0x049u); };
+    auto rowmask = [](int cnt) { return cnt >= 3 ? 0x1ffu : (cnt == 2 ? 0x03Fu : 0x007u); };
+    std::vector<std::map<int, unsigned>> sp(F);
+    for (int fa = 0; fa < F; fa++) {
+        unsigned self = colmask(h->frag_cnt[fa]);
+        for (int a = 0; a < 3; a++) self &= ~(1u << (4 * a));   // an atom with itself
+        sp[fa][fa] = self;
+    }
+    for (int fa = 0; fa < F; fa++)
+        for (int a = 0; a < h->frag_cnt[fa]; a++)
+            for (int p : h->excl[h->frag_atoms[fa][a]]) {
+                const int fb = h->frag_of_atom[p];
+                if (fb < 0) continue;   // (an alchemical partner: the alchemical kernel's pair)
+                auto it = sp[fa].find(fb);
+                if (it == sp[fa].end()) it = sp[fa].emplace(fb, colmask(h->frag_cnt[fb])).first;
+                it->second &= ~(1u << (3 * a + h->frag_pos_of_atom[p]));
+            }
+    h->sp_start_h.assign(F + 1, 0); h->sp_ent_h.clear();
+    h->frag_ok = F > 0 && F < (1 << FR_MASK_SHIFT);
+    {   // (the fragment kernel keeps the environment's Lennard-Jones types in a table of FR_TYPES_MAX entries; one more for absent atoms)
+        std::map<std::pair<float, float>, int> types;
+        for (int i = 0; i < n; i++) if (h->alch_local[i] < 0) types[{(float)(0.5 * h->sigma[i]), (float)(2.0 * std::sqrt(h->eps[i]))}] = 1;
+        if ((int)types.size() + 1 > FR_TYPES_MAX) h->frag_ok = false;
+    }
+    for (int fa = 0; fa < F; fa++) {
+        for (auto& kv : sp[fa]) {
+            unsigned m = kv.second;
+            if (!(m & rowmask(h->frag_cnt[fa]))) m = 0u;   // no live pair among the atoms this fragment has
+            h->sp_ent_h.push_back(make_int2(kv.first, (int)m));
+        }
+        h->sp_start_h[fa + 1] = (int)h->sp_ent_h.size();
+        if (h->sp_start_h[fa + 1] - h->sp_start_h[fa] > FR_SP_MAX) h->frag_ok = false;
+    }
 }
 
 // ------------------------------------------------------------------ topology set-up (once)
@@ -592,11 +666,29 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
 static int sort_and_tile(BluesEngine* h) {
     SetupTimer tm_all(1);
     const int n = h->n;
-    std::vector<std::pair<uint32_t, int>> keys(n);
-    for (int i = 0; i < n; i++) {
+    // fragment lists (kernels_frag.h) where every environment atom moves: mixed precision, more than the lone-chain handful of tiles
+    // fragment lists (kernels_frag.h), mixed precision: where every environment atom moves (more than the lone-chain handful of
+    // tiles); where the per-atom lists over group images cannot hold the system (forbid_atom: the mobile atoms of an NCMC System
+    // have scattered over MD legs, reference blues/simulation.py:1028-1037 hands such a State over every iteration); on request
+    bool want_frag = false;
+    {
+        size_t mobile_env = 0; for (int o : h->mobile) mobile_env += h->alch_local[o] < 0;
+        const int nit = ((int)mobile_env + 63) / 64;
+        const bool all_mobile = mobile_env + h->alch.size() == (size_t)n;
+        want_frag = h->frag_ok && h->precision == 0 && mobile_env > 0 && h->tune.k1_mode != 1 && h->tune.k1_mode != 2
+                    && (h->tune.k1_mode == 3 || h->forbid_atom || (all_mobile && nit * h->batch_R > 32));
+    }
+    std::vector<std::pair<uint64_t, int>> keys(n);
+    auto hkey = [&](int i) {
         uint32_t c[3];
         for (int k = 0; k < 3; k++) { double fr = h->hx[3 * i + k] / h->box[k]; fr -= std::floor(fr); c[k] = std::min<uint32_t>(1023u, (uint32_t)(fr * 1024.0)); }
-        keys[i] = {hilbert3(c[0], c[1], c[2], 10), i};
+        return (uint64_t)hilbert3(c[0], c[1], c[2], 10);
+    };
+    for (int i = 0; i < n; i++) {
+        // (fragment lists: a fragment's atoms stay together, in fragment order, at the place of its first atom)
+        const int fr = want_frag ? h->frag_of_atom[i] : -1;
+        if (fr >= 0) keys[i] = {(hkey(h->frag_atoms[fr][0]) << 32) | (uint64_t)((uint32_t)fr * 4u + (uint32_t)h->frag_pos_of_atom[i]), i};
+        else keys[i] = {(hkey(i) << 32) | 0xffffffffull, i};
     }
     std::stable_sort(keys.begin(), keys.end());
     h->h_orig_of_sorted.resize(n); h->h_sorted_of_orig.resize(n);
@@ -622,8 +714,18 @@ static int sort_and_tile(BluesEngine* h) {
         // (measured at R = 512, us per step: margin 0.12: 661, 0.14: 587, 0.16: 574, 0.20: 554, 0.24: 550, 0.28: 557 -- the rebuild
         // kernels cost in proportion to the members that rebuild, the pruned lists make the nonbonded kernel indifferent)
         h->skin = h->n_itiles * h->batch_R <= 32 ? 0.3 : (mostly_frozen && m > 0.0 ? 0.16 + m : 0.12);
+        // fragment lists: the outer list is cheap to keep long (4 bytes per nine pairs, walked only by the prune), a rebuild is not
+        // (measured at R = 16, us per chain-step: skin 0.3: 37.6, 0.4: 36.5, 0.5: 36.4 with 77 / 53 / 37 rebuilds per 1000 steps)
+        if (want_frag) h->skin = 0.40;   // (also where most atoms are frozen: the lists are a few hundred rows)
     }
     derive_margins(h);
+    if (want_frag) {   // plain Verlet margins (a frozen candidate gets half of them in the builder itself)
+        h->prune_on = false; h->prune_m = h->ptrig = 0.0; h->skin_m = h->skin; h->trig = 0.5 * h->skin;
+    }
+    if (want_frag) {   // inner margin of the dual fragment lists (kernels_frag.h); <= 0: the force kernel walks the outer lists
+        const double m = h->tune.prune_margin < 0.0 ? 0.13 : h->tune.prune_margin;   // (0.07: 37.9 us per chain-step, 0.10: 36.5, 0.13: 35.8, 0.16: 36.4 -- a list of 220-260 fragments is four chunks either way)
+        h->frag_m = m > 0.0 ? std::min(m, 0.6 * h->skin) : h->skin;
+    }
     // capacities
     const double rl = h->cutoff + h->skin;
     const double vol = h->box[0] * h->box[1] * h->box[2], rho = n / vol;
@@ -739,9 +841,21 @@ static int sort_and_tile(BluesEngine* h) {
             }
         }
     }
+    if (!want_frag && h->k1_mode != 2 && h->k1_mode == 1 && h->tune.k1_mode < 0 && !h->forbid_atom && h->frag_ok && h->precision == 0 && h->shape_S == 0) {
+        // the per-atom lists were wanted and no group shape holds this system (scattered mobile atoms): fragment lists instead of the
+        // sub-tile kernel -- they need the fragment-wise sort, so once more from the top
+        h->forbid_atom = true;
+        return sort_and_tile(h);
+    }
+    if (want_frag) {
+        // fragment lists: no group lists but the alchemical tile's, whose capacity must not depend on the density (members of a
+        // batch keep their own boxes under a barostat and still have to agree on the launch geometry)
+        h->k1_mode = 3; h->S = 1; h->acap = 0; h->k1_iw = 64; h->seg_len = 64; h->waves_tile = 1; h->npart = 1; h->wpb = 4; h->fuse_forces = false;
+        jcap = h->alch.empty() ? 64 : std::min(((n + 63) / 64) * 64, 8192); h->jcap = jcap;
+    }
     h->hint_count = h->k1_mode == 2 ? h->jcap - h->jcap / 10 : h->jcap - h->jcap / 7;
     h->n_lists = (std::max(1, h->n_itiles) + h->S - 1) / h->S;
-    if (h->n_itiles == 0) h->n_lists = 0;
+    if (h->n_itiles == 0 || h->k1_mode == 3) h->n_lists = 0;
     h->n_tiles = h->n_lists + (h->alch.empty() ? 0 : 1);
     const int nt = std::max(1, h->n_tiles);
     h->pool_cap = nt * MASK_QUOTA;
@@ -761,7 +875,7 @@ static int sort_and_tile(BluesEngine* h) {
             for (int k = 0; k < 3; k++) { double d = h->hx[3 * h->alch[a] + k] - h->hx[3 * h->alch[0] + k]; d -= h->box[k] * std::rint(d / h->box[k]); r2 += d * d; }
             ext = std::max(ext, std::sqrt(r2));
         }
-        h->k2_dense = h->precision == 0 && h->k1_mode == 2 && !h->fuse_forces && h->batch_R >= 8 && !h->check_env_excl && !h->alch.empty() && h->alch.size() <= 16 &&
+        h->k2_dense = h->precision == 0 && (h->k1_mode == 2 || want_frag) && !h->fuse_forces && h->batch_R >= 8 && !h->check_env_excl && !h->alch.empty() && h->alch.size() <= 16 &&
                       mobile_env <= K2D_MOB && half_min > h->cutoff + ext + 0.3 && h->tune.k2_dense != 0;
         if (h->k2_dense) h->k2_jiter = 1 << 20;   // one logical env block: k2_env_blocks() = 1 wherever the partial slabs are summed
     }
@@ -846,7 +960,64 @@ static int sort_and_tile(BluesEngine* h) {
             h->d_pimg4.alloc((size_t)std::max(1, h->n_lists) * jcap); h->d_pimg2.alloc((size_t)std::max(1, h->n_lists) * jcap); h->d_pimgb.alloc((size_t)std::max(1, h->n_lists) * jcap);
             h->d_mlist.alloc((size_t)std::max(1, h->n_lists) * h->mcap * 2); h->d_mcount.alloc(std::max(1, h->n_lists));
         }
-        h->d_epart_nb.alloc((size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1)) + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
+        if (h->k1_mode == 3) {
+            // fragment layout of this sort: the fragments in image order, capacities from the fragment density
+            const int F = (int)h->frag_atoms.size();
+            // Lennard-Jones types of the environment: the distinct {sigma / 2, 2 sqrt(eps)} of the image, one byte per atom
+            std::vector<float2> ljt; std::map<std::pair<uint32_t, uint32_t>, int> type_of;
+            auto type_id = [&](const AtomF& A) {
+                uint32_t a, b; memcpy(&a, &A.hs, 4); memcpy(&b, &A.se, 4);
+                auto it = type_of.find({a, b});
+                if (it != type_of.end()) return it->second;
+                const int id = (int)ljt.size(); type_of[{a, b}] = id; ljt.push_back(make_float2(A.hs, A.se));
+                return id;
+            };
+            std::vector<FragRec> recs; recs.reserve(F); std::vector<int> ifrag;
+            for (int sx = 0; sx < n; sx++) {
+                const int o = h->h_orig_of_sorted[sx], fr = h->frag_of_atom[o];
+                if (fr < 0 || h->frag_pos_of_atom[o] != 0) continue;
+                FragRec r; memset(&r, 0, sizeof r);
+                const int cnt = h->frag_cnt[fr];
+                r.types = (unsigned)cnt << 24;
+                r.islot0 = -1;
+                for (int b = 0; b < cnt; b++) {
+                    const int ob = h->h_orig_of_sorted[sx + b];
+                    if (h->mass[ob] != 0.0) { r.types |= 1u << (26 + b); if (r.islot0 < 0) r.islot0 = islot[ob]; }
+                }
+                if (FR_MOB(r.types)) ifrag.push_back((int)recs.size());
+                for (int b = 0; b < 3; b++) {
+                    const AtomF& A = imf[sx + std::min(b, cnt - 1)];
+                    r.p[b] = make_uint4(A.x, A.y, A.z, b < cnt ? __builtin_bit_cast(unsigned, A.q) : 0u);
+                    AtomF G = A; if (b >= cnt) { G.hs = 0.0f; G.se = 0.0f; }   // (an atom the fragment does not have: no charge, no epsilon; the masks leave its pairs out anyway)
+                    r.types |= (unsigned)type_id(G) << (8 * b);
+                }
+                r.sid = fr; r.s0 = sx;
+                recs.push_back(r);
+            }
+            if ((int)recs.size() != F) E_FAIL(h, "internal: %zu fragments laid out, %d expected", recs.size(), F);
+            if ((int)ljt.size() > FR_TYPES_MAX) E_FAIL(h, "internal: %zu Lennard-Jones types exceed the fragment kernel's table", ljt.size());
+            h->frag_ntypes = (int)ljt.size();
+            const double rho_f = F / vol;
+            auto cap_for = [&](double margin) {
+                const double r = h->cutoff + margin + 0.16;   // (0.16: two fragment radii of a water)
+                double c = rho_f * 4.0 / 3.0 * M_PI * r * r * r * 1.35;
+                if (h->tune.acap_scale > 0.0) c *= h->tune.acap_scale;
+                return std::max(128, std::min(((F + 63) / 64) * 64 + 64, (((int)c + 63) / 64) * 64));
+            };
+            const int NI = (int)ifrag.size();
+            h->frag_F = F; h->frag_NI = NI; h->frag_nblk = (F + 63) / 64;
+            h->frag_ocap = cap_for(h->skin); h->frag_icap = std::min(h->frag_ocap, cap_for(h->frag_m));
+            h->frag_fpw = (int)std::max<long>(1, std::min<long>(4, (long)NI * h->batch_R / 8192));
+            h->frag_nwg = (NI + 4 * h->frag_fpw - 1) / (4 * h->frag_fpw);
+            h->d_ifrag.upload(ifrag);
+            h->d_fimg.upload(recs); h->d_ljtab.upload(ljt); h->d_sp_start.upload(h->sp_start_h);
+            { std::vector<int2> e = h->sp_ent_h; if (e.empty()) e.push_back(make_int2(-1, 0)); h->d_sp_ent.upload(e); }
+            h->d_fbb.reserve(h->frag_nblk);
+            h->d_olist.reserve((size_t)NI * h->frag_ocap); h->d_ilist.reserve((size_t)NI * h->frag_icap); h->d_ocount.alloc(NI); h->d_icount.alloc(NI);
+            h->d_xprune_s.alloc((size_t)3 * n);
+        }
+        h->d_epart_nb.alloc(h->k1_mode == 3 ? (size_t)2 * h->frag_nwg + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE)
+                                            : (size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1)) + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
         { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi);
           std::vector<FinRec> fr(h->n_islots + 64);
           auto fill = [&](FinRec& r, int atom) {
@@ -975,6 +1146,26 @@ static ListArgs make_list_args(BluesEngine* h) {
     return a;
 }
 
+static FragArgs make_frag_args(BluesEngine* h) {
+    FragArgs a; memset(&a, 0, sizeof a);
+    if (h->k1_mode != 3) return a;
+    a.F = h->frag_F; a.NI = h->frag_NI; a.ifrag = h->d_ifrag.p; a.nblk = h->frag_nblk; a.n = h->n; a.ocap = h->frag_ocap; a.icap = h->frag_icap; a.fpw = h->frag_fpw; a.nwg = h->frag_nwg; a.n_islots = h->n_islots;
+    a.fimg = h->d_fimg.p; a.ljtab = h->d_ljtab.p; a.ntypes = h->frag_ntypes; a.sp_start = h->d_sp_start.p; a.sp_ent = h->d_sp_ent.p; a.bb = h->d_fbb.p;
+    a.olist = h->d_olist.p; a.ocount = h->d_ocount.p; a.ilist = h->d_ilist.p; a.icount = h->d_icount.p; a.xprune = h->d_xprune_s.p;
+    const double ro = h->cutoff + h->skin, ri = h->cutoff + std::min(h->frag_m, h->skin);
+    a.ro2 = (float)(ro * ro) * 1.0001f + 1e-5f; a.ri2 = (float)(ri * ri) * 1.0001f + 1e-5f;
+    {   // a frozen candidate: the pair's separation changes by ONE atom's displacement
+        const double rof = h->cutoff + 0.5 * h->skin, rif = h->cutoff + 0.5 * std::min(h->frag_m, h->skin);
+        a.ro2_f = (float)(rof * rof) * 1.0001f + 1e-5f; a.ri2_f = (float)(rif * rif) * 1.0001f + 1e-5f;
+    }
+    a.ptrig2 = h->frag_m < h->skin ? (float)(0.25 * h->frag_m * h->frag_m) : 1e30f;   // (inner = outer list: never pruned between rebuilds)
+    for (int k = 0; k < 3; k++) a.scale[k] = (float)(h->box[k] / 4294967296.0);
+    a.flags = h->d_flags.p; a.batch_req = batch_req_ptr(h); a.fpart = h->d_fpart.p; a.epart = h->d_epart_nb.p;
+    a.count_builds = h->n_tiles == 0;
+    a.hint_blocks = h->frag_nblk < 64 ? 0x7fffffff : std::max(48, h->frag_nblk * 6 / 10);
+    return a;
+}
+
 // phase 0: the whole rebuild; 1: the group lists only (k_build_lists); 2: the atoms' own lists only (k_build_atom_lists);
 // a batch's leader also: 3: the work list only (k_gather_stale_b); 4: the group lists without the work list (1 = 3 then 4)
 template <typename R> static int launch_lists(BluesEngine* h, int force, int phase = 0) {
@@ -982,7 +1173,7 @@ template <typename R> static int launch_lists(BluesEngine* h, int force, int pha
     const ListArgs a = make_list_args(h);
     const typename Img<R>::Atom* img;
     if constexpr (sizeof(R) == 4) img = h->d_img_f.p; else img = h->d_img_d.p;
-    if (phase == 2) { }
+    if (phase == 2 || phase == 5) { }   // (5: the fragment-list kernels only)
     else if (batch_lead(h)) {
         if (phase != 4) hipLaunchKernelGGL(k_gather_stale_b<R>, dim3(1), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->R(), force, h->batch->d_work.p);
         if (phase != 3) hipLaunchKernelGGL(k_build_lists_b<R>, dim3(std::min((h->n_tiles + 2) * h->batch->R(), REBUILD_GRID)), dim3(LIST_THREADS), 0, h->cur, batch_reps_nb<R>(h->batch), h->batch->d_work.p, h->n_tiles + 2, force);
@@ -997,6 +1188,26 @@ template <typename R> static int launch_lists(BluesEngine* h, int force, int pha
             else hipLaunchKernelGGL(k_build_atom_lists<R>, dim3(items), dim3(ATOM_LIST_THREADS), 0, h->cur, a, make_nbconst<R>(h), img, force);
         }
         h->st_launches++;
+    }
+    if constexpr (sizeof(R) == 4) {
+        if (h->k1_mode == 3 && (phase == 0 || phase == 5) && !batch_dry(h)) {
+            // fragment lists (kernels_frag.h): block boxes / prune trigger, then rebuild or prune where one is due
+            const int wpb = FR_THREADS / 64;
+            const int nb_pre = ((h->frag_NI + 63) / 64 + wpb - 1) / wpb, nb_box = (h->frag_nblk + wpb - 1) / wpb, nb_lists = (h->frag_NI + wpb - 1) / wpb;
+            if (batch_lead(h)) {
+                const int nrep = h->batch->R();
+                hipLaunchKernelGGL(k_frag_pre_b, dim3(nb_pre * nrep), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, nb_pre, nrep, force);
+                hipLaunchKernelGGL(k_gather_frag_b, dim3(1), dim3(LIST_THREADS), 0, h->cur, h->batch->d_nb_f.p, nrep, force, h->batch->d_work_frag.p);
+                hipLaunchKernelGGL(k_frag_boxes_b, dim3(std::min(nb_box * nrep, 4 * REBUILD_GRID)), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, h->batch->d_work_frag.p, nb_box, force);
+                hipLaunchKernelGGL(k_frag_lists_b, dim3(std::min(nb_lists * nrep, 16 * REBUILD_GRID)), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, h->batch->d_work_frag.p, nb_lists, force);
+            } else {
+                const FragArgs fa = make_frag_args(h);
+                hipLaunchKernelGGL(k_frag_pre, dim3(nb_pre), dim3(FR_THREADS), 0, h->cur, fa, h->d_img_f.p, force);
+                hipLaunchKernelGGL(k_frag_boxes, dim3(nb_box), dim3(FR_THREADS), 0, h->cur, fa, h->d_img_f.p, force);
+                hipLaunchKernelGGL(k_frag_lists, dim3(nb_lists), dim3(FR_THREADS), 0, h->cur, fa, force);
+            }
+            h->st_launches += 2;
+        }
     }
     h->st_launches++;
     HIP_OK(h, hipGetLastError());
@@ -1073,6 +1284,18 @@ template <bool ENERGY> static void launch_nb_sub(BluesEngine* h, const NbArgs<fl
 template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
     NbArgs<R> a = make_nb_args<R>(h);
     if constexpr (sizeof(R) == 4) {
+        if (h->k1_mode == 3) {
+            if (!batch_dry(h)) {
+                if (batch_lead(h)) {
+                    BluesBatch::EvPair* tp = ENERGY ? nullptr : k1t_begin(h->batch, h->cur);
+                    hipLaunchKernelGGL((k_nonbonded_frag_b<ENERGY>), dim3(h->frag_nwg * h->batch->R()), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, h->frag_nwg, h->batch->R());
+                    k1t_end(tp, h->cur);
+                } else hipLaunchKernelGGL((k_nonbonded_frag<ENERGY>), dim3(h->frag_nwg), dim3(FR_THREADS), 0, h->cur, make_frag_args(h), make_nbconst<float>(h));
+            }
+            h->st_launches++;
+            HIP_OK(h, hipGetLastError());
+            return 0;
+        }
         if (h->k1_mode == 2) {
             if (launch_nb_atom<ENERGY>(h, a)) return 1;
             h->st_launches++;
@@ -1451,6 +1674,7 @@ static int launch_pme(BluesEngine* h, int want_energy) {
 
 static int download_xyz(BluesEngine* h, double* xyz, DBuf<double>* src);
 static int sort_and_tile(BluesEngine* h);
+static int batch_plan_shape(BluesBatch* B, bool fresh);
 static int resolve_xfer(BluesEngine* h) {
     if (!h->xfer_pending) return 0;
     h->xfer_pending = false;
@@ -1461,7 +1685,11 @@ static int resolve_xfer(BluesEngine* h) {
     // tiles are formed from the mobile non-alchemical atoms.  A few wandering i-atoms only stretch their tile's bounding
     // box, and the device notices when that starts to cost (resort_hint); the host re-sorts when an i-atom is far out
     // or a sizeable part of the system has moved
-    if (h->sorted_ok && (worst > 1.0f || (int)out[2] > h->n / 10)) {
+    // (per-atom lists over group images: the groups are tiles of mobile atoms that were neighbours at the sort, and their lists and
+    // LDS images are sized for that -- a State from the MD leg, reference blues/simulation.py:1028-1037, arrives with those atoms a few
+    // tenths of a nm apart from where they were: re-tile before the lists outgrow their capacity)
+    const float far = h->k1_mode == 2 ? 0.09f : 1.0f;   // (squared displacement: 0.3 nm / 1 nm)
+    if (h->sorted_ok && (worst > far || (int)out[2] > h->n / 10)) {
         if (download_xyz(h, h->hx.data(), h->d_x)) return 1;
         h->sorted_ok = false;
     }
@@ -1471,7 +1699,18 @@ static int resolve_xfer(BluesEngine* h) {
 static int ensure_sorted(BluesEngine* h) {
     if (resolve_xfer(h)) return 1;
     if (!h->have_positions) E_FAIL(h, "positions have not been set");
-    if (!h->sorted_ok) return sort_and_tile(h);
+    if (!h->sorted_ok && sort_and_tile(h)) return 1;
+    // a member of a batch whose re-sorted tiles no longer fit the batch's layout shape (its mobile atoms have spread: a State from
+    // a long MD leg): a new shape for everybody NOW -- the next list build would overflow (the stepping loop's own check comes
+    // every RESORT_POLL steps, too late for a hand-over)
+    if (h->shape_overflow && h->batch && !h->batch->lockstep && !h->batch->replanning) {
+        BluesBatch* B = h->batch;
+        B->replanning = true;
+        hipStreamSynchronize(B->stream);
+        const int rc = batch_plan_shape(B, false);
+        B->replanning = false; B->st_replans++;
+        if (rc) E_FAIL(h, "%s", B->err.c_str());
+    }
     return 0;
 }
 
@@ -1534,6 +1773,34 @@ static int force_pass(BluesEngine* h, int base_L) {
     const bool early = fork && h->s2 && !h->k2_dense && !h->lists_forced && !h->tune.force_lists && (h->batch ? h->batch->tune.k2_early : h->tune.k2_early) != 0;
     int rc = 0;
     bool wait_lists = false;
+    // fragment lists (k1_mode 3) in a batch: the alchemical kernel and the bonded entries (+ the next O step's noise) need the
+    // alchemical tile's list only -- they run on the side stream beside the fragment-list kernels (a rebuild or a prune of one or two
+    // members: a few latency-bound workgroups) and the head of the nonbonded kernel, joined before the sums
+    const bool fork3 = fork_env && batch_lead(h) && h->k1_mode == 3 && !h->ctrl_arg;
+    if (fork3) {
+        if (ensure_side(h)) return 1;
+        hipStream_t main_stream = h->cur;
+        rc = launch_lists<float>(h, h->lists_forced, 1);
+        if (rc) return 1;
+        HIP_OK(h, hipEventRecord(h->evFork, main_stream)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evFork, 0));
+        // (the DENSE alchemical kernel -- a 512-thread workgroup with ~158 KB of LDS per chain -- stays on the main stream, behind the
+        // nonbonded kernel: beside it the two ran at a third of their speed (471 against 166 us per 1024 chains); its alchemical x
+        // alchemical block and the bonded entries are the small kernels that go to the side)
+        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, h->k2_dense ? 3 : 0) || launch_bonded(h, true); h->cur = main_stream;
+        if (rc) return 1;
+        HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
+        rc = launch_lists<float>(h, h->lists_forced, 5);
+        if (rc) return 1;
+        h->lists_forced = false;
+        if (launch_nonbonded<float, false>(h)) return 1;
+        if (h->k2_dense && launch_alchemical(h, ls, le, fmask, 4)) return 1;
+        if (launch_pme(h, 0)) return 1;
+        HIP_OK(h, hipStreamWaitEvent(h->cur, h->evJ1, 0));
+        if (launch_finalize_deferred(h, le, fmask)) return 1;
+        h->pass_valid = true; h->pass_L = base_L; h->st_passes++; h->vel_clean = true; h->acc_cache_valid = false;
+        HIP_OK(h, hipGetLastError());
+        return 0;
+    }
     if (fork) {
         hipStream_t main_stream = h->cur;
         hipStream_t rb = early ? h->s2 : main_stream;   // the rebuild's stream (high priority: see engine creation)
@@ -1638,6 +1905,7 @@ static EnergyShape energy_shape(const BluesEngine* h) {
     const int subs = h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1);   // mode 2: one (LJ, Coulomb) pair per tile
     g.nw = (h->k1_mode == 2 ? h->n_lists : h->n_itiles) * h->npart * subs;
     g.off_frozen = (size_t)std::max(1, h->n_itiles) * h->npart * 2 * subs;
+    if (h->k1_mode == 3) { g.nw = h->frag_nwg; g.off_frozen = (size_t)2 * h->frag_nwg; }   // one (LJ, Coulomb) pair per workgroup of the fragment kernel
     int total_terms = 0; for (int ty = 0; ty < T_NTYPES; ty++) total_terms += h->n_terms[ty];
     g.nbb = (total_terms + 255) / 256; g.nfb = (h->n + FROZEN_TILE - 1) / FROZEN_TILE;
     return g;
@@ -2103,6 +2371,7 @@ static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const ch
     BC(device) BC(n) BC(precision) BC(nsteps) BC(nprop) BC(n_lambda) BC(split) BC(remove_cm) BC(dt) BC(gamma) BC(kT) BC(tol) BC(prop_min) BC(prop_max)
     BC(n_itiles) BC(n_tiles) BC(jcap) BC(n_islots) BC(pool_cap) BC(PA) BC(k2_nblocks_env) BC(k2_jiter) BC(seg_len) BC(waves_tile) BC(wpb) BC(npart)
     BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k1_iw) BC(k1_mode) BC(acap) BC(S) BC(n_lists) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
+    BC(frag_F) BC(frag_NI) BC(frag_nblk) BC(frag_fpw) BC(frag_nwg)
     BC(cutoff) BC(alpha) BC(sc_alpha) BC(annih_elec) BC(annih_ster) BC(nb_method) BC(pme) BC(pme_K[0]) BC(pme_K[1]) BC(pme_K[2]) BC(pme_order) BC(restr_k) BC(total_mass)
     // (not the box: a MonteCarloBarostat leaves every member in its own; margins, fixed-point scales and PME tables are per member in the records)
 #undef BC
@@ -2147,8 +2416,8 @@ static int batch_refresh_args(BluesBatch* B) {
         core[r].al = make_alch_args(h, one, one, 7); core[r].bo = make_bonded_args(h); core[r].fin = make_fin_args(h, one); core[r].in = make_int_args(h);
         core[r].in.work_trace = h->d_trace.p;  // the launch decides whether it is written (IntDyn.tracing)
         core[r].in.n_noise = h->n_noise;
-        if (single) { nf[r].L = make_list_args(h); nf[r].nb = make_nb_args<float>(h); nf[r].c = make_nbconst<float>(h); nf[r].img = h->d_img_f.p; nf[r].pme = make_pme_args<float>(h, false); }
-        else { nd[r].L = make_list_args(h); nd[r].nb = make_nb_args<double>(h); nd[r].c = make_nbconst<double>(h); nd[r].img = h->d_img_d.p; nd[r].pme = make_pme_args<double>(h, false); }
+        if (single) { nf[r].L = make_list_args(h); nf[r].nb = make_nb_args<float>(h); nf[r].c = make_nbconst<float>(h); nf[r].img = h->d_img_f.p; nf[r].pme = make_pme_args<float>(h, false); nf[r].fr = make_frag_args(h); }
+        else { memset(&nd[r].fr, 0, sizeof nd[r].fr); nd[r].L = make_list_args(h); nd[r].nb = make_nb_args<double>(h); nd[r].c = make_nbconst<double>(h); nd[r].img = h->d_img_d.p; nd[r].pme = make_pme_args<double>(h, false); }
         B->seen_epoch[r] = h->args_epoch;
     }
     // the records may be in use by launches still in flight
@@ -2500,6 +2769,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
         if (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h)) return 1;
     }
     if (build_clusters(h, s)) return 1;
+    build_fragments(h, s);
     try { if (build_bonded(h, s)) return 1; } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     return 0;
 }
@@ -2947,11 +3217,15 @@ int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
         std::vector<int> ac; hipSetDevice(h->device); hipStreamSynchronize(h->stream);
         try { h->d_acount.download(ac); for (int c : ac) { stats[14] += c; stats[15] += (c + 63) / 64; } } catch (std::string&) {}
     }
+    if (h->k1_mode == 3 && h->d_icount.p && h->sorted_ok) {   // fragment lists: [14] / [15] entries and 64-entry chunks of the outer lists, [17] / [18] of the inner ones (the lists the kernel walks)
+        std::vector<int> ic, oc; hipSetDevice(h->device); hipStreamSynchronize(h->stream);
+        try { h->d_ocount.download(oc); h->d_icount.download(ic); for (int c : oc) { stats[14] += c; stats[15] += (c + 63) / 64; } for (int c : ic) { stats[17] += c; stats[18] += (c + 63) / 64; } } catch (std::string&) {}
+    }
     stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
     if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) { stats[1] = f.list_gen; stats[10] = f.builds; stats[16] = f.prunes; } }
-    stats[19] = h->prune_on && h->k1_mode == 2;
+    stats[19] = (h->prune_on && h->k1_mode == 2) || (h->k1_mode == 3 && h->frag_m < h->skin);
     stats[20] = h->k2_dense ? 1 : 0;
-    if (stats[19] && h->d_pcount.p && h->sorted_ok) {
+    if (stats[19] && h->k1_mode == 2 && h->d_pcount.p && h->sorted_ok) {
         std::vector<int> pc, ta;
         try { h->d_pcount.download(pc); h->d_tile_atoms.download(ta); for (size_t q = 0; q < pc.size() && q < ta.size(); q++) if (ta[q] >= 0) { stats[17] += pc[q]; stats[18] += (pc[q] + 63) / 64; } } catch (std::string&) {}
     }
@@ -2991,8 +3265,9 @@ int blues_audit_lists(BluesEngine* h, int64_t* out) {
     HIP_OK(h, hipSetDevice(h->device));
     if (flush_program(h)) return 1;
     if (ensure_sorted(h)) return 1;
-    if (h->k1_mode != 2 || h->precision != 0) E_FAIL(h, "blues_audit_lists: the engine is not in per-atom-list mode");
-    if (h->jcap > 8192) E_FAIL(h, "blues_audit_lists: list capacity %d is beyond the audit kernel's bitmap", h->jcap);
+    if ((h->k1_mode != 2 && h->k1_mode != 3) || h->precision != 0) E_FAIL(h, "blues_audit_lists: the engine is not in per-atom-list or fragment-list mode");
+    if (h->k1_mode == 2 && h->jcap > 8192) E_FAIL(h, "blues_audit_lists: list capacity %d is beyond the audit kernel's bitmap", h->jcap);
+    if (h->k1_mode == 3 && (size_t)3 * ((h->n + 31) / 32) * 4 > 64 * 1024) E_FAIL(h, "blues_audit_lists: %d atoms are beyond the fragment audit's bitmap", h->n);
     hipStream_t st = h->batch && h->batch->entered ? h->batch->stream : h->stream;
     hipStream_t keep = h->cur; h->cur = st;
     BluesBatch* B = h->batch; h->batch = nullptr;   // (the member's own rebuild kernels, whoever leads the batch)
@@ -3001,7 +3276,8 @@ int blues_audit_lists(BluesEngine* h, int64_t* out) {
     if (rc) return 1;
     h->lists_forced = false;
     DBuf<unsigned long long> d_out; d_out.alloc(2);
-    hipLaunchKernelGGL(k_audit_atom_lists, dim3(h->n_islots), dim3(256), 0, st, make_nb_args<float>(h), make_list_args(h), make_nbconst<float>(h), h->d_img_f.p, d_out.p);
+    if (h->k1_mode == 3) hipLaunchKernelGGL(k_audit_frag_lists, dim3(h->frag_NI), dim3(256), (size_t)3 * ((h->n + 31) / 32) * 4, st, make_frag_args(h), make_list_args(h), make_nbconst<float>(h), h->d_img_f.p, d_out.p);
+    else hipLaunchKernelGGL(k_audit_atom_lists, dim3(h->n_islots), dim3(256), 0, st, make_nb_args<float>(h), make_list_args(h), make_nbconst<float>(h), h->d_img_f.p, d_out.p);
     HIP_OK(h, hipGetLastError());
     HIP_OK(h, hipStreamSynchronize(st));
     std::vector<unsigned long long> v; d_out.download(v); d_out.release();
@@ -3245,7 +3521,7 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
     B->sync_lists = false;
     B->tune = g_tuning;
     B->sync_lists = B->tune.batch_sync_lists != 0;
-    try { B->d_req.alloc(1); B->d_work.alloc((size_t)2 * count + 1); } catch (std::string& e) { g_batch_create_error = e; batch_detach_all(B); delete B; return 1; }
+    try { B->d_req.alloc(1); B->d_work.alloc((size_t)2 * count + 1); B->d_work_frag.alloc((size_t)count + 1); } catch (std::string& e) { g_batch_create_error = e; batch_detach_all(B); delete B; return 1; }
     B->seen_epoch.assign(count, 0); B->failed.assign(count, 0); B->active.assign(count, 1); B->rec_active.assign(count, 0); B->rec_delta.assign(count, 0); B->leader = engines[0];
     *out = B;
     return 0;

@@ -14,11 +14,13 @@
 #pragma once
 #include "kernels_integrate.h"
 #include "kernels_pme.h"
+#include "kernels_frag.h"
 
 template <typename R> struct RepNb {   // precision-dependent part of a replica's argument record
     int active;   // 0: the member sits this launch out (its blocks return at once)
     ListArgs L; NbArgs<R> nb; NbConst<R> c; const typename Img<R>::Atom* img;
     PmeArgs<R> pme;   // reciprocal space (n = 0: none)
+    FragArgs fr;      // fragment lists (kernels_frag.h; F = 0: not in that mode)
 };
 struct RepCore {
     int active;
@@ -143,6 +145,64 @@ __global__ void __launch_bounds__(1024) k_nonbonded_atom_b(const RepNb<float>* _
     if (!rp.active) return;
     const NbArgs<float> a = rp.nb; const NbConst<float> c = rp.c;
     nonbonded_atom_body<ENERGY>(a, c, rp.img, bx);
+}
+
+// ---- fragment lists (kernels_frag.h): every member's first kernel of a pass, the work list of the members whose lists need
+// the second one (stale: rebuild; an atom past the prune trigger: prune), that kernel over the work list, the force kernel
+__global__ void __launch_bounds__(FR_THREADS) k_frag_pre_b(const RepNb<float>* __restrict__ reps, int nb, int nrep, int force) {
+    const int rep = blockIdx.x / nb, bx = blockIdx.x - rep * nb;
+    const RepNb<float>& rp = reps[rep];
+    if (!rp.active) return;
+    const FragArgs fa = rp.fr;
+    frag_pre_body(fa, rp.img, force, bx * (FR_THREADS / 64) + (threadIdx.x >> 6));
+}
+// (the rebuild's first kernel over the same work list: a member that is only there to prune returns at once)
+__global__ void __launch_bounds__(FR_THREADS) k_frag_boxes_b(const RepNb<float>* __restrict__ reps, const int* __restrict__ work, int bpc, int force) {
+    const int nact = work[0];
+    for (int i = blockIdx.x; i < nact * bpc; i += gridDim.x) {
+        const int m = i / bpc;
+        const RepNb<float>& rp = reps[work[1 + m]];
+        const FragArgs fa = rp.fr;
+        frag_boxes_body(fa, rp.img, force, (i - m * bpc) * (FR_THREADS / 64) + (threadIdx.x >> 6));
+    }
+}
+__global__ void __launch_bounds__(LIST_THREADS) k_gather_frag_b(const RepNb<float>* __restrict__ reps, int nrep, int force, int* __restrict__ work) {
+    __shared__ int s_cnt[LIST_WAVES]; __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < nrep; r0 += LIST_THREADS) {
+        const int r = r0 + tid;
+        bool act = false;
+        if (r < nrep && reps[r].active) { const FragArgs& fa = reps[r].fr; act = frag_stale(fa, force) || fa.flags->prune_req != 0; }
+        const unsigned long long bal = __ballot(act);
+        if (lane == 0) s_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int rank = s_base + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; w++) rank += s_cnt[w];
+        if (act) work[1 + rank] = r;
+        __syncthreads();
+        if (tid == 0) { int tot = 0; for (int w = 0; w < LIST_WAVES; w++) tot += s_cnt[w]; s_base += tot; }
+        __syncthreads();
+    }
+    if (tid == 0) work[0] = s_base;
+}
+__global__ void __launch_bounds__(FR_THREADS) k_frag_lists_b(const RepNb<float>* __restrict__ reps, const int* __restrict__ work, int bpc, int force) {
+    const int nact = work[0];
+    for (int i = blockIdx.x; i < nact * bpc; i += gridDim.x) {
+        const int m = i / bpc;
+        const RepNb<float>& rp = reps[work[1 + m]];
+        const FragArgs fa = rp.fr;
+        frag_lists_body(fa, force, i - m * bpc);
+    }
+}
+template <bool ENERGY>
+__global__ void __launch_bounds__(FR_THREADS) k_nonbonded_frag_b(const RepNb<float>* __restrict__ reps, int nb, int nrep) {
+    int rep, bx; batch_decode(nb, nrep, rep, bx);
+    const RepNb<float>& rp = reps[rep];
+    if (!rp.active) return;
+    const FragArgs fa = rp.fr; const NbConst<float> c = rp.c;
+    nonbonded_frag_body<ENERGY>(fa, c, bx);
 }
 
 // reciprocal space of every member: one workgroup each (kernels_pme.h)

@@ -23,7 +23,8 @@ struct DevFlags {  // device-resident control words
     int nan_flag;
     int resort_hint;             // a j-list has grown to within 15 % of its capacity: the tiles have spread, re-sort soon
     int builds;                  // list builds executed (own requests, forced ones and batch-synchronised ones)
-    int prunes;                  // pruned per-atom lists re-derived so far (one count per atom and prune; nonbonded_atom_body)
+    int prunes;                  // pruned per-atom lists re-derived so far (one count per atom and prune; nonbonded_atom_body); fragment lists: prunes of the whole chain
+    int prune_req;               // fragment lists (kernels_frag.h): an atom has moved half the inner margin since the last prune
 };
 
 struct ListArgs {

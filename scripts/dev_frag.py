@@ -1,0 +1,70 @@
+"""Fragment-list path (k1_mode 3, kernels_frag.h) on a GPU box: parity against the committed oracle vectors of the all-mobile
+water variant, list audit over a run, and timings beside the per-atom-list path (k1_mode=2).
+   python scripts/dev_frag.py [--R 16] [--nsteps 200] ["k1_mode=2" "prune_margin=0.08" ...]"""
+import argparse, copy, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from blues_amd import build, integrators, systems, tuning
+build.build_engine()
+from blues_amd.engine import NativeEngine, NativeBatch
+from blues_amd.replicas import replica_seed
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--R", type=int, default=16)
+ap.add_argument("--nsteps", type=int, default=200)
+ap.add_argument("--no-parity", action="store_true")
+ap.add_argument("specs", nargs="*", default=[""])
+a = ap.parse_args()
+gold = dict(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "s23k_variant_vectors.npz")))
+base, vel = systems.s23k(frozen=False, restrained=40)
+s = copy.copy(base); s.alchemical_atoms = np.array([15, 16, 17], np.int32)
+
+
+def data(replica=0, n=None):
+    return integrators.generateNCMCIntegrator(nstepsNC=n or int(gold["nsteps"]), dt=float(gold["dt"]), temperature=float(gold["temperature"]),
+                                              seed=int(gold["water_seed"])).to_data(precision=0, replica=replica)
+
+
+for spec in a.specs:
+    tuning.reset()
+    if spec:
+        tuning.set(**tuning.parse(spec))
+    if not a.no_parity:
+        g = NativeEngine(s, data())
+        sel = gold["water_force_atoms"]
+        for k, (ls, le) in enumerate(gold["lambdas"]):
+            g.set_global("lambda_sterics", ls); g.set_global("lambda_electrostatics", le)
+            t = g.energy_terms(); eo = gold["water_energy_total"][k]; to = gold["water_energy_terms"][k]
+            f = g.get_forces()[sel]; fo = gold["water_forces"][k]
+            print("[%s] lambda %d: energy rel err %.2e (nonbonded term %.2e), force max err / max %.2e, norm %.2e" % (
+                spec, k, abs(t.sum() - eo) / abs(eo), abs(t[3] - to[3]) / abs(to[3]), np.abs(f - fo).max() / np.abs(fo).max(), np.linalg.norm(f - fo) / np.linalg.norm(fo)), flush=True)
+        st = g.stats()
+        print("[%s] mode %d tiles %d; lists: outer %.1f / inner %.1f entries per fragment-or-atom; audit %s" % (
+            spec, st["nonbonded_kernel"], st["i_tiles"], st["atom_list_entries"] / 7795.0, st["pruned_list_entries"] / 7795.0, g.audit_lists()), flush=True)
+        print("[%s] lone: K1 %.1f us, list build %.1f us" % (spec, g.time_nonbonded(20), g.time_list_build(5)), flush=True)
+        g.set_velocities(vel)
+        w = g.run_switch(40, trace=True)
+        wo = gold["water_work_trace"]
+        print("[%s] 20-step free-running work err %.2e (scale %.2f)" % (spec, np.abs(np.asarray(w[:20]) - wo[:20]).max() / np.abs(wo).max(), np.abs(wo).max()), flush=True)
+        bad = 0
+        for it in range(6):
+            g.step(10); au = g.audit_lists(); bad += au[1]
+        st = g.stats()
+        print("[%s] audits over 60 more steps: missing %d; rebuilds %d prunes %d" % (spec, bad, st["list_builds"], st["atom_prunes"]), flush=True)
+        g.close()
+    engs = []
+    for r in range(a.R):
+        integ = integrators.generateNCMCIntegrator(nstepsNC=a.nsteps + 80, dt=0.004, temperature=300.0, seed=replica_seed(1234, r))
+        g = NativeEngine(s, integ.to_data(precision=0, replica=r)); g.set_velocities(vel); engs.append(g)
+    B = NativeBatch(engs) if a.R > 1 else None
+    step = (lambda n: B.step(n)) if B else (lambda n: engs[0].step(n))
+    step(60)
+    s0 = engs[0].stats()
+    t0 = time.perf_counter(); step(a.nsteps); dt = time.perf_counter() - t0
+    s1 = engs[0].stats()
+    k1 = B.time_nonbonded(20) if B else engs[0].time_nonbonded(20)
+    print("[%s] R=%d: %.1f us per step = %.2f us per chain-step (%.0f ns/day); K1 alone %.1f us per launch = %.2f per chain; rebuilds/1000 steps %.0f, prunes/1000 %.0f; mode %d; audit %s" % (
+        spec, a.R, 1e6 * dt / a.nsteps, 1e6 * dt / a.nsteps / a.R, a.R * a.nsteps * 0.004e-3 / (dt / 86400.0), k1, k1 / a.R,
+        1000.0 * (s1["list_builds"] - s0["list_builds"]) / a.nsteps, 1000.0 * (s1["atom_prunes"] - s0["atom_prunes"]) / a.nsteps, s1["nonbonded_kernel"], engs[-1].audit_lists()), flush=True)
+    if B: B.close()
+    for g in engs: g.close()

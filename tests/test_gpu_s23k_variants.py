@@ -147,7 +147,7 @@ def test_variant_switch_golden(Engine, gold, name, R, precision):
         if precision == 0 and name == "sidechain" and R >= 8:
             assert st["alchemical_kernel"] == 0, st                 # alchemical-environment exclusions: the lane layout, inside a batch
         if precision == 0 and R >= 8:
-            assert st["nonbonded_kernel"] == 2, st                  # per-atom lists (water: full lists, nothing frozen; sidechain: pruned)
+            assert st["nonbonded_kernel"] == (3 if name == "water" else 2), st   # water (nothing frozen): fragment lists; sidechain: pruned per-atom lists
         B.close()
     mob = gold[name + "_mobile_atoms"]
     pos_err = np.abs(engs[0].get_positions()[mob] - gold[name + "_x_end"]).max()
