@@ -623,7 +623,7 @@ def main():
                               "replica_seeds_first_chain_of_each_rank": [int(replica_seed(1234, r * R)) for r in range(world)]},
             "memory": memory_use(),
             "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup, "setup_seconds_by_part": setup_parts,
-                       "plugin_boundary": "one call per operation for all chains (blues_batch_*)" if drivers[0]._batchable() else "chain by chain",
+                       "plugin_boundary": ("one call per operation for all chains (blues_batch_*)" + ("" if drivers[0]._move_batchable() else "; the Move's hooks chain by chain")) if drivers[0]._batchable() else "chain by chain",
                        "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,
                        "list_rebuilds_per_switch": (st1["list_generation"] - st0["list_generation"]) / args.steps,
                        "own_energy_evaluations_per_switch": (st1["own_energy_evaluations"] - st0["own_energy_evaluations"]) / args.steps,

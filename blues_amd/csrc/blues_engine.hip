@@ -207,7 +207,7 @@ struct BluesEngine {
     // (build_fragments), the layout of the current sort, the lists
     std::vector<std::array<int, 3>> frag_atoms; std::vector<int> frag_cnt, frag_of_atom, frag_pos_of_atom; bool frag_ok = false;
     std::vector<int> sp_start_h; std::vector<int2> sp_ent_h;
-    int frag_F = 0, frag_NI = 0, frag_nblk = 0, frag_ocap = 0, frag_icap = 0, frag_fpw = 1, frag_nwg = 0; double frag_m = 0.0; DBuf<int> d_ifrag;
+    int frag_F = 0, frag_NI = 0, frag_nblk = 0, frag_ocap = 0, frag_icap = 0, frag_fpw = 1, frag_nwg = 0; double frag_m = 0.0; DBuf<int> d_ifrag; bool frag_rel = false;
     DBuf<FragRec> d_fimg; DBuf<float2> d_ljtab; int frag_ntypes = 0; DBuf<int> d_sp_start, d_ocount, d_icount; DBuf<int2> d_sp_ent; DBuf<FragBox> d_fbb; DBuf<unsigned> d_olist, d_ilist, d_xprune_s;
     int acap = 0;     // capacity of one atom's list (mode 2)
     // layout shape of the per-atom-list mode.  A lone engine derives (S, jcap) from its own geometry at every re-sort; members
@@ -676,7 +676,7 @@ static int sort_and_tile(BluesEngine* h) {
         const int nit = ((int)mobile_env + 63) / 64;
         const bool all_mobile = mobile_env + h->alch.size() == (size_t)n;
         want_frag = h->frag_ok && h->precision == 0 && mobile_env > 0 && h->tune.k1_mode != 1 && h->tune.k1_mode != 2
-                    && (h->tune.k1_mode == 3 || h->forbid_atom || (all_mobile && nit * h->batch_R > 32));
+                    && (h->tune.k1_mode == 3 || h->forbid_atom || (all_mobile && nit * h->batch_R > 32 && h->tune.fuse_forces != 1));   // (fuse_forces = 1 pins the one-launch force pass)
     }
     std::vector<std::pair<uint64_t, int>> keys(n);
     auto hkey = [&](int i) {
@@ -1007,6 +1007,9 @@ static int sort_and_tile(BluesEngine* h) {
             const int NI = (int)ifrag.size();
             h->frag_F = F; h->frag_NI = NI; h->frag_nblk = (F + 63) / 64;
             h->frag_ocap = cap_for(h->skin); h->frag_icap = std::min(h->frag_ocap, cap_for(h->frag_m));
+            // the relative form of a pair's separation (kernels_frag.h: REL) wants cutoff + a fragment's reach (bonded atoms: well under
+            // 0.6 nm) below half the shortest edge; smaller boxes (the 975-atom test box) take the fixed-point difference per pair
+            h->frag_rel = 0.5 * std::min(h->box[0], std::min(h->box[1], h->box[2])) > h->cutoff + 0.6;
             h->frag_fpw = (int)std::max<long>(1, std::min<long>(4, (long)NI * h->batch_R / 8192));
             h->frag_nwg = (NI + 4 * h->frag_fpw - 1) / (4 * h->frag_fpw);
             h->d_ifrag.upload(ifrag);
@@ -1161,8 +1164,9 @@ static FragArgs make_frag_args(BluesEngine* h) {
     a.ptrig2 = h->frag_m < h->skin ? (float)(0.25 * h->frag_m * h->frag_m) : 1e30f;   // (inner = outer list: never pruned between rebuilds)
     for (int k = 0; k < 3; k++) a.scale[k] = (float)(h->box[k] / 4294967296.0);
     a.flags = h->d_flags.p; a.batch_req = batch_req_ptr(h); a.fpart = h->d_fpart.p; a.epart = h->d_epart_nb.p;
+    a.half_min_edge = (float)(0.5 * std::min(h->box[0], std::min(h->box[1], h->box[2])));
     a.count_builds = h->n_tiles == 0;
-    a.hint_blocks = h->frag_nblk < 64 ? 0x7fffffff : std::max(48, h->frag_nblk * 6 / 10);
+    a.hint_blocks = h->frag_nblk < 64 ? 0x7fffffff : std::max(48, h->frag_nblk * 85 / 100);   // (a re-sort is 5-10 ms of host work per chain: only when the blocks' boxes have stopped pruning anything)
     return a;
 }
 
@@ -1288,9 +1292,11 @@ template <typename R, bool ENERGY> static int launch_nonbonded(BluesEngine* h) {
             if (!batch_dry(h)) {
                 if (batch_lead(h)) {
                     BluesBatch::EvPair* tp = ENERGY ? nullptr : k1t_begin(h->batch, h->cur);
-                    hipLaunchKernelGGL((k_nonbonded_frag_b<ENERGY>), dim3(h->frag_nwg * h->batch->R()), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, h->frag_nwg, h->batch->R());
+                    if (h->frag_rel) hipLaunchKernelGGL((k_nonbonded_frag_b<ENERGY, true>), dim3(h->frag_nwg * h->batch->R()), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, h->frag_nwg, h->batch->R());
+                    else hipLaunchKernelGGL((k_nonbonded_frag_b<ENERGY, false>), dim3(h->frag_nwg * h->batch->R()), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, h->frag_nwg, h->batch->R());
                     k1t_end(tp, h->cur);
-                } else hipLaunchKernelGGL((k_nonbonded_frag<ENERGY>), dim3(h->frag_nwg), dim3(FR_THREADS), 0, h->cur, make_frag_args(h), make_nbconst<float>(h));
+                } else if (h->frag_rel) hipLaunchKernelGGL((k_nonbonded_frag<ENERGY, true>), dim3(h->frag_nwg), dim3(FR_THREADS), 0, h->cur, make_frag_args(h), make_nbconst<float>(h));
+                else hipLaunchKernelGGL((k_nonbonded_frag<ENERGY, false>), dim3(h->frag_nwg), dim3(FR_THREADS), 0, h->cur, make_frag_args(h), make_nbconst<float>(h));
             }
             h->st_launches++;
             HIP_OK(h, hipGetLastError());
@@ -1688,8 +1694,11 @@ static int resolve_xfer(BluesEngine* h) {
     // (per-atom lists over group images: the groups are tiles of mobile atoms that were neighbours at the sort, and their lists and
     // LDS images are sized for that -- a State from the MD leg, reference blues/simulation.py:1028-1037, arrives with those atoms a few
     // tenths of a nm apart from where they were: re-tile before the lists outgrow their capacity)
+    // (fragment lists: the order only decides how many blocks the list builder can skip and how local the force kernel's gathers are;
+    // the builder itself asks for a new order when its blocks have spread (resort_hint) -- a State that arrives from another leg
+    // every iteration must not cost a host-side re-sort every time)
     const float far = h->k1_mode == 2 ? 0.09f : 1.0f;   // (squared displacement: 0.3 nm / 1 nm)
-    if (h->sorted_ok && (worst > far || (int)out[2] > h->n / 10)) {
+    if (h->sorted_ok && h->k1_mode != 3 && (worst > far || (int)out[2] > h->n / 10)) {
         if (download_xyz(h, h->hx.data(), h->d_x)) return 1;
         h->sorted_ok = false;
     }
@@ -2371,7 +2380,7 @@ static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const ch
     BC(device) BC(n) BC(precision) BC(nsteps) BC(nprop) BC(n_lambda) BC(split) BC(remove_cm) BC(dt) BC(gamma) BC(kT) BC(tol) BC(prop_min) BC(prop_max)
     BC(n_itiles) BC(n_tiles) BC(jcap) BC(n_islots) BC(pool_cap) BC(PA) BC(k2_nblocks_env) BC(k2_jiter) BC(seg_len) BC(waves_tile) BC(wpb) BC(npart)
     BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k1_iw) BC(k1_mode) BC(acap) BC(S) BC(n_lists) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
-    BC(frag_F) BC(frag_NI) BC(frag_nblk) BC(frag_fpw) BC(frag_nwg)
+    BC(frag_F) BC(frag_NI) BC(frag_nblk) BC(frag_fpw) BC(frag_nwg) BC(frag_rel)
     BC(cutoff) BC(alpha) BC(sc_alpha) BC(annih_elec) BC(annih_ster) BC(nb_method) BC(pme) BC(pme_K[0]) BC(pme_K[1]) BC(pme_K[2]) BC(pme_order) BC(restr_k) BC(total_mass)
     // (not the box: a MonteCarloBarostat leaves every member in its own; margins, fixed-point scales and PME tables are per member in the records)
 #undef BC

@@ -196,13 +196,13 @@ __global__ void __launch_bounds__(FR_THREADS) k_frag_lists_b(const RepNb<float>*
         frag_lists_body(fa, force, i - m * bpc);
     }
 }
-template <bool ENERGY>
+template <bool ENERGY, bool REL>
 __global__ void __launch_bounds__(FR_THREADS) k_nonbonded_frag_b(const RepNb<float>* __restrict__ reps, int nb, int nrep) {
     int rep, bx; batch_decode(nb, nrep, rep, bx);
     const RepNb<float>& rp = reps[rep];
     if (!rp.active) return;
     const FragArgs fa = rp.fr; const NbConst<float> c = rp.c;
-    nonbonded_frag_body<ENERGY>(fa, c, bx);
+    nonbonded_frag_body<ENERGY, REL>(fa, c, bx);
 }
 
 // reciprocal space of every member: one workgroup each (kernels_pme.h)

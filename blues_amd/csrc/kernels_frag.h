@@ -63,6 +63,7 @@ struct FragArgs {
     unsigned* xprune;           // [3][n] by sorted index: where the atoms were at the last prune (fixed point)
     float ro2, ri2, ptrig2;     // (cutoff + skin)^2, (cutoff + m)^2 (both with the float safety of the other builders), (m / 2)^2
     float ro2_f, ri2_f;         // the same for a FROZEN j-fragment: only one partner moves, half the margins do
+    float half_min_edge;        // half the shortest box edge (nonbonded_frag_body<., REL>)
     float scale[3];             // box edge / 2^32
     DevFlags* flags; int* batch_req;
     double* fpart; double* epart;
@@ -318,7 +319,10 @@ __device__ __forceinline__ void frag_lists_body(const FragArgs& fa, const int fo
 // ---- the force / energy kernel.  A wave owns fa.fpw consecutive fragments; per fragment it walks the inner list 64 entries at a
 // time: entry -> the j-fragment's record (one 64-byte gather, requested one chunk ahead) -> nine pairs.
 #define FR_VREG(x) asm volatile("" : "+v"(x))
-template <bool ENERGY>
+// REL: a pair's separation from the j-atom's offset to the fragment's FIRST atom (one fixed-point minimum image per j-atom and
+// chunk) plus the i-atom's offset inside its fragment -- valid where cutoff + the fragment's reach stays below half the shortest
+// box edge (the host chooses; the kernel checks every fragment).  Otherwise the fixed-point difference per pair.
+template <bool ENERGY, bool REL>
 __device__ __forceinline__ void nonbonded_frag_body(const FragArgs& fa, const NbConst<float>& c, const int wg) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); typedef float f32x2 __attribute__((ext_vector_type(2)));
     __shared__ f32x2 s_lj[FR_TYPES_MAX];
@@ -377,13 +381,21 @@ __device__ __forceinline__ void nonbonded_frag_body(const FragArgs& fa, const Nb
             ox[a] = (float)(int32_t)(ix[a] - ix[0]) * k_sx; oy[a] = (float)(int32_t)(iy[a] - iy[0]) * k_sy; oz[a] = (float)(int32_t)(iz[a] - iz[0]) * k_sz;
             FR_VREG(ox[a]); FR_VREG(oy[a]); FR_VREG(oz[a]);
         }
+        if (REL) {
+            float reach2 = 0.0f;
+#pragma unroll
+            for (int a = 1; a < 3; a++) reach2 = fmaxf(reach2, fmaf(oz[a], oz[a], fmaf(oy[a], oy[a], ox[a] * ox[a])));
+            if (lane == 0 && sqrtf(reach2) + sqrtf(c.rc2) >= fa.half_min_edge) fa.flags->list_overflow = 1;   // (cannot happen for bonded fragments in a box the host let through)
+        }
         const bool lj_a[3] = {ise[0] != 0.0f, ise[1] != 0.0f, ise[2] != 0.0f};   // (wave-uniform: a hydrogen of a water has no epsilon, its pairs no 12-6 term)
         Rec cur, nxt;
         if (nch > 0) load_rec(e_cur, cur);
         float fx[3] = {0.0f, 0.0f, 0.0f}, fy[3] = {0.0f, 0.0f, 0.0f}, fz[3] = {0.0f, 0.0f, 0.0f};
-        auto pair = [&](int a, float rx, float ry, float rz, float jq, const f32x2& jl, float jw, auto masked_tag, auto exact_tag, auto lj_tag, unsigned bit) {
+        auto pair = [&](int a, const u32x4& jp, float rx, float ry, float rz, float jq, const f32x2& jl, float jw, auto masked_tag, auto exact_tag, auto lj_tag, unsigned bit) {
             constexpr bool M = decltype(masked_tag)::value, X = decltype(exact_tag)::value, LJ = decltype(lj_tag)::value;
-            const float dx = a == 0 ? rx : rx + ox[a], dy = a == 0 ? ry : ry + oy[a], dz = a == 0 ? rz : rz + oz[a];
+            float dx, dy, dz;
+            if (REL) { dx = a == 0 ? rx : rx + ox[a]; dy = a == 0 ? ry : ry + oy[a]; dz = a == 0 ? rz : rz + oz[a]; }
+            else { dx = (float)(int32_t)(ix[a] - jp.x) * k_sx; dy = (float)(int32_t)(iy[a] - jp.y) * k_sy; dz = (float)(int32_t)(iz[a] - jp.z) * k_sz; }
             float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
             if (M) r2 = bit ? r2 : k_far;   // a pair the mask leaves out (excluded, the atom itself, a padding entry): beyond the cutoff, finite
             if (!ENERGY) {
@@ -423,7 +435,8 @@ __device__ __forceinline__ void nonbonded_frag_body(const FragArgs& fa, const Nb
             for (int b = 0; b < 3; b++) {
                 jl[b] = s_lj[(R.types >> (8 * b)) & 0xffu];
                 jw[b] = ENERGY ? (((R.types >> (26 + b)) & 1u) ? 0.5f : 1.0f) : 0.0f;
-                rx[b] = (float)(int32_t)(ix[0] - R.p[b].x) * k_sx; ry[b] = (float)(int32_t)(iy[0] - R.p[b].y) * k_sy; rz[b] = (float)(int32_t)(iz[0] - R.p[b].z) * k_sz;
+                if (REL) { rx[b] = (float)(int32_t)(ix[0] - R.p[b].x) * k_sx; ry[b] = (float)(int32_t)(iy[0] - R.p[b].y) * k_sy; rz[b] = (float)(int32_t)(iz[0] - R.p[b].z) * k_sz; }
+                else rx[b] = ry[b] = rz[b] = 0.0f;
             }
 #pragma unroll
             for (int a = 0; a < 3; a++) {
@@ -431,10 +444,10 @@ __device__ __forceinline__ void nonbonded_frag_body(const FragArgs& fa, const Nb
                 if (!((mob_i >> a) & 1u)) continue;   // (a frozen atom of the fragment: nobody reads its force)
                 if (lj_a[a]) {
 #pragma unroll
-                    for (int b = 0; b < 3; b++) pair(a, rx[b], ry[b], rz[b], __uint_as_float(R.p[b].w), jl[b], jw[b], masked_tag, exact_tag, std::true_type{}, (mask >> (3 * a + b)) & 1u);
+                    for (int b = 0; b < 3; b++) pair(a, R.p[b], rx[b], ry[b], rz[b], __uint_as_float(R.p[b].w), jl[b], jw[b], masked_tag, exact_tag, std::true_type{}, (mask >> (3 * a + b)) & 1u);
                 } else {
 #pragma unroll
-                    for (int b = 0; b < 3; b++) pair(a, rx[b], ry[b], rz[b], __uint_as_float(R.p[b].w), jl[b], jw[b], masked_tag, exact_tag, std::false_type{}, (mask >> (3 * a + b)) & 1u);
+                    for (int b = 0; b < 3; b++) pair(a, R.p[b], rx[b], ry[b], rz[b], __uint_as_float(R.p[b].w), jl[b], jw[b], masked_tag, exact_tag, std::false_type{}, (mask >> (3 * a + b)) & 1u);
                 }
             }
         };
@@ -483,9 +496,9 @@ __global__ void __launch_bounds__(FR_THREADS) k_frag_boxes(FragArgs fa, const At
 __global__ void __launch_bounds__(FR_THREADS) k_frag_lists(FragArgs fa, int force) {
     frag_lists_body(fa, force, blockIdx.x);
 }
-template <bool ENERGY>
+template <bool ENERGY, bool REL>
 __global__ void __launch_bounds__(FR_THREADS) k_nonbonded_frag(FragArgs fa, NbConst<float> c) {
-    nonbonded_frag_body<ENERGY>(fa, c, blockIdx.x);
+    nonbonded_frag_body<ENERGY, REL>(fa, c, blockIdx.x);
 }
 
 // Audit (diagnostic; blues_audit_lists): one block per i-fragment.  Every atom of the system within the cutoff of one of the

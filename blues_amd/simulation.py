@@ -64,15 +64,16 @@ def write_state(context, table_entry, parts=_STATE_ORDER):
     return context
 
 
-def metropolis(chain):
+def metropolis(chain, unmodified_at_x1=None):
     """The NCMC acceptance test of one chain (reference blues/simulation.py:1121-1140): log-acceptance of the protocol work plus
-    the alchemical correction against the log of a uniform draw.  Returns the decision record; changes nothing."""
+    the alchemical correction against the log of a uniform draw.  Returns the decision record; changes nothing.
+    unmodified_at_x1: the `alch` context's energy at the switched coordinates where a batch has evaluated it for all chains."""
     integrator = chain._ncmc_sim.context._integrator
     log_p = integrator.getLogAcceptanceProbability(chain._ncmc_sim.context)
     log_u = math.log(chain._rng.random_sample())
     correction = 0.0
     if not np.isnan(log_p):       # a NaN work rejects without asking for energies (the reference's guard)
-        correction = chain._computeAlchemicalCorrection()
+        correction = chain._computeAlchemicalCorrection(unmodified_at_x1)
         logger.debug('NCMCLogAcceptanceProbability = %.6f + Alchemical Correction = %.6f' % (log_p, correction))
         log_p = log_p + correction
     return {'accept': bool(log_p > log_u), 'log_accept': float(log_p), 'correction': float(correction), 'randnum': log_u,
@@ -209,11 +210,13 @@ class BLUESSimulation(object):
             pass
 
     # ---- reference blues/simulation.py:1100-1119: -[ (U_ncmc - U_md)(x0) + (U_alch - U_ncmc)(x1) ] / kT
-    def _computeAlchemicalCorrection(self):
+    def _computeAlchemicalCorrection(self, unmodified_at_x1=None):
         table = self.stateTable
         at_x0 = table['ncmc']['state0']['potential_energy'] - table['md']['state0']['potential_energy']
         end = table['ncmc']['state1']
-        if self._alch_sim is None:
+        if unmodified_at_x1 is not None:
+            pass       # (evaluated for the whole batch: BatchedBLUESSimulation._decide_batched)
+        elif self._alch_sim is None:
             unmodified_at_x1 = self._lambda_one_energy()
         else:
             self._alch_sim.context = write_state(self._alch_sim.context, end, ('box_vectors', 'positions'))
@@ -310,12 +313,17 @@ class BatchedBLUESSimulation(object):
             self._md_batch.device_turn = device_turn
         elif any(c._md_sim is not None for c in self.chains):
             raise ValueError("either every chain has an MD simulation or none has")
+        self._alch_batch = None
+        if all(c._alch_sim is not None for c in self.chains):
+            self._alch_batch = NativeBatch([c._alch_sim.context._engine for c in self.chains])
+        elif any(c._alch_sim is not None for c in self.chains):
+            raise ValueError("either every chain has an `alch` simulation or none has")
 
     def close(self):
         if self._pool is not None:
             self._pool.shutdown()
             self._pool = None
-        for b in (self._ncmc_batch, self._md_batch):
+        for b in (self._ncmc_batch, self._md_batch, self._alch_batch):
             if b is not None:
                 b.close()
 
@@ -352,13 +360,41 @@ class BatchedBLUESSimulation(object):
     # same sequence of operations is issued once for the whole batch.  Same results, bit for bit, as the chain-by-chain path
     # (tests/test_gpu_batch.py); chains with other Moves take that path.
     def _batchable(self):
-        from . import moves
+        """The State hand-overs, the Metropolis step and the reset of all chains in one call per operation: chains of one shape
+        (same System size and box, no barostat, no reporters on the NCMC leg), with or without the md / alch Simulations of the
+        reference's triple (blues/simulation.py:768-809).  What the Move's hooks do is a separate question (_move_batchable)."""
         if not self.batched_boundary or not hasattr(self._ncmc_batch, "snapshot_all"):
             return False
+        first_sim = None
+        for c in self.chains:
+            me = c._move_engine
+            if me is None or len(getattr(me, "moves", [])) < 1:
+                return False
+            # one launch per operation is sized and laid out for ONE system: same atoms, same box, no barostat moving it
+            if first_sim is None:
+                first_sim = c._ncmc_sim
+            sysm, sys0 = getattr(c._ncmc_sim, "system", None), getattr(first_sim, "system", None)
+            if sysm is not sys0 and (getattr(sysm, "n_atoms", None) != getattr(sys0, "n_atoms", None) or not np.array_equal(getattr(sysm, "box", None), getattr(sys0, "box", None))):
+                return False
+            if c._ncmc_sim.reporters or getattr(c._ncmc_sim, "barostat", None) is not None:
+                return False
+            for other in (c._md_sim, c._alch_sim):
+                if other is None:
+                    continue
+                so = getattr(other, "system", None)
+                if getattr(other, "barostat", None) is not None or getattr(so, "n_atoms", None) != getattr(sys0, "n_atoms", None) or not np.array_equal(getattr(so, "box", None), getattr(sys0, "box", None)):
+                    return False
+        return True
+
+    def _move_batchable(self):
+        """The Move itself as ONE gather, the chains' propose() calls on the host, ONE scatter: every chain's move is of one class
+        that exposes its geometry as `propose(coordinates of its atoms)` on the same atoms and leaves the other hooks alone.  Other
+        moves (WaterTranslationMove's beforeMove / afterMove, third-party Move subclasses) run their hooks chain by chain."""
+        from . import moves
         first = None
         for c in self.chains:
             me = c._move_engine
-            if me is None or len(getattr(me, "moves", [])) != 1 or c._alch_sim is not None or c._md_sim is not None:
+            if me is None or len(getattr(me, "moves", [])) != 1:
                 return False
             m = me.moves[0]
             if not hasattr(m, "propose") or any(getattr(type(m), hook) is not getattr(moves.Move, hook) for hook in ("beforeMove", "afterMove", "_error")):
@@ -369,26 +405,21 @@ class BatchedBLUESSimulation(object):
             if owner("move") is not owner("propose"):
                 return False
             if first is None:
-                first, first_sim = m, c._ncmc_sim
+                first = m
             elif type(m) is not type(first) or list(m.atom_indices) != list(first.atom_indices):
-                return False
-            # one launch per operation is sized and laid out for ONE system: same atoms, same box, no barostat moving it
-            sysm, sys0 = getattr(c._ncmc_sim, "system", None), getattr(first_sim, "system", None)
-            if sysm is not sys0 and (getattr(sysm, "n_atoms", None) != getattr(sys0, "n_atoms", None) or not np.array_equal(getattr(sysm, "box", None), getattr(sys0, "box", None))):
-                return False
-            if c._ncmc_sim.reporters or getattr(c._ncmc_sim, "barostat", None) is not None:
                 return False
         return True
 
-    def _capture_states(self, active=None):
-        """getStateFromContext (reference blues/simulation.py:883-911) of every chain's NCMC context: one capture for all."""
-        snaps = self._ncmc_batch.snapshot_all(True, True, active=active)
+    def _capture_states(self, active=None, leg="ncmc"):
+        """getStateFromContext (reference blues/simulation.py:883-911) of every chain's NCMC (or MD) context: one capture for all."""
+        batch = self._ncmc_batch if leg == "ncmc" else self._md_batch
+        snaps = batch.snapshot_all(True, True, active=active)
         out = []
         for r, c in enumerate(self.chains):
             if snaps[r] is None:
                 out.append(None)
                 continue
-            ctx = c._ncmc_sim.context
+            ctx = (c._ncmc_sim if leg == "ncmc" else c._md_sim).context
             e = ctx._engine
             pe, ke = e.energies()
             # (enforcePeriodicBox=True of the chain-by-chain path: what reaches the host is wrapped molecule by molecule, context.getState)
@@ -399,13 +430,17 @@ class BatchedBLUESSimulation(object):
                         'box_vectors': list(ctx.box_vector_quantities()) if hasattr(ctx, "box_vector_quantities") else [unit.Quantity(np.array(row), "nanometer") for row in e.get_box()]})
         return out
 
-    def _restore_states(self, states, velocities=True):
-        """setContextFromState of every chain whose entry is not None (box vectors of an NVT chain never change: context.py)."""
-        snaps = [None if st is None else st['positions'].on_device() for st in states]
-        if any(st is not None and sn is None for st, sn in zip(states, snaps)) or not self._ncmc_batch.restore_all(snaps, True, velocities):
+    def _restore_states(self, states, velocities=True, leg="ncmc"):
+        """setContextFromState of every chain whose entry is not None into its NCMC / MD / alch context (box vectors of an NVT
+        chain never change: context.py).  A State captured from one leg's engine goes into another's device to device."""
+        batch = {"ncmc": self._ncmc_batch, "md": self._md_batch, "alch": self._alch_batch}[leg]
+        sim_of = {"ncmc": (lambda c: c._ncmc_sim), "md": (lambda c: c._md_sim), "alch": (lambda c: c._alch_sim)}[leg]
+        snaps = [None if st is None else (st['positions'].on_device() if hasattr(st['positions'], "on_device") else None) for st in states]
+        if any(st is not None and sn is None for st, sn in zip(states, snaps)) or not batch.restore_all(snaps, True, velocities):
             for c, st in zip(self.chains, states):   # somebody read or edited the arrays on the host: the member calls
                 if st is not None:
-                    c._ncmc_sim.context = c.setContextFromState(c._ncmc_sim.context, st, velocities=velocities)
+                    sim = sim_of(c)
+                    sim.context = c.setContextFromState(sim.context, st, velocities=velocities)
 
     def _stepNCMC_batched(self, nstepsNC, moveStep):
         chains, batch = self.chains, self._ncmc_batch
@@ -418,48 +453,97 @@ class BatchedBLUESSimulation(object):
             c._move_engine.selectMove()
         nstepsNC, moveStep = int(nstepsNC), int(moveStep)
         cuts = sorted(set([0, nstepsNC] + ([moveStep] if 0 <= moveStep < nstepsNC else [])))
+        one_scatter = self._move_batchable()
         failed = {}
+
+        def hook(r, fn):
+            """A Move hook of chain r under the reference's policy (blues/simulation.py:1088-1094): an exception is logged, the
+            move cleans up, the chain's switch is abandoned."""
+            c = chains[r]
+            try:
+                c._ncmc_sim.context = fn(c, c._ncmc_sim.context)
+            except Exception as e:
+                import traceback
+                traceback.print_tb(e.__traceback__)
+                logger.error(e)
+                c._move_engine.selected_move._error(c._ncmc_sim.context)
+                failed[r] = e
+
         for a, b in zip(cuts[:-1], cuts[1:]):
+            if a == 0 and not one_scatter:
+                for r in range(R):
+                    hook(r, lambda c, ctx: c._move_engine.selected_move.beforeMove(ctx))
             live = [r not in failed for r in range(R)]
             if a == moveStep and any(live):
                 if a > 0:   # the work of the instantaneous move needs U(x) before the edit (integrators.py:184-205): for all chains at once
                     batch.prefetch_energies(active=live, kinetic=False)
-                idx = list(chains[0]._move_engine.selected_move.atom_indices)
-                snaps = batch.snapshot_all(True, False, active=live)                 # context.getState(getPositions=True)
-                xyz = batch.read_atoms_all(idx, snaps=snaps)                         # positions[atom_indices]
-                new = np.array([chains[r]._move_engine.selected_move.propose(xyz[r]) if live[r] else xyz[r] for r in range(R)])
-                if not batch.restore_edited_all(snaps, idx, new):                    # positions[i] = ...; context.setPositions(positions)
+                if one_scatter:
+                    idx = list(chains[0]._move_engine.selected_move.atom_indices)
+                    snaps = batch.snapshot_all(True, False, active=live)                 # context.getState(getPositions=True)
+                    xyz = batch.read_atoms_all(idx, snaps=snaps)                         # positions[atom_indices]
+                    new = np.array([chains[r]._move_engine.selected_move.propose(xyz[r]) if live[r] else xyz[r] for r in range(R)])
+                    if not batch.restore_edited_all(snaps, idx, new):                    # positions[i] = ...; context.setPositions(positions)
+                        for r in range(R):
+                            if live[r]:
+                                q = unit.DeviceQuantity(snaps[r], 1, "nanometer")
+                                for k, i in enumerate(idx):
+                                    q[i] = new[r][k]
+                                chains[r]._ncmc_sim.context.setPositions(q)
                     for r in range(R):
                         if live[r]:
-                            q = unit.DeviceQuantity(snaps[r], 1, "nanometer")
-                            for k, i in enumerate(idx):
-                                q[i] = new[r][k]
-                            chains[r]._ncmc_sim.context.setPositions(q)
-                for r in range(R):
-                    if live[r]:
-                        m = chains[r]._move_engine.selected_move
-                        m.positions = new[r]
-                        chains[r]._move_engine.move_name = getattr(chains[r]._move_engine, "move_name", type(m).__name__)
+                            m = chains[r]._move_engine.selected_move
+                            m.positions = new[r]
+                            chains[r]._move_engine.move_name = getattr(chains[r]._move_engine, "move_name", type(m).__name__)
+                else:
+                    for r in range(R):
+                        if live[r]:
+                            logger.info('Performing %s...' % getattr(chains[r]._move_engine, "move_name", "move"))
+                            hook(r, lambda c, ctx: c._move_engine.runEngine(ctx))
             if b > a:
-                failed.update(self._advance(batch, sims, {r: b - a for r in range(R) if r not in failed}))
-        for r, e in failed.items():   # reference policy (simulation.py:1088-1094): log, abandon that chain's switch
-            logger.error(e)
+                for r, e in self._advance(batch, sims, {r: b - a for r in range(R) if r not in failed}).items():
+                    logger.error(e)       # reference policy (simulation.py:1088-1094): log, let the move clean up, abandon that chain's switch
+                    chains[r]._move_engine.selected_move._error(chains[r]._ncmc_sim.context)
+                    failed[r] = e
+            if b == nstepsNC and not one_scatter:
+                for r in range(R):
+                    if r not in failed:
+                        hook(r, lambda c, ctx: c._move_engine.selected_move.afterMove(ctx))
         batch.prefetch_energies(active=[r not in failed for r in range(R)], at_lambda_one=True)
         for c, st in zip(chains, self._capture_states()):
             c._setStateTable('ncmc', 'state1', st)
 
     def _decide_batched(self, temperature):
-        """_acceptRejectMove of every chain (reference blues/simulation.py:1121-1166): the tests chain by chain on numbers already
-        on the host, then the restores of the rejected chains in one call."""
+        """_acceptRejectMove of every chain (reference blues/simulation.py:1121-1166): the `alch` energies of the correction for
+        all chains at once, the tests chain by chain on numbers already on the host, then the State write-backs in one call --
+        accepted chains into their MD contexts where there are such, rejected ones back in place where there are none."""
         chains = self.chains
+        R = len(chains)
+        unmodified = [None] * R
+        if self._alch_batch is not None:
+            # reference simulation.py:1107-1110: the switched coordinates into the alch context, its potential energy
+            ends = [c.stateTable['ncmc']['state1'] for c in chains]
+            self._restore_states(ends, velocities=False, leg="alch")
+            self._alch_batch.prefetch_energies(kinetic=False)
+            unmodified = [c._alch_sim.context.getState(getEnergy=True).getPotentialEnergy() for c in chains]
         restore = []
-        for c in chains:
-            todo = record_decision(c, metropolis(c))
-            restore.append(None if todo is None else todo[1])    # (no separate MD context here: a rejection restores the pre-switch state in place)
-        self._restore_states(restore)
+        for r, c in enumerate(chains):
+            todo = record_decision(c, metropolis(c, unmodified[r]))
+            restore.append(None if todo is None else todo[1])
+        if self._md_batch is None:
+            self._restore_states(restore)            # a rejection restores the pre-switch state in place
+            return
+        self._restore_states(restore, velocities=False, leg="md")     # accepted: the switched configuration becomes the MD state
+        for c, st in zip(chains, restore):
+            if st is None:      # rejected: the MD context must still be where the iteration started (the reference's sanity check)
+                before = c.stateTable['md']['state0']['potential_energy']
+                now = c._md_sim.context.getState(getEnergy=True).getPotentialEnergy()
+                if not math.isclose(before._value, now._value, rel_tol=10.0 ** -rtol):
+                    logger.error('Last MD potential energy %s != Current MD potential energy %s. Potential energy should match the prior state.' % (before, now))
+                    sys.exit(1)
 
     def _reset_batched(self, temperature):
-        """_resetSimulations of every chain (reference blues/simulation.py:1168-1187): one reset, one velocity redraw."""
+        """_resetSimulations of every chain (reference blues/simulation.py:1168-1187): one reset, one velocity redraw (of the MD
+        contexts where the chains have them)."""
         chains = self.chains
         seeds, temps = [], []
         for c in chains:
@@ -468,12 +552,21 @@ class BatchedBLUESSimulation(object):
             temps.append(unit.value_in(temperature if temperature else c._ncmc_sim.context._integrator.getTemperature(), "kelvin"))
             seeds.append(c._rng.randint(0, 2 ** 31 - 1))
         self._ncmc_batch.reset_all()
+        leg = self._ncmc_batch if self._md_batch is None else self._md_batch
         for T in sorted(set(temps)):   # (one launch per distinct temperature: one, in practice)
-            self._ncmc_batch.set_velocities_to_temperature_all(T, seeds, active=[t == T for t in temps])
+            leg.set_velocities_to_temperature_all(T, seeds, active=[t == T for t in temps])
 
     def _sync_batched(self):
-        """_syncStatesMDtoNCMC of every chain where there is no separate MD context (reference blues/simulation.py:1028-1037): the
-        MD state is the NCMC context's own, its potential the one at lambda = 1."""
+        """_syncStatesMDtoNCMC of every chain (reference blues/simulation.py:1028-1037).  With MD contexts: their States in one
+        capture, into the NCMC contexts in one restore (device to device).  Without: the MD state is the NCMC context's own, its
+        potential the one at lambda = 1."""
+        if self._md_batch is not None:
+            self._md_batch.prefetch_energies()
+            states = self._capture_states(leg="md")
+            for c, st in zip(self.chains, states):
+                c._setStateTable('md', 'state0', st)
+            self._restore_states(states, velocities=True, leg="ncmc")
+            return
         self._ncmc_batch.prefetch_energies(at_lambda_one=True)
         for c, st in zip(self.chains, self._capture_states()):
             st['potential_energy'] = c._lambda_one_energy()

@@ -657,6 +657,54 @@ def test_batch_rejects_incongruent_members_and_misuse(Engine, tol_box):
     B2.close(); a.step(1)
 
 
+def test_batched_boundary_of_the_full_triple_equals_chain_by_chain(Engine, tol_box, tune):
+    """Chains that carry the reference's full triple -- md, alch and ncmc Simulations (blues/simulation.py:768-809) -- through whole
+    BLUES iterations with an MD leg (run(): blues/simulation.py:1215-1257): the MD -> NCMC hand-over as one capture of the MD batch and
+    one restore into the NCMC batch, the alch energies of the correction for all chains at once, accepted States into the MD batch in
+    one call, the velocity redraw on the MD batch -- against the same chains taken through those steps one by one: same accept
+    records, same final MD and NCMC states, bit for bit."""
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    md_sys = copy.copy(s); md_sys.alchemical_atoms = np.zeros(0, np.int32)
+    lig = np.arange(15)
+    R, nsteps, nmd, nIter = 4, 10, 6, 3
+    vels = _replica_inputs(s, v, R)
+    tune(assume_batch=R)
+
+    def chains():
+        out = []
+        for r in range(R):
+            sim = Simulation(None, s, _integ(nsteps, seed=700 + r, dt=0.002), precision="mixed", replica=r)
+            md = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=800 + r), precision="mixed", replica=r)
+            alch = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=900 + r), precision="mixed", replica=r)
+            md.context.setPositions(unit.Quantity(s.positions, "nanometer")); md.context.setVelocities(unit.Quantity(vels[r], "nanometer/picosecond"))
+            mover = moves.MoveEngine(moves.RandomLigandRotationMove(lig, s.mass[lig], random_state=90 + r))
+            out.append(simulation.BLUESSimulation(simulation.SimulationSet(sim, md=md, alch=alch), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": nIter, "nstepsMD": nmd},
+                                                  mover, rng=np.random.RandomState(4000 + r)))
+        return out
+
+    results = {}
+    for fast in (False, True):
+        np.random.seed(123)
+        cs = chains()
+        B = simulation.BatchedBLUESSimulation(cs, batched_boundary=fast)
+        assert B._batchable() == fast and B._md_batch is not None and B._alch_batch is not None
+        records = []
+        B.run(nIter=nIter, on_iteration=lambda N, last: records.append([dict(l) for l in last]))
+        results[fast] = (records, [c._md_sim.context._engine.get_positions() for c in cs], [c._md_sim.context._engine.get_velocities() for c in cs],
+                         [c._ncmc_sim.context._engine.get_positions() for c in cs], [c.accept for c in cs])
+        assert all(c._md_sim.currentStep == nIter * nmd for c in cs)
+        B.close()
+    (rec0, x0, v0, n0, acc0), (rec1, x1, v1, n1, acc1) = results[False], results[True]
+    assert acc0 == acc1
+    for N in range(nIter):
+        for r in range(R):
+            for key in ("accept", "log_accept", "correction", "randnum", "protocol_work"):
+                assert rec0[N][r][key] == rec1[N][r][key], (N, r, key, rec0[N][r][key], rec1[N][r][key])
+    for r in range(R):
+        assert np.array_equal(x0[r], x1[r]) and np.array_equal(v0[r], v1[r]) and np.array_equal(n0[r], n1[r])
+
+
 def test_restoring_a_state_that_moves_a_frozen_atom(Engine):
     """setPositions from a device-resident State learns on the device whether a FROZEN atom changed (the frozen-frozen energy is a
     cached constant).  The verdict is read back lazily, by the next evaluation; two restores in a row must not lose it."""
@@ -823,7 +871,7 @@ def test_configs3_full_size_water_switch_properties():
                                                  rng=np.random.RandomState(60 + r)))
     np.random.seed(21)
     B = simulation.BatchedBLUESSimulation(chains)
-    assert not B._batchable()                     # this Move has hooks of its own: the chain-by-chain boundary, as the reference runs it
+    assert B._batchable() and not B._move_batchable()   # State hand-overs, Metropolis step and reset in one call per operation; this Move's hooks (beforeMove / afterMove of its own) chain by chain, as the reference runs them
     records = []
     B.run(nIter=1, on_iteration=lambda N, last: records.append([dict(l) for l in last]))
     last = records[0]
