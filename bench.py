@@ -88,15 +88,22 @@ def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False, md_ste
     return system, vel, chains
 
 
-def md_states(chains, x0, v0, batch=None):
+def md_states(chains, x0, v0, batch=None, driver=None, decorrelate=0):
     """What the MD leg hands over at the start of every iteration (reference simulation.py:1028-1037: getStateFromContext
     on the MD context, setContextFromState on the NCMC one).  There is no MD leg in this benchmark, so the hand-over State
-    is taken once per chain from the initial coordinates; like any State of this engine it lives in HBM, i.e. the inputs
-    of the timed region are resident on the device."""
+    is taken once per chain; like any State of this engine it lives in HBM, i.e. the inputs of the timed region are resident
+    on the device.  decorrelate > 0 (set-up time): every chain gets its OWN state first -- velocities from its own seed, that
+    many steps of its own switch (lambda <= decorrelate / nstepsNC), integrator.reset() -- instead of the common start."""
     from blues_amd import unit
     for c in chains:
         ctx = c._ncmc_sim.context
         ctx.setPositions(unit.Quantity(x0, "nanometer")); ctx.setVelocities(unit.Quantity(v0, "nanometer/picosecond"))
+    if decorrelate > 0 and driver is not None:
+        driver._reset_batched(300.0)      # (velocities: each chain draws its own seed from its own stream)
+        errors = driver._advance(driver._ncmc_batch, [c._ncmc_sim for c in chains], {r: int(decorrelate) for r in range(len(chains))})
+        if errors:
+            raise RuntimeError("decorrelation leg failed: %s" % list(errors.values())[0])
+        driver._reset_batched(300.0)
     if batch is not None:      # the energies every chain's State is about to ask for: one evaluation for the whole batch (set-up time only)
         batch.prefetch_energies()
     return [c.getStateFromContext(c._ncmc_sim.context, c._state_keys) for c in chains]
@@ -328,9 +335,10 @@ def main():
                     "nonbonded launch places one workgroup per chain).  The default, 2048 chains as two batches of 1024, is 48 GB of the 288 GB of "
                     "HBM and 14 s of set-up; one batch of 1024 advances a chain-step in 0.88 us through the driver, 0.95 at 512 (DESIGN.md section 4d)")
     ap.add_argument("--groups", type=int, default=2, help="the rank's chains form this many replica batches, each driven from its own host thread on its "
-                    "own stream.  The batches take TURNS on the device for their stepping calls (one batch's kernels have the GPU to themselves: "
-                    "kernel durations mean what they say) while the other batches' threads do their per-chain host work -- a tenth of an iteration's "
-                    "wall time with one batch (1 = a single batch)")
+                    "own stream.  The batches' STEPPING calls take turns on the device (the other device-side calls of a batch -- energy prefetches, State "
+                    "captures and restores, resets -- are short and may run beside the turn holder's kernels: the in-loop mean of a kernel moves by ~1 %) while the "
+                    "other batches' threads do their per-chain host work -- a tenth of an iteration's wall time with one batch (1 = a single batch); the rank's "
+                    "all-gathers of the accept records follow, in iteration order, after the threads have finished")
     ap.add_argument("--concurrent", action="store_true", help="with --groups: no turns, the batches' kernels share the device (more ns/day; a kernel's "
                     "duration then includes its co-runners: DESIGN.md section 4d)")
     ap.add_argument("--workers", type=int, default=1, help="host threads for the per-chain plugin-boundary work inside a group")
@@ -341,6 +349,9 @@ def main():
                     "triple, and each timed step is sync -> NCMC switch -> Metropolis -> reset -> this many MD steps on the unfrozen System.  `value` stays the "
                     "NCMC leg's ns/day (its share of the wall time); `full_iteration` has both legs.  Use --replicas 16..256 --groups 1 (an all-mobile engine is ~60 MB)")
     ap.add_argument("--no-alch", action="store_true", help="with --md-steps: no `alch` Simulation (the correction's energies then come from the NCMC engine at lambda = 1)")
+    ap.add_argument("--decorrelate", type=int, default=250, help="set-up: steps of its own trajectory every chain runs (own velocities, own noise) before its hand-over State is "
+                    "taken, so that the timed switches start from as many different states as there are chains (1 ps by default)")
+    ap.add_argument("--same-start", action="store_true", help="every chain starts every switch from the SAME coordinates and velocities (rounds 1-4)")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-chain measurement")
@@ -451,7 +462,7 @@ def main():
             c._md_sim.context.setPositions(unit.Quantity(x0, "nanometer")); c._md_sim.context.setVelocities(unit.Quantity(v0, "nanometer/picosecond"))
         gstates = [None]
     else:
-        gstates = [md_states(grp, x0, v0, batch=drv._ncmc_batch) for grp, drv in zip(groups, drivers)]
+        gstates = [md_states(grp, x0, v0, batch=drv._ncmc_batch, driver=drv, decorrelate=0 if args.same_start else args.decorrelate) for grp, drv in zip(groups, drivers)]
     setup_parts["hand_over_states"] = time.perf_counter() - t_part
     t_setup = time.perf_counter() - t_setup - t_single
     clocks = [{"sync": 0.0, "switch": 0.0, "decide": 0.0} for _ in range(G)]
@@ -519,6 +530,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
     rank_elapsed = {"max": float(t.item()), "min": float(tmin.item()), "this_rank": elapsed}   # (host imbalance between ranks shows here first)
+    from blues_amd.replicas import gather_rank_numbers
+    per_rank = gather_rank_numbers([t_setup, memory_use()["host_peak_rss_gib"], float(os.getpid())])   # what N ranks on one host cost: set-up seconds, peak host memory
     elapsed = float(t.item())
 
     # the kernel north_star prices against the HBM roofline: the direct-space nonbonded kernel, timed alone with HIP
@@ -608,7 +621,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 pair math / f64 accumulation, f64 alchemical+integrator", "data": "synthetic",
             "data_note": ("every chain carries its own state from its own MD legs (the warm-up iterations included one)" if full else
-                          "every chain starts every switch from the same coordinates and velocities (its Philox stream differs): rebuild statistics are those of the first 4 ps from one geometry"),
+                          "every chain starts every switch from the same coordinates and velocities (its Philox stream differs): rebuild statistics are those of the first 4 ps from one geometry" if (args.same_start or args.decorrelate <= 0) else
+                          "every chain starts its switches from its OWN state (%d steps of its own trajectory at set-up: own velocities, own noise); there is no MD leg between the timed switches (--md-steps adds it)" % args.decorrelate),
             "nonbonded_method": "PME direct space only" if system.nonbonded_method == 1 else "PME direct + reciprocal space (mesh %dx%dx%d, order %d), dispersion correction %s" % (tuple(system.pme_grid) + (system.pme_order, "on" if system.dispersion_correction else "off")),
             "config": {"workload": "S23k %s: %d atoms, %d mobile, %d alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in %d replica batch(es)"
                        % (args.workload, n_atoms, int((system.mass > 0).sum()), len(system.alchemical_atoms), nsteps, R, G),
@@ -619,6 +633,8 @@ def main():
             "full_iteration": full_iteration,
             "single_replica": single,
             "rank_elapsed_seconds": rank_elapsed,
+            "per_rank": {"setup_seconds": per_rank[:, 0].tolist(), "host_peak_rss_gib": per_rank[:, 1].tolist(), "distinct_processes": int(len(set(per_rank[:, 2].tolist()))),
+                         "nproc": os.cpu_count(), "usable_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None},
             "process_group": {"backend": (args.backend if world > 1 else None), "same_device": bool(args.same_device),
                               "replica_seeds_first_chain_of_each_rank": [int(replica_seed(1234, r * R)) for r in range(world)]},
             "memory": memory_use(),

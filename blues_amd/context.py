@@ -19,8 +19,11 @@ class PeriodicWrapper(object):
     def __init__(self, system):
         # the molecule table depends on the bond / constraint graph alone: R contexts built from one System object share it
         # (26 ms of union-find per context otherwise -- a third of a rank's set-up time at 512 chains)
+        # (keyed on the graph itself, not on the atom count: a copy.copy() of the System shares this attribute, and its bonds or
+        # constraints may have been edited since)
+        graph = (system.n_atoms,) + tuple(hash(np.ascontiguousarray(getattr(system, name, np.zeros((0, 2))), dtype=np.int64).tobytes()) for name in ("bond_atoms", "constraint_atoms"))
         cached = getattr(system, "_periodic_molecules", None)
-        if cached is not None and cached[0] == system.n_atoms:
+        if cached is not None and cached[0] == graph:
             _, self.molecule_of, self._order, self._start = cached
             self.box = np.asarray(system.box, dtype=np.float64).reshape(-1)[:3].copy() if np.size(system.box) == 3 else np.diag(np.asarray(system.box, dtype=np.float64).reshape(3, 3)).copy()
             return
@@ -43,7 +46,7 @@ class PeriodicWrapper(object):
         self._order = order
         self._start = np.searchsorted(self.molecule_of[order], np.arange(self.molecule_of.max() + 2))
         try:
-            system._periodic_molecules = (n, self.molecule_of, self._order, self._start)
+            system._periodic_molecules = (graph, self.molecule_of, self._order, self._start)
         except Exception:
             pass   # (a System that takes no attributes: every context computes its own)
         self.box = np.asarray(system.box, dtype=np.float64).reshape(-1)[:3].copy() if np.size(system.box) == 3 else np.diag(np.asarray(system.box, dtype=np.float64).reshape(3, 3)).copy()

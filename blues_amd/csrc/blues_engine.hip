@@ -38,7 +38,8 @@ static thread_local std::string g_create_error;
 // set-up cost accounting (diagnostic, blues_debug_setup_seconds): [0] blues_engine_create, [1] sort_and_tile, [2] its device uploads,
 // [3] device allocations (hipMalloc), [4] zero-fills, [5] host-to-device copies of DBuf::upload, [6] number of allocations, [7] streams and events
 static double g_setup_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-struct SetupTimer { double* acc; std::chrono::steady_clock::time_point t0; explicit SetupTimer(int k) : acc(&g_setup_sec[k]), t0(std::chrono::steady_clock::now()) {} ~SetupTimer() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } };
+static std::mutex& setup_mu() { static std::mutex m; return m; }   // (engines are built from several host threads: bench.py --groups)
+struct SetupTimer { double* acc; std::chrono::steady_clock::time_point t0; explicit SetupTimer(int k) : acc(&g_setup_sec[k]), t0(std::chrono::steady_clock::now()) {} ~SetupTimer() { const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(setup_mu()); *acc += d; } };
 
 // Launch-policy overrides (include/blues_engine.h, BluesTuning): process-wide defaults copied into every engine / batch at its
 // creation.  The library reads no environment variables.
@@ -52,7 +53,7 @@ template <typename T> struct DBuf {
     void reserve(size_t count) {   // an existing buffer of the right size is reused (a re-sort keeps every address)
         if (!p || count != n) {
             release(); n = count;
-            SetupTimer tm(3); g_setup_sec[6] += 1.0;
+            SetupTimer tm(3); { std::lock_guard<std::mutex> lk(setup_mu()); g_setup_sec[6] += 1.0; }
             if (hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::string("hipMalloc failed");
         }
     }
@@ -216,6 +217,10 @@ struct BluesEngine {
     int hint_count = 0;   // list length that raises resort_hint
     int shape_S = 0, shape_jcap = 0; bool shape_overflow = false, forbid_atom = false; double shape_need = 0.0;
     int layout_R = 0;   // the batch size (batch_R) the current layout was derived for (sort_and_tile)
+    // a member of a batch whose layout is sized from the density (tile / sub-tile kernels): the capacities the batch agreed on, kept while
+    // they hold this member's lists -- a MonteCarloBarostat leaves every member in its own box, and a capacity re-derived from n / V
+    // would differ between members by a step of 64 after a 1 % change of volume (batch_congruent)
+    int pin_jcap = 0, pin_seg = 0, pin_nw = 0, pin_wpb = 0;
     int S = 1, n_lists = 0;   // S consecutive i-tiles share one j-list (mode 2; 1 otherwise); n_lists = ceil(n_itiles / S)
     DBuf<unsigned short> d_alist, d_plist; DBuf<int> d_acount, d_pcount, d_pneed; DBuf<unsigned> d_xprune[3];   // pruned lists (by i-slot)
     DBuf<uint4> d_pimg4; DBuf<float2> d_pimg2; DBuf<int> d_mlist, d_mcount; int mcap = 0;   // packed group images (ListArgs)
@@ -754,6 +759,7 @@ static int sort_and_tile(BluesEngine* h) {
         if (h->tune.fuse_forces >= 0) h->fuse_forces = h->tune.fuse_forces != 0;
         if (h->fuse_forces) { WPB = 4; NW = std::max(4, NW / 3); }  // ~3 segments per wave: as long as the alchemical role
         NW = std::max(WPB, (NW / WPB) * WPB);
+        if (h->pin_jcap > 0 && h->batch && std::min<double>(n, est / 1.8 * 1.2) + 64 <= h->pin_jcap) { jcap = h->pin_jcap; h->jcap = jcap; CH = h->pin_seg; NW = h->pin_nw; WPB = h->pin_wpb; }
         h->seg_len = CH; h->waves_tile = NW; h->wpb = WPB; h->npart = NW / WPB;
         h->k1_iw = 64;
         if (!h->fuse_forces && h->precision == 0) {
@@ -2336,7 +2342,7 @@ static int do_steps(BluesEngine* h, int nsteps) {
 struct BatchSig {
     int h_step, h_lambda_step, h_prop, h_first_step, pass_L, prog_n, prog_trace, nprop;
     unsigned h_draw, prog_draw_base, noise_draw_base;
-    unsigned char pass_valid, lists_forced, vel_clean, noise_valid, tracing, sorted_ok, pass_valid_for_l, have_positions;
+    unsigned char pass_valid, lists_forced, vel_clean, noise_valid, tracing, sorted_ok, pass_valid_for_l, have_positions, fin_pending, fin_mask;
     unsigned char ops[MAX_OPS];
 };
 static int batch_enter(BluesBatch* B) {
@@ -2370,6 +2376,7 @@ static BatchSig batch_sig(const BluesEngine* h) {
     g.h_draw = 0; g.prog_draw_base = h->prog.n ? h->h_draw - h->prog_draw_base : 0; g.noise_draw_base = h->noise_valid ? h->h_draw - h->noise_draw_base : 0;
     g.pass_valid = h->pass_valid; g.lists_forced = h->lists_forced; g.vel_clean = h->vel_clean; g.noise_valid = h->noise_valid; g.tracing = h->tracing;
     g.sorted_ok = h->sorted_ok; g.pass_valid_for_l = h->pass_valid_for_l; g.have_positions = h->have_positions;
+    g.fin_pending = h->fin_pending; g.fin_mask = g.fin_pending ? (unsigned char)h->fin_mask : 0;   // (what flush_program decides on: members in lock step must agree)
     for (int q = 0; q < h->prog.n; q++) g.ops[q] = h->prog.ops[q];
     return g;
 }
@@ -2864,7 +2871,7 @@ static void batch_detach_all(BluesBatch* B) {
     for (BluesEngine* m : B->eng) if (m) {
         hipStreamSynchronize(m->stream);
         m->batch = nullptr; m->batch_index = -1; m->batch_R = m->tune.assume_batch > 0 ? m->tune.assume_batch : 1;
-        m->shape_S = 0; m->shape_jcap = 0; m->forbid_atom = false;
+        m->shape_S = 0; m->shape_jcap = 0; m->forbid_atom = false; m->pin_jcap = m->pin_seg = m->pin_nw = m->pin_wpb = 0;
         relayout(m);
     }
     B->eng.clear(); B->leader = nullptr; B->lockstep = false;
@@ -2933,7 +2940,7 @@ static int load_positions(BluesEngine* h, const double* const src[3], int stride
     if (!h->h_xfer && hipHostMalloc((void**)&h->h_xfer, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) E_FAIL(h, "hipHostMalloc failed");
     HIP_OK(h, hipMemcpyAsync(h->h_xfer, h->d_xfer_out.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     h->xfer_pending = true; h->xfer_stream = h->stream; h->xfer_src = h->h_xfer;
-    h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear();
+    h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->fin_pending = false; h->ecache.clear();
     h->lists_forced = true;
     return 0;
 }
@@ -2966,7 +2973,7 @@ int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
         HIP_OK(h, hipStreamSynchronize(h->stream));
         h->hx = st;
         if (upload_xyz(h, h->hx.data(), h->d_x)) return 1;
-        h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear(); h->e_frozen_valid = false; h->pme_static_valid = false;
+        h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->fin_pending = false; h->ecache.clear(); h->e_frozen_valid = false; h->pme_static_valid = false;
         return sort_and_tile(h);
     }
     // one interleaved transfer; de-interleaving, image refresh and the re-sort statistics happen on the device
@@ -2994,7 +3001,7 @@ int blues_set_box(BluesEngine* h, const double box[9]) {
     h->box[0] = box[0]; h->box[1] = box[4]; h->box[2] = box[8];
     h->box_epoch++;
     derive_margins(h);   // (the layout re-derives the skin for the new box)
-    h->sorted_ok = false; h->pass_valid = false; h->e_frozen_valid = false; h->ecache.clear();
+    h->sorted_ok = false; h->pass_valid = false; h->fin_pending = false; h->e_frozen_valid = false; h->ecache.clear();
     if (h->pme && (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h))) return 1;
     if (h->have_positions) { if (download_xyz(h, h->hx.data(), h->d_x)) return 1; return sort_and_tile(h); }
     return 0;
@@ -3185,7 +3192,7 @@ int blues_set_global(BluesEngine* h, const char* name, double value) {
     }
     else if (k == "step") h->h_step = (int)value;
     else if (k == "lambda") h->h_lambda = value;
-    else if (k == "lambda_step") { h->h_lambda_step = (int)value; h->pass_valid = false; }
+    else if (k == "lambda_step") { h->h_lambda_step = (int)value; h->pass_valid = false; h->fin_pending = false; }
     else if (k == "first_step") h->h_first_step = (int)value;
     else if (k == "prop") h->h_prop = (int)value;
     else if (k == "nprop") h->nprop = (int)value;
@@ -3195,8 +3202,8 @@ int blues_set_global(BluesEngine* h, const char* name, double value) {
     else if (h->switch_mode != BLUES_SWITCH_NONE && (k == "total_work" || k == "naccept" || k == "ntrials")) {
         if (k == "naccept") h->sw_naccept = (int)value; else if (k == "ntrials") h->sw_ntrials = (int)value;   // (total_work is derived)
     }
-    else if (k == "lambda_sterics") { h->cur_ls = value; h->pass_valid = false; }
-    else if (k == "lambda_electrostatics") { h->cur_le = value; h->pass_valid = false; }
+    else if (k == "lambda_sterics") { h->cur_ls = value; h->pass_valid = false; h->fin_pending = false; }
+    else if (k == "lambda_electrostatics") { h->cur_le = value; h->pass_valid = false; h->fin_pending = false; }
     else E_FAIL(h, "global variable '%s' cannot be set", name);
     return 0;
 }
@@ -3205,7 +3212,7 @@ int blues_reset(BluesEngine* h) {
     HIP_OK(h, hipSetDevice(h->device));
     if (flush_program(h)) return 1;
     h->h_step = 0; h->h_lambda = 0.0; h->h_first_step = 0; h->h_perturbed = 0.0; h->h_unperturbed = 0.0; h->h_prop = 1; h->h_lambda_step = 0;
-    h->unpert_valid = false; h->x_edited = false; h->pass_valid = false;
+    h->unpert_valid = false; h->x_edited = false; h->pass_valid = false; h->fin_pending = false;
     HIP_OK(h, hipMemsetAsync(h->d_acc.p, 0, sizeof(DevAccum), h->stream));
     h->acc_cache_valid = false;
     h->sw_shadow = 0.0; h->sw_Einit = 0.0; h->sw_Efinal = 0.0; h->sw_naccept = 0; h->sw_ntrials = 0; h->sw_accept = 0;   // switching.py:1023-1036
@@ -3525,6 +3532,8 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
         m->use_graph = false;  // graph replays carry per-engine frozen arguments
     }
     if (batch_plan_shape(B, true)) { g_batch_create_error = B->err; batch_detach_all(B); delete B; return 1; }
+    if (engines[0]->sorted_ok && engines[0]->k1_mode != 2 && engines[0]->k1_mode != 3)
+        for (int r = 0; r < count; r++) { BluesEngine* m = engines[r]; m->pin_jcap = engines[0]->jcap; m->pin_seg = engines[0]->seg_len; m->pin_nw = engines[0]->waves_tile; m->pin_wpb = engines[0]->wpb; }
     // off by default: measured on MI355X at R = 256 it does not pay (with 256 x 276 mobile atoms SOME atom crosses skin/2
     // every ~3 steps, and rebuilding all members at once costs about what one rebuild per step did: 669 vs 678 us/step)
     B->sync_lists = false;
@@ -3744,7 +3753,7 @@ static int batch_restore_impl(BluesBatch* B, BluesSnapshot* const* snaps, int wh
         BluesEngine* h = B->eng[r];
         if (what & 1) {
             h->xfer_pending = true; h->xfer_stream = h->stream; h->xfer_src = B->h_xfer_all + 4 * r;
-            h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->ecache.clear(); h->lists_forced = true;
+            h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->fin_pending = false; h->ecache.clear(); h->lists_forced = true;
             h->st_launches += n_idx > 0 ? 2 : 1;
             if (snaps[r]->owner == h && n_idx == 0 && snaps[r]->box_epoch == h->box_epoch) h->ecache = snaps[r]->ecache;   // the energy that was known for these positions (in this box) is known again
             if (resolve_xfer(h)) { B->err = h->err; return 1; }   // (already on the host: no wait)
@@ -3809,7 +3818,7 @@ int blues_batch_reset(BluesBatch* B, const int32_t* mask) {
         if (mask && !mask[r]) continue;
         acc[r] = h->d_acc.p;
         h->h_step = 0; h->h_lambda = 0.0; h->h_first_step = 0; h->h_perturbed = 0.0; h->h_unperturbed = 0.0; h->h_prop = 1; h->h_lambda_step = 0;
-        h->unpert_valid = false; h->x_edited = false; h->pass_valid = false; h->acc_cache_valid = false;
+        h->unpert_valid = false; h->x_edited = false; h->pass_valid = false; h->fin_pending = false; h->acc_cache_valid = false;
     }
     int rc = batch_arena_upload(B, sizeof(DevAccum*) * R);
     if (!rc) hipLaunchKernelGGL(k_zero_acc_b, dim3((R + 255) / 256), dim3(256), 0, B->stream, reinterpret_cast<DevAccum* const*>(B->d_arena.p), R);

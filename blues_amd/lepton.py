@@ -60,6 +60,7 @@ def compile_expression(expr):
 
 
 _TABLES = {}   # (expression, n) -> tuple of values: R chains of one protocol share the table (50 ms of tree walking each otherwise)
+_TABLES_LOCK = __import__("threading").Lock()   # (chains are built from several host threads: bench.py --groups)
 
 
 def tabulate(expr, n_lambda_steps):
@@ -67,9 +68,13 @@ def tabulate(expr, n_lambda_steps):
     forms it, (lambda_step+1)/n_lambda_steps (reference blues/integrators.py:222)."""
     n = int(n_lambda_steps)
     key = (str(expr), n)
-    if key not in _TABLES:
+    with _TABLES_LOCK:
+        table = _TABLES.get(key)
+    if table is None:
         f = compile_expression(expr)
-        _TABLES[key] = (f(**{"lambda": 0.0}),) if n <= 0 else tuple(f(**{"lambda": i / n}) for i in range(n + 1))
-        if len(_TABLES) > 64:      # (bounded: protocols are few)
-            _TABLES.pop(next(iter(_TABLES)))
-    return list(_TABLES[key])
+        table = (f(**{"lambda": 0.0}),) if n <= 0 else tuple(f(**{"lambda": i / n}) for i in range(n + 1))
+        with _TABLES_LOCK:
+            _TABLES[key] = table
+            if len(_TABLES) > 64:      # (bounded: protocols are few)
+                _TABLES.pop(next(iter(_TABLES)))
+    return list(table)

@@ -71,6 +71,22 @@ def gather_decision_block(records, device=None):
     return torch.cat(out).cpu().numpy()
 
 
+def gather_rank_numbers(values, device=None):
+    """Per-rank diagnostics (set-up seconds, host memory, ...) -> (world, len(values)) on every rank; the same collective path as
+    the accept records (bookkeeping: once per run)."""
+    import torch
+    import torch.distributed as dist
+    rec = torch.as_tensor(np.asarray(values, dtype=np.float64).reshape(-1))
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec.numpy().reshape(1, -1)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    rec = rec.to(device)
+    out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, rec)
+    return torch.stack(out).cpu().numpy()
+
+
 def acceptance_summary(records):
     r = np.asarray(records, dtype=np.float64).reshape(-1, len(RECORD_FIELDS))
     return {"replicas": int(r.shape[0]), "accepted": int(r[:, 0].sum()), "mean_log_accept": float(np.nanmean(r[:, 2])),

@@ -169,7 +169,9 @@ typedef struct BluesTuning {
                                 * 0: the nonbonded kernel walks the full lists */
     double jcap_scale;         /* > 0: scales the list capacities (tests shrink them to reach the re-sort path) */
     double acap_scale;
-    int32_t k1_mode;           /* -1 auto; 1: never the per-atom-list kernel (sub-tile kernel in its place) */
+    int32_t k1_mode;           /* -1 auto; 1: never the per-atom-list kernel nor fragment lists (sub-tile kernel in their place);
+                                * 2: never fragment lists; 3: fragment lists (kernels_frag.h) wherever the engine can use them (mixed
+                                * precision), also where most atoms are frozen or the system is a handful of tiles */
     int32_t list_group;        /* i-tiles per list of the per-atom-list kernel; 0 auto */
     int32_t sub_iw;            /* i-atoms per wave of the sub-tile kernel (8, 16, 32); 0 auto */
     int32_t sub_chunks;        /* its list chunks per i-tile; 0 auto */
@@ -259,11 +261,11 @@ int blues_reset(BluesEngine *h);
  * builds executed [11] potential-energy evaluations launched by this engine
  * alone (those served by blues_batch_prefetch_energies are not counted)
  * [12] nonbonded kernel in use: 0 tile kernel, 1 sub-tile kernel, 2 per-atom
- * lists over an LDS image [13] i-tiles per j-list [14] entries of all per-atom
- * lists at the last rebuild [15] 64-entry wave iterations they take
- * [16] pruned per-atom lists re-derived so far (one count per atom and prune)
- * [17] entries of all pruned lists now [18] 64-entry wave iterations they take
- * [19] 1 if the nonbonded kernel walks pruned lists [20] alchemical kernel in
+ * lists over an LDS image, 3 fragment lists [13] i-tiles per j-list [14] entries of all per-atom
+ * lists at the last rebuild (fragment lists: of the outer lists) [15] 64-entry wave iterations they take
+ * [16] pruned per-atom lists re-derived so far (one count per atom and prune; fragment lists: prunes of the chain)
+ * [17] entries of all pruned lists now (fragment lists: of the inner lists) [18] 64-entry wave iterations they take
+ * [19] 1 if the nonbonded kernel walks pruned (inner) lists [20] alchemical kernel in
  * use for the env pairs: 0 lane = (atom, list entry), 1 dense pair lists */
 #define BLUES_N_STATS 21
 int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);

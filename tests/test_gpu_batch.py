@@ -546,6 +546,70 @@ def test_batched_md_leg_with_barostat_equals_per_chain(Engine, tol_box, tune):
     batch.close()
 
 
+def test_batched_md_leg_with_barostat_at_benchmark_size(Engine, tune):
+    """The same at the size the review asked for: S23k with nothing frozen, mixed precision.  Every accepted volume move
+    re-lays the member out in its own box; what the members of a batch must agree on (launch geometry) no longer depends on the
+    density -- fragment lists size their rows per member, the capacities of the density-sized layouts are pinned by the batch -- so
+    boxes that differ by a percent neither fail the batch nor cost the shared launches."""
+    from blues_amd.context import Simulation
+    from blues_amd.engine import NativeBatch
+    base, v = systems.s23k(frozen=False)
+    md_sys = systems.add_barostat(copy.copy(base), 300.0, pressure_bar=1.0, frequency=3)
+    md_sys.alchemical_atoms = np.zeros(0, np.int32)
+    R, nmd = 4, 31
+    tune(assume_batch=R)
+
+    def sims():
+        out = []
+        for r in range(R):
+            sim = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=400 + r), precision="mixed", replica=r)
+            sim.context.setVelocities(unit.Quantity(v * (1.0 + 0.02 * r), "nanometer/picosecond"))
+            out.append(sim)
+        return out
+    alone = sims()
+    for sim in alone:
+        sim.step(nmd)
+    together = sims()
+    batch = NativeBatch([sim.context._engine for sim in together])
+    errors = simulation.BatchedBLUESSimulation._advance(batch, together, {r: nmd for r in range(R)})
+    assert not errors, errors
+    boxes = []
+    for a, b in zip(alone, together):
+        assert b.context._engine.stats()["nonbonded_kernel"] == 3
+        assert b.barostat.total_attempted == a.barostat.total_attempted == nmd // 3 and b.barostat.total_accepted == a.barostat.total_accepted
+        assert np.array_equal(a.context._engine.get_box(), b.context._engine.get_box())
+        assert np.array_equal(a.context._engine.get_positions(), b.context._engine.get_positions())
+        boxes.append(np.asarray(b.context._engine.get_box())[0, 0])
+    assert sum(sim.barostat.total_accepted for sim in together) > 0 and len(set(boxes)) > 1
+    assert batch.stats()["lockstep_steps"] >= nmd - 2 * (nmd // 3) - 2, batch.stats()
+    batch.close()
+
+
+def test_fused_and_separate_finalize_agree(Engine, tune):
+    """The steady-state step kernel forms the summed forces of the pass itself (fuse_finalize, the default where one workgroup holds a
+    chain's clusters) or k_finalize does: same forces and energies bit for bit, the centre-of-mass momentum from differently grouped
+    partial sums -- protocol work and positions agree to rounding, not to the bit."""
+    from blues_amd.engine import NativeBatch
+    s, v = systems.s23k(mobile_atoms=275, frozen=True)
+    R, n = 8, 30
+    out = {}
+    for fuse in (1, 0):
+        tune(assume_batch=64, fuse_finalize=fuse)
+        engs = []
+        for r in range(R):
+            g = Engine(s, _integ(n, seed=300 + r, dt=0.004).to_data(precision=0, replica=r)); g.set_velocities(v); engs.append(g)
+        B = NativeBatch(engs)
+        _, w = B.step(n, trace=True)
+        out[fuse] = (w.copy(), [g.get_positions() for g in engs])
+        B.close()
+        for g in engs:
+            g.close()
+    scale = np.abs(out[1][0]).max()
+    assert np.abs(out[1][0] - out[0][0]).max() <= 1e-9 * scale
+    for a, b in zip(out[1][1], out[0][1]):
+        assert np.abs(a - b).max() < 1e-7      # (30 steps of a liquid amplify a last-bit difference of the momentum sums a hundredfold)
+
+
 def test_move_style_edits_of_a_device_resident_state(Engine, tol_box):
     """What a Move does (reference blues/moves.py:292-307): read positions[indices], assign positions[i] = xyz, hand the
     Quantity to setPositions.  On this engine only the touched atoms travel; the result equals the plain host route, also

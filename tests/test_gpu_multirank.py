@@ -82,3 +82,27 @@ def test_two_ranks_with_real_engines_on_one_gpu():
     assert 0.0 < el["min"] <= el["max"] and el["max"] < 600.0
     # every chain of both ranks stepped the whole (short) protocol in lock step with its batch
     assert out["engine"]["lockstep_steps_per_switch"] >= 200 and out["engine"]["fallback_steps_per_switch"] == 0
+
+
+def test_eight_ranks_with_real_engines_on_one_gpu():
+    """Dress rehearsal of the 8-GPU run on the one-GPU box (BASELINE.json configs[2]): bench.py starts EIGHT ranks, all on
+    device 0, each with its own replica batch of 8 real engines; the accept records travel over gloo.  Everything but RCCL and xGMI:
+    eight processes building engines at once (one build lock, one rendezvous port), 64 records in rank order, eight distinct Philox
+    keys, every rank's set-up time and host memory in the line."""
+    if _n_gpus() < 1:
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--same-device", "--steps", "1", "--warmup", "0",
+                        "--replicas", "8", "--groups", "1", "--nsteps-nc", "200", "--no-cpu", "--no-single"], env=env, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["accept_records_last"]["chains"] == 64 and np.isfinite(out["value"])
+    pg = out["process_group"]
+    assert pg["backend"] == "gloo" and pg["same_device"] is True
+    assert len(set(pg["replica_seeds_first_chain_of_each_rank"])) == 8
+    pr = out["per_rank"]
+    assert len(pr["setup_seconds"]) == 8 and pr["distinct_processes"] == 8 and all(0.0 < t < 600.0 for t in pr["setup_seconds"])
+    assert len(pr["host_peak_rss_gib"]) == 8 and all(0.05 < m < 32.0 for m in pr["host_peak_rss_gib"]) and pr["nproc"] >= 1
+    el = out["rank_elapsed_seconds"]
+    assert 0.0 < el["min"] <= el["max"] and el["max"] < 900.0
+    assert out["engine"]["lockstep_steps_per_switch"] >= 200 and out["engine"]["fallback_steps_per_switch"] == 0
