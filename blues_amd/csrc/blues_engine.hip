@@ -54,6 +54,7 @@ template <typename T> struct DBuf {
         if (!p || count != n) {
             release(); n = count;
             SetupTimer tm(3); { std::lock_guard<std::mutex> lk(setup_mu()); g_setup_sec[6] += 1.0; }
+            if (count * sizeof(T) > ((size_t)1 << 31)) fprintf(stderr, "[blues] a single device allocation of %.1f GiB (%zu elements of %zu bytes)\n", count * sizeof(T) / 1073741824.0, count, sizeof(T));
             if (hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::string("hipMalloc failed");
         }
     }
@@ -191,6 +192,7 @@ struct BluesEngine {
     // the copy into pinned memory is queued with the load and looked at by the next evaluation (resolve_xfer)
     unsigned* h_xfer = nullptr; bool xfer_pending = false; hipStream_t xfer_stream = nullptr;
     const unsigned* xfer_src = nullptr;   // where the pending verdict will be found: h_xfer, or this member's slot of a batch-wide read-back
+    bool xfer_foreign = false;            // the positions just loaded are another engine's State (the MD leg's hand-over): resolve_xfer
     hipEvent_t ev_edit = nullptr;                             // recorded after the last copy OUT of the pinned staging area
     unsigned char* h_edit = nullptr; size_t h_edit_cap = 0;   // pinned staging of a Move's edited atoms and of read-backs of a few atoms
     std::vector<int> edit_idx_host;                           // what d_edit_idx holds (a Move asks for the same atoms every time)
@@ -297,7 +299,7 @@ struct BluesBatch {
     DBuf<int> d_req; bool sync_lists = false;
     DBuf<int> d_work;   // [1 + 2R] members that rebuild their lists in the current force pass (kernels_batch.h: k_gather_stale_b)
     bool replanning = false;   // inside batch_plan_shape on behalf of a member (ensure_sorted)
-    DBuf<int> d_work_frag;   // [1 + R] fragment lists: members that rebuild or prune in the current pass (k_gather_frag_b)
+    DBuf<int> d_work_frag;   // [1 + 2R] fragment lists: members that rebuild or prune in the current pass (k_gather_frag_b), and a flag per member
     BluesTuning tune;   // the process-wide tuning at the time the batch was created
     // argument arena of the batched boundary calls (blues_batch_capture ...): pinned host side, device side, one upload per call
     unsigned char* h_arena = nullptr; size_t arena_cap = 0; DBuf<unsigned char> d_arena;
@@ -1001,6 +1003,15 @@ static int sort_and_tile(BluesEngine* h) {
                 recs.push_back(r);
             }
             if ((int)recs.size() != F) E_FAIL(h, "internal: %zu fragments laid out, %d expected", recs.size(), F);
+            {   // the ghost the list rows are padded with (kernels_frag.h): record F
+                FragRec g; memset(&g, 0, sizeof g);
+                AtomF G; memset(&G, 0, sizeof G);
+                const unsigned gt = (unsigned)type_id(G);
+                for (int b = 0; b < 3; b++) g.p[b] = make_uint4(0x12345677u + 7919u * b, 0x9abcdef1u + 104729u * b, 0x31415927u + 15485863u * b, 0u);
+                g.types = gt | (gt << 8) | (gt << 16) | (3u << 24);
+                g.sid = -1; g.islot0 = -1; g.s0 = 0;
+                recs.push_back(g);
+            }
             if ((int)ljt.size() > FR_TYPES_MAX) E_FAIL(h, "internal: %zu Lennard-Jones types exceed the fragment kernel's table", ljt.size());
             h->frag_ntypes = (int)ljt.size();
             const double rho_f = F / vol;
@@ -1703,7 +1714,10 @@ static int resolve_xfer(BluesEngine* h) {
     // (fragment lists: the order only decides how many blocks the list builder can skip and how local the force kernel's gathers are;
     // the builder itself asks for a new order when its blocks have spread (resort_hint) -- a State that arrives from another leg
     // every iteration must not cost a host-side re-sort every time)
-    const float far = h->k1_mode == 2 ? 0.09f : 1.0f;   // (squared displacement: 0.3 nm / 1 nm)
+    // ... only for such a State: a chain's OWN States (the Move's edit at lambda = 0.5, the restore after a rejection) come back every
+    // iteration with the atoms a few tenths of a nm from the sort -- re-sorting for those cost 2 x 5 ms per chain and iteration
+    const float far = (h->k1_mode == 2 && h->xfer_foreign) ? 0.09f : 1.0f;   // (squared displacement: 0.3 nm / 1 nm)
+    h->xfer_foreign = false;
     if (h->sorted_ok && h->k1_mode != 3 && (worst > far || (int)out[2] > h->n / 10)) {
         if (download_xyz(h, h->hx.data(), h->d_x)) return 1;
         h->sorted_ok = false;
@@ -1760,6 +1774,7 @@ static int force_pass(BluesEngine* h, int base_L) {
     // at an even index (first step, or the step after a Move) only V(slot 1).  Energies are always formed for all three.
     int fmask = 7;
     if (h->split == "HVRORVH" && h->nprop == 1) fmask = (base_L & 1) ? 5 : 2;
+    if (h->split == "L") fmask = 1;   // (the MD leg's one kick per step reads slot 0; no lambda, no other slot)
     if (h->tune.slot_mask >= 0) fmask = h->tune.slot_mask & 7;
     h->pass_fmask = fmask;
     // A large batch in per-atom-list mode forks the alchemical kernel onto a side stream after the group lists (which hold its
@@ -1804,6 +1819,9 @@ static int force_pass(BluesEngine* h, int base_L) {
         h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, h->k2_dense ? 3 : 0) || launch_bonded(h, true); h->cur = main_stream;
         if (rc) return 1;
         HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
+        // (tried and dropped in round 5: the nonbonded kernel in two launches -- the members whose lists are current on the main stream
+        // beside the rebuild / prune of the others on a second side stream, those members' share behind it: 707 against 552 us per
+        // step at R = 16, 2,355 against 2,020 at R = 64; the list kernels' workgroups slow the force kernel's more than they hide)
         rc = launch_lists<float>(h, h->lists_forced, 5);
         if (rc) return 1;
         h->lists_forced = false;
@@ -2770,7 +2788,9 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
         h->d_mass.upload(h->mass); h->d_charge.upload(h->charge); h->d_sigma.upload(h->sigma); h->d_eps.upload(h->eps);
         h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ctrl.alloc(1); h->d_stamps.alloc(64); h->d_tab_ls.upload(h->tab_ls); h->d_tab_le.upload(h->tab_le); h->d_ftot.alloc((size_t)9 * n); h->d_alch_self.alloc(9 * 64);
         h->d_alch_orig.upload(h->alch); h->d_alch_local.upload(h->alch_local);
-        h->d_trace.alloc((size_t)std::max(1, h->nsteps)); h->d_scratch.alloc((size_t)std::max(3 * n, 1024));
+        // (the protocol-work trace: one slot per step of the switch; an MD integrator has no H step, no protocol work -- and an
+        // nsteps of 2^30, which used to be 8 GiB of HBM per MD engine)
+        h->d_trace.alloc(it->n_lambda_steps > 0 ? (size_t)std::max(1, h->nsteps) : (size_t)1); h->d_scratch.alloc((size_t)std::max(3 * n, 1024));
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     {
         std::vector<int> mi(n, -1);
@@ -3115,12 +3135,14 @@ int blues_step(BluesEngine* h, int32_t n_steps) {
 int blues_run_switch(BluesEngine* h, int32_t n_steps, double* work_trace) {
     HIP_OK(h, hipSetDevice(h->device));
     const int first = h->h_step;
-    h->tracing = work_trace != nullptr;
+    const bool has_work = h->n_H > 0;   // (no H step: the protocol work stays 0, nothing is traced)
+    h->tracing = work_trace != nullptr && has_work;
     int rc = do_steps(h, n_steps);
     h->tracing = false;
     if (rc) return 1;
     if (check_flags(h)) return 1;
-    if (work_trace) {
+    if (work_trace && !has_work) { for (int i = 0; i < n_steps; i++) work_trace[i] = 0.0; }
+    else if (work_trace) {
         const int done = h->h_step - first;
         if (done > 0) HIP_OK(h, hipMemcpy(work_trace, h->d_trace.p + first, sizeof(double) * done, hipMemcpyDeviceToHost));
         for (int i = std::max(done, 0); i < n_steps; i++) work_trace[i] = done > 0 ? work_trace[done - 1] : 0.0;
@@ -3402,6 +3424,7 @@ int blues_set_positions_from_snapshot(BluesEngine* h, const BluesSnapshot* sn) {
     }
     const double* src[3] = {sn->x[0], sn->x[1], sn->x[2]};
     if (load_positions(h, src, 1, 0)) return 1;
+    h->xfer_foreign = sn->owner != h;
     // the energy that was known for these positions is known again (OpenMM re-evaluates; same value)
     if (sn->owner == h) { if (sn->box_epoch == h->box_epoch) h->ecache = sn->ecache; }   // (not across a change of the box)
     else if (resolve_xfer(h)) return 1;   // another engine's snapshot: its owner may recycle the buffer on its own stream
@@ -3539,7 +3562,7 @@ int blues_batch_create(BluesEngine* const* engines, int32_t count, BluesBatch** 
     B->sync_lists = false;
     B->tune = g_tuning;
     B->sync_lists = B->tune.batch_sync_lists != 0;
-    try { B->d_req.alloc(1); B->d_work.alloc((size_t)2 * count + 1); B->d_work_frag.alloc((size_t)count + 1); } catch (std::string& e) { g_batch_create_error = e; batch_detach_all(B); delete B; return 1; }
+    try { B->d_req.alloc(1); B->d_work.alloc((size_t)2 * count + 1); B->d_work_frag.alloc((size_t)2 * count + 1); } catch (std::string& e) { g_batch_create_error = e; batch_detach_all(B); delete B; return 1; }
     B->seen_epoch.assign(count, 0); B->failed.assign(count, 0); B->active.assign(count, 1); B->rec_active.assign(count, 0); B->rec_delta.assign(count, 0); B->leader = engines[0];
     *out = B;
     return 0;
@@ -3572,11 +3595,13 @@ int blues_batch_step(BluesBatch* b, int32_t n_steps, double* work_trace, int32_t
     std::vector<int> st(R, 0), first(R, 0);
     for (int r = 0; r < R; r++) first[r] = b->eng[r]->h_step;
     if (batch_enter(b)) return 1;
-    const int rc = batch_do_steps(b, n_steps, work_trace != nullptr, st.data());
+    const bool has_work = b->eng[0]->n_H > 0;
+    const int rc = batch_do_steps(b, n_steps, work_trace != nullptr && has_work, st.data());
     batch_leave(b);
     if (status) for (int r = 0; r < R; r++) status[r] = st[r];
     if (rc) return rc;
-    if (work_trace) for (int r = 0; r < R; r++) {
+    if (work_trace && !has_work) { for (size_t i = 0; i < (size_t)R * n_steps; i++) work_trace[i] = 0.0; }
+    else if (work_trace) for (int r = 0; r < R; r++) {
         BluesEngine* h = b->eng[r];
         double* wt = work_trace + (size_t)r * n_steps;
         const int done = st[r] ? 0 : h->h_step - first[r];
@@ -3752,7 +3777,7 @@ static int batch_restore_impl(BluesBatch* B, BluesSnapshot* const* snaps, int wh
     for (int r = 0; r < R; r++) if (snaps[r]) {
         BluesEngine* h = B->eng[r];
         if (what & 1) {
-            h->xfer_pending = true; h->xfer_stream = h->stream; h->xfer_src = B->h_xfer_all + 4 * r;
+            h->xfer_pending = true; h->xfer_stream = h->stream; h->xfer_src = B->h_xfer_all + 4 * r; h->xfer_foreign = snaps[r]->owner != h;
             h->have_positions = true; h->x_edited = true; h->pass_valid = false; h->fin_pending = false; h->ecache.clear(); h->lists_forced = true;
             h->st_launches += n_idx > 0 ? 2 : 1;
             if (snaps[r]->owner == h && n_idx == 0 && snaps[r]->box_epoch == h->box_epoch) h->ecache = snaps[r]->ecache;   // the energy that was known for these positions (in this box) is known again

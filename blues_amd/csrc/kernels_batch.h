@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_frag_lists_b(const RepNb<float>*
     }
 }
 template <bool ENERGY, bool REL>
-__global__ void __launch_bounds__(FR_THREADS) k_nonbonded_frag_b(const RepNb<float>* __restrict__ reps, int nb, int nrep) {
+__global__ void __launch_bounds__(FR_THREADS, FR_MIN_WAVES) k_nonbonded_frag_b(const RepNb<float>* __restrict__ reps, int nb, int nrep) {
     int rep, bx; batch_decode(nb, nrep, rep, bx);
     const RepNb<float>& rp = reps[rep];
     if (!rp.active) return;

@@ -48,6 +48,9 @@ struct FragBox { unsigned c[3]; float h[3]; float pad[2]; };   // bounding box o
 #define FR_FULL 0x1ffu
 #define FR_THREADS 256      // 4 waves: every kernel of this file
 #define FR_SP_MAX 64        // bonded partner fragments of one fragment (one lane each in the builder)
+#ifndef FR_MIN_WAVES
+#define FR_MIN_WAVES 4          // waves per SIMD the force kernel is compiled for (registers: 512 / this)
+#endif
 #define FR_QCAP 1280        // candidates one fragment's first test may let through (the builder's LDS queue, per wave)
 
 struct FragArgs {
@@ -182,7 +185,9 @@ __device__ __forceinline__ void frag_lists_body(const FragArgs& fa, const int fo
     const float sc[3] = {fa.scale[0], fa.scale[1], fa.scale[2]};
     unsigned* irow = fa.ilist + (size_t)fq * fa.icap;
     unsigned* orow = fa.olist + (size_t)fq * fa.ocap;
-    const unsigned pad_entry = (unsigned)f;   // mask 0: the walk counts none of its pairs
+    // rows are padded to whole chunks with the GHOST record (fimg[F]: no charge, no epsilon -- zero force and energy at any finite
+    // distance -- at a point no atom sits on) under a full mask: a padded chunk still takes the plain pair body
+    const unsigned pad_entry = (unsigned)fa.F | (FR_FULL << FR_MASK_SHIFT);
     int icnt = 0;
     auto push = [&](unsigned* row, int cap, int& count, bool pass, unsigned entry) {
         const unsigned long long bal = __ballot(pass);
@@ -438,13 +443,18 @@ __device__ __forceinline__ void nonbonded_frag_body(const FragArgs& fa, const Nb
                 if (REL) { rx[b] = (float)(int32_t)(ix[0] - R.p[b].x) * k_sx; ry[b] = (float)(int32_t)(iy[0] - R.p[b].y) * k_sy; rz[b] = (float)(int32_t)(iz[0] - R.p[b].z) * k_sz; }
                 else rx[b] = ry[b] = rz[b] = 0.0f;
             }
+            const bool ljb[3] = {ENERGY || __ballot(jl[0].y != 0.0f) != 0ull, ENERGY || __ballot(jl[1].y != 0.0f) != 0ull, ENERGY || __ballot(jl[2].y != 0.0f) != 0ull};
 #pragma unroll
             for (int a = 0; a < 3; a++) {
                 if (a >= cnt_i) break;   // wave-uniform
                 if (!((mob_i >> a) & 1u)) continue;   // (a frozen atom of the fragment: nobody reads its force)
                 if (lj_a[a]) {
 #pragma unroll
-                    for (int b = 0; b < 3; b++) pair(a, R.p[b], rx[b], ry[b], rz[b], __uint_as_float(R.p[b].w), jl[b], jw[b], masked_tag, exact_tag, std::true_type{}, (mask >> (3 * a + b)) & 1u);
+                    for (int b = 0; b < 3; b++) {
+                        // (wave-uniform: no lane's j-atom b has an epsilon -- the hydrogens of a chunk of waters -- and the pair has no 12-6 term)
+                        if (ljb[b]) pair(a, R.p[b], rx[b], ry[b], rz[b], __uint_as_float(R.p[b].w), jl[b], jw[b], masked_tag, exact_tag, std::true_type{}, (mask >> (3 * a + b)) & 1u);
+                        else pair(a, R.p[b], rx[b], ry[b], rz[b], __uint_as_float(R.p[b].w), jl[b], jw[b], masked_tag, exact_tag, std::false_type{}, (mask >> (3 * a + b)) & 1u);
+                    }
                 } else {
 #pragma unroll
                     for (int b = 0; b < 3; b++) pair(a, R.p[b], rx[b], ry[b], rz[b], __uint_as_float(R.p[b].w), jl[b], jw[b], masked_tag, exact_tag, std::false_type{}, (mask >> (3 * a + b)) & 1u);

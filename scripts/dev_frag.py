@@ -54,7 +54,7 @@ for spec in a.specs:
         g.close()
     engs = []
     for r in range(a.R):
-        integ = integrators.generateNCMCIntegrator(nstepsNC=a.nsteps + 80, dt=0.004, temperature=300.0, seed=replica_seed(1234, r))
+        integ = integrators.generateNCMCIntegrator(nstepsNC=a.nsteps + 1800, dt=0.004, temperature=300.0, seed=replica_seed(1234, r))
         g = NativeEngine(s, integ.to_data(precision=0, replica=r)); g.set_velocities(vel); engs.append(g)
     B = NativeBatch(engs) if a.R > 1 else None
     step = (lambda n: B.step(n)) if B else (lambda n: engs[0].step(n))
