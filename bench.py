@@ -8,10 +8,12 @@ it: state sync, _stepNCMC with the RandomLigandRotationMove at lambda = 0.5, acc
 
 metric = ns/day of switching trajectory, whole job: the sum over all independent chains on all ranks (SURVEY.md 8d:
 "aggregate over independent replicas").  One chain keeps a few percent of an MI355X busy, so each rank runs
---replicas R chains as ONE replica batch (every kernel launch covers all R); the single-chain
+--replicas R chains (default 2048) as --groups G replica batches (default 2: batches of 1024 whose stepping calls take
+turns on the device; every kernel launch of a batch covers all its chains, DESIGN.md sections 4d and 5); the single-chain
 rate of the same switch (configs[1] to the letter: one replica on one GPU) is measured too and reported beside it as
 "single_replica".  Ranks are independent (weak scaling, no data-path collective; one all-gather of the accept records
-per switch).
+per switch).  Every chain starts from its own state (--decorrelate steps at set-up; --same-start for the common start of
+rounds 1-4).  --md-steps N times the reference's FULL iteration instead (NCMC switch + MD leg on the unfrozen System).
 
     python bench.py --gpus N --steps K --warmup W [--replicas R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...

@@ -208,7 +208,7 @@ struct BluesEngine {
     int k1_mode = 0;  // 0: tile kernel (lane = i-atom), 1: sub-tile kernel, 2: per-atom Verlet lists + LDS tile image (nonbonded_atom_body), 3: fragment lists (kernels_frag.h)
     // fragment lists (every environment atom mobile): the static cut of the environment into fragments of <= 3 atoms
     // (build_fragments), the layout of the current sort, the lists
-    std::vector<std::array<int, 3>> frag_atoms; std::vector<int> frag_cnt, frag_of_atom, frag_pos_of_atom; bool frag_ok = false;
+    std::vector<std::array<int, 3>> frag_atoms; std::vector<int> frag_cnt, frag_of_atom, frag_pos_of_atom; bool frag_ok = false, frag_built = false; std::vector<int32_t> link_pairs;   // (bonds and constraints: what holds a molecule together)
     std::vector<int> sp_start_h; std::vector<int2> sp_ent_h;
     int frag_F = 0, frag_NI = 0, frag_nblk = 0, frag_ocap = 0, frag_icap = 0, frag_fpw = 1, frag_nwg = 0; double frag_m = 0.0; DBuf<int> d_ifrag; bool frag_rel = false;
     DBuf<FragRec> d_fimg; DBuf<float2> d_ljtab; int frag_ntypes = 0; DBuf<int> d_sp_start, d_ocount, d_icount; DBuf<int2> d_sp_ent; DBuf<FragBox> d_fbb; DBuf<unsigned> d_olist, d_ilist, d_xprune_s;
@@ -441,12 +441,12 @@ template <typename R> static NbConst<R> make_nbconst(const BluesEngine* h) {
 // breadth-first order over its bonds and constraints, three at a time -- a rigid water is one fragment, consecutive atoms of a
 // solute are a bond or two apart.  With them the static table of fragment pairs that hold an excluded atom pair (and of every
 // fragment with itself): the 9-bit masks the list builder copies into such entries.
-static void build_fragments(BluesEngine* h, const BluesSystemDesc* s) {
+static void build_fragments(BluesEngine* h) {
     const int n = h->n;
+    h->frag_built = true;
     std::vector<std::vector<int>> adj(n);
     auto link = [&](int a, int b) { if (a >= 0 && b >= 0 && a < n && b < n && a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
-    for (int e = 0; e < s->n_bonds; e++) link(s->bond_atoms[2 * e], s->bond_atoms[2 * e + 1]);
-    for (int e = 0; e < s->n_constraints; e++) link(s->constraint_atoms[2 * e], s->constraint_atoms[2 * e + 1]);
+    for (size_t e = 0; e + 1 < h->link_pairs.size(); e += 2) link(h->link_pairs[e], h->link_pairs[e + 1]);
     h->frag_atoms.clear(); h->frag_cnt.clear();
     h->frag_of_atom.assign(n, -1); h->frag_pos_of_atom.assign(n, 0);
     std::vector<char> seen(n, 0);
@@ -682,6 +682,9 @@ static int sort_and_tile(BluesEngine* h) {
         size_t mobile_env = 0; for (int o : h->mobile) mobile_env += h->alch_local[o] < 0;
         const int nit = ((int)mobile_env + 63) / 64;
         const bool all_mobile = mobile_env + h->alch.size() == (size_t)n;
+        const bool asked = h->precision == 0 && mobile_env > 0 && h->tune.k1_mode != 1 && h->tune.k1_mode != 2
+                           && (h->tune.k1_mode == 3 || h->forbid_atom || (all_mobile && nit * h->batch_R > 32 && h->tune.fuse_forces != 1));
+        if (asked && !h->frag_built) build_fragments(h);   // (a few ms of host work per engine: only where a layout wants them)
         want_frag = h->frag_ok && h->precision == 0 && mobile_env > 0 && h->tune.k1_mode != 1 && h->tune.k1_mode != 2
                     && (h->tune.k1_mode == 3 || h->forbid_atom || (all_mobile && nit * h->batch_R > 32 && h->tune.fuse_forces != 1));   // (fuse_forces = 1 pins the one-launch force pass)
     }
@@ -849,7 +852,7 @@ static int sort_and_tile(BluesEngine* h) {
             }
         }
     }
-    if (!want_frag && h->k1_mode != 2 && h->k1_mode == 1 && h->tune.k1_mode < 0 && !h->forbid_atom && h->frag_ok && h->precision == 0 && h->shape_S == 0) {
+    if (!want_frag && h->k1_mode != 2 && h->k1_mode == 1 && h->tune.k1_mode < 0 && !h->forbid_atom && h->precision == 0 && h->shape_S == 0) {
         // the per-atom lists were wanted and no group shape holds this system (scattered mobile atoms): fragment lists instead of the
         // sub-tile kernel -- they need the fragment-wise sort, so once more from the top
         h->forbid_atom = true;
@@ -1215,16 +1218,17 @@ template <typename R> static int launch_lists(BluesEngine* h, int force, int pha
             // fragment lists (kernels_frag.h): block boxes / prune trigger, then rebuild or prune where one is due
             const int wpb = FR_THREADS / 64;
             const int nb_pre = ((h->frag_NI + 63) / 64 + wpb - 1) / wpb, nb_box = (h->frag_nblk + wpb - 1) / wpb, nb_lists = (h->frag_NI + wpb - 1) / wpb;
+            const int merged = nb_pre == nb_box;   // (every fragment is an i-fragment: the boxes ride in the first kernel)
             if (batch_lead(h)) {
                 const int nrep = h->batch->R();
-                hipLaunchKernelGGL(k_frag_pre_b, dim3(nb_pre * nrep), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, nb_pre, nrep, force);
+                hipLaunchKernelGGL(k_frag_pre_b, dim3(nb_pre * nrep), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, nb_pre, nrep, force, merged);
                 hipLaunchKernelGGL(k_gather_frag_b, dim3(1), dim3(LIST_THREADS), 0, h->cur, h->batch->d_nb_f.p, nrep, force, h->batch->d_work_frag.p);
-                hipLaunchKernelGGL(k_frag_boxes_b, dim3(std::min(nb_box * nrep, 4 * REBUILD_GRID)), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, h->batch->d_work_frag.p, nb_box, force);
+                if (!merged) hipLaunchKernelGGL(k_frag_boxes_b, dim3(std::min(nb_box * nrep, 4 * REBUILD_GRID)), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, h->batch->d_work_frag.p, nb_box, force);
                 hipLaunchKernelGGL(k_frag_lists_b, dim3(std::min(nb_lists * nrep, 16 * REBUILD_GRID)), dim3(FR_THREADS), 0, h->cur, h->batch->d_nb_f.p, h->batch->d_work_frag.p, nb_lists, force);
             } else {
                 const FragArgs fa = make_frag_args(h);
-                hipLaunchKernelGGL(k_frag_pre, dim3(nb_pre), dim3(FR_THREADS), 0, h->cur, fa, h->d_img_f.p, force);
-                hipLaunchKernelGGL(k_frag_boxes, dim3(nb_box), dim3(FR_THREADS), 0, h->cur, fa, h->d_img_f.p, force);
+                hipLaunchKernelGGL(k_frag_pre, dim3(nb_pre), dim3(FR_THREADS), 0, h->cur, fa, h->d_img_f.p, force, merged);
+                if (!merged) hipLaunchKernelGGL(k_frag_boxes, dim3(nb_box), dim3(FR_THREADS), 0, h->cur, fa, h->d_img_f.p, force);
                 hipLaunchKernelGGL(k_frag_lists, dim3(nb_lists), dim3(FR_THREADS), 0, h->cur, fa, force);
             }
             h->st_launches += 2;
@@ -2805,7 +2809,8 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
         if (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h)) return 1;
     }
     if (build_clusters(h, s)) return 1;
-    build_fragments(h, s);
+    // (the fragments of kernels_frag.h are cut when a layout first asks for them: sort_and_tile)
+    h->link_pairs.assign(s->bond_atoms, s->bond_atoms + 2 * (size_t)s->n_bonds); h->link_pairs.insert(h->link_pairs.end(), s->constraint_atoms, s->constraint_atoms + 2 * (size_t)s->n_constraints);
     try { if (build_bonded(h, s)) return 1; } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     return 0;
 }

@@ -149,12 +149,14 @@ __global__ void __launch_bounds__(1024) k_nonbonded_atom_b(const RepNb<float>* _
 
 // ---- fragment lists (kernels_frag.h): every member's first kernel of a pass, the work list of the members whose lists need
 // the second one (stale: rebuild; an atom past the prune trigger: prune), that kernel over the work list, the force kernel
-__global__ void __launch_bounds__(FR_THREADS) k_frag_pre_b(const RepNb<float>* __restrict__ reps, int nb, int nrep, int force) {
+__global__ void __launch_bounds__(FR_THREADS) k_frag_pre_b(const RepNb<float>* __restrict__ reps, int nb, int nrep, int force, int with_boxes) {
     const int rep = blockIdx.x / nb, bx = blockIdx.x - rep * nb;
     const RepNb<float>& rp = reps[rep];
     if (!rp.active) return;
     const FragArgs fa = rp.fr;
-    frag_pre_body(fa, rp.img, force, bx * (FR_THREADS / 64) + (threadIdx.x >> 6));
+    const int blk = bx * (FR_THREADS / 64) + (threadIdx.x >> 6);
+    frag_pre_body(fa, rp.img, force, blk);
+    if (with_boxes) frag_boxes_body(fa, rp.img, force, blk);   // (k_frag_pre: the rebuild's first kernel rides along)
 }
 // (the rebuild's first kernel over the same work list: a member that is only there to prune returns at once)
 __global__ void __launch_bounds__(FR_THREADS) k_frag_boxes_b(const RepNb<float>* __restrict__ reps, const int* __restrict__ work, int bpc, int force) {

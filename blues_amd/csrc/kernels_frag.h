@@ -497,8 +497,12 @@ __device__ __forceinline__ void nonbonded_frag_body(const FragArgs& fa, const Nb
 }
 #undef FR_VREG
 
-__global__ void __launch_bounds__(FR_THREADS) k_frag_pre(FragArgs fa, const AtomF* __restrict__ img, int force) {
-    frag_pre_body(fa, img, force, blockIdx.x * (FR_THREADS / 64) + (threadIdx.x >> 6));
+// with_boxes: the rebuild's first kernel rides along (every environment atom mobile: the two kernels have the same grid, and a
+// launch that finds nothing to do still costs its 4-5 us)
+__global__ void __launch_bounds__(FR_THREADS) k_frag_pre(FragArgs fa, const AtomF* __restrict__ img, int force, int with_boxes) {
+    const int blk = blockIdx.x * (FR_THREADS / 64) + (threadIdx.x >> 6);
+    frag_pre_body(fa, img, force, blk);
+    if (with_boxes) frag_boxes_body(fa, img, force, blk);
 }
 __global__ void __launch_bounds__(FR_THREADS) k_frag_boxes(FragArgs fa, const AtomF* __restrict__ img, int force) {
     frag_boxes_body(fa, img, force, blockIdx.x * (FR_THREADS / 64) + (threadIdx.x >> 6));

@@ -132,8 +132,9 @@ def test_bench_configuration_golden(Engine, gold, s23k):
     own policy (default BluesTuning: per-atom lists pruned in passing, default margins and alchemical block shape, side-stream fork),
     mixed precision, BASELINE.json configs[0] -- the 100-step switch with the rigid rotation at step 50 -- teacher-forced every 10
     steps from the committed oracle states: protocol work within 1e-5 of max|w| for every member, and members that were given
-    identical inputs stay bitwise identical (they share launches but never data).  bench.py's default is 512 chains: the same code
-    path and decomposition (the layout changes at n_itiles * R > 32); 256 halves this test's set-up time."""
+    identical inputs stay bitwise identical (they share launches but never data).  bench.py's default is two such batches of 1024 chains taking
+    turns on the device (test_two_batches_taking_turns_meet_the_golden_vectors below): the same code path and decomposition (the layout
+    changes at n_itiles * R > 32); 256 keeps this test's set-up time down."""
     from blues_amd import tuning
     from blues_amd.engine import NativeBatch
     assert tuning.as_dict() == {k: getattr(tuning.defaults(), k) for k in tuning.FIELDS}       # no override is active
@@ -159,6 +160,44 @@ def test_bench_configuration_golden(Engine, gold, s23k):
         g.close()
     print("bench configuration (R = %d, default policy) teacher-forced work error %.2e of max|w| = %.3f kJ/mol; %d per-atom prunes, %d rebuilds per chain"
           % (R, max(errs), scale, st["atom_prunes"], st["list_generation"]))
+
+
+def test_two_batches_taking_turns_meet_the_golden_vectors(Engine, gold, s23k):
+    """The ARRANGEMENT bench.py runs by default: two replica batches on one GPU, each driven from its own host thread, their stepping
+    calls taking turns on the device under one lock (simulation.BatchedBLUESSimulation(device_turn=...), engine.NativeBatch.device_turn).
+    Both batches run the teacher-forced golden switch at the same time: every member within 1e-5 of max|w|, members bitwise equal."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from blues_amd import tuning
+    from blues_amd.engine import NativeBatch
+    assert tuning.as_dict() == {k: getattr(tuning.defaults(), k) for k in tuning.FIELDS}
+    s, v = s23k
+    R = 128
+    wo = gold["work_trace"]; scale = np.abs(wo).max()
+    turn = threading.Lock()
+    groups = []
+    for g in range(2):
+        engs = [Engine(s, _data(gold, 0)) for _ in range(R)]
+        B = NativeBatch(engs); B.device_turn = turn
+        groups.append((engs, B))
+
+    def run(g):
+        engs, B = groups[g]
+        return _run_switch_teacher(engs, lambda n: B.step(n, trace=True)[1], s, v, gold)
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        ws = list(pool.map(run, range(2)))
+    for (engs, B), w in zip(groups, ws):
+        st = engs[0].stats()
+        assert st["nonbonded_kernel"] == 2 and st["alchemical_kernel"] == 1 and st["pruned_lists"] == 1, st
+        errs = [np.abs(w[r] - wo).max() / scale for r in (0, 1, 63, 64, 127)]
+        assert max(errs) <= 1e-5, errs
+        for r in range(1, R):
+            assert np.array_equal(w[r], w[0]), r
+    assert np.array_equal(ws[0][0], ws[1][0])       # the two batches ran the same chains: the turns change no bit
+    for engs, B in groups:
+        B.close()
+        for g in engs:
+            g.close()
 
 
 def _run_switch_free(engines, stepper, s, v, gold):
