@@ -349,7 +349,8 @@ def main():
                     help="rotmove = the benchmark (configs[1]); water / sidechain = full-size runs of configs[3] / configs[4]")
     ap.add_argument("--md-steps", type=int, default=0, help="> 0: time the reference's FULL iteration (blues/simulation.py:1215-1257): every chain carries the md / alch / ncmc "
                     "triple, and each timed step is sync -> NCMC switch -> Metropolis -> reset -> this many MD steps on the unfrozen System.  `value` stays the "
-                    "NCMC leg's ns/day (its share of the wall time); `full_iteration` has both legs.  Use --replicas 16..256 --groups 1 (an all-mobile engine is ~60 MB)")
+                    "NCMC leg's ns/day (its share of the wall time); `full_iteration` has both legs.  Use --replicas 16..256 --groups 1 (an all-mobile engine is ~60 MB) and "
+                    "--warmup 2: the SECOND iteration is the first whose NCMC leg receives a State from an MD leg, and the NCMC engines re-lay themselves out for it once")
     ap.add_argument("--no-alch", action="store_true", help="with --md-steps: no `alch` Simulation (the correction's energies then come from the NCMC engine at lambda = 1)")
     ap.add_argument("--decorrelate", type=int, default=250, help="set-up: steps of its own trajectory every chain runs (own velocities, own noise) before its hand-over State is "
                     "taken, so that the timed switches start from as many different states as there are chains (1 ps by default)")

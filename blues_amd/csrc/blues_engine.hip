@@ -211,7 +211,7 @@ struct BluesEngine {
     std::vector<std::array<int, 3>> frag_atoms; std::vector<int> frag_cnt, frag_of_atom, frag_pos_of_atom; bool frag_ok = false, frag_built = false; std::vector<int32_t> link_pairs;   // (bonds and constraints: what holds a molecule together)
     std::vector<int> sp_start_h; std::vector<int2> sp_ent_h;
     int frag_F = 0, frag_NI = 0, frag_nblk = 0, frag_ocap = 0, frag_icap = 0, frag_fpw = 1, frag_nwg = 0; double frag_m = 0.0; DBuf<int> d_ifrag; bool frag_rel = false;
-    DBuf<FragRec> d_fimg; DBuf<float2> d_ljtab; int frag_ntypes = 0; DBuf<int> d_sp_start, d_ocount, d_icount; DBuf<int2> d_sp_ent; DBuf<FragBox> d_fbb; DBuf<unsigned> d_olist, d_ilist, d_xprune_s;
+    DBuf<FragRec> d_fimg; DBuf<uint4> d_fpos0; DBuf<float2> d_ljtab; int frag_ntypes = 0; DBuf<int> d_sp_start, d_ocount, d_icount; DBuf<int2> d_sp_ent; DBuf<FragBox> d_fbb; DBuf<unsigned> d_olist, d_ilist, d_xprune_s;
     int acap = 0;     // capacity of one atom's list (mode 2)
     // layout shape of the per-atom-list mode.  A lone engine derives (S, jcap) from its own geometry at every re-sort; members
     // of a batch must stay congruent, so the batch fixes the shape for all of them (shape_S > 0) and re-plans it for
@@ -1035,7 +1035,7 @@ static int sort_and_tile(BluesEngine* h) {
             h->d_ifrag.upload(ifrag);
             h->d_fimg.upload(recs); h->d_ljtab.upload(ljt); h->d_sp_start.upload(h->sp_start_h);
             { std::vector<int2> e = h->sp_ent_h; if (e.empty()) e.push_back(make_int2(-1, 0)); h->d_sp_ent.upload(e); }
-            h->d_fbb.reserve(h->frag_nblk);
+            h->d_fbb.reserve(h->frag_nblk); h->d_fpos0.reserve(F);
             h->d_olist.reserve((size_t)NI * h->frag_ocap); h->d_ilist.reserve((size_t)NI * h->frag_icap); h->d_ocount.alloc(NI); h->d_icount.alloc(NI);
             h->d_xprune_s.alloc((size_t)3 * n);
         }
@@ -1173,7 +1173,7 @@ static FragArgs make_frag_args(BluesEngine* h) {
     FragArgs a; memset(&a, 0, sizeof a);
     if (h->k1_mode != 3) return a;
     a.F = h->frag_F; a.NI = h->frag_NI; a.ifrag = h->d_ifrag.p; a.nblk = h->frag_nblk; a.n = h->n; a.ocap = h->frag_ocap; a.icap = h->frag_icap; a.fpw = h->frag_fpw; a.nwg = h->frag_nwg; a.n_islots = h->n_islots;
-    a.fimg = h->d_fimg.p; a.ljtab = h->d_ljtab.p; a.ntypes = h->frag_ntypes; a.sp_start = h->d_sp_start.p; a.sp_ent = h->d_sp_ent.p; a.bb = h->d_fbb.p;
+    a.fimg = h->d_fimg.p; a.ljtab = h->d_ljtab.p; a.ntypes = h->frag_ntypes; a.sp_start = h->d_sp_start.p; a.sp_ent = h->d_sp_ent.p; a.bb = h->d_fbb.p; a.fpos0 = h->d_fpos0.p;
     a.olist = h->d_olist.p; a.ocount = h->d_ocount.p; a.ilist = h->d_ilist.p; a.icount = h->d_icount.p; a.xprune = h->d_xprune_s.p;
     const double ro = h->cutoff + h->skin, ri = h->cutoff + std::min(h->frag_m, h->skin);
     a.ro2 = (float)(ro * ro) * 1.0001f + 1e-5f; a.ri2 = (float)(ri * ri) * 1.0001f + 1e-5f;

@@ -61,6 +61,7 @@ struct FragArgs {
     const int* sp_start;        // [F + 1] by STATIC fragment id: rows of sp_ent
     const int2* sp_ent;         // {partner's static id, mask}: fragment pairs with an excluded atom pair, and the fragment with itself
     FragBox* bb;
+    uint4* fpos0;               // [F] every fragment's FIRST atom at the last rebuild, packed: what the builder's first phase streams (16 of a record's 64 bytes)
     unsigned* olist; int* ocount;   // outer lists [F][ocap] (entry: the j-fragment's place in fimg | mask << 23), lengths
     unsigned* ilist; int* icount;   // inner lists [F][icap]
     unsigned* xprune;           // [3][n] by sorted index: where the atoms were at the last prune (fixed point)
@@ -134,6 +135,7 @@ __device__ __forceinline__ void frag_boxes_body(const FragArgs& fa, const AtomF*
         for (int b = 0; b < 3; b++) { unsigned* w = reinterpret_cast<unsigned*>(&rec->p[b]); w[0] = p[b][0]; w[1] = p[b][1]; w[2] = p[b][2]; }
 #pragma unroll
         for (int b = 0; b < 3; b++) if (b < cnt) for (int k = 0; k < 3; k++) fa.xprune[(size_t)k * fa.n + s0 + b] = p[b][k];
+        fa.fpos0[f] = make_uint4(p[0][0], p[0][1], p[0][2], 0u);
     }
     // bounding box relative to the block's first atom (a fixed-point difference is the minimum image)
     FragBox B;
@@ -269,7 +271,7 @@ __device__ __forceinline__ void frag_lists_body(const FragArgs& fa, const int fo
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 blk[q] = todo ? __ffsll((long long)todo) - 1 : -1;
-                if (blk[q] >= 0) { todo &= todo - 1ull; P0[q] = fa.fimg[min((b0 + blk[q]) * 64 + lane, fa.F - 1)].p[0]; }
+                if (blk[q] >= 0) { todo &= todo - 1ull; P0[q] = fa.fpos0[min((b0 + blk[q]) * 64 + lane, fa.F - 1)]; }
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
