@@ -733,7 +733,9 @@ static int sort_and_tile(BluesEngine* h) {
         h->prune_on = false; h->prune_m = h->ptrig = 0.0; h->skin_m = h->skin; h->trig = 0.5 * h->skin;
     }
     if (want_frag) {   // inner margin of the dual fragment lists (kernels_frag.h); <= 0: the force kernel walks the outer lists
-        const double m = h->tune.prune_margin < 0.0 ? 0.13 : h->tune.prune_margin;   // (0.07: 37.9 us per chain-step, 0.10: 36.5, 0.13: 35.8, 0.16: 36.4 -- a list of 220-260 fragments is four chunks either way)
+        // (bare stepping at R = 16, us per chain-step: 0.07: 37.9, 0.10: 36.5, 0.13: 35.8, 0.16: 36.4; configs[3] through the driver, ns/day: 0.11: 9,584,
+        // 0.12: 9,712, 0.13: 9,784, 0.15: 9,897 -- a list of 220-256 fragments is four chunks either way, a wider margin prunes less often)
+        const double m = h->tune.prune_margin < 0.0 ? 0.15 : h->tune.prune_margin;
         h->frag_m = m > 0.0 ? std::min(m, 0.6 * h->skin) : h->skin;
     }
     // capacities
