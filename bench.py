@@ -217,7 +217,7 @@ def cpu_baseline(system, vel, nsteps_sample):
     return out
 
 
-PMC_FILE = "profiles/r04_pmc_nonbonded.json"
+PMC_FILE = "profiles/r05_pmc_nonbonded.json"
 
 
 def kernel_source_sha():

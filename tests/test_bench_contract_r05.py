@@ -1,0 +1,91 @@
+"""CPU suite: the committed bench lines of round 5 (profiles/r05/*.json, written by `python bench.py ...` on an MI355X) carry what the
+measurement contract asks for: the default line (2048 chains per GPU, every chain its own start state) with a roofline that can be
+recomputed from the committed counters and agrees with the committed rocprofv3 summary; the FULL iteration (NCMC switch + MD leg,
+the reference's md / alch / ncmc triple per chain, reference blues/simulation.py:1215-1257); configs[3] through the fragment lists."""
+import csv
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R05 = os.path.join(ROOT, "profiles", "r05")
+R04 = os.path.join(ROOT, "profiles", "r04")
+
+
+def _load(name, where=R05):
+    return json.load(open(os.path.join(where, name)))
+
+
+def test_default_line_contract_and_own_start_states():
+    d = _load("bench_default.json")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "ns/day" and d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["replicas_per_gpu"] == 2048 and d["config"]["batches_per_gpu"] == 2 and d["config"]["batches_take_turns"] is True
+    assert "OWN state" in d["data_note"]
+    r = d["roofline"]
+    assert r["timed"] == "in the stepping loop" and r["launches_timed"] >= 500 and r["frac"] >= 0.40
+    assert r["achieved"] == pytest.approx(36.0 * 23400 * 1024 / (r["usec_per_launch"] * 1e-6) / 1e9, rel=1e-9)
+    c = d["cpu_baseline"]
+    assert c["cores"] == 1 and c["kind"] == "port" and c["all_cores"]["value"] > c["value"]
+    # the common start of rounds 1-4 hid nothing: the line with 2048 different start states is within 3 % of the one with a single state
+    same = _load("bench_same_start.json")
+    assert "same coordinates" in same["data_note"]
+    assert abs(d["value"] - same["value"]) <= 0.03 * same["value"]
+    # ... and within 4 % of round 4's line (no kernel of this configuration changed)
+    last = _load("bench_R2048_G2.json", R04)
+    assert d["value"] >= 0.96 * last["value"]
+
+
+def test_default_line_agrees_with_rocprof_and_counters():
+    d = _load("bench_default_with_counters.json")
+    r = d["roofline"]
+    rows = list(csv.DictReader(open(os.path.join(R05, "kernel_stats_default.csv"))))
+    k1 = [x for x in rows if x["Name"].startswith("void k_nonbonded_atom_b<false>")]
+    assert len(k1) == 1 and int(k1[0]["Calls"]) >= 4000
+    csv_us = float(k1[0]["AverageNs"]) / 1e3
+    assert abs(r["usec_per_launch"] - csv_us) <= 0.04 * csv_us, (r["usec_per_launch"], csv_us)
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_nonbonded.json")))["rotmove_R1024"]
+    assert r["pmc_source"]["source_sha"] == pmc["source_sha"]
+    c = pmc["counters_per_launch"]
+    assert r["traffic"] == pytest.approx(1024.0 * (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]), rel=1e-9)
+    assert r["valu"]["insts_per_launch"] == c["SQ_INSTS_VALU"]
+    assert r["traffic"] < r["algorithmic_bytes_per_launch"] and r["traffic"] > 5.0 * r["mobile_only"]["algorithmic_bytes"]
+
+
+@pytest.mark.parametrize("R,both_legs", [(16, 15000.0), (64, 19000.0)])
+def test_full_iteration_lines(R, both_legs):
+    """bench.py --md-steps 1000: the reference's whole iteration, the triple per chain, the batched plugin boundary."""
+    d = _load("full_R%d.json" % R)
+    f = d["full_iteration"]
+    assert f is not None and f["md_steps"] == 1000 and f["triple"].startswith("md + alch + ncmc")
+    assert d["config"]["replicas_per_gpu"] == R and d["config"]["batches_per_gpu"] == 1
+    assert d["engine"]["plugin_boundary"].startswith("one call per operation")
+    assert f["md_engine"]["nonbonded_kernel"] == 3                       # the MD leg runs through the fragment lists
+    assert f["ns_day_both_legs"] >= both_legs
+    wall = (f["ms_sync"] + f["ms_ncmc"] + f["ms_boundary"] + f["ms_md"]) * 1e-3
+    assert f["ns_day_both_legs"] == pytest.approx(R * 2000 * 0.004e-3 / (wall / 86400.0), rel=0.03)
+    assert 0.05 < f["ncmc_share_of_wall"] < 0.5 and f["ms_boundary"] < 0.05 * (f["ms_ncmc"] + f["ms_md"])
+    assert f["us_per_chain_step_md"] < 40.0                               # (round 4: 78 us per all-mobile chain-step)
+    # `value` keeps BASELINE.json's definition: the switching leg alone
+    t_ncmc = (f["ms_sync"] + f["ms_ncmc"] + f["ms_boundary"]) * 1e-3
+    assert d["value"] == pytest.approx(R * 1000 * 0.004e-3 / (t_ncmc / 86400.0), rel=0.02)
+    assert "own state" in d["data_note"]
+
+
+def test_configs3_through_fragment_lists():
+    """BASELINE.json configs[3] to the letter (2000-step switch, nothing frozen): more than twice round 4, rebuilds under 100 per 1000 steps."""
+    w16, w1 = _load("water_R16.json"), _load("water_R1.json")
+    old16, old1 = _load("water_R16.json", R04), _load("water_R1.json", R04)
+    for d in (w16, w1):
+        assert "nstepsNC=2000" in d["config"]["workload"] and "23400 mobile" in d["config"]["workload"]
+        assert "k_nonbonded_frag_b" in d["roofline"]["kernel"] or d["config"]["replicas_per_gpu"] == 1
+        assert d["engine"]["list_rebuilds_per_switch"] <= 200.0          # <= 100 per 1000 steps
+    assert w16["value"] >= 2.0 * old16["value"] and w16["value"] >= 9000.0
+    assert w1["value"] >= 1.35 * old1["value"]
+    assert w16["roofline"]["usec_per_launch"] <= 0.7 * old16["roofline"]["usec_per_launch"]
+    assert w16["engine"]["plugin_boundary"].startswith("one call per operation") and "hooks chain by chain" in w16["engine"]["plugin_boundary"]
+    rows = list(csv.DictReader(open(os.path.join(R05, "kernel_stats_water_R16.csv"))))
+    k1 = [x for x in rows if x["Name"].startswith("void k_nonbonded_frag_b<false")]
+    assert len(k1) == 1 and float(k1[0]["AverageNs"]) / 1e3 / 16 <= 19.0   # us per chain and launch (round 4: 27.3)
