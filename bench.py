@@ -153,6 +153,7 @@ def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
         each(lambda r, c: c._resetSimulations(300.0))
     t3 = time.perf_counter()
     clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2
+    clock.setdefault("iterations", []).append(t3 - t0)
     return recs
 
 
@@ -487,7 +488,7 @@ def main():
     engs = [c._ncmc_sim.context._engine for c in chains]
     st0 = engs[0].stats(); b0 = [d._ncmc_batch.stats() for d in drivers]
     for ck in clocks:
-        ck.update({"sync": 0.0, "switch": 0.0, "decide": 0.0, "md": 0.0})
+        ck.update({"sync": 0.0, "switch": 0.0, "decide": 0.0, "md": 0.0, "iterations": []})
     # the nonbonded kernel is timed WHERE IT RUNS: every 4th force launch of the timed switches is bracketed by two HIP events on
     # the batch's stream (blues_batch_kernel_timing); that mean is roofline.usec_per_launch, what rocprofv3 averages for the same loop
     timing_batch = None if args.no_kernel_timing or not hasattr(drivers[0]._ncmc_batch, "kernel_timing") else drivers[0]._ncmc_batch
@@ -525,7 +526,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     st1 = engs[0].stats(); b1 = [d._ncmc_batch.stats() for d in drivers]
-    clock = {k: max(ck[k] for ck in clocks) for k in clocks[0]}
+    iteration_seconds = [list(ck.get("iterations", [])) for ck in clocks]     # per batch, per timed iteration (with several batches: the turns it waited for included)
+    clock = {k: max(ck[k] for ck in clocks) for k in clocks[0] if k != "iterations"}
     b0 = {k: sum(b[k] for b in b0) / G for k in b0[0]}; b1 = {k: sum(b[k] for b in b1) / G for k in b1[0]}
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if (world == 1 or args.backend == "nccl") else "cpu")
     tmin = t.clone()
@@ -641,7 +643,7 @@ def main():
             "process_group": {"backend": (args.backend if world > 1 else None), "same_device": bool(args.same_device),
                               "replica_seeds_first_chain_of_each_rank": [int(replica_seed(1234, r * R)) for r in range(world)]},
             "memory": memory_use(),
-            "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "setup_seconds": t_setup, "setup_seconds_by_part": setup_parts,
+            "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "iteration_seconds_by_batch": iteration_seconds, "setup_seconds": t_setup, "setup_seconds_by_part": setup_parts,
                        "plugin_boundary": ("one call per operation for all chains (blues_batch_*)" + ("" if drivers[0]._move_batchable() else "; the Move's hooks chain by chain")) if drivers[0]._batchable() else "chain by chain",
                        "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,
                        "list_rebuilds_per_switch": (st1["list_generation"] - st0["list_generation"]) / args.steps,

@@ -29,6 +29,9 @@
 #include "kernels_bonded.h"
 #include <chrono>
 #include <mutex>
+#include <thread>
+#include <functional>
+#include <atomic>
 #include "kernels_integrate.h"
 #include "kernels_nb.h"
 #include "kernels_pme.h"
@@ -2845,6 +2848,32 @@ static int relayout(BluesEngine* h) {
     return sort_and_tile(h);
 }
 
+// A new layout for MANY members of a batch at once (a new shape for everybody: 5-10 ms of host work per member -- sort, exclusion rows,
+// image, uploads -- i.e. 8 s for 1024 members one after the other, in the middle of a switch): the members are independent, so the
+// host's cores share them.  prepare(m) sets what the new layout is to follow (shape, forbid_atom) and says whether m needs one.
+static BluesEngine* relayout_many(const std::vector<BluesEngine*>& members, const std::function<bool(BluesEngine*)>& prepare) {
+    std::vector<BluesEngine*> todo;
+    for (BluesEngine* m : members) if (prepare(m)) todo.push_back(m);
+    if (todo.empty()) return nullptr;
+    unsigned nthr = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+#if defined(__linux__)
+    { cpu_set_t set; CPU_ZERO(&set); if (sched_getaffinity(0, sizeof set, &set) == 0) nthr = std::min<unsigned>(nthr, (unsigned)std::max(1, CPU_COUNT(&set))); }
+#endif
+    nthr = (unsigned)std::min<size_t>(nthr, todo.size());
+    std::atomic<size_t> next{0}; std::atomic<BluesEngine*> failed{nullptr};
+    auto work = [&]() {
+        hipSetDevice(todo[0]->device);
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= todo.size() || failed.load()) return;
+            if (relayout(todo[i])) failed.store(todo[i]);
+        }
+    };
+    if (nthr <= 1) work();
+    else { std::vector<std::thread> pool; for (unsigned t = 0; t < nthr; t++) pool.emplace_back(work); for (auto& t : pool) t.join(); }
+    return failed.load();
+}
+
 // One layout shape for all members of a batch in the per-atom-list mode (k1_mode 2), where the number of tiles per list and the
 // list capacity follow from the geometry: the leader's S (or the next smaller one whose lists fit the LDS), and a capacity
 // that holds the largest member's lists with room for the i-atoms to spread.  fresh: start from the members' own choices.
@@ -2859,33 +2888,34 @@ static int batch_plan_shape(BluesBatch* B, bool fresh) {
         if (!same && relayout(m)) return fail(m);
     }
     BluesEngine* lead = B->eng[0];
-    if (lead->k1_mode != 2) {   // the other modes size everything from the density: congruent by construction
-        for (BluesEngine* m : B->eng) if (m->k1_mode == 2) { m->forbid_atom = true; if (relayout(m)) return fail(m); }
+    if (lead->k1_mode != 2) {   // the other modes size everything from the topology or the density: congruent by construction
+        // (a re-plan in the middle of a run finds the leader here when ITS tiles fit no shape any more -- scattered mobile atoms: it is in
+        // the sub-tile layout for want of a shape, and everybody, the leader included, moves on to fragment lists)
+        if (BluesEngine* bad = relayout_many(B->eng, [&](BluesEngine* m) {
+                const bool was = m->forbid_atom; m->forbid_atom = true;
+                return m->k1_mode == 2 || (!fresh && !was && m->k1_mode != 3); })) return fail(bad);
         return 0;
     }
     const int lds_max = 6400;
     static const int cand[] = {16, 12, 8, 6, 5, 4, 3, 2, 1};
     int S = lead->S;
     for (;;) {
+        if (BluesEngine* bad = relayout_many(B->eng, [&](BluesEngine* m) { if (m->k1_mode == 2 && m->S == S) return false; m->shape_S = S; m->shape_jcap = lds_max; return true; })) return fail(bad);
         double need = 0.0;
-        for (BluesEngine* m : B->eng) {
-            if (m->k1_mode != 2 || m->S != S) { m->shape_S = S; m->shape_jcap = lds_max; if (relayout(m)) return fail(m); }
-            need = std::max(need, m->shape_need);
-        }
+        for (BluesEngine* m : B->eng) need = std::max(need, m->shape_need);
         const int cap = need * 1.3 + 64 <= 3328 ? 3328 : (need * 1.3 + 64 <= lds_max ? lds_max : lds_max + 64);   // the two capacities of sort_and_tile
         if (cap <= lds_max) {
-            for (BluesEngine* m : B->eng) {
-                // (a member whose own layout already has the batch's shape only takes note of it: a re-layout under shape (S, cap) gives what it has)
-                const bool has_it = m->k1_mode == 2 && m->S == S && m->jcap == cap && !m->shape_overflow && m->shape_need * 1.1 + 64 <= cap;
-                m->shape_S = S; m->shape_jcap = cap;
-                if (!has_it && relayout(m)) return fail(m);
-            }
+            // (a member whose own layout already has the batch's shape only takes note of it: a re-layout under shape (S, cap) gives what it has)
+            if (BluesEngine* bad = relayout_many(B->eng, [&](BluesEngine* m) {
+                    const bool has_it = m->k1_mode == 2 && m->S == S && m->jcap == cap && !m->shape_overflow && m->shape_need * 1.1 + 64 <= cap;
+                    m->shape_S = S; m->shape_jcap = cap;
+                    return !has_it; })) return fail(bad);
             return 0;
         }
         int next = 0;
         for (int c : cand) if (c < S) { next = c; break; }
-        if (!next) {   // not even one tile per list fits: the bitmask kernels for everybody
-            for (BluesEngine* m : B->eng) { m->forbid_atom = true; m->shape_S = 0; m->shape_jcap = 0; if (relayout(m)) return fail(m); }
+        if (!next) {   // not even one tile per list fits: fragment lists (or the bitmask kernels) for everybody
+            if (BluesEngine* bad = relayout_many(B->eng, [](BluesEngine* m) { m->forbid_atom = true; m->shape_S = 0; m->shape_jcap = 0; return true; })) return fail(bad);
             return 0;
         }
         S = next;
