@@ -2892,8 +2892,9 @@ static int batch_plan_shape(BluesBatch* B, bool fresh) {
         // (a re-plan in the middle of a run finds the leader here when ITS tiles fit no shape any more -- scattered mobile atoms: it is in
         // the sub-tile layout for want of a shape, and everybody, the leader included, moves on to fragment lists)
         if (BluesEngine* bad = relayout_many(B->eng, [&](BluesEngine* m) {
-                const bool was = m->forbid_atom; m->forbid_atom = true;
-                return m->k1_mode == 2 || (!fresh && !was && m->k1_mode != 3); })) return fail(bad);
+                const bool need = m->k1_mode == 2 || (!fresh && !m->forbid_atom && m->k1_mode != 3);
+                if (need) m->forbid_atom = true;   // (members that stay as they are keep their flags: their next re-sort must give the same mode again)
+                return need; })) return fail(bad);
         return 0;
     }
     const int lds_max = 6400;
