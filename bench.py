@@ -35,14 +35,14 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_ATOM = 36.0     # x,y,z + q,sigma,eps read, fx,fy,fz written, per force evaluation
 
 
-def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False, md_steps=0, with_alch=True):
+def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False, md_steps=0, with_alch=True, setup_threads=None):
     """R independent BLUES chains on this rank's GPU: own integrator (Philox key), context, move engine, state table.
     md_steps > 0: every chain gets the reference's full triple (blues/simulation.py:768-809): the NCMC Simulation on the alchemical
     (frozen) System, an MD Simulation (openmm.LangevinIntegrator, reference simulation.py:647) and an `alch` Simulation, both on
     the UNFROZEN, non-alchemical System."""
     from blues_amd import integrators, moves, simulation, systems
     from blues_amd.context import Simulation
-    from blues_amd.replicas import replica_seed
+    from blues_amd.replicas import replica_seed, build_in_parallel
     import copy
     if workload == "water":
         # configs[3]: nothing frozen, "backbone" restraints, the alchemical species is one 3-atom water (the first one,
@@ -75,8 +75,7 @@ def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False, md_ste
         md_system.alchemical_atoms = np.zeros(0, np.int32)
         if reciprocal:
             md_system = systems.with_reciprocal_space(md_system)
-    chains = []
-    for c in range(R):
+    def make_chain(c):
         gid = rank * R + c   # global chain index
         integ = integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=DT_PS, temperature=300.0, seed=replica_seed(1234, gid))
         sim = Simulation(None, system, integ, device=local_rank, precision="mixed", replica=gid)
@@ -86,7 +85,8 @@ def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False, md_ste
             md = Simulation(None, md_system, integrators.LangevinIntegrator(300.0, 1.0, DT_PS, seed=replica_seed(4321, gid)), device=local_rank, precision="mixed", replica=gid)
             if with_alch:
                 alch = Simulation(None, md_system, integrators.LangevinIntegrator(300.0, 1.0, DT_PS, seed=replica_seed(8765, gid)), device=local_rank, precision="mixed", replica=gid)
-        chains.append(simulation.BLUESSimulation(simulation.SimulationSet(sim, md=md, alch=alch), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": 1, "nstepsMD": md_steps}, mover))
+        return simulation.BLUESSimulation(simulation.SimulationSet(sim, md=md, alch=alch), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": 1, "nstepsMD": md_steps}, mover)
+    chains = build_in_parallel(make_chain, R, workers=setup_threads)   # (host threads: a chain's set-up is native host work)
     return system, vel, chains
 
 
@@ -355,6 +355,7 @@ def main():
     ap.add_argument("--no-alch", action="store_true", help="with --md-steps: no `alch` Simulation (the correction's energies then come from the NCMC engine at lambda = 1)")
     ap.add_argument("--decorrelate", type=int, default=250, help="set-up: steps of its own trajectory every chain runs (own velocities, own noise) before its hand-over State is "
                     "taken, so that the timed switches start from as many different states as there are chains (1 ps by default)")
+    ap.add_argument("--setup-threads", type=int, default=None, help="host threads that create the chains (default min(16, cores) divided among the ranks of the host; 1 = one after the other)")
     ap.add_argument("--same-start", action="store_true", help="every chain starts every switch from the SAME coordinates and velocities (rounds 1-4)")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
@@ -414,8 +415,10 @@ def main():
     G0 = max(1, min(args.groups, R))
     # the chains are laid out from the start as members of the batch they are about to join (BluesTuning.assume_batch: the layout a
     # batch of that size gives its members anyway), so that forming the batch re-lays nobody out: set-up time, nothing else
+    if args.setup_threads is None:   # (the ranks of one host share its cores)
+        args.setup_threads = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
     with tuning.override(assume_batch=(R + G0 - 1) // G0):
-        system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R, reciprocal=args.reciprocal, md_steps=args.md_steps, with_alch=not args.no_alch)
+        system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R, reciprocal=args.reciprocal, md_steps=args.md_steps, with_alch=not args.no_alch, setup_threads=args.setup_threads)
     x0 = system.positions.copy()
     v0 = vel.copy()
     setup_parts = {"chains": time.perf_counter() - t_setup}
@@ -643,7 +646,7 @@ def main():
             "process_group": {"backend": (args.backend if world > 1 else None), "same_device": bool(args.same_device),
                               "replica_seeds_first_chain_of_each_rank": [int(replica_seed(1234, r * R)) for r in range(world)]},
             "memory": memory_use(),
-            "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "iteration_seconds_by_batch": iteration_seconds, "setup_seconds": t_setup, "setup_seconds_by_part": setup_parts,
+            "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "iteration_seconds_by_batch": iteration_seconds, "setup_seconds": t_setup, "setup_seconds_by_part": setup_parts, "setup_threads": args.setup_threads,
                        "plugin_boundary": ("one call per operation for all chains (blues_batch_*)" + ("" if drivers[0]._move_batchable() else "; the Move's hooks chain by chain")) if drivers[0]._batchable() else "chain by chain",
                        "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,
                        "list_rebuilds_per_switch": (st1["list_generation"] - st0["list_generation"]) / args.steps,

@@ -40,6 +40,21 @@ def replica_seed(base_seed, rank):
     return (int(base_seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
 
+def build_in_parallel(make, count, workers=None):
+    """[make(0), ..., make(count - 1)] with the calls spread over host threads.  Creating a chain is mostly native host work (the
+    engine derives exclusion tables, constraint clusters, fragments and the first sorted layout: 6-8 ms per 23k-atom chain; the ctypes
+    call releases the interpreter lock), so the 2048 chains of a GPU are ready in a fraction of the serial time.  Order is kept;
+    the first exception is re-raised.  workers: default min(16, host cores); 1 = the plain loop."""
+    import os
+    if workers is None:
+        workers = min(16, os.cpu_count() or 1)
+    if workers <= 1 or count <= 1:
+        return [make(i) for i in range(count)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(workers, count)) as pool:
+        return list(pool.map(make, range(count)))
+
+
 def gather_decisions(accept, iteration, log_accept, protocol_work, correction=0.0, device=None):
     """All-gather of {accept, iter, log_accept, protocol_work, correction} -> (world, 5) float64 array on every rank."""
     import torch
