@@ -1819,9 +1819,13 @@ static int force_pass(BluesEngine* h, int base_L) {
     if (fork3) {
         if (ensure_side(h)) return 1;
         hipStream_t main_stream = h->cur;
-        rc = launch_lists<float>(h, h->lists_forced, 1);
-        if (rc) return 1;
         HIP_OK(h, hipEventRecord(h->evFork, main_stream)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evFork, 0));
+        // (the alchemical tile's list -- work list + builder, 6 + 22 us at R = 16 -- is read by the side stream's kernels only; the list
+        // kernels read the flags, nobody writes them before the nonbonded kernel: it goes to the side stream with its readers)
+        // (both of its kernels read the flags the nonbonded kernel resets: that kernel waits for evA)
+        h->cur = h->s1; rc = launch_lists<float>(h, h->lists_forced, 1); h->cur = main_stream;
+        if (rc) return 1;
+        HIP_OK(h, hipEventRecord(h->evA, h->s1));
         // (the DENSE alchemical kernel -- a 512-thread workgroup with ~158 KB of LDS per chain -- stays on the main stream, behind the
         // nonbonded kernel: beside it the two ran at a third of their speed (471 against 166 us per 1024 chains); its alchemical x
         // alchemical block and the bonded entries are the small kernels that go to the side)
@@ -1834,6 +1838,7 @@ static int force_pass(BluesEngine* h, int base_L) {
         rc = launch_lists<float>(h, h->lists_forced, 5);
         if (rc) return 1;
         h->lists_forced = false;
+        HIP_OK(h, hipStreamWaitEvent(main_stream, h->evA, 0));
         if (launch_nonbonded<float, false>(h)) return 1;
         if (h->k2_dense && launch_alchemical(h, ls, le, fmask, 4)) return 1;
         if (launch_pme(h, 0)) return 1;
