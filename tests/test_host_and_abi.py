@@ -311,3 +311,28 @@ def test_amber_restart_round_trip(tmp_path):
     amber.write_rst7(p, x[:2], None, None)       # two atoms: a single, partly filled coordinate line and nothing else
     x4, v4, b4 = amber.read_rst7(p)
     assert x4.shape == (2, 3) and v4 is None and b4 is None
+
+
+def test_build_in_parallel_keeps_order_and_raises():
+    """replicas.build_in_parallel: the chains of a GPU are created on host threads (their set-up is native host work); the result
+    is in chain order whatever thread made it, and the first failure surfaces as it would from the plain loop."""
+    import threading
+    import time
+    from blues_amd.replicas import build_in_parallel
+    seen = set()
+
+    def make(i):
+        time.sleep(0.002 * ((7 * i) % 5))
+        seen.add(threading.get_ident())
+        return i * i
+    assert build_in_parallel(make, 40, workers=8) == [i * i for i in range(40)]
+    assert len(seen) > 1
+    assert build_in_parallel(make, 5, workers=1) == [0, 1, 4, 9, 16]
+    assert build_in_parallel(make, 0) == []
+
+    def bad(i):
+        if i == 3:
+            raise ValueError("chain 3")
+        return i
+    with pytest.raises(ValueError, match="chain 3"):
+        build_in_parallel(bad, 8, workers=4)
