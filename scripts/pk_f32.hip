@@ -72,7 +72,6 @@ int main() {
     run<4>("v_add_f32", 1, out, cyc, h);
     run<5>("v_pk_add_f32", 1, out, cyc, h);
     run<7>("v_rsq_f32", 1, out, cyc, h);
-    run<8>("v_cndmask_b32", 1, out, cyc, h);
     run<9>("v_mov_b32", 1, out, cyc, h);
     run<10>("v_pk_mov_b32", 1, out, cyc, h);
     return 0;
