@@ -1035,7 +1035,9 @@ static int sort_and_tile(BluesEngine* h) {
             // the relative form of a pair's separation (kernels_frag.h: REL) wants cutoff + a fragment's reach (bonded atoms: well under
             // 0.6 nm) below half the shortest edge; smaller boxes (the 975-atom test box) take the fixed-point difference per pair
             h->frag_rel = 0.5 * std::min(h->box[0], std::min(h->box[1], h->box[2])) > h->cutoff + 0.6;
-            h->frag_fpw = (int)std::max<long>(1, std::min<long>(4, (long)NI * h->batch_R / 8192));
+            // (4096 waves fill the chip at four per SIMD: a lone chain's 7,800 fragments go two per wave -- one round, the second fragment's
+            // head requested while the first computes -- instead of one per wave in two rounds)
+            h->frag_fpw = (int)std::max<long>(1, std::min<long>(4, ((long)NI * h->batch_R + 4095) / 4096));
             h->frag_nwg = (NI + 4 * h->frag_fpw - 1) / (4 * h->frag_fpw);
             h->d_ifrag.upload(ifrag);
             h->d_fimg.upload(recs); h->d_ljtab.upload(ljt); h->d_sp_start.upload(h->sp_start_h);
@@ -2786,9 +2788,12 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
       static std::mutex pool_mu; static std::map<int, std::vector<hipStream_t>> pool; static std::map<int, size_t> next;
       std::lock_guard<std::mutex> lk(pool_mu);
       std::vector<hipStream_t>& v = pool[h->device];
-      if (v.size() < 8) { hipStream_t q = nullptr; HIP_OK(h, hipStreamCreate(&q)); v.push_back(q); h->stream = q; }
-      else h->stream = v[next[h->device]++ % v.size()];
-      h->stream_pooled = true;
+      if (h->tune.use_graph > 0) { HIP_OK(h, hipStreamCreate(&h->stream)); h->stream_pooled = false; }   // (a stream under graph capture must see no other engine's work)
+      else {
+          if (v.size() < 8) { hipStream_t q = nullptr; HIP_OK(h, hipStreamCreate(&q)); v.push_back(q); h->stream = q; }
+          else h->stream = v[next[h->device]++ % v.size()];
+          h->stream_pooled = true;
+      }
     }
     h->cur = h->stream;
     if (h->tune.use_graph >= 0) h->use_graph = h->tune.use_graph != 0;

@@ -358,14 +358,25 @@ __device__ __forceinline__ void nonbonded_frag_body(const FragArgs& fa, const Nb
         for (int b = 0; b < 3; b++) R.p[b] = *FG1(const u32x4, base + 16 * b);
         R.types = *FG1(const unsigned, base + 48);
     };
+    // the head of the NEXT fragment -- which fragment, how long its row, the row's first two chunks of entries -- is requested while
+    // the current one computes: a fragment then starts with one round trip (its own record beside the first chunk's records)
+    // instead of three in a row
+    int f_pf = 0, cnt_pf = 0; unsigned e0_pf = 0u, e1_pf = 0u;
+    const bool two_chunks = fa.icap > 64;
+    auto prefetch_head = [&](int fqn) {
+        f_pf = g_ifrag[fqn]; cnt_pf = g_icount[fqn];
+        const auto rown = g_ilist + (size_t)fqn * fa.icap;
+        e0_pf = rown[lane];
+        if (two_chunks) e1_pf = rown[64 + lane];   // (inside the row whatever its length: used only if the row has a second chunk)
+    };
+    if (q0 < q1) prefetch_head(q0);
     for (int fq = q0; fq < q1; fq++) {
-        const int f = __builtin_amdgcn_readfirstlane(g_ifrag[fq]);
-        const int cnt = __builtin_amdgcn_readfirstlane(g_icount[fq]);
+        const int f = __builtin_amdgcn_readfirstlane(f_pf);
+        const int cnt = __builtin_amdgcn_readfirstlane(cnt_pf);
         const int nch = (cnt + 63) >> 6;
         const auto row = g_ilist + (size_t)fq * fa.icap;
-        unsigned e_cur = 0u, e_nxt = 0u;
-        if (nch > 0) e_cur = row[lane];
-        if (nch > 1) e_nxt = row[64 + lane];
+        unsigned e_cur = nch > 0 ? e0_pf : 0u, e_nxt = nch > 1 ? e1_pf : 0u;
+        if (fq + 1 < q1) prefetch_head(fq + 1);
         // the fragment's own atoms (same address in every lane: stays in vector registers)
         Rec me; load_rec((unsigned)f, me);
         const int islot0 = __builtin_amdgcn_readfirstlane(*FG1(const int, g_fimg + (size_t)f * sizeof(FragRec) + 56));
