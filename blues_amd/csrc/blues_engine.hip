@@ -1817,7 +1817,9 @@ static int force_pass(BluesEngine* h, int base_L) {
     // fragment lists (k1_mode 3) in a batch: the alchemical kernel and the bonded entries (+ the next O step's noise) need the
     // alchemical tile's list only -- they run on the side stream beside the fragment-list kernels (a rebuild or a prune of one or two
     // members: a few latency-bound workgroups) and the head of the nonbonded kernel, joined before the sums
-    const bool fork3 = fork_env && batch_lead(h) && h->k1_mode == 3 && !h->ctrl_arg;
+    // (a lone chain of a few thousand fragments too: its step is eight launches back to back, and the alchemical tile's list, the
+    // alchemical kernel and the bonded entries -- a third of them -- need nothing from the fragment lists)
+    const bool fork3 = fork_env && h->k1_mode == 3 && !h->ctrl_arg && (batch_lead(h) || (!batch_dry(h) && h->frag_NI >= 2048));
     if (fork3) {
         if (ensure_side(h)) return 1;
         hipStream_t main_stream = h->cur;
