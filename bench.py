@@ -186,6 +186,7 @@ def one_iteration(driver, chains, nsteps, md_steps, it, clock):
     driver._stepMD(md_steps)
     t4 = time.perf_counter()
     clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2; clock["md"] = clock.get("md", 0.0) + t4 - t3
+    clock.setdefault("iterations", []).append(t4 - t0)
     return recs
 
 

@@ -159,6 +159,7 @@ struct BluesEngine {
     double skin_m = 0.12, trig = 0.06;   // margin of MOBILE list candidates, and the displacement that asks for a rebuild (derive_margins)
     // pruned per-atom lists (nonbonded_atom_body): inner margins for frozen / mobile candidates, displacement that asks for a prune
     bool prune_on = false; double prune_m = 0.0, ptrig = 0.0;
+    int steps_since_sort = 0;   // whole steps taken in the current order (fragment lists re-sort by age: resort_by_age)
     EwaldPoly ewpoly;   // degree-9 fit of the smooth part of the Ewald pair force (fit_ewald_poly), mixed precision
     // ---- integrator
     double dt = 0, temperature = 0, gamma = 1, kT = 0, tol = 1e-8;
@@ -676,6 +677,7 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
 static int sort_and_tile(BluesEngine* h) {
     SetupTimer tm_all(1);
     const int n = h->n;
+    h->steps_since_sort = 0;
     // fragment lists (kernels_frag.h) where every environment atom moves: mixed precision, more than the lone-chain handful of tiles
     // fragment lists (kernels_frag.h), mixed precision: where every environment atom moves (more than the lone-chain handful of
     // tiles); where the per-atom lists over group images cannot hold the system (forbid_atom: the mobile atoms of an NCMC System
@@ -1193,7 +1195,7 @@ static FragArgs make_frag_args(BluesEngine* h) {
     a.flags = h->d_flags.p; a.batch_req = batch_req_ptr(h); a.fpart = h->d_fpart.p; a.epart = h->d_epart_nb.p;
     a.half_min_edge = (float)(0.5 * std::min(h->box[0], std::min(h->box[1], h->box[2])));
     a.count_builds = h->n_tiles == 0;
-    a.hint_blocks = h->frag_nblk < 64 ? 0x7fffffff : std::max(48, h->frag_nblk * 85 / 100);   // (a re-sort is 5-10 ms of host work per chain: only when the blocks' boxes have stopped pruning anything)
+    a.hint_blocks = h->frag_nblk < 64 ? 0x7fffffff : std::max(48, h->frag_nblk * 85 / 100);   // (a re-sort is 5-10 ms of host work per chain and a rebuild of everything: only when the blocks' boxes have stopped pruning anything -- asked for at 45 / 65 / 85 % of the blocks a full iteration of 64 chains took 2.80 / 2.25 / 2.14 s)
     return a;
 }
 
@@ -1709,6 +1711,7 @@ static int launch_pme(BluesEngine* h, int want_energy) {
 static int download_xyz(BluesEngine* h, double* xyz, DBuf<double>* src);
 static int sort_and_tile(BluesEngine* h);
 static int batch_plan_shape(BluesBatch* B, bool fresh);
+static BluesEngine* relayout_many(const std::vector<BluesEngine*>& members, const std::function<bool(BluesEngine*)>& prepare);
 static int resolve_xfer(BluesEngine* h) {
     if (!h->xfer_pending) return 0;
     h->xfer_pending = false;
@@ -1936,17 +1939,30 @@ static int check_flags(BluesEngine* h) {
 #define RESORT_POLL 64
 static int relayout(BluesEngine* h);
 static int batch_plan_shape(BluesBatch* B, bool fresh);
-static int poll_resort(BluesEngine* h) {
-    if (flush_program(h)) return 1;
-    HIP_OK(h, hipStreamSynchronize(h->stream));
+// poll_resort_due: 1 = the engine's builder asked for a new order (flag cleared, counted) and nothing is wrong with it, 0 = no, -1 = error
+static int poll_resort_due(BluesEngine* h) {
+    if (flush_program(h)) return -1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "stream synchronisation failed"; return -1; }
     DevFlags f;
-    HIP_OK(h, hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost));
+    if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "flag read-back failed"; return -1; }
     if (!f.resort_hint || f.list_overflow || f.nan_flag || f.constraint_fail) return 0;   // errors are reported by check_flags
     if (h->tune.debug_lists) { std::vector<int> jc; h->d_jcount.download(jc); fprintf(stderr, "[resort] member %d step %d jcount[0]=%d hint_count %d jcap %d\n", h->batch_index, h->h_step, jc.empty() ? -1 : jc[0], h->hint_count, h->jcap); }
     f.resort_hint = 0;
-    HIP_OK(h, hipMemcpy(h->d_flags.p, &f, sizeof f, hipMemcpyHostToDevice));
+    if (hipMemcpy(h->d_flags.p, &f, sizeof f, hipMemcpyHostToDevice) != hipSuccess) { h->err = "flag write-back failed"; return -1; }
     h->st_resorts++;
-    return relayout(h);
+    return 1;
+}
+// Fragment lists of a system in which (nearly) everything moves: the order ages -- the builder's blocks spread as the molecules diffuse,
+// its kernels slow down by 1 % per thousand steps, and when the builder finally asks (resort_hint) every member of a batch asks within a few
+// hundred steps of the others, one or two per poll, each re-sort 10 ms of host work with the batch waiting: 0.2 s per 16 chains every
+// ~6,000 steps (scripts/dev_order_age.py).  A re-sort by AGE instead -- a function of the chain's own step count, so a member still does
+// what the lone chain does -- comes due for all members of a batch at the same poll, where the host's cores share them.
+#define RESORT_AGE 4096
+static bool resort_by_age(const BluesEngine* h) { return h->k1_mode == 3 && h->sorted_ok && 2 * h->mobile.size() > (size_t)h->n && h->steps_since_sort >= RESORT_AGE; }
+static int poll_resort(BluesEngine* h) {
+    if (resort_by_age(h)) { h->st_resorts++; return relayout(h); }
+    const int due = poll_resort_due(h);
+    return due < 0 ? 1 : (due ? relayout(h) : 0);
 }
 
 // launch geometry of an energy evaluation (partials per kind)
@@ -2296,7 +2312,7 @@ static int try_graph_steps(BluesEngine* h, int max_steps) {
     if (hipMemcpyAsync(h->d_ctrl.p, &c, sizeof c, hipMemcpyHostToDevice, h->stream) != hipSuccess) { h->err = "ctrl upload failed"; return -1; }
     for (int r = 0; r < count / h->graph_units; r++)
         if (hipGraphLaunch(h->gexec, h->stream) != hipSuccess) { h->err = "hipGraphLaunch failed"; return -1; }
-    h->h_step += count; h->h_lambda_step += 2 * count; h->h_lambda = (double)h->h_lambda_step / h->n_lambda;
+    h->h_step += count; h->steps_since_sort += count; h->h_lambda_step += 2 * count; h->h_lambda = (double)h->h_lambda_step / h->n_lambda;
     h->cur_ls = h->tab_ls[h->h_lambda_step]; h->cur_le = h->tab_le[h->h_lambda_step];
     h->h_draw += (unsigned)count; h->pass_L += 2 * count;
     h->prog_trace = h->h_step - 1; h->prog_draw_base = h->h_draw; h->noise_draw_base = h->h_draw; h->noise_valid = true;
@@ -2351,7 +2367,7 @@ static int step_body(BluesEngine* h) {
             if (emit(h, OP_END)) return 1;
             h->prog_trace = h->h_step;
         }
-        h->h_step++; h->h_prop = 1;
+        h->h_step++; h->h_prop = 1; h->steps_since_sort++;
     }
     return 0;
 }
@@ -2646,8 +2662,21 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
                     if (hipStreamSynchronize(B->leader->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
                     B->d_hints.download(hints);
                 } catch (std::string& e) { B->err = e; return 1; }
-                for (int r = 0; r < R; r++)
-                    if (!B->failed[r] && (hints[r] & 1) && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0 && poll_resort(B->eng[r])) fail(r);
+                {   // the members whose builders asked for a new order: re-sorted on the host's cores together (5-10 ms of host work each)
+                    std::vector<BluesEngine*> todo;
+                    for (int r = 0; r < R; r++)
+                        if (!B->failed[r] && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0) {
+                            if (resort_by_age(B->eng[r])) { B->eng[r]->st_resorts++; todo.push_back(B->eng[r]); continue; }
+                            if (!(hints[r] & 1)) continue;
+                            const int due = poll_resort_due(B->eng[r]);
+                            if (due < 0) fail(r); else if (due) todo.push_back(B->eng[r]);
+                        }
+                    if (todo.size() == 1) { if (relayout(todo[0])) fail(todo[0]->batch_index); }
+                    else if (!todo.empty()) {
+                        relayout_many(todo, [](BluesEngine*) { return true; });
+                        for (BluesEngine* m : todo) if (!m->sorted_ok) fail(m->batch_index);
+                    }
+                }
                 {   // a member whose lists have outgrown the batch's layout shape: a new shape for everybody (rare)
                     bool over = false;
                     for (int r = 0; r < R; r++) over |= !B->failed[r] && B->eng[r]->shape_overflow;

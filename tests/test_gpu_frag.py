@@ -161,3 +161,30 @@ def test_scattered_mobile_atoms_fall_back_to_fragment_lists(Engine, tune):
     g.step(10)
     assert g.audit_lists()[1] == 0
     g.close()
+
+
+def test_resort_by_age_keeps_a_member_equal_to_the_lone_chain(Engine, tol_box, tune):
+    """Fragment-list engines of an all-mobile system re-sort by AGE (4096 steps in one order; blues_engine.hip: resort_by_age): a
+    function of the chain's own step count, so the members of a batch re-sort together (the host's cores share them) and still do
+    exactly what the lone chain does.  4,200 steps cross that age once."""
+    from blues_amd.engine import NativeBatch
+    s, v = tol_box
+    md = copy.copy(s); md.alchemical_atoms = np.zeros(0, np.int32)
+    R, n = 3, 4200
+    tune(k1_mode=3, assume_batch=R)
+
+    def make(r):
+        g = Engine(md, integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=40 + r).to_data(precision=0, replica=r)); g.set_velocities(v * (1.0 + 0.01 * r)); return g
+    alone = [make(r) for r in range(R)]
+    for g in alone:
+        g.step(n)
+    together = [make(r) for r in range(R)]
+    B = NativeBatch(together)
+    B.step(n)
+    for a, b in zip(alone, together):
+        assert a.stats()["resorts"] >= 1 and b.stats()["resorts"] == a.stats()["resorts"]
+        assert np.array_equal(a.get_positions(), b.get_positions()) and np.array_equal(a.get_velocities(), b.get_velocities())
+        assert b.audit_lists()[1] == 0
+    B.close()
+    for g in alone + together:
+        g.close()
