@@ -74,6 +74,16 @@ def test_full_iteration_lines(R, both_legs):
     assert "own state" in d["data_note"]
 
 
+def test_full_iteration_at_256_chains():
+    """The batch size at which the NCMC leg has become a sixteenth of the iteration: the MD leg's per-chain-step cost is what is left."""
+    d = _load("full_R256.json")
+    f = d["full_iteration"]
+    assert d["config"]["replicas_per_gpu"] == 256 and f["md_steps"] == 1000 and f["md_engine"]["nonbonded_kernel"] == 3
+    assert f["ns_day_both_legs"] >= 22000.0 and f["us_per_chain_step_md"] < 30.0 and f["us_per_chain_step_ncmc"] < 2.5
+    assert f["ncmc_share_of_wall"] < 0.1 and d["memory"]["device_in_use_gib"] < 64.0
+    assert len(d["engine"]["iteration_seconds_by_batch"][0]) == d["steps"]
+
+
 def test_configs3_through_fragment_lists():
     """BASELINE.json configs[3] to the letter (2000-step switch, nothing frozen): more than twice round 4, rebuilds under 100 per 1000 steps."""
     w16, w1 = _load("water_R16.json"), _load("water_R1.json")
