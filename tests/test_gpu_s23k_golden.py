@@ -162,6 +162,48 @@ def test_bench_configuration_golden(Engine, gold, s23k):
           % (R, max(errs), scale, st["atom_prunes"], st["list_generation"]))
 
 
+def test_benchmarked_system_through_fragment_lists_golden(Engine, gold, s23k, tune):
+    """What a real run's NCMC engines become once their mobile atoms have scattered over MD legs (the engine re-lays
+    itself out on its own, tests/test_gpu_frag.py::test_scattered_mobile_atoms_fall_back_to_fragment_lists): the benchmarked System
+    -- 276 mobile atoms, everything else frozen -- through the fragment lists (i-side: the 97 fragments that hold a mobile atom; frozen
+    j-fragments with half the margins), mixed precision.  Energies, term sums and mobile-atom forces at the four committed lambda
+    pairs within 1e-5, and configs[0]'s 100-step switch teacher-forced in a batch of 8: work within 1e-5 of max|w|, lists audited."""
+    from blues_amd.engine import NativeBatch
+    s, v = s23k
+    mob = gold["mobile_atoms"]
+    tune(k1_mode=3)
+    g = Engine(s, _data(gold, 0))
+    assert g.stats()["nonbonded_kernel"] == 3, g.stats()
+    for k, (ls, le) in enumerate(gold["lambdas"]):
+        g.set_global("lambda_sterics", ls); g.set_global("lambda_electrostatics", le)
+        t = g.energy_terms()
+        assert abs(t.sum() - gold["energy_total"][k]) <= 1e-5 * abs(gold["energy_total"][k])
+        for q in range(8):
+            assert abs(t[q] - gold["energy_terms"][k][q]) <= 1e-5 * max(1.0, abs(gold["energy_terms"][k][q])), (k, q)
+        f = g.get_forces()[mob]
+        fo = gold["forces_mobile"][k]
+        assert np.abs(f - fo).max() <= 1e-5 * np.abs(fo).max(), (k, np.abs(f - fo).max() / np.abs(fo).max())
+    assert g.audit_lists()[1] == 0
+    g.close()
+    R = 8
+    tune(k1_mode=3, assume_batch=R)
+    wo = gold["work_trace"]; scale = np.abs(wo).max()
+    engs = [Engine(s, _data(gold, 0)) for _ in range(R)]
+    B = NativeBatch(engs)
+    w = _run_switch_teacher(engs, lambda n: B.step(n, trace=True)[1], s, v, gold)
+    err = max(np.abs(wr - wo).max() for wr in w) / scale
+    assert engs[0].stats()["nonbonded_kernel"] == 3
+    for e in (engs[0], engs[-1]):
+        assert e.audit_lists()[1] == 0
+    for wr in w[1:]:
+        assert np.array_equal(wr, w[0])
+    B.close()
+    for e in engs:
+        e.close()
+    assert err <= 1e-5, err
+    print("benchmarked System through fragment lists: teacher-forced work error %.2e of max|w| = %.3f kJ/mol" % (err, scale))
+
+
 def test_two_batches_taking_turns_meet_the_golden_vectors(Engine, gold, s23k):
     """The ARRANGEMENT bench.py runs by default: two replica batches on one GPU, each driven from its own host thread, their stepping
     calls taking turns on the device under one lock (simulation.BatchedBLUESSimulation(device_turn=...), engine.NativeBatch.device_turn).
