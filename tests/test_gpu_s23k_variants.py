@@ -156,3 +156,43 @@ def test_variant_switch_golden(Engine, gold, name, R, precision):
     assert err <= (1e-9 if precision == 1 else 1e-5), (name, R, precision, err)
     assert pos_err <= (1e-8 if precision == 1 else 1e-4), pos_err
     print("S23k %s variant: precision=%d R=%d teacher-forced work error %.2e of max|w| = %.3f kJ/mol, end positions within %.1e nm" % (name, precision, R, err, scale, pos_err))
+
+
+def test_sidechain_variant_through_fragment_lists(Engine, gold, tune):
+    """configs[4]'s System -- a PARTIALLY alchemical solute (its non-alchemical atoms are fragments with bonded-pair masks towards
+    each other; alchemical-environment exclusions and 1-4 exceptions in the alchemical kernel), 276 mobile atoms in a frozen box --
+    through the fragment lists (k1_mode 3: what its engines become once their mobile atoms have scattered): energies,
+    term sums and forces at the four committed lambda pairs and the teacher-forced 40-step switch in a batch of 8, mixed precision, 1e-5."""
+    from blues_amd.engine import NativeBatch
+    name = "sidechain"
+    s, v, move = _variant(name)
+    sel = gold[name + "_force_atoms"]
+    tune(k1_mode=3)
+    g = Engine(s, _data(gold, name, 0))
+    assert g.stats()["nonbonded_kernel"] == 3, g.stats()
+    for k, (ls, le) in enumerate(gold["lambdas"]):
+        g.set_global("lambda_sterics", ls); g.set_global("lambda_electrostatics", le)
+        t = g.energy_terms()
+        eo, to = gold[name + "_energy_total"][k], gold[name + "_energy_terms"][k]
+        assert abs(t.sum() - eo) <= 1e-5 * abs(eo), (k, t.sum(), eo)
+        for q in range(min(len(t), len(to))):
+            assert abs(t[q] - to[q]) <= 1e-5 * max(1.0, abs(to[q]), 1e-3 * abs(eo)), (k, q, t[q], to[q])
+        f = g.get_forces()[sel]
+        fo = gold[name + "_forces"][k]
+        assert np.abs(f - fo).max() <= 1e-5 * np.abs(fo).max(), (k, np.abs(f - fo).max() / np.abs(fo).max())
+    assert g.audit_lists()[1] == 0
+    g.close()
+    R = 8
+    tune(k1_mode=3, assume_batch=R)
+    wo = gold[name + "_work_trace"]
+    engs = [Engine(s, _data(gold, name, 0)) for _ in range(R)]
+    B = NativeBatch(engs)
+    w = _teacher_forced(engs, lambda n: B.step(n, trace=True)[1], s, v, move, gold, name)
+    err = max(np.abs(wr - wo).max() for wr in w) / np.abs(wo).max()
+    assert engs[0].stats()["nonbonded_kernel"] == 3 and engs[0].audit_lists()[1] == 0
+    for wr in w[1:]:
+        assert np.array_equal(wr, w[0])
+    B.close()
+    for e in engs:
+        e.close()
+    assert err <= 1e-5, err
