@@ -303,6 +303,7 @@ struct BluesBatch {
     DBuf<int> d_req; bool sync_lists = false;
     DBuf<int> d_work;   // [1 + 2R] members that rebuild their lists in the current force pass (kernels_batch.h: k_gather_stale_b)
     bool replanning = false;   // inside batch_plan_shape on behalf of a member (ensure_sorted)
+    DBuf<int> d_frozen_work; DBuf<double> d_frozen_sum;   // the members without a frozen-frozen energy constant, their constants (batch_prefetch)
     DBuf<int> d_work_frag;   // [1 + 2R] fragment lists: members that rebuild or prune in the current pass (k_gather_frag_b), and a flag per member
     BluesTuning tune;   // the process-wide tuning at the time the batch was created
     // argument arena of the batched boundary calls (blues_batch_capture ...): pinned host side, device side, one upload per call
@@ -2513,9 +2514,41 @@ static int batch_prefetch(BluesBatch* B, int what) {
     bool ok = true;
     auto pe_pass = [&]() -> int {   // potential energies at the members' CURRENT alchemical parameters
         int n_need = 0, n_live = 0;
-        for (int r = 0; r < R; r++) if (live[r] && !B->eng[r]->e_frozen_valid) {   // one-off constant of a member: its own evaluation
-            double E;
-            if (total_energy(B->eng[r], &E)) { B->failed[r] = 1; live[r] = 0; }
+        {   // the frozen-frozen constant of the members that have none.  One member (a chain that joined late): its own evaluation.
+            // Several -- every chain of a batch whose State came from the MD leg, in every iteration: the frozen atoms were given new
+            // positions -- in one launch over a work list; member by member this was a full lone energy evaluation with its host
+            // synchronisations each, 0.7 s per 1024 chains and iteration (half of the NCMC leg of a real run)
+            std::vector<int> lack;
+            for (int r = 0; r < R; r++) if (live[r] && !B->eng[r]->e_frozen_valid) lack.push_back(r);
+            bool together = lack.size() > 1;
+            for (size_t q = 0; q < lack.size() && together; q++) { const char* why = ""; together = batch_congruent_cached(B, lack[q], lead, &why) && B->eng[lack[q]]->prog.n == 0; }
+            if (together) {
+                if (batch_enter(B)) return 1;
+                B->leader = lead;
+                if (batch_refresh_args(B)) { if (!was_entered) batch_leave(B); return 1; }
+                const EnergyShape g = energy_shape(lead);
+                const int count = (int)lack.size();
+                std::vector<double> sums;
+                try {
+                    if ((int)B->d_frozen_work.n < count) B->d_frozen_work.alloc(R);
+                    if ((int)B->d_frozen_sum.n < 2 * count) B->d_frozen_sum.alloc((size_t)2 * R);
+                    if (hipMemcpyAsync(B->d_frozen_work.p, lack.data(), sizeof(int) * count, hipMemcpyHostToDevice, B->stream) != hipSuccess) throw std::string("upload of the work list failed");
+                    if (lead->precision == 0) {
+                        hipLaunchKernelGGL(k_energy_frozen_b<float>, dim3(g.nfb, count), dim3(256), 0, B->stream, B->d_nb_f.p, B->d_frozen_work.p, (int)g.off_frozen);
+                        hipLaunchKernelGGL(k_sum_frozen_b<float>, dim3((count + 63) / 64), dim3(64), 0, B->stream, B->d_nb_f.p, B->d_frozen_work.p, count, (int)g.off_frozen, g.nfb, B->d_frozen_sum.p);
+                    } else {
+                        hipLaunchKernelGGL(k_energy_frozen_b<double>, dim3(g.nfb, count), dim3(256), 0, B->stream, B->d_nb_d.p, B->d_frozen_work.p, (int)g.off_frozen);
+                        hipLaunchKernelGGL(k_sum_frozen_b<double>, dim3((count + 63) / 64), dim3(64), 0, B->stream, B->d_nb_d.p, B->d_frozen_work.p, count, (int)g.off_frozen, g.nfb, B->d_frozen_sum.p);
+                    }
+                    if (hipStreamSynchronize(B->stream) != hipSuccess) throw std::string("frozen-frozen energy launch failed");
+                    sums.resize((size_t)2 * count);
+                    if (hipMemcpy(sums.data(), B->d_frozen_sum.p, sizeof(double) * 2 * count, hipMemcpyDeviceToHost) != hipSuccess) throw std::string("download of the frozen-frozen energies failed");
+                } catch (std::string& e) { B->err = e; if (!was_entered) batch_leave(B); return 1; }
+                for (int q = 0; q < count; q++) { BluesEngine* m = B->eng[lack[q]]; m->e_frozen[0] = sums[2 * q]; m->e_frozen[1] = sums[2 * q + 1]; m->e_frozen_valid = true; m->st_launches++; }
+            } else for (int r : lack) {
+                double E;
+                if (total_energy(B->eng[r], &E)) { B->failed[r] = 1; live[r] = 0; }
+            }
         }
         for (int r = 0; r < R; r++) if (live[r]) {
             BluesEngine* m = B->eng[r];

@@ -422,6 +422,24 @@ __global__ void __launch_bounds__(256) k_kinetic_b(const RepCore* __restrict__ r
 
 // energy partials of every member into one slab [R][stride]: nonbonded partials | bonded partials | alchemical partials |
 // the alchemical tile's list length -- one read-back for the whole batch; the host sums them as it does for a lone engine
+// The frozen-frozen energy constant of the members that have none (their frozen atoms were given new positions: a State from the MD leg,
+// reference blues/simulation.py:1028-1037, does that to every chain in every iteration): blockIdx.y walks the work list, blockIdx.x the
+// member's tiles; then one thread per listed member adds its tiles' partials up in tile order (the order of the lone engine's host loop).
+template <typename R>
+__global__ void __launch_bounds__(256) k_energy_frozen_b(const RepNb<R>* __restrict__ rnb, const int* __restrict__ work, int off_frozen) {
+    const RepNb<R>& rp = rnb[work[blockIdx.y]];
+    energy_frozen_body<R>(rp.L.n, rp.c, rp.img, rp.L.ex_start, rp.L.ex_idx, rp.nb.epart + off_frozen, blockIdx.x);
+}
+template <typename R>
+__global__ void __launch_bounds__(64) k_sum_frozen_b(const RepNb<R>* __restrict__ rnb, const int* __restrict__ work, int count, int off_frozen, int nfb, double* __restrict__ out) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= count) return;
+    const double* ep = rnb[work[q]].nb.epart + off_frozen;
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < nfb; t++) { a += ep[2 * t]; b += ep[2 * t + 1]; }
+    out[2 * q] = a; out[2 * q + 1] = b;
+}
+
 template <typename R>
 __global__ void __launch_bounds__(256) k_gather_energy_parts_b(const RepNb<R>* __restrict__ rnb, const RepCore* __restrict__ reps, int n_nb, int n_b, int n_alch, int stride, double* out) {
     const int r = blockIdx.x;

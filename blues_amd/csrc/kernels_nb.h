@@ -1080,13 +1080,13 @@ __global__ void __launch_bounds__(1024) k_nonbonded_atom(NbArgs<float> a, NbCons
 // staged in LDS and paired 64 x 64 (about 1 tile in 7 at 23k atoms; the all-pairs loop this replaces took 5.6 ms).
 #define FROZEN_TILE 64
 template <typename R>
-__global__ void __launch_bounds__(256) k_energy_frozen(int n, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img,
-                                                       const int* __restrict__ ex_start, const int* __restrict__ ex_idx, double* epart) {
+__device__ __forceinline__ void energy_frozen_body(const int n, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img,
+                                                   const int* __restrict__ ex_start, const int* __restrict__ ex_idx, double* epart, const int it) {
     using Atom = typename Img<R>::Atom;
     using sfix = typename Img<R>::sfix;
     using ufix = typename Img<R>::ufix;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int it = blockIdx.x, nt = (n + FROZEN_TILE - 1) / FROZEN_TILE;
+    const int nt = (n + FROZEN_TILE - 1) / FROZEN_TILE;
     const int i = it * FROZEN_TILE + lane;
     __shared__ Atom lds[4][64];
     __shared__ double s[2][4];
@@ -1150,9 +1150,14 @@ __global__ void __launch_bounds__(256) k_energy_frozen(int n, NbConst<R> c, cons
     if (lane == 0) { s[0][wv] = elj; s[1][wv] = ecl; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        epart[2 * blockIdx.x] = s[0][0] + s[0][1] + s[0][2] + s[0][3];
-        epart[2 * blockIdx.x + 1] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+        epart[2 * it] = s[0][0] + s[0][1] + s[0][2] + s[0][3];
+        epart[2 * it + 1] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
     }
+}
+template <typename R>
+__global__ void __launch_bounds__(256) k_energy_frozen(int n, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img,
+                                                       const int* __restrict__ ex_start, const int* __restrict__ ex_idx, double* epart) {
+    energy_frozen_body<R>(n, c, img, ex_start, ex_idx, epart, blockIdx.x);
 }
 
 __device__ inline void to_fixed32(const double p[3], const Box3& box, unsigned u[3]);
