@@ -23,6 +23,7 @@ for w in $what; do case $w in
   full_R16) run full_R16 --md-steps 1000 --replicas 16 --groups 1 --steps 8 --warmup 2 --no-cpu ;;
   full_R64) run full_R64 --md-steps 1000 --replicas 64 --groups 1 --steps 8 --warmup 2 --no-cpu ;;
   full_R256) run full_R256 --md-steps 1000 --replicas 256 --groups 1 --steps 2 --warmup 2 --no-cpu --no-single ;;
+  full_R1024) run full_R1024 --md-steps 1000 --replicas 1024 --groups 1 --steps 2 --warmup 2 --no-cpu --no-single ;;
   water_R1) run water_R1 --workload water --nsteps-nc 2000 --replicas 1 --groups 1 --steps 2 --warmup 1 --no-cpu --no-single ;;
   water_R16) run water_R16 --workload water --nsteps-nc 2000 --replicas 16 --groups 1 --steps 2 --warmup 1 --no-cpu --no-single ;;
   water_R64) run water_R64 --workload water --nsteps-nc 2000 --replicas 64 --groups 1 --steps 2 --warmup 1 --no-cpu --no-single ;;
