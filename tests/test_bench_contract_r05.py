@@ -84,6 +84,17 @@ def test_full_iteration_at_256_chains():
     assert len(d["engine"]["iteration_seconds_by_batch"][0]) == d["steps"]
 
 
+def test_full_iteration_at_1024_chains():
+    """A real run's switching leg at the headline's batch size: the MD leg hands every NCMC System new frozen coordinates in every
+    iteration, so every chain needs a new frozen-frozen energy constant -- one launch for the batch (k_energy_frozen_b), not 1024 lone
+    energy evaluations (1,549 ms per switch before)."""
+    d = _load("full_R1024.json")
+    f = d["full_iteration"]
+    assert d["config"]["replicas_per_gpu"] == 1024 and f["md_steps"] == 1000
+    assert f["ms_ncmc"] < 1000.0 and f["us_per_chain_step_ncmc"] < 1.0 and f["ns_day_both_legs"] >= 22500.0
+    assert d["memory"]["device_in_use_gib"] < 160.0 and d["engine"]["fallback_steps_per_switch"] <= 2.0
+
+
 def test_configs3_through_fragment_lists():
     """BASELINE.json configs[3] to the letter (2000-step switch, nothing frozen): more than twice round 4, rebuilds under 100 per 1000 steps."""
     w16, w1 = _load("water_R16.json"), _load("water_R1.json")
