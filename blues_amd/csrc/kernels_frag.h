@@ -28,7 +28,7 @@
 // Exclusions and fragments with fewer than three atoms travel as a 9-bit mask in the list entry (bit 3a + b: pair of i-atom a
 // with j-atom b counts); the builder takes the masks of bonded fragment pairs from a static table (sp_*), every other entry has
 // all nine bits (minus the columns of atoms the j-fragment does not have).  A chunk of 64 entries in which every mask is full
-// takes the plain pair body; rows are padded to whole chunks with entries of mask 0.
+// takes the plain pair body; rows are padded to whole chunks with the ghost record (no charge, no epsilon) under a full mask.
 #pragma once
 #include "kernels_nb.h"
 
@@ -207,7 +207,7 @@ __device__ __forceinline__ void frag_lists_body(const FragArgs& fa, const int fo
     };
     if (!rebuild) {
         // ---- prune: walk the outer list, keep what is within cutoff + inner margin now
-        const int ocnt = fa.ocount[fq], nch = (ocnt + 63) >> 6;   // (rows are padded to whole chunks with valid entries of mask 0)
+        const int ocnt = fa.ocount[fq], nch = (ocnt + 63) >> 6;   // (rows are padded to whole chunks with the ghost entry: never kept)
         unsigned e_cur = 0u, e_nxt = 0u;
         if (nch > 0) e_cur = orow[lane];
         if (nch > 1) e_nxt = orow[64 + lane];
@@ -225,7 +225,7 @@ __device__ __forceinline__ void frag_lists_body(const FragArgs& fa, const int fo
                 for (int b = 0; b < 3; b++) { const float d2 = frag_d2(xi[a], pc[b], sc); if ((mask >> (3 * a + b)) & 1u) best = fminf(best, d2); }
             }
             // (a pair the mask leaves out never counts, so it need not keep the entry either; the fragment's entry for itself has
-            // its live pairs at bond distance; padding entries have no live pair)
+            // its live pairs at bond distance; the padding lies beyond ocnt)
             push(irow, fa.icap, icnt, u * 64 + lane < ocnt && best < (FR_MOB(tc) ? fa.ri2 : fa.ri2_f), e_cur);
             e_cur = e_nxt; e_nxt = e_n2; pc[0] = pn[0]; pc[1] = pn[1]; pc[2] = pn[2]; tc = tn;
         }
