@@ -1049,8 +1049,10 @@ static int sort_and_tile(BluesEngine* h) {
             h->d_olist.reserve((size_t)NI * h->frag_ocap); h->d_ilist.reserve((size_t)NI * h->frag_icap); h->d_ocount.alloc(NI); h->d_icount.alloc(NI);
             h->d_xprune_s.alloc((size_t)3 * n);
         }
-        h->d_epart_nb.alloc(h->k1_mode == 3 ? (size_t)2 * h->frag_nwg + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE)
-                                            : (size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1)) + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
+        // (behind the force kernels' partial sums: two per tile of the frozen-frozen energy kernel, then its tile boxes)
+        h->d_epart_nb.alloc((h->k1_mode == 3 ? (size_t)2 * h->frag_nwg
+                                             : (size_t)std::max(1, h->n_itiles) * h->npart * 2 * (h->k1_mode == 2 ? 1 : (h->k1_iw != 64 ? 64 / h->k1_iw : 1)))
+                            + (size_t)(2 + FROZEN_BOX_DOUBLES) * ((n + FROZEN_TILE - 1) / FROZEN_TILE));
         { std::vector<int> ooi(h->n_islots, -1); for (int o = 0; o < n; o++) if (islot[o] >= 0) ooi[islot[o]] = o; h->d_orig_of_islot.upload(ooi);
           std::vector<FinRec> fr(h->n_islots + 64);
           auto fill = [&](FinRec& r, int atom) {
@@ -2041,9 +2043,14 @@ static int energy_terms(BluesEngine* h, double T[BLUES_N_ENERGY_TERMS]) {
     const EnergyShape g = energy_shape(h);
     if (!h->e_frozen_valid) {
         double* ep = h->d_epart_nb.p + g.off_frozen;
-        if (h->precision == 0) hipLaunchKernelGGL(k_energy_frozen<float>, dim3(g.nfb), dim3(256), 0, h->stream, h->n, make_nbconst<float>(h), h->d_img_f.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
-        else hipLaunchKernelGGL(k_energy_frozen<double>, dim3(g.nfb), dim3(256), 0, h->stream, h->n, make_nbconst<double>(h), h->d_img_d.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
-        h->st_launches++;
+        if (h->precision == 0) {
+            hipLaunchKernelGGL(k_frozen_boxes<float>, dim3((g.nfb + 3) / 4), dim3(256), 0, h->stream, h->n, make_nbconst<float>(h), h->d_img_f.p, ep);
+            hipLaunchKernelGGL(k_energy_frozen<float>, dim3(g.nfb), dim3(256), 0, h->stream, h->n, make_nbconst<float>(h), h->d_img_f.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
+        } else {
+            hipLaunchKernelGGL(k_frozen_boxes<double>, dim3((g.nfb + 3) / 4), dim3(256), 0, h->stream, h->n, make_nbconst<double>(h), h->d_img_d.p, ep);
+            hipLaunchKernelGGL(k_energy_frozen<double>, dim3(g.nfb), dim3(256), 0, h->stream, h->n, make_nbconst<double>(h), h->d_img_d.p, h->d_ex_start.p, h->d_ex_idx.p, ep);
+        }
+        h->st_launches += 2;
     }
     if (check_flags(h)) return 1;
     std::vector<double> enb, eb, ep; std::vector<int> jc;
@@ -2534,9 +2541,11 @@ static int batch_prefetch(BluesBatch* B, int what) {
                     if ((int)B->d_frozen_sum.n < 2 * count) B->d_frozen_sum.alloc((size_t)2 * R);
                     if (hipMemcpyAsync(B->d_frozen_work.p, lack.data(), sizeof(int) * count, hipMemcpyHostToDevice, B->stream) != hipSuccess) throw std::string("upload of the work list failed");
                     if (lead->precision == 0) {
+                        hipLaunchKernelGGL(k_frozen_boxes_b<float>, dim3((g.nfb + 3) / 4, count), dim3(256), 0, B->stream, B->d_nb_f.p, B->d_frozen_work.p, (int)g.off_frozen);
                         hipLaunchKernelGGL(k_energy_frozen_b<float>, dim3(g.nfb, count), dim3(256), 0, B->stream, B->d_nb_f.p, B->d_frozen_work.p, (int)g.off_frozen);
                         hipLaunchKernelGGL(k_sum_frozen_b<float>, dim3((count + 63) / 64), dim3(64), 0, B->stream, B->d_nb_f.p, B->d_frozen_work.p, count, (int)g.off_frozen, g.nfb, B->d_frozen_sum.p);
                     } else {
+                        hipLaunchKernelGGL(k_frozen_boxes_b<double>, dim3((g.nfb + 3) / 4, count), dim3(256), 0, B->stream, B->d_nb_d.p, B->d_frozen_work.p, (int)g.off_frozen);
                         hipLaunchKernelGGL(k_energy_frozen_b<double>, dim3(g.nfb, count), dim3(256), 0, B->stream, B->d_nb_d.p, B->d_frozen_work.p, (int)g.off_frozen);
                         hipLaunchKernelGGL(k_sum_frozen_b<double>, dim3((count + 63) / 64), dim3(64), 0, B->stream, B->d_nb_d.p, B->d_frozen_work.p, count, (int)g.off_frozen, g.nfb, B->d_frozen_sum.p);
                     }

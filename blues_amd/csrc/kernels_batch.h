@@ -426,6 +426,11 @@ __global__ void __launch_bounds__(256) k_kinetic_b(const RepCore* __restrict__ r
 // reference blues/simulation.py:1028-1037, does that to every chain in every iteration): blockIdx.y walks the work list, blockIdx.x the
 // member's tiles; then one thread per listed member adds its tiles' partials up in tile order (the order of the lone engine's host loop).
 template <typename R>
+__global__ void __launch_bounds__(256) k_frozen_boxes_b(const RepNb<R>* __restrict__ rnb, const int* __restrict__ work, int off_frozen) {
+    const RepNb<R>& rp = rnb[work[blockIdx.y]];
+    frozen_boxes_body<R>(rp.L.n, rp.c, rp.img, reinterpret_cast<FrozenBox<R>*>(rp.nb.epart + off_frozen + 2 * ((rp.L.n + FROZEN_TILE - 1) / FROZEN_TILE)), blockIdx.x);
+}
+template <typename R>
 __global__ void __launch_bounds__(256) k_energy_frozen_b(const RepNb<R>* __restrict__ rnb, const int* __restrict__ work, int off_frozen) {
     const RepNb<R>& rp = rnb[work[blockIdx.y]];
     energy_frozen_body<R>(rp.L.n, rp.c, rp.img, rp.L.ex_start, rp.L.ex_idx, rp.nb.epart + off_frozen, blockIdx.x);

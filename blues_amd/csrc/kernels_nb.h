@@ -1079,6 +1079,43 @@ __global__ void __launch_bounds__(1024) k_nonbonded_atom(NbArgs<float> a, NbCons
 // tests one j-atom of the tile against the i-tile's bounding box, and only tiles with an atom inside cutoff range are
 // staged in LDS and paired 64 x 64 (about 1 tile in 7 at 23k atoms; the all-pairs loop this replaces took 5.6 ms).
 #define FROZEN_TILE 64
+// Bounding box of a tile's frozen atoms (centre in fixed point, padded half extents; any = 0: the tile has none): written by
+// k_frozen_boxes for every tile, read by the energy kernel to leave out the tiles no atom of which can be in range (6 in 7 at 23k atoms)
+// WITHOUT loading them -- every block used to stream the whole image past its tile: 134 MB of L2 reads per chain.
+template <typename R> struct FrozenBox { typename Img<R>::ufix c[3]; float h[3]; int any; };
+#define FROZEN_BOX_DOUBLES 6    // room per tile behind the kernel's partial sums (sizeof(FrozenBox<double>) = 40)
+template <typename R>
+__device__ __forceinline__ void frozen_tile_box(const int n, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, const int it, const int lane,
+                                                typename Img<R>::ufix cf[3], float hf[3], bool& any, typename Img<R>::Atom& ai, bool& i_on) {
+    using sfix = typename Img<R>::sfix;
+    using ufix = typename Img<R>::ufix;
+    const int i = it * FROZEN_TILE + lane;
+    const unsigned skip = FLAG_ALCH | FLAG_MOBILE;
+    ai = img[min(i, n - 1)];
+    i_on = i < n && !(ai.flags & skip);
+    // relative to the tile's first atom (every wave computes it for itself)
+    const typename Img<R>::Atom a0 = img[it * FROZEN_TILE];
+    const ufix ref[3] = {a0.x, a0.y, a0.z};
+    const ufix pi[3] = {ai.x, ai.y, ai.z};
+    any = __ballot(i_on) != 0ull;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double off = i_on ? (double)(sfix)(pi[k] - ref[k]) * c.dscale[k] : 0.0;
+        double lo = off, hi = off;
+        for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+        cf[k] = ref[k] + (ufix)(sfix)llrint(0.5 * (lo + hi) / c.dscale[k]);
+        hf[k] = (float)(0.5 * (hi - lo) + 2.0 * c.dscale[k]) * 1.00001f + 1e-6f;
+    }
+}
+template <typename R>
+__device__ __forceinline__ void frozen_boxes_body(const int n, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img, FrozenBox<R>* boxes, const int blk) {
+    const int lane = threadIdx.x & 63, it = blk * 4 + (threadIdx.x >> 6);
+    if (it >= (n + FROZEN_TILE - 1) / FROZEN_TILE) return;
+    typename Img<R>::ufix cf[3]; float hf[3]; bool any, i_on; typename Img<R>::Atom ai;
+    frozen_tile_box<R>(n, c, img, it, lane, cf, hf, any, ai, i_on);
+    if (lane == 0) { FrozenBox<R> B; for (int k = 0; k < 3; k++) { B.c[k] = cf[k]; B.h[k] = hf[k]; } B.any = any ? 1 : 0; boxes[it] = B; }
+}
+
 template <typename R>
 __device__ __forceinline__ void energy_frozen_body(const int n, const NbConst<R>& c, const typename Img<R>::Atom* __restrict__ img,
                                                    const int* __restrict__ ex_start, const int* __restrict__ ex_idx, double* epart, const int it) {
@@ -1091,27 +1128,33 @@ __device__ __forceinline__ void energy_frozen_body(const int n, const NbConst<R>
     __shared__ Atom lds[4][64];
     __shared__ double s[2][4];
     const unsigned skip = FLAG_ALCH | FLAG_MOBILE;
-    const Atom ai = img[min(i, n - 1)];
-    const bool i_on = i < n && !(ai.flags & skip);
-    // bounding box of the tile's frozen atoms relative to its first atom (every wave computes it for itself)
-    const Atom a0 = img[it * FROZEN_TILE];
-    const ufix ref[3] = {a0.x, a0.y, a0.z};
-    const ufix pi[3] = {ai.x, ai.y, ai.z};
+    const FrozenBox<R>* boxes = reinterpret_cast<const FrozenBox<R>*>(epart + 2 * nt);   // (k_frozen_boxes ran before this kernel)
+    Atom ai; bool i_on, any_i;
     ufix cf[3]; float hf[3]; float cs[3];
+    frozen_tile_box<R>(n, c, img, it, lane, cf, hf, any_i, ai, i_on);
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        cs[k] = (float)c.dscale[k];
-        double off = i_on ? (double)(sfix)(pi[k] - ref[k]) * c.dscale[k] : 0.0;
-        double lo = off, hi = off;
-        for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
-        cf[k] = ref[k] + (ufix)(sfix)llrint(0.5 * (lo + hi) / c.dscale[k]);
-        hf[k] = (float)(0.5 * (hi - lo) + 2.0 * c.dscale[k]) * 1.00001f + 1e-6f;
-    }
+    for (int k = 0; k < 3; k++) cs[k] = (float)c.dscale[k];
     const float rc2f = (float)c.rc2 * 1.0001f + 1e-5f;
+    const float rc2b = rc2f * 1.001f + 1e-4f;    // box against box: never tighter than the atom-against-box test below
     const int e0 = i < n ? ex_start[i] : 0, e1 = i < n ? ex_start[i + 1] : 0;
     double elj = 0.0, ecl = 0.0;
     Atom* my = lds[wv];
-    for (int jt = it + wv; jt < nt; jt += 4) {
+    // wave wv takes the tiles jt = it + wv, it + wv + 4, ... as before (the order of every lane's sum is unchanged): 64 of its tiles
+    // at a time, a lane per tile, box against box
+    for (int jb = it + wv; jb < nt; jb += 256) {
+        const int jl = jb + 4 * lane;
+        bool cand = false;
+        if (jl < nt && any_i) {
+            const FrozenBox<R> B = boxes[jl];
+            float d2 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { float d = fabsf((float)(sfix)(B.c[k] - cf[k]) * cs[k]) - hf[k] - B.h[k]; d = fmaxf(d, 0.0f); d2 = fmaf(d, d, d2); }
+            cand = B.any && d2 < rc2b;
+        }
+        unsigned long long todo = __ballot(cand);
+      while (todo) {
+        const int jt = jb + 4 * (__ffsll((long long)todo) - 1);
+        todo &= todo - 1ull;
         const int j = jt * FROZEN_TILE + lane;
         const Atom aj = img[min(j, n - 1)];
         const bool j_on = j < n && !(aj.flags & skip);
@@ -1145,6 +1188,7 @@ __device__ __forceinline__ void energy_frozen_body(const int n, const NbConst<R>
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     }
     elj = wave_sum(elj); ecl = wave_sum(ecl);
     if (lane == 0) { s[0][wv] = elj; s[1][wv] = ecl; }
@@ -1153,6 +1197,11 @@ __device__ __forceinline__ void energy_frozen_body(const int n, const NbConst<R>
         epart[2 * it] = s[0][0] + s[0][1] + s[0][2] + s[0][3];
         epart[2 * it + 1] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
     }
+}
+// (two launches: the boxes of ALL tiles first -- they live behind the nt pairs of partial sums in epart)
+template <typename R>
+__global__ void __launch_bounds__(256) k_frozen_boxes(int n, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img, double* epart) {
+    frozen_boxes_body<R>(n, c, img, reinterpret_cast<FrozenBox<R>*>(epart + 2 * ((n + FROZEN_TILE - 1) / FROZEN_TILE)), blockIdx.x);
 }
 template <typename R>
 __global__ void __launch_bounds__(256) k_energy_frozen(int n, NbConst<R> c, const typename Img<R>::Atom* __restrict__ img,
