@@ -337,10 +337,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--replicas", type=int, default=2048, help="independent chains per GPU (a multiple of 256 per batch fills the 256 CUs evenly: the "
                     "nonbonded launch places one workgroup per chain).  The default, 2048 chains as two batches of 1024, is 48 GB of the 288 GB of "
-                    "HBM and 14 s of set-up; one batch of 1024 advances a chain-step in 0.88 us through the driver, 0.95 at 512 (DESIGN.md section 4d)")
+                    "HBM and 4-5 s of set-up; one batch of 1024 advances a chain-step in 0.88 us through the driver, 0.95 at 512 (DESIGN.md section 4d)")
     ap.add_argument("--groups", type=int, default=2, help="the rank's chains form this many replica batches, each driven from its own host thread on its "
                     "own stream.  The batches' STEPPING calls take turns on the device (the other device-side calls of a batch -- energy prefetches, State "
-                    "captures and restores, resets -- are short and may run beside the turn holder's kernels: the in-loop mean of a kernel moves by ~1 %) while the "
+                    "captures and restores, resets -- are short and may run beside the turn holder's kernels: the in-loop mean of a kernel moves by ~1 %%) while the "
                     "other batches' threads do their per-chain host work -- a tenth of an iteration's wall time with one batch (1 = a single batch); the rank's "
                     "all-gathers of the accept records follow, in iteration order, after the threads have finished")
     ap.add_argument("--concurrent", action="store_true", help="with --groups: no turns, the batches' kernels share the device (more ns/day; a kernel's "

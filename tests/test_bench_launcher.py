@@ -54,3 +54,12 @@ def test_eight_ranks_under_the_driver_launcher():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["records"] == 16 and out["max_rank_time"] == 8.0
     assert out["work"] == [10.0 + q // 2 for q in range(16)]       # two records per rank, in rank order
+
+
+def test_help_text_renders():
+    """argparse expands % in help strings: a literal percent sign must be doubled (round 5: `python bench.py --help` raised ValueError)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert "--md-steps" in out.stdout and "--setup-threads" in out.stdout
