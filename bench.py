@@ -571,12 +571,14 @@ def main():
             t_ncmc = (clock["sync"] + clock["switch"] + clock["decide"]) / args.steps
             t_md = clock["md"] / args.steps
             mde = chains[0]._md_sim.context._engine.stats()
+            nce = chains[0]._ncmc_sim.context._engine.stats()   # (after MD legs the NCMC System's mobile atoms have scattered: its engine has moved to fragment lists)
             full_iteration = {"ns_day_both_legs": world * R * args.steps * (nsteps + args.md_steps) * DT_PS * 1e-3 / (elapsed / 86400.0),
                               "ns_day_md_leg": world * R * args.md_steps * DT_PS * 1e-3 / (t_md / 86400.0) if t_md > 0 else None,
                               "ms_sync": 1e3 * clock["sync"] / args.steps, "ms_ncmc": 1e3 * clock["switch"] / args.steps, "ms_boundary": 1e3 * clock["decide"] / args.steps,
                               "ms_md": 1e3 * t_md, "md_steps": args.md_steps, "ncmc_share_of_wall": t_ncmc / (t_ncmc + t_md),
                               "us_per_chain_step_md": 1e6 * t_md / (R * args.md_steps), "us_per_chain_step_ncmc": 1e6 * clock["switch"] / args.steps / (R * nsteps),
                               "md_engine": {"nonbonded_kernel": mde["nonbonded_kernel"], "list_builds": mde["list_builds"], "chain_prunes": mde["atom_prunes"], "force_passes": mde["force_passes"]},
+                              "ncmc_engine": {"nonbonded_kernel": nce["nonbonded_kernel"], "resorts": nce["resorts"], "list_builds": nce["list_builds"]},
                               "triple": "md + alch + ncmc Simulations per chain" if chains[0]._alch_sim is not None else "md + ncmc Simulations per chain",
                               "reference": "blues/simulation.py:1215-1257 (run), 1189-1213 (_stepMD), 768-809 (the triple)"}
             ns_day = world * R * nsteps * DT_PS * 1e-3 / (t_ncmc / 86400.0)

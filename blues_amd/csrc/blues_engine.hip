@@ -160,6 +160,7 @@ struct BluesEngine {
     // pruned per-atom lists (nonbonded_atom_body): inner margins for frozen / mobile candidates, displacement that asks for a prune
     bool prune_on = false; double prune_m = 0.0, ptrig = 0.0;
     int steps_since_sort = 0;   // whole steps taken in the current order (fragment lists re-sort by age: resort_by_age)
+    double frag_grow_o = 1.0, frag_grow_i = 1.0;   // room given to the fragment lists beyond the density estimate (frag_grow_caps: a row reached 90 % of its capacity)
     EwaldPoly ewpoly;   // degree-9 fit of the smooth part of the Ewald pair force (fit_ewald_poly), mixed precision
     // ---- integrator
     double dt = 0, temperature = 0, gamma = 1, kT = 0, tol = 1e-8;
@@ -1034,7 +1035,8 @@ static int sort_and_tile(BluesEngine* h) {
             };
             const int NI = (int)ifrag.size();
             h->frag_F = F; h->frag_NI = NI; h->frag_nblk = (F + 63) / 64;
-            h->frag_ocap = cap_for(h->skin); h->frag_icap = std::min(h->frag_ocap, cap_for(h->frag_m));
+            auto grown = [&](int cap, double g) { return std::min(((F + 63) / 64) * 64 + 64, (((int)(cap * g) + 63) / 64) * 64); };
+            h->frag_ocap = grown(cap_for(h->skin), h->frag_grow_o); h->frag_icap = std::min(h->frag_ocap, grown(cap_for(h->frag_m), h->frag_grow_i));
             // the relative form of a pair's separation (kernels_frag.h: REL) wants cutoff + a fragment's reach (bonded atoms: well under
             // 0.6 nm) below half the shortest edge; smaller boxes (the 975-atom test box) take the fixed-point difference per pair
             h->frag_rel = 0.5 * std::min(h->box[0], std::min(h->box[1], h->box[2])) > h->cutoff + 0.6;
@@ -1931,6 +1933,16 @@ static int check_flags(BluesEngine* h) {
         fprintf(stderr, "[overflow] member %d mode %d S %d n_lists %d n_itiles %d jcap %d max jcount %d (lists %zu) acap %d max acount %d skin %.3f skin_m %.3f trig %.3f\n",
                 h->batch_index, h->k1_mode, h->S, h->n_lists, h->n_itiles, h->jcap, mj, jc.size(), h->acap, ma, h->skin, h->skin_m, h->trig);
     }
+    if (f.list_overflow && h->k1_mode == 3 && (f.list_overflow & ~1)) {
+        int mo = -1, mi = -1;
+        try { std::vector<int> oc, ic; h->d_ocount.download(oc); h->d_icount.download(ic); mo = mi = 0;
+              for (int q = 0; q < h->frag_NI && q < (int)oc.size(); q++) mo = std::max(mo, oc[q]);
+              for (int q = 0; q < h->frag_NI && q < (int)ic.size(); q++) mi = std::max(mi, ic[q]); } catch (std::string&) {}
+        E_FAIL(h, "neighbour list capacity exceeded (fragment lists:%s%s%s%s; longest outer row %d of %d, inner %d of %d; %d fragments)",
+               (f.list_overflow & FR_OVER_OUTER) ? " outer rows" : "", (f.list_overflow & FR_OVER_INNER) ? " inner rows" : "",
+               (f.list_overflow & FR_OVER_QUEUE) ? " the builder's candidate queue" : "", (f.list_overflow & FR_OVER_REACH) ? " a fragment's reach against the box" : "",
+               mo, h->frag_ocap, mi, h->frag_icap, h->frag_F);
+    }
     if (f.list_overflow) E_FAIL(h, "neighbour list capacity exceeded (jcap=%d)", h->jcap);
     if (f.constraint_fail) E_FAIL(h, "constraint solver did not converge (the step is unstable)");
     return 0;
@@ -1942,6 +1954,20 @@ static int check_flags(BluesEngine* h) {
 #define RESORT_POLL 64
 static int relayout(BluesEngine* h);
 static int batch_plan_shape(BluesBatch* B, bool fresh);
+// Fragment lists: the builder raises resort_hint when a row has reached 90 % of its capacity (kernels_frag.h: finish) as well as when its
+// blocks have spread.  Before the re-layout that follows, the rows' lengths say whether the lists want more room than the density estimate
+// gave them (a solute-rich region, a denser phase): then the next layout gets a quarter more -- before an entry is ever dropped.
+static void frag_grow_caps(BluesEngine* h) {
+    if (h->k1_mode != 3 || h->frag_NI <= 0) return;
+    std::vector<int> oc, ic;
+    try { h->d_ocount.download(oc); h->d_icount.download(ic); } catch (std::string&) { return; }
+    int mo = 0, mi = 0;
+    for (int q = 0; q < h->frag_NI && q < (int)oc.size(); q++) mo = std::max(mo, oc[q]);
+    for (int q = 0; q < h->frag_NI && q < (int)ic.size(); q++) mi = std::max(mi, ic[q]);
+    if (100 * mo > 85 * h->frag_ocap || mo > h->frag_ocap - 64) h->frag_grow_o *= 1.25;
+    if (100 * mi > 85 * h->frag_icap || mi > h->frag_icap - 64) h->frag_grow_i *= 1.25;
+    if (h->tune.debug_lists) fprintf(stderr, "[frag caps] member %d: longest outer row %d of %d, inner %d of %d; growth %.2f / %.2f\n", h->batch_index, mo, h->frag_ocap, mi, h->frag_icap, h->frag_grow_o, h->frag_grow_i);
+}
 // poll_resort_due: 1 = the engine's builder asked for a new order (flag cleared, counted) and nothing is wrong with it, 0 = no, -1 = error
 static int poll_resort_due(BluesEngine* h) {
     if (flush_program(h)) return -1;
@@ -1953,6 +1979,7 @@ static int poll_resort_due(BluesEngine* h) {
     f.resort_hint = 0;
     if (hipMemcpy(h->d_flags.p, &f, sizeof f, hipMemcpyHostToDevice) != hipSuccess) { h->err = "flag write-back failed"; return -1; }
     h->st_resorts++;
+    frag_grow_caps(h);
     return 1;
 }
 // Fragment lists of a system in which (nearly) everything moves: the order ages -- the builder's blocks spread as the molecules diffuse,

@@ -52,6 +52,11 @@ struct FragBox { unsigned c[3]; float h[3]; float pad[2]; };   // bounding box o
 #define FR_MIN_WAVES 4          // waves per SIMD the force kernel is compiled for (registers: 512 / this)
 #endif
 #define FR_QCAP 1280        // candidates one fragment's first test may let through (the builder's LDS queue, per wave)
+// DevFlags::list_overflow of the fragment-list kernels: which capacity (the other builders write 1)
+#define FR_OVER_OUTER 2
+#define FR_OVER_INNER 4
+#define FR_OVER_QUEUE 8
+#define FR_OVER_REACH 16
 
 struct FragArgs {
     int F, nblk, n, ocap, icap, fpw, nwg, n_islots;
@@ -197,12 +202,15 @@ __device__ __forceinline__ void frag_lists_body(const FragArgs& fa, const int fo
         if (pass && pos < cap) row[pos] = entry;
         count += __popcll(bal);
     };
-    auto finish = [&](unsigned* row, int cap, int* counts, int count) {
+    // (list_overflow says which capacity: FR_OVER_*; a row that has reached 90 % of its capacity, or its last chunk, asks for a new layout -- the host gives the
+    // lists more room then, blues_engine.hip: frag_grow_caps -- before anything is lost)
+    auto finish = [&](unsigned* row, int cap, int* counts, int count, int code) {
         const int c0 = min(count, cap), padto = min((c0 + 63) & ~63, cap);
         if (c0 + lane < padto) row[c0 + lane] = pad_entry;
         if (lane == 0) {
             counts[fq] = c0;
-            if (count > cap) fa.flags->list_overflow = 1;
+            if (count > cap) atomicOr(&fa.flags->list_overflow, code);
+            else if (10 * count > 9 * cap || count > cap - 64) fa.flags->resort_hint = 1;   // (90 %, or the row's last chunk is in use)
         }
     };
     if (!rebuild) {
@@ -229,7 +237,7 @@ __device__ __forceinline__ void frag_lists_body(const FragArgs& fa, const int fo
             push(irow, fa.icap, icnt, u * 64 + lane < ocnt && best < (FR_MOB(tc) ? fa.ri2 : fa.ri2_f), e_cur);
             e_cur = e_nxt; e_nxt = e_n2; pc[0] = pn[0]; pc[1] = pn[1]; pc[2] = pn[2]; tc = tn;
         }
-        finish(irow, fa.icap, fa.icount, icnt);
+        finish(irow, fa.icap, fa.icount, icnt, FR_OVER_INNER);
         if (fq == 0 && lane == 0) fa.flags->prunes++;
         if (lane < cnt_i) {
 #pragma unroll
@@ -287,7 +295,7 @@ __device__ __forceinline__ void frag_lists_body(const FragArgs& fa, const int fo
             }
         }
     }
-    if (qn > FR_QCAP) { if (lane == 0) fa.flags->list_overflow = 1; qn = FR_QCAP; }
+    if (qn > FR_QCAP) { if (lane == 0) atomicOr(&fa.flags->list_overflow, FR_OVER_QUEUE); qn = FR_QCAP; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the queue is wave-private: this wave's LDS stores have landed)
     FragRec P;
     if (qn > 0) P = fa.fimg[queue[min(lane, qn - 1)]];
@@ -318,8 +326,8 @@ __device__ __forceinline__ void frag_lists_body(const FragArgs& fa, const int fo
         push(irow, fa.icap, icnt, in_o && best < (jmob ? fa.ri2 : fa.ri2_f), entry);
         P = Pn;
     }
-    finish(orow, fa.ocap, fa.ocount, ocnt);
-    finish(irow, fa.icap, fa.icount, icnt);
+    finish(orow, fa.ocap, fa.ocount, ocnt, FR_OVER_OUTER);
+    finish(irow, fa.icap, fa.icount, icnt, FR_OVER_INNER);
     if (lane == 0 && nblocks_seen > fa.hint_blocks) fa.flags->resort_hint = 1;
 }
 
@@ -403,7 +411,7 @@ __device__ __forceinline__ void nonbonded_frag_body(const FragArgs& fa, const Nb
             float reach2 = 0.0f;
 #pragma unroll
             for (int a = 1; a < 3; a++) reach2 = fmaxf(reach2, fmaf(oz[a], oz[a], fmaf(oy[a], oy[a], ox[a] * ox[a])));
-            if (lane == 0 && sqrtf(reach2) + sqrtf(c.rc2) >= fa.half_min_edge) fa.flags->list_overflow = 1;   // (cannot happen for bonded fragments in a box the host let through)
+            if (lane == 0 && sqrtf(reach2) + sqrtf(c.rc2) >= fa.half_min_edge) atomicOr(&fa.flags->list_overflow, FR_OVER_REACH);   // (cannot happen for bonded fragments in a box the host let through)
         }
         const bool lj_a[3] = {ise[0] != 0.0f, ise[1] != 0.0f, ise[2] != 0.0f};   // (wave-uniform: a hydrogen of a water has no epsilon, its pairs no 12-6 term)
         Rec cur, nxt;

@@ -188,3 +188,43 @@ def test_resort_by_age_keeps_a_member_equal_to_the_lone_chain(Engine, tol_box, t
     B.close()
     for g in alone + together:
         g.close()
+
+
+def test_fragment_lists_get_more_room_before_a_row_overflows(Engine, tune):
+    """A row of the fragment lists that reaches its last chunk asks for a new layout, and the host then gives the lists a quarter more room
+    (blues_engine.hip: frag_grow_caps) -- before an entry is dropped.  The capacities are shrunk (acap_scale) until the first list build
+    overflows; one 64-entry step above that, the longest row sits in its last chunk: the engine must re-lay itself out at its first
+    poll and carry on with clean lists.  An overflow names the capacity that was exceeded."""
+    from blues_amd.engine import EngineError
+    s, v = systems.s23k(frozen=False, restrained=0)
+    s = copy.copy(s); s.alchemical_atoms = np.zeros(0, np.int32)
+    data = integrators.LangevinIntegrator(300.0, 1.0, 0.004, seed=9).to_data(precision=0)
+
+    def attempt(scale, nsteps):
+        tune(k1_mode=3, acap_scale=scale)
+        g = Engine(s, data)
+        try:
+            g.set_velocities(v)
+            g.step(nsteps)
+            return g.stats(), g.audit_lists(), None
+        except EngineError as e:
+            return None, None, str(e)
+        finally:
+            g.close()
+
+    last_ok = None
+    scale = 1.0
+    while scale > 0.4:
+        st, au, err = attempt(scale, 2)
+        if err is not None:
+            assert "fragment lists" in err and ("outer rows" in err or "inner rows" in err), err
+            break
+        last_ok = scale
+        scale -= 0.04
+    assert last_ok is not None and scale > 0.4, "no capacity was small enough to overflow"
+    st, au, err = attempt(last_ok, 200)
+    if err is not None:   # (the longest row grew past the capacity in the 64 steps before the first poll)
+        assert "fragment lists" in err
+        pytest.skip("the row outgrew its capacity before the first poll: " + err)
+    assert st["resorts"] >= 1 and st["nonbonded_kernel"] == 3, st
+    assert au[0] > 0 and au[1] == 0
