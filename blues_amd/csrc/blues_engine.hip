@@ -1964,8 +1964,8 @@ static void frag_grow_caps(BluesEngine* h) {
     int mo = 0, mi = 0;
     for (int q = 0; q < h->frag_NI && q < (int)oc.size(); q++) mo = std::max(mo, oc[q]);
     for (int q = 0; q < h->frag_NI && q < (int)ic.size(); q++) mi = std::max(mi, ic[q]);
-    if (100 * mo > 85 * h->frag_ocap || mo > h->frag_ocap - 64) h->frag_grow_o *= 1.25;
-    if (100 * mi > 85 * h->frag_icap || mi > h->frag_icap - 64) h->frag_grow_i *= 1.25;
+    if (h->frag_ocap <= h->frag_F && (100 * mo > 85 * h->frag_ocap || mo > h->frag_ocap - 64)) h->frag_grow_o *= 1.25;   // (a row of F + 1 places holds every fragment)
+    if (h->frag_icap <= h->frag_F && (100 * mi > 85 * h->frag_icap || mi > h->frag_icap - 64)) h->frag_grow_i *= 1.25;
     if (h->tune.debug_lists) fprintf(stderr, "[frag caps] member %d: longest outer row %d of %d, inner %d of %d; growth %.2f / %.2f\n", h->batch_index, mo, h->frag_ocap, mi, h->frag_icap, h->frag_grow_o, h->frag_grow_i);
 }
 // poll_resort_due: 1 = the engine's builder asked for a new order (flag cleared, counted) and nothing is wrong with it, 0 = no, -1 = error

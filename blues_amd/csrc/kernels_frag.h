@@ -210,7 +210,7 @@ __device__ __forceinline__ void frag_lists_body(const FragArgs& fa, const int fo
         if (lane == 0) {
             counts[fq] = c0;
             if (count > cap) atomicOr(&fa.flags->list_overflow, code);
-            else if (10 * count > 9 * cap || count > cap - 64) fa.flags->resort_hint = 1;   // (90 %, or the row's last chunk is in use)
+            else if (cap <= fa.F && (10 * count > 9 * cap || count > cap - 64)) fa.flags->resort_hint = 1;   // (90 %, or the row's last chunk is in use; a row of F + 1 places cannot overflow)
         }
     };
     if (!rebuild) {
