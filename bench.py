@@ -111,6 +111,14 @@ def md_states(chains, x0, v0, batch=None, driver=None, decorrelate=0):
     return [c.getStateFromContext(c._ncmc_sim.context, c._state_keys) for c in chains]
 
 
+def _record(c, it):
+    """[accept, iteration, log_accept, protocol_work, correction] of a chain's last decision (a retired chain: not accepted, NaN)"""
+    l = c.last or {}
+    if l.get("failed"):
+        return [0.0, it, float("nan"), float("nan"), float("nan")]
+    return [l["accept"], it, l["log_accept"], l["protocol_work"], l["correction"]]
+
+
 def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
     """One BLUES iteration's NCMC leg for every chain: MD->NCMC hand-over -> switch -> Metropolis -> gather -> reset."""
     from blues_amd.replicas import gather_decision_block
@@ -144,7 +152,7 @@ def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
         driver._decide_batched(300.0)
     else:
         each(lambda r, c: c._acceptRejectMove())
-    recs = np.array([[c.last["accept"], it, c.last["log_accept"], c.last["protocol_work"], c.last["correction"]] for c in chains], dtype=np.float64)
+    recs = np.array([_record(c, it) for c in chains], dtype=np.float64)
     if gather:
         recs = gather_decision_block(recs)
     if fast:
@@ -177,7 +185,7 @@ def one_iteration(driver, chains, nsteps, md_steps, it, clock):
         driver._decide_batched(300.0)
     else:
         driver.for_each_chain(lambda r, c: c._acceptRejectMove())
-    recs = gather_decision_block(np.array([[c.last["accept"], it, c.last["log_accept"], c.last["protocol_work"], c.last["correction"]] for c in chains], dtype=np.float64))
+    recs = gather_decision_block(np.array([_record(c, it) for c in chains], dtype=np.float64))
     if fast:
         driver._reset_batched(300.0)
     else:
@@ -454,7 +462,8 @@ def main():
     t_part = time.perf_counter()
     import threading
     turn = threading.Lock() if (G > 1 and not args.concurrent) else None
-    drivers = [simulation.BatchedBLUESSimulation(grp, workers=args.workers, device_turn=turn) for grp in groups]
+    # (isolate_failures: a chain that dies -- a move that blows its switch up -- is retired and counted in `chains_failed`; it does not end the other 2047)
+    drivers = [simulation.BatchedBLUESSimulation(grp, workers=args.workers, device_turn=turn, isolate_failures=True) for grp in groups]
     setup_parts["batches"] = time.perf_counter() - t_part; t_part = time.perf_counter()
     if G > 1:   # chains driven from different threads draw from their own streams (reproducible whatever the interleaving)
         for c in chains:
@@ -540,7 +549,7 @@ def main():
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
     rank_elapsed = {"max": float(t.item()), "min": float(tmin.item()), "this_rank": elapsed}   # (host imbalance between ranks shows here first)
     from blues_amd.replicas import gather_rank_numbers
-    per_rank = gather_rank_numbers([t_setup, memory_use()["host_peak_rss_gib"], float(os.getpid())])   # what N ranks on one host cost: set-up seconds, peak host memory
+    per_rank = gather_rank_numbers([t_setup, memory_use()["host_peak_rss_gib"], float(os.getpid()), float(sum(len(d.dead) for d in drivers))])   # what N ranks on one host cost: set-up seconds, peak host memory; chains retired after a failure
     elapsed = float(t.item())
 
     # the kernel north_star prices against the HBM roofline: the direct-space nonbonded kernel, timed alone with HIP
@@ -626,6 +635,10 @@ def main():
                       v["transcendental_insts_per_launch"] = c["SQ_INSTS_VALU_TRANS_F32"]
                   roofline["valu"] = v
               roofline["pmc_source"] = {"file": PMC_FILE, "source_sha": ev["source_sha"], "kernel": ev["kernel"]}
+        # chains that were retired after a failure (BatchedBLUESSimulation.isolate_failures: a switch that blew up) do not count
+        chains_failed = int(per_rank[:, 3].sum())
+        if chains_failed:
+            ns_day *= (world * R - chains_failed) / float(world * R)
         out = {
             "metric": "NCMC ns/day (23k-atom toluene box, 1000-step switch, RandomLigandRotationMove), aggregate over independent chains",
             "value": ns_day, "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -640,6 +653,7 @@ def main():
                        "replicas_per_gpu": R, "batches_per_gpu": G, "host_workers": args.workers,
                        "parallelism": "%d replica batch(es) x %d chains per gpu%s, %d gpu(s)" % (G, R_launch, "" if G == 1 else (" taking turns on the device" if turn is not None else " sharing the device"), world),
                        "batches_take_turns": turn is not None},
+            "chains_failed": chains_failed,
             "roofline": roofline,
             "full_iteration": full_iteration,
             "single_replica": single,

@@ -283,15 +283,23 @@ class BatchedBLUESSimulation(object):
     NCMC engines form one native batch (and the MD engines another), so `step(n)` is one kernel launch sequence for all
     chains.  Hooks, state exchange and the Metropolis test run per chain, in chain order."""
 
-    def __init__(self, chains, workers=1, batched_boundary=True, device_turn=None):
+    def __init__(self, chains, workers=1, batched_boundary=True, device_turn=None, isolate_failures=False):
         """workers > 1: the per-chain host work (hooks, state exchange through the plugin boundary, Metropolis test) of
         different chains runs on a thread pool -- the C-ABI calls release the GIL and engines are independent objects;
         each chain then draws from its own RandomState (seeded here, in chain order, from numpy's global stream).
 
         device_turn: a threading.Lock shared by several BatchedBLUESSimulation objects on ONE GPU, each driven from its own
         host thread.  Their stepping calls then take turns on the device (one batch's kernels have the GPU to themselves),
-        and the per-chain host work of one batch -- a tenth of an iteration's wall time -- runs while another batch steps."""
+        and the per-chain host work of one batch -- a tenth of an iteration's wall time -- runs while another batch steps.
+
+        isolate_failures: the reference runs one chain per process, so a chain that dies -- an exception from getState after a switch
+        that blew up (blues/simulation.py:1096 is outside the try), sys.exit(1) after an MD-leg exception (:1203-1213) -- takes nobody
+        with it.  True gives the chains of a batch the same independence on the batched path: the chain is logged and retired (`dead`:
+        {chain index: the exception}), sits every later operation out, and the others carry on with the results they would have had
+        anyway (chains share launches, never data).  False (default): the first such failure ends the run, as ONE reference process ends."""
         from .engine import NativeBatch
+        self.isolate_failures = bool(isolate_failures)
+        self.dead = {}
         self.chains = list(chains)
         if not self.chains:
             raise ValueError("no chains")
@@ -333,6 +341,15 @@ class BatchedBLUESSimulation(object):
         if self._pool is None or len(idx) < 2:
             return [fn(r, self.chains[r]) for r in idx]
         return list(self._pool.map(lambda r: fn(r, self.chains[r]), idx))
+
+    def _alive(self):
+        return [r not in self.dead for r in range(len(self.chains))]
+
+    def _retire(self, r, error, where):
+        """A chain that cannot go on (isolate_failures): logged with what the reference would have logged, then left out of everything."""
+        logger.error("chain %d is retired after a failure in %s: %s" % (r, where, error))
+        self.dead[r] = error
+        self.chains[r].last = dict(self.chains[r].last or {}, failed=True)
 
     @staticmethod
     def _advance(batch, sims, wanted):
@@ -410,8 +427,9 @@ class BatchedBLUESSimulation(object):
                 return False
         return True
 
-    def _capture_states(self, active=None, leg="ncmc"):
-        """getStateFromContext (reference blues/simulation.py:883-911) of every chain's NCMC (or MD) context: one capture for all."""
+    def _capture_states(self, active=None, leg="ncmc", tolerate=False):
+        """getStateFromContext (reference blues/simulation.py:883-911) of every chain's NCMC (or MD) context: one capture for all.
+        tolerate: a chain whose context cannot be read (it blew up) yields the exception in place of a State instead of raising."""
         batch = self._ncmc_batch if leg == "ncmc" else self._md_batch
         snaps = batch.snapshot_all(True, True, active=active)
         out = []
@@ -421,7 +439,13 @@ class BatchedBLUESSimulation(object):
                 continue
             ctx = (c._ncmc_sim if leg == "ncmc" else c._md_sim).context
             e = ctx._engine
-            pe, ke = e.energies()
+            try:
+                pe, ke = e.energies()
+            except Exception as err:
+                if not tolerate:
+                    raise
+                out.append(err)
+                continue
             # (enforcePeriodicBox=True of the chain-by-chain path: what reaches the host is wrapped molecule by molecule, context.getState)
             periodic = getattr(ctx._system, "nonbonded_method", 1) != 0 and hasattr(ctx._system, "n_atoms") and hasattr(ctx, "periodic_wrapper")
             out.append({'positions': unit.DeviceQuantity(snaps[r], 1, "nanometer", wrapper=ctx.periodic_wrapper() if periodic else None),
@@ -446,15 +470,18 @@ class BatchedBLUESSimulation(object):
         chains, batch = self.chains, self._ncmc_batch
         R = len(chains)
         sims = [c._ncmc_sim for c in chains]
-        batch.prefetch_energies()
-        for c, st in zip(chains, self._capture_states()):
+        alive = self._alive() if self.dead else None
+        batch.prefetch_energies(active=alive)
+        for c, st in zip(chains, self._capture_states(active=alive)):
+            if st is None:
+                continue
             c._setStateTable('ncmc', 'state0', st)
             c._ncmc_sim.currentIter = c.currentIter
             c._move_engine.selectMove()
         nstepsNC, moveStep = int(nstepsNC), int(moveStep)
         cuts = sorted(set([0, nstepsNC] + ([moveStep] if 0 <= moveStep < nstepsNC else [])))
         one_scatter = self._move_batchable()
-        failed = {}
+        failed = dict(self.dead)      # (retired chains sit the switch out like chains whose switch has been abandoned)
 
         def hook(r, fn):
             """A Move hook of chain r under the reference's policy (blues/simulation.py:1088-1094): an exception is logged, the
@@ -472,7 +499,8 @@ class BatchedBLUESSimulation(object):
         for a, b in zip(cuts[:-1], cuts[1:]):
             if a == 0 and not one_scatter:
                 for r in range(R):
-                    hook(r, lambda c, ctx: c._move_engine.selected_move.beforeMove(ctx))
+                    if r not in failed:
+                        hook(r, lambda c, ctx: c._move_engine.selected_move.beforeMove(ctx))
             live = [r not in failed for r in range(R)]
             if a == moveStep and any(live):
                 if a > 0:   # the work of the instantaneous move needs U(x) before the edit (integrators.py:184-205): for all chains at once
@@ -509,8 +537,14 @@ class BatchedBLUESSimulation(object):
                     if r not in failed:
                         hook(r, lambda c, ctx: c._move_engine.selected_move.afterMove(ctx))
         batch.prefetch_energies(active=[r not in failed for r in range(R)], at_lambda_one=True)
-        for c, st in zip(chains, self._capture_states()):
-            c._setStateTable('ncmc', 'state1', st)
+        # the reference reads the State of a chain whose switch was abandoned all the same (simulation.py:1096: outside the try); a
+        # context that blew up raises there and that chain's process ends.  isolate_failures: that chain is retired, the others go on.
+        states = self._capture_states(active=self._alive() if self.dead else None, tolerate=self.isolate_failures)
+        for r, (c, st) in enumerate(zip(chains, states)):
+            if isinstance(st, Exception):
+                self._retire(r, st, "reading the State after the NCMC switch")
+            elif st is not None:
+                c._setStateTable('ncmc', 'state1', st)
 
     def _decide_batched(self, temperature):
         """_acceptRejectMove of every chain (reference blues/simulation.py:1121-1166): the `alch` energies of the correction for
@@ -519,22 +553,26 @@ class BatchedBLUESSimulation(object):
         chains = self.chains
         R = len(chains)
         unmodified = [None] * R
+        alive = self._alive()
         if self._alch_batch is not None:
             # reference simulation.py:1107-1110: the switched coordinates into the alch context, its potential energy
-            ends = [c.stateTable['ncmc']['state1'] for c in chains]
+            ends = [c.stateTable['ncmc']['state1'] if alive[r] else None for r, c in enumerate(chains)]
             self._restore_states(ends, velocities=False, leg="alch")
-            self._alch_batch.prefetch_energies(kinetic=False)
-            unmodified = [c._alch_sim.context.getState(getEnergy=True).getPotentialEnergy() for c in chains]
+            self._alch_batch.prefetch_energies(kinetic=False, active=alive if self.dead else None)
+            unmodified = [c._alch_sim.context.getState(getEnergy=True).getPotentialEnergy() if alive[r] else None for r, c in enumerate(chains)]
         restore = []
         for r, c in enumerate(chains):
+            if not alive[r]:
+                restore.append(None)
+                continue
             todo = record_decision(c, metropolis(c, unmodified[r]))
             restore.append(None if todo is None else todo[1])
         if self._md_batch is None:
             self._restore_states(restore)            # a rejection restores the pre-switch state in place
             return
         self._restore_states(restore, velocities=False, leg="md")     # accepted: the switched configuration becomes the MD state
-        for c, st in zip(chains, restore):
-            if st is None:      # rejected: the MD context must still be where the iteration started (the reference's sanity check)
+        for r, (c, st) in enumerate(zip(chains, restore)):
+            if st is None and alive[r]:      # rejected: the MD context must still be where the iteration started (the reference's sanity check)
                 before = c.stateTable['md']['state0']['potential_energy']
                 now = c._md_sim.context.getState(getEnergy=True).getPotentialEnergy()
                 if not math.isclose(before._value, now._value, rel_tol=10.0 ** -rtol):
@@ -551,24 +589,29 @@ class BatchedBLUESSimulation(object):
             c._ncmc_sim.context._integrator._pre_globals = {}       # integrator.reset(): the engine part follows for all chains at once
             temps.append(unit.value_in(temperature if temperature else c._ncmc_sim.context._integrator.getTemperature(), "kelvin"))
             seeds.append(c._rng.randint(0, 2 ** 31 - 1))
-        self._ncmc_batch.reset_all()
+        alive = self._alive()       # (seeds are drawn for every chain, retired or not: the others' streams do not move)
+        self._ncmc_batch.reset_all(active=alive if self.dead else None)
         leg = self._ncmc_batch if self._md_batch is None else self._md_batch
         for T in sorted(set(temps)):   # (one launch per distinct temperature: one, in practice)
-            leg.set_velocities_to_temperature_all(T, seeds, active=[t == T for t in temps])
+            leg.set_velocities_to_temperature_all(T, seeds, active=[t == T and ok for t, ok in zip(temps, alive)])
 
     def _sync_batched(self):
         """_syncStatesMDtoNCMC of every chain (reference blues/simulation.py:1028-1037).  With MD contexts: their States in one
         capture, into the NCMC contexts in one restore (device to device).  Without: the MD state is the NCMC context's own, its
         potential the one at lambda = 1."""
+        alive = self._alive() if self.dead else None
         if self._md_batch is not None:
-            self._md_batch.prefetch_energies()
-            states = self._capture_states(leg="md")
+            self._md_batch.prefetch_energies(active=alive)
+            states = self._capture_states(active=alive, leg="md")
             for c, st in zip(self.chains, states):
-                c._setStateTable('md', 'state0', st)
+                if st is not None:
+                    c._setStateTable('md', 'state0', st)
             self._restore_states(states, velocities=True, leg="ncmc")
             return
-        self._ncmc_batch.prefetch_energies(at_lambda_one=True)
-        for c, st in zip(self.chains, self._capture_states()):
+        self._ncmc_batch.prefetch_energies(at_lambda_one=True, active=alive)
+        for c, st in zip(self.chains, self._capture_states(active=alive)):
+            if st is None:
+                continue
             st['potential_energy'] = c._lambda_one_energy()
             c._setStateTable('md', 'state0', st)
 
@@ -607,8 +650,11 @@ class BatchedBLUESSimulation(object):
         sims = [c._md_sim for c in self.chains]
         for r, c in enumerate(self.chains):
             sims[r].currentIter = c.currentIter
-        errors = self._advance(self._md_batch, sims, {r: int(nstepsMD) for r in range(len(sims))})
-        for r, e in errors.items():  # reference blues/simulation.py:1207-1213: an MD failure is fatal
+        errors = self._advance(self._md_batch, sims, {r: int(nstepsMD) for r in range(len(sims)) if r not in self.dead})
+        for r, e in errors.items():  # reference blues/simulation.py:1207-1213: an MD failure is fatal -- to that chain's process
+            if self.isolate_failures:
+                self._retire(r, e, "the MD leg")
+                continue
             logger.error(e, exc_info=True)
             sys.exit(1)
 

@@ -769,6 +769,58 @@ def test_batched_boundary_of_the_full_triple_equals_chain_by_chain(Engine, tol_b
         assert np.array_equal(x0[r], x1[r]) and np.array_equal(v0[r], v1[r]) and np.array_equal(n0[r], n1[r])
 
 
+def test_a_chain_that_dies_is_retired_and_the_others_carry_on(Engine, tol_box, tune):
+    """isolate_failures: the reference runs one chain per process, so a chain whose switch blows up (getState raises after the abandoned
+    switch, blues/simulation.py:1096) or whose MD leg raises (sys.exit(1), :1203-1213) takes nobody with it.  On the batched path
+    a chain that dies in iteration 2 -- two waters of its MD state placed on top of each other before the hand-over -- is retired;
+    the other chains finish all iterations with exactly the records and states they have in a run in which nobody dies."""
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    md_sys = copy.copy(s); md_sys.alchemical_atoms = np.zeros(0, np.int32)
+    lig = np.arange(15)
+    R, nsteps, nmd, nIter = 4, 10, 6, 3
+    vels = _replica_inputs(s, v, R)
+    tune(assume_batch=R)
+
+    def chains():
+        out = []
+        for r in range(R):
+            sim = Simulation(None, s, _integ(nsteps, seed=700 + r, dt=0.002), precision="mixed", replica=r)
+            md = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=800 + r), precision="mixed", replica=r)
+            alch = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=900 + r), precision="mixed", replica=r)
+            md.context.setPositions(unit.Quantity(s.positions, "nanometer")); md.context.setVelocities(unit.Quantity(vels[r], "nanometer/picosecond"))
+            mover = moves.MoveEngine(moves.RandomLigandRotationMove(lig, s.mass[lig], random_state=90 + r))
+            out.append(simulation.BLUESSimulation(simulation.SimulationSet(sim, md=md, alch=alch), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": nIter, "nstepsMD": nmd},
+                                                  mover, rng=np.random.RandomState(4000 + r)))
+        return out
+
+    results = {}
+    for sabotage in (False, True):
+        np.random.seed(123)
+        cs = chains()
+        B = simulation.BatchedBLUESSimulation(cs, isolate_failures=True)
+        assert B._batchable()
+        records = []
+
+        def after(N, last):
+            records.append([dict(l) for l in last])
+            if sabotage and N == 0:      # (between the decision and the reset of iteration 1: chain 2's MD state for iteration 2)
+                e = cs[2]._md_sim.context._engine
+                x = e.get_positions(); x[18] = x[21] + 1e-4; x[19] = x[22] + 1e-4; x[20] = x[23] + 1e-4
+                e.set_positions(x)
+        B.run(nIter=nIter, on_iteration=after)
+        results[sabotage] = (records, [c._md_sim.context._engine.get_positions() for c in cs], [c.accept for c in cs], dict(B.dead))
+        B.close()
+    (rec0, x0, acc0, dead0), (rec1, x1, acc1, dead1) = results[False], results[True]
+    assert dead0 == {} and list(dead1) == [2], (dead0, dead1)
+    for r in (0, 1, 3):
+        assert acc0[r] == acc1[r] and np.array_equal(x0[r], x1[r])
+        for N in range(nIter):
+            for key in ("accept", "log_accept", "correction", "randnum", "protocol_work"):
+                assert rec0[N][r][key] == rec1[N][r][key], (N, r, key)
+    assert rec1[-1][2].get("failed") is True
+
+
 def test_restoring_a_state_that_moves_a_frozen_atom(Engine):
     """setPositions from a device-resident State learns on the device whether a FROZEN atom changed (the frozen-frozen energy is a
     cached constant).  The verdict is read back lazily, by the next evaluation; two restores in a row must not lose it."""
