@@ -33,6 +33,7 @@ NSTEPS_NC = 1000
 DT_PS = 0.004
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_ATOM = 36.0     # x,y,z + q,sigma,eps read, fx,fy,fz written, per force evaluation
+DECORRELATE_LEG = 25           # steps per leg of the set-up decorrelation (lambda <= DECORRELATE_LEG / nstepsNC throughout)
 
 
 def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False, md_steps=0, with_alch=True, setup_threads=None):
@@ -102,9 +103,20 @@ def md_states(chains, x0, v0, batch=None, driver=None, decorrelate=0):
         ctx.setPositions(unit.Quantity(x0, "nanometer")); ctx.setVelocities(unit.Quantity(v0, "nanometer/picosecond"))
     if decorrelate > 0 and driver is not None:
         driver._reset_batched(300.0)      # (velocities: each chain draws its own seed from its own stream)
-        errors = driver._advance(driver._ncmc_batch, [c._ncmc_sim for c in chains], {r: int(decorrelate) for r in range(len(chains))})
-        if errors:
-            raise RuntimeError("decorrelation leg failed: %s" % list(errors.values())[0])
+        # legs of DECORRELATE_LEG steps with the integrator reset in between: lambda never passes DECORRELATE_LEG / nstepsNC (0.025: the
+        # ligand keeps >= 87 % of its charges, sterics untouched), so the hand-over State is an equilibrium state of the lambda = 0
+        # System to that approximation -- not a configuration relaxed around a half-decoupled ligand (one 250-step leg reached 0.25)
+        sims = [c._ncmc_sim for c in chains]
+        left = int(decorrelate)
+        while left > 0:
+            n = min(DECORRELATE_LEG, left); left -= n
+            errors = driver._advance(driver._ncmc_batch, sims, {r: n for r in range(len(chains))})
+            if errors:
+                raise RuntimeError("decorrelation leg failed: %s" % list(errors.values())[0])
+            for c in chains:
+                c._ncmc_sim.currentStep = 0
+                c._ncmc_sim.context._integrator._pre_globals = {}
+            driver._ncmc_batch.reset_all()
         driver._reset_batched(300.0)
     if batch is not None:      # the energies every chain's State is about to ask for: one evaluation for the whole batch (set-up time only)
         batch.prefetch_energies()
@@ -162,7 +174,21 @@ def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
     t3 = time.perf_counter()
     clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2
     clock.setdefault("iterations", []).append(t3 - t0)
+    _note_layout_events(driver, clock)
     return recs
+
+
+def _note_layout_events(driver, clock):
+    """What the batch's layout cost in the iteration that just ended (NativeBatch.counters: re-plans of the layout shape, members
+    re-sorted at the 64-step polls, members laid out again, the seconds those took): a slow iteration names its cause."""
+    if driver is None or not hasattr(driver._ncmc_batch, "counters"):
+        return
+    now = driver._ncmc_batch.counters()
+    last = clock.get("_counters")
+    clock["_counters"] = now
+    if last is not None:
+        clock.setdefault("layout_events", []).append({k: (round(now[k] - last[k], 4) if k.endswith("seconds") else now[k] - last[k])
+                                                       for k in ("replans", "replan_seconds", "relayouts", "poll_resorts", "resort_seconds", "reshapes")})
 
 
 def one_iteration(driver, chains, nsteps, md_steps, it, clock):
@@ -195,6 +221,7 @@ def one_iteration(driver, chains, nsteps, md_steps, it, clock):
     t4 = time.perf_counter()
     clock["sync"] += t1 - t0; clock["switch"] += t2 - t1; clock["decide"] += t3 - t2; clock["md"] = clock.get("md", 0.0) + t4 - t3
     clock.setdefault("iterations", []).append(t4 - t0)
+    _note_layout_events(driver, clock)
     return recs
 
 
@@ -364,7 +391,7 @@ def main():
     ap.add_argument("--no-alch", action="store_true", help="with --md-steps: no `alch` Simulation (the correction's energies then come from the NCMC engine at lambda = 1)")
     ap.add_argument("--decorrelate", type=int, default=250, help="set-up: steps of its own trajectory every chain runs (own velocities, own noise) before its hand-over State is "
                     "taken, so that the timed switches start from as many different states as there are chains (1 ps by default)")
-    ap.add_argument("--setup-threads", type=int, default=None, help="host threads that create the chains (default min(16, cores) divided among the ranks of the host; 1 = one after the other)")
+    ap.add_argument("--setup-threads", type=int, default=None, help="host threads that create the chains (default: the cores this process may use divided among the ranks of the host, at most 16; 1 = one after the other)")
     ap.add_argument("--same-start", action="store_true", help="every chain starts every switch from the SAME coordinates and velocities (rounds 1-4)")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
@@ -424,8 +451,10 @@ def main():
     G0 = max(1, min(args.groups, R))
     # the chains are laid out from the start as members of the batch they are about to join (BluesTuning.assume_batch: the layout a
     # batch of that size gives its members anyway), so that forming the batch re-lays nobody out: set-up time, nothing else
-    if args.setup_threads is None:   # (the ranks of one host share its cores)
-        args.setup_threads = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    from blues_amd.replicas import host_thread_share, share_host_threads
+    host_threads = share_host_threads(world)   # (the ranks of one host share its cores: set-up threads here, re-sorts of several members inside the library)
+    if args.setup_threads is None:
+        args.setup_threads = host_threads
     with tuning.override(assume_batch=(R + G0 - 1) // G0):
         system, vel, chains = build_chains(rank, local_rank, nsteps, args.workload, R, reciprocal=args.reciprocal, md_steps=args.md_steps, with_alch=not args.no_alch, setup_threads=args.setup_threads)
     x0 = system.positions.copy()
@@ -500,8 +529,10 @@ def main():
         switch_all(w)      # on the main thread: every kernel variant has been launched once before threads start
     engs = [c._ncmc_sim.context._engine for c in chains]
     st0 = engs[0].stats(); b0 = [d._ncmc_batch.stats() for d in drivers]
-    for ck in clocks:
-        ck.update({"sync": 0.0, "switch": 0.0, "decide": 0.0, "md": 0.0, "iterations": []})
+    for ck, drv in zip(clocks, drivers):
+        ck.update({"sync": 0.0, "switch": 0.0, "decide": 0.0, "md": 0.0, "iterations": [], "layout_events": []})
+        if hasattr(drv._ncmc_batch, "counters"):
+            ck["_counters"] = drv._ncmc_batch.counters()
     # the nonbonded kernel is timed WHERE IT RUNS: every 4th force launch of the timed switches is bracketed by two HIP events on
     # the batch's stream (blues_batch_kernel_timing); that mean is roofline.usec_per_launch, what rocprofv3 averages for the same loop
     timing_batch = None if args.no_kernel_timing or not hasattr(drivers[0]._ncmc_batch, "kernel_timing") else drivers[0]._ncmc_batch
@@ -540,7 +571,9 @@ def main():
     elapsed = time.perf_counter() - t0
     st1 = engs[0].stats(); b1 = [d._ncmc_batch.stats() for d in drivers]
     iteration_seconds = [list(ck.get("iterations", [])) for ck in clocks]     # per batch, per timed iteration (with several batches: the turns it waited for included)
-    clock = {k: max(ck[k] for ck in clocks) for k in clocks[0] if k != "iterations"}
+    layout_events = [list(ck.get("layout_events", [])) for ck in clocks]       # per batch, per timed iteration
+    layout_now = [d._ncmc_batch.counters() if hasattr(d._ncmc_batch, "counters") else {} for d in drivers]
+    clock = {k: max(ck[k] for ck in clocks) for k in ("sync", "switch", "decide", "md") if k in clocks[0]}
     b0 = {k: sum(b[k] for b in b0) / G for k in b0[0]}; b1 = {k: sum(b[k] for b in b1) / G for k in b1[0]}
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if (world == 1 or args.backend == "nccl") else "cpu")
     tmin = t.clone()
@@ -646,7 +679,7 @@ def main():
             "dtype": "f32 pair math / f64 accumulation, f64 alchemical+integrator", "data": "synthetic",
             "data_note": ("every chain carries its own state from its own MD legs (the warm-up iterations included one)" if full else
                           "every chain starts every switch from the same coordinates and velocities (its Philox stream differs): rebuild statistics are those of the first 4 ps from one geometry" if (args.same_start or args.decorrelate <= 0) else
-                          "every chain starts its switches from its OWN state (%d steps of its own trajectory at set-up: own velocities, own noise); there is no MD leg between the timed switches (--md-steps adds it)" % args.decorrelate),
+                          "every chain starts its switches from its OWN state (%d steps of its own trajectory at set-up: own velocities, own noise, lambda <= %g throughout -- legs of %d steps with the integrator reset in between); there is no MD leg between the timed switches (--md-steps adds it)" % (args.decorrelate, DECORRELATE_LEG / float(nsteps), DECORRELATE_LEG)),
             "nonbonded_method": "PME direct space only" if system.nonbonded_method == 1 else "PME direct + reciprocal space (mesh %dx%dx%d, order %d), dispersion correction %s" % (tuple(system.pme_grid) + (system.pme_order, "on" if system.dispersion_correction else "off")),
             "config": {"workload": "S23k %s: %d atoms, %d mobile, %d alchemical, nstepsNC=%d, dt=4fs; %d independent chains per GPU in %d replica batch(es)"
                        % (args.workload, n_atoms, int((system.mass > 0).sum()), len(system.alchemical_atoms), nsteps, R, G),
@@ -663,7 +696,17 @@ def main():
             "process_group": {"backend": (args.backend if world > 1 else None), "same_device": bool(args.same_device),
                               "replica_seeds_first_chain_of_each_rank": [int(replica_seed(1234, r * R)) for r in range(world)]},
             "memory": memory_use(),
-            "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "iteration_seconds_by_batch": iteration_seconds, "setup_seconds": t_setup, "setup_seconds_by_part": setup_parts, "setup_threads": args.setup_threads,
+            "engine": {"seconds": {k: v / args.steps for k, v in clock.items()}, "iteration_seconds_by_batch": iteration_seconds,
+                       "iteration_seconds_max_over_median": max(max(it) / float(np.median(it)) for it in iteration_seconds if it) if any(iteration_seconds) else None,
+                       # what the batches' layouts cost inside the timed iterations (blues_batch_get_counters): totals over the batches, then per
+                       # batch and iteration wherever something happened -- a slow iteration names its cause
+                       "replans": sum(e["replans"] for ev in layout_events for e in ev), "replan_seconds": sum(e["replan_seconds"] for ev in layout_events for e in ev),
+                       "relayouts": sum(e["relayouts"] for ev in layout_events for e in ev), "reshapes": sum(e["reshapes"] for ev in layout_events for e in ev),
+                       "resorts": sum(e["poll_resorts"] for ev in layout_events for e in ev), "resort_seconds": sum(e["resort_seconds"] for ev in layout_events for e in ev),
+                       "layout_events_by_batch": [{str(k): e for k, e in enumerate(ev) if any(e.values())} for ev in layout_events],
+                       "layout_shape_by_batch": [{k: c.get(k) for k in ("tiles_per_list", "jcap", "nonbonded_kernel")} for c in layout_now],
+                       "host_threads": host_threads,
+                       "setup_seconds": t_setup, "setup_seconds_by_part": setup_parts, "setup_threads": args.setup_threads,
                        "plugin_boundary": ("one call per operation for all chains (blues_batch_*)" + ("" if drivers[0]._move_batchable() else "; the Move's hooks chain by chain")) if drivers[0]._batchable() else "chain by chain",
                        "force_passes_per_switch": (st1["force_passes"] - st0["force_passes"]) / args.steps,
                        "list_rebuilds_per_switch": (st1["list_generation"] - st0["list_generation"]) / args.steps,

@@ -9,13 +9,14 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 SWITCH_NONE, SWITCH_VV, SWITCH_GHMC = 0, 1, 2
 NB_NOCUTOFF = 0
 NB_PME_DIRECT = 1
 NB_PME = 2
 N_ENERGY_TERMS = 10
 N_STATS = 21
+N_BATCH_COUNTERS = 10
 ENERGY_TERM_NAMES = ("bonds", "angles", "torsions", "nonbonded", "exceptions", "alch_sterics",
                      "alch_electrostatics", "restraint", "reciprocal", "dispersion_correction")
 
@@ -69,7 +70,7 @@ class BluesTuning(C.Structure):
         ("fork", C.c_int32), ("use_graph", C.c_int32), ("graph_units", C.c_int32), ("graph_fork", C.c_int32),
         ("batch_sync_lists", C.c_int32), ("force_lists", C.c_int32), ("no_sphere", C.c_int32),
         ("pme_general", C.c_int32), ("debug_lists", C.c_int32), ("assume_batch", C.c_int32), ("k1_threads", C.c_int32),
-        ("k2_dense", C.c_int32), ("k2_early", C.c_int32), ("fuse_finalize", C.c_int32),
+        ("k2_dense", C.c_int32), ("k2_early", C.c_int32), ("fuse_finalize", C.c_int32), ("host_threads", C.c_int32),
     ]
 
 
@@ -280,6 +281,7 @@ def declare_engine_prototypes(lib):
         "blues_batch_reset": ([H, C.POINTER(C.c_int32)], C.c_int),
         "blues_batch_set_velocities_to_temperature": ([H, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)], C.c_int),
         "blues_batch_get_stats": ([H, C.POINTER(C.c_int64)], C.c_int),
+        "blues_batch_get_counters": ([H, _dp], C.c_int),
         "blues_batch_time_nonbonded": ([H, C.c_int32, _dp], C.c_int),
         "blues_batch_time_nonbonded_modes": ([H, C.c_int32, _dp, _dp], C.c_int),
         "blues_debug_setup_seconds": ([_dp], C.c_int),
@@ -305,6 +307,6 @@ ENGINE_SYMBOLS = (
     "blues_batch_create", "blues_batch_destroy", "blues_batch_last_error", "blues_batch_size", "blues_batch_step", "blues_batch_set_active", "blues_batch_prefetch_energies",
     "blues_batch_snapshot_capture", "blues_batch_restore", "blues_batch_restore_edited", "blues_batch_read_atoms", "blues_batch_reset",
     "blues_batch_set_velocities_to_temperature",
-    "blues_batch_get_stats", "blues_batch_time_nonbonded", "blues_batch_time_nonbonded_modes",
+    "blues_batch_get_stats", "blues_batch_get_counters", "blues_batch_time_nonbonded", "blues_batch_time_nonbonded_modes",
     "blues_batch_kernel_timing", "blues_batch_get_kernel_timing", "blues_debug_setup_seconds",
 )

@@ -50,6 +50,8 @@ static BluesTuning g_tuning = [] { BluesTuning t; blues_tuning_default(&t); retu
 
 // workgroups of the kernels of a batch that run from the rebuild's work list (kernels_batch.h: k_gather_stale_b): two per CU
 static const int REBUILD_GRID = 512;
+static const int SHAPE_CAND[9] = {1, 2, 3, 4, 5, 6, 8, 12, 16};   // tiles per group list the per-atom-list layout chooses from
+static inline int shape_index(int S) { for (int q = 0; q < 9; q++) if (SHAPE_CAND[q] == S) return q; return -1; }
 
 template <typename T> struct DBuf {
     T* p = nullptr; size_t n = 0;
@@ -186,7 +188,7 @@ struct BluesEngine {
     // the sums of the last force pass are still to be formed (launch_finalize_deferred): by the step kernel itself if the next
     // program is the steady-state one, by k_finalize otherwise
     bool fin_pending = false; double fin_le[3] = {0, 0, 0}; int fin_mask = 7;
-    bool have_positions = false, sorted_ok = false, lists_forced = true;
+    bool have_positions = false, sorted_ok = false, lists_forced = true, relayout_failed = false;
     std::vector<double> hx;        // host copy of the positions the tiles were last laid out from (caller order, [n][3])
     std::vector<double> h_stage;   // staging for host transfers
     std::vector<double> hx_sort;   // positions at the last sort
@@ -223,6 +225,11 @@ struct BluesEngine {
     // everybody when some member's list outgrows it (shape_overflow)
     int hint_count = 0;   // list length that raises resort_hint
     int shape_S = 0, shape_jcap = 0; bool shape_overflow = false, forbid_atom = false; double shape_need = 0.0;
+    // what every candidate shape would need with the atoms where the last sort found them (sort_and_tile; SHAPE_CAND): the expected
+    // length of the longest group list, the radius of the widest group.  A batch plans its shape from its members' tables and moves
+    // everybody to it WITHOUT a new sort (reshape_groups): the sorted order, the image and the tiles do not depend on S
+    double need_by_S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rad_by_S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; bool need_table_ok = false;
+    int lists_alloc = 0;   // group lists the per-atom-list buffers have room for (mode 2: one per i-tile, the finest shape)
     int layout_R = 0;   // the batch size (batch_R) the current layout was derived for (sort_and_tile)
     // a member of a batch whose layout is sized from the density (tile / sub-tile kernels): the capacities the batch agreed on, kept while
     // they hold this member's lists -- a MonteCarloBarostat leaves every member in its own box, and a capacity re-derived from n / V
@@ -269,7 +276,7 @@ struct BluesEngine {
     // pending integrate program
     Program prog; unsigned prog_draw_base = 0; int prog_trace = -1; bool tracing = false;
     // stats
-    int64_t st_passes = 0, st_launches = 0, st_resorts = 0, st_energy_evals = 0;
+    int64_t st_passes = 0, st_launches = 0, st_resorts = 0, st_energy_evals = 0, st_reshapes = 0;
     std::vector<int> h_sorted_of_orig, h_orig_of_sorted;
 
     ~BluesEngine() {
@@ -315,7 +322,7 @@ struct BluesBatch {
     // each member's pending work and the members issue into it; leave: the batch stream is drained, members go home.
     hipStream_t stream = nullptr; bool entered = false;
     DBuf<double> d_gather; int64_t st_prefetch_pe = 0, st_prefetch_ke = 0;
-    int64_t st_lockstep_steps = 0, st_fallback_steps = 0, st_replans = 0;
+    int64_t st_lockstep_steps = 0, st_fallback_steps = 0, st_replans = 0, st_relayouts = 0, st_poll_resorts = 0; double st_replan_sec = 0.0, st_resort_sec = 0.0;   // (blues_batch_get_counters)
     // in-situ timing of the nonbonded force kernel (blues_batch_kernel_timing): every `k1t_every`-th lock-step force launch of the
     // stepping loop is bracketed by two events on the stream it runs on; finished pairs are harvested lazily (no synchronisation)
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; bool busy = false; };
@@ -790,7 +797,7 @@ static int sort_and_tile(BluesEngine* h) {
         // (nonbonded_atom_body).  S consecutive i-tiles share one list / one image; S and the list capacity come from the
         // geometry: the list holds what lies within cutoff+skin of the group's bounding sphere.
         h->k1_mode = h->k1_iw != 64 ? 1 : 0;
-        h->S = 1; h->acap = 0;
+        h->S = 1; h->acap = 0; h->need_table_ok = false;
         bool want_atom = h->k1_mode == 1;
         if (h->tune.k1_mode == 1) want_atom = false;
         if (h->forbid_atom) want_atom = false;
@@ -824,6 +831,12 @@ static int sort_and_tile(BluesEngine* h) {
             const int lds_max = 6400;     // list entries whose image (24 B each) fits the 160 KB of LDS beside the kernel's statics
             double best_cost = 1e300; int best_S = 0, best_cap = 0;
             h->shape_overflow = false;
+            for (int q = 0; q < 9; q++) {
+                const int S = SHAPE_CAND[q];
+                if (S > 1 && S > h->n_itiles) { h->need_by_S[q] = 1e30; h->rad_by_S[q] = 1e30; continue; }
+                h->need_by_S[q] = group_est(S); h->rad_by_S[q] = est_rad;
+            }
+            h->need_table_ok = true;
             if (h->shape_S > 0) {   // member of a batch: the batch's shape, as long as this member's lists fit it
                 best_S = std::min(h->shape_S, std::max(1, h->n_itiles)); best_cap = h->shape_jcap;
                 h->shape_need = group_est(best_S);
@@ -951,8 +964,12 @@ static int sort_and_tile(BluesEngine* h) {
           for (size_t a2 = 0; a2 < h->alch.size(); a2++) { AlchARec& r = ar[a2]; const int ao = h->alch[a2]; r.ao = ao; r.asrt = h->h_sorted_of_orig[ao]; r.pad = 0; r.sig = h->sigma[ao]; r.eps = std::sqrt(h->eps[ao]); r.q = h->charge[ao];   // (eps: its square root, see AlchARec)
             r.has_env_excl = 0; for (int p2 : h->excl[ao]) if (h->alch_local[p2] < 0) r.has_env_excl = 1; }
           h->d_arec.upload(ar); }
-        h->d_jlist.alloc((size_t)nt * jcap); h->d_jstage.alloc((size_t)nt * LIST_WAVES * ((((n + LIST_WAVES - 1) / LIST_WAVES) + 63) & ~63)); h->d_jcount.alloc(nt); h->d_batch_slot.alloc((size_t)nt * (jcap / 64));
-        h->d_mask_pool.alloc((size_t)h->pool_cap * 64);
+        // (per-atom lists: room for one group list per i-tile, so that a batch can move its members to a finer shape -- fewer tiles per
+        // list -- without laying anybody out again: reshape_groups; 1.5 MB per member of the benchmark system)
+        h->lists_alloc = h->k1_mode == 2 ? std::max(1, h->n_itiles) : 0;
+        const int nt_alloc = h->k1_mode == 2 ? h->lists_alloc + 1 : nt;
+        h->d_jlist.alloc((size_t)nt_alloc * jcap); h->d_jstage.alloc((size_t)nt_alloc * LIST_WAVES * ((((n + LIST_WAVES - 1) / LIST_WAVES) + 63) & ~63)); h->d_jcount.alloc(nt_alloc); h->d_batch_slot.alloc((size_t)nt_alloc * (jcap / 64));
+        h->d_mask_pool.alloc((size_t)nt_alloc * MASK_QUOTA * 64);
         h->d_fpart.alloc((size_t)h->npart * 3 * h->n_islots);
         if (h->k1_mode == 2) {
             h->d_alist.alloc((size_t)h->n_islots * h->acap); h->d_acount.alloc(h->n_islots); h->d_aself.alloc(h->n_islots);
@@ -977,8 +994,8 @@ static int sort_and_tile(BluesEngine* h) {
             // packed group images: what the builder of the atoms' lists streams its candidates from (always), and what the nonbonded
             // kernel stages its LDS image from where most list entries are frozen atoms (the same condition as the pruned lists)
             h->mcap = std::min(jcap, (((int)h->mobile.size() + 63) / 64) * 64);
-            h->d_pimg4.alloc((size_t)std::max(1, h->n_lists) * jcap); h->d_pimg2.alloc((size_t)std::max(1, h->n_lists) * jcap); h->d_pimgb.alloc((size_t)std::max(1, h->n_lists) * jcap);
-            h->d_mlist.alloc((size_t)std::max(1, h->n_lists) * h->mcap * 2); h->d_mcount.alloc(std::max(1, h->n_lists));
+            h->d_pimg4.alloc((size_t)h->lists_alloc * jcap); h->d_pimg2.alloc((size_t)h->lists_alloc * jcap); h->d_pimgb.alloc((size_t)h->lists_alloc * jcap);
+            h->d_mlist.alloc((size_t)h->lists_alloc * h->mcap * 2); h->d_mcount.alloc(h->lists_alloc);
         }
         if (h->k1_mode == 3) {
             // fragment layout of this sort: the fragments in image order, capacities from the fragment density
@@ -1990,9 +2007,11 @@ static int poll_resort_due(BluesEngine* h) {
 #define RESORT_AGE 4096
 static bool resort_by_age(const BluesEngine* h) { return h->k1_mode == 3 && h->sorted_ok && 2 * h->mobile.size() > (size_t)h->n && h->steps_since_sort >= RESORT_AGE; }
 static int poll_resort(BluesEngine* h) {
-    if (resort_by_age(h)) { h->st_resorts++; return relayout(h); }
-    const int due = poll_resort_due(h);
-    return due < 0 ? 1 : (due ? relayout(h) : 0);
+    const bool aged = resort_by_age(h);
+    const int due = poll_resort_due(h);   // (clears a pending hint and gives the lists more room where they ask: also when the age brings the re-sort anyway)
+    if (due < 0) return 1;
+    if (aged && !due) h->st_resorts++;
+    return (aged || due) ? relayout(h) : 0;
 }
 
 // launch geometry of an energy evaluation (partials per kind)
@@ -2735,15 +2754,21 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
                     std::vector<BluesEngine*> todo;
                     for (int r = 0; r < R; r++)
                         if (!B->failed[r] && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0) {
-                            if (resort_by_age(B->eng[r])) { B->eng[r]->st_resorts++; todo.push_back(B->eng[r]); continue; }
-                            if (!(hints[r] & 1)) continue;
+                            const bool aged = resort_by_age(B->eng[r]);
+                            if (!aged && !(hints[r] & 1)) continue;
+                            // (a member that is due by age may have a hint pending as well: it is cleared -- and the lists given more room
+                            // where they ask for it -- here, or the builder's request would cost a second re-sort 64 steps later)
                             const int due = poll_resort_due(B->eng[r]);
-                            if (due < 0) fail(r); else if (due) todo.push_back(B->eng[r]);
+                            if (due < 0) { fail(r); continue; }
+                            if (aged && !due) B->eng[r]->st_resorts++;
+                            if (aged || due) todo.push_back(B->eng[r]);
                         }
-                    if (todo.size() == 1) { if (relayout(todo[0])) fail(todo[0]->batch_index); }
-                    else if (!todo.empty()) {
+                    if (!todo.empty()) {
+                        const auto t_rs = std::chrono::steady_clock::now();
                         relayout_many(todo, [](BluesEngine*) { return true; });
-                        for (BluesEngine* m : todo) if (!m->sorted_ok) fail(m->batch_index);
+                        for (BluesEngine* m : todo) if (m->relayout_failed) fail(m->batch_index);
+                        B->st_poll_resorts += (int64_t)todo.size();
+                        B->st_resort_sec += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rs).count();
                     }
                 }
                 {   // a member whose lists have outgrown the batch's layout shape: a new shape for everybody (rare)
@@ -2961,76 +2986,144 @@ static int relayout(BluesEngine* h) {
 // A new layout for MANY members of a batch at once (a new shape for everybody: 5-10 ms of host work per member -- sort, exclusion rows,
 // image, uploads -- i.e. 8 s for 1024 members one after the other, in the middle of a switch): the members are independent, so the
 // host's cores share them.  prepare(m) sets what the new layout is to follow (shape, forbid_atom) and says whether m needs one.
-static BluesEngine* relayout_many(const std::vector<BluesEngine*>& members, const std::function<bool(BluesEngine*)>& prepare) {
-    std::vector<BluesEngine*> todo;
-    for (BluesEngine* m : members) if (prepare(m)) todo.push_back(m);
-    if (todo.empty()) return nullptr;
+// Host threads for work the members of a batch (or the chains of a rank at set-up) share: the cores this process may use, at most 16,
+// or BluesTuning.host_threads where the caller knows better (N ranks on one host: cores / N -- blues_amd/replicas.py sets it).
+static unsigned host_pool_threads(size_t items) {
     unsigned nthr = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
 #if defined(__linux__)
     { cpu_set_t set; CPU_ZERO(&set); if (sched_getaffinity(0, sizeof set, &set) == 0) nthr = std::min<unsigned>(nthr, (unsigned)std::max(1, CPU_COUNT(&set))); }
 #endif
-    nthr = (unsigned)std::min<size_t>(nthr, todo.size());
-    std::atomic<size_t> next{0}; std::atomic<BluesEngine*> failed{nullptr};
+    if (g_tuning.host_threads > 0) nthr = (unsigned)g_tuning.host_threads;
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(nthr, items));
+}
+// Returns the first member whose re-layout failed (its err says why; relayout_failed is set on every such member), or null.  A
+// failure of one member does not keep the others from their turn.
+static BluesEngine* relayout_many(const std::vector<BluesEngine*>& members, const std::function<bool(BluesEngine*)>& prepare) {
+    std::vector<BluesEngine*> todo;
+    for (BluesEngine* m : members) { m->relayout_failed = false; if (prepare(m)) todo.push_back(m); }
+    if (todo.empty()) return nullptr;
+    const unsigned nthr = host_pool_threads(todo.size());
+    std::atomic<size_t> next{0};
     auto work = [&]() {
         hipSetDevice(todo[0]->device);
         for (;;) {
             const size_t i = next.fetch_add(1);
-            if (i >= todo.size() || failed.load()) return;
-            if (relayout(todo[i])) failed.store(todo[i]);
+            if (i >= todo.size()) return;
+            if (relayout(todo[i])) { todo[i]->relayout_failed = true; todo[i]->sorted_ok = false; }
         }
     };
     if (nthr <= 1) work();
     else { std::vector<std::thread> pool; for (unsigned t = 0; t < nthr; t++) pool.emplace_back(work); for (auto& t : pool) t.join(); }
-    return failed.load();
+    for (BluesEngine* m : todo) if (m->relayout_failed) return m;
+    return nullptr;
+}
+
+// A member of a batch moves to another number of tiles per group list WITHOUT a new sort: the sorted order, the image, the tiles, the
+// exclusion rows and every per-slot table are independent of S; what changes is how many group lists there are and which tiles share
+// one -- the device rebuilds them at the next force pass (lists_forced).  Possible where the buffers have room for the new number of
+// lists (sort_and_tile allocates for the finest shape) and the capacity stays what it is.  Returns false if the member needs a full
+// re-layout instead (relayout under shape_S / shape_jcap).
+static bool reshape_possible(const BluesEngine* h, int S, int cap) {
+    if (!h->sorted_ok || h->k1_mode != 2 || h->jcap != cap || !h->need_table_ok || h->forbid_atom) return false;
+    const int nl = (std::max(1, h->n_itiles) + S - 1) / S;
+    return nl <= h->lists_alloc && shape_index(S) >= 0;
+}
+static int reshape_groups(BluesEngine* h, int S, int cap) {
+    const int q = shape_index(S);
+    h->shape_S = S; h->shape_jcap = cap;
+    h->shape_need = q >= 0 ? h->need_by_S[q] : 0.0;
+    h->shape_overflow = h->shape_need * 1.1 + 64 > cap;
+    S = std::min(S, std::max(1, h->n_itiles));
+    if (h->S == S) return 0;   // (it has the shape already: only takes note of it)
+    if (flush_program(h)) return 1;
+    h->fin_pending = false;    // (the sums of a pass over the old lists are dropped with the pass)
+    h->S = S;
+    h->n_lists = (std::max(1, h->n_itiles) + S - 1) / S;
+    h->n_tiles = h->n_lists + (h->alch.empty() ? 0 : 1);
+    h->pool_cap = std::max(1, h->n_tiles) * MASK_QUOTA;
+    h->lists_forced = true; h->pass_valid = false; h->graph_valid = false;
+    h->args_epoch++;
+    h->st_reshapes++;
+    return 0;
 }
 
 // One layout shape for all members of a batch in the per-atom-list mode (k1_mode 2), where the number of tiles per list and the
 // list capacity follow from the geometry: the leader's S (or the next smaller one whose lists fit the LDS), and a capacity
 // that holds the largest member's lists with room for the i-atoms to spread.  fresh: start from the members' own choices.
+// Round 6: the shape is PLANNED from the members' own tables (need_by_S: what each candidate shape would need where the member's last
+// sort found its atoms) and the members move to it without a new sort (reshape_groups) -- a re-plan in the middle of a switch used to
+// re-lay every member out up to three times (10 ms of host work each: 3 s for a batch of 1024 with the device idle and, with several
+// batches taking turns, the other batches waiting); now it costs a few microseconds per member and one forced list build.
 static int batch_plan_shape(BluesBatch* B, bool fresh) {
     if (B->eng.empty()) return 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct Clock { BluesBatch* B; std::chrono::steady_clock::time_point t0; ~Clock() { B->st_replan_sec += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } clock{B, t_begin};
     auto fail = [&](BluesEngine* m) { B->err = "re-layout for the batch failed: " + m->err; return 1; };
+    auto relayout_counted = [&](const std::function<bool(BluesEngine*)>& prepare) -> BluesEngine* {
+        return relayout_many(B->eng, [&](BluesEngine* m) { const bool need = prepare(m); if (need) B->st_relayouts++; return need; });
+    };
     if (fresh) for (BluesEngine* m : B->eng) {
         // (a member that was already laid out on its own for a batch of this size -- BluesTuning.assume_batch -- keeps its layout:
         // re-deriving it would give the same one, 10 ms of host work per member)
         const bool same = m->sorted_ok && m->layout_R == m->batch_R && m->shape_S == 0 && !m->forbid_atom;
         m->shape_S = 0; m->shape_jcap = 0; m->forbid_atom = false;
-        if (!same && relayout(m)) return fail(m);
+        if (!same) { B->st_relayouts++; if (relayout(m)) return fail(m); }
     }
     BluesEngine* lead = B->eng[0];
     if (lead->k1_mode != 2) {   // the other modes size everything from the topology or the density: congruent by construction
         // (a re-plan in the middle of a run finds the leader here when ITS tiles fit no shape any more -- scattered mobile atoms: it is in
         // the sub-tile layout for want of a shape, and everybody, the leader included, moves on to fragment lists)
-        if (BluesEngine* bad = relayout_many(B->eng, [&](BluesEngine* m) {
+        if (BluesEngine* bad = relayout_counted([&](BluesEngine* m) {
                 const bool need = m->k1_mode == 2 || (!fresh && !m->forbid_atom && m->k1_mode != 3);
                 if (need) m->forbid_atom = true;   // (members that stay as they are keep their flags: their next re-sort must give the same mode again)
                 return need; })) return fail(bad);
         return 0;
     }
-    const int lds_max = 6400;
-    static const int cand[] = {16, 12, 8, 6, 5, 4, 3, 2, 1};
+    const int lds_max = NB_JCAP_MAX;
+    const double longest = std::max(lead->box[0], std::max(lead->box[1], lead->box[2]));
     int S = lead->S;
-    for (;;) {
-        if (BluesEngine* bad = relayout_many(B->eng, [&](BluesEngine* m) { if (m->k1_mode == 2 && m->S == S) return false; m->shape_S = S; m->shape_jcap = lds_max; return true; })) return fail(bad);
-        double need = 0.0;
-        for (BluesEngine* m : B->eng) need = std::max(need, m->shape_need);
-        const int cap = need * 1.3 + 64 <= 3328 ? 3328 : (need * 1.3 + 64 <= lds_max ? lds_max : lds_max + 64);   // the two capacities of sort_and_tile
-        if (cap <= lds_max) {
-            // (a member whose own layout already has the batch's shape only takes note of it: a re-layout under shape (S, cap) gives what it has)
-            if (BluesEngine* bad = relayout_many(B->eng, [&](BluesEngine* m) {
-                    const bool has_it = m->k1_mode == 2 && m->S == S && m->jcap == cap && !m->shape_overflow && m->shape_need * 1.1 + 64 <= cap;
-                    m->shape_S = S; m->shape_jcap = cap;
-                    return !has_it; })) return fail(bad);
+    for (int round = 0; round < 12; round++) {
+        // the coarsest shape, from S downwards, that holds every member's lists with room to spread (factor 1.3, as a lone engine
+        // chooses its own) -- from the members' tables; a member without one (another mode: it joined from a different layout) is laid
+        // out under the candidate shape first
+        int pick = 0, cap = 0;
+        for (int q = 8; q >= 0 && !pick; q--) {
+            const int c = SHAPE_CAND[q];
+            if (c > S) continue;
+            double need = 0.0, rad = 0.0; bool known = true;
+            for (BluesEngine* m : B->eng) { if (!m->need_table_ok || m->k1_mode != 2) { known = false; continue; } need = std::max(need, m->need_by_S[q]); rad = std::max(rad, m->rad_by_S[q]); }
+            if (!known && need == 0.0) { pick = c; cap = lds_max; break; }   // (nobody has a table yet: the sweep below produces them)
+            if (2.0 * rad + 1.0 + 0.6 >= longest) continue;                 // (the ghost record's place: sort_and_tile)
+            if (need * 1.3 + 64 > lds_max) continue;
+            pick = c; cap = need * 1.3 + 64 <= 3328 ? 3328 : lds_max;      // the two capacities of sort_and_tile
+        }
+        if (!pick) {   // not even one tile per list fits: fragment lists (or the bitmask kernels) for everybody
+            if (BluesEngine* bad = relayout_counted([](BluesEngine* m) { m->forbid_atom = true; m->shape_S = 0; m->shape_jcap = 0; return true; })) return fail(bad);
             return 0;
         }
+        // members that can take the shape as they are move to it in place; the others (another capacity, another mode, no layout)
+        // are laid out under it, on the host's cores
+        if (BluesEngine* bad = relayout_counted([&](BluesEngine* m) {
+                if (reshape_possible(m, pick, cap)) return false;
+                m->shape_S = pick; m->shape_jcap = cap; return true; })) return fail(bad);
+        bool again = false;
+        for (BluesEngine* m : B->eng) {
+            if (m->k1_mode != 2) { again = true; continue; }            // (its own geometry fits no group shape under this S: a finer one)
+            if (m->S != pick || m->shape_S != pick || m->shape_jcap != cap) { if (reshape_groups(m, pick, cap)) return fail(m); }
+            again |= m->shape_overflow || m->jcap != cap;
+        }
+        if (!again) return 0;
+        // somebody's lists do not fit after all (a table older than its atoms' spread, or the quantised capacity): the next finer shape
         int next = 0;
-        for (int c : cand) if (c < S) { next = c; break; }
-        if (!next) {   // not even one tile per list fits: fragment lists (or the bitmask kernels) for everybody
-            if (BluesEngine* bad = relayout_many(B->eng, [](BluesEngine* m) { m->forbid_atom = true; m->shape_S = 0; m->shape_jcap = 0; return true; })) return fail(bad);
+        for (int q = 8; q >= 0; q--) if (SHAPE_CAND[q] < pick) { next = SHAPE_CAND[q]; break; }
+        if (!next) {
+            if (BluesEngine* bad = relayout_counted([](BluesEngine* m) { m->forbid_atom = true; m->shape_S = 0; m->shape_jcap = 0; return true; })) return fail(bad);
             return 0;
         }
         S = next;
     }
+    B->err = "internal: the batch's layout shape did not settle";
+    return 1;
 }
 
 static void batch_detach_all(BluesBatch* B) {
@@ -3392,7 +3485,7 @@ int blues_reset(BluesEngine* h) {
 int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
     for (int i = 0; i < BLUES_N_STATS; i++) stats[i] = 0;
     stats[9] = h->st_resorts; stats[11] = h->st_energy_evals;
-    if (h->d_jcount.p && h->sorted_ok) { std::vector<int> jc; hipSetDevice(h->device); hipStreamSynchronize(h->stream); try { h->d_jcount.download(jc); for (int c : jc) stats[8] = std::max<int64_t>(stats[8], c); } catch (std::string&) {} }
+    if (h->d_jcount.p && h->sorted_ok) { std::vector<int> jc; hipSetDevice(h->device); hipStreamSynchronize(h->stream); try { h->d_jcount.download(jc); for (int q = 0; q < (int)jc.size() && q < std::max(1, h->n_tiles); q++) stats[8] = std::max<int64_t>(stats[8], jc[q]); } catch (std::string&) {} }
     if (h->tune.debug_lists && h->k1_mode == 2 && h->d_acount.p) {
         std::vector<int> ac; h->d_acount.download(ac); std::vector<int> jc2; h->d_jcount.download(jc2);
         fprintf(stderr, "[lists] S=%d n_lists=%d jcap=%d acap=%d jcount:", h->S, h->n_lists, h->jcap, h->acap); for (int c : jc2) fprintf(stderr, " %d", c);
@@ -3764,6 +3857,15 @@ int blues_batch_prefetch_energies(BluesBatch* b, int32_t what) {
     if (hipSetDevice(b->eng[0]->device) != hipSuccess) { b->err = "hipSetDevice failed"; return 1; }
     b->failed.assign(b->R(), 0);
     return batch_prefetch(b, what);
+}
+
+int blues_batch_get_counters(BluesBatch* b, double out[BLUES_N_BATCH_COUNTERS]) {
+    if (!b || !out) return 2;
+    for (int q = 0; q < BLUES_N_BATCH_COUNTERS; q++) out[q] = 0.0;
+    out[0] = (double)b->st_replans; out[1] = b->st_replan_sec; out[2] = (double)b->st_relayouts; out[3] = (double)b->st_poll_resorts; out[4] = b->st_resort_sec;
+    for (const BluesEngine* m : b->eng) { out[5] += (double)m->st_reshapes; out[6] += (double)m->st_resorts; }
+    if (!b->eng.empty()) { out[7] = (double)b->eng[0]->S; out[8] = (double)b->eng[0]->jcap; out[9] = (double)b->eng[0]->k1_mode; }
+    return 0;
 }
 
 int blues_batch_get_stats(BluesBatch* b, int64_t stats[4]) {

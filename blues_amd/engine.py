@@ -359,6 +359,17 @@ class NativeBatch:
         self._lib.blues_batch_get_stats(self._h, s)
         return {"lockstep_steps": s[0], "fallback_steps": s[1], "replicas": s[2], "batched_energy_evaluations": s[3]}
 
+    COUNTERS = ("replans", "replan_seconds", "relayouts", "poll_resorts", "resort_seconds", "reshapes", "resorts", "tiles_per_list", "jcap", "nonbonded_kernel")
+
+    def counters(self):
+        """What the batch's layout has cost so far (include/blues_engine.h: blues_batch_get_counters): re-plans of the layout shape and
+        the seconds they took, members laid out again from a new sort, members re-sorted at the 64-step polls and the seconds that took,
+        members moved to another shape in place; the shape now."""
+        o = (C.c_double * _abi.N_BATCH_COUNTERS)()
+        if self._lib.blues_batch_get_counters(self._h, o):
+            raise EngineError(self._lib.blues_batch_last_error(self._h).decode())
+        return {k: (float(o[i]) if k.endswith("seconds") else int(o[i])) for i, k in enumerate(self.COUNTERS)}
+
     def time_nonbonded(self, reps=20):
         u = C.c_double()
         if self._lib.blues_batch_time_nonbonded(self._h, int(reps), C.byref(u)):

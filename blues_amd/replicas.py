@@ -35,6 +35,29 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
+def host_thread_share(world=None, cap=16):
+    """Host threads a rank may use for work its chains share (set-up on host threads, re-sorts of several batch members at a poll): the
+    cores this process may run on, divided among the ranks of the host, at most `cap`.  N ranks on one node must not each start 16
+    threads on a 16-core quota (one process per GPU, host-side work included)."""
+    if world is None:
+        world = env_rank()[2]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    # (local ranks: the launcher exports LOCAL_WORLD_SIZE; without it every rank is assumed to be on this host)
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", world) or world)
+    return max(1, min(int(cap), cores // max(1, local)))
+
+
+def share_host_threads(world=None):
+    """Tells the native library this rank's share of the host's cores (BluesTuning.host_threads); returns it."""
+    from . import tuning
+    n = host_thread_share(world)
+    tuning.set(host_threads=n)
+    return n
+
+
 def replica_seed(base_seed, rank):
     """Distinct, reproducible Philox keys per replica."""
     return (int(base_seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
@@ -44,10 +67,9 @@ def build_in_parallel(make, count, workers=None):
     """[make(0), ..., make(count - 1)] with the calls spread over host threads.  Creating a chain is mostly native host work (the
     engine derives exclusion tables, constraint clusters, fragments and the first sorted layout: 6-8 ms per 23k-atom chain; the ctypes
     call releases the interpreter lock), so the 2048 chains of a GPU are ready in a fraction of the serial time.  Order is kept;
-    the first exception is re-raised.  workers: default min(16, host cores); 1 = the plain loop."""
-    import os
+    the first exception is re-raised.  workers: default this rank's share of the host's cores (host_thread_share); 1 = the plain loop."""
     if workers is None:
-        workers = min(16, os.cpu_count() or 1)
+        workers = host_thread_share()
     if workers <= 1 or count <= 1:
         return [make(i) for i in range(count)]
     from concurrent.futures import ThreadPoolExecutor

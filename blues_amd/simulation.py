@@ -296,7 +296,11 @@ class BatchedBLUESSimulation(object):
         that blew up (blues/simulation.py:1096 is outside the try), sys.exit(1) after an MD-leg exception (:1203-1213) -- takes nobody
         with it.  True gives the chains of a batch the same independence on the batched path: the chain is logged and retired (`dead`:
         {chain index: the exception}), sits every later operation out, and the others carry on with the results they would have had
-        anyway (chains share launches, never data).  False (default): the first such failure ends the run, as ONE reference process ends."""
+        anyway (chains share launches, never data; every chain that still draws from numpy's global stream is given a private RandomState
+        here, seeded from it in chain order, so that a retired chain's missing draws shift nobody's numbers).  Covered: the State reads at
+        the head of the iteration and after the switch, the `alch` energy of the correction, the MD energy check after a rejection, the MD
+        leg; on the chain-by-chain path (reporters on the NCMC leg, batched_boundary=False) a retired chain is skipped by every per-chain
+        operation.  False (default): the first such failure ends the run, as ONE reference process ends."""
         from .engine import NativeBatch
         self.isolate_failures = bool(isolate_failures)
         self.dead = {}
@@ -308,6 +312,12 @@ class BatchedBLUESSimulation(object):
         if workers and workers > 1 and len(self.chains) > 1:
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=min(int(workers), len(self.chains)))
+            for c in self.chains:
+                if c._rng is np.random:
+                    c._rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1))
+        if self.isolate_failures:
+            # "the others carry on with the results they would have had anyway" needs every chain on a stream of its own: chains that share
+            # numpy's global stream (rng=None, the reference's default) would see shifted uniforms after a retired chain's skipped draws
             for c in self.chains:
                 if c._rng is np.random:
                     c._rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1))
@@ -338,6 +348,8 @@ class BatchedBLUESSimulation(object):
     def for_each_chain(self, fn, indices=None):
         """[fn(r, chain) for the given chains] -- on the pool when there is one."""
         idx = list(range(len(self.chains))) if indices is None else list(indices)
+        if self.dead:      # (a retired chain sits every per-chain operation out, on the chain-by-chain path as on the batched one)
+            idx = [r for r in idx if r not in self.dead]
         if self._pool is None or len(idx) < 2:
             return [fn(r, self.chains[r]) for r in idx]
         return list(self._pool.map(lambda r: fn(r, self.chains[r]), idx))
@@ -559,10 +571,20 @@ class BatchedBLUESSimulation(object):
             ends = [c.stateTable['ncmc']['state1'] if alive[r] else None for r, c in enumerate(chains)]
             self._restore_states(ends, velocities=False, leg="alch")
             self._alch_batch.prefetch_energies(kinetic=False, active=alive if self.dead else None)
-            unmodified = [c._alch_sim.context.getState(getEnergy=True).getPotentialEnergy() if alive[r] else None for r, c in enumerate(chains)]
+            for r, c in enumerate(chains):
+                if not alive[r]:
+                    continue
+                try:
+                    unmodified[r] = c._alch_sim.context.getState(getEnergy=True).getPotentialEnergy()
+                except Exception as e:       # (the switched coordinates cannot be evaluated: that chain's process would end here)
+                    if not self.isolate_failures:
+                        raise
+                    self._retire(r, e, "the alch energy of the correction")
+                    alive[r] = False
         restore = []
         for r, c in enumerate(chains):
             if not alive[r]:
+                c._rng.random_sample()      # (its own stream under isolate_failures: drawn for symmetry with the seed of _reset_batched)
                 restore.append(None)
                 continue
             todo = record_decision(c, metropolis(c, unmodified[r]))
@@ -571,13 +593,25 @@ class BatchedBLUESSimulation(object):
             self._restore_states(restore)            # a rejection restores the pre-switch state in place
             return
         self._restore_states(restore, velocities=False, leg="md")     # accepted: the switched configuration becomes the MD state
-        for r, (c, st) in enumerate(zip(chains, restore)):
-            if st is None and alive[r]:      # rejected: the MD context must still be where the iteration started (the reference's sanity check)
-                before = c.stateTable['md']['state0']['potential_energy']
+        # rejected: the MD context must still be where the iteration started (the reference's sanity check, simulation.py:1156-1166):
+        # the energies of all such chains in one evaluation, the comparisons on host numbers
+        rejected = [st is None and alive[r] for r, st in enumerate(restore)]
+        if any(rejected):
+            self._md_batch.prefetch_energies(kinetic=False, active=rejected)
+        for r, c in enumerate(chains):
+            if not rejected[r]:
+                continue
+            before = c.stateTable['md']['state0']['potential_energy']
+            try:
                 now = c._md_sim.context.getState(getEnergy=True).getPotentialEnergy()
-                if not math.isclose(before._value, now._value, rel_tol=10.0 ** -rtol):
-                    logger.error('Last MD potential energy %s != Current MD potential energy %s. Potential energy should match the prior state.' % (before, now))
-                    sys.exit(1)
+            except Exception as e:
+                if not self.isolate_failures:
+                    raise
+                self._retire(r, e, "the MD energy check after a rejection")
+                continue
+            if not math.isclose(before._value, now._value, rel_tol=10.0 ** -rtol):
+                logger.error('Last MD potential energy %s != Current MD potential energy %s. Potential energy should match the prior state.' % (before, now))
+                sys.exit(1)
 
     def _reset_batched(self, temperature):
         """_resetSimulations of every chain (reference blues/simulation.py:1168-1187): one reset, one velocity redraw (of the MD
@@ -602,14 +636,22 @@ class BatchedBLUESSimulation(object):
         alive = self._alive() if self.dead else None
         if self._md_batch is not None:
             self._md_batch.prefetch_energies(active=alive)
-            states = self._capture_states(active=alive, leg="md")
-            for c, st in zip(self.chains, states):
-                if st is not None:
+            # (an MD context that blew up without raising in its leg raises HERE, when its State is read: under isolate_failures that
+            # chain is retired like one whose leg raised, reference blues/simulation.py:1203-1213 -- and does not end the batch)
+            states = self._capture_states(active=alive, leg="md", tolerate=self.isolate_failures)
+            for r, (c, st) in enumerate(zip(self.chains, states)):
+                if isinstance(st, Exception):
+                    self._retire(r, st, "reading the MD State at the head of the iteration")
+                    states[r] = None
+                elif st is not None:
                     c._setStateTable('md', 'state0', st)
             self._restore_states(states, velocities=True, leg="ncmc")
             return
         self._ncmc_batch.prefetch_energies(at_lambda_one=True, active=alive)
-        for c, st in zip(self.chains, self._capture_states(active=alive)):
+        for r, (c, st) in enumerate(zip(self.chains, self._capture_states(active=alive, tolerate=self.isolate_failures))):
+            if isinstance(st, Exception):
+                self._retire(r, st, "reading the State at the head of the iteration")
+                continue
             if st is None:
                 continue
             st['potential_energy'] = c._lambda_one_energy()
@@ -633,9 +675,10 @@ class BatchedBLUESSimulation(object):
 
         # every chain is about to ask its context for energies (state0 here; the unperturbed energy of the move and state1
         # after each advance): evaluate them for the whole batch at once, the per-chain calls then find them cached
-        self._ncmc_batch.prefetch_energies()
-        got = self.for_each_chain(lambda r, c: resume(r, first=True))
-        wanted = {r: n for r, n in enumerate(got) if n is not DONE}
+        live = [r for r in range(len(sims)) if r not in self.dead]
+        self._ncmc_batch.prefetch_energies(active=self._alive() if self.dead else None)
+        got = self.for_each_chain(lambda r, c: resume(r, first=True), live)
+        wanted = {r: n for r, n in zip(live, got) if n is not DONE}
         while wanted:
             errors = self._advance(self._ncmc_batch, sims, wanted)
             idx = sorted(wanted)
@@ -676,7 +719,7 @@ class BatchedBLUESSimulation(object):
                     c.currentIter = N
                 self._sync_batched()
             else:
-                (self._md_batch or self._ncmc_batch).prefetch_energies(at_lambda_one=self._md_batch is None)
+                (self._md_batch or self._ncmc_batch).prefetch_energies(at_lambda_one=self._md_batch is None, active=self._alive() if self.dead else None)
                 self.for_each_chain(sync)
             self._stepNCMC(nstepsNC, moveStep, batchable=fast)
             if fast:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define BLUES_ABI_VERSION 5
+#define BLUES_ABI_VERSION 6
 
 /* nonbonded_method */
 #define BLUES_NB_NOCUTOFF 0   /* oracle only: vacuum systems (vacDivaline, two-body checks) */
@@ -203,6 +203,8 @@ typedef struct BluesTuning {
                                 * in a force pass starts beside the rebuild of the others; 0 (default): after the group lists */
     int32_t fuse_finalize;     /* 1 (default): where one workgroup holds every constraint cluster of a chain, the steady-state step kernel
                                 * forms the summed forces of the pass itself (no k_finalize launch); 0: always the separate kernel */
+    int32_t host_threads;      /* host threads for work the members of a batch share (re-sorts and re-layouts of several members at a poll);
+                                * 0: the cores this process may use, at most 16.  N ranks on one host: cores / N (blues_amd/replicas.py) */
 } BluesTuning;
 void blues_tuning_default(BluesTuning *t);
 /* NULL restores the defaults.  Applies to engines and batches created afterwards. */
@@ -375,6 +377,13 @@ int blues_batch_set_velocities_to_temperature(BluesBatch *b, double temperature,
 /* [0] steps issued in lock step (one launch for all members) [1] steps that
  * fell back to per-member launches [2] members [3] batched energy evaluations */
 int blues_batch_get_stats(BluesBatch *b, int64_t stats[4]);
+/* What the layout of a batch has cost so far (ABI 6; bench.py reports the per-iteration differences, so that a slow iteration names its
+ * cause): [0] re-plans of the layout shape (a member's group lists outgrew it) [1] seconds spent in them [2] members laid out again from a new
+ * sort inside batch calls (creation included) [3] members re-sorted at the 64-step polls (their builders asked, or by age) [4] seconds spent
+ * there [5] members moved to another shape in place (no sort) [6] re-sorts of all members, whoever asked [7] tiles per group list now
+ * [8] list capacity [9] nonbonded kernel (blues_get_stats [12]). */
+#define BLUES_N_BATCH_COUNTERS 10
+int blues_batch_get_counters(BluesBatch *b, double out[BLUES_N_BATCH_COUNTERS]);
 /* as blues_time_nonbonded, for one batched launch covering all members.  With pruned per-atom lists an atom is served in
  * one of two ways: from its current pruned list, or from its full list while the pruned one is re-derived.  usec[0] / usec[1]:
  * the launch with every atom served the first / the second way; prune_fraction: the share of (atom, pass) pairs served the

@@ -142,3 +142,34 @@ def test_reporter_intervals_split_the_shared_steps(doubles, tol_box):
     assert [st for st, _ in reporter.seen] == [2, 4, 6, 8]
     for a, b in zip(plain, rep):
         assert np.array_equal(a.stateTable["ncmc"]["state1"]["positions"]._value, b.stateTable["ncmc"]["state1"]["positions"]._value)
+
+
+def test_a_retired_chain_sits_out_the_chain_by_chain_path(doubles, tol_box):
+    """isolate_failures on the path that is NOT batched (here: a test double without the batched plugin boundary; in production: reporters
+    on the NCMC leg, batched_boundary=False): a retired chain is skipped by the sync, the switch, the Metropolis step and the reset, and
+    the others -- every chain on a private RandomState, although rng=None was asked for -- come out exactly as in a run in which nobody
+    was retired (the numbers a dead chain does not draw shift nobody's stream)."""
+    from blues_amd import simulation
+    s, v = tol_box
+    R, nsteps = 3, 4
+
+    def run(retire):
+        np.random.seed(7)
+        chains = [_chain(doubles, s, v, r, nsteps, nIter=2) for r in range(R)]
+        B = simulation.BatchedBLUESSimulation(chains, isolate_failures=True)
+        assert not B._batchable()
+        assert all(c._rng is not np.random for c in chains)
+        if retire is not None:
+            B._retire(retire, RuntimeError("blown up"), "a test")
+        B.run(nIter=2, nstepsNC=nsteps, moveStep=nsteps // 2)
+        return B, chains
+
+    B0, all_alive = run(None)
+    B1, one_dead = run(1)
+    assert sorted(B1.dead) == [1] and one_dead[1].last.get("failed")
+    assert one_dead[1]._ncmc_sim.context._integrator.getGlobalVariableByName("step") == 0      # never stepped, never reset, never read
+    assert (1, ) not in [tuple(i for i, a in enumerate(act) if a) for _, act in B1._ncmc_batch.calls if act is not None]
+    for r in (0, 2):
+        assert one_dead[r].last == all_alive[r].last
+        assert one_dead[r].accept == all_alive[r].accept
+        assert np.array_equal(one_dead[r]._ncmc_sim.context._engine.get_positions(), all_alive[r]._ncmc_sim.context._engine.get_positions())

@@ -1073,3 +1073,72 @@ def test_the_order_of_a_pass_kernels_changes_no_bit(Engine, tune):
         assert np.array_equal(out[0][0], out[other][0]), other
         for a, b in zip(out[0][1], out[other][1]):
             assert np.array_equal(a, b), other
+
+
+def test_a_batch_moves_to_a_finer_list_shape_in_place(Engine, tune):
+    """A member whose mobile atoms have spread beyond what the batch's layout shape holds (S tiles per group list, capacity fixed by
+    the LDS image) makes the batch re-plan the shape for everybody.  Round 5 re-laid every member out from a new sort, up to three times
+    (3 s for 1024 members in the middle of a switch, BENCH_r05: one 4.5 s iteration in both batches); now the shape is planned from the
+    members' own tables and they move to it IN PLACE (blues_engine.hip: reshape_groups) -- no sort, no upload, one forced list build.
+    Two mobile waters of member 0 exchange places with two frozen ones 1.6 nm from the ligand (identical molecules: the same
+    configuration, another set of mobile atoms): the one group of five tiles no longer fits, the batch moves to fewer tiles per list,
+    the counters say how, the lists are complete, and the OTHER members come out as in a run in which nothing happened."""
+    from blues_amd.engine import NativeBatch
+    s, v = systems.s23k(mobile_atoms=275, frozen=True)
+    R, n = 6, 20
+    tune(assume_batch=64)      # (the layout of a large batch: per-atom lists over group images, the benchmark's)
+    res = np.asarray(s.residue_of_atom)
+    lig = np.asarray(s.alchemical_atoms)
+
+    def build():
+        engs = []
+        for r in range(R):
+            g = Engine(s, _integ(100, seed=300 + r).to_data(precision=0, replica=r)); g.set_velocities(v * (1.0 + 0.02 * r)); engs.append(g)
+        return engs, NativeBatch(engs)
+
+    calm, Bc = build()
+    Bc.step(2 * n)
+    c0 = Bc.counters()
+    assert c0["replans"] == 0 and c0["tiles_per_list"] == 5 and c0["nonbonded_kernel"] == 2, c0
+    ref = [(_state(g)) for g in calm]
+    Bc.close()
+    for g in calm:
+        g.close()
+
+    engs, B = build()
+    B.step(n)
+    x = engs[0].get_positions()
+    centre = x[lig].mean(axis=0)
+    box = np.asarray(s.box, dtype=float).reshape(-1)[:3]
+    first = np.array([np.nonzero(res == q)[0][0] for q in np.unique(res)])           # first atom of every residue
+    d = x[first] - centre; d -= box * np.rint(d / box)
+    dist = np.linalg.norm(d, axis=1)
+    is_water = np.array([np.count_nonzero(res == res[a]) == 3 for a in first])
+    frozen_w = first[is_water & (s.mass[first] == 0.0)]
+    mobile_w = first[is_water & (s.mass[first] > 0.0)]
+    dist_of = dict(zip(first.tolist(), dist.tolist()))
+    w1 = min(frozen_w, key=lambda a: abs(dist_of[int(a)] - 1.6))                        # a frozen water 1.6 nm from the ligand ...
+    dd = x[frozen_w] - x[w1]; dd -= box * np.rint(dd / box)
+    w2 = frozen_w[np.argsort(np.linalg.norm(dd, axis=1))[1]]                            # ... and its nearest frozen neighbour
+    near = sorted(mobile_w, key=lambda a: dist_of[int(a)])[:2]                          # the two mobile waters nearest the ligand
+    for a, b in zip(near, (w1, w2)):
+        ia, ib = np.arange(a, a + 3), np.arange(b, b + 3)
+        x[ia], x[ib] = x[ib].copy(), x[ia].copy()
+    engs[0].set_positions(x)
+    B.step(n)
+    c = B.counters()
+    assert c["replans"] >= 1 and c["nonbonded_kernel"] == 2 and c["tiles_per_list"] < 5, c
+    assert c["reshapes"] >= R - 1 and c["relayouts"] == 0, c            # everybody moved in place; nobody was laid out again by the batch
+    assert c["replan_seconds"] < 0.25, c
+    for g in engs:
+        assert g.audit_lists()[1] == 0
+        assert g.stats()["tiles_per_list"] == c["tiles_per_list"]
+    assert B.stats()["fallback_steps"] == 0
+    wmax = max(abs(r_[2]) for r_ in ref) + 1.0
+    for g, (xr, vr, wr) in list(zip(engs, ref))[1:]:
+        xg, vg, wg = _state(g)
+        assert abs(wg - wr) <= 1e-5 * wmax, (wg, wr)
+        assert np.abs(xg - xr).max() < 1e-4
+    B.close()
+    for g in engs:
+        g.close()
