@@ -209,6 +209,7 @@ struct BluesEngine {
     std::vector<HostCluster> clusters;
     int n_itiles = 0, n_tiles = 0, jcap = 0, n_islots = 0, pool_cap = 0, PA = 1, k2_nblocks_env = 0, k2_jiter = 1;
     bool k2_dense = false;   // the alchemical kernel's env pairs in their dense form (kernels_alch.h: alchemical_dense_body)
+    bool k2_f32 = false;     // ... in fp32 pair arithmetic with the work from per-pair differences (alchemical_dense32_body; round 6)
     int seg_len = 64, waves_tile = 4, wpb = 4, npart = 1;  // K1 decomposition
     bool fuse_forces = false, fast_step = true, fuse_big = false;  // fuse_big: measured slower (the alchemical role's 140 VGPRs and 36 KB LDS cap the occupancy of the nonbonded role)
     int k1_iw = 64;  // i-atoms per wave in the nonbonded kernel: 64 = classic tile kernel, 8/16 = sub-tile throughput kernel
@@ -687,6 +688,7 @@ static int sort_and_tile(BluesEngine* h) {
     SetupTimer tm_all(1);
     const int n = h->n;
     h->steps_since_sort = 0;
+    h->shape_overflow = false;   // (set again below if this layout still does not fit the batch's shape; a layout that left the per-atom lists has no shape to outgrow)
     // fragment lists (kernels_frag.h) where every environment atom moves: mixed precision, more than the lone-chain handful of tiles
     // fragment lists (kernels_frag.h), mixed precision: where every environment atom moves (more than the lone-chain handful of
     // tiles); where the per-atom lists over group images cannot hold the system (forbid_atom: the mobile atoms of an NCMC System
@@ -911,6 +913,7 @@ static int sort_and_tile(BluesEngine* h) {
         h->k2_dense = h->precision == 0 && (h->k1_mode == 2 || want_frag) && !h->fuse_forces && h->batch_R >= 8 && !h->check_env_excl && !h->alch.empty() && h->alch.size() <= 16 &&
                       mobile_env <= K2D_MOB && half_min > h->cutoff + ext + 0.3 && h->tune.k2_dense != 0;
         if (h->k2_dense) h->k2_jiter = 1 << 20;   // one logical env block: k2_env_blocks() = 1 wherever the partial slabs are summed
+        h->k2_f32 = h->k2_dense && h->tune.k2_dense != 2;   // (2: the round-5 fp64 body, kept as the reference the fp32 form is tested against)
     }
     h->k2_nblocks_env = k2_env_blocks(jcap, h->PA, h->k2_jiter);
     // exclusions in sorted space (self included)
@@ -1395,8 +1398,37 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
     if (h->k2_dense) {
         // dense env pairs: one workgroup per chain; the alchemical x alchemical block is the other kernel's (a grid of self blocks only)
         if (batch_dry(h)) { h->st_launches++; return 0; }
-        static thread_local bool opened[2] = {false, false};
         const bool lead = batch_lead(h);
+        if (h->k2_f32) {
+            // the fp32 form (kernels_alch.h: alchemical_dense32_body): its LDS record depends on how many force slots the pass produces
+            static thread_local bool opened32[2] = {false, false};
+            if (!opened32[lead]) {
+                hipError_t e = hipSuccess;
+#define OPEN32(M, NS) do { if (e == hipSuccess) e = lead ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_alchemical_dense32_b<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K2FLds<NS>)) \
+                                                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_alchemical_dense32<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K2FLds<NS>)); } while (0)
+                OPEN32(5, 2); OPEN32(2, 1); OPEN32(-1, 3);
+#undef OPEN32
+                if (e != hipSuccess) E_FAIL(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
+                opened32[lead] = true;
+            }
+            if (lead) {
+                const int nrep = h->batch->R();
+                const AlchDyn D = make_alch_dyn(A);
+#define DENSE32_B(M, NS) do { if (part != 3) hipLaunchKernelGGL((k_alchemical_dense32_b<M>), dim3(nrep), dim3(K2F_THREADS), sizeof(K2FLds<NS>), h->cur, h->batch->d_core.p, D); \
+                              if (part != 4) hipLaunchKernelGGL((k_alchemical_b<true, M>), dim3(nrep), dim3(256), 0, h->cur, h->batch->d_core.p, D, 1, nrep, (const int*)nullptr); } while (0)
+                if (slot_mask == 5) DENSE32_B(5, 2); else if (slot_mask == 2) DENSE32_B(2, 1); else DENSE32_B(-1, 3);
+#undef DENSE32_B
+            } else {
+                if (slot_mask == 5) hipLaunchKernelGGL(k_alchemical_dense32<5>, dim3(1), dim3(K2F_THREADS), sizeof(K2FLds<2>), h->cur, A);
+                else if (slot_mask == 2) hipLaunchKernelGGL(k_alchemical_dense32<2>, dim3(1), dim3(K2F_THREADS), sizeof(K2FLds<1>), h->cur, A);
+                else hipLaunchKernelGGL(k_alchemical_dense32<-1>, dim3(1), dim3(K2F_THREADS), sizeof(K2FLds<3>), h->cur, A);
+                hipLaunchKernelGGL(k_alchemical<true>, dim3(1), dim3(256), 0, h->cur, A);
+            }
+            h->st_launches++;
+            HIP_OK(h, hipGetLastError());
+            return 0;
+        }
+        static thread_local bool opened[2] = {false, false};
         const size_t lds = sizeof(K2DLds);
         if (!opened[lead]) {
             hipError_t e = hipSuccess;
@@ -1458,6 +1490,8 @@ static AlchArgs make_alch_args(BluesEngine* h, const double ls[3], const double 
     A.pme = h->nb_method == BLUES_NB_PME_DIRECT; A.annih_elec = h->annih_elec; A.annih_ster = h->annih_ster; A.slot_mask = slot_mask; A.check_env_excl = h->check_env_excl;
     for (int s = 0; s < 3; s++) { A.ls[s] = ls[s]; A.le[s] = le[s]; }
     A.fJ = h->d_fJ.p; A.self_part = h->d_self_part.p; A.e_part = h->d_e_part.p; A.ctrl = h->ctrl_arg;
+    A.img = h->precision == 0 ? h->d_img_f.p : nullptr;
+    for (int k = 0; k < 3; k++) A.fscale[k] = (float)(h->box[k] / 4294967296.0);
     return A;
 }
 
@@ -2492,7 +2526,7 @@ static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const ch
 #define BC(f) if (a->f != b->f) { *why = #f; return false; }
     BC(device) BC(n) BC(precision) BC(nsteps) BC(nprop) BC(n_lambda) BC(split) BC(remove_cm) BC(dt) BC(gamma) BC(kT) BC(tol) BC(prop_min) BC(prop_max)
     BC(n_itiles) BC(n_tiles) BC(jcap) BC(n_islots) BC(pool_cap) BC(PA) BC(k2_nblocks_env) BC(k2_jiter) BC(seg_len) BC(waves_tile) BC(wpb) BC(npart)
-    BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k1_iw) BC(k1_mode) BC(acap) BC(S) BC(n_lists) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
+    BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k2_dense) BC(k2_f32) BC(k1_iw) BC(k1_mode) BC(acap) BC(S) BC(n_lists) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
     BC(frag_F) BC(frag_NI) BC(frag_nblk) BC(frag_fpw) BC(frag_nwg) BC(frag_rel)
     BC(cutoff) BC(alpha) BC(sc_alpha) BC(annih_elec) BC(annih_ster) BC(nb_method) BC(pme) BC(pme_K[0]) BC(pme_K[1]) BC(pme_K[2]) BC(pme_order) BC(restr_k) BC(total_mass)
     // (not the box: a MonteCarloBarostat leaves every member in its own; margins, fixed-point scales and PME tables are per member in the records)
@@ -3503,7 +3537,7 @@ int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
     stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
     if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) { stats[1] = f.list_gen; stats[10] = f.builds; stats[16] = f.prunes; } }
     stats[19] = (h->prune_on && h->k1_mode == 2) || (h->k1_mode == 3 && h->frag_m < h->skin);
-    stats[20] = h->k2_dense ? 1 : 0;
+    stats[20] = h->k2_dense ? (h->k2_f32 ? 1 : 2) : 0;   // (1: the dense form in fp32 pair arithmetic, round 6; 2: its fp64 predecessor, BluesTuning.k2_dense = 2)
     if (stats[19] && h->k1_mode == 2 && h->d_pcount.p && h->sorted_ok) {
         std::vector<int> pc, ta;
         try { h->d_pcount.download(pc); h->d_tile_atoms.download(ta); for (size_t q = 0; q < pc.size() && q < ta.size(); q++) if (ta[q] >= 0) { stats[17] += pc[q]; stats[18] += (pc[q] + 63) / 64; } } catch (std::string&) {}
@@ -4205,6 +4239,12 @@ int blues_batch_time_nonbonded_modes(BluesBatch* b, int32_t reps, double usec[2]
     b->lockstep = false;
     for (BluesEngine* m : b->eng) m->lists_forced = false;
     if (rc) { b->err = "timing launch failed: " + h->err; batch_leave(b); return 1; }
+#ifdef BLUES_STAMP
+    { long long st[64]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nb_stamps), sizeof st);
+      fprintf(stderr, "[stamps] nonbonded_atom_b, the workgroup that stamped last (10 ns ticks since its entry: slot records, image requested + mobile positions asked for, barrier, then wave 0's turns: walked / reduced ...):");
+      for (int i = 17; i < 28; i++) fprintf(stderr, " %lld", st[i] - st[16]);
+      fprintf(stderr, " | waves out of atoms at:"); for (int i = 44; i < 60; i++) fprintf(stderr, " %lld", st[i] - st[16]); fprintf(stderr, "\n"); }
+#endif
     usec[0] = 1000.0 * ms[0] / std::max(1, reps); usec[1] = 1000.0 * ms[1] / std::max(1, reps);
     batch_leave(b);
     for (BluesEngine* m : b->eng) if (check_flags(m)) { b->err = m->err; return 1; }

@@ -58,6 +58,8 @@ struct AlchArgs {
     double* e_part;     // [nblocks][K2_NP]
     const DevCtrl* ctrl; // non-null in graph replays: lambda slots come from the device tables
     int* flags_overflow; // -> DevFlags::list_overflow (the dense form: more mobile list entries than it has accumulators for)
+    const AtomF* img;    // the fixed-point image (mixed precision; the fp32 dense form stages its records from it), or null
+    float fscale[3];     // box edge / 2^32
 };
 
 __device__ inline bool excluded_sorted(const int* ex_start, const int* ex_idx, int a_sorted, int j_sorted) {
@@ -638,6 +640,245 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
     if (tid < 3) { double t = 0.0; for (int a = 0; a < A.n_alch; a++) t += (double)(long long)S.fa[tid][a] * (1.0 / K2D_FIX); A.e_part[K2_NE + tid] = slot_on(0) ? t : 0.0; }
     NB_STAMP(blockIdx.x == 0 && threadIdx.x == 0, 41);
 }
+
+// ---- round 6: the dense form in fp32 pair arithmetic (the form the batch decomposition runs; the fp64 body above stays as
+// BluesTuning.k2_dense = 2, the reference the new one is tested against).
+// What changed and why.  The fp64 body spent 17 k of its ~30 k cycles per marking pass in ~350 fp64 instructions per pair (two Newton-
+// refined reciprocals, an rsqrt, a libm exp, a degree-16 erfc fit), ran two marking passes (its pair lists and fp64 positions fill the
+// LDS: one workgroup per CU, two waves per SIMD at 187 registers) and staged positions through two dependent gathers of 32 + 24 bytes
+// per list entry.  Here:
+//  * an entry is staged with ONE 32-byte gather from the fixed-point image the step kernel refreshes (kernels_integrate.h) into the
+//    24-byte LDS record the nonbonded kernel uses -- {x, y, z as fractions of the box edge in u32, q sqrt(k_e)} + {sigma / 2, 2 sqrt(eps)};
+//    a fixed-point difference IS the minimum image, exact, and its fp32 conversion carries one rounding (6e-8 of the separation);
+//  * pair arithmetic in fp32 (~100 instructions: one v_rsq, one v_exp, four v_rcp) with fp64 accumulation of the energies per lane;
+//  * THE PROTOCOL WORK keeps its precision because the kernel never differences two rounded energies: for a pair, with
+//    x_s = 1 / (A_s + (r / sigma)^6), A_s = alpha (1 - ls_s), the change of the softcore energy between two lambda slots is
+//        U_b - U_a = 4 eps [ ls_b (x_b - x_a)(x_a + x_b - 1) + (ls_b - ls_a) x_a (x_a - 1) ],   x_b - x_a = (A_a - A_b) x_a x_b   (exact algebra),
+//    formed from the SMALL numbers (A_a - A_b), (ls_b - ls_a) -- its rounding error is ~3e-7 of the difference itself, not of U.  The
+//    kernel accumulates S_0, D_01 = sum (U_1 - U_0), D_12 and publishes S_0, S_0 + D_01, S_0 + D_01 + D_12 in fp64: what finalize
+//    differences comes back as D to 1e-16 of S.  Electrostatics is linear in lambda_electrostatics: one sum C, the work is (le_b - le_a) C;
+//  * a wave owns an alchemical atom: it sweeps the staged list, compacts the entries within the cutoff into a 128-entry ring in LDS and
+//    runs the pair arithmetic whenever 64 are waiting -- every lane busy, no pair list for the whole list, no second pass, no barrier
+//    between marking and arithmetic; the force on its atom is a per-lane fp32 sum and one DPP reduction (a fixed order: batch = solo
+//    stays bitwise); the force on a mobile environment atom goes to 64-bit fixed-point accumulators in LDS as before (integer
+//    addition is associative);
+//  * 78 KB of LDS and < 128 registers: two workgroups per CU.
+#define K2F_THREADS 512
+#define K2F_WAVES (K2F_THREADS / 64)
+#define K2F_JC 2432        // list entries staged at a time (38 chunks; the alchemical tile's list of the benchmark system is ~2,400 entries)
+#define K2F_MOB 288        // mobile entries per round with a force accumulator
+#define K2F_RING 128
+template <int NS> struct K2FLds {
+    uint4 r4[K2F_JC];                       // x, y, z (fixed point), q sqrt(k_e) as float bits
+    float2 r2[K2F_JC];                      // sigma / 2, 2 sqrt(eps)
+    unsigned short mslot[K2F_JC];
+    unsigned long long fj[3 * NS][K2F_MOB];
+    unsigned short ring[K2F_WAVES][K2F_RING];
+    int mcnt[(K2F_JC + 63) / 64 + 2];
+    unsigned xa[3][16]; float aq[16], ahs[16], ase[16];
+    float fa[16][9];
+    double e[K2F_WAVES][4];
+};
+static_assert(sizeof(K2FLds<2>) <= 80 * 1024, "two workgroups of the fp32 dense alchemical kernel per CU");
+
+template <int MASK>
+__device__ __forceinline__ void alchemical_dense32_body(AlchArgs& A) {
+    constexpr int NS = MASK == 5 ? 2 : (MASK == 2 ? 1 : 3);                    // force slots this instantiation produces
+    auto slot_on = [&](int s) -> bool { return MASK >= 0 ? ((MASK >> s) & 1) != 0 : ((A.slot_mask >> s) & 1) != 0; };
+    auto slot_ix = [&](int s) -> int { return MASK == 5 ? (s >> 1) : (MASK == 2 ? 0 : s); };   // where slot s lives among the NS accumulators
+    if (A.ctrl) {
+        const int L = A.ctrl->L0 + 2 * A.ctrl->kpass;
+#pragma unroll
+        for (int s = 0; s < 3; s++) { const int Ls = min(L + s, A.ctrl->n_lambda); A.ls[s] = A.ctrl->tab_ls[Ls]; A.le[s] = A.ctrl->tab_le[Ls]; }
+    }
+    extern __shared__ __align__(16) unsigned char k2d_smem[];
+    K2FLds<NS>& S = *reinterpret_cast<K2FLds<NS>*>(k2d_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int count = *A.jcount;
+    if (count <= 0) return;   // (finalize reads no env slab then)
+    const AtomF* __restrict__ img = A.img;
+    // uniform lambda arithmetic in fp64, handed to the pair body as floats of SMALL numbers (differences) and of the slots' own values
+    const bool no_elec = A.le[0] == 0.0 && A.le[1] == 0.0 && A.le[2] == 0.0, same_ls = A.ls[0] == A.ls[1] && A.ls[1] == A.ls[2];
+    const float sA[3] = {(float)(A.sc_alpha * (1.0 - A.ls[0])), (float)(A.sc_alpha * (1.0 - A.ls[1])), (float)(A.sc_alpha * (1.0 - A.ls[2]))};
+    const float ls[3] = {(float)A.ls[0], (float)A.ls[1], (float)A.ls[2]}, le[3] = {(float)A.le[0], (float)A.le[1], (float)A.le[2]};
+    const float dA01 = (float)(A.sc_alpha * (A.ls[1] - A.ls[0])), dA12 = (float)(A.sc_alpha * (A.ls[2] - A.ls[1]));   // A_a - A_b = alpha (ls_b - ls_a)
+    const float dl01 = (float)(A.ls[1] - A.ls[0]), dl12 = (float)(A.ls[2] - A.ls[1]);
+    const float rc2 = (float)A.rc2, alpha = (float)A.alpha, c2 = TWO_OVER_SQRT_PI_F * (float)A.alpha;
+    const float sc0 = A.fscale[0], sc1 = A.fscale[1], sc2 = A.fscale[2];
+    if (tid < 16) {
+        const bool on = tid < A.n_alch;
+        const AlchARec ar = A.arec[on ? tid : 0];
+        const AtomF me = img[ar.asrt];
+        S.xa[0][tid] = me.x; S.xa[1][tid] = me.y; S.xa[2][tid] = me.z;
+        S.aq[tid] = on ? (float)(ar.q * sqrt(ONE_4PI_EPS0)) : 0.0f; S.ahs[tid] = on ? (float)(0.5 * ar.sig) : 0.0f; S.ase[tid] = on ? (float)(2.0 * ar.eps) : 0.0f;   // (ar.eps is sqrt(epsilon))
+    }
+    for (int w = tid; w < 16 * 9; w += K2F_THREADS) S.fa[w / 9][w % 9] = 0.0f;
+    double eC = 0.0, eS0 = 0.0, eD01 = 0.0, eD12 = 0.0;
+    constexpr int NIT = (K2F_JC + K2F_THREADS - 1) / K2F_THREADS;
+    for (int j0 = 0; j0 < count; j0 += K2F_JC) {
+        const int nst = min(K2F_JC, count - j0), nchunk = (nst + 63) >> 6;
+        // ---- stage the round: list entry -> image record (two dependent loads, every entry of a level in flight together); mobile
+        // entries numbered in list order
+        for (int w = tid; w < 3 * NS * K2F_MOB; w += K2F_THREADS) S.fj[w / K2F_MOB][w % K2F_MOB] = 0ull;
+        int js[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) { const int k = it * K2F_THREADS + tid; js[it] = k < nst ? A.jlist[j0 + k] : -1; }
+        bool mob[NIT]; int mrank[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int k = it * K2F_THREADS + tid, ch = k >> 6;
+            mob[it] = false;
+            if (k < K2F_JC) {
+                if (js[it] >= 0) {
+                    const uint4 lo = *reinterpret_cast<const uint4*>(&img[js[it]]);            // x, y, z, q
+                    const uint4 hi = *(reinterpret_cast<const uint4*>(&img[js[it]]) + 1);      // hs, se, flags, orig
+                    S.r4[k] = lo; S.r2[k] = make_float2(__uint_as_float(hi.x), __uint_as_float(hi.y));
+                    mob[it] = (hi.z & FLAG_MOBILE) != 0;
+                }
+            }
+            const unsigned long long b = __ballot(mob[it]);
+            mrank[it] = __popcll(b & ((1ull << lane) - 1ull));
+            if (lane == 0 && k < K2F_JC) S.mcnt[ch] = __popcll(b);
+        }
+        __syncthreads();
+        {
+            int c = lane < (K2F_JC + 63) / 64 ? S.mcnt[lane] : 0, inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            const int exc = inc - c;
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int k = it * K2F_THREADS + tid, ch = k >> 6;
+                const int ms = __shfl(exc, min(ch, 63), 64) + mrank[it];
+                if (k < K2F_JC) S.mslot[k] = (mob[it] && ms < K2F_MOB) ? (unsigned short)ms : (unsigned short)0xffff;
+            }
+        }
+        __syncthreads();
+        // ---- a wave per alchemical atom: sweep, compact, compute
+        for (int a = wv; a < A.n_alch; a += K2F_WAVES) {
+            const unsigned xa = S.xa[0][a], ya = S.xa[1][a], za = S.xa[2][a];
+            const float qa = S.aq[a], hsa = S.ahs[a], sea = S.ase[a];
+            float fa[NS][3];
+#pragma unroll
+            for (int s = 0; s < NS; s++) { fa[s][0] = fa[s][1] = fa[s][2] = 0.0f; }
+            unsigned short* const ring = S.ring[wv];
+            int head = 0, fill = 0;   // (uniform)
+            auto pairs = [&](int nvalid) {
+                const bool valid = lane < nvalid;
+                const int k = valid ? (int)ring[(head + lane) & (K2F_RING - 1)] : 0;
+                const uint4 p = S.r4[k]; const float2 t = S.r2[k];
+                const float dx = (float)(int)(xa - p.x) * sc0, dy = (float)(int)(ya - p.y) * sc1, dz = (float)(int)(za - p.z) * sc2;
+                const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                float ft[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) ft[s] = 0.0f;
+                if (valid) {
+                    const float sig = hsa + t.x, eps4 = sea * t.y, qq = qa * __uint_as_float(p.w);
+                    float fc = 0.0f;
+                    if (!no_elec && qq != 0.0f) {
+                        const float inv_r = __builtin_amdgcn_rsqf(r2), inv_r2 = inv_r * inv_r, arr = alpha * (r2 * inv_r);
+                        const float ex = __expf(-arr * arr), ec = erfc_scaled_f(arr) * ex;
+                        eC += (double)(qq * ec * inv_r);
+                        fc = qq * fmaf(c2, ex, ec * inv_r) * inv_r2;
+                    }
+                    float fs[3] = {0.0f, 0.0f, 0.0f};
+                    if (eps4 != 0.0f) {
+                        const float inv_s2 = __builtin_amdgcn_rcpf(fmaxf(sig * sig, 1e-12f)), q2 = r2 * inv_s2, q4 = q2 * q2, q6 = q4 * q2;
+                        const float g6 = 6.0f * eps4 * q4 * inv_s2;
+                        const float den0 = sA[0] + q6, x0 = __builtin_amdgcn_rcpf(den0);
+                        const float u0 = x0 * x0 * (1.0f - den0);          // x (x - 1) without the cancellation at x ~ 1
+                        eS0 += (double)(ls[0] * eps4 * u0);
+                        fs[0] = ls[0] * g6 * fmaf(2.0f, x0, -1.0f) * x0 * x0;
+                        if (same_ls) { fs[1] = fs[2] = fs[0]; }
+                        else {
+                            const float den1 = sA[1] + q6, x1 = __builtin_amdgcn_rcpf(den1), den2 = sA[2] + q6, x2 = __builtin_amdgcn_rcpf(den2);
+                            const float u1 = x1 * x1 * (1.0f - den1);
+                            // (A_0 - A_1) = alpha (ls_1 - ls_0) = dA01; x_1 - x_0 = dA01 x_0 x_1
+                            const float d01 = dA01 * x0 * x1, d12 = dA12 * x1 * x2;
+                            eD01 += (double)(eps4 * fmaf(ls[1] * d01, x0 + x1 - 1.0f, dl01 * u0));
+                            eD12 += (double)(eps4 * fmaf(ls[2] * d12, x1 + x2 - 1.0f, dl12 * u1));
+                            fs[1] = ls[1] * g6 * fmaf(2.0f, x1, -1.0f) * x1 * x1;
+                            fs[2] = ls[2] * g6 * fmaf(2.0f, x2, -1.0f) * x2 * x2;
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 3; s++) if (slot_on(s)) ft[slot_ix(s)] = fmaf(le[s], fc, fs[s]);
+                }
+                const unsigned ms = valid ? (unsigned)S.mslot[k] : 0xffffu;
+#pragma unroll
+                for (int s = 0; s < 3; s++) {
+                    if (!slot_on(s)) continue;
+                    const int q = slot_ix(s);
+                    const float fx = ft[q] * dx, fy = ft[q] * dy, fz = ft[q] * dz;
+                    fa[q][0] += fx; fa[q][1] += fy; fa[q][2] += fz;
+                    if (ms != 0xffffu) {   // force on a mobile environment atom: minus the pair force
+                        atomicAdd(&S.fj[3 * q + 0][ms], (unsigned long long)__double2ll_rn(-(double)fx * K2D_FIX));
+                        atomicAdd(&S.fj[3 * q + 1][ms], (unsigned long long)__double2ll_rn(-(double)fy * K2D_FIX));
+                        atomicAdd(&S.fj[3 * q + 2][ms], (unsigned long long)__double2ll_rn(-(double)fz * K2D_FIX));
+                    }
+                }
+            };
+            for (int ch = 0; ch < nchunk; ch++) {
+                const int k = ch * 64 + lane;
+                const uint4 p = S.r4[min(k, nst - 1)];
+                const float dx = (float)(int)(xa - p.x) * sc0, dy = (float)(int)(ya - p.y) * sc1, dz = (float)(int)(za - p.z) * sc2;
+                const bool hit = k < nst && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < rc2;
+                const unsigned long long b = __ballot(hit);
+                if (hit) ring[(head + fill + __popcll(b & ((1ull << lane) - 1ull))) & (K2F_RING - 1)] = (unsigned short)k;
+                fill += __popcll(b);
+                if (fill >= 64) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the ring is written and read by this wave only)
+                    pairs(64);
+                    head = (head + 64) & (K2F_RING - 1); fill -= 64;
+                }
+            }
+            if (fill > 0) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); pairs(fill); }
+            // the force on this wave's atom: one reduction per component, added to what earlier rounds left (this wave is the only writer)
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                if (!slot_on(s)) continue;
+                const int q = slot_ix(s);
+#pragma unroll
+                for (int c3 = 0; c3 < 3; c3++) { const float v = wave_sum_dpp_f32(fa[q][c3]); if (lane == 0) S.fa[a][s * 3 + c3] += v; }
+            }
+        }
+        __syncthreads();
+        // ---- the round's mobile entries: force by sorted index (every one of them is written: zero if it had no pair)
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int k = it * K2F_THREADS + tid;
+            if (k < nst && mob[it]) {
+                const unsigned ms = S.mslot[k];
+                if (ms == 0xffffu) { if (A.flags_overflow) A.flags_overflow[0] = 1; continue; }
+#pragma unroll
+                for (int s = 0; s < 3; s++) {
+                    if (!slot_on(s)) continue;
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; c3++) A.fJ[(size_t)(s * 3 + c3) * A.n + js[it]] = (double)(long long)S.fj[3 * slot_ix(s) + c3][ms] * (1.0 / K2D_FIX);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- partial slabs of logical block 0
+    if (tid < A.PA) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) A.self_part[(size_t)q * A.PA + tid] = (tid < A.n_alch && tid < 16 && slot_on(q / 3)) ? (double)S.fa[tid][q] : 0.0;
+    }
+    eC = wave_sum(eC); eS0 = wave_sum(eS0); eD01 = wave_sum(eD01); eD12 = wave_sum(eD12);
+    if (lane == 0) { S.e[wv][0] = eC; S.e[wv][1] = eS0; S.e[wv][2] = eD01; S.e[wv][3] = eD12; }
+    __syncthreads();
+    if (tid == 0) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int w = 0; w < K2F_WAVES; w++) for (int q = 0; q < 4; q++) t[q] += S.e[w][q];
+        A.e_part[0] = t[0]; A.e_part[1] = t[1]; A.e_part[2] = t[1] + t[2]; A.e_part[3] = t[1] + t[2] + t[3];
+        A.e_part[4] = 0.0; A.e_part[5] = 0.0;
+    }
+    if (tid < 3) { double t = 0.0; for (int a = 0; a < A.n_alch && a < 16; a++) t += (double)S.fa[a][tid]; A.e_part[K2_NE + tid] = slot_on(0) ? t : 0.0; }
+}
+
+template <int MASK>
+__global__ void __launch_bounds__(K2F_THREADS, 4) k_alchemical_dense32(AlchArgs A) { alchemical_dense32_body<MASK>(A); }
 
 template <int MASK>
 __global__ void __launch_bounds__(K2D_THREADS) k_alchemical_dense(AlchArgs A) { alchemical_dense_body<MASK>(A); }

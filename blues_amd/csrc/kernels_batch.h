@@ -254,6 +254,15 @@ __global__ void __launch_bounds__(K2D_THREADS) k_alchemical_dense_b(const RepCor
     alchemical_dense_body<MASK>(A);
 }
 
+// ... and its fp32 form (round 6, kernels_alch.h: alchemical_dense32_body): two workgroups per CU
+template <int MASK>
+__global__ void __launch_bounds__(K2F_THREADS, 4) k_alchemical_dense32_b(const RepCore* __restrict__ reps, AlchDyn d) {
+    const int rep = blockIdx.x;
+    if (!reps[rep].active) return;
+    AlchArgs A = reps[rep].al; apply_dyn(A, d);
+    alchemical_dense32_body<MASK>(A);
+}
+
 __global__ void __launch_bounds__(128) k_bonded_entries_b(const RepCore* __restrict__ reps, BondedDyn d) {
     if (!reps[blockIdx.y].active) return;
     BondedArgs B = reps[blockIdx.y].bo; apply_dyn(B, d, reps[blockIdx.y].draw_delta);

@@ -807,13 +807,21 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     if (tid == 0) *s_next = nw;   // (the first nw atoms are dealt statically; the barrier behind the image staging publishes this)
     auto grab = [&]() -> int { int v = 0; if (lane == 0) v = __hip_atomic_fetch_add(s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return __builtin_amdgcn_readfirstlane(v); };
     NB_STAMP(t == 0 && tid == 0, 16);
+    // Round 6: the prologue as THREE dependent round trips instead of seven.  A 5-atom group's workgroup took 37 us beside 62 us for
+    // the 256-atom one (scripts/r06_sweep_groups.sh: the same launch with 4 + 1 tiles per chain): more than half of a workgroup's time was
+    // this prologue -- count -> tile_atoms -> pneed -> acount -> image copy -> barrier -> mcount -> mlist -> live image -> barrier, each a
+    // trip to a memory system that 255 other CUs are streaming lists from -- with ONE workgroup per CU, i.e. nothing to overlap it with.
+    // Now every load whose address does not depend on another load is issued at once: (1) the list's length, the number of mobile
+    // entries, and the five facts of every i-slot; (2) the packed image and the list of mobile entries; (3) their live positions.
+    const int mc = G1(const int, a.mcount)[t]; const auto ml = G1(const int, a.mlist) + (size_t)t * a.mcap * 2;
     for (int sl = tid; sl < nslot; sl += blockDim.x) {   // the slot records (one pass: nslot <= 1024)
         const int ia = g_tile_atoms[slot0 + sl];
+        const int need = dual ? g_pneed[slot0 + sl] : 1;   // (no pruned lists: every atom walks its full list)
+        const int c_full = g_acount[(long)(slot0 + sl)], c_pruned = g_acount[(long)(slot0 + sl) + pcount_off];   // (both lengths: which one counts is known with `need`)
+        const unsigned self = G1(const unsigned short, a.aself)[slot0 + sl];
         int r0 = -1, r1 = 0;
         if (ia >= 0) {
-            const int need = dual ? g_pneed[slot0 + sl] : 1;   // (no pruned lists: every atom walks its full list)
-            r0 = g_acount[(long)(slot0 + sl) + (need ? 0L : pcount_off)];
-            const unsigned self = G1(const unsigned short, a.aself)[slot0 + sl];
+            r0 = need ? c_full : c_pruned;
             if (self == 0xffffu) g_flags->list_overflow = 1;   // (the atom is not in its own group's list: only if that list overflowed)
             r1 = (int)(self | ((unsigned)need << 16));
         }
@@ -825,6 +833,9 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         // thread in flight before its first LDS store; then the few mobile entries from the live image
         constexpr int SU = 7;   // 7 x 1024 threads >= the largest list capacity whose image fits LDS
         const int nthr = blockDim.x;
+        // (the mobile entries' places, requested with the image: at most one per thread in the first sweep -- mcap <= the workgroup)
+        int mk0 = -1, mjs0 = 0;
+        if (tid < mc) { mk0 = ml[2 * tid]; mjs0 = ml[2 * tid + 1]; }
         for (int base = 0; base <= count; base += SU * nthr) {
             u32x4 r4[SU]; f32x2 r2[SU];
 #pragma unroll
@@ -832,10 +843,12 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
 #pragma unroll
             for (int u = 0; u < SU; u++) { const int k = base + u * nthr + tid; if (k <= count) { *L3(u32x4, lds + NB_LQ_BYTES + 16 * k) = r4[u]; *L3(f32x2, lds + 8 * k) = r2[u]; } }
         }
+        unsigned mx = 0u, my = 0u, mz = 0u;
+        if (mk0 >= 0) { mx = g_img[mjs0].x; my = g_img[mjs0].y; mz = g_img[mjs0].z; }   // (in flight across the barrier)
         __syncthreads();
         request(wv);   // (the first atom's list travels while the mobile entries are refreshed)
-        const int mc = G1(const int, a.mcount)[t]; const auto ml = G1(const int, a.mlist) + (size_t)t * a.mcap * 2;
-        for (int q = tid; q < mc; q += blockDim.x) {
+        if (mk0 >= 0) { const auto pj = L3(unsigned, lds + NB_LQ_BYTES + 16 * mk0); pj[0] = mx; pj[1] = my; pj[2] = mz; }
+        for (int q = tid + blockDim.x; q < mc; q += blockDim.x) {   // (more mobile entries than threads: small workgroups only)
             const int k = ml[2 * q], js = ml[2 * q + 1];
             const auto pj = L3(unsigned, lds + NB_LQ_BYTES + 16 * k);
             pj[0] = g_img[js].x; pj[1] = g_img[js].y; pj[2] = g_img[js].z;
@@ -1017,6 +1030,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     }
 #undef G1
 #undef NB_VREG
+    NB_STAMP(t == 0 && lane == 0, 44 + min(wv, 15));   // (stamped builds: when each wave ran out of atoms)
     if (ENERGY) {
         elj = wave_sum(elj); ecl = wave_sum(ecl);
         if (lane == 0) { s_e[2 * wv] = elj; s_e[2 * wv + 1] = ecl; }

@@ -198,7 +198,8 @@ typedef struct BluesTuning {
                                 * chain advanced alone, bit for bit" testable */
     int32_t k1_threads;        /* threads per workgroup of the per-atom-list kernel (multiple of 64, <= 1024); 0: 1024 */
     int32_t k2_dense;          /* -1 auto (on where it applies: large batch, mixed precision, free alchemical group of <= 16 atoms);
-                                * 0: the alchemical kernel keeps its (atom, list entry) lane layout */
+                                * 0: the alchemical kernel keeps its (atom, list entry) lane layout; 2: the dense form with the fp64 pair
+                                * arithmetic of round 5 (the reference the fp32 form of round 6 is tested against) */
     int32_t k2_early;          /* 1: with `fork`, the alchemical kernel of the members of a batch that do not rebuild their lists
                                 * in a force pass starts beside the rebuild of the others; 0 (default): after the group lists */
     int32_t fuse_finalize;     /* 1 (default): where one workgroup holds every constraint cluster of a chain, the steady-state step kernel

@@ -93,24 +93,30 @@ def reflect(xyz):
     return 2.0 * c - np.asarray(xyz, dtype=np.float64)
 
 
+_MOVE_CLASS = {}
+
+
 def make_move(moves_module):
-    class PointReflectionMove(moves_module.Move):
-        def __init__(self):
-            self.atom_indices = [0]
-            self.positions = None
+    """A PointReflectionMove (one class per moves module: chains of a batch must carry moves of ONE class to share the batched scatter)."""
+    if moves_module not in _MOVE_CLASS:
+        class PointReflectionMove(moves_module.Move):
+            def __init__(self):
+                self.atom_indices = [0]
+                self.positions = None
 
-        def propose(self, ligand_positions):
-            self.positions = ligand_positions
-            return reflect(ligand_positions)
+            def propose(self, ligand_positions):
+                self.positions = ligand_positions
+                return reflect(ligand_positions)
 
-        def move(self, context):
-            everything = context.getState(getPositions=True).getPositions(asNumpy=True)
-            new = self.propose(everything[self.atom_indices]._value)
-            for atom, xyz in zip(self.atom_indices, new):
-                everything[atom] = xyz
-            context.setPositions(everything)
-            return context
-    return PointReflectionMove()
+            def move(self, context):
+                everything = context.getState(getPositions=True).getPositions(asNumpy=True)
+                new = self.propose(everything[self.atom_indices]._value)
+                for atom, xyz in zip(self.atom_indices, new):
+                    everything[atom] = xyz
+                context.setPositions(everything)
+                return context
+        _MOVE_CLASS[moves_module] = PointReflectionMove
+    return _MOVE_CLASS[moves_module]()
 
 
 def build_chain(context_module, r, nstepsNC, nstepsMD, temperature, dt, seed0=5000, precision="mixed", device=0, friction_md=10.0):
