@@ -16,7 +16,7 @@ NB_PME_DIRECT = 1
 NB_PME = 2
 N_ENERGY_TERMS = 10
 N_STATS = 21
-N_BATCH_COUNTERS = 10
+N_BATCH_COUNTERS = 13
 ENERGY_TERM_NAMES = ("bonds", "angles", "torsions", "nonbonded", "exceptions", "alch_sterics",
                      "alch_electrostatics", "restraint", "reciprocal", "dispersion_correction")
 
@@ -251,6 +251,7 @@ def declare_engine_prototypes(lib):
         "blues_get_energy": ([H, _dp, _dp], C.c_int),
         "blues_get_energy_at": ([H, C.c_double, C.c_double, _dp], C.c_int),
         "blues_get_energy_terms": ([H, _dp], C.c_int),
+        "blues_mesh_energy": ([H, C.c_int32, _dp], C.c_int),
         "blues_step": ([H, C.c_int32], C.c_int),
         "blues_run_switch": ([H, C.c_int32, _dp], C.c_int),
         "blues_get_global": ([H, C.c_char_p, _dp], C.c_int),
@@ -280,6 +281,7 @@ def declare_engine_prototypes(lib):
         "blues_batch_read_atoms": ([H, C.POINTER(H), C.c_int32, C.POINTER(C.c_int32), C.c_int32, _dp], C.c_int),
         "blues_batch_reset": ([H, C.POINTER(C.c_int32)], C.c_int),
         "blues_batch_set_velocities_to_temperature": ([H, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)], C.c_int),
+        "blues_batch_mesh_energy": ([H, C.c_int32, C.POINTER(C.c_int32), _dp], C.c_int),
         "blues_batch_get_stats": ([H, C.POINTER(C.c_int64)], C.c_int),
         "blues_batch_get_counters": ([H, _dp], C.c_int),
         "blues_batch_time_nonbonded": ([H, C.c_int32, _dp], C.c_int),
@@ -300,13 +302,13 @@ ENGINE_SYMBOLS = (
     "blues_tuning_default", "blues_set_tuning", "blues_get_tuning",
     "blues_set_positions", "blues_set_velocities", "blues_set_box", "blues_get_positions",
     "blues_get_velocities", "blues_get_forces", "blues_get_box", "blues_set_velocities_to_temperature",
-    "blues_get_energy", "blues_get_energy_at", "blues_get_energy_terms", "blues_step", "blues_run_switch", "blues_get_global",
+    "blues_get_energy", "blues_get_energy_at", "blues_get_energy_terms", "blues_mesh_energy", "blues_step", "blues_run_switch", "blues_get_global",
     "blues_set_global", "blues_reset", "blues_get_stats", "blues_time_nonbonded", "blues_time_list_build", "blues_audit_lists",
     "blues_snapshot_capture", "blues_snapshot_release", "blues_snapshot_read", "blues_set_positions_from_snapshot",
     "blues_set_velocities_from_snapshot", "blues_snapshot_read_atoms", "blues_set_positions_from_snapshot_edited",
     "blues_batch_create", "blues_batch_destroy", "blues_batch_last_error", "blues_batch_size", "blues_batch_step", "blues_batch_set_active", "blues_batch_prefetch_energies",
     "blues_batch_snapshot_capture", "blues_batch_restore", "blues_batch_restore_edited", "blues_batch_read_atoms", "blues_batch_reset",
-    "blues_batch_set_velocities_to_temperature",
+    "blues_batch_set_velocities_to_temperature", "blues_batch_mesh_energy",
     "blues_batch_get_stats", "blues_batch_get_counters", "blues_batch_time_nonbonded", "blues_batch_time_nonbonded_modes",
     "blues_batch_kernel_timing", "blues_batch_get_kernel_timing", "blues_debug_setup_seconds",
 )

@@ -189,6 +189,7 @@ struct BluesEngine {
     // program is the steady-state one, by k_finalize otherwise
     bool fin_pending = false; double fin_le[3] = {0, 0, 0}; int fin_mask = 7;
     bool have_positions = false, sorted_ok = false, lists_forced = true, relayout_failed = false;
+    bool straggler = false;   // member of a batch whose own layout no longer fits the batch's shape: it steps on launches of its own until it fits again (batch_do_steps)
     std::vector<double> hx;        // host copy of the positions the tiles were last laid out from (caller order, [n][3])
     std::vector<double> h_stage;   // staging for host transfers
     std::vector<double> hx_sort;   // positions at the last sort
@@ -266,7 +267,7 @@ struct BluesEngine {
     template <typename T> struct PmeBufs { DBuf<T> a_re, a_im, b_re, b_im, eterm, tw_cos[3], tw_sin[3], qf_re, qf_im, phi_f; };
     bool pme = false; int pme_K[3] = {0, 0, 0}, pme_order = 5, disp_corr = 0;
     std::vector<double> qn; std::vector<int> pme_frozen;   // NonbondedForce charges (alchemical atoms 0); frozen atoms that carry charge
-    DBuf<double> d_qn, d_frec, d_pme_e; DBuf<int> d_pme_frozen; DBuf<unsigned long long> d_pme_acc;
+    DBuf<double> d_qn, d_qn_full, d_frec, d_pme_e; DBuf<int> d_pme_frozen; DBuf<unsigned long long> d_pme_acc;
     PmeBufs<float> pme_f; PmeBufs<double> pme_d;
     bool pme_static_valid = false;
     double e_ewald_const = 0.0, e_disp = 0.0;   // self term + neutralising background; dispersion correction (functions of the box)
@@ -323,7 +324,7 @@ struct BluesBatch {
     // each member's pending work and the members issue into it; leave: the batch stream is drained, members go home.
     hipStream_t stream = nullptr; bool entered = false;
     DBuf<double> d_gather; int64_t st_prefetch_pe = 0, st_prefetch_ke = 0;
-    int64_t st_lockstep_steps = 0, st_fallback_steps = 0, st_replans = 0, st_relayouts = 0, st_poll_resorts = 0; double st_replan_sec = 0.0, st_resort_sec = 0.0;   // (blues_batch_get_counters)
+    int64_t st_lockstep_steps = 0, st_fallback_steps = 0, st_replans = 0, st_relayouts = 0, st_poll_resorts = 0, st_stragglers = 0, st_rejoined = 0; double st_replan_sec = 0.0, st_resort_sec = 0.0;   // (blues_batch_get_counters)
     // in-situ timing of the nonbonded force kernel (blues_batch_kernel_timing): every `k1t_every`-th lock-step force launch of the
     // stepping loop is bracketed by two events on the stream it runs on; finished pairs are harvested lazily (no synchronisation)
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; bool busy = false; };
@@ -1708,7 +1709,7 @@ template <typename T> static PmeArgs<T> make_pme_args(BluesEngine* h, bool is_st
     P.n_sel = is_static ? (int)h->pme_frozen.size() : (int)h->mobile.size();
     P.sel = is_static ? h->d_pme_frozen.p : h->d_mobile_atoms.p;
     for (int k = 0; k < 3; k++) { P.x[k] = h->d_x[k].p; P.tw_cos[k] = b.tw_cos[k].p; P.tw_sin[k] = b.tw_sin[k].p; }
-    P.qn = h->d_qn.p; P.box = make_box(h); P.acc = h->d_pme_acc.p;
+    P.qn = h->d_qn.p; P.qn_full = h->d_qn_full.p; P.box = make_box(h); P.acc = h->d_pme_acc.p;
     P.a_re = b.a_re.p; P.a_im = b.a_im.p; P.b_re = b.b_re.p; P.b_im = b.b_im.p; P.eterm = b.eterm.p;
     P.qf_re = b.qf_re.p; P.qf_im = b.qf_im.p; P.phi_f = b.phi_f.p; P.have_static = !h->pme_frozen.empty();
     P.frec = h->d_frec.p; P.epart = h->d_pme_e.p; P.want_energy = 0;
@@ -1749,7 +1750,7 @@ template <typename T> static int launch_pme_t(BluesEngine* h, int want_energy) {
         } else hipLaunchKernelGGL(k_pme_b<T>, dim3(h->batch->R()), dim3(PME_THREADS), 0, h->cur, batch_reps_nb<T>(h->batch), want_energy);
     } else {
         pme_ensure_static<T>(h);
-        PmeArgs<T> P = make_pme_args<T>(h, false); P.want_energy = want_energy;
+        PmeArgs<T> P = make_pme_args<T>(h, false); P.want_energy = want_energy & 1; if (want_energy & 2) P.qn = P.qn_full;
         if constexpr (sizeof(T) == 4) {
             if (fast) hipLaunchKernelGGL(k_pme_fast, dim3(1), dim3(PME_THREADS), lds, h->cur, P);
             else hipLaunchKernelGGL((k_pme<T, false>), dim3(1), dim3(PME_THREADS), 0, h->cur, P);
@@ -1795,6 +1796,36 @@ static int resolve_xfer(BluesEngine* h) {
     return 0;
 }
 
+// A member whose lists have outgrown the batch's layout shape.  Round 5 re-planned the shape for EVERYBODY (a re-layout of every member:
+// seconds for a batch of 1024, the other batches of the device waiting) -- and in the benchmark geometry, one compact group of mobile
+// atoms, no other shape holds less, so the whole batch ended on fragment lists for good (7 % slower) because ONE chain's move had thrown
+// a few waters outward for the rest of ONE switch (bench.py: the same chain at the same iteration in every run -- its rotation is drawn from
+// its own stream).  Round 6: such a member becomes a STRAGGLER: it lays itself out on its own (fragment lists), leaves the shared launches
+// (its record is inactive) and is stepped by launches of its own behind them -- ~60 us per step for that one chain, nothing for the others --
+// until its atoms fit the batch's shape again (tried at the start of its next switch: a State that arrives from the MD leg or the restore
+// after a rejection brings the compact arrangement back).  Only when more than a handful of members straggle does the batch re-plan.
+static int relayout(BluesEngine* h);
+static bool batch_can_straggle(const BluesBatch* B, const BluesEngine* h) {
+    if (h->straggler || h->k1_mode != 2 && h->shape_S == 0) return false;
+    int n = 0; for (const BluesEngine* m : B->eng) n += m->straggler;
+    return n + 1 <= std::max(1, B->R() / 32) && B->R() > 1;
+}
+static int make_straggler(BluesBatch* B, BluesEngine* h) {
+    h->straggler = true; h->forbid_atom = true; h->shape_S = 0; h->shape_jcap = 0; h->shape_overflow = false;
+    B->st_stragglers++;
+    if (h->tune.debug_lists) fprintf(stderr, "[straggler] member %d leaves the shared launches at step %d\n", h->batch_index, h->h_step);
+    return relayout(h);
+}
+// ... and back: the batch's shape, if the member's atoms fit it now (its first step of a switch)
+static int try_rejoin(BluesBatch* B, BluesEngine* h, const BluesEngine* like) {
+    h->forbid_atom = false; h->shape_S = like->S; h->shape_jcap = like->jcap;
+    if (relayout(h)) return 1;
+    if (h->sorted_ok && h->k1_mode == 2 && !h->shape_overflow && h->S == like->S && h->jcap == like->jcap) { h->straggler = false; B->st_rejoined++; return 0; }
+    h->straggler = false;   // (make_straggler counts it again: st_stragglers is "times a member left", st_rejoined "times one came back")
+    B->st_stragglers--;
+    return make_straggler(B, h);
+}
+
 static int ensure_sorted(BluesEngine* h) {
     if (resolve_xfer(h)) return 1;
     if (!h->have_positions) E_FAIL(h, "positions have not been set");
@@ -1804,6 +1835,7 @@ static int ensure_sorted(BluesEngine* h) {
     // every RESORT_POLL steps, too late for a hand-over)
     if (h->shape_overflow && h->batch && !h->batch->lockstep && !h->batch->replanning) {
         BluesBatch* B = h->batch;
+        if (batch_can_straggle(B, h)) return make_straggler(B, h);
         B->replanning = true;
         hipStreamSynchronize(B->stream);
         const int rc = batch_plan_shape(B, false);
@@ -2555,7 +2587,7 @@ static bool batch_congruent_cached(BluesBatch* B, int r, const BluesEngine* lead
 static int batch_refresh_args(BluesBatch* B) {
     bool dirty = false;
     BluesEngine* lead = B->leader ? B->leader : B->eng[0];
-    for (int r = 0; r < B->R(); r++) dirty |= B->seen_epoch[r] != B->eng[r]->args_epoch || B->rec_active[r] != (char)(B->active[r] && !B->failed[r])
+    for (int r = 0; r < B->R(); r++) dirty |= B->seen_epoch[r] != B->eng[r]->args_epoch || B->rec_active[r] != (char)(B->active[r] && !B->failed[r] && !B->eng[r]->straggler)
                                               || (!B->failed[r] && B->rec_delta[r] != B->eng[r]->h_draw - lead->h_draw);
     if (!dirty) return 0;
     const double one[3] = {1.0, 1.0, 1.0};
@@ -2564,7 +2596,7 @@ static int batch_refresh_args(BluesBatch* B) {
     if (single) nf.resize(B->R()); else nd.resize(B->R());
     for (int r = 0; r < B->R(); r++) {
         BluesEngine* h = B->eng[r];
-        B->rec_active[r] = (char)(B->active[r] && !B->failed[r]);
+        B->rec_active[r] = (char)(B->active[r] && !B->failed[r] && !h->straggler);   // (a straggler's kernels are its own: the shared launches pass it by)
         core[r].active = B->rec_active[r];
         B->rec_delta[r] = h->h_draw - lead->h_draw; core[r].draw_delta = B->rec_delta[r];
         if (single) nf[r].active = B->rec_active[r]; else nd[r].active = B->rec_active[r];
@@ -2592,11 +2624,11 @@ static int batch_prefetch(BluesBatch* B, int what) {
     if (R == 0) return 0;
     std::vector<char> live(R), need(R, 0);
     for (int r = 0; r < R; r++) if (B->active[r] && !B->failed[r] && resolve_xfer(B->eng[r])) B->failed[r] = 1;
-    for (int r = 0; r < R; r++) live[r] = B->active[r] && !B->failed[r] && B->eng[r]->have_positions && B->eng[r]->sorted_ok;
+    for (int r = 0; r < R; r++) live[r] = B->active[r] && !B->failed[r] && B->eng[r]->have_positions && B->eng[r]->sorted_ok && !B->eng[r]->straggler;   // (a straggler evaluates on demand, with launches of its own)
     BluesEngine* lead = nullptr;
     for (int r = 0; r < R; r++) if (live[r]) { lead = B->eng[r]; break; }
     if (!lead) return 0;
-    for (int r = 0; r < R; r++) if (B->active[r] && !B->failed[r] && !live[r]) return 0;   // a member without a layout yet: everybody evaluates on demand
+    for (int r = 0; r < R; r++) if (B->active[r] && !B->failed[r] && !live[r] && !B->eng[r]->straggler) return 0;   // a member without a layout yet: everybody evaluates on demand
     const bool was_entered = B->entered;
     bool ok = true;
     auto pe_pass = [&]() -> int {   // potential energies at the members' CURRENT alchemical parameters
@@ -2735,10 +2767,17 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
     for (int r = 0; r < R; r++) { status[r] = 0; B->eng[r]->tracing = tracing; if (!B->active[r]) B->failed[r] = 1; }
     auto fail = [&](int r) { B->failed[r] = 1; status[r] = 1; };
     for (int r = 0; r < R; r++) if (!B->failed[r] && ensure_sorted(B->eng[r])) fail(r);
-    auto pick_leader = [&]() { B->leader = nullptr; for (int r = 0; r < R; r++) if (!B->failed[r]) { B->leader = B->eng[r]; break; } };
+    // the leader issues the shared launches: a member in the batch's layout (stragglers issue their own)
+    auto pick_leader = [&]() { B->leader = nullptr; for (int r = 0; r < R; r++) if (!B->failed[r] && !B->eng[r]->straggler) { B->leader = B->eng[r]; break; } };
+    auto any_straggler = [&]() { for (int r = 0; r < R; r++) if (!B->failed[r] && B->eng[r]->straggler) return true; return false; };
     pick_leader();
-    if (!B->leader) return 0;
-    for (int r = 0; r < R; r++) if (!B->failed[r]) {
+    if (B->leader) for (int r = 0; r < R; r++) if (!B->failed[r] && B->eng[r]->straggler && B->eng[r]->h_step == 0 && B->eng[r]->have_positions) {
+        // a straggler at the start of a switch: back into the shared launches if its atoms fit the batch's shape again
+        if (hipStreamSynchronize(B->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
+        if (try_rejoin(B, B->eng[r], B->leader)) fail(r);
+    }
+    if (!B->leader && !any_straggler()) return 0;
+    for (int r = 0; r < R; r++) if (!B->failed[r] && !B->eng[r]->straggler) {
         const char* why = "";
         if (!batch_congruent_cached(B, r, B->leader, &why)) { B->err = std::string("replicas of a batch must be congruent; they differ in ") + why; return 1; }
     }
@@ -2746,24 +2785,28 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
     // phase(f): run f on every live member, in lock step when their signatures agree
     auto phase = [&](int (*f)(BluesEngine*)) -> int {
         pick_leader();
-        if (!B->leader) return 0;
+        if (!B->leader && !any_straggler()) return 0;
         if (batch_refresh_args(B)) return 1;   // leader change, a member dropped out, a re-sort: cheap no-op otherwise
-        const BatchSig lead = batch_sig(B->leader);
-        bool uniform = true;
-        for (int r = 0; r < R && uniform; r++) if (!B->failed[r]) { const BatchSig g = batch_sig(B->eng[r]); uniform = !memcmp(&g, &lead, sizeof g); }
-        if (uniform) {
-            B->lockstep = true;
-            for (int r = 0; r < R; r++) if (!B->failed[r] && f(B->eng[r])) {
-                // a host-side failure of the leader leaves the shared launch sequence incomplete: every member is affected
-                if (B->eng[r] == B->leader) { for (int q = 0; q < R; q++) if (!B->failed[q]) { if (q != r) B->eng[q]->err = "batch leader failed: " + B->leader->err; fail(q); } }
-                else fail(r);
+        if (B->leader) {
+            const BatchSig lead = batch_sig(B->leader);
+            bool uniform = true;
+            for (int r = 0; r < R && uniform; r++) if (!B->failed[r] && !B->eng[r]->straggler) { const BatchSig g = batch_sig(B->eng[r]); uniform = !memcmp(&g, &lead, sizeof g); }
+            if (uniform) {
+                B->lockstep = true;
+                for (int r = 0; r < R; r++) if (!B->failed[r] && !B->eng[r]->straggler && f(B->eng[r])) {
+                    // a host-side failure of the leader leaves the shared launch sequence incomplete: every member is affected
+                    if (B->eng[r] == B->leader) { for (int q = 0; q < R; q++) if (!B->failed[q] && !B->eng[q]->straggler) { if (q != r) B->eng[q]->err = "batch leader failed: " + B->leader->err; fail(q); } }
+                    else fail(r);
+                }
+                B->lockstep = false;
+                B->st_lockstep_steps++;
+            } else {
+                for (int r = 0; r < R; r++) if (!B->failed[r] && !B->eng[r]->straggler && f(B->eng[r])) fail(r);
+                B->st_fallback_steps++;
             }
-            B->lockstep = false;
-            B->st_lockstep_steps++;
-        } else {
-            for (int r = 0; r < R; r++) if (!B->failed[r] && f(B->eng[r])) fail(r);
-            B->st_fallback_steps++;
         }
+        // the stragglers: the same function, launches of their own (behind the shared ones, on the batch's stream)
+        for (int r = 0; r < R; r++) if (!B->failed[r] && B->eng[r]->straggler && f(B->eng[r])) fail(r);
         return 0;
     };
     for (int s = 0; s < n_steps; s++) {
@@ -2774,14 +2817,14 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
             for (int r = 0; r < R; r++) due |= !B->failed[r] && B->eng[r]->h_step > 0 && B->eng[r]->h_step % RESORT_POLL == 0;
             if (due) {
                 pick_leader();
-                if (!B->leader) return 0;
+                if (!B->leader && !any_straggler()) return 0;
                 if (phase(flush_program)) return 1;
                 if (batch_refresh_args(B)) return 1;
                 std::vector<int> hints;
                 try {
                     if ((int)B->d_hints.n != R) B->d_hints.alloc(R);
-                    hipLaunchKernelGGL(k_gather_hints_b, dim3((R + 255) / 256), dim3(256), 0, B->leader->stream, B->d_core.p, R, B->d_hints.p);
-                    if (hipStreamSynchronize(B->leader->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
+                    hipLaunchKernelGGL(k_gather_hints_b, dim3((R + 255) / 256), dim3(256), 0, B->stream, B->d_core.p, R, B->d_hints.p);
+                    if (hipStreamSynchronize(B->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
                     B->d_hints.download(hints);
                 } catch (std::string& e) { B->err = e; return 1; }
                 {   // the members whose builders asked for a new order: re-sorted on the host's cores together (5-10 ms of host work each)
@@ -2805,11 +2848,17 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
                         B->st_resort_sec += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rs).count();
                     }
                 }
-                {   // a member whose lists have outgrown the batch's layout shape: a new shape for everybody (rare)
+                {   // a member whose lists have outgrown the batch's layout shape: it steps on its own from here (make_straggler); a new
+                    // shape for everybody only when more than a handful have (rare: a run whose mobile atoms scatter for good)
                     bool over = false;
-                    for (int r = 0; r < R; r++) over |= !B->failed[r] && B->eng[r]->shape_overflow;
+                    for (int r = 0; r < R; r++) if (!B->failed[r] && B->eng[r]->shape_overflow && !B->eng[r]->straggler) {
+                        if (batch_can_straggle(B, B->eng[r])) {
+                            if (hipStreamSynchronize(B->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
+                            if (make_straggler(B, B->eng[r])) fail(r);
+                        } else over = true;
+                    }
                     if (over) {
-                        if (hipStreamSynchronize(B->leader->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
+                        if (hipStreamSynchronize(B->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
                         if (batch_plan_shape(B, false)) return 1;
                         B->st_replans++;
                     }
@@ -2847,11 +2896,11 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
     pick_leader();
     bool gathered = false;
     std::vector<int> hints;
-    if (B->leader && !batch_refresh_args(B)) {
+    if ((B->leader || any_straggler()) && !batch_refresh_args(B)) {
         try {
             if ((int)B->d_hints.n != R) B->d_hints.alloc(R);
-            hipLaunchKernelGGL(k_gather_hints_b, dim3((R + 255) / 256), dim3(256), 0, B->leader->stream, B->d_core.p, R, B->d_hints.p);
-            if (hipStreamSynchronize(B->leader->stream) == hipSuccess) { B->d_hints.download(hints); gathered = (int)hints.size() == R; }
+            hipLaunchKernelGGL(k_gather_hints_b, dim3((R + 255) / 256), dim3(256), 0, B->stream, B->d_core.p, R, B->d_hints.p);
+            if (hipStreamSynchronize(B->stream) == hipSuccess) { B->d_hints.download(hints); gathered = (int)hints.size() == R; }
         } catch (std::string&) { gathered = false; }
     }
     B->leader = B->eng[0];
@@ -2979,7 +3028,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     if (h->pme) {
         h->qn = h->charge; for (int a : h->alch) h->qn[a] = 0.0;
         for (int i = 0; i < n; i++) if (h->mass[i] == 0.0 && h->qn[i] != 0.0) h->pme_frozen.push_back(i);
-        try { h->d_qn.upload(h->qn); h->d_pme_frozen.upload(h->pme_frozen); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+        try { h->d_qn.upload(h->qn); h->d_qn_full.upload(h->charge); h->d_pme_frozen.upload(h->pme_frozen); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
         if (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h)) return 1;
     }
     if (build_clusters(h, s)) return 1;
@@ -3104,12 +3153,14 @@ static int batch_plan_shape(BluesBatch* B, bool fresh) {
         if (!same) { B->st_relayouts++; if (relayout(m)) return fail(m); }
     }
     BluesEngine* lead = B->eng[0];
+    for (BluesEngine* m : B->eng) if (!m->straggler) { lead = m; break; }   // (a member in the batch's layout speaks for it)
     if (lead->k1_mode != 2) {   // the other modes size everything from the topology or the density: congruent by construction
         // (a re-plan in the middle of a run finds the leader here when ITS tiles fit no shape any more -- scattered mobile atoms: it is in
         // the sub-tile layout for want of a shape, and everybody, the leader included, moves on to fragment lists)
         if (BluesEngine* bad = relayout_counted([&](BluesEngine* m) {
                 const bool need = m->k1_mode == 2 || (!fresh && !m->forbid_atom && m->k1_mode != 3);
                 if (need) m->forbid_atom = true;   // (members that stay as they are keep their flags: their next re-sort must give the same mode again)
+                m->straggler = false;              // (everybody is in one layout again)
                 return need; })) return fail(bad);
         return 0;
     }
@@ -3125,23 +3176,25 @@ static int batch_plan_shape(BluesBatch* B, bool fresh) {
             const int c = SHAPE_CAND[q];
             if (c > S) continue;
             double need = 0.0, rad = 0.0; bool known = true;
-            for (BluesEngine* m : B->eng) { if (!m->need_table_ok || m->k1_mode != 2) { known = false; continue; } need = std::max(need, m->need_by_S[q]); rad = std::max(rad, m->rad_by_S[q]); }
+            for (BluesEngine* m : B->eng) { if (m->straggler) continue; if (!m->need_table_ok || m->k1_mode != 2) { known = false; continue; } need = std::max(need, m->need_by_S[q]); rad = std::max(rad, m->rad_by_S[q]); }
             if (!known && need == 0.0) { pick = c; cap = lds_max; break; }   // (nobody has a table yet: the sweep below produces them)
             if (2.0 * rad + 1.0 + 0.6 >= longest) continue;                 // (the ghost record's place: sort_and_tile)
             if (need * 1.3 + 64 > lds_max) continue;
             pick = c; cap = need * 1.3 + 64 <= 3328 ? 3328 : lds_max;      // the two capacities of sort_and_tile
         }
         if (!pick) {   // not even one tile per list fits: fragment lists (or the bitmask kernels) for everybody
-            if (BluesEngine* bad = relayout_counted([](BluesEngine* m) { m->forbid_atom = true; m->shape_S = 0; m->shape_jcap = 0; return true; })) return fail(bad);
+            if (BluesEngine* bad = relayout_counted([](BluesEngine* m) { m->forbid_atom = true; m->shape_S = 0; m->shape_jcap = 0; m->straggler = false; return true; })) return fail(bad);
             return 0;
         }
         // members that can take the shape as they are move to it in place; the others (another capacity, another mode, no layout)
         // are laid out under it, on the host's cores
         if (BluesEngine* bad = relayout_counted([&](BluesEngine* m) {
+                if (m->straggler) return false;      // (it keeps its own layout while the others change shape)
                 if (reshape_possible(m, pick, cap)) return false;
                 m->shape_S = pick; m->shape_jcap = cap; return true; })) return fail(bad);
         bool again = false;
         for (BluesEngine* m : B->eng) {
+            if (m->straggler) continue;
             if (m->k1_mode != 2) { again = true; continue; }            // (its own geometry fits no group shape under this S: a finer one)
             if (m->S != pick || m->shape_S != pick || m->shape_jcap != cap) { if (reshape_groups(m, pick, cap)) return fail(m); }
             again |= m->shape_overflow || m->jcap != cap;
@@ -3625,6 +3678,68 @@ int blues_time_list_build(BluesEngine* h, int32_t reps, double* usec) {
     return check_flags(h);
 }
 
+// ---- the reciprocal-space mesh energy at the current positions, with the NonbondedForce charges of this (alchemical) System or with
+// every atom's own charge (what the non-alchemical System of the MD / alch contexts carries): include/blues_engine.h, blues_mesh_energy
+int blues_mesh_energy(BluesEngine* h, int32_t with_alchemical_charges, double* out) {
+    if (!out) E_FAIL(h, "mesh energy: no output");
+    HIP_OK(h, hipSetDevice(h->device));
+    *out = 0.0;
+    if (!h->pme) return 0;
+    if (flush_program(h)) return 1;
+    if (ensure_sorted(h)) return 1;
+    h->fin_pending = false; h->pass_valid = false;   // (the launch overwrites the reciprocal-space forces of the last pass)
+    if (launch_pme(h, 1 | (with_alchemical_charges ? 2 : 0))) return 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    HIP_OK(h, hipMemcpy(out, h->d_pme_e.p, sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int blues_batch_mesh_energy(BluesBatch* B, int32_t with_alchemical_charges, const int32_t* mask, double* out) {
+    if (!B || B->eng.empty() || !out) { if (B) B->err = "mesh energy: no batch / no output"; return 2; }
+    const int R = B->R();
+    if (hipSetDevice(B->eng[0]->device) != hipSuccess) { B->err = "hipSetDevice failed"; return 1; }
+    for (int r = 0; r < R; r++) out[r] = 0.0;
+    BluesEngine* lead = nullptr;
+    B->failed.assign(R, 0);
+    std::vector<int> alone;   // (stragglers: their own launches)
+    for (int r = 0; r < R; r++) {
+        B->active[r] = mask ? (mask[r] != 0) : 1;
+        if (!B->active[r]) continue;
+        BluesEngine* m = B->eng[r];
+        if (flush_program(m) || ensure_sorted(m)) { B->err = "mesh energy: " + m->err; return 1; }
+        m->fin_pending = false; m->pass_valid = false;
+        if (m->straggler) { alone.push_back(r); B->active[r] = 0; continue; }
+        if (!lead) lead = m;
+    }
+    for (int r : alone) if (blues_mesh_energy(B->eng[r], with_alchemical_charges, &out[r])) { B->err = "mesh energy: " + B->eng[r]->err; for (int q = 0; q < R; q++) B->active[q] = 1; return 1; }
+    if (!lead || !lead->pme) { for (int q = 0; q < R; q++) B->active[q] = 1; return 0; }
+    for (int r = 0; r < R; r++) if (B->active[r]) { const char* why = ""; if (!batch_congruent_cached(B, r, lead, &why)) { B->err = std::string("mesh energy: members differ in ") + why; return 1; } }
+    const bool was_entered = B->entered;
+    if (batch_enter(B)) return 1;
+    B->leader = lead;
+    int rc = batch_refresh_args(B);
+    if (!rc) {
+        B->lockstep = true;
+        for (int r = 0; r < R && !rc; r++) if (B->active[r]) rc = launch_pme(B->eng[r], 1 | (with_alchemical_charges ? 2 : 0));
+        B->lockstep = false;
+        if (rc) B->err = "mesh energy: " + lead->err;
+    }
+    if (!rc) {
+        try {
+            if (B->d_gather.n < (size_t)R) B->d_gather.alloc((size_t)R);
+            if (lead->precision == 0) hipLaunchKernelGGL(k_gather_pme_e_b<float>, dim3((R + 255) / 256), dim3(256), 0, B->stream, B->d_nb_f.p, R, B->d_gather.p);
+            else hipLaunchKernelGGL(k_gather_pme_e_b<double>, dim3((R + 255) / 256), dim3(256), 0, B->stream, B->d_nb_d.p, R, B->d_gather.p);
+            std::vector<double> got(R, 0.0);
+            if (hipStreamSynchronize(B->stream) != hipSuccess || hipMemcpy(got.data(), B->d_gather.p, sizeof(double) * R, hipMemcpyDeviceToHost) != hipSuccess) { B->err = "mesh energy: read-back failed"; rc = 1; }
+            else for (int r = 0; r < R; r++) if (B->active[r]) out[r] = got[r];
+        } catch (std::string& e) { B->err = e; rc = 1; }
+    }
+    if (!was_entered) batch_leave(B);
+    B->leader = B->eng[0];
+    for (int r = 0; r < R; r++) B->active[r] = 1;
+    return rc;
+}
+
 // ---- State snapshots (include/blues_engine.h, "Device-resident State")
 int blues_snapshot_capture(BluesEngine* h, int32_t what, BluesSnapshot** out) {
     if (!out || !(what & 3)) E_FAIL(h, "snapshot: nothing requested");
@@ -3898,7 +4013,11 @@ int blues_batch_get_counters(BluesBatch* b, double out[BLUES_N_BATCH_COUNTERS]) 
     for (int q = 0; q < BLUES_N_BATCH_COUNTERS; q++) out[q] = 0.0;
     out[0] = (double)b->st_replans; out[1] = b->st_replan_sec; out[2] = (double)b->st_relayouts; out[3] = (double)b->st_poll_resorts; out[4] = b->st_resort_sec;
     for (const BluesEngine* m : b->eng) { out[5] += (double)m->st_reshapes; out[6] += (double)m->st_resorts; }
-    if (!b->eng.empty()) { out[7] = (double)b->eng[0]->S; out[8] = (double)b->eng[0]->jcap; out[9] = (double)b->eng[0]->k1_mode; }
+    const BluesEngine* rep = nullptr;
+    for (const BluesEngine* m : b->eng) { if (!m->straggler && !rep) rep = m; out[10] += m->straggler ? 1.0 : 0.0; }
+    if (!rep && !b->eng.empty()) rep = b->eng[0];
+    if (rep) { out[7] = (double)rep->S; out[8] = (double)rep->jcap; out[9] = (double)rep->k1_mode; }
+    out[11] = (double)b->st_stragglers; out[12] = (double)b->st_rejoined;
     return 0;
 }
 

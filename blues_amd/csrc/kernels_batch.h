@@ -212,15 +212,22 @@ template <typename R>
 __global__ void __launch_bounds__(PME_THREADS) k_pme_b(const RepNb<R>* __restrict__ reps, int want_energy) {
     const RepNb<R>& rp = reps[blockIdx.x];
     if (!rp.active) return;
-    PmeArgs<R> P = rp.pme; P.want_energy = want_energy;
+    PmeArgs<R> P = rp.pme; P.want_energy = want_energy & 1; if (want_energy & 2) P.qn = P.qn_full;
     pme_body<R, false, 5>(P);
 }
 
 __global__ void __launch_bounds__(PME_THREADS) k_pme_fast_b(const RepNb<float>* __restrict__ reps, int want_energy) {
     const RepNb<float>& rp = reps[blockIdx.x];
     if (!rp.active) return;
-    PmeArgs<float> P = rp.pme; P.want_energy = want_energy;
+    PmeArgs<float> P = rp.pme; P.want_energy = want_energy & 1; if (want_energy & 2) P.qn = P.qn_full;
     pme_fast_body<5>(P);
+}
+
+// the members' mesh energies (PmeArgs::epart) side by side: one read-back for the batch (blues_batch_mesh_energy)
+template <typename R>
+__global__ void __launch_bounds__(256) k_gather_pme_e_b(const RepNb<R>* __restrict__ reps, int nrep, double* __restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < nrep) out[r] = reps[r].active && reps[r].pme.epart ? reps[r].pme.epart[0] : 0.0;
 }
 
 // stale: null = every member; else the work list of the rebuild (k_gather_stale_b): the members that rebuild are left to

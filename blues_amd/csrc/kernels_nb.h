@@ -734,6 +734,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); typedef float f32x4 __attribute__((ext_vector_type(4))); typedef float f32x2 __attribute__((ext_vector_type(2)));   // (plain vector types: loads through an address-space pointer stay loads)
     extern __shared__ __align__(16) unsigned char nb_smem[];   // (the kernel has NO static LDS: the dynamic area then starts at address 0 and a list entry IS an LDS address)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    const bool stamp_wg = t == 0 && blockIdx.x == (gridDim.x * 5u) / 8u;   // (stamped builds: ONE workgroup of the launch's third quarter writes the phase stamps)
     if (t == 0 && tid == 0) { a.flags->list_gen = a.flags->req_gen; if (a.batch_req) *a.batch_req = 0; }  // lists are current for this pass
     if (t >= a.n_lists) return;
     // Every pointer below arrives inside an argument record read from memory, i.e. as a GENERIC pointer: left like that, each
@@ -806,7 +807,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
     const auto s_e = L3(double, lds + NB_LQ_BYTES + 16 * a.jcap + 16);   // [16][2], energy kernel only
     if (tid == 0) *s_next = nw;   // (the first nw atoms are dealt statically; the barrier behind the image staging publishes this)
     auto grab = [&]() -> int { int v = 0; if (lane == 0) v = __hip_atomic_fetch_add(s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return __builtin_amdgcn_readfirstlane(v); };
-    NB_STAMP(t == 0 && tid == 0, 16);
+    NB_STAMP(stamp_wg && tid == 0, 16);
     // Round 6: the prologue as THREE dependent round trips instead of seven.  A 5-atom group's workgroup took 37 us beside 62 us for
     // the 256-atom one (scripts/r06_sweep_groups.sh: the same launch with 4 + 1 tiles per chain): more than half of a workgroup's time was
     // this prologue -- count -> tile_atoms -> pneed -> acount -> image copy -> barrier -> mcount -> mlist -> live image -> barrier, each a
@@ -827,7 +828,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
         }
         s_slot[2 * sl] = r0; s_slot[2 * sl + 1] = r1;
     }
-    NB_STAMP(t == 0 && tid == 0, 17);
+    NB_STAMP(stamp_wg && tid == 0, 17);
     {
         // the packed image (frozen entries as the builder left them, the ghost behind them): a straight copy, every load of a
         // thread in flight before its first LDS store; then the few mobile entries from the live image
@@ -854,9 +855,9 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
             pj[0] = g_img[js].x; pj[1] = g_img[js].y; pj[2] = g_img[js].z;
         }
     }
-    NB_STAMP(t == 0 && tid == 0, 18);
+    NB_STAMP(stamp_wg && tid == 0, 18);
     __syncthreads();
-    NB_STAMP(t == 0 && tid == 0, 19);
+    NB_STAMP(stamp_wg && tid == 0, 19);
     // constants of the pair body, in vector registers (see the header)
 #define NB_VREG(x) asm volatile("" : "+v"(x))
     float kw[EWALD_POLY_DEG + 1];
@@ -1011,7 +1012,7 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
                 __hip_atomic_fetch_add(&g_flags->prunes, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        NB_STAMP(t == 0 && tid == 0, 20 + min(2 * (s / nw), 6));
+        NB_STAMP(stamp_wg && tid == 0, 20 + min(2 * (s / nw), 6));
         // 64 lanes -> one force: fp32 on DPP, fixed order (bitwise reproducible).  A lane's partial is a few pair terms of at
         // most ~10^3 kJ/mol/nm; six levels of fp32 adds put ~10^-3 kJ/mol/nm on a force of that size, the rounding the
         // per-lane fp32 accumulation carries anyway (tolerance: 10^-5 of the largest force, ~2 10^-2).  Lists past the
@@ -1026,11 +1027,11 @@ __device__ __forceinline__ void nonbonded_atom_body(const NbArgs<float>& a, cons
             fx += (double)sx; fy += (double)sy; fz += (double)sz;
             if (lane == 0) { g_fpart[islot] = fx; g_fpart[a.n_islots + islot] = fy; g_fpart[2 * a.n_islots + islot] = fz; }
         }
-        NB_STAMP(t == 0 && tid == 0, 21 + min(2 * (s / nw), 6));
+        NB_STAMP(stamp_wg && tid == 0, 21 + min(2 * (s / nw), 6));
     }
 #undef G1
 #undef NB_VREG
-    NB_STAMP(t == 0 && lane == 0, 44 + min(wv, 15));   // (stamped builds: when each wave ran out of atoms)
+    NB_STAMP(stamp_wg && lane == 0, 44 + min(wv, 15));   // (stamped builds: when each wave ran out of atoms)
     if (ENERGY) {
         elj = wave_sum(elj); ecl = wave_sum(ecl);
         if (lane == 0) { s_e[2 * wv] = elj; s_e[2 * wv + 1] = ecl; }

@@ -26,6 +26,7 @@ template <typename T> struct PmeArgs {
     int n_sel; const int* sel;         // atoms this launch spreads (and gathers): caller indices
     const double* x[3];                // master positions
     const double* qn;                  // [n] NonbondedForce charges (alchemical atoms: 0)
+    const double* qn_full;             // [n] every atom's own charge: the NonbondedForce of the NON-alchemical System (want_energy bit 1: the mesh energy the MD / alch context would report)
     Box3 box;
     unsigned long long* acc;           // [ng] fixed-point charge mesh
     T* a_re; T* a_im; T* b_re; T* b_im;   // work meshes

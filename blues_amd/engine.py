@@ -124,6 +124,10 @@ class NativeEngine:
     def energy_terms(self):
         t = np.zeros(_abi.N_ENERGY_TERMS); self._check(self._lib.blues_get_energy_terms(self._h, self._ptr(t))); return t
 
+    def mesh_energy(self, with_alchemical_charges=False):
+        """Reciprocal-space mesh energy of the current coordinates (kJ/mol; 0 without PME): include/blues_engine.h, blues_mesh_energy."""
+        e = C.c_double(); self._check(self._lib.blues_mesh_energy(self._h, 1 if with_alchemical_charges else 0, C.byref(e))); return e.value
+
     def step(self, n=1):
         self.__dict__["_gcache"] = {}
         self._check(self._lib.blues_step(self._h, int(n)))
@@ -354,12 +358,20 @@ class NativeBatch:
         if self._lib.blues_batch_set_velocities_to_temperature(self._h, float(temperature), sd, self._mask(active)):
             self._fail()
 
+    def mesh_energy_all(self, with_alchemical_charges=False, active=None):
+        """(R,) reciprocal-space mesh energies of the members' current coordinates: one launch, one read-back (blues_batch_mesh_energy)."""
+        out = np.zeros(len(self.engines))
+        if self._lib.blues_batch_mesh_energy(self._h, 1 if with_alchemical_charges else 0, self._mask(active), out.ctypes.data_as(_dp)):
+            self._fail()
+        return out
+
     def stats(self):
         s = (C.c_int64 * 4)()
         self._lib.blues_batch_get_stats(self._h, s)
         return {"lockstep_steps": s[0], "fallback_steps": s[1], "replicas": s[2], "batched_energy_evaluations": s[3]}
 
-    COUNTERS = ("replans", "replan_seconds", "relayouts", "poll_resorts", "resort_seconds", "reshapes", "resorts", "tiles_per_list", "jcap", "nonbonded_kernel")
+    COUNTERS = ("replans", "replan_seconds", "relayouts", "poll_resorts", "resort_seconds", "reshapes", "resorts", "tiles_per_list", "jcap", "nonbonded_kernel",
+                "stragglers", "straggled", "rejoined")
 
     def counters(self):
         """What the batch's layout has cost so far (include/blues_engine.h: blues_batch_get_counters): re-plans of the layout shape and

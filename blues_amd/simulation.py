@@ -64,16 +64,17 @@ def write_state(context, table_entry, parts=_STATE_ORDER):
     return context
 
 
-def metropolis(chain, unmodified_at_x1=None):
+def metropolis(chain, unmodified_at_x1=None, correction=None):
     """The NCMC acceptance test of one chain (reference blues/simulation.py:1121-1140): log-acceptance of the protocol work plus
     the alchemical correction against the log of a uniform draw.  Returns the decision record; changes nothing.
-    unmodified_at_x1: the `alch` context's energy at the switched coordinates where a batch has evaluated it for all chains."""
+    unmodified_at_x1: the `alch` context's energy at the switched coordinates where a batch has evaluated it for all chains.
+    correction: the correction itself where a batch has formed it as a differential (BatchedBLUESSimulation._decide_batched)."""
     integrator = chain._ncmc_sim.context._integrator
     log_p = integrator.getLogAcceptanceProbability(chain._ncmc_sim.context)
     log_u = math.log(chain._rng.random_sample())
-    correction = 0.0
+    given, correction = correction, 0.0
     if not np.isnan(log_p):       # a NaN work rejects without asking for energies (the reference's guard)
-        correction = chain._computeAlchemicalCorrection(unmodified_at_x1)
+        correction = chain._computeAlchemicalCorrection(unmodified_at_x1) if given is None else float(given)
         logger.debug('NCMCLogAcceptanceProbability = %.6f + Alchemical Correction = %.6f' % (log_p, correction))
         log_p = log_p + correction
     return {'accept': bool(log_p > log_u), 'log_accept': float(log_p), 'correction': float(correction), 'randnum': log_u,
@@ -99,10 +100,32 @@ def record_decision(chain, decision):
 class BLUESSimulation(object):
     """One BLUES chain: `run` = nIter x (sync MD -> NCMC, NCMC switch with the Move's hooks, Metropolis test, reset, MD leg)."""
 
-    def __init__(self, simulations, config=None, move_engine=None, rng=None):
+    def __init__(self, simulations, config=None, move_engine=None, rng=None, differential_correction=None):
+        """differential_correction: None (default) = form the alchemical correction (reference blues/simulation.py:1100-1119) from the
+        terms in which the `alch` System and the NCMC System at lambda = 1 differ, evaluated in the NCMC engine, wherever the two
+        Systems are recognisably one force field (systems.alchemical_difference_plan) -- SURVEY.md 8f.3; the reference's four total
+        energies otherwise.  False: always the four energies (the form the differential is tested against).  True: insist."""
         # the reference draws from numpy's global stream (simulation.py:1133); a private RandomState can be handed in
         # where several chains are driven from worker threads (BatchedBLUESSimulation)
         self._rng = np.random if rng is None else rng
+        self._diff_plan = None
+        if differential_correction is not False and simulations.alch is not None:
+            from . import systems
+            a, p = getattr(simulations.ncmc, "system", None), getattr(simulations.alch, "system", None)
+            m = getattr(simulations.md, "system", None) if simulations.md is not None else p
+            try:
+                plan = systems.alchemical_difference_plan(a, p) if hasattr(a, "n_atoms") and hasattr(p, "n_atoms") else None
+                if plan is not None and m is not p and systems.alchemical_difference_plan(a, m) is None:
+                    plan = None        # (the MD System is another force field than the alch one: U_md(x0) is then not U_alch(x0))
+            except Exception:
+                plan = None
+            eng = getattr(simulations.ncmc.context, "_engine", None)
+            if plan is not None and plan["kind"] == "pme" and not hasattr(eng, "mesh_energy"):
+                plan = None
+            self._diff_plan = plan
+            if differential_correction is True and plan is None:
+                raise ValueError("differential_correction=True, but the alch / md Systems are not the NCMC System's force field without its alchemical atoms")
+        self._dU0 = None
         self._move_engine = move_engine if move_engine is not None else getattr(simulations, "_move_engine", None)
         self._md_sim, self._alch_sim, self._ncmc_sim = simulations.md, simulations.alch, simulations.ncmc
         self._config = config or {}
@@ -146,6 +169,22 @@ class BLUESSimulation(object):
             ctx.setParameter(p, v)
         return e
 
+    # ---- D(x) = U_alch(x) - U_ncmc(x; lambda = 1) from the terms in which the two Systems differ
+    def _alchemical_difference(self):
+        """D at the NCMC context's current coordinates (kJ/mol).  Zero without reciprocal space; with PME the ligand's share of the
+        mesh energy (two launches of the NCMC engine's own mesh kernel), the erf corrections of the excluded pairs that hold an
+        alchemical atom (host arithmetic on a handful of atoms), and constants of the box."""
+        plan = self._diff_plan
+        if plan["kind"] == "zero":
+            return 0.0
+        from . import systems
+        ctx = self._ncmc_sim.context
+        eng = ctx._engine
+        mesh = eng.mesh_energy(True) - eng.mesh_energy(False)
+        xyz = ctx.getState(getPositions=True).getPositions(asNumpy=True)[[int(i) for i in plan["atoms"]]]
+        xyz = np.asarray(getattr(xyz, "_value", xyz), dtype=np.float64)
+        return float(mesh + plan["const"] + systems.excluded_pair_term(plan, xyz))
+
     # ---- reference blues/simulation.py:1028-1037
     def _syncStatesMDtoNCMC(self):
         if self._md_sim is None:
@@ -157,6 +196,8 @@ class BLUESSimulation(object):
         entry = read_state(self._md_sim.context, self._state_keys)
         self._setStateTable('md', 'state0', entry)
         self._ncmc_sim.context = write_state(self._ncmc_sim.context, entry)
+        if self._diff_plan is not None:
+            self._dU0 = self._alchemical_difference()      # (at x0, while the NCMC context holds it)
 
     # ---- reference blues/simulation.py:1039-1098
     def _ncmc_plan(self, nstepsNC, moveStep, move_engine=None):
@@ -211,6 +252,9 @@ class BLUESSimulation(object):
 
     # ---- reference blues/simulation.py:1100-1119: -[ (U_ncmc - U_md)(x0) + (U_alch - U_ncmc)(x1) ] / kT
     def _computeAlchemicalCorrection(self, unmodified_at_x1=None):
+        if self._diff_plan is not None and unmodified_at_x1 is None and self._dU0 is not None and self._md_sim is not None:
+            # (U_ncmc - U_md)(x0) = -D(x0), (U_alch - U_ncmc)(x1) = +D(x1): -[ -D(x0) + D(x1) ] / kT.  The NCMC context still holds x1.
+            return (self._dU0 - self._alchemical_difference()) / self._ncmc_sim.context._integrator.kT._value
         table = self.stateTable
         at_x0 = table['ncmc']['state0']['potential_energy'] - table['md']['state0']['potential_energy']
         end = table['ncmc']['state1']
@@ -332,6 +376,7 @@ class BatchedBLUESSimulation(object):
         elif any(c._md_sim is not None for c in self.chains):
             raise ValueError("either every chain has an MD simulation or none has")
         self._alch_batch = None
+        self._dU0_all = None
         if all(c._alch_sim is not None for c in self.chains):
             self._alch_batch = NativeBatch([c._alch_sim.context._engine for c in self.chains])
         elif any(c._alch_sim is not None for c in self.chains):
@@ -558,6 +603,27 @@ class BatchedBLUESSimulation(object):
             elif st is not None:
                 c._setStateTable('ncmc', 'state1', st)
 
+    def _alchemical_difference_all(self, alive):
+        """D(x) of every live chain at the coordinates its NCMC context holds now (BLUESSimulation._alchemical_difference for the
+        whole batch): two batched launches of the mesh kernel, one gather of the handful of atoms the excluded-pair term needs."""
+        plan = self.chains[0]._diff_plan
+        R = len(self.chains)
+        if plan["kind"] == "zero":
+            return np.zeros(R)
+        from . import systems
+        mask = alive if self.dead else None
+        mesh = self._ncmc_batch.mesh_energy_all(True, active=mask) - self._ncmc_batch.mesh_energy_all(False, active=mask)
+        xyz = self._ncmc_batch.read_atoms_all([int(i) for i in plan["atoms"]])
+        return mesh + plan["const"] + systems.excluded_pair_term(plan, xyz)
+
+    def _differential(self):
+        """The alchemical correction of every chain as a differential: every chain has a plan, and it is the same one."""
+        plans = [c._diff_plan for c in self.chains]
+        if any(p is None for p in plans) or self._md_batch is None or not hasattr(self._ncmc_batch, "mesh_energy_all"):
+            return False
+        first = plans[0]
+        return all(p is first or (p["kind"] == first["kind"] and p.get("const") == first.get("const") and np.array_equal(p.get("atoms"), first.get("atoms"))) for p in plans)
+
     def _decide_batched(self, temperature):
         """_acceptRejectMove of every chain (reference blues/simulation.py:1121-1166): the `alch` energies of the correction for
         all chains at once, the tests chain by chain on numbers already on the host, then the State write-backs in one call --
@@ -566,7 +632,16 @@ class BatchedBLUESSimulation(object):
         R = len(chains)
         unmodified = [None] * R
         alive = self._alive()
-        if self._alch_batch is not None:
+        corrections = [None] * R
+        if self._differential() and self._dU0_all is not None:
+            # -[ (U_ncmc - U_md)(x0) + (U_alch - U_ncmc)(x1) ] / kT = (D(x0) - D(x1)) / kT with D = U_alch - U_ncmc(lambda = 1): formed in the
+            # NCMC engine from the terms in which the two Systems differ -- no copy of the switched coordinates into the `alch` batch,
+            # no evaluation of an all-mobile System (a full list rebuild for ONE energy), no frozen-frozen constant
+            dU1 = self._alchemical_difference_all(alive)
+            for r, c in enumerate(chains):
+                if alive[r]:
+                    corrections[r] = (self._dU0_all[r] - dU1[r]) / c._ncmc_sim.context._integrator.kT._value
+        elif self._alch_batch is not None:
             # reference simulation.py:1107-1110: the switched coordinates into the alch context, its potential energy
             ends = [c.stateTable['ncmc']['state1'] if alive[r] else None for r, c in enumerate(chains)]
             self._restore_states(ends, velocities=False, leg="alch")
@@ -587,7 +662,7 @@ class BatchedBLUESSimulation(object):
                 c._rng.random_sample()      # (its own stream under isolate_failures: drawn for symmetry with the seed of _reset_batched)
                 restore.append(None)
                 continue
-            todo = record_decision(c, metropolis(c, unmodified[r]))
+            todo = record_decision(c, metropolis(c, unmodified[r], correction=corrections[r]))
             restore.append(None if todo is None else todo[1])
         if self._md_batch is None:
             self._restore_states(restore)            # a rejection restores the pre-switch state in place
@@ -646,6 +721,7 @@ class BatchedBLUESSimulation(object):
                 elif st is not None:
                     c._setStateTable('md', 'state0', st)
             self._restore_states(states, velocities=True, leg="ncmc")
+            self._dU0_all = self._alchemical_difference_all(self._alive()) if self._differential() else None      # (at x0, while the NCMC contexts hold it)
             return
         self._ncmc_batch.prefetch_energies(at_lambda_one=True, active=alive)
         for r, (c, st) in enumerate(zip(self.chains, self._capture_states(active=alive, tolerate=self.isolate_failures))):

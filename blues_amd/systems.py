@@ -220,3 +220,94 @@ def s23k(mobile_atoms=275, reps=(2, 3, 4), frozen=True, restrained=0, restraint_
         if v is not None:
             v = v.copy(); v[big.mass == 0.0] = 0.0
     return big, v
+
+
+# ---- the alchemical correction as a differential (reference blues/simulation.py:1100-1119)
+ONE_4PI_EPS0 = 138.935456
+
+
+def dispersion_correction_energy(system: SystemData, zero_epsilon=()):
+    """OpenMM's long-range dispersion correction of a NonbondedForce with the cutoff and no switching function, in the form the engine
+    and the oracle use (blues_engine.hip: pme_tables; oracle/blues_oracle.c: dispersion_correction) [recalled: NonbondedForceImpl::
+    calcDispersionCorrection]; the atoms in `zero_epsilon` enter with epsilon 0 (disable_alchemical_dispersion_correction=True)."""
+    n = system.n_atoms
+    eps = np.array(system.epsilon, dtype=np.float64)
+    eps[np.asarray(zero_epsilon, dtype=np.int64)] = 0.0
+    sig = np.asarray(system.sigma, dtype=np.float64)
+    classes, counts = np.unique(np.stack([sig, eps], axis=1), axis=0, return_counts=True)
+    s12 = s6 = 0.0
+    for a in range(len(classes)):
+        for b in range(a, len(classes)):
+            cnt = 0.5 * counts[a] * (counts[a] + 1.0) if a == b else float(counts[a]) * counts[b]
+            sg = 0.5 * (classes[a][0] + classes[b][0]); e = np.sqrt(classes[a][1] * classes[b][1]); sg6 = sg ** 6
+            s12 += cnt * e * sg6 * sg6; s6 += cnt * e * sg6
+    tot = 0.5 * n * (n + 1.0)
+    rc3 = system.cutoff ** 3; rc9 = rc3 ** 3
+    V = float(np.prod(np.asarray(system.box, dtype=np.float64).reshape(-1)[:3]))
+    return 8.0 * n * float(n) * np.pi * (s12 / tot / (9.0 * rc9) - s6 / tot / (3.0 * rc3)) / V
+
+
+_FORCE_FIELD_ARRAYS = ("charge", "sigma", "epsilon", "exclusions", "exception_atoms", "exception_params", "bond_atoms", "bond_params", "angle_atoms",
+                       "angle_params", "torsion_atoms", "torsion_params", "restraint_atoms", "restraint_x0")
+_FORCE_FIELD_SCALARS = ("restraint_k", "nonbonded_method", "cutoff", "ewald_alpha", "softcore_alpha", "pme_order", "dispersion_correction")
+
+
+def alchemical_difference_plan(alchemical: SystemData, plain: SystemData):
+    """How D(x) = U_plain(x) - U_alchemical(x; lambda_sterics = lambda_electrostatics = 1) can be had WITHOUT evaluating U_plain, where
+    `plain` is the non-alchemical System of the reference's md / alch contexts (blues/simulation.py:791-792) and `alchemical` the NCMC
+    one.  If the two describe the same force field -- every parameter array equal; masses (freezing), constraints and the list of
+    alchemical atoms are free to differ, they do not enter a potential energy -- the softcore forms at lambda = 1 ARE the plain ones
+     and every direct-space term cancels.  What is left:
+      * nothing, without reciprocal space ({"kind": "zero"});
+      * with PME ('direct-space' alchemical treatment: the alchemical atoms' charges stay out of the mesh, the self term and the
+        excluded-pair corrections, their epsilons out of the dispersion correction): the mesh energy with every atom's charge minus the
+        mesh energy with the alchemical charges at 0 (the engine: blues_mesh_energy), the erf corrections of the excluded pairs that
+        hold an alchemical atom (a handful of intra-ligand pairs: host arithmetic), and three constants of the box.
+    Returns None when the Systems differ in anything else: the four energies of the reference's formula are evaluated then."""
+    if alchemical is None or plain is None or alchemical.n_atoms != plain.n_atoms:
+        return None
+    if len(np.asarray(plain.alchemical_atoms).reshape(-1)) != 0 or len(np.asarray(alchemical.alchemical_atoms).reshape(-1)) == 0:
+        return None
+    if not np.array_equal(np.asarray(alchemical.box, dtype=np.float64).reshape(-1), np.asarray(plain.box, dtype=np.float64).reshape(-1)):
+        return None
+    for name in _FORCE_FIELD_ARRAYS:
+        if not np.array_equal(np.asarray(getattr(alchemical, name)), np.asarray(getattr(plain, name))):
+            return None
+    for name in _FORCE_FIELD_SCALARS:
+        if getattr(alchemical, name) != getattr(plain, name):
+            return None
+    if alchemical.nonbonded_method != NB_PME:
+        return {"kind": "zero"}
+    if tuple(alchemical.pme_grid) != tuple(plain.pme_grid) or getattr(alchemical, "barostat", None) or getattr(plain, "barostat", None):
+        return None
+    lig = np.asarray(alchemical.alchemical_atoms, dtype=np.int64)
+    q = np.asarray(alchemical.charge, dtype=np.float64)
+    is_lig = np.zeros(alchemical.n_atoms, bool); is_lig[lig] = True
+    pairs = set()
+    for arr in (alchemical.exclusions,):      # (the excluded pairs -- exceptions are among them -- as the engine and the oracle take them: blues_engine.hip T_EWEX)
+        for a, b in np.asarray(arr, dtype=np.int64).reshape(-1, 2):
+            if (is_lig[a] or is_lig[b]) and q[a] != 0.0 and q[b] != 0.0 and a != b:
+                pairs.add((int(min(a, b)), int(max(a, b))))
+    pairs = np.array(sorted(pairs), dtype=np.int64).reshape(-1, 2)
+    atoms = np.unique(np.concatenate([lig, pairs.reshape(-1)]))          # whose coordinates the host part needs
+    alpha = float(alchemical.ewald_alpha)
+    V = float(np.prod(np.asarray(alchemical.box, dtype=np.float64).reshape(-1)[:3]))
+    q_env = q.copy(); q_env[lig] = 0.0
+    const = -ONE_4PI_EPS0 * alpha / np.sqrt(np.pi) * float((q[lig] ** 2).sum())
+    const += -np.pi * ONE_4PI_EPS0 * (q.sum() ** 2 - q_env.sum() ** 2) / (2.0 * V * alpha * alpha)
+    if alchemical.dispersion_correction:
+        const += dispersion_correction_energy(alchemical) - dispersion_correction_energy(alchemical, zero_epsilon=lig)
+    return {"kind": "pme", "atoms": atoms, "pairs": np.searchsorted(atoms, pairs), "qq": ONE_4PI_EPS0 * q[pairs[:, 0]] * q[pairs[:, 1]] if len(pairs) else np.zeros(0),
+            "alpha": alpha, "box": np.asarray(alchemical.box, dtype=np.float64).reshape(-1)[:3].copy(), "const": float(const)}
+
+
+def excluded_pair_term(plan, xyz):
+    """- sum k_e q_i q_j erf(alpha r) / r over plan["pairs"], for coordinates xyz of plan["atoms"] ((..., n_atoms_of_plan, 3), nm)."""
+    from scipy.special import erf
+    xyz = np.asarray(xyz, dtype=np.float64)
+    if len(plan["qq"]) == 0:
+        return np.zeros(xyz.shape[:-2])
+    d = xyz[..., plan["pairs"][:, 0], :] - xyz[..., plan["pairs"][:, 1], :]
+    d -= plan["box"] * np.rint(d / plan["box"])
+    r = np.sqrt((d * d).sum(-1))
+    return -(plan["qq"] * erf(plan["alpha"] * r) / r).sum(-1)

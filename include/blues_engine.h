@@ -231,6 +231,13 @@ int blues_get_energy(BluesEngine *h, double *potential, double *kinetic);
  * that it copies the coordinates into (simulation.py:1107-1110, 791-792).  For (1, 1) the value normally lies in the energy
  * cache already (every evaluation leaves it there); otherwise one evaluation. */
 int blues_get_energy_at(BluesEngine *h, double lambda_sterics, double lambda_electrostatics, double *potential);
+/* The reciprocal-space MESH energy 1/2 sum_m eterm(m) |Q^(m)|^2 of the current coordinates (0 unless BLUES_NB_PME), with the charges
+ * of this System's NonbondedForce -- alchemical atoms 0 (alchemical_pme_treatment='direct-space') -- or, with_alchemical_charges != 0,
+ * with every atom's own charge: the mesh energy of the NON-alchemical System the reference's md / alch contexts wrap
+ * (blues/simulation.py:791-792).  Their difference is the x-dependent part of (U_alch - U_ncmc)(x) that no direct-space term holds:
+ * what blues_amd/simulation.py forms the alchemical correction from (simulation.py:1100-1119) instead of four total energies, two of
+ * them in another context.  Overwrites the reciprocal-space forces of the last pass (the next step evaluates a fresh one). */
+int blues_mesh_energy(BluesEngine *h, int32_t with_alchemical_charges, double *out);
 /* per-term potential energies at the current state, for parity tests:
  * [0] bonds [1] angles [2] torsions [3] nonbonded env-env [4] exceptions
  * [5] alchemical sterics [6] alchemical electrostatics [7] restraint
@@ -374,6 +381,7 @@ int blues_batch_read_atoms(BluesBatch *b, BluesSnapshot *const *snaps /* NULL: t
 int blues_batch_reset(BluesBatch *b, const int32_t *mask);                                                       /* blues_reset */
 int blues_batch_set_velocities_to_temperature(BluesBatch *b, double temperature, const uint64_t *seeds,
                                               const int32_t *mask);                                              /* blues_set_velocities_to_temperature */
+int blues_batch_mesh_energy(BluesBatch *b, int32_t with_alchemical_charges, const int32_t *mask, double *out /* [count] */);   /* blues_mesh_energy */
 
 /* [0] steps issued in lock step (one launch for all members) [1] steps that
  * fell back to per-member launches [2] members [3] batched energy evaluations */
@@ -382,8 +390,9 @@ int blues_batch_get_stats(BluesBatch *b, int64_t stats[4]);
  * cause): [0] re-plans of the layout shape (a member's group lists outgrew it) [1] seconds spent in them [2] members laid out again from a new
  * sort inside batch calls (creation included) [3] members re-sorted at the 64-step polls (their builders asked, or by age) [4] seconds spent
  * there [5] members moved to another shape in place (no sort) [6] re-sorts of all members, whoever asked [7] tiles per group list now
- * [8] list capacity [9] nonbonded kernel (blues_get_stats [12]). */
-#define BLUES_N_BATCH_COUNTERS 10
+ * [8] list capacity [9] nonbonded kernel (blues_get_stats [12]) -- of the members in the batch's layout [10] members that step on launches
+ * of their own now because their lists have outgrown the batch's shape (stragglers) [11] times a member became one [12] times one came back. */
+#define BLUES_N_BATCH_COUNTERS 13
 int blues_batch_get_counters(BluesBatch *b, double out[BLUES_N_BATCH_COUNTERS]);
 /* as blues_time_nonbonded, for one batched launch covering all members.  With pruned per-atom lists an atom is served in
  * one of two ways: from its current pruned list, or from its full list while the pruned one is re-derived.  usec[0] / usec[1]:

@@ -125,3 +125,67 @@ def test_alchemical_correction_is_no_longer_zero(Engine, oracle_mod, tol_box):
     # without reciprocal space the two systems coincide at lambda = 1
     assert Engine(s, data).potential_energy() == pytest.approx(oracle_mod.Oracle(s, data).energy_forces(1.0, 1.0)[0], rel=1e-10)
     ga.close(); gm.close()
+
+
+@pytest.mark.parametrize("reciprocal", [False, True])
+def test_differential_correction_equals_the_four_energy_form(Engine, tol_box, reciprocal, tune):
+    """SURVEY.md 8f.3 for the arrangement the reference actually runs -- md, alch and ncmc Simulations per chain
+    (/root/reference/blues/simulation.py:768-809; the alch context wraps the MD System, :791-792): the alchemical correction
+    -[(U_ncmc - U_md)(x0) + (U_alch - U_ncmc)(x1)] / kT (:1100-1119) formed as (D(x0) - D(x1)) / kT, D = U_alch - U_ncmc(lambda = 1) from the
+    terms in which the two Systems differ -- nothing without reciprocal space; with PME the ligand's share of the mesh energy (the NCMC
+    engine's own mesh kernel run with and without the alchemical charges: blues_mesh_energy), the erf corrections of the ligand's excluded
+    pairs and constants of the box -- against the reference's four total energies, two of them in another context.  Double precision,
+    whole BLUES iterations with MD legs, batched and chain by chain: the same corrections to 1e-9 of the energies they are differences of,
+    the same decisions, the same states."""
+    import copy as _copy
+    from blues_amd import moves, simulation, unit
+    from blues_amd.context import Simulation
+    s, v = tol_box
+    if reciprocal:
+        s = systems.with_reciprocal_space(s)
+    md_sys = _copy.copy(s); md_sys.alchemical_atoms = np.zeros(0, np.int32)
+    plan = systems.alchemical_difference_plan(s, md_sys)
+    assert plan is not None and plan["kind"] == ("pme" if reciprocal else "zero")
+    lig = np.arange(15)
+    R, nsteps, nmd, nIter = 3, 10, 6, 2
+    tune(assume_batch=R)
+
+    def chains(differential):
+        out = []
+        for r in range(R):
+            sim = Simulation(None, s, integrators.generateNCMCIntegrator(nstepsNC=nsteps, dt=0.002, temperature=300.0, seed=700 + r), precision="double", replica=r)
+            md = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=800 + r), precision="double", replica=r)
+            alch = Simulation(None, md_sys, integrators.LangevinIntegrator(300.0, 1.0, 0.002, seed=900 + r), precision="double", replica=r)
+            md.context.setPositions(unit.Quantity(s.positions, "nanometer")); md.context.setVelocities(unit.Quantity(v * (1.0 + 0.03 * r), "nanometer/picosecond"))
+            mover = moves.MoveEngine(moves.RandomLigandRotationMove(lig, s.mass[lig], random_state=90 + r))
+            out.append(simulation.BLUESSimulation(simulation.SimulationSet(sim, md=md, alch=alch), {"nstepsNC": nsteps, "moveStep": nsteps // 2, "nIter": nIter, "nstepsMD": nmd},
+                                                  mover, rng=np.random.RandomState(4000 + r), differential_correction=differential))
+        return out
+
+    results = {}
+    for differential in (False, None):
+        for batched in (True, False):
+            cs = chains(differential)
+            assert all((c._diff_plan is not None) == (differential is None) for c in cs)
+            B = simulation.BatchedBLUESSimulation(cs, batched_boundary=batched)
+            assert B._differential() == (differential is None)
+            records = []
+            B.run(nIter=nIter, on_iteration=lambda N, last: records.append([dict(l) for l in last]))
+            e_scale = max(abs(c.stateTable["md"]["state0"]["potential_energy"]._value) for c in cs)
+            results[(differential, batched)] = (records, [c._md_sim.context._engine.get_positions() for c in cs], e_scale)
+            B.close()
+    kT = 0.0083144626 * 300.0
+    ref = results[(False, True)]
+    if reciprocal:   # (the correction is not zero: the ligand's share of reciprocal space changes between x0 and x1)
+        assert max(abs(ref[0][N][r]["correction"]) for N in range(nIter) for r in range(R)) > 1e-4
+    for key in ((None, True), (None, False), (False, False)):
+        rec, xs, _ = results[key]
+        for N in range(nIter):
+            for r in range(R):
+                a, b = rec[N][r], ref[0][N][r]
+                assert abs(a["correction"] - b["correction"]) <= 1e-9 * ref[2] / kT, (key, N, r, a["correction"], b["correction"])
+                assert a["accept"] == b["accept"] and a["protocol_work"] == pytest.approx(b["protocol_work"], rel=1e-9, abs=1e-9)
+        for r in range(R):
+            assert np.abs(xs[r] - ref[1][r]).max() < 1e-9
+    if not reciprocal:   # the direct-space model: identically zero, no energy of another context evaluated
+        assert all(results[(None, True)][0][N][r]["correction"] == 0.0 for N in range(nIter) for r in range(R))
