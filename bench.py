@@ -56,6 +56,13 @@ def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False, md_ste
         o_idx = [i for i in range(15, system.n_atoms - 2) if res[i] == res[i + 2] and (i == 0 or res[i - 1] != res[i]) and system.mass[i] > 10.0]
         waters = [[i, i + 1, i + 2] for i in o_idx]
         make_move = lambda gid: moves.WaterTranslationMove(waters, np.arange(15), system.mass[:15], radius=2.0)
+    elif workload == "rotmove-solute":
+        # the mobile region of the reference's freeze_radius (blues/simulation.py:394-480: `(<center> <: d) & !(<solvent>)`): the ligand and the
+        # 18 toluenes packed around it -- 285 SOLUTE atoms with bonds, angles, torsions, 1-4 exceptions and C-H constraint clusters -- all water
+        # frozen (systems.s23k_solute; the headline's mobile set is the ligand + 87 rigid waters: no bonded term, water triangles only)
+        system, vel = systems.s23k_solute(frozen=True)
+        lig = np.asarray(system.alchemical_atoms)
+        make_move = lambda gid: moves.RandomLigandRotationMove(lig, system.mass[lig], random_state=1000 + gid)
     elif workload == "sidechain":
         # configs[4]: a torsion move on a partially alchemical solute (the methyl group of the first toluene: alchemical-
         # environment exclusions and 1-4 exceptions active), long protocol
@@ -71,7 +78,7 @@ def build_chains(rank, local_rank, nsteps, workload, R, reciprocal=False, md_ste
         system = systems.with_reciprocal_space(system)
     md_system = None
     if md_steps > 0:
-        md_system = systems.s23k(frozen=False, restrained=40 if workload == "water" else 0)[0]
+        md_system = (systems.s23k_solute(frozen=False) if workload == "rotmove-solute" else systems.s23k(frozen=False, restrained=40 if workload == "water" else 0))[0]
         md_system = copy.copy(md_system)
         md_system.alchemical_atoms = np.zeros(0, np.int32)
         if reciprocal:
@@ -382,8 +389,9 @@ def main():
                     "duration then includes its co-runners: DESIGN.md section 4d)")
     ap.add_argument("--workers", type=int, default=1, help="host threads for the per-chain plugin-boundary work inside a group")
     ap.add_argument("--nsteps-nc", type=int, default=NSTEPS_NC)
-    ap.add_argument("--workload", default="rotmove", choices=["rotmove", "water", "sidechain"],
-                    help="rotmove = the benchmark (configs[1]); water / sidechain = full-size runs of configs[3] / configs[4]")
+    ap.add_argument("--workload", default="rotmove", choices=["rotmove", "rotmove-solute", "water", "sidechain"],
+                    help="rotmove = the benchmark (configs[1]: the ligand and the 87 nearest rigid waters mobile); rotmove-solute = the same switch with the mobile region of the "
+                         "reference's freeze_radius (285 bonded solute atoms, all water frozen); water / sidechain = full-size runs of configs[3] / configs[4]")
     ap.add_argument("--md-steps", type=int, default=0, help="> 0: time the reference's FULL iteration (blues/simulation.py:1215-1257): every chain carries the md / alch / ncmc "
                     "triple, and each timed step is sync -> NCMC switch -> Metropolis -> reset -> this many MD steps on the unfrozen System.  `value` stays the "
                     "NCMC leg's ns/day (its share of the wall time); `full_iteration` has both legs.  Use --replicas 16..256 --groups 1 (an all-mobile engine is ~60 MB) and "

@@ -452,9 +452,9 @@ template <typename R> static NbConst<R> make_nbconst(const BluesEngine* h) {
 }
 
 // ------------------------------------------------------------------ fragments (kernels_frag.h), once per engine
-// The environment (every atom that is not alchemical) cut into fragments of up to three atoms: a molecule's atoms in
-// breadth-first order over its bonds and constraints, three at a time -- a rigid water is one fragment, consecutive atoms of a
-// solute are a bond or two apart.  With them the static table of fragment pairs that hold an excluded atom pair (and of every
+// The environment (every atom that is not alchemical) cut into fragments of up to three atoms: walking a molecule in breadth-first
+// order over its bonds and constraints, an atom not yet in a fragment takes up to two of its own free neighbours -- a rigid water is one
+// fragment, the atoms of a solute's fragment are a bond or two apart.  With them the static table of fragment pairs that hold an excluded atom pair (and of every
 // fragment with itself): the 9-bit masks the list builder copies into such entries.
 static void build_fragments(BluesEngine* h) {
     const int n = h->n;
@@ -474,10 +474,18 @@ static void build_fragments(BluesEngine* h) {
             std::sort(nb.begin(), nb.end());
             for (int b : nb) if (!seen[b] && h->alch_local[b] < 0) { seen[b] = 1; order.push_back(b); }
         }
-        for (size_t q = 0; q < order.size(); q += 3) {
-            std::array<int, 3> fr = {-1, -1, -1};
-            int c = 0;
-            for (; c < 3 && q + c < order.size(); c++) { fr[c] = order[q + c]; h->frag_of_atom[order[q + c]] = (int)h->frag_atoms.size(); h->frag_pos_of_atom[order[q + c]] = c; }
+        // a fragment = an atom and up to two of its own neighbours (bonded or constrained to it): every pair of its atoms is at most two
+        // bonds apart, whatever the molecule -- a fragment's reach stays ~0.25 nm and constant over time.  (Round 5 cut the breadth-first
+        // order into consecutive triples: at a branch of a large molecule -- a side chain beside the backbone frontier, a ring closure --
+        // consecutive entries are not bonded to each other, the reach grows to several bonds and the list margins, sized for water-like
+        // fragments, no longer cover it: kernels_frag.h, FR_OVER_REACH.)  A rigid water is still one fragment: O, H, H.
+        for (size_t q = 0; q < order.size(); q++) {
+            const int a0 = order[q];
+            if (h->frag_of_atom[a0] >= 0) continue;
+            std::array<int, 3> fr = {a0, -1, -1};
+            int c = 1;
+            for (int b : adj[a0]) if (c < 3 && h->frag_of_atom[b] < 0 && h->alch_local[b] < 0 && b != fr[1]) fr[c++] = b;   // (adj is sorted: see the walk above)
+            for (int k = 0; k < c; k++) { h->frag_of_atom[fr[k]] = (int)h->frag_atoms.size(); h->frag_pos_of_atom[fr[k]] = k; }
             h->frag_atoms.push_back(fr); h->frag_cnt.push_back(c);
         }
     }
@@ -883,6 +891,7 @@ static int sort_and_tile(BluesEngine* h) {
         h->forbid_atom = true;
         return sort_and_tile(h);
     }
+    if (!want_frag) { h->frag_F = 0; h->frag_NI = 0; h->frag_nblk = 0; h->frag_ocap = 0; h->frag_icap = 0; h->frag_fpw = 1; h->frag_nwg = 0; h->frag_rel = false; }   // (a layout that left the fragment lists -- a straggler that came back -- is congruent with members that never had them)
     if (want_frag) {
         // fragment lists: no group lists but the alchemical tile's, whose capacity must not depend on the density (members of a
         // batch keep their own boxes under a barostat and still have to agree on the launch geometry)
@@ -1894,7 +1903,7 @@ static int force_pass(BluesEngine* h, int base_L) {
     // builder of the atoms' lists (85 us, no LDS, 94 registers) and are done before it: 756 -> 716 us per step of 1024 chains.
     // The dense kernel itself beside that builder (fork = 2) gains nothing; beside the GROUP-list builder the small kernels cost
     // it what they saved (round 4, first half).
-    const bool small_side = fork && h->k2_dense && fork_mode != 2;
+    const bool small_side = fork && h->k2_dense && fork_mode != 2 && fork_mode != 3;   // (3: every alchemical kernel and the bonded entries on the side stream, joined before the sums)
     if (fork && ensure_side(h)) return 1;
     // k2_early (off by default): the alchemical kernel of the members that do NOT rebuild needs nothing from the rebuild and can
     // start as soon as the work list says who they are, with the rebuild kernels on a high-priority stream beside it and the

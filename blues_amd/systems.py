@@ -222,6 +222,85 @@ def s23k(mobile_atoms=275, reps=(2, 3, 4), frozen=True, restrained=0, restraint_
     return big, v
 
 
+def assemble_s23k_solute(base: SystemData, vel, removed_waters, inserted_x, inserted_v):
+    """S23k with `len(inserted_x) / 15` more toluenes (the ligand's own parameters and topology) in place of the waters whose first atoms
+    are `removed_waters`: atom order = ligand, inserted toluenes, everything else in the old order.  Returns (SystemData, velocities)."""
+    n_lig = len(base.alchemical_atoms)
+    lig = np.arange(n_lig)
+    assert np.array_equal(np.asarray(base.alchemical_atoms), lig)
+    n_new = len(inserted_x) // n_lig
+    res = np.asarray(base.residue_of_atom)
+    gone = np.zeros(base.n_atoms, bool)
+    for a in removed_waters:
+        gone[res == res[a]] = True
+    keep = np.nonzero(~gone)[0]
+    keep_rest = keep[keep >= n_lig]
+    # old index -> new index (kept atoms); the ligand stays 0..n_lig-1, the inserted molecules follow
+    new_of_old = np.full(base.n_atoms, -1, np.int64)
+    new_of_old[lig] = lig
+    new_of_old[keep_rest] = n_lig + n_new * n_lig + np.arange(len(keep_rest))
+    n = n_lig + n_new * n_lig + len(keep_rest)
+
+    def per_atom(a, new_vals):
+        a = np.asarray(a)
+        return np.concatenate([a[lig]] + [new_vals] * 1 + [a[keep_rest]])
+    copies = lambda a: np.concatenate([np.asarray(a)[lig]] * n_new) if n_new else np.asarray(a)[:0]
+
+    def terms(atoms, params):
+        """rows of a term list re-indexed: rows of kept atoms, plus one copy per inserted molecule of the rows that lie inside the ligand"""
+        atoms = np.asarray(atoms, np.int64).reshape(len(atoms), -1) if len(atoms) else np.zeros((0, 2), np.int64)
+        params = np.asarray(params)
+        if len(atoms) == 0:
+            return atoms.astype(np.int32), params
+        alive = ~gone[atoms].any(1)
+        inside = (atoms < n_lig).all(1)
+        out_a = [new_of_old[atoms[alive]]]
+        out_p = [params[alive]] if params is not None and len(params) else []
+        for m in range(n_new):
+            out_a.append(atoms[inside] + n_lig * (m + 1))
+            if params is not None and len(params):
+                out_p.append(params[inside])
+        return np.concatenate(out_a).astype(np.int32), (np.concatenate(out_p) if out_p else params)
+    excl, _ = terms(base.exclusions, np.zeros((len(base.exclusions), 0)))
+    exc_a, exc_p = terms(base.exception_atoms, base.exception_params)
+    bond_a, bond_p = terms(base.bond_atoms, base.bond_params)
+    ang_a, ang_p = terms(base.angle_atoms, base.angle_params)
+    tor_a, tor_p = terms(base.torsion_atoms, base.torsion_params)
+    con_a, con_d = terms(base.constraint_atoms, np.asarray(base.constraint_dist).reshape(-1, 1))
+    pos = np.concatenate([base.positions[lig], np.asarray(inserted_x, np.float64).reshape(-1, 3), base.positions[keep_rest]])
+    v = None
+    if vel is not None:
+        v = np.concatenate([vel[lig], np.asarray(inserted_v, np.float64).reshape(-1, 3), vel[keep_rest]])
+    new_res = np.concatenate([np.zeros(n_lig, np.int64)] + [np.full(n_lig, m + 1, np.int64) for m in range(n_new)] + [np.unique(res[keep_rest], return_inverse=True)[1] + n_new + 1])
+    s = SystemData(
+        box=np.asarray(base.box, np.float64).copy(), mass=per_atom(base.mass, copies(base.mass)), charge=per_atom(base.charge, copies(base.charge)),
+        sigma=per_atom(base.sigma, copies(base.sigma)), epsilon=per_atom(base.epsilon, copies(base.epsilon)),
+        exclusions=excl, exception_atoms=exc_a, exception_params=exc_p, bond_atoms=bond_a, bond_params=bond_p, angle_atoms=ang_a, angle_params=ang_p,
+        torsion_atoms=tor_a, torsion_params=tor_p, constraint_atoms=con_a, constraint_dist=np.asarray(con_d).reshape(-1),
+        alchemical_atoms=np.arange(n_lig, dtype=np.int32), nonbonded_method=base.nonbonded_method, cutoff=base.cutoff, ewald_alpha=base.ewald_alpha,
+        softcore_alpha=base.softcore_alpha, annihilate_electrostatics=base.annihilate_electrostatics, annihilate_sterics=base.annihilate_sterics,
+        remove_cm_motion=base.remove_cm_motion, pme_order=base.pme_order, dispersion_correction=base.dispersion_correction, positions=pos,
+        residue_of_atom=new_res.astype(np.int32))
+    assert s.n_atoms == n
+    return s, v
+
+
+def s23k_solute(frozen=True):
+    """S23k-solute: the S23k box with 18 more toluenes packed around the ligand in place of 90 waters (23,400 atoms still), built and
+    relaxed by tests/golden/make_s23k_solute.py.  frozen=True: the ligand and those toluenes -- 285 atoms, all of them solute atoms with
+    bonds, angles, torsions, 1-4 exceptions and C-H constraint clusters -- keep their mass, ALL water is frozen: the mobile region of
+    the reference's `freeze_radius` (blues/simulation.py:394-480: `(<center> <: d) & !(<solvent>)`).  Returns (SystemData, velocities)."""
+    z = np.load(os.path.join(_DATA, "s23k_solute.npz"))
+    base, vel = s23k(frozen=False)
+    s, v = assemble_s23k_solute(base, vel, z["removed_waters"], z["inserted_x"], z["inserted_v"])
+    s.positions[z["moved_atoms"]] = z["moved_x"]
+    if frozen:
+        mobile = np.arange(len(base.alchemical_atoms) + len(z["inserted_x"]))
+        s = freeze_except(s, mobile)
+        v = v.copy(); v[s.mass == 0.0] = 0.0
+    return s, v
+
+
 # ---- the alchemical correction as a differential (SURVEY.md 8f.3; reference blues/simulation.py:1100-1119)
 ONE_4PI_EPS0 = 138.935456
 

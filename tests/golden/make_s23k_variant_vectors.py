@@ -4,6 +4,9 @@ configs[4]; bench.py --workload water / sidechain): run in the build container (
 
     python tests/golden/make_s23k_variant_vectors.py
 
+solute    : blues_amd.systems.s23k_solute(frozen=True) -- the mobile region of the reference's freeze_radius: 285 SOLUTE atoms (the ligand + 18
+            toluenes packed around it: bonds, angles, torsions, 1-4 exceptions, C-H constraint clusters), all water frozen; the move is a rigid
+            rotation of the ligand at step 20 (python tests/golden/make_s23k_variant_vectors.py solute regenerates this variant only).
 water     : blues_amd.systems.s23k(frozen=False, restrained=40) with the first water (atoms 15, 16, 17) alchemical -- every atom
             mobile, 40 position restraints (reference examples/example_water.py, blues/moves.py:846-1083: the species
             WaterTranslationMove inserts); the move of the vectors is a fixed translation of that water at step 20.
@@ -33,7 +36,7 @@ from oracle import oracle  # noqa: E402
 NSTEPS = 40
 MOVE_STEP = 20
 LAMBDAS = ((1.0, 1.0), (0.5, 0.3), (0.05, 0.0), (0.0, 0.0))
-SEEDS = {"water": 20261, "sidechain": 20262}
+SEEDS = {"water": 20261, "sidechain": 20262, "solute": 20263}
 
 
 def variant(name):
@@ -46,6 +49,19 @@ def variant(name):
 
         def move(x):
             xn = x.copy(); xn[[15, 16, 17]] += shift
+            return xn
+        return s, vel, move
+    if name == "solute":
+        # S23k-solute (tests/golden/make_s23k_solute.py): the ligand + 18 toluenes mobile -- 285 SOLUTE atoms with bonds, angles, torsions,
+        # 1-4 exceptions and C-H constraint clusters -- ALL water frozen (reference blues/simulation.py:394-480: the mobile region of
+        # freeze_radius); the move: a rigid rotation of the ligand by 0.35 rad about z through its centroid (RandomLigandRotationMove's geometry)
+        s, vel = systems.s23k_solute(frozen=True)
+        lig = np.arange(15)
+        th = 0.35
+        Rz = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+
+        def move(x):
+            xn = x.copy(); c = x[lig].mean(0); xn[lig] = c + (x[lig] - c) @ Rz.T
             return xn
         return s, vel, move
     base, vel = systems.s23k(mobile_atoms=275, frozen=True)
@@ -66,7 +82,11 @@ def variant(name):
 
 def main():
     out = {"nsteps": NSTEPS, "move_step": MOVE_STEP, "dt": 0.004, "temperature": 300.0, "lambdas": np.array(LAMBDAS)}
-    for name in ("water", "sidechain"):
+    path = os.path.join(ROOT, "tests", "golden", "s23k_variant_vectors.npz")
+    only = sys.argv[1:]       # (variants to (re)generate; the others are kept from the committed file)
+    if only and os.path.exists(path):
+        out.update({k: v for k, v in np.load(path).items() if not any(k.startswith(n + "_") for n in only)})
+    for name in (only or ("water", "sidechain", "solute")):
         s, v, move = variant(name)
         mob = np.nonzero(s.mass > 0)[0]
         fsel = mob[::8] if name == "water" else mob
@@ -95,7 +115,6 @@ def main():
         out[p + "work_trace"] = np.array(work); out[p + "work_before_move_step"] = wm
         out[p + "x_after_move"] = xm.astype(np.float64); out[p + "v_at_move"] = vm.astype(np.float64)
         out[p + "x_end"] = o.get_positions()[mob]
-    path = os.path.join(ROOT, "tests", "golden", "s23k_variant_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 

@@ -1187,7 +1187,7 @@ def test_a_member_that_outgrows_the_shape_steps_on_its_own(Engine, tune):
         return engs, NativeBatch(engs)
 
     calm, Bc = build()
-    Bc.step(2 * n)
+    Bc.step(n); Bc.step(n)      # (in the same two calls as below: the first and last step of a call go through the general step kernel, whose sums are grouped differently)
     c0 = Bc.counters()
     assert c0["replans"] == 0 and c0["tiles_per_list"] == 5 and c0["nonbonded_kernel"] == 2 and c0["straggled"] == 0, c0
     ref = [(_state(g)) for g in calm]
@@ -1209,7 +1209,9 @@ def test_a_member_that_outgrows_the_shape_steps_on_its_own(Engine, tune):
         assert g.audit_lists()[1] == 0
     for g, (xr, vr, wr) in list(zip(engs, ref))[1:]:
         xg, vg, wg = _state(g)
-        assert wg == wr and np.array_equal(xg, xr) and np.array_equal(vg, vr)           # bit for bit: nobody else noticed
+        assert wg == wr, (wg, wr)
+        assert np.array_equal(xg, xr), (np.abs(xg - xr).max(), int((np.abs(xg - xr).max(axis=1) > 0).sum()), np.nonzero(np.abs(xg - xr).max(axis=1) > 0)[0][:10])
+        assert np.array_equal(vg, vr), np.abs(vg - vr).max()           # bit for bit: nobody else noticed
     # the next switch starts from a compact arrangement again (what a restored State brings): the straggler comes back
     B.reset_all()
     engs[0].set_positions(x_before)

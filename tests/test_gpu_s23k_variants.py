@@ -1,8 +1,11 @@
-"""GPU suite: the two S23k system VARIANTS bench.py runs beside the headline configuration, at full size, against committed oracle
+"""GPU suite: the S23k system VARIANTS bench.py runs beside the headline configuration, at full size, against committed oracle
 vectors (tests/golden/s23k_variant_vectors.npz; generator: tests/golden/make_s23k_variant_vectors.py):
 
   water     -- BASELINE.json configs[3]: nothing frozen (23,400 mobile atoms, 366 i-tiles), 40 position restraints, the first water
                alchemical (reference examples/example_water.py, blues/moves.py:846-1083);
+  solute    -- the mobile region of the reference's freeze_radius (blues/simulation.py:394-480): the ligand and 18 toluenes around it
+               (285 solute atoms: bonds, angles, torsions, 1-4 exceptions, C-H constraint clusters), ALL water frozen
+               (blues_amd.systems.s23k_solute; VERDICT r05 missing #5) -- the bonded kernel and the constraint solver on a representative mix;
   sidechain -- configs[4]: a PARTIALLY alchemical solute (atoms 0, 7, 8, 9 of the first toluene): alchemical-environment exclusions
                and 1-4 exceptions active, which puts the alchemical kernel into its lane layout inside a batch
                (reference blues/moves.py:752-844).
@@ -22,6 +25,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s23k_variant_vectors.npz")
 WATER_SHIFT = np.array([0.012, -0.017, 0.009])
 SIDECHAIN_THETA = 1.1
+SOLUTE_THETA = 0.35
 
 
 @pytest.fixture(scope="module")
@@ -48,6 +52,16 @@ def _variant(name):
             xn = x.copy(); xn[[15, 16, 17]] += sign * WATER_SHIFT
             return xn
         return s, vel, move
+    if name == "solute":
+        s, vel = systems.s23k_solute(frozen=True)
+        lig = np.arange(15)
+
+        def move(x, sign=1.0):   # rigid rotation of the ligand about z through its centroid (the centroid does not move: the inverse is the rotation by -theta)
+            th = sign * SOLUTE_THETA
+            Rz = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+            xn = x.copy(); c = x[lig].mean(0); xn[lig] = c + (x[lig] - c) @ Rz.T
+            return xn
+        return s, vel, move
     base, vel = systems.s23k(mobile_atoms=275, frozen=True)
     s = copy.copy(base)
     s.alchemical_atoms = np.array([0, 7, 8, 9], np.int32)
@@ -69,7 +83,7 @@ def _data(gold, name, precision, replica=0):
                                               seed=int(gold[name + "_seed"])).to_data(precision=precision, replica=replica)
 
 
-@pytest.mark.parametrize("name", ["water", "sidechain"])
+@pytest.mark.parametrize("name", ["water", "sidechain", "solute"])
 @pytest.mark.parametrize("precision,tol", [(1, 1e-10), (0, 1e-5)])
 def test_variant_energies_and_forces_golden(Engine, gold, name, precision, tol):
     s, v, _ = _variant(name)
@@ -124,7 +138,7 @@ def _teacher_forced(engines, stepper, s, v, move, gold, name):
     return out
 
 
-@pytest.mark.parametrize("name,R", [("water", 1), ("water", 8), ("sidechain", 1), ("sidechain", 8), ("sidechain", 64)])
+@pytest.mark.parametrize("name,R", [("water", 1), ("water", 8), ("sidechain", 1), ("sidechain", 8), ("sidechain", 64), ("solute", 1), ("solute", 8), ("solute", 64)])
 @pytest.mark.parametrize("precision", [1, 0])
 def test_variant_switch_golden(Engine, gold, name, R, precision):
     from blues_amd.engine import NativeBatch
@@ -147,7 +161,9 @@ def test_variant_switch_golden(Engine, gold, name, R, precision):
         if precision == 0 and name == "sidechain" and R >= 8:
             assert st["alchemical_kernel"] == 0, st                 # alchemical-environment exclusions: the lane layout, inside a batch
         if precision == 0 and R >= 8:
-            assert st["nonbonded_kernel"] == (3 if name == "water" else 2), st   # water (nothing frozen): fragment lists; sidechain: pruned per-atom lists
+            assert st["nonbonded_kernel"] == (2 if name == "sidechain" else 3), st   # water (nothing frozen) and solute (a mobile region of radius 1.5 nm: no group list holds it): fragment lists; sidechain: pruned per-atom lists
+        if name == "solute":
+            assert st["clusters"] > 100 and B.stats()["lockstep_steps"] > 0                     # a CH3 star, five C-H pairs and two lone carbons per toluene: the constraint solver's whole repertoire but the water triangle
         B.close()
     mob = gold[name + "_mobile_atoms"]
     pos_err = np.abs(engs[0].get_positions()[mob] - gold[name + "_x_end"]).max()
