@@ -590,7 +590,8 @@ def main():
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
     rank_elapsed = {"max": float(t.item()), "min": float(tmin.item()), "this_rank": elapsed}   # (host imbalance between ranks shows here first)
     from blues_amd.replicas import gather_rank_numbers
-    per_rank = gather_rank_numbers([t_setup, memory_use()["host_peak_rss_gib"], float(os.getpid()), float(sum(len(d.dead) for d in drivers))])   # what N ranks on one host cost: set-up seconds, peak host memory; chains retired after a failure
+    per_rank = gather_rank_numbers([t_setup, memory_use()["host_peak_rss_gib"], float(os.getpid()), float(sum(len(d.dead) for d in drivers)),
+                                    (clock["sync"] + clock["decide"]) / max(1, args.steps)])   # what N ranks on one host cost: set-up seconds, peak host memory; chains retired after a failure; the plugin boundary's seconds per iteration (hand-over + Metropolis + reset: per-chain host work)
     elapsed = float(t.item())
 
     # the kernel north_star prices against the HBM roofline: the direct-space nonbonded kernel, timed alone with HIP
@@ -700,6 +701,7 @@ def main():
             "single_replica": single,
             "rank_elapsed_seconds": rank_elapsed,
             "per_rank": {"setup_seconds": per_rank[:, 0].tolist(), "host_peak_rss_gib": per_rank[:, 1].tolist(), "distinct_processes": int(len(set(per_rank[:, 2].tolist()))),
+                         "boundary_seconds_per_iteration": per_rank[:, 4].tolist(),
                          "nproc": os.cpu_count(), "usable_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None},
             "process_group": {"backend": (args.backend if world > 1 else None), "same_device": bool(args.same_device),
                               "replica_seeds_first_chain_of_each_rank": [int(replica_seed(1234, r * R)) for r in range(world)]},

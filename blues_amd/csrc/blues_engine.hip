@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -133,8 +134,20 @@ struct BluesSnapshot {
     uint64_t box_epoch = 0;   // ... in the box the owner had then (a barostat move or set_box in between makes them stale)
 };
 
+// What the engines made from ONE System share on the host (round 6): per-atom parameters, exclusion lists, the bond / constraint graph.
+// 2048 chains of the benchmark are 2048 engines of one System: each used to keep its own copy (~3 MB of the 5.6 MB of host memory per
+// chain; the exclusion lists are 23,400 small vectors).  blues_engine_create finds the System's table by a hash of its arrays.
+struct HostTopology {
+    std::vector<double> mass, charge, sigma, eps;
+    std::vector<double> qn;                      // NonbondedForce charges: the alchemical atoms' are 0
+    std::vector<std::vector<int>> excl;          // per atom, both directions
+    std::vector<int> alch_local;                 // [n] -> local alchemical index or -1
+    std::vector<int32_t> link_pairs;             // bonds and constraints: what holds a molecule together
+};
+
 struct BluesEngine {
     std::string err;
+    std::shared_ptr<HostTopology> T;   // (shared with the other engines of the same System)
     int device = 0;
     // replica batching (see BluesBatch below): while the batch is in lock step the leader's launches cover every
     // replica (gridDim.y) and the other members only advance their mirrored control state
@@ -150,10 +163,7 @@ struct BluesEngine {
     // ---- system (host copies, caller order)
     int n = 0;
     double box[3] = {0, 0, 0};
-    std::vector<double> mass, charge, sigma, eps;
-    std::vector<std::vector<int>> excl;  // per atom, both directions
     std::vector<int> alch;               // caller indices
-    std::vector<int> alch_local;         // [n] -> local index or -1
     int nb_method = 1; double cutoff = 1, alpha = 0, sc_alpha = 0.5;
     int annih_elec = 1, annih_ster = 0, remove_cm = 0, check_env_excl = 0;
     BluesTuning tune;   // the process-wide tuning at the time this engine was created
@@ -191,8 +201,6 @@ struct BluesEngine {
     bool have_positions = false, sorted_ok = false, lists_forced = true, relayout_failed = false;
     bool straggler = false;   // member of a batch whose own layout no longer fits the batch's shape: it steps on launches of its own until it fits again (batch_do_steps)
     std::vector<double> hx;        // host copy of the positions the tiles were last laid out from (caller order, [n][3])
-    std::vector<double> h_stage;   // staging for host transfers
-    std::vector<double> hx_sort;   // positions at the last sort
     double e_frozen[2] = {0, 0}; bool e_frozen_valid = false;
     ECache ecache;  // total potential energy at the current positions
     double ke_cache = 0; bool ke_cache_valid = false;
@@ -217,7 +225,7 @@ struct BluesEngine {
     int k1_mode = 0;  // 0: tile kernel (lane = i-atom), 1: sub-tile kernel, 2: per-atom Verlet lists + LDS tile image (nonbonded_atom_body), 3: fragment lists (kernels_frag.h)
     // fragment lists (every environment atom mobile): the static cut of the environment into fragments of <= 3 atoms
     // (build_fragments), the layout of the current sort, the lists
-    std::vector<std::array<int, 3>> frag_atoms; std::vector<int> frag_cnt, frag_of_atom, frag_pos_of_atom; bool frag_ok = false, frag_built = false; std::vector<int32_t> link_pairs;   // (bonds and constraints: what holds a molecule together)
+    std::vector<std::array<int, 3>> frag_atoms; std::vector<int> frag_cnt, frag_of_atom, frag_pos_of_atom; bool frag_ok = false, frag_built = false;   // (bonds and constraints: what holds a molecule together)
     std::vector<int> sp_start_h; std::vector<int2> sp_ent_h;
     int frag_F = 0, frag_NI = 0, frag_nblk = 0, frag_ocap = 0, frag_icap = 0, frag_fpw = 1, frag_nwg = 0; double frag_m = 0.0; DBuf<int> d_ifrag; bool frag_rel = false;
     DBuf<FragRec> d_fimg; DBuf<uint4> d_fpos0; DBuf<float2> d_ljtab; int frag_ntypes = 0; DBuf<int> d_sp_start, d_ocount, d_icount; DBuf<int2> d_sp_ent; DBuf<FragBox> d_fbb; DBuf<unsigned> d_olist, d_ilist, d_xprune_s;
@@ -266,7 +274,7 @@ struct BluesEngine {
     // reciprocal space (BLUES_NB_PME, kernels_pme.h)
     template <typename T> struct PmeBufs { DBuf<T> a_re, a_im, b_re, b_im, eterm, tw_cos[3], tw_sin[3], qf_re, qf_im, phi_f; };
     bool pme = false; int pme_K[3] = {0, 0, 0}, pme_order = 5, disp_corr = 0;
-    std::vector<double> qn; std::vector<int> pme_frozen;   // NonbondedForce charges (alchemical atoms 0); frozen atoms that carry charge
+    std::vector<int> pme_frozen;   // NonbondedForce charges (alchemical atoms 0); frozen atoms that carry charge
     DBuf<double> d_qn, d_qn_full, d_frec, d_pme_e; DBuf<int> d_pme_frozen; DBuf<unsigned long long> d_pme_acc;
     PmeBufs<float> pme_f; PmeBufs<double> pme_d;
     bool pme_static_valid = false;
@@ -461,18 +469,18 @@ static void build_fragments(BluesEngine* h) {
     h->frag_built = true;
     std::vector<std::vector<int>> adj(n);
     auto link = [&](int a, int b) { if (a >= 0 && b >= 0 && a < n && b < n && a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
-    for (size_t e = 0; e + 1 < h->link_pairs.size(); e += 2) link(h->link_pairs[e], h->link_pairs[e + 1]);
+    for (size_t e = 0; e + 1 < h->T->link_pairs.size(); e += 2) link(h->T->link_pairs[e], h->T->link_pairs[e + 1]);
     h->frag_atoms.clear(); h->frag_cnt.clear();
     h->frag_of_atom.assign(n, -1); h->frag_pos_of_atom.assign(n, 0);
     std::vector<char> seen(n, 0);
     std::vector<int> order;
     for (int i = 0; i < n; i++) {
-        if (seen[i] || h->alch_local[i] >= 0) continue;
+        if (seen[i] || h->T->alch_local[i] >= 0) continue;
         order.clear(); order.push_back(i); seen[i] = 1;
         for (size_t q = 0; q < order.size(); q++) {
             std::vector<int>& nb = adj[order[q]];
             std::sort(nb.begin(), nb.end());
-            for (int b : nb) if (!seen[b] && h->alch_local[b] < 0) { seen[b] = 1; order.push_back(b); }
+            for (int b : nb) if (!seen[b] && h->T->alch_local[b] < 0) { seen[b] = 1; order.push_back(b); }
         }
         // a fragment = an atom and up to two of its own neighbours (bonded or constrained to it): every pair of its atoms is at most two
         // bonds apart, whatever the molecule -- a fragment's reach stays ~0.25 nm and constant over time.  (Round 5 cut the breadth-first
@@ -484,7 +492,7 @@ static void build_fragments(BluesEngine* h) {
             if (h->frag_of_atom[a0] >= 0) continue;
             std::array<int, 3> fr = {a0, -1, -1};
             int c = 1;
-            for (int b : adj[a0]) if (c < 3 && h->frag_of_atom[b] < 0 && h->alch_local[b] < 0 && b != fr[1]) fr[c++] = b;   // (adj is sorted: see the walk above)
+            for (int b : adj[a0]) if (c < 3 && h->frag_of_atom[b] < 0 && h->T->alch_local[b] < 0 && b != fr[1]) fr[c++] = b;   // (adj is sorted: see the walk above)
             for (int k = 0; k < c; k++) { h->frag_of_atom[fr[k]] = (int)h->frag_atoms.size(); h->frag_pos_of_atom[fr[k]] = k; }
             h->frag_atoms.push_back(fr); h->frag_cnt.push_back(c);
         }
@@ -500,7 +508,7 @@ static void build_fragments(BluesEngine* h) {
     }
     for (int fa = 0; fa < F; fa++)
         for (int a = 0; a < h->frag_cnt[fa]; a++)
-            for (int p : h->excl[h->frag_atoms[fa][a]]) {
+            for (int p : h->T->excl[h->frag_atoms[fa][a]]) {
                 const int fb = h->frag_of_atom[p];
                 if (fb < 0) continue;   // (an alchemical partner: the alchemical kernel's pair)
                 auto it = sp[fa].find(fb);
@@ -511,7 +519,7 @@ static void build_fragments(BluesEngine* h) {
     h->frag_ok = F > 0 && F < (1 << FR_MASK_SHIFT);
     {   // (the fragment kernel keeps the environment's Lennard-Jones types in a table of FR_TYPES_MAX entries; one more for absent atoms)
         std::map<std::pair<float, float>, int> types;
-        for (int i = 0; i < n; i++) if (h->alch_local[i] < 0) types[{(float)(0.5 * h->sigma[i]), (float)(2.0 * std::sqrt(h->eps[i]))}] = 1;
+        for (int i = 0; i < n; i++) if (h->T->alch_local[i] < 0) types[{(float)(0.5 * h->T->sigma[i]), (float)(2.0 * std::sqrt(h->T->eps[i]))}] = 1;
         if ((int)types.size() + 1 > FR_TYPES_MAX) h->frag_ok = false;
     }
     for (int fa = 0; fa < F; fa++) {
@@ -532,7 +540,7 @@ static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
     std::vector<std::pair<int, int>> cons; std::vector<double> cdist;
     for (int c = 0; c < s->n_constraints; c++) {
         const int i = s->constraint_atoms[2 * c], j = s->constraint_atoms[2 * c + 1];
-        const bool mi = h->mass[i] == 0.0, mj = h->mass[j] == 0.0;
+        const bool mi = h->T->mass[i] == 0.0, mj = h->T->mass[j] == 0.0;
         if (mi && mj) continue;  // OpenMM ignores constraints between two massless particles
         if (mi != mj) E_FAIL(h, "A constraint cannot involve a massless particle (%d-%d)", i, j);
         cons.push_back({i, j}); cdist.push_back(s->constraint_dist[c]);
@@ -547,7 +555,7 @@ static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
     std::vector<HostCluster> alch_first, rest;
     auto push = [&](const HostCluster& hc) {
         bool is_alch = false;
-        for (int a = 0; a < 4; a++) if (hc.atoms[a] >= 0 && h->alch_local[hc.atoms[a]] >= 0) is_alch = true;
+        for (int a = 0; a < 4; a++) if (hc.atoms[a] >= 0 && h->T->alch_local[hc.atoms[a]] >= 0) is_alch = true;
         (is_alch ? alch_first : rest).push_back(hc);
     };
     for (auto& kv : by_root) {
@@ -613,7 +621,7 @@ static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
     {
         std::vector<int> cal(ncl * 4, -1), cmo(ncl * 4, 0), mi(n, 0);
         for (size_t m = 0; m < h->mobile.size(); m++) mi[h->mobile[m]] = (int)m;
-        for (int c = 0; c < ncl * 4; c++) if (ca[c] >= 0) { cal[c] = h->alch_local[ca[c]]; cmo[c] = mi[ca[c]]; }
+        for (int c = 0; c < ncl * 4; c++) if (ca[c] >= 0) { cal[c] = h->T->alch_local[ca[c]]; cmo[c] = mi[ca[c]]; }
         h->d_cl_alch.upload(cal); h->d_cl_mobile.upload(cmo); h->d_cl_sorted.alloc((size_t)ncl * 4);
         h->h_recs.assign(ncl, ClusterRec());
         for (int c = 0; c < ncl; c++) {
@@ -621,7 +629,7 @@ static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
             r.type = ct[c]; r.nc = cn[c]; r.na = 0;
             for (int a = 0; a < 4; a++) {
                 r.atoms[a] = ca[c * 4 + a]; r.alch[a] = cal[c * 4 + a]; r.mobile[a] = cmo[c * 4 + a]; r.sorted[a] = 0; r.islot[a] = -1;
-                if (r.atoms[a] >= 0) { r.na = a + 1; r.w[a] = 1.0 / h->mass[r.atoms[a]]; }
+                if (r.atoms[a] >= 0) { r.na = a + 1; r.w[a] = 1.0 / h->T->mass[r.atoms[a]]; }
             }
             for (int q = 0; q < 3; q++) r.dist[q] = cd[c * 3 + q];
         }
@@ -636,7 +644,7 @@ static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
 static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
     // all terms are kept for energies; rows (force gather) only for mobile atoms
     std::vector<int> ta[T_NTYPES]; std::vector<double> tp[T_NTYPES];
-    auto is_alch = [&](int i) { return h->alch_local[i] >= 0; };
+    auto is_alch = [&](int i) { return h->T->alch_local[i] >= 0; };
     for (int b = 0; b < s->n_bonds; b++) { ta[T_BOND].push_back(s->bond_atoms[2 * b]); ta[T_BOND].push_back(s->bond_atoms[2 * b + 1]); tp[T_BOND].push_back(s->bond_params[2 * b]); tp[T_BOND].push_back(s->bond_params[2 * b + 1]); }
     for (int a = 0; a < s->n_angles; a++) { for (int q = 0; q < 3; q++) ta[T_ANGLE].push_back(s->angle_atoms[3 * a + q]); tp[T_ANGLE].push_back(s->angle_params[2 * a]); tp[T_ANGLE].push_back(s->angle_params[2 * a + 1]); }
     for (int t = 0; t < s->n_torsions; t++) { for (int q = 0; q < 4; q++) ta[T_TORSION].push_back(s->torsion_atoms[4 * t + q]); for (int q = 0; q < 3; q++) tp[T_TORSION].push_back(s->torsion_params[3 * t + q]); }
@@ -647,16 +655,16 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
         const double* p = s->exception_params + 3 * e;
         if (!is_alch(i) && !is_alch(j)) { ta[T_EXC].push_back(i); ta[T_EXC].push_back(j); for (int q = 0; q < 3; q++) tp[T_EXC].push_back(p[q]); }
         else if (is_alch(i) && is_alch(j)) {
-            arow_partner[h->alch_local[i]].push_back(j); for (int q = 0; q < 3; q++) arow_par[h->alch_local[i]].push_back(p[q]);
-            arow_partner[h->alch_local[j]].push_back(i); for (int q = 0; q < 3; q++) arow_par[h->alch_local[j]].push_back(p[q]);
+            arow_partner[h->T->alch_local[i]].push_back(j); for (int q = 0; q < 3; q++) arow_par[h->T->alch_local[i]].push_back(p[q]);
+            arow_partner[h->T->alch_local[j]].push_back(i); for (int q = 0; q < 3; q++) arow_par[h->T->alch_local[j]].push_back(p[q]);
         } else if (p[0] != 0.0 || p[2] != 0.0) {  // alchemical x environment: one row entry on the alchemical side
             const int a = is_alch(i) ? i : j, e2 = is_alch(i) ? j : i;
-            arow_partner[h->alch_local[a]].push_back(e2); for (int q = 0; q < 3; q++) arow_par[h->alch_local[a]].push_back(p[q]);
+            arow_partner[h->T->alch_local[a]].push_back(e2); for (int q = 0; q < 3; q++) arow_par[h->T->alch_local[a]].push_back(p[q]);
         }
     }
     if (h->pme) for (int e = 0; e < s->n_exclusions; e++) {   // every excluded pair: its reciprocal-space interaction is removed again
         const int i = s->exclusions[2 * e], j = s->exclusions[2 * e + 1];
-        const double qq = h->qn[i] * h->qn[j];
+        const double qq = h->T->qn[i] * h->T->qn[j];
         if (qq != 0.0) { ta[T_EWEX].push_back(i); ta[T_EWEX].push_back(j); tp[T_EWEX].push_back(qq); }
     }
     for (int r = 0; r < s->n_restraints; r++) { ta[T_RESTR].push_back(s->restraint_atoms[r]); for (int q = 0; q < 3; q++) tp[T_RESTR].push_back(s->restraint_x0[3 * r + q]); }
@@ -668,7 +676,7 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
         for (int t = 0; t < h->n_terms[ty]; t++) for (int q = 0; q < width[ty]; q++) {
             const int i = ta[ty][t * width[ty] + q];
             if (i < 0 || i >= h->n) E_FAIL(h, "bonded term references atom %d", i);
-            if (h->mass[i] != 0.0) { rtype[i].push_back(ty); rterm[i].push_back(t); rrole[i].push_back(q); }
+            if (h->T->mass[i] != 0.0) { rtype[i].push_back(ty); rterm[i].push_back(t); rrole[i].push_back(q); }
         }
         h->d_term_atoms[ty].upload(ta[ty]); h->d_term_params[ty].upload(tp[ty]);
     }
@@ -687,7 +695,7 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
     // alchemical exception rows
     std::vector<int> es(1, 0), ep, eo; std::vector<double> epar;
     for (size_t a = 0; a < h->alch.size(); a++) { eo.insert(eo.end(), arow_partner[a].size(), h->alch[a]); ep.insert(ep.end(), arow_partner[a].begin(), arow_partner[a].end()); epar.insert(epar.end(), arow_par[a].begin(), arow_par[a].end()); es.push_back((int)ep.size()); }
-    { std::vector<int> ie(ep.size()); for (size_t q = 0; q < ep.size(); q++) ie[q] = h->alch_local[ep[q]] < 0; h->d_exc_is_env.upload(ie); }
+    { std::vector<int> ie(ep.size()); for (size_t q = 0; q < ep.size(); q++) ie[q] = h->T->alch_local[ep[q]] < 0; h->d_exc_is_env.upload(ie); }
     h->d_exc_start.upload(es); h->d_exc_partner.upload(ep); h->d_exc_owner.upload(eo); h->d_exc_params.upload(epar);
     return 0;
 }
@@ -704,7 +712,7 @@ static int sort_and_tile(BluesEngine* h) {
     // have scattered over MD legs, reference blues/simulation.py:1028-1037 hands such a State over every iteration); on request
     bool want_frag = false;
     {
-        size_t mobile_env = 0; for (int o : h->mobile) mobile_env += h->alch_local[o] < 0;
+        size_t mobile_env = 0; for (int o : h->mobile) mobile_env += h->T->alch_local[o] < 0;
         const int nit = ((int)mobile_env + 63) / 64;
         const bool all_mobile = mobile_env + h->alch.size() == (size_t)n;
         const bool asked = h->precision == 0 && mobile_env > 0 && h->tune.k1_mode != 1 && h->tune.k1_mode != 2
@@ -732,7 +740,7 @@ static int sort_and_tile(BluesEngine* h) {
     std::vector<int> tile_atoms, islot(n, -1);
     for (int s = 0; s < n; s++) {
         const int o = h->h_orig_of_sorted[s];
-        if (h->mass[o] != 0.0 && h->alch_local[o] < 0) { islot[o] = (int)tile_atoms.size(); tile_atoms.push_back(s); }
+        if (h->T->mass[o] != 0.0 && h->T->alch_local[o] < 0) { islot[o] = (int)tile_atoms.size(); tile_atoms.push_back(s); }
     }
     h->n_itiles = ((int)tile_atoms.size() + 63) / 64;
     tile_atoms.resize((size_t)h->n_itiles * 64, -1);
@@ -812,7 +820,7 @@ static int sort_and_tile(BluesEngine* h) {
         bool want_atom = h->k1_mode == 1;
         if (h->tune.k1_mode == 1) want_atom = false;
         if (h->forbid_atom) want_atom = false;
-        for (int o : h->mobile) if ((int)h->excl[o].size() + 1 > SX_MAX) want_atom = false;   // (the builder of the atoms' lists keeps an atom's excluded partners in one fixed row: kernels_nb.h SX_ROW)
+        for (int o : h->mobile) if ((int)h->T->excl[o].size() + 1 > SX_MAX) want_atom = false;   // (the builder of the atoms' lists keeps an atom's excluded partners in one fixed row: kernels_nb.h SX_ROW)
         if (want_atom && h->n_itiles > 0) {
             double est_rad = 0.0;   // radius of the widest group of the last estimate
             auto group_est = [&](int S) {   // largest expected list length over the groups of S tiles
@@ -910,7 +918,7 @@ static int sort_and_tile(BluesEngine* h) {
     h->k2_jiter = std::min(h->k2_jiter, h->PA);   // an env block stages (256 / PA) * jiter <= K2_STAGE list entries in LDS
     {   // dense form: large batches in mixed precision whose alchemical group is free (no excluded environment partner) and small
         double half_min = 1e30; for (int k = 0; k < 3; k++) half_min = std::min(half_min, 0.5 * h->box[k]);
-        int mobile_env = 0; for (int o : h->mobile) mobile_env += h->alch_local[o] < 0;
+        int mobile_env = 0; for (int o : h->mobile) mobile_env += h->T->alch_local[o] < 0;
         // (its marking pass measures every list entry from the first alchemical atom and subtracts the other atoms' offsets: a pair
         // within the cutoff comes out as its minimum image as long as half a box edge exceeds cutoff + the group's extent; the
         // pair pass takes the minimum image itself)
@@ -931,7 +939,7 @@ static int sort_and_tile(BluesEngine* h) {
     for (int s = 0; s < n; s++) {
         const int o = h->h_orig_of_sorted[s];
         std::vector<int> row; row.push_back(s);
-        for (int p : h->excl[o]) row.push_back(h->h_sorted_of_orig[p]);
+        for (int p : h->T->excl[o]) row.push_back(h->h_sorted_of_orig[p]);
         std::sort(row.begin(), row.end());
         ex_idx.insert(ex_idx.end(), row.begin(), row.end());
         ex_start[s + 1] = (int)ex_idx.size();
@@ -943,11 +951,11 @@ static int sort_and_tile(BluesEngine* h) {
     if (h->precision == 0) imf.resize(n); else imd.resize(n);
     for (int s = 0; s < n; s++) {
         const int o = h->h_orig_of_sorted[s];
-        const bool al = h->alch_local[o] >= 0;
-        const unsigned flags = (al ? FLAG_ALCH : 0u) | ((h->mass[o] != 0.0 && !al) ? FLAG_MOBILE : 0u);
+        const bool al = h->T->alch_local[o] >= 0;
+        const unsigned flags = (al ? FLAG_ALCH : 0u) | ((h->T->mass[o] != 0.0 && !al) ? FLAG_MOBILE : 0u);
         unsigned long long u[3];
         for (int k = 0; k < 3; k++) { double fr = h->hx[3 * o + k] / h->box[k]; fr -= std::floor(fr); if (fr >= 1.0) fr = 0.0; u[k] = (unsigned long long)(fr * 18446744073709551616.0); }
-        const double q = al ? 0.0 : h->charge[o] * sq, hs = 0.5 * h->sigma[o], se = al ? 0.0 : 2.0 * std::sqrt(h->eps[o]);
+        const double q = al ? 0.0 : h->T->charge[o] * sq, hs = 0.5 * h->T->sigma[o], se = al ? 0.0 : 2.0 * std::sqrt(h->T->eps[o]);
         if (h->precision == 0) {
             AtomF& A = imf[s];
             A.x = (uint32_t)((u[0] + 0x80000000ull) >> 32); A.y = (uint32_t)((u[1] + 0x80000000ull) >> 32); A.z = (uint32_t)((u[2] + 0x80000000ull) >> 32);
@@ -974,8 +982,8 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_ex_start.upload(ex_start); h->d_ex_idx.upload(ex_idx);
         h->d_jrec.alloc((size_t)jcap);
         { std::vector<AlchARec> ar(h->alch.size());
-          for (size_t a2 = 0; a2 < h->alch.size(); a2++) { AlchARec& r = ar[a2]; const int ao = h->alch[a2]; r.ao = ao; r.asrt = h->h_sorted_of_orig[ao]; r.pad = 0; r.sig = h->sigma[ao]; r.eps = std::sqrt(h->eps[ao]); r.q = h->charge[ao];   // (eps: its square root, see AlchARec)
-            r.has_env_excl = 0; for (int p2 : h->excl[ao]) if (h->alch_local[p2] < 0) r.has_env_excl = 1; }
+          for (size_t a2 = 0; a2 < h->alch.size(); a2++) { AlchARec& r = ar[a2]; const int ao = h->alch[a2]; r.ao = ao; r.asrt = h->h_sorted_of_orig[ao]; r.pad = 0; r.sig = h->T->sigma[ao]; r.eps = std::sqrt(h->T->eps[ao]); r.q = h->T->charge[ao];   // (eps: its square root, see AlchARec)
+            r.has_env_excl = 0; for (int p2 : h->T->excl[ao]) if (h->T->alch_local[p2] < 0) r.has_env_excl = 1; }
           h->d_arec.upload(ar); }
         // (per-atom lists: room for one group list per i-tile, so that a batch can move its members to a finer shape -- fewer tiles per
         // list -- without laying anybody out again: reshape_groups; 1.5 MB per member of the benchmark system)
@@ -1032,7 +1040,7 @@ static int sort_and_tile(BluesEngine* h) {
                 r.islot0 = -1;
                 for (int b = 0; b < cnt; b++) {
                     const int ob = h->h_orig_of_sorted[sx + b];
-                    if (h->mass[ob] != 0.0) { r.types |= 1u << (26 + b); if (r.islot0 < 0) r.islot0 = islot[ob]; }
+                    if (h->T->mass[ob] != 0.0) { r.types |= 1u << (26 + b); if (r.islot0 < 0) r.islot0 = islot[ob]; }
                 }
                 if (FR_MOB(r.types)) ifrag.push_back((int)recs.size());
                 for (int b = 0; b < 3; b++) {
@@ -1097,7 +1105,6 @@ static int sort_and_tile(BluesEngine* h) {
         h->d_fJ.alloc((size_t)9 * n);
         h->d_self_part.alloc((size_t)(h->k2_nblocks_env + 1) * 9 * 64); h->d_e_part.alloc((size_t)(h->k2_nblocks_env + 1) * K2_NP); h->d_mom_part.alloc((size_t)(h->n_islots / 64 + 2) * 6);
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
-    h->hx_sort = h->hx;
     for (int k = 0; k < 3; k++)   // the master positions on the device are the ones just sorted (every caller uploads / downloads first)
         if (hipMemcpy(h->d_x_sort[k].p, h->d_x[k].p, sizeof(double) * n, hipMemcpyDeviceToDevice) != hipSuccess) E_FAIL(h, "hipMemcpy D2D failed");
     h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->graph_valid = false;
@@ -1684,14 +1691,14 @@ template <typename T> static int pme_tables(BluesEngine* h) {
     } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     // constants of the box: self term, neutralising background, dispersion correction
     double qsum = 0.0, q2 = 0.0;
-    for (double q : h->qn) { qsum += q; q2 += q * q; }
+    for (double q : h->T->qn) { qsum += q; q2 += q * q; }
     const double V = h->box[0] * h->box[1] * h->box[2];
     h->e_ewald_const = -ONE_4PI_EPS0 * h->alpha / std::sqrt(M_PI) * q2 - M_PI * ONE_4PI_EPS0 * qsum * qsum / (2.0 * V * h->alpha * h->alpha);
     h->e_disp = 0.0;
     if (h->disp_corr) {   // [recalled: OpenMM NonbondedForceImpl::calcDispersionCorrection without switching function]; alchemical atoms enter with epsilon 0
         std::vector<double> cs, ce; std::vector<long long> cn;
         for (int i = 0; i < h->n; i++) {
-            const double e = h->alch_local[i] >= 0 ? 0.0 : h->eps[i], sg = h->sigma[i];
+            const double e = h->T->alch_local[i] >= 0 ? 0.0 : h->T->eps[i], sg = h->T->sigma[i];
             size_t c = 0; for (; c < cs.size(); c++) if (cs[c] == sg && ce[c] == e) break;
             if (c == cs.size()) { cs.push_back(sg); ce.push_back(e); cn.push_back(0); }
             cn[c]++;
@@ -2958,20 +2965,47 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     derive_margins(h);   // (again once the mobile set is known: sort_and_tile)
     fit_ewald_poly(h->alpha, h->cutoff, &h->ewpoly);
     h->annih_elec = s->annihilate_electrostatics; h->annih_ster = s->annihilate_sterics; h->remove_cm = s->remove_cm_motion;
-    h->mass.assign(s->mass, s->mass + n); h->charge.assign(s->charge, s->charge + n); h->sigma.assign(s->sigma, s->sigma + n); h->eps.assign(s->epsilon, s->epsilon + n);
-    h->excl.assign(n, {});
-    for (int e = 0; e < s->n_exclusions; e++) {
-        const int a = s->exclusions[2 * e], b = s->exclusions[2 * e + 1];
-        if (a < 0 || b < 0 || a >= n || b >= n) E_FAIL(h, "exclusion references atom out of range");
-        h->excl[a].push_back(b); h->excl[b].push_back(a);
-    }
     h->alch.assign(s->alchemical_atoms, s->alchemical_atoms + s->n_alchemical);
     if (h->alch.size() > 64) E_FAIL(h, "more than 64 alchemical atoms is not supported yet");
-    h->alch_local.assign(n, -1);
-    for (size_t a = 0; a < h->alch.size(); a++) h->alch_local[h->alch[a]] = (int)a;
-    for (int a : h->alch) for (int p : h->excl[a]) if (h->alch_local[p] < 0) h->check_env_excl = 1;
+    for (int a : h->alch) if (a < 0 || a >= n) E_FAIL(h, "alchemical atom out of range");
+    {   // the System's host tables: found by content (FNV-1a over every array they are made from), built once
+        static std::mutex mu; static std::map<uint64_t, std::weak_ptr<HostTopology>> known;
+        uint64_t key = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t bytes) {   // (FNV-1a over 64-bit words, the tail byte by byte: 2 MB of arrays per engine)
+            const unsigned char* c = static_cast<const unsigned char*>(p);
+            size_t i = 0;
+            for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, c + i, 8); key ^= w; key *= 1099511628211ull; key ^= key >> 29; }
+            for (; i < bytes; i++) { key ^= c[i]; key *= 1099511628211ull; }
+        };
+        const int32_t counts[5] = {n, s->n_exclusions, s->n_alchemical, s->n_bonds, s->n_constraints};
+        mix(counts, sizeof counts);
+        mix(s->mass, sizeof(double) * n); mix(s->charge, sizeof(double) * n); mix(s->sigma, sizeof(double) * n); mix(s->epsilon, sizeof(double) * n);
+        mix(s->exclusions, sizeof(int32_t) * 2 * (size_t)s->n_exclusions); mix(s->alchemical_atoms, sizeof(int32_t) * (size_t)s->n_alchemical);
+        mix(s->bond_atoms, sizeof(int32_t) * 2 * (size_t)s->n_bonds); mix(s->constraint_atoms, sizeof(int32_t) * 2 * (size_t)s->n_constraints);
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = known.find(key);
+        if (it != known.end()) h->T = it->second.lock();
+        if (h->T && ((int)h->T->mass.size() != n || (int)h->T->link_pairs.size() != 2 * (s->n_bonds + s->n_constraints))) h->T.reset();   // (a hash collision: build afresh, share nothing)
+        if (!h->T) {
+            auto T = std::make_shared<HostTopology>();
+            T->mass.assign(s->mass, s->mass + n); T->charge.assign(s->charge, s->charge + n); T->sigma.assign(s->sigma, s->sigma + n); T->eps.assign(s->epsilon, s->epsilon + n);
+            T->excl.assign(n, {});
+            for (int e = 0; e < s->n_exclusions; e++) {
+                const int a = s->exclusions[2 * e], b = s->exclusions[2 * e + 1];
+                if (a < 0 || b < 0 || a >= n || b >= n) E_FAIL(h, "exclusion references atom out of range");
+                T->excl[a].push_back(b); T->excl[b].push_back(a);
+            }
+            T->alch_local.assign(n, -1);
+            for (size_t a = 0; a < h->alch.size(); a++) T->alch_local[h->alch[a]] = (int)a;
+            T->qn = T->charge; for (int a : h->alch) T->qn[a] = 0.0;
+            T->link_pairs.assign(s->bond_atoms, s->bond_atoms + 2 * (size_t)s->n_bonds); T->link_pairs.insert(T->link_pairs.end(), s->constraint_atoms, s->constraint_atoms + 2 * (size_t)s->n_constraints);
+            h->T = T; known[key] = T;
+            for (auto q = known.begin(); q != known.end();) { if (q->second.expired()) q = known.erase(q); else ++q; }
+        }
+    }
+    for (int a : h->alch) for (int p : h->T->excl[a]) if (h->T->alch_local[p] < 0) h->check_env_excl = 1;
     h->total_mass = 0.0;
-    for (int i = 0; i < n; i++) if (h->mass[i] != 0.0) { h->mobile.push_back(i); h->total_mass += h->mass[i]; }
+    for (int i = 0; i < n; i++) if (h->T->mass[i] != 0.0) { h->mobile.push_back(i); h->total_mass += h->T->mass[i]; }
     // integrator
     h->dt = it->timestep; h->temperature = it->temperature; h->gamma = it->collision_rate; h->kT = KB_KJ * it->temperature;
     h->tol = it->constraint_tolerance; h->nsteps = it->nsteps_neq; h->nprop = it->nprop; h->n_lambda = it->n_lambda_steps;
@@ -3021,9 +3055,9 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     try {
         for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); h->d_x_sort[k].alloc(n); }
         h->d_stage.alloc((size_t)3 * n); h->d_xfer_out.alloc(4); h->hx.assign((size_t)3 * n, 0.0);
-        h->d_mass.upload(h->mass); h->d_charge.upload(h->charge); h->d_sigma.upload(h->sigma); h->d_eps.upload(h->eps);
+        h->d_mass.upload(h->T->mass); h->d_charge.upload(h->T->charge); h->d_sigma.upload(h->T->sigma); h->d_eps.upload(h->T->eps);
         h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ctrl.alloc(1); h->d_stamps.alloc(64); h->d_tab_ls.upload(h->tab_ls); h->d_tab_le.upload(h->tab_le); h->d_ftot.alloc((size_t)9 * n); h->d_alch_self.alloc(9 * 64);
-        h->d_alch_orig.upload(h->alch); h->d_alch_local.upload(h->alch_local);
+        h->d_alch_orig.upload(h->alch); h->d_alch_local.upload(h->T->alch_local);
         // (the protocol-work trace: one slot per step of the switch; an MD integrator has no H step, no protocol work -- and an
         // nsteps of 2^30, which used to be 8 GiB of HBM per MD engine)
         h->d_trace.alloc(it->n_lambda_steps > 0 ? (size_t)std::max(1, h->nsteps) : (size_t)1); h->d_scratch.alloc((size_t)std::max(3 * n, 1024));
@@ -3035,14 +3069,12 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
               h->d_noise.alloc((size_t)h->n_noise * 3 * std::max<size_t>(1, h->mobile.size())); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     }
     if (h->pme) {
-        h->qn = h->charge; for (int a : h->alch) h->qn[a] = 0.0;
-        for (int i = 0; i < n; i++) if (h->mass[i] == 0.0 && h->qn[i] != 0.0) h->pme_frozen.push_back(i);
-        try { h->d_qn.upload(h->qn); h->d_qn_full.upload(h->charge); h->d_pme_frozen.upload(h->pme_frozen); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
+        for (int i = 0; i < n; i++) if (h->T->mass[i] == 0.0 && h->T->qn[i] != 0.0) h->pme_frozen.push_back(i);
+        try { h->d_qn.upload(h->T->qn); h->d_qn_full.upload(h->T->charge); h->d_pme_frozen.upload(h->pme_frozen); } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
         if (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h)) return 1;
     }
     if (build_clusters(h, s)) return 1;
     // (the fragments of kernels_frag.h are cut when a layout first asks for them: sort_and_tile)
-    h->link_pairs.assign(s->bond_atoms, s->bond_atoms + 2 * (size_t)s->n_bonds); h->link_pairs.insert(h->link_pairs.end(), s->constraint_atoms, s->constraint_atoms + 2 * (size_t)s->n_constraints);
     try { if (build_bonded(h, s)) return 1; } catch (std::string& e) { E_FAIL(h, "%s", e.c_str()); }
     return 0;
 }
@@ -3319,7 +3351,7 @@ int blues_set_positions(BluesEngine* h, const double* xyz, int32_t n_atoms) {
     if (before_position_edit(h)) return 1;
     // store every constraint cluster as one whole periodic image (a lattice translation of single atoms is
     // physically a no-op); the cluster solves in k_integrate then need no minimum-image arithmetic
-    std::vector<double>& st = h->h_stage;
+    static thread_local std::vector<double> st;   // (staging of one host transfer: per thread, not per engine -- 560 KB x 2048 chains otherwise)
     st.assign(xyz, xyz + 3 * (size_t)h->n);
     for (const HostCluster& c : h->clusters) for (int a = 1; a < 4; a++) if (c.atoms[a] >= 0)
         for (int k = 0; k < 3; k++) {
@@ -4343,7 +4375,7 @@ int blues_batch_time_nonbonded_modes(BluesBatch* b, int32_t reps, double usec[2]
             if (hipMemcpy(&f, m->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) np += f.prunes;
             nf += (double)m->st_passes;
         }
-        int n_i = 0; for (int i : h->mobile) if (h->alch_local[i] < 0) n_i++;
+        int n_i = 0; for (int i : h->mobile) if (h->T->alch_local[i] < 0) n_i++;
         if (prune_fraction) *prune_fraction = (h->prune_on && h->k1_mode == 2) ? (nf > 0.0 && n_i > 0 ? std::min(1.0, np / (nf * n_i)) : 1.0) : 0.0;
     }
     b->failed.assign(b->R(), 0); b->active.assign(b->R(), 1);

@@ -106,3 +106,16 @@ def test_eight_ranks_with_real_engines_on_one_gpu():
     el = out["rank_elapsed_seconds"]
     assert 0.0 < el["min"] <= el["max"] and el["max"] < 900.0
     assert out["engine"]["lockstep_steps_per_switch"] >= 200 and out["engine"]["fallback_steps_per_switch"] == 0
+    # eight ranks on one host share its cores: set-up threads and the library's re-sort pool are cores / ranks each (replicas.host_thread_share)
+    import os as _os
+    cores = len(_os.sched_getaffinity(0))
+    assert out["engine"]["host_threads"] == max(1, min(16, cores // 8)) and out["engine"]["setup_threads"] == out["engine"]["host_threads"]
+    # ... and the per-chain host work of the plugin boundary (hand-over, Metropolis test, reset) of a rank must not suffer from its seven
+    # neighbours: against ONE rank running the same thing alone.  (All eight ranks share ONE GPU here, which the eight-GPU node does not:
+    # the bound leaves room for their launches queueing behind each other.)
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                         "--replicas", "8", "--groups", "1", "--nsteps-nc", "200", "--no-cpu", "--no-single"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    alone = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])["per_rank"]["boundary_seconds_per_iteration"][0]
+    together = pr["boundary_seconds_per_iteration"]
+    assert len(together) == 8 and max(together) <= 1.5 * alone + 0.05, (together, alone)
