@@ -261,7 +261,7 @@ def cpu_baseline(system, vel, nsteps_sample):
     return out
 
 
-PMC_FILE = "profiles/r05_pmc_nonbonded.json"
+PMC_FILE = "profiles/r06_pmc_nonbonded.json"
 
 
 def kernel_source_sha():
@@ -658,6 +658,10 @@ def main():
                       "algorithmic_bytes_per_launch": algo,
                       "algorithmic_bytes_definition": "36 B x all %d atoms x %d chains (SURVEY.md 8d: nominal, defined on all atoms)" % (n_atoms, R_launch),
                       "traffic": ev["traffic_bytes_per_launch"] if ev and "traffic_bytes_per_launch" in ev else None,
+                      # the same roofline on MEASURED HBM bytes (north_star: "evidenced by rocprof HBM GB/s"): the counters' traffic over the launch's
+                      # duration -- an upper bound where the reads are gathers (FETCH_SIZE is doubled: profiles/README.md); null without counters of this build
+                      "achieved_counter": (ev["traffic_bytes_per_launch"] / secs / 1e9) if ev and "traffic_bytes_per_launch" in ev else None,
+                      "frac_counter": (ev["traffic_bytes_per_launch"] / secs / 1e9 / HBM_PEAK_GBS) if ev and "traffic_bytes_per_launch" in ev else None,
                       "mobile_only": {"algorithmic_bytes": mob_bytes, "achieved": mob_bytes / secs / 1e9, "frac": mob_bytes / secs / 1e9 / HBM_PEAK_GBS,
                                       "definition": "24 B x %d environment atoms within the cutoff of a mobile atom + 12 B x %d mobile atoms, per chain" % (n_touched, n_i)},
                       "pairs": {"in_range_per_launch": n_pairs * R_launch,

@@ -1427,6 +1427,7 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
 #undef OPEN32
                 if (e != hipSuccess) E_FAIL(h, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
                 opened32[lead] = true;
+                if (h->tune.debug_lists && lead) { int nb = -1; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_alchemical_dense32_b<5>, K2F_THREADS, sizeof(K2FLds<2>)); fprintf(stderr, "[dense32] %zu bytes of LDS per workgroup: %d workgroups per CU\n", sizeof(K2FLds<2>), nb); }
             }
             if (lead) {
                 const int nrep = h->batch->R();
@@ -4403,7 +4404,9 @@ int blues_batch_time_nonbonded_modes(BluesBatch* b, int32_t reps, double usec[2]
     { long long st[64]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nb_stamps), sizeof st);
       fprintf(stderr, "[stamps] nonbonded_atom_b, the workgroup that stamped last (10 ns ticks since its entry: slot records, image requested + mobile positions asked for, barrier, then wave 0's turns: walked / reduced ...):");
       for (int i = 17; i < 28; i++) fprintf(stderr, " %lld", st[i] - st[16]);
-      fprintf(stderr, " | waves out of atoms at:"); for (int i = 44; i < 60; i++) fprintf(stderr, " %lld", st[i] - st[16]); fprintf(stderr, "\n"); }
+      fprintf(stderr, " | waves out of atoms at:"); for (int i = 44; i < 60; i++) fprintf(stderr, " %lld", st[i] - st[16]); fprintf(stderr, "\n");
+      fprintf(stderr, "[stamps] alchemical_dense32_b, one workgroup (cycles since its entry: image staged; wave 0 done with its first, second atom; waves 0..7 out of atoms; end):");
+      for (int i = 33; i < 44; i++) fprintf(stderr, " %lld", st[i] - st[32]); fprintf(stderr, " %lld\n", st[60] - st[32]); }
 #endif
     usec[0] = 1000.0 * ms[0] / std::max(1, reps); usec[1] = 1000.0 * ms[1] / std::max(1, reps);
     batch_leave(b);

@@ -662,24 +662,26 @@ __device__ __forceinline__ void alchemical_dense_body(AlchArgs& A) {
 //    between marking and arithmetic; the force on its atom is a per-lane fp32 sum and one DPP reduction (a fixed order: batch = solo
 //    stays bitwise); the force on a mobile environment atom goes to 64-bit fixed-point accumulators in LDS as before (integer
 //    addition is associative);
-//  * 78 KB of LDS and < 128 registers: two workgroups per CU.
+//  * 73 KB of LDS and < 128 registers: two workgroups per CU.
 #define K2F_THREADS 512
 #define K2F_WAVES (K2F_THREADS / 64)
 #define K2F_JC 2432        // list entries staged at a time (38 chunks; the alchemical tile's list of the benchmark system is ~2,400 entries)
 #define K2F_MOB 288        // mobile entries per round with a force accumulator
 #define K2F_RING 128
+#define K2F_FIX 8192.0f    // 2^13: the reaction accumulators resolve 1.2e-4 kJ/mol/nm (1e-8 of the forces a clash produces; the fp32 pair force itself carries 3e-7 of its size) and hold +-2.6e5 kJ/mol/nm:
+                           // 32-bit, so that two workgroups fit a CU's LDS with room to spare (64-bit accumulators put the record at 80.5 KB: ONE workgroup per CU on the hardware, 96 us per launch)
 template <int NS> struct K2FLds {
     uint4 r4[K2F_JC];                       // x, y, z (fixed point), q sqrt(k_e) as float bits
     float2 r2[K2F_JC];                      // sigma / 2, 2 sqrt(eps)
     unsigned short mslot[K2F_JC];
-    unsigned long long fj[3 * NS][K2F_MOB];
+    int fj[3 * NS][K2F_MOB];                // reaction on the mobile entries: 32-bit fixed point (K2F_FIX), see below
     unsigned short ring[K2F_WAVES][K2F_RING];
     int mcnt[(K2F_JC + 63) / 64 + 2];
     unsigned xa[3][16]; float aq[16], ahs[16], ase[16];
     float fa[16][9];
     double e[K2F_WAVES][4];
 };
-static_assert(sizeof(K2FLds<2>) <= 80 * 1024, "two workgroups of the fp32 dense alchemical kernel per CU");
+static_assert(sizeof(K2FLds<2>) <= 76 * 1024, "two workgroups of the fp32 dense alchemical kernel per CU, with room for the allocation granule");
 
 template <int MASK>
 __device__ __forceinline__ void alchemical_dense32_body(AlchArgs& A) {
@@ -694,6 +696,8 @@ __device__ __forceinline__ void alchemical_dense32_body(AlchArgs& A) {
     extern __shared__ __align__(16) unsigned char k2d_smem[];
     K2FLds<NS>& S = *reinterpret_cast<K2FLds<NS>*>(k2d_smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool stamp_wg = blockIdx.x == (gridDim.x * 5u) / 8u;   // (stamped builds: one workgroup of the launch's third quarter)
+    NB_STAMP(stamp_wg && tid == 0, 32);
     const int count = *A.jcount;
     if (count <= 0) return;   // (finalize reads no env slab then)
     const AtomF* __restrict__ img = A.img;
@@ -719,7 +723,7 @@ __device__ __forceinline__ void alchemical_dense32_body(AlchArgs& A) {
         const int nst = min(K2F_JC, count - j0), nchunk = (nst + 63) >> 6;
         // ---- stage the round: list entry -> image record (two dependent loads, every entry of a level in flight together); mobile
         // entries numbered in list order
-        for (int w = tid; w < 3 * NS * K2F_MOB; w += K2F_THREADS) S.fj[w / K2F_MOB][w % K2F_MOB] = 0ull;
+        for (int w = tid; w < 3 * NS * K2F_MOB; w += K2F_THREADS) S.fj[w / K2F_MOB][w % K2F_MOB] = 0;
         int js[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; it++) { const int k = it * K2F_THREADS + tid; js[it] = k < nst ? A.jlist[j0 + k] : -1; }
@@ -754,6 +758,7 @@ __device__ __forceinline__ void alchemical_dense32_body(AlchArgs& A) {
             }
         }
         __syncthreads();
+        NB_STAMP(stamp_wg && tid == 0, 33);
         // ---- a wave per alchemical atom: sweep, compact, compute
         for (int a = wv; a < A.n_alch; a += K2F_WAVES) {
             const unsigned xa = S.xa[0][a], ya = S.xa[1][a], za = S.xa[2][a];
@@ -812,9 +817,9 @@ __device__ __forceinline__ void alchemical_dense32_body(AlchArgs& A) {
                     const float fx = ft[q] * dx, fy = ft[q] * dy, fz = ft[q] * dz;
                     fa[q][0] += fx; fa[q][1] += fy; fa[q][2] += fz;
                     if (ms != 0xffffu) {   // force on a mobile environment atom: minus the pair force
-                        atomicAdd(&S.fj[3 * q + 0][ms], (unsigned long long)__double2ll_rn(-(double)fx * K2D_FIX));
-                        atomicAdd(&S.fj[3 * q + 1][ms], (unsigned long long)__double2ll_rn(-(double)fy * K2D_FIX));
-                        atomicAdd(&S.fj[3 * q + 2][ms], (unsigned long long)__double2ll_rn(-(double)fz * K2D_FIX));
+                        atomicAdd(&S.fj[3 * q + 0][ms], __float2int_rn(-fx * K2F_FIX));
+                        atomicAdd(&S.fj[3 * q + 1][ms], __float2int_rn(-fy * K2F_FIX));
+                        atomicAdd(&S.fj[3 * q + 2][ms], __float2int_rn(-fz * K2F_FIX));
                     }
                 }
             };
@@ -841,7 +846,9 @@ __device__ __forceinline__ void alchemical_dense32_body(AlchArgs& A) {
 #pragma unroll
                 for (int c3 = 0; c3 < 3; c3++) { const float v = wave_sum_dpp_f32(fa[q][c3]); if (lane == 0) S.fa[a][s * 3 + c3] += v; }
             }
+            NB_STAMP(stamp_wg && lane == 0 && wv == 0, 34 + min(a / K2F_WAVES, 1));
         }
+        NB_STAMP(stamp_wg && lane == 0, 36 + min(wv, 7));
         __syncthreads();
         // ---- the round's mobile entries: force by sorted index (every one of them is written: zero if it had no pair)
 #pragma unroll
@@ -854,7 +861,7 @@ __device__ __forceinline__ void alchemical_dense32_body(AlchArgs& A) {
                 for (int s = 0; s < 3; s++) {
                     if (!slot_on(s)) continue;
 #pragma unroll
-                    for (int c3 = 0; c3 < 3; c3++) A.fJ[(size_t)(s * 3 + c3) * A.n + js[it]] = (double)(long long)S.fj[3 * slot_ix(s) + c3][ms] * (1.0 / K2D_FIX);
+                    for (int c3 = 0; c3 < 3; c3++) A.fJ[(size_t)(s * 3 + c3) * A.n + js[it]] = (double)S.fj[3 * slot_ix(s) + c3][ms] * (1.0 / (double)K2F_FIX);
                 }
             }
         }
@@ -875,6 +882,7 @@ __device__ __forceinline__ void alchemical_dense32_body(AlchArgs& A) {
         A.e_part[4] = 0.0; A.e_part[5] = 0.0;
     }
     if (tid < 3) { double t = 0.0; for (int a = 0; a < A.n_alch && a < 16; a++) t += (double)S.fa[a][tid]; A.e_part[K2_NE + tid] = slot_on(0) ? t : 0.0; }
+    NB_STAMP(stamp_wg && tid == 0, 60);
 }
 
 template <int MASK>
