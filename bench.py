@@ -535,6 +535,10 @@ def main():
 
     for w in range(args.warmup):
         switch_all(w)      # on the main thread: every kernel variant has been launched once before threads start
+    # what one batch's iteration takes when it has the device to itself (the warm-up ran the batches one after the other): the batches' threads
+    # start a fraction of it apart, in the phase the turn-taking settles into anyway -- started together, the batch that loses the first turn
+    # spends the first half switch of the other one waiting inside its first timed iteration (1.52 s against 1.36 s for every later one)
+    alone = min((min(ck["iterations"]) for ck in clocks if ck.get("iterations")), default=0.0)
     engs = [c._ncmc_sim.context._engine for c in chains]
     st0 = engs[0].stats(); b0 = [d._ncmc_batch.stats() for d in drivers]
     for ck, drv in zip(clocks, drivers):
@@ -561,8 +565,12 @@ def main():
         # while the others' threads are in their host phases; nobody waits at an iteration boundary), and the rank's all-gathers
         # of the accept records -- bookkeeping, one per iteration -- follow in iteration order
         from concurrent.futures import ThreadPoolExecutor
+        def run_batch(g):
+            if g:
+                time.sleep(0.22 * alone * g / max(1, G - 1))       # (inside the timed region; the batch would have spent it waiting for its first turn)
+            return [switch_group(g, k) for k in range(args.steps)]
         with ThreadPoolExecutor(max_workers=G) as pool:
-            parts = list(pool.map(lambda g: [switch_group(g, k) for k in range(args.steps)], range(G)))
+            parts = list(pool.map(run_batch, range(G)))
         for k in range(args.steps):
             recs.append(gather_decision_block(np.concatenate([parts[g][k] for g in range(G)])))
     else:
