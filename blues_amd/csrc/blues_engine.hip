@@ -3187,12 +3187,16 @@ static int batch_plan_shape(BluesBatch* B, bool fresh) {
     auto relayout_counted = [&](const std::function<bool(BluesEngine*)>& prepare) -> BluesEngine* {
         return relayout_many(B->eng, [&](BluesEngine* m) { const bool need = prepare(m); if (need) B->st_relayouts++; return need; });
     };
-    if (fresh) for (BluesEngine* m : B->eng) {
+    if (fresh) {
         // (a member that was already laid out on its own for a batch of this size -- BluesTuning.assume_batch -- keeps its layout:
-        // re-deriving it would give the same one, 10 ms of host work per member)
-        const bool same = m->sorted_ok && m->layout_R == m->batch_R && m->shape_S == 0 && !m->forbid_atom;
-        m->shape_S = 0; m->shape_jcap = 0; m->forbid_atom = false;
-        if (!same) { B->st_relayouts++; if (relayout(m)) return fail(m); }
+        // re-deriving it would give the same one, 10 ms of host work per member; so does a member that went to fragment lists by itself
+        // because no group shape holds its mobile atoms -- that layout does not depend on a shape, and it keeps the flag that says so.
+        // The others are laid out on the host's cores together: one after the other, the 2048 engines of the S23k-solute line took 10 s)
+        if (BluesEngine* bad = relayout_counted([&](BluesEngine* m) {
+                const bool own_frag = m->sorted_ok && m->k1_mode == 3 && m->forbid_atom && m->layout_R == m->batch_R && m->shape_S == 0;
+                const bool same = own_frag || (m->sorted_ok && m->layout_R == m->batch_R && m->shape_S == 0 && !m->forbid_atom);
+                m->shape_S = 0; m->shape_jcap = 0; if (!own_frag) m->forbid_atom = false;
+                return !same; })) return fail(bad);
     }
     BluesEngine* lead = B->eng[0];
     for (BluesEngine* m : B->eng) if (!m->straggler) { lead = m; break; }   // (a member in the batch's layout speaks for it)
