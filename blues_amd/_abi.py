@@ -15,7 +15,7 @@ NB_NOCUTOFF = 0
 NB_PME_DIRECT = 1
 NB_PME = 2
 N_ENERGY_TERMS = 10
-N_STATS = 21
+N_STATS = 22
 N_BATCH_COUNTERS = 13
 ENERGY_TERM_NAMES = ("bonds", "angles", "torsions", "nonbonded", "exceptions", "alch_sterics",
                      "alch_electrostatics", "restraint", "reciprocal", "dispersion_correction")
@@ -71,6 +71,7 @@ class BluesTuning(C.Structure):
         ("batch_sync_lists", C.c_int32), ("force_lists", C.c_int32), ("no_sphere", C.c_int32),
         ("pme_general", C.c_int32), ("debug_lists", C.c_int32), ("assume_batch", C.c_int32), ("k1_threads", C.c_int32),
         ("k2_dense", C.c_int32), ("k2_early", C.c_int32), ("fuse_finalize", C.c_int32), ("host_threads", C.c_int32),
+        ("pack_clusters", C.c_int32),
     ]
 
 

@@ -251,6 +251,7 @@ struct BluesEngine {
     DBuf<unsigned short> d_aself; DBuf<uint4> d_pimgb; DBuf<int> d_sx_row;
     int n_entries = 0;
     int int_blocks = 1, int_threads = 128;
+    bool clusters_packed = false;   // BluesTuning.pack_clusters took effect (build_clusters): a 128-thread block may run the fused step kernel
     double total_mass = 0;
     // ---- device buffers
     DBuf<double> d_x[3], d_v[3], d_xbuild[3], d_mass, d_charge, d_sigma, d_eps;
@@ -609,6 +610,20 @@ static int build_clusters(BluesEngine* h, const BluesSystemDesc* s) {
             if (any) while (h->clusters.size() % 64) h->clusters.push_back(empty);
         }
         while (!h->clusters.empty() && h->clusters.back().atoms[0] < 0) h->clusters.pop_back();
+        // BluesTuning.pack_clusters: in a batch of more than 512 chains the step kernel (two 256-register waves per SIMD: 2048 waves
+        // on the device) runs in rounds, and what counts is the NUMBER of waves per chain, not the length of one wave's chain: the
+        // kinds back to back, largest first -- the flagship's 87 triangles, 6 stars and 1 single atom are 2 waves instead of 4, the
+        // second one runs both solvers.  Same arithmetic per cluster; the sums over the block (centre of mass) take another order.
+        const int pack = h->tune.pack_clusters;
+        if ((pack == 2 || (pack == 0 && h->tune.assume_batch > 512)) && all.size() <= 256 && (all.size() + 63) / 64 < (h->clusters.size() + 63) / 64) {   // (one block per chain: the fused step kernel's case)
+            int cnt[3] = {0, 0, 0};
+            for (const HostCluster& c : all) cnt[c.type]++;
+            int order[3] = {0, 1, 2};
+            std::stable_sort(order, order + 3, [&](int a, int b) { return cnt[a] > cnt[b]; });
+            h->clusters.clear();
+            for (int q = 0; q < 3; q++) for (const HostCluster& c : all) if (c.type == order[q]) h->clusters.push_back(c);
+            h->clusters_packed = true;
+        }
     }
     const int ncl = (int)h->clusters.size();
     std::vector<int> ca(ncl * 4), ct(ncl), cn(ncl); std::vector<double> cd(ncl * 3);
@@ -1575,7 +1590,7 @@ static int launch_finalize(BluesEngine* h, const double le[3], int slot_mask = 7
 // program are served by this pass (slots 0 and 2).  What else needs the summed forces resolves the pending sums first.
 // (npart == 1: the per-atom-list kernel's single slab; a lone chain's tile kernel leaves dozens of partial slabs, and four atoms per
 // thread summing them one after the other took longer than k_finalize's thread per atom: 77 against 52 us per step)
-static bool fin_fusable(const BluesEngine* h) { return h->fast_step && h->int_blocks == 1 && h->int_threads == 256 && h->npart == 1 && h->n_entries <= STEP_FENT_LDS && h->tune.fuse_finalize != 0 && !h->ctrl_arg; }   // (one slab, the bonded entries fit the step kernel's LDS: step_default_body<CM, true>)
+static bool fin_fusable(const BluesEngine* h) { return h->fast_step && h->int_blocks == 1 && (h->int_threads == 256 || (h->int_threads == 128 && h->clusters_packed)) && h->npart == 1 && h->n_entries <= STEP_FENT_LDS && h->tune.fuse_finalize != 0 && !h->ctrl_arg; }   // (one slab, the bonded entries fit the step kernel's LDS: step_default_body<CM, true>)
 static int launch_finalize_deferred(BluesEngine* h, const double le[3], int slot_mask) {
     if (!fin_fusable(h) || (slot_mask & 5) != 5) { h->fin_pending = false; return launch_finalize(h, le, slot_mask); }
     h->fin_pending = true; h->fin_mask = slot_mask;
@@ -2575,7 +2590,7 @@ static bool batch_congruent(const BluesEngine* a, const BluesEngine* b, const ch
 #define BC(f) if (a->f != b->f) { *why = #f; return false; }
     BC(device) BC(n) BC(precision) BC(nsteps) BC(nprop) BC(n_lambda) BC(split) BC(remove_cm) BC(dt) BC(gamma) BC(kT) BC(tol) BC(prop_min) BC(prop_max)
     BC(n_itiles) BC(n_tiles) BC(jcap) BC(n_islots) BC(pool_cap) BC(PA) BC(k2_nblocks_env) BC(k2_jiter) BC(seg_len) BC(waves_tile) BC(wpb) BC(npart)
-    BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k2_dense) BC(k2_f32) BC(k1_iw) BC(k1_mode) BC(acap) BC(S) BC(n_lists) BC(n_entries) BC(int_blocks) BC(int_threads) BC(n_noise) BC(n_rows)
+    BC(fuse_forces) BC(fast_step) BC(fuse_big) BC(k2_dense) BC(k2_f32) BC(k1_iw) BC(k1_mode) BC(acap) BC(S) BC(n_lists) BC(n_entries) BC(int_blocks) BC(int_threads) BC(clusters_packed) BC(n_noise) BC(n_rows)
     BC(frag_F) BC(frag_NI) BC(frag_nblk) BC(frag_fpw) BC(frag_nwg) BC(frag_rel)
     BC(cutoff) BC(alpha) BC(sc_alpha) BC(annih_elec) BC(annih_ster) BC(nb_method) BC(pme) BC(pme_K[0]) BC(pme_K[1]) BC(pme_K[2]) BC(pme_order) BC(restr_k) BC(total_mass)
     // (not the box: a MonteCarloBarostat leaves every member in its own; margins, fixed-point scales and PME tables are per member in the records)
@@ -3636,6 +3651,7 @@ int blues_get_stats(BluesEngine* h, int64_t stats[BLUES_N_STATS]) {
     stats[0] = h->st_passes; stats[2] = h->st_launches; stats[3] = h->n_itiles; stats[4] = (int64_t)h->clusters.size(); stats[5] = h->jcap; stats[6] = h->npart; stats[7] = h->seg_len * 1000 + h->wpb;
     if (h->d_flags.p) { DevFlags f; hipSetDevice(h->device); hipStreamSynchronize(h->stream); if (hipMemcpy(&f, h->d_flags.p, sizeof f, hipMemcpyDeviceToHost) == hipSuccess) { stats[1] = f.list_gen; stats[10] = f.builds; stats[16] = f.prunes; } }
     stats[19] = (h->prune_on && h->k1_mode == 2) || (h->k1_mode == 3 && h->frag_m < h->skin);
+    stats[21] = h->int_threads;
     stats[20] = h->k2_dense ? (h->k2_f32 ? 1 : 2) : 0;   // (1: the dense form in fp32 pair arithmetic, round 6; 2: its fp64 predecessor, BluesTuning.k2_dense = 2)
     if (stats[19] && h->k1_mode == 2 && h->d_pcount.p && h->sorted_ok) {
         std::vector<int> pc, ta;

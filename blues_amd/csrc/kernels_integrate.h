@@ -99,15 +99,47 @@ struct Cluster {
     double d2[3];
 };
 
-// ---- cluster-local constraint solves with compile-time index tables (no register-array indexing by runtime values)
+// ---- cluster-local constraint solves (no register-array indexing by runtime values)
 //   type 1 (star):     constraints (0,1) (0,2) (0,3)
 //   type 2 (triangle): constraints (0,1) (0,2) (1,2)
-template <int TYPE> struct ClTab {
-    static __device__ constexpr int ci(int c) { return TYPE == 1 ? 0 : (c == 2 ? 1 : 0); }
-    static __device__ constexpr int cj(int c) { return TYPE == 1 ? c + 1 : (c == 0 ? 1 : 2); }
-    // s(c2, a): +1 if a is the first atom of constraint c2, -1 if the second
-    static __device__ constexpr int s(int c2, int a) { return (a == ci(c2)) - (a == cj(c2)); }
+// Round 6: ONE code path for both kinds.  The tables differ in the third constraint only -- (0,3) against (1,2) -- so the solver
+// selects that constraint's two atoms and the five entries of the coupling matrix that involve it per lane (v_cndmask), and applies
+// the third multiplier to all four atoms through weights of which two are zero (fma(t, 0, v) = v exactly).  A wave that holds stars
+// AND triangles -- the second wave of a chain whose clusters are packed into two, BluesTuning.pack_clusters -- used to run the star
+// solver and the triangle solver one after the other; the arithmetic per cluster is what the two templates did.
+struct ClSel {
+    bool star;
+    double wa0, wa1, wb2, wb3;   // third constraint: weight of atoms 0 / 1 as its first atom, of atoms 2 / 3 as its second (two of them zero)
+    double cf[3][3];             // coef(c, c2) = w[ci(c)] s(c2, ci(c)) - w[cj(c)] s(c2, cj(c)), s(c2, a) = +1 / -1 if a is the first / second atom of c2
 };
+__device__ __forceinline__ ClSel cl_select(const Cluster& C) {
+    ClSel S; S.star = C.type == 1;
+    const double w0 = C.w[0], w1 = C.w[1], w2 = C.w[2], w3 = C.w[3];
+    S.wa0 = S.star ? w0 : 0.0; S.wa1 = S.star ? 0.0 : w1; S.wb2 = S.star ? 0.0 : w2; S.wb3 = S.star ? w3 : 0.0;
+    S.cf[0][0] = w0 + w1; S.cf[0][1] = w0;      S.cf[0][2] = S.star ? w0 : -w1;
+    S.cf[1][0] = w0;      S.cf[1][1] = w0 + w2; S.cf[1][2] = S.star ? w0 : w2;
+    S.cf[2][0] = S.star ? w0 : -w1; S.cf[2][1] = S.star ? w0 : w2; S.cf[2][2] = S.star ? w0 + w3 : w1 + w2;
+    return S;
+}
+// r[c] = a[first atom of c] - a[second atom of c]
+__device__ __forceinline__ void cl_diffs(const double a[4][3], const bool star, const int nc, double r[3][3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        r[0][k] = a[0][k] - a[1][k];
+        r[1][k] = nc > 1 ? a[0][k] - a[2][k] : 0.0;
+        const double p = star ? a[0][k] : a[1][k], q = star ? a[3][k] : a[2][k];
+        r[2][k] = nc > 2 ? p - q : 0.0;
+    }
+}
+// a[first atom of c] += mu[c] r[c] w, a[second atom of c] -= mu[c] r[c] w, constraint by constraint
+__device__ __forceinline__ void cl_apply(double a[4][3], const Cluster& C, const ClSel& S, const double mu[3], const double r[3][3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        { const double t = mu[0] * r[0][k]; a[0][k] += t * C.w[0]; a[1][k] -= t * C.w[1]; }
+        if (C.nc > 1) { const double t = mu[1] * r[1][k]; a[0][k] += t * C.w[0]; a[2][k] -= t * C.w[2]; }
+        if (C.nc > 2) { const double t = mu[2] * r[2][k]; a[0][k] += t * S.wa0; a[1][k] += t * S.wa1; a[2][k] -= t * S.wb2; a[3][k] -= t * S.wb3; }
+    }
+}
 
 __device__ __forceinline__ void solve_small(int n, const double M[3][3], const double b[3], double x[3]) {
     if (n == 1) { x[0] = b[0] / M[0][0]; x[1] = x[2] = 0.0; return; }
@@ -126,66 +158,38 @@ __device__ __forceinline__ void solve_small(int n, const double M[3][3], const d
 }
 
 // RATTLE: (v_i - v_j).r_ij = 0 is linear in the multipliers -> one small solve (same algebra as the oracle)
-template <int TYPE> __device__ __forceinline__ void rattle_t(Cluster& C, const IntArgs& A) {
-    using T = ClTab<TYPE>;
-    double r[3][3], M[3][3], b[3], mu[3];
+__device__ __forceinline__ void rattle(Cluster& C, double tol, const IntArgs& A) {
+    if (C.nc == 0) return;
+    const ClSel S = cl_select(C);
+    double r[3][3], dv[3][3], M[3][3], b[3], mu[3];
+    cl_diffs(C.x, S.star, C.nc, r);
+    cl_diffs(C.v, S.star, C.nc, dv);
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        double rv = 0.0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            r[c][k] = 0.0;
-            if (c < C.nc) {
-                r[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k];
-                rv += (C.v[T::ci(c)][k] - C.v[T::cj(c)][k]) * r[c][k];
-            }
-        }
-        b[c] = -rv;
-    }
+    for (int c = 0; c < 3; c++) b[c] = -(dv[c][0] * r[c][0] + dv[c][1] * r[c][1] + dv[c][2] * r[c][2]);
 #pragma unroll
     for (int c = 0; c < 3; c++)
 #pragma unroll
-        for (int c2 = 0; c2 < 3; c2++) {
-            const double coef = C.w[T::ci(c)] * T::s(c2, T::ci(c)) - C.w[T::cj(c)] * T::s(c2, T::cj(c));
-            M[c][c2] = (r[c][0] * r[c2][0] + r[c][1] * r[c2][1] + r[c][2] * r[c2][2]) * coef;
-        }
+        for (int c2 = 0; c2 < 3; c2++) M[c][c2] = (r[c][0] * r[c2][0] + r[c][1] * r[c2][1] + r[c][2] * r[c2][2]) * S.cf[c][c2];
     solve_small(C.nc, M, b, mu);
-#pragma unroll
-    for (int c = 0; c < 3; c++) if (c < C.nc) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) { C.v[T::ci(c)][k] += mu[c] * r[c][k] * C.w[T::ci(c)]; C.v[T::cj(c)][k] -= mu[c] * r[c][k] * C.w[T::cj(c)]; }
-    }
-}
-
-__device__ __forceinline__ void rattle(Cluster& C, double tol, const IntArgs& A) {
-    if (C.nc == 0) return;
-    if (C.type == 1) rattle_t<1>(C, A); else rattle_t<2>(C, A);
+    cl_apply(C.v, C, S, mu, r);
 }
 
 // SHAKE: Newton on the multipliers, directions from the reference geometry xr; converged to
 // |r^2 - d^2| <= 2 tol d^2 plus one polishing iteration (same sequence as the oracle)
-template <int TYPE> __device__ __forceinline__ bool shake_t(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
-    using T = ClTab<TYPE>;
+__device__ __forceinline__ bool shake(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
+    if (C.nc == 0) return true;
+    const ClSel S = cl_select(C);
     double r[3][3];
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            r[c][k] = 0.0;
-            if (c < C.nc) { r[c][k] = xr[T::ci(c)][k] - xr[T::cj(c)][k]; }
-        }
+    cl_diffs(xr, S.star, C.nc, r);
     int it;
     for (it = 0; it < 50; it++) {
         double D[3][3], g[3], J[3][3], dl[3];
         bool conv = true, tight = true;
+        cl_diffs(C.x, S.star, C.nc, D);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             g[c] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) D[c][k] = 0.0;
             if (c < C.nc) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) { D[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k]; }
                 g[c] = -(D[c][0] * D[c][0] + D[c][1] * D[c][1] + D[c][2] * D[c][2] - C.d2[c]);
                 if (fabs(g[c]) > 2.0 * tol * C.d2[c]) conv = false;
                 if (fabs(g[c]) > 1e-13 * C.d2[c]) tight = false;
@@ -195,24 +199,12 @@ template <int TYPE> __device__ __forceinline__ bool shake_t(Cluster& C, const do
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
-            for (int c2 = 0; c2 < 3; c2++) {
-                const double coef = C.w[T::ci(c)] * T::s(c2, T::ci(c)) - C.w[T::cj(c)] * T::s(c2, T::cj(c));
-                J[c][c2] = 2.0 * (D[c][0] * r[c2][0] + D[c][1] * r[c2][1] + D[c][2] * r[c2][2]) * coef;
-            }
+            for (int c2 = 0; c2 < 3; c2++) J[c][c2] = 2.0 * (D[c][0] * r[c2][0] + D[c][1] * r[c2][1] + D[c][2] * r[c2][2]) * S.cf[c][c2];
         solve_small(C.nc, J, g, dl);
-#pragma unroll
-        for (int c = 0; c < 3; c++) if (c < C.nc) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) { C.x[T::ci(c)][k] += dl[c] * r[c][k] * C.w[T::ci(c)]; C.x[T::cj(c)][k] -= dl[c] * r[c][k] * C.w[T::cj(c)]; }
-        }
+        cl_apply(C.x, C, S, dl, r);
         if (conv) break;
     }
     return it < 50;
-}
-
-__device__ __forceinline__ bool shake(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
-    if (C.nc == 0) return true;
-    return C.type == 1 ? shake_t<1>(C, xr, tol, A) : shake_t<2>(C, xr, tol, A);
 }
 
 __device__ __forceinline__ void load_force(const IntArgs& A, const Cluster& C, int slot, double F[4][3]) {
@@ -279,10 +271,10 @@ __device__ __forceinline__ double fin_alch_self(const double* __restrict__ self_
     if (on && tid < n_alch) for (int u = 0; u < NG; u++) t += s_red[u * PA + tid];   // fixed order
     return t;
 }
-// the K2_NP sums over the alchemical kernel's blocks (energies per kind, slot-0 force on the alchemical atoms) -> s_e[K2_NP]; 256 threads, one barrier at the end
+// the K2_NP sums over the alchemical kernel's blocks (energies per kind, slot-0 force on the alchemical atoms) -> s_e[K2_NP]; whole waves (256 threads; 128 in the packed step kernel), one barrier at the end
 __device__ __forceinline__ void fin_energy_sums(const double* __restrict__ e_part, int nb_env, int k2_nblocks_env, double* s_e) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int q = wv; q < K2_NP; q += 4) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = (int)(blockDim.x >> 6);   // (a wave forms a sum in lane order: the same bits whichever wave takes it)
+    for (int q = wv; q < K2_NP; q += nwv) {
         double s = 0.0;
         for (int b = lane; b < nb_env; b += 64) s += e_part[(size_t)b * K2_NP + q];
         if (lane == 0) s += e_part[(size_t)k2_nblocks_env * K2_NP + q];
@@ -799,7 +791,8 @@ __global__ void __launch_bounds__(256) k_forces_fused(NbArgs<R> a, NbConst<R> c,
 // FUSED (round 4): the kernel forms the pass's forces itself from the force kernels' slabs -- what k_finalize would have left in
 // ftot / alch_self / acc->e_slot / mom_part, by the same shared functions in the same order -- so a steady-state step has one
 // launch fewer and no round trip of the summed forces through memory.  One block of 256 threads holds every cluster of the chain
-// (host: int_blocks == 1, int_threads == 256), so the total momentum for CMMotionRemover is a block reduction.
+// (host: int_blocks == 1, int_threads == 256 -- or 128 where BluesTuning.pack_clusters packed the chain's clusters into two waves: a
+// batch of more than 512 chains runs its 256-register waves in rounds), so the total momentum for CMMotionRemover is a block reduction.
 // LATE (with FUSED in a batch): the noise of the O substep and the reference positions of the list checks are loaded where they are
 // used instead of at the top -- 60 registers less across the constraint solves, which lets two waves share a SIMD (256 registers:
 // kernels_batch.h) where the kernel otherwise runs one wave per SIMD in two rounds.
@@ -847,7 +840,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
     const int jc_alch = (FUSED && A.n_alch > 0) ? *A.jcount_alch : 0;   // (asked for here: on its way while the entries are staged)
     STEP_STAMP(10);
     if (FUSED) {
-        for (int e = tid; e < 3 * A.n_entries; e += 256) s_fent[e] = A.fent[e];
+        for (int e = tid; e < 3 * A.n_entries; e += (int)blockDim.x) s_fent[e] = A.fent[e];
         __syncthreads();
     }
     STEP_STAMP(11);
@@ -879,25 +872,30 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
     if (FUSED && A.n_alch > 0) {   // (uniform) what the last 10 blocks of k_finalize do, the same sums in the same order (fin_alch_self, fin_energy_sums),
         // with every slab's loads in flight together and ONE barrier for all of them
         const int nb_env = k2_env_blocks(jc_alch, A.PA, A.k2_jiter);
-        const int PA = A.PA, NG = 256 / PA, aa = tid & (PA - 1), gg = tid / PA;
-        double sv[6], s0[6], sx[6];
+        const int PA = A.PA, NG = 256 / PA;
+        // (a 128-thread block -- BluesTuning.pack_clusters -- plays both halves of the 256 threads k_finalize sums with: same slabs
+        // per partial sum, same order of the partial sums)
+        for (int vt = tid; vt < 256; vt += (int)blockDim.x) {
+            const int aa = vt & (PA - 1), gg = vt / PA;
+            double sv[6], s0[6], sx[6];
 #pragma unroll
-        for (int q6 = 0; q6 < 6; q6++) {   // (the thread's first slab and the alchemical x alchemical slab of all six sums requested together)
-            const int q = q6 < 3 ? q6 : q6 + 3;
-            s0[q6] = gg < nb_env ? A.self_part[((size_t)gg * 9 + q) * PA + aa] : 0.0;
-            sx[q6] = gg == 0 ? A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * PA + aa] : 0.0;
+            for (int q6 = 0; q6 < 6; q6++) {   // (the thread's first slab and the alchemical x alchemical slab of all six sums requested together)
+                const int q = q6 < 3 ? q6 : q6 + 3;
+                s0[q6] = gg < nb_env ? A.self_part[((size_t)gg * 9 + q) * PA + aa] : 0.0;
+                sx[q6] = gg == 0 ? A.self_part[((size_t)A.k2_nblocks_env * 9 + q) * PA + aa] : 0.0;
+            }
+#pragma unroll
+            for (int q6 = 0; q6 < 6; q6++) {
+                const int q = q6 < 3 ? q6 : q6 + 3;
+                double sq = 0.0;
+                if (gg < nb_env) sq += s0[q6];
+                for (int b = gg + NG; b < nb_env; b += NG) sq += A.self_part[((size_t)b * 9 + q) * PA + aa];   // (the dense kernel leaves one slab)
+                if (gg == 0) sq += sx[q6];
+                sv[q6] = sq;
+            }
+#pragma unroll
+            for (int q6 = 0; q6 < 6; q6++) s_fin[q6][vt] = sv[q6];
         }
-#pragma unroll
-        for (int q6 = 0; q6 < 6; q6++) {
-            const int q = q6 < 3 ? q6 : q6 + 3;
-            double sq = 0.0;
-            if (gg < nb_env) sq += s0[q6];
-            for (int b = gg + NG; b < nb_env; b += NG) sq += A.self_part[((size_t)b * 9 + q) * PA + aa];   // (the dense kernel leaves one slab)
-            if (gg == 0) sq += sx[q6];
-            sv[q6] = sq;
-        }
-#pragma unroll
-        for (int q6 = 0; q6 < 6; q6++) s_fin[q6][tid] = sv[q6];
         fin_energy_sums(A.e_part, nb_env, A.k2_nblocks_env, s_esum);   // (ends with a barrier: s_fin is published too)
         if (tid < 64) {
 #pragma unroll

@@ -168,7 +168,7 @@ class NativeEngine:
                 "clusters": s[4], "jcap": s[5], "npart": s[6], "seg_len": s[7] // 1000, "wpb": s[7] % 1000,
                 "max_jcount": s[8], "resorts": s[9], "list_builds": s[10], "own_energy_evaluations": s[11],
                 "nonbonded_kernel": s[12], "tiles_per_list": s[13], "atom_list_entries": s[14], "atom_list_iterations": s[15],
-                "atom_prunes": s[16], "pruned_list_entries": s[17], "pruned_list_iterations": s[18], "pruned_lists": s[19], "alchemical_kernel": s[20]}
+                "atom_prunes": s[16], "pruned_list_entries": s[17], "pruned_list_iterations": s[18], "pruned_lists": s[19], "alchemical_kernel": s[20], "step_threads": s[21]}
 
     def time_nonbonded(self, reps=20):
         u = C.c_double(); self._check(self._lib.blues_time_nonbonded(self._h, int(reps), C.byref(u))); return u.value

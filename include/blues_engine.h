@@ -206,6 +206,11 @@ typedef struct BluesTuning {
                                 * forms the summed forces of the pass itself (no k_finalize launch); 0: always the separate kernel */
     int32_t host_threads;      /* host threads for work the members of a batch share (re-sorts and re-layouts of several members at a poll);
                                 * 0: the cores this process may use, at most 16.  N ranks on one host: cores / N (blues_amd/replicas.py) */
+    int32_t pack_clusters;     /* order of the constraint clusters among the step kernel's threads.  1: each kind (star, single atom, triangle)
+                                * starts on a wave boundary, so no wave runs two solvers (shortest chain per wave: a lone chain, small batches);
+                                * 2: kinds packed back to back, largest first -- fewer waves per chain, one of them mixed (a batch of more than
+                                * 512 chains, whose step kernel otherwise runs in two rounds at two 256-register waves per SIMD);
+                                * 0: auto (2 where assume_batch > 512 and it saves waves) */
 } BluesTuning;
 void blues_tuning_default(BluesTuning *t);
 /* NULL restores the defaults.  Applies to engines and batches created afterwards. */
@@ -276,8 +281,9 @@ int blues_reset(BluesEngine *h);
  * [16] pruned per-atom lists re-derived so far (one count per atom and prune; fragment lists: prunes of the chain)
  * [17] entries of all pruned lists now (fragment lists: of the inner lists) [18] 64-entry wave iterations they take
  * [19] 1 if the nonbonded kernel walks pruned (inner) lists [20] alchemical kernel in
- * use for the env pairs: 0 lane = (atom, list entry), 1 dense pair lists */
-#define BLUES_N_STATS 21
+ * use for the env pairs: 0 lane = (atom, list entry), 1 dense pair lists in fp32 pair arithmetic, 2 in fp64
+ * [21] threads per block of the step kernel (BluesTuning.pack_clusters) */
+#define BLUES_N_STATS 22
 int blues_get_stats(BluesEngine *h, int64_t stats[BLUES_N_STATS]);
 /* time `reps` launches of the dominant nonbonded kernel alone with HIP events
  * on the engine's own stream; returns mean microseconds per launch. */

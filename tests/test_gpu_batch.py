@@ -435,16 +435,20 @@ def test_batched_energy_prefetch_equals_per_member_evaluation(Engine, tol_box, s
     B.close()
 
 
-def test_full_size_batch_of_eight(Engine, oracle_mod, tune):
+@pytest.mark.parametrize("R,pack", [(8, 0), (8, 2), (64, 2)])
+def test_full_size_batch_of_eight(Engine, oracle_mod, tune, R, pack):
     """The benchmark system (S23k, 276 mobile atoms) in a batch of 8: the member count is a multiple of 8, so the nonbonded
     and alchemical launches use the XCD-aware block -> replica map, and the engine's own policy puts a batch of 8 such chains
     into the decomposition bench.py runs at R = 512 (separate force kernels, per-atom lists pruned in passing, side-stream fork).
     Every member equals its solo run bit for bit (the lone engines lay themselves out as members of a batch of 8 would:
-    BluesTuning.assume_batch, nothing else pinned), and one member is checked against the oracle."""
+    BluesTuning.assume_batch, nothing else pinned), and one member is checked against the oracle.
+    pack = 2 (round 6): the constraint clusters packed into two waves per chain instead of one wave per kind of cluster
+    (BluesTuning.pack_clusters: what a batch of more than 512 chains does by itself) -- the step kernel runs as a 128-thread block
+    whose second wave holds triangles, stars and the single atom; at R = 64 it is the two-waves-per-SIMD form the benchmark runs."""
     from blues_amd.engine import NativeBatch
     s, v = systems.s23k(mobile_atoms=275, frozen=True)
-    R, n = 8, 10
-    tune(assume_batch=R)
+    n = 10
+    tune(assume_batch=R, pack_clusters=pack)
     rng = np.random.RandomState(5)
     vels = [v * (1.0 + 0.03 * r) for r in range(R)]
     solo = _make(Engine, s, vels, n, 0)
@@ -456,7 +460,8 @@ def test_full_size_batch_of_eight(Engine, oracle_mod, tune):
     for r in range(R):
         assert np.array_equal(wb[r], ws[r]), (r, np.abs(wb[r] - ws[r]).max())
         assert np.array_equal(solo[r].get_positions(), bat[r].get_positions())
-    assert len({w[-1] for w in ws}) == R                  # eight different trajectories
+    assert len({w[-1] for w in ws}) == R                  # R different trajectories
+    assert bat[0].stats()["step_threads"] == (128 if pack == 2 else 256)
     r = 5
     o = oracle_mod.Oracle(s, _integ(n, seed=100 + r).to_data(precision=0, replica=r))
     o.set_velocities(vels[r])
