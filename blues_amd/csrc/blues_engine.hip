@@ -1447,8 +1447,10 @@ static int launch_alchemical(BluesEngine* h, const double ls[3], const double le
             if (lead) {
                 const int nrep = h->batch->R();
                 const AlchDyn D = make_alch_dyn(A);
-#define DENSE32_B(M, NS) do { if (part != 3) hipLaunchKernelGGL((k_alchemical_dense32_b<M>), dim3(nrep), dim3(K2F_THREADS), sizeof(K2FLds<NS>), h->cur, h->batch->d_core.p, D); \
-                              if (part != 4) hipLaunchKernelGGL((k_alchemical_b<true, M>), dim3(nrep), dim3(256), 0, h->cur, h->batch->d_core.p, D, 1, nrep, (const int*)nullptr); } while (0)
+                // (part 5 / 6: the dense kernel only, for the members that do not / do rebuild their lists in this pass -- force_pass, fork mode 4)
+                const int* stale = part >= 5 ? h->batch->d_work.p : nullptr;
+#define DENSE32_B(M, NS) do { if (part != 3) hipLaunchKernelGGL((k_alchemical_dense32_b<M>), dim3(nrep), dim3(K2F_THREADS), sizeof(K2FLds<NS>), h->cur, h->batch->d_core.p, D, stale, part == 6 ? 1 : 0); \
+                              if (part < 4) hipLaunchKernelGGL((k_alchemical_b<true, M>), dim3(nrep), dim3(256), 0, h->cur, h->batch->d_core.p, D, 1, nrep, (const int*)nullptr); } while (0)
                 if (slot_mask == 5) DENSE32_B(5, 2); else if (slot_mask == 2) DENSE32_B(2, 1); else DENSE32_B(-1, 3);
 #undef DENSE32_B
             } else {
@@ -1926,7 +1928,12 @@ static int force_pass(BluesEngine* h, int base_L) {
     // builder of the atoms' lists (85 us, no LDS, 94 registers) and are done before it: 756 -> 716 us per step of 1024 chains.
     // The dense kernel itself beside that builder (fork = 2) gains nothing; beside the GROUP-list builder the small kernels cost
     // it what they saved (round 4, first half).
-    const bool small_side = fork && h->k2_dense && fork_mode != 2 && fork_mode != 3;   // (3: every alchemical kernel and the bonded entries on the side stream, joined before the sums)
+    // 4 (round 6): the work list and the group lists are two latency-bound kernels of a few hundred workgroups -- 68 us during which the
+    // chip idles.  The kernels that need nothing from them start WITH them on the side streams: the two small ones at once, the dense
+    // alchemical kernel of the members that do not rebuild as soon as the work list says who they are (all but ~40 of 1024), that of the
+    // members that rebuild behind the group lists; all joined before the nonbonded kernel, which keeps the device to itself.
+    const bool beside_lists = fork && fork_mode == 4 && h->k2_dense && h->k2_f32;
+    const bool small_side = fork && h->k2_dense && fork_mode != 2 && fork_mode != 3 && !beside_lists;   // (3: every alchemical kernel and the bonded entries on the side stream, joined before the sums)
     if (fork && ensure_side(h)) return 1;
     // k2_early (off by default): the alchemical kernel of the members that do NOT rebuild needs nothing from the rebuild and can
     // start as soon as the work list says who they are, with the rebuild kernels on a high-priority stream beside it and the
@@ -1975,7 +1982,26 @@ static int force_pass(BluesEngine* h, int base_L) {
         HIP_OK(h, hipGetLastError());
         return 0;
     }
-    if (fork) {
+    if (beside_lists) {
+        hipStream_t main_stream = h->cur;
+#define LISTS(ph) (h->precision == 0 ? launch_lists<float>(h, h->lists_forced, ph) : launch_lists<double>(h, h->lists_forced, ph))
+        HIP_OK(h, hipEventRecord(h->evFork, main_stream)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evFork, 0));
+        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, 3) || launch_bonded(h, true); h->cur = main_stream;
+        if (rc) return 1;
+        if (LISTS(3)) return 1;
+        HIP_OK(h, hipEventRecord(h->evA, main_stream)); HIP_OK(h, hipStreamWaitEvent(h->s1, h->evA, 0));
+        h->cur = h->s1; rc = launch_alchemical(h, ls, le, fmask, 5); h->cur = main_stream;
+        if (rc) return 1;
+        HIP_OK(h, hipEventRecord(h->evJ1, h->s1));
+        if (LISTS(4)) return 1;
+        HIP_OK(h, hipEventRecord(h->evJ2, main_stream)); HIP_OK(h, hipStreamWaitEvent(h->s2, h->evJ2, 0));
+        h->cur = h->s2; rc = launch_alchemical(h, ls, le, fmask, 6); h->cur = main_stream;
+        if (rc) return 1;
+        HIP_OK(h, hipEventRecord(h->evB, h->s2));
+        if (LISTS(2)) return 1;
+#undef LISTS
+        HIP_OK(h, hipStreamWaitEvent(main_stream, h->evJ1, 0)); HIP_OK(h, hipStreamWaitEvent(main_stream, h->evB, 0));
+    } else if (fork) {
         hipStream_t main_stream = h->cur;
         hipStream_t rb = early ? h->s2 : main_stream;   // the rebuild's stream (high priority: see engine creation)
 #define LISTS(ph) (h->precision == 0 ? launch_lists<float>(h, h->lists_forced, ph) : launch_lists<double>(h, h->lists_forced, ph))

@@ -262,10 +262,14 @@ __global__ void __launch_bounds__(K2D_THREADS) k_alchemical_dense_b(const RepCor
 }
 
 // ... and its fp32 form (round 6, kernels_alch.h: alchemical_dense32_body): two workgroups per CU
+// stale / want (BluesTuning.fork = 4): null = every member; else the work list of the rebuild (k_gather_stale_b) and which side of
+// it this launch serves -- 0: the members that do not rebuild their lists in this pass (they need nothing from the rebuild and run
+// beside it), 1: those that do (behind the builder of the group lists, which leaves the alchemical tile's list)
 template <int MASK>
-__global__ void __launch_bounds__(K2F_THREADS, 4) k_alchemical_dense32_b(const RepCore* __restrict__ reps, AlchDyn d) {
+__global__ void __launch_bounds__(K2F_THREADS, 4) k_alchemical_dense32_b(const RepCore* __restrict__ reps, AlchDyn d, const int* __restrict__ stale, int want) {
     const int rep = blockIdx.x;
     if (!reps[rep].active) return;
+    if (stale && stale[1 + gridDim.x + rep] != want) return;
     AlchArgs A = reps[rep].al; apply_dyn(A, d);
     alchemical_dense32_body<MASK>(A);
 }

@@ -56,6 +56,9 @@ struct ListArgs {
     int S, n_lists;          // S consecutive i-tiles share one j-list (1 in the bitmask modes); n_lists = ceil(n_itiles / S), the alchemical tile's list comes after them
     // pruned-list mode (NbArgs; null: none): the atom-list build writes every atom's pruned list along with the full one -- it
     // has the distances at hand -- so a rebuild leaves nothing for the nonbonded kernel to re-derive
+    // (round 6 measured the other way round -- full lists only, every slot flagged, the force kernel prunes in its next pass: this
+    // builder 87.5 -> 73.0 us per step of 1024 chains, the force kernel 222.5 -> 257.4: a workgroup whose chain re-derives every list
+    // takes 1.6 x as long, and with one workgroup per CU the launch waits for those)
     int* pneed; unsigned short* plist; int* pcount; unsigned* xprune[3];
     // packed image of every group list (null: not kept): the list's atoms as the nonbonded kernel stages them, {x,y,z,q} and
     // {sigma/2, 2 sqrt(eps)}, written when the list is built -- frozen atoms never change, so the kernel copies it with

@@ -184,7 +184,11 @@ typedef struct BluesTuning {
     int32_t slot_mask;         /* -1 auto; else the lambda slots whose force a pass produces */
     int32_t fork;              /* 1 (default): a batch runs the alchemical / bonded kernels on a side stream beside the builder of the atoms'
                                 * lists -- of a pass with the dense alchemical kernel only the two small ones (alchemical x alchemical block,
-                                * bonded entries); 0: every kernel alone; 2: the dense kernel too, joined before the nonbonded kernel (no gain) */
+                                * bonded entries); 0: every kernel alone; 2: the dense kernel too, joined before the nonbonded kernel (no gain);
+                                * 3: every alchemical kernel and the bonded entries on the side stream, joined before the sums;
+                                * 4: the small kernels and the dense kernel of the members that do not rebuild their lists beside the work list
+                                * and the group-list builder (which leave the chip idle), the dense kernel of the others behind the group lists;
+                                * all joined before the nonbonded kernel */
     int32_t use_graph;         /* -1 auto (off): hipGraph replay of the steady-state step of a lone engine */
     int32_t graph_units;       /* 0 auto */
     int32_t graph_fork;        /* -1 auto (off) */

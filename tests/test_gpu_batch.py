@@ -1079,7 +1079,7 @@ def test_dense_alchemical_kernel_equals_the_lane_layout(Engine, tune):
 
 
 def test_the_order_of_a_pass_kernels_changes_no_bit(Engine, tune):
-    """BluesTuning.fork = 0 / 1 / 2 only decide which stream the alchemical and bonded kernels of a batched force pass run on and where
+    """BluesTuning.fork = 0 / 1 / 2 / 3 / 4 only decide which stream the alchemical and bonded kernels of a batched force pass run on and where
     they are joined (1, the default: the two small ones beside the builder of the atoms' lists; 2: the dense kernel too, joined
     before the nonbonded kernel).  Every sum of a pass is formed in a fixed order, so a batch of the bench decomposition ends on the
     same bits whichever it is."""
@@ -1087,7 +1087,7 @@ def test_the_order_of_a_pass_kernels_changes_no_bit(Engine, tune):
     from blues_amd.engine import NativeBatch
     s, v = systems.s23k(mobile_atoms=275, frozen=True)
     out = {}
-    for fork in (0, 1, 2):
+    for fork in (0, 1, 2, 3, 4):
         tune(fork=fork)
         engs = [Engine(s, integrators.generateNCMCIntegrator(nstepsNC=60, dt=0.004, temperature=300.0, seed=33).to_data(precision=0, replica=r)) for r in range(8)]
         for g in engs:
@@ -1101,7 +1101,7 @@ def test_the_order_of_a_pass_kernels_changes_no_bit(Engine, tune):
         B.close()
         for g in engs:
             g.close()
-    for other in (1, 2):
+    for other in (1, 2, 3, 4):
         assert np.array_equal(out[0][0], out[other][0]), other
         for a, b in zip(out[0][1], out[other][1]):
             assert np.array_equal(a, b), other
