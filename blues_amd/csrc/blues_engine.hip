@@ -55,10 +55,14 @@ static const int SHAPE_CAND[9] = {1, 2, 3, 4, 5, 6, 8, 12, 16};   // tiles per g
 static inline int shape_index(int S) { for (int q = 0; q < 9; q++) if (SHAPE_CAND[q] == S) return q; return -1; }
 
 template <typename T> struct DBuf {
-    T* p = nullptr; size_t n = 0;
-    void reserve(size_t count) {   // an existing buffer of the right size is reused (a re-sort keeps every address)
-        if (!p || count != n) {
-            release(); n = count;
+    T* p = nullptr; size_t n = 0, cap = 0;
+    // an existing buffer that is large enough is reused (a re-sort keeps every address).  Round 6: large ENOUGH, not of the same size -- a
+    // member that leaves its batch's layout for fragment lists and comes back changes the size of a dozen buffers twice, and with ~10^5
+    // allocations in the process every hipFree / hipMalloc pair took milliseconds (one member's return: 0.2 s with the device idle)
+    void reserve(size_t count) {
+        if (p && count <= cap) { n = count; return; }
+        {
+            release(); n = count; cap = count;
             SetupTimer tm(3); { std::lock_guard<std::mutex> lk(setup_mu()); g_setup_sec[6] += 1.0; }
             if (count * sizeof(T) > ((size_t)1 << 31)) fprintf(stderr, "[blues] a single device allocation of %.1f GiB (%zu elements of %zu bytes)\n", count * sizeof(T) / 1073741824.0, count, sizeof(T));
             if (hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::string("hipMalloc failed");
@@ -78,7 +82,7 @@ template <typename T> struct DBuf {
         h.resize(n);
         if (n && hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) throw std::string("hipMemcpy D2H failed");
     }
-    void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) hipFree(p); p = nullptr; n = 0; cap = 0; }
     ~DBuf() { release(); }
 };
 
@@ -199,6 +203,7 @@ struct BluesEngine {
     // program is the steady-state one, by k_finalize otherwise
     bool fin_pending = false; double fin_le[3] = {0, 0, 0}; int fin_mask = 7;
     bool have_positions = false, sorted_ok = false, lists_forced = true, relayout_failed = false;
+    bool solo_now = false;    // out of step with the rest of its batch for the phase that is running: it takes it on launches of its own (batch_do_steps: phase)
     bool straggler = false;   // member of a batch whose own layout no longer fits the batch's shape: it steps on launches of its own until it fits again (batch_do_steps)
     std::vector<double> hx;        // host copy of the positions the tiles were last laid out from (caller order, [n][3])
     double e_frozen[2] = {0, 0}; bool e_frozen_valid = false;
@@ -333,7 +338,7 @@ struct BluesBatch {
     // each member's pending work and the members issue into it; leave: the batch stream is drained, members go home.
     hipStream_t stream = nullptr; bool entered = false;
     DBuf<double> d_gather; int64_t st_prefetch_pe = 0, st_prefetch_ke = 0;
-    int64_t st_lockstep_steps = 0, st_fallback_steps = 0, st_replans = 0, st_relayouts = 0, st_poll_resorts = 0, st_stragglers = 0, st_rejoined = 0; double st_replan_sec = 0.0, st_resort_sec = 0.0;   // (blues_batch_get_counters)
+    int64_t st_lockstep_steps = 0, st_fallback_steps = 0, st_replans = 0, st_relayouts = 0, st_poll_resorts = 0, st_stragglers = 0, st_rejoined = 0; double st_replan_sec = 0.0, st_resort_sec = 0.0, st_straggle_sec = 0.0;   // (blues_batch_get_counters)
     // in-situ timing of the nonbonded force kernel (blues_batch_kernel_timing): every `k1t_every`-th lock-step force launch of the
     // stepping loop is bracketed by two events on the stream it runs on; finished pairs are harvested lazily (no synchronisation)
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; bool busy = false; };
@@ -1848,12 +1853,20 @@ static int make_straggler(BluesBatch* B, BluesEngine* h) {
     h->straggler = true; h->forbid_atom = true; h->shape_S = 0; h->shape_jcap = 0; h->shape_overflow = false;
     B->st_stragglers++;
     if (h->tune.debug_lists) fprintf(stderr, "[straggler] member %d leaves the shared launches at step %d\n", h->batch_index, h->h_step);
-    return relayout(h);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = relayout(h);
+    B->st_straggle_sec += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 // ... and back: the batch's shape, if the member's atoms fit it now (its first step of a switch)
 static int try_rejoin(BluesBatch* B, BluesEngine* h, const BluesEngine* like) {
     h->forbid_atom = false; h->shape_S = like->S; h->shape_jcap = like->jcap;
-    if (relayout(h)) return 1;
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = relayout(h);
+        B->st_straggle_sec += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc) return 1;
+    }
     if (h->sorted_ok && h->k1_mode == 2 && !h->shape_overflow && h->S == like->S && h->jcap == like->jcap) { h->straggler = false; B->st_rejoined++; return 0; }
     h->straggler = false;   // (make_straggler counts it again: st_stragglers is "times a member left", st_rejoined "times one came back")
     B->st_stragglers--;
@@ -2645,7 +2658,7 @@ static bool batch_congruent_cached(BluesBatch* B, int r, const BluesEngine* lead
 static int batch_refresh_args(BluesBatch* B) {
     bool dirty = false;
     BluesEngine* lead = B->leader ? B->leader : B->eng[0];
-    for (int r = 0; r < B->R(); r++) dirty |= B->seen_epoch[r] != B->eng[r]->args_epoch || B->rec_active[r] != (char)(B->active[r] && !B->failed[r] && !B->eng[r]->straggler)
+    for (int r = 0; r < B->R(); r++) dirty |= B->seen_epoch[r] != B->eng[r]->args_epoch || B->rec_active[r] != (char)(B->active[r] && !B->failed[r] && !B->eng[r]->straggler && !B->eng[r]->solo_now)
                                               || (!B->failed[r] && B->rec_delta[r] != B->eng[r]->h_draw - lead->h_draw);
     if (!dirty) return 0;
     const double one[3] = {1.0, 1.0, 1.0};
@@ -2654,7 +2667,7 @@ static int batch_refresh_args(BluesBatch* B) {
     if (single) nf.resize(B->R()); else nd.resize(B->R());
     for (int r = 0; r < B->R(); r++) {
         BluesEngine* h = B->eng[r];
-        B->rec_active[r] = (char)(B->active[r] && !B->failed[r] && !h->straggler);   // (a straggler's kernels are its own: the shared launches pass it by)
+        B->rec_active[r] = (char)(B->active[r] && !B->failed[r] && !h->straggler && !h->solo_now);   // (a straggler's kernels are its own: the shared launches pass it by)
         core[r].active = B->rec_active[r];
         B->rec_delta[r] = h->h_draw - lead->h_draw; core[r].draw_delta = B->rec_delta[r];
         if (single) nf[r].active = B->rec_active[r]; else nd[r].active = B->rec_active[r];
@@ -2840,29 +2853,57 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
         if (!batch_congruent_cached(B, r, B->leader, &why)) { B->err = std::string("replicas of a batch must be congruent; they differ in ") + why; return 1; }
     }
     if (batch_refresh_args(B)) return 1;
-    // phase(f): run f on every live member, in lock step when their signatures agree
+    // phase(f): run f on every live member, in lock step when their signatures agree.  Round 6: a FEW members out of step with the rest
+    // -- one that was laid out again inside this call (a re-sort at a poll, a straggler that came back: its lists are forced, its last
+    // pass is gone) -- take the step on launches of their own, as a straggler does, and the others stay in lock step; one step later the
+    // mirrors agree again.  (Until then ONE such member sent all of them through per-member launches for a step: 0.25 s per 1024 chains.)
     auto phase = [&](int (*f)(BluesEngine*)) -> int {
         pick_leader();
         if (!B->leader && !any_straggler()) return 0;
-        if (batch_refresh_args(B)) return 1;   // leader change, a member dropped out, a re-sort: cheap no-op otherwise
+        std::vector<int> odd;
         if (B->leader) {
-            const BatchSig lead = batch_sig(B->leader);
-            bool uniform = true;
-            for (int r = 0; r < R && uniform; r++) if (!B->failed[r] && !B->eng[r]->straggler) { const BatchSig g = batch_sig(B->eng[r]); uniform = !memcmp(&g, &lead, sizeof g); }
-            if (uniform) {
-                B->lockstep = true;
-                for (int r = 0; r < R; r++) if (!B->failed[r] && !B->eng[r]->straggler && f(B->eng[r])) {
-                    // a host-side failure of the leader leaves the shared launch sequence incomplete: every member is affected
-                    if (B->eng[r] == B->leader) { for (int q = 0; q < R; q++) if (!B->failed[q] && !B->eng[q]->straggler) { if (q != r) B->eng[q]->err = "batch leader failed: " + B->leader->err; fail(q); } }
-                    else fail(r);
+            auto split = [&](const BluesEngine* ref) {
+                odd.clear();
+                const BatchSig lead = batch_sig(ref);
+                int same = 0;
+                for (int r = 0; r < R; r++) if (!B->failed[r] && !B->eng[r]->straggler) {
+                    const BatchSig g = batch_sig(B->eng[r]);
+                    if (!memcmp(&g, &lead, sizeof g)) { same++; continue; }
+                    if (odd.empty() && B->tune.debug_lists) {
+#define SIGF(fld) if (g.fld != lead.fld) fprintf(stderr, "[lockstep] member %d differs from member %d in %s: %d against %d (step %d)\n", r, ref->batch_index, #fld, (int)g.fld, (int)lead.fld, g.h_step);
+                        SIGF(h_step) SIGF(h_lambda_step) SIGF(h_prop) SIGF(h_first_step) SIGF(pass_L) SIGF(prog_n) SIGF(prog_trace) SIGF(nprop) SIGF(prog_draw_base) SIGF(noise_draw_base)
+                        SIGF(pass_valid) SIGF(lists_forced) SIGF(vel_clean) SIGF(noise_valid) SIGF(tracing) SIGF(sorted_ok) SIGF(pass_valid_for_l) SIGF(have_positions) SIGF(fin_pending) SIGF(fin_mask)
+#undef SIGF
+                    }
+                    odd.push_back(r);
                 }
-                B->lockstep = false;
-                B->st_lockstep_steps++;
+                return same;
+            };
+            int same = split(B->leader);
+            if ((int)odd.size() > same) { B->leader = B->eng[odd[0]]; same = split(B->leader); }   // (the first member is the one out of step: the majority leads)
+            const bool partial = !odd.empty() && (int)odd.size() <= std::max(1, R / 32);
+            if (odd.empty() || partial) {
+                for (int r : odd) B->eng[r]->solo_now = true;   // (out of the shared records for this phase: batch_refresh_args)
+                int rc = batch_refresh_args(B);
+                if (!rc) {
+                    B->lockstep = true;
+                    for (int r = 0; r < R; r++) if (!B->failed[r] && !B->eng[r]->straggler && !B->eng[r]->solo_now && f(B->eng[r])) {
+                        // a host-side failure of the leader leaves the shared launch sequence incomplete: every member is affected
+                        if (B->eng[r] == B->leader) { for (int q = 0; q < R; q++) if (!B->failed[q] && !B->eng[q]->straggler && !B->eng[q]->solo_now) { if (q != r) B->eng[q]->err = "batch leader failed: " + B->leader->err; fail(q); } }
+                        else fail(r);
+                    }
+                    B->lockstep = false;
+                    B->st_lockstep_steps++;
+                    for (int r : odd) if (!B->failed[r] && f(B->eng[r])) fail(r);
+                }
+                for (int r : odd) B->eng[r]->solo_now = false;
+                if (rc) return 1;
             } else {
+                if (batch_refresh_args(B)) return 1;
                 for (int r = 0; r < R; r++) if (!B->failed[r] && !B->eng[r]->straggler && f(B->eng[r])) fail(r);
                 B->st_fallback_steps++;
             }
-        }
+        } else if (batch_refresh_args(B)) return 1;   // leader change, a member dropped out, a re-sort: cheap no-op otherwise
         // the stragglers: the same function, launches of their own (behind the shared ones, on the batch's stream)
         for (int r = 0; r < R; r++) if (!B->failed[r] && B->eng[r]->straggler && f(B->eng[r])) fail(r);
         return 0;
@@ -4105,7 +4146,7 @@ int blues_batch_get_counters(BluesBatch* b, double out[BLUES_N_BATCH_COUNTERS]) 
     for (const BluesEngine* m : b->eng) { if (!m->straggler && !rep) rep = m; out[10] += m->straggler ? 1.0 : 0.0; }
     if (!rep && !b->eng.empty()) rep = b->eng[0];
     if (rep) { out[7] = (double)rep->S; out[8] = (double)rep->jcap; out[9] = (double)rep->k1_mode; }
-    out[11] = (double)b->st_stragglers; out[12] = (double)b->st_rejoined;
+    out[11] = (double)b->st_stragglers; out[12] = (double)b->st_rejoined; out[13] = b->st_straggle_sec;
     return 0;
 }
 

@@ -1224,7 +1224,7 @@ def test_a_member_that_outgrows_the_shape_steps_on_its_own(Engine, tune):
     c2 = B.counters()
     assert c2["rejoined"] == 1 and c2["stragglers"] == 0 and c2["replans"] == 0, c2
     assert [g.stats()["nonbonded_kernel"] for g in engs] == [2] * R
-    assert B.stats()["fallback_steps"] <= 2
+    assert B.stats()["fallback_steps"] == 0      # (the member that came back took ONE step on launches of its own -- its lists were forced -- the others stayed in lock step)
     for g in engs:
         assert g.audit_lists()[1] == 0
     B.close()
