@@ -197,7 +197,7 @@ def _note_layout_events(driver, clock):
     clock["_counters"] = now
     if last is not None:
         clock.setdefault("layout_events", []).append({k: (round(now[k] - last[k], 4) if k.endswith("seconds") else now[k] - last[k])
-                                                       for k in ("replans", "replan_seconds", "relayouts", "poll_resorts", "resort_seconds", "reshapes", "straggled", "rejoined", "straggle_seconds") if k in now})
+                                                       for k in ("replans", "replan_seconds", "relayouts", "poll_resorts", "resort_seconds", "reshapes", "straggled", "rejoined", "straggle_seconds", "partial_steps") if k in now})
 
 
 def one_iteration(driver, chains, nsteps, md_steps, it, clock):
@@ -729,6 +729,7 @@ def main():
                        "resorts": sum(e["poll_resorts"] for ev in layout_events for e in ev), "resort_seconds": sum(e["resort_seconds"] for ev in layout_events for e in ev),
                        "straggled": sum(e["straggled"] for ev in layout_events for e in ev), "rejoined": sum(e["rejoined"] for ev in layout_events for e in ev),
                        "straggle_seconds": sum(e.get("straggle_seconds", 0.0) for ev in layout_events for e in ev),
+                       "partial_steps": sum(e.get("partial_steps", 0) for ev in layout_events for e in ev),
                        "layout_events_by_batch": [{str(k): e for k, e in enumerate(ev) if any(e.values())} for ev in layout_events],
                        "layout_shape_by_batch": [{k: c.get(k) for k in ("tiles_per_list", "jcap", "nonbonded_kernel", "stragglers")} for c in layout_now],
                        "host_threads": host_threads,

@@ -16,7 +16,7 @@ NB_PME_DIRECT = 1
 NB_PME = 2
 N_ENERGY_TERMS = 10
 N_STATS = 22
-N_BATCH_COUNTERS = 14
+N_BATCH_COUNTERS = 15
 ENERGY_TERM_NAMES = ("bonds", "angles", "torsions", "nonbonded", "exceptions", "alch_sterics",
                      "alch_electrostatics", "restraint", "reciprocal", "dispersion_correction")
 

@@ -338,7 +338,7 @@ struct BluesBatch {
     // each member's pending work and the members issue into it; leave: the batch stream is drained, members go home.
     hipStream_t stream = nullptr; bool entered = false;
     DBuf<double> d_gather; int64_t st_prefetch_pe = 0, st_prefetch_ke = 0;
-    int64_t st_lockstep_steps = 0, st_fallback_steps = 0, st_replans = 0, st_relayouts = 0, st_poll_resorts = 0, st_stragglers = 0, st_rejoined = 0; double st_replan_sec = 0.0, st_resort_sec = 0.0, st_straggle_sec = 0.0;   // (blues_batch_get_counters)
+    int64_t st_lockstep_steps = 0, st_fallback_steps = 0, st_replans = 0, st_relayouts = 0, st_poll_resorts = 0, st_stragglers = 0, st_rejoined = 0, st_partial_steps = 0; double st_replan_sec = 0.0, st_resort_sec = 0.0, st_straggle_sec = 0.0;   // (blues_batch_get_counters)
     // in-situ timing of the nonbonded force kernel (blues_batch_kernel_timing): every `k1t_every`-th lock-step force launch of the
     // stepping loop is bracketed by two events on the stream it runs on; finished pairs are harvested lazily (no synchronisation)
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; bool busy = false; };
@@ -2894,6 +2894,7 @@ static int batch_do_steps(BluesBatch* B, int n_steps, bool tracing, int* status)
                     }
                     B->lockstep = false;
                     B->st_lockstep_steps++;
+                    if (partial) B->st_partial_steps++;
                     for (int r : odd) if (!B->failed[r] && f(B->eng[r])) fail(r);
                 }
                 for (int r : odd) B->eng[r]->solo_now = false;
@@ -4146,7 +4147,7 @@ int blues_batch_get_counters(BluesBatch* b, double out[BLUES_N_BATCH_COUNTERS]) 
     for (const BluesEngine* m : b->eng) { if (!m->straggler && !rep) rep = m; out[10] += m->straggler ? 1.0 : 0.0; }
     if (!rep && !b->eng.empty()) rep = b->eng[0];
     if (rep) { out[7] = (double)rep->S; out[8] = (double)rep->jcap; out[9] = (double)rep->k1_mode; }
-    out[11] = (double)b->st_stragglers; out[12] = (double)b->st_rejoined; out[13] = b->st_straggle_sec;
+    out[11] = (double)b->st_stragglers; out[12] = (double)b->st_rejoined; out[13] = b->st_straggle_sec; out[14] = (double)b->st_partial_steps;
     return 0;
 }
 

@@ -371,7 +371,7 @@ class NativeBatch:
         return {"lockstep_steps": s[0], "fallback_steps": s[1], "replicas": s[2], "batched_energy_evaluations": s[3]}
 
     COUNTERS = ("replans", "replan_seconds", "relayouts", "poll_resorts", "resort_seconds", "reshapes", "resorts", "tiles_per_list", "jcap", "nonbonded_kernel",
-                "stragglers", "straggled", "rejoined", "straggle_seconds")
+                "stragglers", "straggled", "rejoined", "straggle_seconds", "partial_steps")
 
     def counters(self):
         """What the batch's layout has cost so far (include/blues_engine.h: blues_batch_get_counters): re-plans of the layout shape and

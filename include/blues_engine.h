@@ -402,8 +402,9 @@ int blues_batch_get_stats(BluesBatch *b, int64_t stats[4]);
  * there [5] members moved to another shape in place (no sort) [6] re-sorts of all members, whoever asked [7] tiles per group list now
  * [8] list capacity [9] nonbonded kernel (blues_get_stats [12]) -- of the members in the batch's layout [10] members that step on launches
  * of their own now because their lists have outgrown the batch's shape (stragglers) [11] times a member became one [12] times one came back
- * [13] seconds spent laying those members out (leaving and coming back). */
-#define BLUES_N_BATCH_COUNTERS 14
+ * [13] seconds spent laying those members out (leaving and coming back) [14] phases of a step in which a few members, out of step with the
+ * rest (laid out again inside the call), took their own launches while the others stayed in lock step. */
+#define BLUES_N_BATCH_COUNTERS 15
 int blues_batch_get_counters(BluesBatch *b, double out[BLUES_N_BATCH_COUNTERS]);
 /* as blues_time_nonbonded, for one batched launch covering all members.  With pruned per-atom lists an atom is served in
  * one of two ways: from its current pruned list, or from its full list while the pruned one is re-derived.  usec[0] / usec[1]:

@@ -20,14 +20,19 @@ last = {}
 def timed(label, n=20):
     t0 = time.perf_counter(); B.step(n); dt = time.perf_counter() - t0
     c = B.counters(); st = B.stats()
-    for r in (0, 1):
-        e = engs[r].stats(); d = {k: e[k] - last.get((r, k), 0) for k in ("kernel_launches", "list_builds", "atom_prunes", "own_energy_evaluations", "force_passes", "resorts")}
-        for k in d: last[(r, k)] = e[k]
-        print("      member %d: %s jcap %d tiles/list %d max_jcount %d pruned entries %d" % (r, d, e["jcap"], e["tiles_per_list"], e["max_jcount"], e["pruned_list_entries"]))
-    print("%-44s %7.1f ms for %d steps | straggled %d rejoined %d stragglers %d straggle_seconds %.4f fallback %d" % (label, 1e3 * dt, n, c["straggled"], c["rejoined"], c["stragglers"], c["straggle_seconds"], st["fallback_steps"]), flush=True)
+    print("%-44s %7.1f ms for %d steps | straggled %d rejoined %d stragglers %d straggle_seconds %.4f fallback %d partial %d resorts %d" % (label, 1e3 * dt, n, c["straggled"], c["rejoined"], c["stragglers"], c["straggle_seconds"], st["fallback_steps"], c["partial_steps"], c["poll_resorts"]), flush=True)
 timed("warm-up"); timed("steady")
 x0 = engs[0].get_positions()
-for cycle in range(3):
+# a spread that asks for a re-sort at the next 64-step poll without outgrowing the shape
+for dist in (0.9, 1.1, 1.3):
+    B.reset_all(); engs[0].set_positions(_swap_waters_outward(s, x0, n_pairs=1, distance=dist))
+    timed("one water %.1f nm out: first 70 steps" % dist, 70)
+    for q in range(3):
+        timed("   ... 70 more", 70)
+    print("      member 0 max_jcount %d" % engs[0].stats()["max_jcount"])
+B.reset_all(); engs[0].set_positions(x0)
+timed("back to the compact arrangement", 70)
+for cycle in range(1):
     engs[0].set_positions(_swap_waters_outward(s, x0))
     timed("member 0 outgrows the shape (cycle %d)" % cycle)
     timed("  ... steps on its own")

@@ -44,5 +44,5 @@ PY
   full_R1024) run full_R1024 --md-steps 1000 --replicas 1024 --groups 1 --steps 2 --warmup 2 --no-cpu --no-single ;;
   water_R16) run water_R16 --workload water --nsteps-nc 2000 --replicas 16 --groups 1 --steps 2 --warmup 1 --no-cpu --no-single ;;
   sidechain_R64) run sidechain_R64 --workload sidechain --replicas 64 --groups 1 --nsteps-nc 5000 --steps 2 --warmup 1 --no-cpu --no-single ;;
-  step) bash scripts/r06_step.sh final > $out/step.txt 2>&1; cp gpurun_out/r06/step_final/kernel_stats.csv $out/kernel_stats_step_R1024.csv 2>/dev/null; cat $out/step.txt ;;
+  step) bash scripts/r06_step.sh final "assume_batch=1024" > $out/step.txt 2>&1; cp gpurun_out/r06/step_final/kernel_stats.csv $out/kernel_stats_step_R1024.csv 2>/dev/null; cat $out/step.txt ;;
 esac; done
