@@ -42,7 +42,7 @@ def test_five_consecutive_default_lines_have_no_slow_iteration():
         assert d["value"] == pytest.approx(2048 * 20 * 1000 * 0.004e-3 / (d["ms_per_step"] * 20e-3 / 86400.0), rel=1e-6)
         values.append(d["value"])
     assert min(values) >= 455000.0                         # the bar of VERDICT r05 ...
-    assert min(values) >= 495000.0                         # ... and what the round's kernels deliver
+    assert min(values) >= 540000.0                         # ... and the bar of its item 2 (what the round's kernels deliver: 551-553 k)
     assert max(values) <= 1.04 * min(values)               # box to box
     last = _load("bench_default_steps20.json", R05)
     assert min(values) >= 1.05 * last["value"]
@@ -76,7 +76,9 @@ def test_bare_stepping_kernel_table():
     rows = list(csv.DictReader(open(os.path.join(R06, "kernel_stats_step_R1024.csv"))))
     us = {x["Name"].split("(")[0]: float(x["AverageNs"]) / 1e3 for x in rows if int(x["Calls"]) >= 500}
     main = sum(v for k, v in us.items() if any(q in k for q in ("k_nonbonded_atom_b<false>", "k_step_default_late_b", "k_alchemical_dense32_b", "k_build_atom_lists_b", "k_build_lists_b", "k_gather_stale_b")))
-    assert 560.0 < main < 650.0, main                     # (round 5: 221 + 157 + 167 + 87 + 56 + 12 = 700)
+    assert 560.0 < main < 615.0, main                     # (round 5: 221 + 157 + 167 + 87 + 56 + 12 = 700)
+    step = [v for k, v in us.items() if "k_step_default_late_b" in k]
+    assert len(step) == 1 and step[0] < 125.0             # (round 5: 156.9 us -- two waves per chain instead of four, one solver path: BluesTuning.pack_clusters)
 
 
 def test_solute_line():

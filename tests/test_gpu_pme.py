@@ -183,7 +183,9 @@ def test_differential_correction_equals_the_four_energy_form(Engine, tol_box, re
         for N in range(nIter):
             for r in range(R):
                 a, b = rec[N][r], ref[0][N][r]
-                assert abs(a["correction"] - b["correction"]) <= 1e-9 * ref[2] / kT, (key, N, r, a["correction"], b["correction"])
+                # (1e-9 of the energies the correction is a difference of: a 10-step switch in this small box can end in a clash -- "the step is
+                # unstable", protocol work 10^5 - 10^6 kJ/mol -- and the energies at x1 are then of that size, not of the start state's)
+                assert abs(a["correction"] - b["correction"]) <= 1e-9 * max(ref[2], abs(b["protocol_work"])) / kT, (key, N, r, a["correction"], b["correction"], b["protocol_work"])
                 assert a["accept"] == b["accept"] and a["protocol_work"] == pytest.approx(b["protocol_work"], rel=1e-9, abs=1e-9)
         for r in range(R):
             assert np.abs(xs[r] - ref[1][r]).max() < 1e-9
