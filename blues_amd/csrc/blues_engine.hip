@@ -54,22 +54,69 @@ static const int REBUILD_GRID = 512;
 static const int SHAPE_CAND[9] = {1, 2, 3, 4, 5, 6, 8, 12, 16};   // tiles per group list the per-atom-list layout chooses from
 static inline int shape_index(int S) { for (int q = 0; q < 9; q++) if (SHAPE_CAND[q] == S) return q; return -1; }
 
+// ---- device memory of the engines' buffers (round 6).  An engine holds ~100 device buffers; 2048 chains were 134,000 hipMalloc calls at
+// set-up -- 40 % of its thread-time, behind the runtime's lock whatever the number of host threads -- and as many zero-fills.  Buffers of up
+// to SLAB_DIRECT bytes now come from slabs: 128 MiB allocations zero-filled once, handed out by a bump pointer under a mutex (a fresh
+// block needs no fill); released blocks wait in a free list by size for the next buffer of that size (the engines of a System ask for the
+// same sizes).  Slabs live as long as the process.  Every block carries a guard of 256 bytes behind it.
+#define SLAB_BYTES ((size_t)128 << 20)
+#define SLAB_DIRECT ((size_t)8 << 20)
+struct DevSlabs {
+    struct Slab { char* base; size_t size, used; };
+    std::mutex mu;
+    std::map<int, std::vector<Slab>> slabs;                              // by device
+    std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;    // (device, bytes) -> released blocks
+    static size_t round(size_t bytes) { return ((std::max<size_t>(bytes, 1) + 255) & ~(size_t)255) + 256; }
+    // returns a block of round(bytes) bytes; *zeroed: it has never been handed out (still holds the slab's zeros)
+    void* get(int dev, size_t bytes, bool* zeroed) {
+        const size_t rb = round(bytes);
+        std::lock_guard<std::mutex> lk(mu);
+        auto f = free_blocks.find({dev, rb});
+        if (f != free_blocks.end() && !f->second.empty()) { void* q = f->second.back(); f->second.pop_back(); *zeroed = false; return q; }
+        std::vector<Slab>& v = slabs[dev];
+        if (v.empty() || v.back().used + rb > v.back().size) {
+            Slab sl; sl.size = std::max(SLAB_BYTES, rb); sl.used = 0; sl.base = nullptr;
+            if (hipMalloc((void**)&sl.base, sl.size) != hipSuccess) return nullptr;
+            if (hipMemset(sl.base, 0, sl.size) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { hipFree(sl.base); return nullptr; }   // (done before any stream can touch a block)
+            v.push_back(sl);
+        }
+        void* q = v.back().base + v.back().used; v.back().used += rb; *zeroed = true;
+        return q;
+    }
+    void put(int dev, void* q, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        free_blocks[{dev, round(bytes)}].push_back(q);
+    }
+};
+static DevSlabs& dev_slabs() { static DevSlabs* s = new DevSlabs; return *s; }   // (never destroyed: buffers of static engines may outlive any destructor order)
+
 template <typename T> struct DBuf {
     T* p = nullptr; size_t n = 0, cap = 0;
+    bool direct = false; int dev = 0;   // direct: its own hipMalloc (large buffers); the device the block lives on
     // an existing buffer that is large enough is reused (a re-sort keeps every address).  Round 6: large ENOUGH, not of the same size -- a
     // member that leaves its batch's layout for fragment lists and comes back changes the size of a dozen buffers twice, and with ~10^5
     // allocations in the process every hipFree / hipMalloc pair took milliseconds (one member's return: 0.2 s with the device idle)
-    void reserve(size_t count) {
-        if (p && count <= cap) { n = count; return; }
-        {
-            release(); n = count; cap = count;
-            SetupTimer tm(3); { std::lock_guard<std::mutex> lk(setup_mu()); g_setup_sec[6] += 1.0; }
-            if (count * sizeof(T) > ((size_t)1 << 31)) fprintf(stderr, "[blues] a single device allocation of %.1f GiB (%zu elements of %zu bytes)\n", count * sizeof(T) / 1073741824.0, count, sizeof(T));
-            if (hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) throw std::string("hipMalloc failed");
+    // returns true if the block is NEW and still holds the slab's zeros (alloc then needs no fill)
+    bool reserve(size_t count) {
+        if (p && count <= cap) { n = count; return false; }
+        release(); n = count; cap = count;
+        SetupTimer tm(3); { std::lock_guard<std::mutex> lk(setup_mu()); g_setup_sec[6] += 1.0; }
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        if (bytes > ((size_t)1 << 31)) fprintf(stderr, "[blues] a single device allocation of %.1f GiB (%zu elements of %zu bytes)\n", bytes / 1073741824.0, count, sizeof(T));
+        if (hipGetDevice(&dev) != hipSuccess) { n = cap = 0; throw std::string("hipGetDevice failed"); }
+        if (bytes > SLAB_DIRECT) {
+            direct = true;
+            if (hipMalloc((void**)&p, bytes) != hipSuccess) { p = nullptr; n = cap = 0; throw std::string("hipMalloc failed"); }
+            return false;
         }
+        direct = false;
+        bool zeroed = false;
+        p = (T*)dev_slabs().get(dev, bytes, &zeroed);
+        if (!p) { n = cap = 0; throw std::string("hipMalloc failed"); }
+        return zeroed;
     }
     void alloc(size_t count) {   // zero-filled
-        reserve(count);
+        if (reserve(count)) return;   // (a block nobody has written to)
         SetupTimer tm(4);
         hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
     }
@@ -82,7 +129,10 @@ template <typename T> struct DBuf {
         h.resize(n);
         if (n && hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) throw std::string("hipMemcpy D2H failed");
     }
-    void release() { if (p) hipFree(p); p = nullptr; n = 0; cap = 0; }
+    void release() {
+        if (p) { if (direct) hipFree(p); else dev_slabs().put(dev, p, std::max<size_t>(cap, 1) * sizeof(T)); }
+        p = nullptr; n = 0; cap = 0; direct = false;
+    }
     ~DBuf() { release(); }
 };
 
