@@ -771,9 +771,15 @@ static int build_bonded(BluesEngine* h, const BluesSystemDesc* s) {
 }
 
 // ------------------------------------------------------------------ spatial sort + tile image (host, at set_positions)
+static int download_xyz(BluesEngine* h, double* xyz, DBuf<double>* src);
 static int sort_and_tile(BluesEngine* h) {
     SetupTimer tm_all(1);
     const int n = h->n;
+    if (h->hx.size() != (size_t)3 * n) {   // (the positions this layout is made from: normally filled by the caller; the copy is dropped when the layout is done)
+        if (!h->have_positions) E_FAIL(h, "positions have not been set");
+        h->hx.resize((size_t)3 * n);
+        if (download_xyz(h, h->hx.data(), h->d_x)) return 1;
+    }
     h->steps_since_sort = 0;
     h->shape_overflow = false;   // (set again below if this layout still does not fit the batch's shape; a layout that left the per-atom lists has no shape to outgrow)
     // fragment lists (kernels_frag.h) where every environment atom moves: mixed precision, more than the lone-chain handful of tiles
@@ -1180,6 +1186,7 @@ static int sort_and_tile(BluesEngine* h) {
     h->sorted_ok = true; h->lists_forced = true; h->pass_valid = false; h->graph_valid = false;
     h->layout_R = h->batch_R;
     h->args_epoch++;
+    std::vector<double>().swap(h->hx);   // (only a layout reads it, and every caller fills it first: 560 KB x 2048 chains of host memory otherwise)
     return 0;
 }
 
@@ -1878,10 +1885,7 @@ static int resolve_xfer(BluesEngine* h) {
     // iteration with the atoms a few tenths of a nm from the sort -- re-sorting for those cost 2 x 5 ms per chain and iteration
     const float far = (h->k1_mode == 2 && h->xfer_foreign) ? 0.09f : 1.0f;   // (squared displacement: 0.3 nm / 1 nm)
     h->xfer_foreign = false;
-    if (h->sorted_ok && h->k1_mode != 3 && (worst > far || (int)out[2] > h->n / 10)) {
-        if (download_xyz(h, h->hx.data(), h->d_x)) return 1;
-        h->sorted_ok = false;
-    }
+    if (h->sorted_ok && h->k1_mode != 3 && (worst > far || (int)out[2] > h->n / 10)) h->sorted_ok = false;   // (the layout that follows fetches the positions itself: sort_and_tile)
     return 0;
 }
 
@@ -3188,7 +3192,7 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     if (h->tune.graph_fork >= 0) h->graph_fork = h->tune.graph_fork != 0;
     try {
         for (int k = 0; k < 3; k++) { h->d_x[k].alloc(n); h->d_v[k].alloc(n); h->d_xbuild[k].alloc(n); h->d_x_sort[k].alloc(n); }
-        h->d_stage.alloc((size_t)3 * n); h->d_xfer_out.alloc(4); h->hx.assign((size_t)3 * n, 0.0);
+        h->d_stage.alloc((size_t)3 * n); h->d_xfer_out.alloc(4);
         h->d_mass.upload(h->T->mass); h->d_charge.upload(h->T->charge); h->d_sigma.upload(h->T->sigma); h->d_eps.upload(h->T->eps);
         h->d_flags.alloc(1); h->d_acc.alloc(1); h->d_ctrl.alloc(1); h->d_stamps.alloc(64); h->d_tab_ls.upload(h->tab_ls); h->d_tab_le.upload(h->tab_le); h->d_ftot.alloc((size_t)9 * n); h->d_alch_self.alloc(9 * 64);
         h->d_alch_orig.upload(h->alch); h->d_alch_local.upload(h->T->alch_local);
@@ -3236,7 +3240,7 @@ static int relayout(BluesEngine* h) {
     if (!h->have_positions) { h->sorted_ok = false; return 0; }
     if (flush_program(h)) return 1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    if (download_xyz(h, h->hx.data(), h->d_x)) return 1;
+    std::vector<double>().swap(h->hx);   // (sort_and_tile fetches the positions that are on the device now)
     h->sorted_ok = false;
     return sort_and_tile(h);
 }
@@ -3530,7 +3534,7 @@ int blues_set_box(BluesEngine* h, const double box[9]) {
     derive_margins(h);   // (the layout re-derives the skin for the new box)
     h->sorted_ok = false; h->pass_valid = false; h->fin_pending = false; h->e_frozen_valid = false; h->ecache.clear();
     if (h->pme && (h->precision == 0 ? pme_tables<float>(h) : pme_tables<double>(h))) return 1;
-    if (h->have_positions) { if (download_xyz(h, h->hx.data(), h->d_x)) return 1; return sort_and_tile(h); }
+    if (h->have_positions) { std::vector<double>().swap(h->hx); return sort_and_tile(h); }
     return 0;
 }
 

@@ -76,7 +76,9 @@ struct ListArgs {
 // (n / 64 / LIST_WAVES / LIST_PREFETCH) latencies: 4 waves x 1 load took 60-70 us at n = 23,400; 16 x 4 takes ~12.
 #define MASK_QUOTA 24   // exclusion-mask tiles per i-tile (j-batches that hold an excluded pair; a handful in practice)
 #define LIST_WAVES 16
+#ifndef LIST_PREFETCH
 #define LIST_PREFETCH 4
+#endif
 #define LIST_THREADS (LIST_WAVES * 64)
 #define ATOM_LIST_WAVES 4                   // waves per block of build_atom_lists_body: a 256-thread block with < 168 registers per
 #define ATOM_LIST_THREADS (ATOM_LIST_WAVES * 64)   // lane fits exactly where a workgroup of the alchemical kernel retires
