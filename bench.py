@@ -187,6 +187,13 @@ def one_switch(driver, chains, states, nsteps, it, clock, gather=True):
     return recs
 
 
+def _stage(name):
+    """One line per stage on stderr (never stdout: the JSON line is alone there): if the process dies -- a GPU memory fault ends it without a
+    Python traceback -- the last marker says where."""
+    if os.environ.get("RANK", "0") == "0":
+        sys.stderr.write("[bench] %s\n" % name); sys.stderr.flush()
+
+
 def _note_layout_events(driver, clock):
     """What the batch's layout cost in the iteration that just ended (NativeBatch.counters: re-plans of the layout shape, members
     re-sorted at the 64-step polls, members laid out again, the seconds those took): a slow iteration names its cause."""
@@ -310,8 +317,17 @@ def memory_use():
     import resource
     import torch
     free, total = torch.cuda.mem_get_info()
-    return {"host_peak_rss_gib": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0,
-            "device_in_use_gib": (total - free) / 2.0 ** 30, "device_total_gib": total / 2.0 ** 30}
+    out = {"host_peak_rss_gib": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0,
+           "device_in_use_gib": (total - free) / 2.0 ** 30, "device_total_gib": total / 2.0 ** 30}
+    try:   # the engines' device buffers end in 256 bytes nobody owns: a kernel that wrote past a buffer's end has left a mark there
+        import ctypes
+        from blues_amd import _lib
+        g = (ctypes.c_int64 * 8)()
+        if _lib.load().blues_debug_check_guards(g) == 0:
+            out["device_buffer_guards"] = {"blocks": int(g[0]), "marked": int(g[1])}
+    except Exception:
+        pass
+    return out
 
 
 def _free_port():
@@ -470,6 +486,7 @@ def main():
     x0 = system.positions.copy()
     v0 = vel.copy()
     setup_parts = {"chains": time.perf_counter() - t_setup}
+    _stage("chains built")
 
     # ---- configs[1] to the letter: ONE chain on the GPU, a lone engine with a lone engine's layout (its own construction, default tuning)
     single = None
@@ -494,6 +511,7 @@ def main():
                                "note": "one chain keeps a few of the 256 CUs busy: every kernel of its step is latency-bound (DESIGN.md section 4)"}}
         e1.close()
     t_single = time.perf_counter() - t_single      # (a measurement, not set-up: taken out of setup_seconds below)
+    _stage("single replica measured")
 
     G = max(1, min(args.groups, R))
     bounds = [(g * R) // G for g in range(G + 1)]
@@ -520,6 +538,7 @@ def main():
     else:
         gstates = [md_states(grp, x0, v0, batch=drv._ncmc_batch, driver=drv, decorrelate=0 if args.same_start else args.decorrelate) for grp, drv in zip(groups, drivers)]
     setup_parts["hand_over_states"] = time.perf_counter() - t_part
+    _stage("batches made, states handed over")
     t_setup = time.perf_counter() - t_setup - t_single
     clocks = [{"sync": 0.0, "switch": 0.0, "decide": 0.0} for _ in range(G)]
 
@@ -537,6 +556,7 @@ def main():
 
     for w in range(args.warmup):
         switch_all(w)      # on the main thread: every kernel variant has been launched once before threads start
+    _stage("warm-up done")
     # what one batch's iteration takes when it has the device to itself (the warm-up ran the batches one after the other): the batches' threads
     # start a fraction of it apart, in the phase the turn-taking settles into anyway -- started together, the batch that loses the first turn
     # spends the first half switch of the other one waiting inside its first timed iteration (1.52 s against 1.36 s for every later one)
@@ -587,6 +607,7 @@ def main():
                 recs.append(gather_decision_block(np.concatenate(parts)))
     barrier()
     elapsed = time.perf_counter() - t0
+    _stage("timed iterations done")
     st1 = engs[0].stats(); b1 = [d._ncmc_batch.stats() for d in drivers]
     iteration_seconds = [list(ck.get("iterations", [])) for ck in clocks]     # per batch, per timed iteration (with several batches: the turns it waited for included)
     layout_events = [list(ck.get("layout_events", [])) for ck in clocks]       # per batch, per timed iteration
@@ -746,7 +767,8 @@ def main():
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(system, vel, args.cpu_steps)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)   # (flushed before the chains are torn down at the end of main(): a fault there must not take the line with it)
+        _stage("line printed")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -288,6 +288,7 @@ def declare_engine_prototypes(lib):
         "blues_batch_time_nonbonded": ([H, C.c_int32, _dp], C.c_int),
         "blues_batch_time_nonbonded_modes": ([H, C.c_int32, _dp, _dp], C.c_int),
         "blues_debug_setup_seconds": ([_dp], C.c_int),
+        "blues_debug_check_guards": ([C.POINTER(C.c_int64)], C.c_int),
         "blues_batch_kernel_timing": ([H, C.c_int32], C.c_int),
         "blues_batch_get_kernel_timing": ([H, _dp], C.c_int),
     }
@@ -311,5 +312,5 @@ ENGINE_SYMBOLS = (
     "blues_batch_snapshot_capture", "blues_batch_restore", "blues_batch_restore_edited", "blues_batch_read_atoms", "blues_batch_reset",
     "blues_batch_set_velocities_to_temperature", "blues_batch_mesh_energy",
     "blues_batch_get_stats", "blues_batch_get_counters", "blues_batch_time_nonbonded", "blues_batch_time_nonbonded_modes",
-    "blues_batch_kernel_timing", "blues_batch_get_kernel_timing", "blues_debug_setup_seconds",
+    "blues_batch_kernel_timing", "blues_batch_get_kernel_timing", "blues_debug_setup_seconds", "blues_debug_check_guards",
 )

@@ -68,6 +68,7 @@ struct DevSlabs {
     std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;    // (device, bytes) -> released blocks
     static size_t round(size_t bytes) { return ((std::max<size_t>(bytes, 1) + 255) & ~(size_t)255) + 256; }
     // returns a block of round(bytes) bytes; *zeroed: it has never been handed out (still holds the slab's zeros)
+    std::vector<std::pair<char*, size_t>> blocks;   // every block ever handed out (base, rounded bytes): blues_debug_check_guards
     void* get(int dev, size_t bytes, bool* zeroed) {
         const size_t rb = round(bytes);
         std::lock_guard<std::mutex> lk(mu);
@@ -81,6 +82,7 @@ struct DevSlabs {
             v.push_back(sl);
         }
         void* q = v.back().base + v.back().used; v.back().used += rb; *zeroed = true;
+        blocks.push_back({(char*)q, rb});
         return q;
     }
     void put(int dev, void* q, size_t bytes) {
@@ -2749,6 +2751,19 @@ static int batch_prefetch(BluesBatch* B, int what) {
     if (R == 0) return 0;
     std::vector<char> live(R), need(R, 0);
     for (int r = 0; r < R; r++) if (B->active[r] && !B->failed[r] && resolve_xfer(B->eng[r])) B->failed[r] = 1;
+    {   // A few members whose State arrived far from where their tiles were laid out (a restore after a re-sort at a poll: resolve_xfer) have
+        // no layout now.  They are laid out HERE: left as they were, the check below sent ALL members to their own on-demand evaluation --
+        // 1024 lone energy evaluations, 0.15-0.25 s, in an iteration that names no layout event (round 6: three such iterations in 40 runs).
+        int lacking = 0, have = 0;
+        for (int r = 0; r < R; r++) if (B->active[r] && !B->failed[r] && B->eng[r]->have_positions && !B->eng[r]->straggler) { have++; lacking += !B->eng[r]->sorted_ok; }
+        if (lacking > 0 && lacking <= std::max(1, have / 8) && !B->lockstep) {
+            if (hipStreamSynchronize(B->stream) != hipSuccess) { B->err = "stream synchronisation failed"; return 1; }
+            for (int r = 0; r < R; r++) if (B->active[r] && !B->failed[r] && B->eng[r]->have_positions && !B->eng[r]->straggler && !B->eng[r]->sorted_ok) {
+                if (ensure_sorted(B->eng[r])) B->failed[r] = 1;
+                B->st_relayouts++;
+            }
+        }
+    }
     for (int r = 0; r < R; r++) live[r] = B->active[r] && !B->failed[r] && B->eng[r]->have_positions && B->eng[r]->sorted_ok && !B->eng[r]->straggler;   // (a straggler evaluates on demand, with launches of its own)
     BluesEngine* lead = nullptr;
     for (int r = 0; r < R; r++) if (live[r]) { lead = B->eng[r]; break; }
@@ -3217,6 +3232,39 @@ static int create_impl(BluesEngine* h, const BluesSystemDesc* s, const BluesInte
     return 0;
 }
 
+// Diagnostic: every block of the device slabs ends in 256 bytes nobody owns, zero since the slab was made.  A kernel that writes past the
+// end of a buffer leaves a mark there.  out[0] blocks checked, out[1] guards with a mark, then for the first three: rounded size of the
+// block in bytes, byte offset of the first marked word within the guard.
+__global__ void k_check_guards(const unsigned* const* guards, int n, int* out /* [2 + 3 * 2] */) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= n) return;
+    const unsigned w = guards[b][lane];
+    const unsigned long long bal = __ballot(w != 0u);
+    if (bal && lane == 0) {
+        const int k = atomicAdd(&out[0], 1);
+        if (k < 3) { out[2 + 2 * k] = b; out[3 + 2 * k] = 4 * (int)__builtin_ctzll(bal); }
+    }
+}
+int blues_debug_check_guards(int64_t* out8) {
+    if (!out8) return 2;
+    for (int k = 0; k < 8; k++) out8[k] = 0;
+    DevSlabs& S = dev_slabs();
+    std::vector<const unsigned*> g; std::vector<size_t> sz;
+    { std::lock_guard<std::mutex> lk(S.mu); for (auto& b : S.blocks) { g.push_back((const unsigned*)(b.first + b.second - 256)); sz.push_back(b.second); } }
+    out8[0] = (int64_t)g.size();
+    if (g.empty()) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    const unsigned** d_g = nullptr; int* d_out = nullptr;
+    if (hipMalloc((void**)&d_g, g.size() * sizeof(void*)) != hipSuccess || hipMalloc((void**)&d_out, 8 * sizeof(int)) != hipSuccess) return 1;
+    hipMemcpy(d_g, g.data(), g.size() * sizeof(void*), hipMemcpyHostToDevice); hipMemset(d_out, 0, 8 * sizeof(int));
+    hipLaunchKernelGGL(k_check_guards, dim3(((int)g.size() + 3) / 4), dim3(256), 0, nullptr, (const unsigned* const*)d_g, (int)g.size(), d_out);
+    int h_out[8]; const bool ok = hipMemcpy(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost) == hipSuccess;
+    hipFree(d_g); hipFree(d_out);
+    if (!ok) return 1;
+    out8[1] = h_out[0];
+    for (int k = 0; k < 3 && k < h_out[0]; k++) { out8[2 + 2 * k] = (int64_t)sz[h_out[2 + 2 * k]]; out8[3 + 2 * k] = h_out[3 + 2 * k]; }
+    return 0;
+}
 int blues_debug_setup_seconds(double* out8) { if (!out8) return 2; for (int k = 0; k < 8; k++) out8[k] = g_setup_sec[k]; return 0; }
 
 int blues_engine_create(const BluesSystemDesc* s, const BluesIntegratorDesc* it, int device, BluesEngine** out) {
@@ -3403,7 +3451,9 @@ static void batch_detach_all(BluesBatch* B) {
         hipStreamSynchronize(m->stream);
         m->batch = nullptr; m->batch_index = -1; m->batch_R = m->tune.assume_batch > 0 ? m->tune.assume_batch : 1;
         m->shape_S = 0; m->shape_jcap = 0; m->forbid_atom = false; m->pin_jcap = m->pin_seg = m->pin_nw = m->pin_wpb = 0;
-        relayout(m);
+        // its own layout again -- when it is next used (ensure_sorted: the layout fetches the positions from the device itself).  Laid out
+        // here and now, the end of a run re-sorted every member of every batch, 5 ms each, moments before destroying it.
+        if (m->have_positions) { flush_program(m); m->straggler = false; m->sorted_ok = false; m->pass_valid = false; m->fin_pending = false; }
     }
     B->eng.clear(); B->leader = nullptr; B->lockstep = false;
     if (B->stream) { hipStreamDestroy(B->stream); B->stream = nullptr; }
@@ -3412,8 +3462,9 @@ static void batch_detach_all(BluesBatch* B) {
 int blues_engine_destroy(BluesEngine* h) {
     if (!h) return 0;
     hipSetDevice(h->device);
-    if (h->batch) batch_detach_all(h->batch);  // a batch does not outlive any of its members
+    if (h->batch) { if (h->batch->stream) hipStreamSynchronize(h->batch->stream); batch_detach_all(h->batch); }  // a batch does not outlive any of its members (and none of its launches the member's buffers)
     hipStreamSynchronize(h->stream);
+    for (hipStream_t q : {h->s1, h->s2}) if (q) hipStreamSynchronize(q);
     if (h->sw_saved) { blues_snapshot_release(h->sw_saved); h->sw_saved = nullptr; }
     if (h->h_xfer) { hipHostFree(h->h_xfer); h->h_xfer = nullptr; }
     if (h->h_edit) { hipHostFree(h->h_edit); h->h_edit = nullptr; }
@@ -4146,6 +4197,9 @@ int blues_batch_destroy(BluesBatch* b) {
     if (b) { k1t_harvest(b, true); for (auto& p : b->k1t_pairs) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); } b->k1t_pairs.clear(); }
     if (!b) return 0;
     if (!b->eng.empty()) hipSetDevice(b->eng[0]->device);
+    // (nothing of this batch may still run when its records and pinned areas go: device buffers from the slabs are released without the
+    // implicit device-wide wait every hipFree used to be)
+    if (b->stream) hipStreamSynchronize(b->stream);
     for (BluesEngine* m : b->eng) if (m && m->xfer_pending && m->xfer_src != m->h_xfer) resolve_xfer(m);   // (a verdict parked in the batch's buffer)
     batch_detach_all(b);
     if (b->h_arena) { hipHostFree(b->h_arena); b->h_arena = nullptr; }

@@ -419,6 +419,10 @@ int blues_batch_time_nonbonded(BluesBatch *b, int32_t reps, double *usec_per_lau
 /* Diagnostic: where the set-up time of this process went so far (seconds): [0] blues_engine_create, [1] laying out tiles and lists
  * (sort_and_tile), [2] of which image + uploads, [3] device allocations, [4] zero-fills, [5] host-to-device copies, [6] allocations made, [7] stream and event creation. */
 int blues_debug_setup_seconds(double *out8);
+/* Diagnostic: the engines' device buffers of up to 8 MiB are carved from zero-filled slabs, 256 bytes that nobody owns behind each.  out8[0] blocks
+ * checked, out8[1] blocks whose guard carries a mark (a kernel wrote past the end of a buffer), then for the first three of them: size of the
+ * block in bytes (rounded to 256, guard included), byte offset of the first marked word within the guard.  Synchronises the device. */
+int blues_debug_check_guards(int64_t *out8);
 int blues_batch_kernel_timing(BluesBatch *b, int32_t every);
 int blues_batch_get_kernel_timing(BluesBatch *b, double out[3]);
 

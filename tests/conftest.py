@@ -13,6 +13,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_guards_seen = [0]
+
+
+@pytest.fixture(autouse=True)
+def _device_buffer_guards(request):
+    """After every GPU test: no kernel may have written past the end of a device buffer (the engines' buffers come from slabs with 256
+    unowned bytes behind each block: include/blues_engine.h, blues_debug_check_guards)."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import ctypes
+    from blues_amd import _lib
+    lib = _lib.load()
+    out = (ctypes.c_int64 * 8)()
+    assert lib.blues_debug_check_guards(out) == 0
+    marked = int(out[1])
+    new, _guards_seen[0] = marked - _guards_seen[0], marked
+    assert new <= 0, "a kernel wrote past the end of a device buffer during this test: %d guard(s) marked; first blocks (bytes, offset in guard): %s" % (new, [int(v) for v in out[2:8]])
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle
