@@ -767,8 +767,7 @@ def main():
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(system, vel, args.cpu_steps)
-        print(json.dumps(out), flush=True)   # (flushed before the chains are torn down at the end of main(): a fault there must not take the line with it)
-        _stage("line printed")
+        print(json.dumps(out), flush=True)   # (flushed before the chains are torn down at the end of main(): a fault there must not take the line with it; nothing is written after it, on either stream)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

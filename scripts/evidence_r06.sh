@@ -10,7 +10,7 @@
 #   step         bare stepping of 1024 chains + its kernel table                                              -> step.txt, kernel_stats_step_R1024.csv
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/ev_r06; mkdir -p $out
-run() { name=$1; shift; timeout 1500 python3 bench.py "$@" > $out/$name.log 2>&1; tail -1 $out/$name.log > $out/$name.json; python3 - <<PY
+run() { name=$1; shift; timeout 1500 python3 bench.py "$@" > $out/$name.log 2>&1; grep '^{' $out/$name.log | tail -1 > $out/$name.json; python3 - <<PY
 import json
 try:
     d = json.loads(open("$out/$name.json").read())
