@@ -158,7 +158,7 @@ __device__ __forceinline__ void solve_small(int n, const double M[3][3], const d
 }
 
 // RATTLE: (v_i - v_j).r_ij = 0 is linear in the multipliers -> one small solve (same algebra as the oracle)
-__device__ __forceinline__ void rattle(Cluster& C, double tol, const IntArgs& A) {
+__device__ __forceinline__ void rattle_u(Cluster& C, double tol, const IntArgs& A) {
     if (C.nc == 0) return;
     const ClSel S = cl_select(C);
     double r[3][3], dv[3][3], M[3][3], b[3], mu[3];
@@ -176,7 +176,7 @@ __device__ __forceinline__ void rattle(Cluster& C, double tol, const IntArgs& A)
 
 // SHAKE: Newton on the multipliers, directions from the reference geometry xr; converged to
 // |r^2 - d^2| <= 2 tol d^2 plus one polishing iteration (same sequence as the oracle)
-__device__ __forceinline__ bool shake(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
+__device__ __forceinline__ bool shake_u(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
     if (C.nc == 0) return true;
     const ClSel S = cl_select(C);
     double r[3][3];
@@ -206,6 +206,109 @@ __device__ __forceinline__ bool shake(Cluster& C, const double xr[4][3], double 
     }
     return it < 50;
 }
+
+// ---- the two-table form (compile-time index tables per kind of cluster): what every kernel but the fused steady-state step kernels runs --
+// a wave that holds one kind of cluster (the lone chain's layout, the MD leg, the general interpreter) pays no selects; a wave with both
+// kinds runs the two instantiations one after the other.  Same algebra as rattle_u / shake_u above.
+template <int TYPE> struct ClTab {
+    static __device__ constexpr int ci(int c) { return TYPE == 1 ? 0 : (c == 2 ? 1 : 0); }
+    static __device__ constexpr int cj(int c) { return TYPE == 1 ? c + 1 : (c == 0 ? 1 : 2); }
+    // s(c2, a): +1 if a is the first atom of constraint c2, -1 if the second
+    static __device__ constexpr int s(int c2, int a) { return (a == ci(c2)) - (a == cj(c2)); }
+};
+
+// RATTLE: (v_i - v_j).r_ij = 0 is linear in the multipliers -> one small solve (same algebra as the oracle)
+template <int TYPE> __device__ __forceinline__ void rattle_t(Cluster& C, const IntArgs& A) {
+    using T = ClTab<TYPE>;
+    double r[3][3], M[3][3], b[3], mu[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double rv = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            r[c][k] = 0.0;
+            if (c < C.nc) {
+                r[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k];
+                rv += (C.v[T::ci(c)][k] - C.v[T::cj(c)][k]) * r[c][k];
+            }
+        }
+        b[c] = -rv;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int c2 = 0; c2 < 3; c2++) {
+            const double coef = C.w[T::ci(c)] * T::s(c2, T::ci(c)) - C.w[T::cj(c)] * T::s(c2, T::cj(c));
+            M[c][c2] = (r[c][0] * r[c2][0] + r[c][1] * r[c2][1] + r[c][2] * r[c2][2]) * coef;
+        }
+    solve_small(C.nc, M, b, mu);
+#pragma unroll
+    for (int c = 0; c < 3; c++) if (c < C.nc) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { C.v[T::ci(c)][k] += mu[c] * r[c][k] * C.w[T::ci(c)]; C.v[T::cj(c)][k] -= mu[c] * r[c][k] * C.w[T::cj(c)]; }
+    }
+}
+
+__device__ __forceinline__ void rattle(Cluster& C, double tol, const IntArgs& A) {
+    if (C.nc == 0) return;
+    if (C.type == 1) rattle_t<1>(C, A); else rattle_t<2>(C, A);
+}
+
+// SHAKE: Newton on the multipliers, directions from the reference geometry xr; converged to
+// |r^2 - d^2| <= 2 tol d^2 plus one polishing iteration (same sequence as the oracle)
+template <int TYPE> __device__ __forceinline__ bool shake_t(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
+    using T = ClTab<TYPE>;
+    double r[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            r[c][k] = 0.0;
+            if (c < C.nc) { r[c][k] = xr[T::ci(c)][k] - xr[T::cj(c)][k]; }
+        }
+    int it;
+    for (it = 0; it < 50; it++) {
+        double D[3][3], g[3], J[3][3], dl[3];
+        bool conv = true, tight = true;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            g[c] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) D[c][k] = 0.0;
+            if (c < C.nc) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { D[c][k] = C.x[T::ci(c)][k] - C.x[T::cj(c)][k]; }
+                g[c] = -(D[c][0] * D[c][0] + D[c][1] * D[c][1] + D[c][2] * D[c][2] - C.d2[c]);
+                if (fabs(g[c]) > 2.0 * tol * C.d2[c]) conv = false;
+                if (fabs(g[c]) > 1e-13 * C.d2[c]) tight = false;
+            }
+        }
+        if (tight) break;
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int c2 = 0; c2 < 3; c2++) {
+                const double coef = C.w[T::ci(c)] * T::s(c2, T::ci(c)) - C.w[T::cj(c)] * T::s(c2, T::cj(c));
+                J[c][c2] = 2.0 * (D[c][0] * r[c2][0] + D[c][1] * r[c2][1] + D[c][2] * r[c2][2]) * coef;
+            }
+        solve_small(C.nc, J, g, dl);
+#pragma unroll
+        for (int c = 0; c < 3; c++) if (c < C.nc) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { C.x[T::ci(c)][k] += dl[c] * r[c][k] * C.w[T::ci(c)]; C.x[T::cj(c)][k] -= dl[c] * r[c][k] * C.w[T::cj(c)]; }
+        }
+        if (conv) break;
+    }
+    return it < 50;
+}
+
+__device__ __forceinline__ bool shake(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) {
+    if (C.nc == 0) return true;
+    return C.type == 1 ? shake_t<1>(C, xr, tol, A) : shake_t<2>(C, xr, tol, A);
+}
+// U: the one-path form (the fused steady-state step kernels: a batch's packed layout mixes the kinds in one wave)
+template <bool U> __device__ __forceinline__ void rattle_sel(Cluster& C, double tol, const IntArgs& A) { if constexpr (U) rattle_u(C, tol, A); else rattle(C, tol, A); }
+template <bool U> __device__ __forceinline__ bool shake_sel(Cluster& C, const double xr[4][3], double tol, const IntArgs& A) { if constexpr (U) return shake_u(C, xr, tol, A); else return shake(C, xr, tol, A); }
 
 __device__ __forceinline__ void load_force(const IntArgs& A, const Cluster& C, int slot, double F[4][3]) {
 #pragma unroll
@@ -953,7 +1056,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
         for (int a = 0; a < 4; a++)
 #pragma unroll
             for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * FA[a][k] * C.w[a];
-        rattle(C, A.tol, A);
+        rattle_sel<FUSED>(C, A.tol, A);
     }
     STEP_STAMP(3);
     if (blockIdx.x == 0 && tid == 0) {
@@ -990,7 +1093,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
         for (int a = 0; a < 4; a++)
 #pragma unroll
             for (int k = 0; k < 3; k++) C.v[a][k] += A.hV * FB[a][k] * C.w[a];
-        rattle(C, A.tol, A);
+        rattle_sel<FUSED>(C, A.tol, A);
         STEP_STAMP(5);
         for (int half = 0; half < 2; half++) {
             // R
@@ -999,10 +1102,10 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
             for (int a = 0; a < 4; a++)
 #pragma unroll
                 for (int k = 0; k < 3; k++) { xr[a][k] = C.x[a][k]; if (a < C.na) C.x[a][k] += A.hR * C.v[a][k]; x1[a][k] = C.x[a][k]; }
-            ok &= shake(C, xr, A.tol, A);
+            ok &= shake_sel<FUSED>(C, xr, A.tol, A);
 #pragma unroll
             for (int a = 0; a < 4; a++) if (a < C.na) for (int k = 0; k < 3; k++) C.v[a][k] += (C.x[a][k] - x1[a][k]) * A.inv_hR;
-            rattle(C, A.tol, A);
+            rattle_sel<FUSED>(C, A.tol, A);
             STEP_STAMP(6 + 2 * half);
             if (half == 0) {
                 // O
@@ -1022,7 +1125,7 @@ __device__ __forceinline__ void step_default_body(IntArgs& A) {
 #pragma unroll
                     for (int k = 0; k < 3; k++) C.v[a][k] = A.aO * C.v[a][k] + A.bO * s * g[k];
                 }
-                rattle(C, A.tol, A);
+                rattle_sel<FUSED>(C, A.tol, A);
                 STEP_STAMP(7);
             }
         }
