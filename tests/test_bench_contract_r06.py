@@ -41,6 +41,18 @@ def test_five_consecutive_default_lines_have_no_slow_iteration():
         assert "lambda <=" in d["data_note"]              # decorrelated at lambda ~ 0, not through a quarter of a switch
         assert d["value"] == pytest.approx(2048 * 20 * 1000 * 0.004e-3 / (d["ms_per_step"] * 20e-3 / 86400.0), rel=1e-6)
         values.append(d["value"])
+    # (what the end of the round added to the line: host readiness -- VERDICT r05 item 7 --, the members out of step, the guard zones)
+    for k in range(1, 6):
+        d = _load("bench_default_run%d.json" % k)
+        e = d["engine"]
+        assert e["setup_seconds"] <= 3.2 and d["memory"]["host_peak_rss_gib"] <= 4.0, (k, e["setup_seconds"], d["memory"])
+        assert d["memory"]["device_buffer_guards"]["marked"] == 0 and d["memory"]["device_buffer_guards"]["blocks"] > 200000
+        assert e["fallback_steps_per_switch"] == 0.0                       # a member out of step never sent its batch through per-member launches
+        for ev in e["layout_events_by_batch"]:
+            for it, what in ev.items():
+                assert what["replans"] == 0 and set(what) >= {"poll_resorts", "straggled", "rejoined", "straggle_seconds", "partial_steps"}, (k, it, what)
+        assert e["partial_steps"] == sum(w["partial_steps"] for ev in e["layout_events_by_batch"] for w in ev.values())
+        assert d["single_replica"]["value"] >= 6800.0                     # configs[1] to the letter: not slower than round 5's 6,935-6,959 by more than box noise
     assert min(values) >= 455000.0                         # the bar of VERDICT r05 ...
     assert min(values) >= 540000.0                         # ... and the bar of its item 2 (what the round's kernels deliver: 551-553 k)
     assert max(values) <= 1.04 * min(values)               # box to box
