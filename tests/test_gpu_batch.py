@@ -1232,6 +1232,49 @@ def test_a_member_that_outgrows_the_shape_steps_on_its_own(Engine, tune):
         g.close()
 
 
+def test_a_member_without_a_layout_does_not_cost_the_batched_energies(Engine, tune):
+    """The head of a BLUES iteration restores every chain's State and asks for the energies of all of them (blues_batch_prefetch_energies).
+    A member whose State arrives far from where its tiles were last laid out -- it was re-sorted in a spread arrangement during the
+    previous switch -- has no layout at that point (resolve_xfer drops it), and the prefetch used to give up: every member then
+    evaluated on demand, 1024 lone energy evaluations in an iteration that named no layout event.  It is laid out at the head of the
+    prefetch now (counted in `relayouts`) and the OTHER members' energies come from the batched launches (none of them launches an
+    evaluation of its own)."""
+    from blues_amd.engine import NativeBatch
+    s, v = systems.s23k(mobile_atoms=275, frozen=True)
+    R, n = 6, 10
+    tune(assume_batch=64)
+    engs = []
+    for r in range(R):
+        g = Engine(s, _integ(100, seed=300 + r).to_data(precision=0, replica=r)); g.set_velocities(v * (1.0 + 0.02 * r)); engs.append(g)
+    B = NativeBatch(engs)
+    B.step(n)
+    snaps = B.snapshot_all()                                         # the States the next iteration starts from (compact arrangement)
+    engs[2].set_positions(_swap_waters_outward(s, engs[2].get_positions(), n_pairs=1, distance=1.3))
+    B.step(n)                                                        # member 2 is laid out again for the spread arrangement (or leaves the batch's layout)
+    B.reset_all()
+    B.restore_all(snaps)                                             # ... and gets its compact State back: far from that layout
+    c0, own0 = B.counters(), [g.stats()["own_energy_evaluations"] for g in engs]
+    B.prefetch_energies(potential=True, kinetic=False)
+    e_batched = [g.potential_energy() for g in engs]
+    c1, own1 = B.counters(), [g.stats()["own_energy_evaluations"] for g in engs]
+    assert c1["relayouts"] >= c0["relayouts"] + 1 or c1["rejoined"] > c0["rejoined"] or c1["stragglers"] > 0, (c0, c1)
+    others = [r for r in range(R) if r != 2]
+    assert [own1[r] for r in others] == [own0[r] for r in others], (own0, own1)     # served from the batched launches: nobody else evaluated alone
+    ref = []
+    for r, g in enumerate(engs):                                    # the same numbers from lone evaluations of the same states
+        lone = Engine(s, _integ(100, seed=300 + r).to_data(precision=0, replica=r))
+        lone.set_positions(g.get_positions())
+        for name in ("lambda_sterics", "lambda_electrostatics"):     # (reset() leaves the context parameters where the last switch put them, as OpenMM does)
+            lone.set_global(name, g.get_global(name))
+        ref.append(lone.potential_energy())
+        lone.close()
+    B.close()
+    for r in range(R):
+        assert e_batched[r] == pytest.approx(ref[r], rel=2e-7, abs=1e-3), r          # (mixed precision: fp32 pair sums in another layout)
+    for g in engs:
+        g.close()
+
+
 def test_a_batch_whose_shape_is_outgrown_by_many_moves_on_in_one_sweep(Engine, tune):
     """More members outgrow the shape than may straggle (one in 32; here: the second of six): the batch re-plans for everybody -- in
     the benchmark geometry that means fragment lists -- in ONE sweep over the members on the host's cores (round 5: up to three),
